@@ -1,0 +1,126 @@
+"""ctypes mirror of include/hunter_hip.h (hb_model / hb_config / hb_stats) and builders from flattened params."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+NX, NU, NV, NJ, NC, NBODY, NWBC, NRBD, SWING_REF = 22, 22, 16, 10, 4, 11, 38, 32, 6
+FLY, MODE_R, MODE_L, STANCE = 0, 1, 2, 3
+
+
+class HbModel(C.Structure):
+    _fields_ = [
+        ("parent", C.c_int32 * NJ),
+        ("joint_origin", (C.c_double * 3) * NJ),
+        ("joint_axis", (C.c_double * 3) * NJ),
+        ("q_lower", C.c_double * NJ), ("q_upper", C.c_double * NJ),
+        ("qd_limit", C.c_double * NJ), ("effort", C.c_double * NJ),
+        ("mass", C.c_double * NBODY),
+        ("com", (C.c_double * 3) * NBODY),
+        ("inertia", (C.c_double * 6) * NBODY),
+        ("contact_body", C.c_int32 * NC),
+        ("contact_offset", (C.c_double * 3) * NC),
+        ("gravity", C.c_double),
+    ]
+
+
+class HbConfig(C.Structure):
+    _fields_ = [
+        ("dt", C.c_double),
+        ("sqp_iterations", C.c_int32), ("wbc_type", C.c_int32),
+        ("g_max", C.c_double), ("g_min", C.c_double),
+        ("alpha_decay", C.c_double), ("alpha_min", C.c_double), ("gamma_c", C.c_double), ("armijo_factor", C.c_double),
+        ("Q_diag", C.c_double * NX),
+        ("R_task_diag", C.c_double * 24),
+        ("initial_state", C.c_double * NX),
+        ("friction_mu", C.c_double), ("friction_reg", C.c_double), ("friction_gripper", C.c_double),
+        ("friction_hess_shift", C.c_double),
+        ("friction_barrier_mu", C.c_double), ("friction_barrier_delta", C.c_double),
+        ("soft_swing_weight", C.c_double),
+        ("pos_limit_barrier", C.c_double * 2), ("vel_limit_barrier", C.c_double * 2),
+        ("force_limit_barrier", C.c_double * 2), ("force_limit", C.c_double * 2),
+        ("position_error_gain", C.c_double),
+        ("zero_vel_z_gain", C.c_double), ("zero_vel_z_offset", C.c_double),
+        ("xy_ref_gain", C.c_double),
+        ("torque_limits", C.c_double * 5),
+        ("wbc_friction_mu", C.c_double),
+        ("swing_kp", C.c_double), ("swing_kd", C.c_double),
+        ("base_height_kp", C.c_double), ("base_height_kd", C.c_double),
+        ("base_angular_kp", C.c_double), ("base_angular_kd", C.c_double),
+        ("weight_swing_leg", C.c_double), ("weight_base_accel", C.c_double), ("weight_contact_force", C.c_double),
+        ("wbc_eps_reg", C.c_double),
+        ("wbc_max_iter", C.c_int32), ("reserved", C.c_int32),
+        ("default_joint_state", C.c_double * NJ),
+    ]
+
+
+class HbStats(C.Structure):
+    _fields_ = [
+        ("ms_lq", C.c_double), ("ms_riccati_bwd", C.c_double), ("ms_riccati_fwd", C.c_double),
+        ("ms_linesearch", C.c_double), ("ms_mpc_total", C.c_double), ("ms_wbc", C.c_double),
+        ("n_mpc_solves", C.c_int64), ("n_wbc_solves", C.c_int64),
+        ("n_status", C.c_int32 * 4),
+    ]
+
+
+def _fill(arr, values):
+    a = np.asarray(values)
+    if a.ndim == 1:
+        for i, v in enumerate(a):
+            arr[i] = v.item()
+    else:
+        for i in range(a.shape[0]):
+            for j in range(a.shape[1]):
+                arr[i][j] = a[i, j].item()
+
+
+def make_model(params: dict) -> HbModel:
+    m = params["model"]
+    out = HbModel()
+    for name in ("parent", "joint_origin", "joint_axis", "q_lower", "q_upper", "qd_limit", "effort", "mass", "com",
+                 "inertia", "contact_body", "contact_offset"):
+        _fill(getattr(out, name), m[name])
+    out.gravity = m["gravity"]
+    return out
+
+
+def make_config(params: dict, **overrides) -> HbConfig:
+    c = params["config"]
+    out = HbConfig()
+    out.dt = c["dt"]
+    out.sqp_iterations = c["sqp_iterations"]
+    out.wbc_type = 0
+    out.g_max, out.g_min = c["g_max"], c["g_min"]
+    # OCS2 FilterLinesearch defaults
+    out.alpha_decay, out.alpha_min, out.gamma_c, out.armijo_factor = 0.5, 1e-4, 1e-6, 1e-4
+    _fill(out.Q_diag, c["Q_diag"])
+    _fill(out.R_task_diag, c["R_task_diag"])
+    _fill(out.initial_state, c["initial_state"])
+    out.friction_mu = c["friction_mu"]
+    # FrictionConeConstraint::Config defaults (FrictionConeConstraint.h:77-83)
+    out.friction_reg, out.friction_gripper, out.friction_hess_shift = 25.0, 0.0, 1e-6
+    out.friction_barrier_mu, out.friction_barrier_delta = c["friction_barrier_mu"], c["friction_barrier_delta"]
+    out.soft_swing_weight = c["soft_swing_weight"]
+    # LeggedInterface.cpp:337-339,352
+    _fill(out.pos_limit_barrier, [1.0, 0.1])
+    _fill(out.vel_limit_barrier, [1.0, 0.1])
+    _fill(out.force_limit_barrier, [0.1, 1.0])
+    _fill(out.force_limit, [0.0, 350.0])
+    out.position_error_gain = c["position_error_gain"]
+    # LeggedInterface.cpp:436-444: Ax(2,2) = 3, b(2) = -3*0.02
+    out.zero_vel_z_gain, out.zero_vel_z_offset = 3.0, -0.06
+    out.xy_ref_gain = 3.0  # LeggedRobotPreComputation.cpp:113-116
+    _fill(out.torque_limits, c["torque_limits"])
+    out.wbc_friction_mu = c["wbc_friction_mu"]
+    out.swing_kp, out.swing_kd = c["swing_kp"], c["swing_kd"]
+    out.base_height_kp, out.base_height_kd = c["base_height_kp"], c["base_height_kd"]
+    out.base_angular_kp, out.base_angular_kd = c["base_angular_kp"], c["base_angular_kd"]
+    out.weight_swing_leg, out.weight_base_accel = c["weight_swing_leg"], c["weight_base_accel"]
+    out.weight_contact_force = c["weight_contact_force"]
+    out.wbc_eps_reg = 1e-8
+    out.wbc_max_iter = 120
+    _fill(out.default_joint_state, c["default_joint_state"])
+    for k, v in overrides.items():
+        setattr(out, k, v)
+    return out

@@ -1,0 +1,210 @@
+/*
+ * hunter_hip.h — C ABI of the MI355X-native batched NMPC + WBC solver for the EC-hunter80 biped.
+ *
+ * This is the drop-in boundary for the hot path of bridgedp/hunter_bipedal_control.
+ * Every entry point names the reference interface it replaces (paths relative to the reference root).
+ * Plain pointers and sizes only; no C++/torch types.  All functions return 0 on success and a
+ * negative hb_status on failure (never throw); hb_last_error() gives the message.
+ *
+ * Conventions
+ *   MPC state  x[22] = [h_lin/m (3), h_ang/m (3), base pos (3), base ZYX euler (3), joints l1..l5 r1..r5 (10)]
+ *   MPC input  u[22] = [F(L_f1) F(R_f1) F(L_f2) F(R_f2) (world frame, 12), joint velocities (10)]
+ *   rbd state  [32]  = [zyx(3), pos(3), q_j(10), omega_world(3), v_lin(3), qd_j(10)]
+ *                      (legged_estimation/src/StateEstimateBase.cpp:73-106)
+ *   WBC output [38]  = [qdd(16) | F(12) | tau(10)]            (legged_wbc/src/WbcBase.cpp:40)
+ *   modes: 0 FLY, 1 R (feet 1,3 closed), 2 L (feet 0,2 closed), 3 STANCE
+ *                      (legged_interface/include/legged_interface/gait/MotionPhaseDefinition.h:55-95)
+ *   All matrices passed through this ABI are row-major doubles.
+ *
+ * Batch layout: instance-major.  Host buffers are caller-owned; device buffers are library-owned.
+ * One hb_ctx drives one GPU (one process per GPU; ranks shard the batch).
+ */
+#ifndef HUNTER_HIP_H
+#define HUNTER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HB_NX 22
+#define HB_NU 22
+#define HB_NV 16   /* generalized coordinates: base pos(3) + zyx(3) + joints(10) */
+#define HB_NJ 10
+#define HB_NC 4    /* 3-DoF point contacts */
+#define HB_NBODY 11 /* base + 10 links (fixed URDF children merged into their parent) */
+#define HB_NWBC 38
+#define HB_NRBD 32
+#define HB_SWING_REF 6 /* per foot and node: pos xyz, vel xyz of the swing reference */
+
+typedef enum hb_status {
+  HB_OK = 0,
+  HB_ERR_ARG = -1,       /* bad argument (null pointer, range) */
+  HB_ERR_DEVICE = -2,    /* HIP runtime error */
+  HB_ERR_STATE = -3,     /* call order (e.g. solve before references were set) */
+  HB_ERR_NO_GPU = -4     /* no gfx950 device visible: the product path never falls back to a CPU */
+} hb_status;
+
+/* Per-instance solver status words written by the device (SURVEY.md §5 "failure detection"). */
+#define HB_INST_OK 0
+#define HB_INST_MAXITER 1   /* WBC QP hit its working-set-change limit: previous solution reused
+                               (legged_wbc/src/WeightedWbc.cpp:57-65) */
+#define HB_INST_INFEASIBLE 2
+#define HB_INST_NAN 3       /* non-finite value / non-positive Riccati pivot */
+
+/* Rigid-body model, replaces PinocchioInterface built from the URDF
+ * (legged_interface/src/LeggedInterface.cpp:188-200).  Body 0 is base_link, bodies 1..5 the left leg
+ * links, 6..10 the right leg links; joint j connects body parent[j] to body j+1. */
+typedef struct hb_model {
+  int32_t parent[HB_NJ];
+  double joint_origin[HB_NJ][3];   /* joint frame origin in the parent body frame (all URDF rpy are 0) */
+  double joint_axis[HB_NJ][3];
+  double q_lower[HB_NJ], q_upper[HB_NJ], qd_limit[HB_NJ], effort[HB_NJ];
+  double mass[HB_NBODY];
+  double com[HB_NBODY][3];         /* body frame */
+  double inertia[HB_NBODY][6];     /* about the body COM, body axes: xx xy xz yy yz zz */
+  int32_t contact_body[HB_NC];     /* order L_f1, R_f1, L_f2, R_f2 (ModelSettings.h:62) */
+  double contact_offset[HB_NC][3];
+  double gravity;                  /* 9.81 (legged_interface/include/legged_interface/common/utils.h:82) */
+} hb_model;
+
+/* Flattened task.info / reference.info (legged_controllers/config/hunter). */
+typedef struct hb_config {
+  /* sqp block, task.info:79-96 */
+  double dt;
+  int32_t sqp_iterations;
+  int32_t wbc_type;                /* 0 WeightedWbc (LeggedController.cpp:85), 1 HierarchicalWbc */
+  double g_max, g_min;             /* filter line search thresholds */
+  double alpha_decay, alpha_min, gamma_c, armijo_factor; /* OCS2 FilterLinesearch defaults 0.5 1e-4 1e-6 1e-4 */
+  /* cost, task.info:186-253 + LeggedInterface.cpp:263-312 */
+  double Q_diag[HB_NX];
+  double R_task_diag[24];          /* 12 contact-force weights, 12 foot-velocity (task space) weights */
+  double initial_state[HB_NX];     /* configuration at which the task-space R is pulled back to joint space */
+  /* soft constraints */
+  double friction_mu, friction_reg, friction_gripper, friction_hess_shift; /* FrictionConeConstraint.h:77-83 */
+  double friction_barrier_mu, friction_barrier_delta;                      /* task.info:255-262 */
+  double soft_swing_weight;        /* task.info:265-268 */
+  double pos_limit_barrier[2], vel_limit_barrier[2], force_limit_barrier[2]; /* (mu,delta) LeggedInterface.cpp:337-339 */
+  double force_limit[2];           /* [0,350] LeggedInterface.cpp:352 */
+  /* equality constraints */
+  double position_error_gain;      /* swing normal-velocity constraint, task.info:10 */
+  double zero_vel_z_gain, zero_vel_z_offset; /* Ax(2,2)=3, b(2)=-0.06, LeggedInterface.cpp:436-444 */
+  double xy_ref_gain;              /* 3, LeggedRobotPreComputation.cpp:113-116 */
+  /* WBC, task.info:289-333 */
+  double torque_limits[5];
+  double wbc_friction_mu;
+  double swing_kp, swing_kd, base_height_kp, base_height_kd, base_angular_kp, base_angular_kd;
+  double weight_swing_leg, weight_base_accel, weight_contact_force;
+  double wbc_eps_reg;              /* Tikhonov term of the regularised-minimiser rule */
+  int32_t wbc_max_iter;            /* working-set-change limit; reference nWSR = 20 (WeightedWbc.cpp:50) */
+  int32_t reserved;
+  double default_joint_state[HB_NJ]; /* reference.info:7-19 */
+} hb_config;
+
+typedef struct hb_ctx hb_ctx;
+
+/* Aggregate per-phase device time of the last hb_mpc_solve / hb_wbc_update (HIP events on the
+ * library's own streams), replacing the reference's mpcTimer_/wbcTimer_ (LeggedController.cpp:359-366). */
+typedef struct hb_stats {
+  double ms_lq, ms_riccati_bwd, ms_riccati_fwd, ms_linesearch, ms_mpc_total;
+  double ms_wbc;
+  int64_t n_mpc_solves, n_wbc_solves;
+  int32_t n_status[4];             /* histogram of the last WBC status words */
+} hb_stats;
+
+/* ---- lifetime -------------------------------------------------------------------------------
+ * Replaces LeggedController::init -> setupLeggedInterface/setupMpc/setupMrt + WeightedWbc ctor +
+ * loadTasksSetting (LeggedController.cpp:41-88,376-431).  `batch` robot instances live on HIP
+ * device `device`; every instance has at most `max_nodes` shooting intervals. */
+int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch, int32_t max_nodes,
+                  int32_t device, hb_ctx** out);
+void hb_destroy(hb_ctx* ctx);
+const char* hb_last_error(const hb_ctx* ctx); /* ctx may be NULL: message of the failed hb_create */
+
+/* ---- references ------------------------------------------------------------------------------
+ * Node tables produced by the reference manager before each solve, replacing what
+ * SwitchedModelReferenceManager::modifyReferences (SwitchedModelReferenceManager.cpp:136-171) and the
+ * OCS2 time discretisation hand to the SQP solver:
+ *   n_nodes[i]            number of shooting intervals N_i <= max_nodes
+ *   t[i][k], k<=N_i       node times (event times are grid nodes; interval k uses mode[i][k])
+ *   mode[i][k], k<N_i     contact mode of interval k (ModeSchedule::modeAtTime just after t_k)
+ *   x_ref[i][k][22]       TargetTrajectories::getDesiredState(t_k)
+ *   swing_ref[i][k][4][6] SwingTrajectoryPlanner::get{X,Y,Z}{position,velocity}Constraint(foot, t_k)
+ * Host arrays are strided by max_nodes(+1) as declared in hb_create. */
+int32_t hb_mpc_set_references(hb_ctx* ctx, int32_t inst_begin, int32_t inst_count, const int32_t* n_nodes,
+                              const double* t, const int32_t* mode, const double* x_ref,
+                              const double* swing_ref);
+
+/* Cold start: x_k = x0, u_k = weight compensation of mode_k (LeggedRobotInitializer.cpp:67-77). */
+int32_t hb_mpc_reset(hb_ctx* ctx, const double* x0 /*[batch][22]*/);
+/* Warm start from caller-provided trajectories (x [batch][max_nodes+1][22], u [batch][max_nodes][22]). */
+int32_t hb_mpc_set_trajectory(hb_ctx* ctx, const double* x, const double* u);
+
+/* ---- MPC -------------------------------------------------------------------------------------
+ * One MPC call = config.sqp_iterations SQP iterations (LQ approximation, constraint projection,
+ * backward/forward Riccati, filter line search) for every instance, from measured state x0.
+ * Replaces MPC_MRT_Interface::advanceMpc -> SqpSolver::runImpl (LeggedController.cpp:406).
+ * Asynchronous on the library's MPC stream. x0 is a host pointer [batch][22] or NULL to keep the
+ * device-resident x0 (previous call). */
+int32_t hb_mpc_solve(hb_ctx* ctx, const double* x0);
+/* Make the last solution the active policy (MPC_MRT_Interface::updatePolicy, LeggedController.cpp:154). */
+int32_t hb_mpc_publish(hb_ctx* ctx);
+/* Copy trajectories to the host (PrimalSolution, LeggedController.cpp:269); any pointer may be NULL.
+ * x [count][max_nodes+1][22], u [count][max_nodes][22]. Synchronises the MPC stream. */
+int32_t hb_mpc_get_solution(hb_ctx* ctx, int32_t inst_begin, int32_t inst_count, double* x, double* u);
+/* Per-instance performance index of the accepted step: [merit, dynamics SSE, equality SSE, step size]. */
+int32_t hb_mpc_get_performance(hb_ctx* ctx, double* perf /*[batch][4]*/);
+
+/* ---- WBC -------------------------------------------------------------------------------------
+ * Evaluates the published policy at t_now (MPC_MRT_Interface::evaluatePolicy, LeggedController.cpp:155)
+ * unless walk_flag[i]==0, in which case the stand-still target of LeggedController.cpp:161-173 is used;
+ * then runs WbcBase::update + WeightedWbc::update (legged_wbc/src/WeightedWbc.cpp:18-66) or
+ * HierarchicalWbc::update (legged_wbc/src/HierarchicalWbc.cpp:18-30) for every instance.
+ * Host in: t_now[batch], rbd[batch][32], walk_flag[batch] (NULL = all walking).
+ * Host out (any may be NULL): sol[batch][38], x_des[batch][22], u_des[batch][22], planned_mode[batch],
+ * status[batch].  Synchronous with respect to the WBC stream when an output pointer is given. */
+int32_t hb_wbc_update(hb_ctx* ctx, const double* t_now, const double* rbd, const int32_t* walk_flag,
+                      double dt, double* sol, double* x_des, double* u_des, int32_t* planned_mode,
+                      int32_t* status);
+/* Direct form of WbcBase::update(stateDesired, inputDesired, rbdStateMeasured, mode, period)
+ * (legged_wbc/include/legged_wbc/WbcBase.h:43-44), batched; host pointers. */
+int32_t hb_wbc_update_direct(hb_ctx* ctx, const double* x_des, const double* u_des, const double* rbd,
+                             const int32_t* mode, const int32_t* stance_flag, double dt, double* sol,
+                             int32_t* status);
+
+/* ---- device-resident stepping (bench / rollouts; inputs already in HBM) ------------------------
+ * hb_step_resident runs hb_mpc_solve(NULL) + hb_mpc_publish + WBC on device-resident t_now/rbd that
+ * were uploaded once with hb_set_resident_inputs; nothing crosses PCIe. */
+int32_t hb_set_resident_inputs(hb_ctx* ctx, const double* x0, const double* t_now, const double* rbd,
+                               const int32_t* walk_flag);
+int32_t hb_step_resident(hb_ctx* ctx, double dt);
+int32_t hb_get_wbc_solution(hb_ctx* ctx, double* sol /*[batch][38]*/, int32_t* status /*[batch]*/);
+
+/* ---- misc ------------------------------------------------------------------------------------ */
+int32_t hb_sync(hb_ctx* ctx);
+int32_t hb_get_stats(hb_ctx* ctx, hb_stats* out);
+/* Joint-space input cost R (22x22) built at init from R_task_diag (LeggedInterface.cpp:263-290). */
+int32_t hb_get_input_cost(const hb_ctx* ctx, double* R /*[22][22]*/);
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+int32_t hb_version(void);
+
+/* ---- unit-level entry points used by the parity tests (each is one HIP kernel launch) ----------- */
+/* Centroidal flow map and its Jacobians (PinocchioCentroidalDynamicsAD, LeggedRobotDynamicsAD.cpp:57-70). */
+int32_t hb_eval_flow_map(hb_ctx* ctx, int32_t n, const double* x, const double* u, double* f /*[n][22]*/,
+                         double* dfdx /*[n][22][22] or NULL*/, double* dfdu /*[n][22][22] or NULL*/);
+/* Foot positions / velocities (PinocchioEndEffectorKinematicsCppAd, EndEffectorLinearConstraint.cpp:105-128). */
+int32_t hb_eval_foot_kinematics(hb_ctx* ctx, int32_t n, const double* x, const double* u,
+                                double* pos /*[n][4][3]*/, double* vel /*[n][4][3]*/);
+/* Rigid-body quantities of WbcBase::updateMeasured (WbcBase.cpp:70-120): M[16][16], nle[16], J[12][16], dJv[12]. */
+int32_t hb_eval_rbd(hb_ctx* ctx, int32_t n, const double* rbd, double* M, double* nle, double* J, double* dJv);
+/* Solve a batch of equality-free LQ problems with the Riccati kernels (HPIPM's role):
+ * stage data row-major, nu_k <= 22 inputs per stage given in nu[n][N]. */
+int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, const double* A, const double* B, const double* b,
+                         const double* Q, const double* R, const double* P, const double* q, const double* r,
+                         const double* dx0, double* dx /*[n][N+1][22]*/, double* du /*[n][N][22]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HUNTER_HIP_H */

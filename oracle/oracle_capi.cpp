@@ -1,0 +1,285 @@
+// TEST INFRASTRUCTURE — CPU oracle of the hunter NMPC + WBC hot path (C ABI for ctypes).
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+//
+// PARITY UNPINNED: the reference ships no golden vectors for this path (only the property test
+// legged_wbc/test/HoQp_test.cpp), and OCS2 / HPIPM / pinocchio / qpOASES cannot be built here, so this is a
+// from-scratch restatement pinned by invariants (tests/test_oracle_*.py) and by the few known answers the
+// reference does hold (total mass, FK of the default stance, relaxed-barrier formula).
+#include <atomic>
+#include <cstdio>
+#include <thread>
+
+#include "sqp.hpp"
+#include "wbc.hpp"
+
+using namespace orc;
+
+namespace {
+template <class F>
+void parallel_for(int n, int threads, F&& fn) {
+  if (threads <= 1 || n <= 1) {
+    for (int i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::atomic<int> next{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t)
+    pool.emplace_back([&] {
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= n) return;
+        fn(i);
+      }
+    });
+  for (auto& th : pool) th.join();
+}
+void copy_mat(const Mat& m, double* out) {
+  if (out) std::memcpy(out, m.a.data(), sizeof(double) * m.a.size());
+}
+}  // namespace
+
+extern "C" {
+
+void* orc_create(const hb_model* mdl, const hb_config* cfg) {
+  auto* p = new Problem();
+  p->init(*mdl, *cfg);
+  return p;
+}
+void orc_destroy(void* h) { delete static_cast<Problem*>(h); }
+
+void orc_input_cost(void* h, double* R) { copy_mat(static_cast<Problem*>(h)->R, R); }
+
+double orc_relaxed_barrier(double mu, double delta, double hval, int order) {
+  const RelaxedBarrier b{mu, delta};
+  return order == 0 ? b.value(hval) : (order == 1 ? b.d1(hval) : b.d2(hval));
+}
+
+void orc_flow_map(void* h, int n, const double* x, const double* u, double* f, double* dfdx, double* dfdu) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  for (int i = 0; i < n; ++i) {
+    if (dfdx || dfdu) {
+      Mat A, B;
+      flow_jacobian(pb, x + i * HB_NX, u + i * HB_NU, f + i * HB_NX, A, B);
+      if (dfdx) copy_mat(A, dfdx + size_t(i) * HB_NX * HB_NX);
+      if (dfdu) copy_mat(B, dfdu + size_t(i) * HB_NX * HB_NU);
+    } else {
+      flow_map<double>(pb.mdl, x + i * HB_NX, u + i * HB_NU, f + i * HB_NX);
+    }
+  }
+}
+
+void orc_foot_kinematics(void* h, int n, const double* x, const double* u, double* pos, double* vel) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  for (int i = 0; i < n; ++i) {
+    V3<double> p[HB_NC], v[HB_NC];
+    foot_kinematics<double>(pb.mdl, x + i * HB_NX, u + i * HB_NU, p, v);
+    for (int c = 0; c < HB_NC; ++c)
+      for (int r = 0; r < 3; ++r) {
+        pos[(i * HB_NC + c) * 3 + r] = p[c][r];
+        vel[(i * HB_NC + c) * 3 + r] = v[c][r];
+      }
+  }
+}
+
+void orc_centroidal_matrix(void* h, const double* q, double* A /*6x16*/, double* com /*3*/) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  Kin<double> k;
+  k.compute(pb.mdl, q);
+  double Am[6][HB_NV];
+  centroidal_momentum_matrix<double>(pb.mdl, k, Am);
+  std::memcpy(A, Am, sizeof(Am));
+  for (int r = 0; r < 3; ++r) com[r] = k.com[r];
+}
+
+void orc_rbd(void* h, int n, const double* rbd, double* M, double* nle, double* J, double* dJv) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  for (int i = 0; i < n; ++i) {
+    double q[HB_NV], v[HB_NV];
+    rbd_to_qv(pb.mdl, rbd + i * HB_NRBD, q, v);
+    RbdQuantities r;
+    rbd_measured(pb.mdl, q, v, r);
+    if (M) copy_mat(r.M, M + size_t(i) * 256);
+    if (nle) std::memcpy(nle + i * 16, r.nle.data(), 16 * sizeof(double));
+    if (J) copy_mat(r.J, J + size_t(i) * 192);
+    if (dJv) std::memcpy(dJv + i * 12, r.dJv.data(), 12 * sizeof(double));
+  }
+}
+
+void orc_rbd_qv(void* h, const double* q, const double* v, double* M, double* nle, double* J, double* dJv) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  RbdQuantities r;
+  rbd_measured(pb.mdl, q, v, r);
+  copy_mat(r.M, M);
+  std::memcpy(nle, r.nle.data(), 16 * sizeof(double));
+  copy_mat(r.J, J);
+  std::memcpy(dJv, r.dJv.data(), 12 * sizeof(double));
+}
+
+void orc_desired_kinematics(void* h, const double* x, const double* u, double* base_pose, double* base_vel,
+                            double* base_acc, double* foot_pos, double* foot_vel) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  DesiredKinematics d;
+  desired_kinematics(pb.mdl, x, u, d);
+  std::memcpy(base_pose, d.base_pose, 48);
+  std::memcpy(base_vel, d.base_vel, 48);
+  std::memcpy(base_acc, d.base_acc, 48);
+  for (int c = 0; c < HB_NC; ++c)
+    for (int r = 0; r < 3; ++r) {
+      foot_pos[3 * c + r] = d.foot_pos[c][r];
+      foot_vel[3 * c + r] = d.foot_vel[c][r];
+    }
+}
+
+// LQ approximation of one node. Output buffers are sized for the maximum (16 constraint rows, 22 columns).
+// Returns the number of equality rows; *rank_out the rank of D.
+int orc_node_lq(void* h, double dt, int mode, const double* x_ref, const double* swing, const double* x,
+                const double* u, const double* x_next, double* A, double* B, double* b, double* Q, double* R,
+                double* P, double* q, double* r, double* C, double* D, double* e, double* cost, int* rank_out,
+                double* Px, double* Pe) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  NodeRef ref;
+  ref.dt = dt; ref.mode = mode; ref.x_ref = x_ref; ref.swing = swing;
+  NodeLQ lq;
+  node_lq(pb, ref, x, u, x_next, lq);
+  copy_mat(lq.A, A); copy_mat(lq.B, B); copy_mat(lq.Q, Q); copy_mat(lq.R, R); copy_mat(lq.P, P);
+  std::memcpy(b, lq.b.data(), 22 * 8); std::memcpy(q, lq.q.data(), 22 * 8); std::memcpy(r, lq.r.data(), 22 * 8);
+  copy_mat(lq.C, C); copy_mat(lq.D, D);
+  std::memcpy(e, lq.e.data(), lq.e.size() * 8);
+  if (cost) *cost = lq.val.cost;
+  if (rank_out) *rank_out = lq.rank;
+  if (Px) copy_mat(lq.Px, Px);
+  if (Pe) std::memcpy(Pe, lq.Pe.data(), 22 * 8);
+  return lq.C.r;
+}
+
+// Generic unconstrained LQ solve (dense stage data, nu inputs per stage) — checks the Riccati restatement
+// against a dense KKT solve in the tests and is the oracle for hb_riccati_solve.
+int orc_riccati(int N, int nu, const double* A, const double* B, const double* b, const double* Q, const double* R,
+                const double* P, const double* q, const double* r, const double* dx0, double* dx, double* du) {
+  std::vector<NodeLQ> lq(N);
+  for (int k = 0; k < N; ++k) {
+    NodeLQ& n = lq[k];
+    n.At = Mat(HB_NX, HB_NX); n.Bt = Mat(HB_NX, nu); n.Qt = Mat(HB_NX, HB_NX); n.Rt = Mat(nu, nu); n.Pt = Mat(nu, HB_NX);
+    std::memcpy(n.At.a.data(), A + size_t(k) * HB_NX * HB_NX, 8 * HB_NX * HB_NX);
+    std::memcpy(n.Bt.a.data(), B + size_t(k) * HB_NX * nu, 8 * HB_NX * nu);
+    std::memcpy(n.Qt.a.data(), Q + size_t(k) * HB_NX * HB_NX, 8 * HB_NX * HB_NX);
+    std::memcpy(n.Rt.a.data(), R + size_t(k) * nu * nu, 8 * nu * nu);
+    std::memcpy(n.Pt.a.data(), P + size_t(k) * nu * HB_NX, 8 * nu * HB_NX);
+    n.bt.assign(b + size_t(k) * HB_NX, b + size_t(k + 1) * HB_NX);
+    n.qt.assign(q + size_t(k) * HB_NX, q + size_t(k + 1) * HB_NX);
+    n.rt.assign(r + size_t(k) * nu, r + size_t(k + 1) * nu);
+  }
+  std::vector<Vec> dxs, dus;
+  Vec d0(dx0, dx0 + HB_NX);
+  if (!riccati_solve(lq, d0, dxs, dus)) return -1;
+  for (int k = 0; k <= N; ++k) std::memcpy(dx + size_t(k) * HB_NX, dxs[k].data(), 8 * HB_NX);
+  for (int k = 0; k < N; ++k) std::memcpy(du + size_t(k) * nu, dus[k].data(), 8 * nu);
+  return 0;
+}
+
+// Batched MPC: `iters` SQP iterations per instance.  Tables strided by max_nodes like hb_mpc_set_references.
+// x [n][max_nodes+1][22], u [n][max_nodes][22] are in/out (warm start in, solution out).
+// perf [n][4] = merit, dyn_sse, eq_sse, step of the last iteration.  dx/du optional: QP step of the last iteration.
+int orc_mpc_solve(void* h, int n, int max_nodes, const int* n_nodes, const double* t, const int* mode,
+                  const double* x_ref, const double* swing, const double* x0, double* x, double* u, double* perf,
+                  int iters, int threads, double* dx_out, double* du_out) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  std::atomic<int> fail{0};
+  parallel_for(n, threads, [&](int i) {
+    MpcInstance in;
+    in.N = n_nodes[i];
+    const size_t so = size_t(i) * (max_nodes + 1), si = size_t(i) * max_nodes;
+    in.t.assign(t + so, t + so + in.N + 1);
+    in.mode.assign(mode + si, mode + si + in.N);
+    in.x_ref.assign(x_ref + si * HB_NX, x_ref + (si + in.N) * HB_NX);
+    in.swing.assign(swing + si * 24, swing + (si + in.N) * 24);
+    in.x.assign(x + so * HB_NX, x + (so + in.N + 1) * HB_NX);
+    in.u.assign(u + si * HB_NU, u + (si + in.N) * HB_NU);
+    SqpResult r;
+    std::vector<Vec> dxs, dus;
+    for (int it = 0; it < iters; ++it) r = sqp_iteration(pb, in, x0 + size_t(i) * HB_NX, &dxs, &dus);
+    if (!r.ok) fail.fetch_add(1);
+    std::memcpy(x + so * HB_NX, in.x.data(), in.x.size() * 8);
+    std::memcpy(u + si * HB_NU, in.u.data(), in.u.size() * 8);
+    if (perf) {
+      perf[4 * i] = r.accepted.merit; perf[4 * i + 1] = r.accepted.dyn_sse;
+      perf[4 * i + 2] = r.accepted.eq_sse; perf[4 * i + 3] = r.step;
+    }
+    if (dx_out && r.ok)
+      for (int k = 0; k <= in.N; ++k) std::memcpy(dx_out + (so + k) * HB_NX, dxs[k].data(), 8 * HB_NX);
+    if (du_out && r.ok)
+      for (int k = 0; k < in.N; ++k) std::memcpy(du_out + (si + k) * HB_NU, dus[k].data(), 8 * HB_NU);
+  });
+  return -fail.load();
+}
+
+void orc_cold_start(void* h, int N, const int* mode, const double* x0, double* x, double* u) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  MpcInstance in;
+  in.N = N;
+  in.mode.assign(mode, mode + N);
+  cold_start(pb, in, x0);
+  std::memcpy(x, in.x.data(), in.x.size() * 8);
+  std::memcpy(u, in.u.data(), in.u.size() * 8);
+}
+
+void orc_performance(void* h, int N, const double* t, const int* mode, const double* x_ref, const double* swing,
+                     const double* x, const double* u, double* out3) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  MpcInstance in;
+  in.N = N;
+  in.t.assign(t, t + N + 1);
+  in.mode.assign(mode, mode + N);
+  in.x_ref.assign(x_ref, x_ref + size_t(N) * HB_NX);
+  in.swing.assign(swing, swing + size_t(N) * 24);
+  std::vector<double> xs(x, x + size_t(N + 1) * HB_NX), us(u, u + size_t(N) * HB_NU);
+  const Performance p = evaluate_performance(pb, in, xs, us);
+  out3[0] = p.merit; out3[1] = p.dyn_sse; out3[2] = p.eq_sse;
+}
+
+// Batched WeightedWbc::update. sol [n][38] in/out (previous solution is kept when the QP fails).
+void orc_wbc_update(void* h, int n, const double* x_des, const double* u_des, const double* rbd, const int* mode,
+                    const int* stance_flag, double* sol, int* status, int* iters, int threads) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  parallel_for(n, threads, [&](int i) {
+    const QpResult r = weighted_wbc(pb, x_des + size_t(i) * HB_NX, u_des + size_t(i) * HB_NU, rbd + size_t(i) * HB_NRBD,
+                                    mode[i], stance_flag ? stance_flag[i] != 0 : false);
+    if (r.status == 0) std::memcpy(sol + size_t(i) * HB_NWBC, r.x.data(), 8 * HB_NWBC);
+    if (status) status[i] = r.status;
+    if (iters) iters[i] = r.iterations;
+  });
+}
+
+// WBC problem data of one instance (for property tests): A_eq[nA x 38], D[nD x 38], cost rows.
+int orc_wbc_problem(void* h, const double* x_des, const double* u_des, const double* rbd, int mode, int stance,
+                    double* Aeq, double* beq, int* n_eq, double* Din, double* fin, int* n_in, double* Aw, double* bw,
+                    int* n_w) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  WbcWorkspace ws;
+  ws.update(pb, x_des, u_des, rbd, mode);
+  const Task cons = Task::stack(Task::stack(ws.eom(), ws.torque_limits()), ws.friction_cone());
+  Task cost;
+  if (stance) cost = ws.stance_base_accel().scaled(pb.cfg.weight_base_accel);
+  else
+    cost = Task::stack(Task::stack(ws.swing_leg().scaled(pb.cfg.weight_swing_leg), ws.base_accel().scaled(pb.cfg.weight_base_accel)),
+                       ws.contact_force(u_des).scaled(pb.cfg.weight_contact_force));
+  copy_mat(cons.A, Aeq); std::memcpy(beq, cons.b.data(), cons.b.size() * 8); *n_eq = cons.A.r;
+  copy_mat(cons.D, Din); std::memcpy(fin, cons.f.data(), cons.f.size() * 8); *n_in = cons.D.r;
+  copy_mat(cost.A, Aw); std::memcpy(bw, cost.b.data(), cost.b.size() * 8); *n_w = cost.A.r;
+  return 0;
+}
+
+// Generic LS-QP entry (property tests of the QP restatement).
+int orc_lsqp(int n, int mA, const double* A, const double* b, double eps, int mE, const double* E, const double* e,
+             int mD, const double* D, const double* f, int max_iter, double* x, int* iters) {
+  Mat Am(mA, n), Em(mE, n), Dm(mD, n);
+  if (mA) std::memcpy(Am.a.data(), A, 8 * size_t(mA) * n);
+  if (mE) std::memcpy(Em.a.data(), E, 8 * size_t(mE) * n);
+  if (mD) std::memcpy(Dm.a.data(), D, 8 * size_t(mD) * n);
+  const QpResult r = solve_lsqp(Am, Vec(b, b + mA), eps, Em, Vec(e, e + mE), Dm, Vec(f, f + mD), max_iter);
+  std::memcpy(x, r.x.data(), 8 * n);
+  if (iters) *iters = r.iterations;
+  return r.status;
+}
+
+}  // extern "C"

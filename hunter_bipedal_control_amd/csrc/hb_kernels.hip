@@ -1,0 +1,781 @@
+// HIP kernels (gfx950) + C-ABI implementation of include/hunter_hip.h.
+// One process per GPU; two HIP streams mirror the reference's two threads (MPC thread / control thread,
+// legged_controllers/src/LeggedController.cpp:396-421).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hb_host.hpp"
+#include "hb_riccati.hpp"
+#include "hb_wbc.hpp"
+
+using namespace hb;
+
+namespace {
+
+struct DeviceCtx {
+  int lane, nlanes;
+  __device__ DeviceCtx() : lane(threadIdx.x), nlanes(blockDim.x) {}
+  __device__ void sync() const { __syncthreads(); }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// device-resident problem data of a batch
+struct Batch {
+  int B, Nmax;
+  int* n_nodes;     // [B]
+  double* t;        // [B][Nmax+1]
+  int* mode;        // [B][Nmax]
+  double* xref;     // [B][Nmax][22]
+  double* swing;    // [B][Nmax][24]
+  double* x;        // [B][Nmax+1][22]
+  double* u;        // [B][Nmax][22]
+  double* x0;       // [B][22]
+  double* recs;     // [B][Nmax][REC_SIZE]
+  double* gains;    // [B][Nmax][GAIN_SIZE]
+  double* dx;       // [B][Nmax+1][22]
+  double* du;       // [B][Nmax][22]
+  double* acc;      // [B][4] armijo, base merit, base dyn, base eq
+  double* partial;  // [B][Nmax][3]
+  int* accepted;    // [B]
+  double* perf;     // [B][4] merit dyn eq step
+  int* ric_fail;    // [B]
+};
+
+__global__ void k_set_x0(Batch b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.B * HB_NX) return;
+  const int inst = i / HB_NX, c = i % HB_NX;
+  b.x[size_t(inst) * (b.Nmax + 1) * HB_NX + c] = b.x0[i];
+}
+
+// cold start: x_k = x0, u_k = weight compensation of mode_k (LeggedRobotInitializer.cpp:67-77)
+__global__ void k_cold_start(Batch b, const DevModel* __restrict__ M) {
+  const int k = blockIdx.x, inst = blockIdx.y;
+  const int lane = threadIdx.x;
+  if (k > b.n_nodes[inst]) return;
+  double* xk = b.x + (size_t(inst) * (b.Nmax + 1) + k) * HB_NX;
+  if (lane < HB_NX) xk[lane] = b.x0[inst * HB_NX + lane];
+  if (k < b.n_nodes[inst] && lane < HB_NU) {
+    bool cf[HB_NC];
+    mode_flags(b.mode[size_t(inst) * b.Nmax + k], cf);
+    int nc = 0;
+    for (int i = 0; i < HB_NC; ++i) nc += cf[i];
+    double v = 0.0;
+    if (lane < 12 && lane % 3 == 2 && cf[lane / 3]) v = M->total_mass * M->gravity / nc;
+    b.u[(size_t(inst) * b.Nmax + k) * HB_NU + lane] = v;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_lq(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
+  const int k = blockIdx.x, inst = blockIdx.y;
+  if (k >= b.n_nodes[inst]) return;
+  __shared__ double lds[LqLds::total];
+  const size_t nd = size_t(inst) * b.Nmax + k;
+  const double* tt = b.t + size_t(inst) * (b.Nmax + 1);
+  NodeIn in;
+  in.x = b.x + (size_t(inst) * (b.Nmax + 1) + k) * HB_NX;
+  in.xnext = in.x + HB_NX;
+  in.u = b.u + nd * HB_NU;
+  in.xref = b.xref + nd * HB_NX;
+  in.swing = b.swing + nd * 24;
+  in.dt = tt[k + 1] - tt[k];
+  in.mode = b.mode[nd];
+  lq_node(DeviceCtx(), *M, *C, in, lds, b.recs + nd * REC_SIZE);
+}
+
+__global__ __launch_bounds__(64) void k_ric_bwd(Batch b) {
+  const int inst = blockIdx.x;
+  __shared__ double lds[RicLds::total];
+  const DeviceCtx cx;
+  for (int i = cx.lane; i < 484 + 24; i += cx.nlanes) lds[RicLds::S + i] = 0.0;
+  if (cx.lane == 0) lds[RicLds::flag] = 0.0;
+  __syncthreads();
+  const int n = b.n_nodes[inst];
+  for (int k = n - 1; k >= 0; --k) {
+    const double* rec = b.recs + (size_t(inst) * b.Nmax + k) * REC_SIZE;
+    for (int i = cx.lane; i < REC_RICCATI_END / 2; i += cx.nlanes)
+      reinterpret_cast<double2*>(lds + RicLds::node)[i] = reinterpret_cast<const double2*>(rec)[i];
+    __syncthreads();
+    riccati_bwd_node(cx, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE);
+  }
+  if (cx.lane == 0) b.ric_fail[inst] = lds[RicLds::flag] != 0.0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
+  const int inst = blockIdx.x;
+  __shared__ double lds[FwdLds::total];
+  const DeviceCtx cx;
+  for (int i = cx.lane; i < FwdLds::total; i += cx.nlanes) lds[i] = 0.0;  // dx0 = 0: x[0] is the measured state
+  __syncthreads();
+  const int n = b.n_nodes[inst];
+  for (int k = 0; k < n; ++k) {
+    const size_t nd = size_t(inst) * b.Nmax + k;
+    riccati_fwd_node(cx, lds, b.recs + nd * REC_SIZE, b.gains + nd * GAIN_SIZE,
+                     b.dx + (size_t(inst) * (b.Nmax + 1) + k) * HB_NX, b.du + nd * HB_NU);
+  }
+  if (cx.lane < HB_NX) b.dx[(size_t(inst) * (b.Nmax + 1) + n) * HB_NX + cx.lane] = lds[FwdLds::dx + cx.lane];
+  if (cx.lane < 4) b.acc[inst * 4 + cx.lane] = lds[FwdLds::acc + cx.lane];
+  if (cx.lane == 0) {
+    b.accepted[inst] = 0;
+    b.perf[inst * 4 + 0] = lds[FwdLds::acc + 1];
+    b.perf[inst * 4 + 1] = lds[FwdLds::acc + 2];
+    b.perf[inst * 4 + 2] = lds[FwdLds::acc + 3];
+    b.perf[inst * 4 + 3] = 0.0;
+  }
+}
+
+// line search: value of trial point (x + alpha dx, u + alpha du), one thread per node
+__global__ __launch_bounds__(64) void k_ls_eval(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C,
+                                                double alpha) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int inst = gid / b.Nmax, k = gid % b.Nmax;
+  if (inst >= b.B) return;
+  if (b.accepted[inst] || k >= b.n_nodes[inst]) return;
+  const size_t nd = size_t(inst) * b.Nmax + k;
+  const size_t xo = (size_t(inst) * (b.Nmax + 1) + k) * HB_NX;
+  double x[HB_NX], xn[HB_NX], u[HB_NU];
+#pragma unroll
+  for (int i = 0; i < HB_NX; ++i) {
+    x[i] = b.x[xo + i] + alpha * b.dx[xo + i];
+    xn[i] = b.x[xo + HB_NX + i] + alpha * b.dx[xo + HB_NX + i];
+    u[i] = b.u[nd * HB_NU + i] + alpha * b.du[nd * HB_NU + i];
+  }
+  const double* tt = b.t + size_t(inst) * (b.Nmax + 1);
+  double o3[3];
+  node_value(*M, *C, x, u, xn, b.xref + nd * HB_NX, b.swing + nd * 24, tt[k + 1] - tt[k], b.mode[nd], o3);
+  b.partial[nd * 3 + 0] = o3[0];
+  b.partial[nd * 3 + 1] = o3[1];
+  b.partial[nd * 3 + 2] = o3[2];
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return __shfl(v, 0, 64);
+}
+
+__global__ __launch_bounds__(64) void k_ls_decide(Batch b, const DevConfig* __restrict__ C, double alpha) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  if (b.accepted[inst]) return;
+  const int n = b.n_nodes[inst];
+  double m = 0, d = 0, e = 0;
+  for (int k = lane; k < n; k += 64) {
+    const double* p = b.partial + (size_t(inst) * b.Nmax + k) * 3;
+    m += p[0];
+    d += p[1];
+    e += p[2];
+  }
+  m = wave_sum(m);
+  d = wave_sum(d);
+  e = wave_sum(e);
+  const double armijo = b.acc[inst * 4 + 0], base_merit = b.acc[inst * 4 + 1];
+  const double base_viol = sqrt(b.acc[inst * 4 + 2] + b.acc[inst * 4 + 3]);
+  const bool ok = filter_accept(*C, base_merit, base_viol, m, sqrt(d + e), alpha, armijo) && !b.ric_fail[inst];
+  if (!ok) return;
+  // commit the step
+  const size_t xo = size_t(inst) * (b.Nmax + 1) * HB_NX, uo = size_t(inst) * b.Nmax * HB_NU;
+  for (int i = lane; i < (n + 1) * HB_NX; i += 64) b.x[xo + i] += alpha * b.dx[xo + i];
+  for (int i = lane; i < n * HB_NU; i += 64) b.u[uo + i] += alpha * b.du[uo + i];
+  if (lane == 0) {
+    b.accepted[inst] = 1;
+    b.perf[inst * 4 + 0] = m;
+    b.perf[inst * 4 + 1] = d;
+    b.perf[inst * 4 + 2] = e;
+    b.perf[inst * 4 + 3] = alpha;
+  }
+}
+
+// ---- unit-level kernels -----------------------------------------------------------------------------------
+__global__ void k_flow_map(int n, const DevModel* __restrict__ M, const double* x, const double* u, double* f,
+                           double* pos, double* vel) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double xl[HB_NX], ul[HB_NU], fl[HB_NX];
+  for (int c = 0; c < HB_NX; ++c) { xl[c] = x[i * HB_NX + c]; ul[c] = u[i * HB_NU + c]; }
+  Centroidal<double> c;
+  flow_map<double>(*M, xl, ul, fl, &c);
+  if (f) for (int r = 0; r < HB_NX; ++r) f[i * HB_NX + r] = fl[r];
+  for (int k = 0; k < HB_NC; ++k) {
+    if (pos) { pos[(i * 4 + k) * 3] = xl[6] + c.foot_rel[k].x; pos[(i * 4 + k) * 3 + 1] = xl[7] + c.foot_rel[k].y; pos[(i * 4 + k) * 3 + 2] = xl[8] + c.foot_rel[k].z; }
+    if (vel) { vel[(i * 4 + k) * 3] = c.foot_vel[k].x; vel[(i * 4 + k) * 3 + 1] = c.foot_vel[k].y; vel[(i * 4 + k) * 3 + 2] = c.foot_vel[k].z; }
+  }
+}
+// one 64-lane block per sample, lane = direction
+__global__ __launch_bounds__(64) void k_flow_jac(const DevModel* __restrict__ M, const double* x, const double* u, double* dfdx,
+                                                 double* dfdu) {
+  const int i = blockIdx.x, dir = threadIdx.x;
+  if (dir >= 44) return;
+  Dual1 xd[HB_NX], ud[HB_NU], fd[HB_NX];
+  for (int c = 0; c < HB_NX; ++c) {
+    xd[c] = Dual1(x[i * HB_NX + c], dir == c ? 1.0 : 0.0);
+    ud[c] = Dual1(u[i * HB_NU + c], dir == HB_NX + c ? 1.0 : 0.0);
+  }
+  Centroidal<Dual1> ce;
+  flow_map<Dual1>(*M, xd, ud, fd, &ce);
+  double* dst = (dir < HB_NX) ? dfdx : dfdu;
+  const int col = (dir < HB_NX) ? dir : dir - HB_NX;
+  if (dst)
+    for (int r = 0; r < HB_NX; ++r) dst[(size_t(i) * HB_NX + r) * HB_NX + col] = fd[r].d;
+}
+
+}  // namespace
+
+// ===========================================================================================================
+// host side
+// ===========================================================================================================
+struct hb_ctx {
+  int device = 0, B = 0, Nmax = 0;
+  hb_model model;
+  hb_config config;
+  DevModel hmodel;
+  DevConfig hconfig;
+  DevModel* dmodel = nullptr;
+  DevConfig* dconfig = nullptr;
+  Batch b{};
+  hipStream_t s_mpc = nullptr, s_wbc = nullptr;
+  hipEvent_t ev[8]{};
+  bool refs_set = false, traj_set = false, timed = false;
+  std::vector<void*> allocs;
+  std::string err;
+  WbcBatch w{};
+  hb_stats stats{};
+};
+
+static thread_local std::string g_create_error;
+
+#define HB_HIP(call)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+      return HB_ERR_DEVICE;                                                                \
+    }                                                                                      \
+  } while (0)
+
+template <class T>
+static hipError_t dalloc(hb_ctx* ctx, T** p, size_t n) {
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
+  if (e == hipSuccess) {
+    ctx->allocs.push_back(*p);
+    e = hipMemset(*p, 0, n * sizeof(T));
+  }
+  return e;
+}
+
+extern "C" {
+
+int32_t hb_version(void) { return 100; }
+
+const char* hb_last_error(const hb_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch, int32_t max_nodes, int32_t device,
+                  hb_ctx** out) {
+  if (!model || !config || !out || batch <= 0 || max_nodes <= 0) {
+    g_create_error = "hb_create: bad argument";
+    return HB_ERR_ARG;
+  }
+  if (!topology_supported(*model)) {
+    g_create_error = "hb_create: model topology is not base + two 5-joint legs";
+    return HB_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) {
+    g_create_error = "hb_create: no HIP device visible (the solver has no CPU fallback)";
+    return HB_ERR_NO_GPU;
+  }
+  hb_ctx* ctx = new hb_ctx();
+  ctx->device = device;
+  ctx->B = batch;
+  ctx->Nmax = max_nodes;
+  ctx->model = *model;
+  ctx->config = *config;
+  ctx->hmodel = make_dev_model(*model);
+  ctx->hconfig = make_dev_config(*config, ctx->hmodel);
+  auto fail = [&](const char* what, hipError_t e) {
+    g_create_error = std::string("hb_create: ") + what + ": " + hipGetErrorString(e);
+    for (void* p : ctx->allocs) (void)hipFree(p);
+    delete ctx;
+    return HB_ERR_DEVICE;
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&ctx->s_mpc, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
+  if ((e = hipStreamCreateWithFlags(&ctx->s_wbc, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
+  for (auto& ev : ctx->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return fail("event", e);
+  const size_t B = batch, N = max_nodes;
+  Batch& b = ctx->b;
+  b.B = batch;
+  b.Nmax = max_nodes;
+#define A(ptr, n) if ((e = dalloc(ctx, &ptr, n)) != hipSuccess) return fail(#ptr, e)
+  A(ctx->dmodel, 1);
+  A(ctx->dconfig, 1);
+  A(b.n_nodes, B);
+  A(b.t, B * (N + 1));
+  A(b.mode, B * N);
+  A(b.xref, B * N * HB_NX);
+  A(b.swing, B * N * 24);
+  A(b.x, B * (N + 1) * HB_NX);
+  A(b.u, B * N * HB_NU);
+  A(b.x0, B * HB_NX);
+  A(b.recs, B * N * REC_SIZE);
+  A(b.gains, B * N * GAIN_SIZE);
+  A(b.dx, B * (N + 1) * HB_NX);
+  A(b.du, B * N * HB_NU);
+  A(b.acc, B * 4);
+  A(b.partial, B * N * 3);
+  A(b.accepted, B);
+  A(b.perf, B * 4);
+  A(b.ric_fail, B);
+  WbcBatch& w = ctx->w;
+  w.B = batch;
+  A(w.t_now, B);
+  A(w.rbd, B * HB_NRBD);
+  A(w.walk, B);
+  A(w.xdes, B * HB_NX);
+  A(w.udes, B * HB_NU);
+  A(w.mode, B);
+  A(w.stance, B);
+  A(w.sol, B * HB_NWBC);
+  A(w.status, B);
+  A(w.iters, B);
+  A(w.px, B * (N + 1) * HB_NX);
+  A(w.pu, B * N * HB_NU);
+  A(w.pt, B * (N + 1));
+  A(w.pmode, B * N);
+  A(w.pn, B);
+#undef A
+  if ((e = hipMemcpy(ctx->dmodel, &ctx->hmodel, sizeof(DevModel), hipMemcpyHostToDevice)) != hipSuccess) return fail("model", e);
+  if ((e = hipMemcpy(ctx->dconfig, &ctx->hconfig, sizeof(DevConfig), hipMemcpyHostToDevice)) != hipSuccess) return fail("config", e);
+  // walking by default
+  std::vector<int> ones(B, 1);
+  if ((e = hipMemcpy(w.walk, ones.data(), B * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return fail("walk", e);
+  *out = ctx;
+  return HB_OK;
+}
+
+void hb_destroy(hb_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : ctx->allocs) (void)hipFree(p);
+  for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
+  (void)hipStreamDestroy(ctx->s_mpc);
+  (void)hipStreamDestroy(ctx->s_wbc);
+  delete ctx;
+}
+
+int32_t hb_sync(hb_ctx* ctx) {
+  if (!ctx) return HB_ERR_ARG;
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  HB_HIP(hipStreamSynchronize(ctx->s_wbc));
+  return HB_OK;
+}
+
+int32_t hb_get_input_cost(const hb_ctx* ctx, double* R) {
+  if (!ctx || !R) return HB_ERR_ARG;
+  std::memset(R, 0, sizeof(double) * HB_NU * HB_NU);
+  for (int i = 0; i < 12; ++i) R[i * HB_NU + i] = ctx->hconfig.R_FF_diag[i];
+  for (int a = 0; a < HB_NJ; ++a)
+    for (int c = 0; c < HB_NJ; ++c) R[(12 + a) * HB_NU + 12 + c] = ctx->hconfig.R_jj[a * HB_NJ + c];
+  return HB_OK;
+}
+
+int32_t hb_mpc_set_references(hb_ctx* ctx, int32_t i0, int32_t cnt, const int32_t* n_nodes, const double* t,
+                              const int32_t* mode, const double* x_ref, const double* swing_ref) {
+  if (!ctx || !n_nodes || !t || !mode || !x_ref || !swing_ref || i0 < 0 || cnt <= 0 || i0 + cnt > ctx->B) {
+    if (ctx) ctx->err = "hb_mpc_set_references: bad argument";
+    return HB_ERR_ARG;
+  }
+  for (int i = 0; i < cnt; ++i)
+    if (n_nodes[i] < 1 || n_nodes[i] > ctx->Nmax) {
+      ctx->err = "hb_mpc_set_references: n_nodes out of range";
+      return HB_ERR_ARG;
+    }
+  const size_t N = ctx->Nmax;
+  Batch& b = ctx->b;
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipMemcpyAsync(b.n_nodes + i0, n_nodes, cnt * sizeof(int), hipMemcpyHostToDevice, ctx->s_mpc));
+  HB_HIP(hipMemcpyAsync(b.t + i0 * (N + 1), t, cnt * (N + 1) * 8, hipMemcpyHostToDevice, ctx->s_mpc));
+  HB_HIP(hipMemcpyAsync(b.mode + i0 * N, mode, cnt * N * sizeof(int), hipMemcpyHostToDevice, ctx->s_mpc));
+  HB_HIP(hipMemcpyAsync(b.xref + i0 * N * HB_NX, x_ref, cnt * N * HB_NX * 8, hipMemcpyHostToDevice, ctx->s_mpc));
+  HB_HIP(hipMemcpyAsync(b.swing + i0 * N * 24, swing_ref, cnt * N * 24 * 8, hipMemcpyHostToDevice, ctx->s_mpc));
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));  // host buffers are caller-owned: safe to reuse on return
+  ctx->refs_set = true;
+  return HB_OK;
+}
+
+int32_t hb_mpc_reset(hb_ctx* ctx, const double* x0) {
+  if (!ctx || !x0) return HB_ERR_ARG;
+  if (!ctx->refs_set) {
+    ctx->err = "hb_mpc_reset: references not set";
+    return HB_ERR_STATE;
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipMemcpyAsync(ctx->b.x0, x0, size_t(ctx->B) * HB_NX * 8, hipMemcpyHostToDevice, ctx->s_mpc));
+  hipLaunchKernelGGL(k_cold_start, dim3(ctx->Nmax + 1, ctx->B), dim3(64), 0, ctx->s_mpc, ctx->b, ctx->dmodel);
+  HB_HIP(hipGetLastError());
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  ctx->traj_set = true;
+  return HB_OK;
+}
+
+int32_t hb_mpc_set_trajectory(hb_ctx* ctx, const double* x, const double* u) {
+  if (!ctx || !x || !u) return HB_ERR_ARG;
+  const size_t B = ctx->B, N = ctx->Nmax;
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipMemcpyAsync(ctx->b.x, x, B * (N + 1) * HB_NX * 8, hipMemcpyHostToDevice, ctx->s_mpc));
+  HB_HIP(hipMemcpyAsync(ctx->b.u, u, B * N * HB_NU * 8, hipMemcpyHostToDevice, ctx->s_mpc));
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  ctx->traj_set = true;
+  return HB_OK;
+}
+
+static int32_t mpc_iterations(hb_ctx* ctx) {
+  Batch& b = ctx->b;
+  hipStream_t s = ctx->s_mpc;
+  const int B = ctx->B, N = ctx->Nmax;
+  for (int it = 0; it < ctx->config.sqp_iterations; ++it) {
+    const bool timed = (it == 0);
+    hipLaunchKernelGGL(k_set_x0, dim3((B * HB_NX + 255) / 256), dim3(256), 0, s, b);
+    if (timed) HB_HIP(hipEventRecord(ctx->ev[0], s));
+    hipLaunchKernelGGL(k_lq, dim3(N, B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig);
+    if (timed) HB_HIP(hipEventRecord(ctx->ev[1], s));
+    hipLaunchKernelGGL(k_ric_bwd, dim3(B), dim3(64), 0, s, b);
+    if (timed) HB_HIP(hipEventRecord(ctx->ev[2], s));
+    hipLaunchKernelGGL(k_ric_fwd, dim3(B), dim3(64), 0, s, b);
+    if (timed) HB_HIP(hipEventRecord(ctx->ev[3], s));
+    double alpha = 1.0;
+    while (alpha >= ctx->config.alpha_min) {
+      hipLaunchKernelGGL(k_ls_eval, dim3((B * N + 63) / 64), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, alpha);
+      hipLaunchKernelGGL(k_ls_decide, dim3(B), dim3(64), 0, s, b, ctx->dconfig, alpha);
+      alpha *= ctx->config.alpha_decay;
+    }
+    if (timed) HB_HIP(hipEventRecord(ctx->ev[4], s));
+  }
+  HB_HIP(hipGetLastError());
+  ctx->timed = true;
+  ctx->stats.n_mpc_solves += B;
+  return HB_OK;
+}
+
+int32_t hb_mpc_solve(hb_ctx* ctx, const double* x0) {
+  if (!ctx) return HB_ERR_ARG;
+  if (!ctx->refs_set || !ctx->traj_set) {
+    ctx->err = "hb_mpc_solve: call hb_mpc_set_references and hb_mpc_reset/hb_mpc_set_trajectory first";
+    return HB_ERR_STATE;
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  if (x0) {
+    HB_HIP(hipMemcpyAsync(ctx->b.x0, x0, size_t(ctx->B) * HB_NX * 8, hipMemcpyHostToDevice, ctx->s_mpc));
+    HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  }
+  return mpc_iterations(ctx);
+}
+
+int32_t hb_mpc_get_solution(hb_ctx* ctx, int32_t i0, int32_t cnt, double* x, double* u) {
+  if (!ctx || i0 < 0 || cnt <= 0 || i0 + cnt > ctx->B) return HB_ERR_ARG;
+  const size_t N = ctx->Nmax;
+  HB_HIP(hipSetDevice(ctx->device));
+  if (x) HB_HIP(hipMemcpyAsync(x, ctx->b.x + i0 * (N + 1) * HB_NX, cnt * (N + 1) * HB_NX * 8, hipMemcpyDeviceToHost, ctx->s_mpc));
+  if (u) HB_HIP(hipMemcpyAsync(u, ctx->b.u + i0 * N * HB_NU, cnt * N * HB_NU * 8, hipMemcpyDeviceToHost, ctx->s_mpc));
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  return HB_OK;
+}
+
+int32_t hb_mpc_get_step(hb_ctx* ctx, double* dx, double* du) {
+  if (!ctx) return HB_ERR_ARG;
+  const size_t B = ctx->B, N = ctx->Nmax;
+  HB_HIP(hipSetDevice(ctx->device));
+  if (dx) HB_HIP(hipMemcpyAsync(dx, ctx->b.dx, B * (N + 1) * HB_NX * 8, hipMemcpyDeviceToHost, ctx->s_mpc));
+  if (du) HB_HIP(hipMemcpyAsync(du, ctx->b.du, B * N * HB_NU * 8, hipMemcpyDeviceToHost, ctx->s_mpc));
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  return HB_OK;
+}
+
+int32_t hb_mpc_get_performance(hb_ctx* ctx, double* perf) {
+  if (!ctx || !perf) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipMemcpyAsync(perf, ctx->b.perf, size_t(ctx->B) * 4 * 8, hipMemcpyDeviceToHost, ctx->s_mpc));
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  return HB_OK;
+}
+
+int32_t hb_mpc_publish(hb_ctx* ctx) {
+  if (!ctx) return HB_ERR_ARG;
+  const size_t B = ctx->B, N = ctx->Nmax;
+  HB_HIP(hipSetDevice(ctx->device));
+  // device-to-device copy of the solution into the policy buffers read by the WBC stream
+  hipStream_t s = ctx->s_mpc;
+  HB_HIP(hipMemcpyAsync(ctx->w.px, ctx->b.x, B * (N + 1) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
+  HB_HIP(hipMemcpyAsync(ctx->w.pu, ctx->b.u, B * N * HB_NU * 8, hipMemcpyDeviceToDevice, s));
+  HB_HIP(hipMemcpyAsync(ctx->w.pt, ctx->b.t, B * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
+  HB_HIP(hipMemcpyAsync(ctx->w.pmode, ctx->b.mode, B * N * sizeof(int), hipMemcpyDeviceToDevice, s));
+  HB_HIP(hipMemcpyAsync(ctx->w.pn, ctx->b.n_nodes, B * sizeof(int), hipMemcpyDeviceToDevice, s));
+  HB_HIP(hipEventRecord(ctx->ev[7], s));
+  HB_HIP(hipStreamWaitEvent(ctx->s_wbc, ctx->ev[7], 0));
+  ctx->w.policy_valid = true;
+  return HB_OK;
+}
+
+static int32_t wbc_launch(hb_ctx* ctx, bool from_policy, double dt) {
+  (void)dt;
+  WbcBatch& w = ctx->w;
+  hipStream_t s = ctx->s_wbc;
+  HB_HIP(hipEventRecord(ctx->ev[5], s));
+  if (from_policy) {
+    hipLaunchKernelGGL(k_policy_eval, dim3((ctx->B + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
+  }
+  hipLaunchKernelGGL(k_wbc, dim3(ctx->B), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
+  HB_HIP(hipEventRecord(ctx->ev[6], s));
+  HB_HIP(hipGetLastError());
+  ctx->stats.n_wbc_solves += ctx->B;
+  return HB_OK;
+}
+
+int32_t hb_wbc_update(hb_ctx* ctx, const double* t_now, const double* rbd, const int32_t* walk_flag, double dt,
+                      double* sol, double* x_des, double* u_des, int32_t* planned_mode, int32_t* status) {
+  if (!ctx || !t_now || !rbd) return HB_ERR_ARG;
+  if (!ctx->w.policy_valid) {
+    ctx->err = "hb_wbc_update: no published policy (hb_mpc_publish)";
+    return HB_ERR_STATE;
+  }
+  const size_t B = ctx->B;
+  WbcBatch& w = ctx->w;
+  hipStream_t s = ctx->s_wbc;
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipMemcpyAsync(w.t_now, t_now, B * 8, hipMemcpyHostToDevice, s));
+  HB_HIP(hipMemcpyAsync(w.rbd, rbd, B * HB_NRBD * 8, hipMemcpyHostToDevice, s));
+  if (walk_flag) HB_HIP(hipMemcpyAsync(w.walk, walk_flag, B * sizeof(int), hipMemcpyHostToDevice, s));
+  int32_t rc = wbc_launch(ctx, true, dt);
+  if (rc != HB_OK) return rc;
+  if (sol) HB_HIP(hipMemcpyAsync(sol, w.sol, B * HB_NWBC * 8, hipMemcpyDeviceToHost, s));
+  if (x_des) HB_HIP(hipMemcpyAsync(x_des, w.xdes, B * HB_NX * 8, hipMemcpyDeviceToHost, s));
+  if (u_des) HB_HIP(hipMemcpyAsync(u_des, w.udes, B * HB_NU * 8, hipMemcpyDeviceToHost, s));
+  if (planned_mode) HB_HIP(hipMemcpyAsync(planned_mode, w.mode, B * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (status) HB_HIP(hipMemcpyAsync(status, w.status, B * sizeof(int), hipMemcpyDeviceToHost, s));
+  HB_HIP(hipStreamSynchronize(s));
+  return HB_OK;
+}
+
+int32_t hb_wbc_update_direct(hb_ctx* ctx, const double* x_des, const double* u_des, const double* rbd, const int32_t* mode,
+                             const int32_t* stance_flag, double dt, double* sol, int32_t* status) {
+  if (!ctx || !x_des || !u_des || !rbd || !mode) return HB_ERR_ARG;
+  const size_t B = ctx->B;
+  WbcBatch& w = ctx->w;
+  hipStream_t s = ctx->s_wbc;
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipMemcpyAsync(w.xdes, x_des, B * HB_NX * 8, hipMemcpyHostToDevice, s));
+  HB_HIP(hipMemcpyAsync(w.udes, u_des, B * HB_NU * 8, hipMemcpyHostToDevice, s));
+  HB_HIP(hipMemcpyAsync(w.rbd, rbd, B * HB_NRBD * 8, hipMemcpyHostToDevice, s));
+  HB_HIP(hipMemcpyAsync(w.mode, mode, B * sizeof(int), hipMemcpyHostToDevice, s));
+  if (stance_flag) HB_HIP(hipMemcpyAsync(w.stance, stance_flag, B * sizeof(int), hipMemcpyHostToDevice, s));
+  else HB_HIP(hipMemsetAsync(w.stance, 0, B * sizeof(int), s));
+  int32_t rc = wbc_launch(ctx, false, dt);
+  if (rc != HB_OK) return rc;
+  if (sol) HB_HIP(hipMemcpyAsync(sol, w.sol, B * HB_NWBC * 8, hipMemcpyDeviceToHost, s));
+  if (status) HB_HIP(hipMemcpyAsync(status, w.status, B * sizeof(int), hipMemcpyDeviceToHost, s));
+  HB_HIP(hipStreamSynchronize(s));
+  return HB_OK;
+}
+
+int32_t hb_set_resident_inputs(hb_ctx* ctx, const double* x0, const double* t_now, const double* rbd, const int32_t* walk_flag) {
+  if (!ctx || !x0 || !t_now || !rbd) return HB_ERR_ARG;
+  const size_t B = ctx->B;
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipMemcpy(ctx->b.x0, x0, B * HB_NX * 8, hipMemcpyHostToDevice));
+  HB_HIP(hipMemcpy(ctx->w.t_now, t_now, B * 8, hipMemcpyHostToDevice));
+  HB_HIP(hipMemcpy(ctx->w.rbd, rbd, B * HB_NRBD * 8, hipMemcpyHostToDevice));
+  if (walk_flag) HB_HIP(hipMemcpy(ctx->w.walk, walk_flag, B * sizeof(int), hipMemcpyHostToDevice));
+  return HB_OK;
+}
+
+int32_t hb_step_resident(hb_ctx* ctx, double dt) {
+  if (!ctx) return HB_ERR_ARG;
+  if (!ctx->refs_set || !ctx->traj_set) {
+    ctx->err = "hb_step_resident: references / trajectory not initialised";
+    return HB_ERR_STATE;
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  int32_t rc = mpc_iterations(ctx);
+  if (rc != HB_OK) return rc;
+  rc = hb_mpc_publish(ctx);
+  if (rc != HB_OK) return rc;
+  rc = wbc_launch(ctx, true, dt);
+  if (rc != HB_OK) return rc;
+  // the next MPC iteration must not overwrite the policy buffers while the WBC reads them
+  HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev[6], 0));
+  return HB_OK;
+}
+
+int32_t hb_get_wbc_solution(hb_ctx* ctx, double* sol, int32_t* status) {
+  if (!ctx) return HB_ERR_ARG;
+  const size_t B = ctx->B;
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipStreamSynchronize(ctx->s_wbc));
+  if (sol) HB_HIP(hipMemcpy(sol, ctx->w.sol, B * HB_NWBC * 8, hipMemcpyDeviceToHost));
+  if (status) HB_HIP(hipMemcpy(status, ctx->w.status, B * sizeof(int), hipMemcpyDeviceToHost));
+  return HB_OK;
+}
+
+int32_t hb_get_stats(hb_ctx* ctx, hb_stats* out) {
+  if (!ctx || !out) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  HB_HIP(hipStreamSynchronize(ctx->s_wbc));
+  float ms = 0;
+  if (ctx->timed) {
+    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->stats.ms_lq = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->stats.ms_riccati_bwd = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->stats.ms_riccati_fwd = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->stats.ms_linesearch = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]) == hipSuccess) ctx->stats.ms_mpc_total = ms;
+  }
+  if (ctx->stats.n_wbc_solves > 0 && hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->stats.ms_wbc = ms;
+  if (ctx->stats.n_wbc_solves > 0) {
+    std::vector<int> st(ctx->B);
+    HB_HIP(hipMemcpy(st.data(), ctx->w.status, size_t(ctx->B) * sizeof(int), hipMemcpyDeviceToHost));
+    for (int& v : ctx->stats.n_status) v = 0;
+    for (int v : st)
+      if (v >= 0 && v < 4) ctx->stats.n_status[v]++;
+  }
+  *out = ctx->stats;
+  return HB_OK;
+}
+
+// ---- unit-level entry points ---------------------------------------------------------------------------
+int32_t hb_eval_flow_map(hb_ctx* ctx, int32_t n, const double* x, const double* u, double* f, double* dfdx, double* dfdu) {
+  if (!ctx || n <= 0 || !x || !u || !f) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  double *dx_, *du_, *df_, *dA = nullptr, *dB = nullptr;
+  HB_HIP(hipMalloc(&dx_, size_t(n) * HB_NX * 8));
+  HB_HIP(hipMalloc(&du_, size_t(n) * HB_NU * 8));
+  HB_HIP(hipMalloc(&df_, size_t(n) * HB_NX * 8));
+  HB_HIP(hipMemcpy(dx_, x, size_t(n) * HB_NX * 8, hipMemcpyHostToDevice));
+  HB_HIP(hipMemcpy(du_, u, size_t(n) * HB_NU * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_flow_map, dim3((n + 63) / 64), dim3(64), 0, ctx->s_mpc, n, ctx->dmodel, dx_, du_, df_, (double*)nullptr, (double*)nullptr);
+  if (dfdx || dfdu) {
+    HB_HIP(hipMalloc(&dA, size_t(n) * 484 * 8));
+    HB_HIP(hipMalloc(&dB, size_t(n) * 484 * 8));
+    hipLaunchKernelGGL(k_flow_jac, dim3(n), dim3(64), 0, ctx->s_mpc, ctx->dmodel, dx_, du_, dA, dB);
+  }
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  HB_HIP(hipMemcpy(f, df_, size_t(n) * HB_NX * 8, hipMemcpyDeviceToHost));
+  if (dfdx) HB_HIP(hipMemcpy(dfdx, dA, size_t(n) * 484 * 8, hipMemcpyDeviceToHost));
+  if (dfdu) HB_HIP(hipMemcpy(dfdu, dB, size_t(n) * 484 * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(dx_); (void)hipFree(du_); (void)hipFree(df_);
+  if (dA) (void)hipFree(dA);
+  if (dB) (void)hipFree(dB);
+  return HB_OK;
+}
+
+int32_t hb_eval_foot_kinematics(hb_ctx* ctx, int32_t n, const double* x, const double* u, double* pos, double* vel) {
+  if (!ctx || n <= 0 || !x || !u || !pos || !vel) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  double *dx_, *du_, *dp, *dv;
+  HB_HIP(hipMalloc(&dx_, size_t(n) * HB_NX * 8));
+  HB_HIP(hipMalloc(&du_, size_t(n) * HB_NU * 8));
+  HB_HIP(hipMalloc(&dp, size_t(n) * 12 * 8));
+  HB_HIP(hipMalloc(&dv, size_t(n) * 12 * 8));
+  HB_HIP(hipMemcpy(dx_, x, size_t(n) * HB_NX * 8, hipMemcpyHostToDevice));
+  HB_HIP(hipMemcpy(du_, u, size_t(n) * HB_NU * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_flow_map, dim3((n + 63) / 64), dim3(64), 0, ctx->s_mpc, n, ctx->dmodel, dx_, du_, (double*)nullptr, dp, dv);
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  HB_HIP(hipMemcpy(pos, dp, size_t(n) * 12 * 8, hipMemcpyDeviceToHost));
+  HB_HIP(hipMemcpy(vel, dv, size_t(n) * 12 * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(dx_); (void)hipFree(du_); (void)hipFree(dp); (void)hipFree(dv);
+  return HB_OK;
+}
+
+int32_t hb_eval_rbd(hb_ctx* ctx, int32_t n, const double* rbd, double* Mo, double* nle, double* J, double* dJv) {
+  if (!ctx || n <= 0 || !rbd) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  double *dr, *dM, *dn, *dJ, *dd;
+  HB_HIP(hipMalloc(&dr, size_t(n) * HB_NRBD * 8));
+  HB_HIP(hipMalloc(&dM, size_t(n) * 256 * 8));
+  HB_HIP(hipMalloc(&dn, size_t(n) * 16 * 8));
+  HB_HIP(hipMalloc(&dJ, size_t(n) * 192 * 8));
+  HB_HIP(hipMalloc(&dd, size_t(n) * 12 * 8));
+  HB_HIP(hipMemcpy(dr, rbd, size_t(n) * HB_NRBD * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_rbd, dim3((n + 63) / 64), dim3(64), 0, ctx->s_wbc, n, ctx->dmodel, dr, dM, dn, dJ, dd);
+  HB_HIP(hipStreamSynchronize(ctx->s_wbc));
+  if (Mo) HB_HIP(hipMemcpy(Mo, dM, size_t(n) * 256 * 8, hipMemcpyDeviceToHost));
+  if (nle) HB_HIP(hipMemcpy(nle, dn, size_t(n) * 16 * 8, hipMemcpyDeviceToHost));
+  if (J) HB_HIP(hipMemcpy(J, dJ, size_t(n) * 192 * 8, hipMemcpyDeviceToHost));
+  if (dJv) HB_HIP(hipMemcpy(dJv, dd, size_t(n) * 12 * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(dr); (void)hipFree(dM); (void)hipFree(dn); (void)hipFree(dJ); (void)hipFree(dd);
+  return HB_OK;
+}
+
+int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, int32_t nu, const double* A, const double* Bm, const double* bv,
+                         const double* Q, const double* R, const double* P, const double* q, const double* r,
+                         const double* dx0, double* dx, double* du) {
+  if (!ctx || n <= 0 || N <= 0 || nu <= 0 || nu > NU_T || n > ctx->B || N > ctx->Nmax) return HB_ERR_ARG;
+  // pack stage data into node records on the host, run the same kernels the MPC uses
+  const size_t Nm = ctx->Nmax;
+  std::vector<double> recs(size_t(n) * Nm * REC_SIZE, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < N; ++k) {
+      double* rec = recs.data() + (size_t(i) * Nm + k) * REC_SIZE;
+      const size_t sk = size_t(i) * N + k;
+      std::memcpy(rec + REC_AT, A + sk * 484, 484 * 8);
+      std::memcpy(rec + REC_QT, Q + sk * 484, 484 * 8);
+      std::memcpy(rec + REC_bT, bv + sk * 22, 22 * 8);
+      std::memcpy(rec + REC_qT, q + sk * 22, 22 * 8);
+      for (int row = 0; row < 22; ++row)
+        for (int c = 0; c < nu; ++c) rec[REC_BT + row * NU_T + c] = Bm[(sk * 22 + row) * nu + c];
+      for (int a = 0; a < NU_T; ++a) {
+        for (int c = 0; c < NU_T; ++c)
+          rec[REC_RT + a * NU_T + c] = (a < nu && c < nu) ? R[(sk * nu + a) * nu + c] : (a == c ? 1.0 : 0.0);
+        if (a < nu) {
+          std::memcpy(rec + REC_PT + a * 22, P + (sk * nu + a) * 22, 22 * 8);
+          rec[REC_rT + a] = r[sk * nu + a];
+        }
+      }
+      rec[REC_META + 0] = 0.0;  // forward pass: treat all inputs as "kernel" columns is not needed here
+    }
+  // The forward kernel reconstructs du through the projection data; for this unit entry point the reduced input
+  // is returned directly, so run backward on the device and the (cheap) forward recursion on the host.
+  HB_HIP(hipSetDevice(ctx->device));
+  std::vector<int> nn(ctx->B, 1);
+  for (int i = 0; i < n; ++i) nn[i] = N;
+  HB_HIP(hipMemcpy(ctx->b.n_nodes, nn.data(), size_t(ctx->B) * sizeof(int), hipMemcpyHostToDevice));
+  HB_HIP(hipMemcpy(ctx->b.recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_ric_bwd, dim3(n), dim3(64), 0, ctx->s_mpc, ctx->b);
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  std::vector<double> gains(size_t(n) * Nm * GAIN_SIZE);
+  HB_HIP(hipMemcpy(gains.data(), ctx->b.gains, gains.size() * 8, hipMemcpyDeviceToHost));
+  ctx->refs_set = false;  // the batch buffers were clobbered
+  for (int i = 0; i < n; ++i) {
+    double xk[22];
+    std::memcpy(xk, dx0 + size_t(i) * 22, 22 * 8);
+    for (int k = 0; k < N; ++k) {
+      const double* g = gains.data() + (size_t(i) * Nm + k) * GAIN_SIZE;
+      const size_t sk = size_t(i) * N + k;
+      std::memcpy(dx + (size_t(i) * (N + 1) + k) * 22, xk, 22 * 8);
+      double ut[NU_T];
+      for (int a = 0; a < nu; ++a) {
+        double s = g[264 + a];
+        for (int c = 0; c < 22; ++c) s += g[a * 22 + c] * xk[c];
+        ut[a] = s;
+        du[sk * nu + a] = s;
+      }
+      double xn[22];
+      for (int row = 0; row < 22; ++row) {
+        double s = bv[sk * 22 + row];
+        for (int c = 0; c < 22; ++c) s += A[(sk * 22 + row) * 22 + c] * xk[c];
+        for (int a = 0; a < nu; ++a) s += Bm[(sk * 22 + row) * nu + a] * ut[a];
+        xn[row] = s;
+      }
+      std::memcpy(xk, xn, 22 * 8);
+    }
+    std::memcpy(dx + (size_t(i) * (N + 1) + N) * 22, xk, 22 * 8);
+  }
+  return HB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,522 @@
+// LQ approximation of one shooting node, executed by one 64-lane workgroup (one wavefront) with its working
+// set in LDS.  Produces the PROJECTED stage data the Riccati kernels consume plus what is needed to recover the
+// full input step and to run the line search.
+//
+//   phase 1  lane l (< 44) carries d/d(x,u)_l through the whole RK2 step with a one-tangent dual number, so
+//            column l of [A_k | B_k] and of every foot-constraint row falls out without forming the four
+//            continuous-time Jacobians (OCS2 RK2 sensitivity).
+//   phase 2  projection of the state-input equality constraints.  Their input Jacobian is block structured:
+//            zero-force rows select contact-force inputs, velocity rows touch the 10 joint velocities only,
+//            so only G (r x 10, r <= 12, rank deficient because both contact points of a foot sit on one rigid
+//            link) is factorised: diagonally pivoted Cholesky of G'G gives a basic least-squares solution and
+//            a kernel basis (DESIGN.md "constraint projection"; OCS2 luConstraintProjection role).
+//   phase 3/4 change of input variables for dynamics and cost (OCS2 changeOfInputVariables), using the block
+//            structure (R = blkdiag(R_FF, R_jj), P only on joint rows).
+// Reference terms: legged_interface/src/LeggedInterface.cpp:102-161,263-357,433-447;
+// LeggedRobotPreComputation.cpp:96-119; FrictionConeConstraint.cpp:70-233; utils.h:75-93.
+#pragma once
+#include "hb_model.hpp"
+
+namespace hb {
+
+struct DevConfig {
+  double Q_diag[HB_NX];
+  double R_FF_diag[12];
+  double R_jj[HB_NJ * HB_NJ];
+  double friction_mu, friction_reg, friction_gripper, friction_shift, fb_mu, fb_delta;
+  double soft_w;
+  double pos_b[2], vel_b[2], force_b[2], force_lim[2];
+  double kp_normal, zv_gain, zv_off, xy_gain;
+  double g_max, g_min, alpha_decay, alpha_min, gamma_c, armijo;
+  // WBC
+  double torque_limits[5];
+  double wbc_mu, swing_kp, swing_kd, bh_kp, bh_kd, ba_kp, ba_kd, w_swing, w_base, w_force, wbc_eps;
+  int wbc_max_iter, wbc_type;
+  double default_joint_state[HB_NJ];
+};
+
+// ---- node record layout in HBM (doubles) ------------------------------------------------------------
+constexpr int NU_T = 12;                 // projected input width (padded)
+constexpr int REC_AT = 0;                // 22x22
+constexpr int REC_BT = 484;              // 22x12
+constexpr int REC_bT = 748;              // 22
+constexpr int REC_QT = 770;              // 22x22
+constexpr int REC_PT = 1254;             // 12x22
+constexpr int REC_RT = 1518;             // 12x12
+constexpr int REC_qT = 1662;             // 22
+constexpr int REC_rT = 1684;             // 12
+constexpr int REC_RICCATI_END = 1696;
+constexpr int REC_KX = 1696;             // 10x22
+constexpr int REC_KE = 1916;             // 10
+constexpr int REC_Z = 1926;              // 10x6
+constexpr int REC_DF = 1986;             // 12: constant part of dF (= -F on swing feet)
+constexpr int REC_QF = 1998;             // 22 unprojected cost gradient wrt x (x dt)
+constexpr int REC_RF = 2020;             // 22 unprojected cost gradient wrt u (x dt)
+constexpr int REC_META = 2042;           // nf, nz, mode, cost*dt, dyn_sse*dt, eq_sse*dt
+constexpr int REC_SIZE = 2048;
+constexpr int GAIN_SIZE = 288;           // K~ 12x22 (264) + k~ 12 + pad
+
+struct RelaxedBarrierD {
+  double mu, delta;
+  HB_HD double value(double h) const {
+    if (h > delta) return -mu * log(h);
+    const double z = (h - 2.0 * delta) / delta;
+    return mu * (-log(delta) + 0.5 * z * z - 0.5);
+  }
+  HB_HD double d1(double h) const { return h > delta ? -mu / h : mu * (h - 2.0 * delta) / (delta * delta); }
+  HB_HD double d2(double h) const { return h > delta ? mu / (h * h) : mu / (delta * delta); }
+};
+
+// LDS carve (doubles)
+struct LqLds {
+  static constexpr int ABt = 0;              // [44][22]
+  static constexpr int CDt = ABt + 968;      // [44][12]
+  static constexpr int xplus = CDt + 528;    // 22
+  static constexpr int rowval = xplus + 22;  // 12
+  static constexpr int GtG = rowval + 12;    // 10x10 (becomes L)
+  static constexpr int W = GtG + 100;        // 10x23 (G'C | G'e), then reused
+  static constexpr int Kx = W + 230;         // 10x23 (Kx | ke)
+  static constexpr int Z = Kx + 230;         // 10x6
+  static constexpr int Pj = Z + 60;          // 10x22
+  static constexpr int Rjj = Pj + 220;       // 10x10
+  static constexpr int Mm = Rjj + 100;       // 10x22
+  static constexpr int RFF = Mm + 220;       // 4 blocks 3x3
+  static constexpr int qx = RFF + 36;        // 22 (continuous-time gradient wrt x)
+  static constexpr int ru = qx + 22;         // 22 (wrt u)
+  static constexpr int Qd = ru + 22;         // 22 diagonal of Q incl. barriers/shift
+  static constexpr int scal = Qd + 22;       // 16 scalars (cost, sums, ...)
+  static constexpr int ints = scal + 16;     // 32 ints packed in 16 doubles: perm[10], rank, eq slots...
+  static constexpr int total = ints + 16;
+};
+
+struct NodeIn {
+  const double* x;      // 22
+  const double* u;      // 22
+  const double* xnext;  // 22
+  const double* xref;   // 22
+  const double* swing;  // 24
+  double dt;
+  int mode;
+};
+
+template <class Ctx>
+HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const NodeIn& in, double* lds, double* rec) {
+  double* ABt = lds + LqLds::ABt;
+  double* CDt = lds + LqLds::CDt;
+  double* xplus = lds + LqLds::xplus;
+  double* rowval = lds + LqLds::rowval;
+  double* GtG = lds + LqLds::GtG;
+  double* W = lds + LqLds::W;
+  double* Kx = lds + LqLds::Kx;
+  double* Z = lds + LqLds::Z;
+  double* Pj = lds + LqLds::Pj;
+  double* Rjj = lds + LqLds::Rjj;
+  double* Mm = lds + LqLds::Mm;
+  double* RFF = lds + LqLds::RFF;
+  double* qx = lds + LqLds::qx;
+  double* ru = lds + LqLds::ru;
+  double* Qd = lds + LqLds::Qd;
+  double* scal = lds + LqLds::scal;
+  int* ints = reinterpret_cast<int*>(lds + LqLds::ints);
+  int* perm = ints;          // [10]
+  int* eqs = ints + 12;      // [12] eq slot list
+  int* softs = ints + 24;    // [8] soft slot list
+
+  const double dt = in.dt;
+  bool cf[HB_NC];
+  mode_flags(in.mode, cf);
+
+  // -------------------------------------------------------------- phase 1: dual pass per direction
+  for (int dir = cx.lane; dir < 44; dir += cx.nlanes) {
+    Dual1 xd[HB_NX], ud[HB_NU], f1[HB_NX], f2[HB_NX];
+#pragma unroll
+    for (int i = 0; i < HB_NX; ++i) {
+      xd[i] = Dual1(in.x[i], dir == i ? 1.0 : 0.0);
+      ud[i] = Dual1(in.u[i], dir == HB_NX + i ? 1.0 : 0.0);
+    }
+    Centroidal<Dual1> c1;
+    flow_map<Dual1>(M, xd, ud, f1, &c1);
+    // constraint rows: slot 3i+a
+#pragma unroll
+    for (int i = 0; i < HB_NC; ++i) {
+      const Dual1 pz = xd[8] + c1.foot_rel[i].z;
+      const Dual1 px = xd[6] + c1.foot_rel[i].x, py = xd[7] + c1.foot_rel[i].y;
+      Dual1 r0, r1, r2;
+      if (cf[i]) {  // zero velocity (LeggedInterface.cpp:436-444)
+        r0 = c1.foot_vel[i].x;
+        r1 = c1.foot_vel[i].y;
+        r2 = c1.foot_vel[i].z + C.zv_gain * pz + C.zv_off;
+      } else {      // normal velocity + xy soft reference (LeggedRobotPreComputation.cpp:96-117)
+        const double* sw = in.swing + 6 * i;
+        r0 = c1.foot_vel[i].z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
+        r1 = C.xy_gain * px + c1.foot_vel[i].x - (sw[3] + C.xy_gain * sw[0]);
+        r2 = C.xy_gain * py + c1.foot_vel[i].y - (sw[4] + C.xy_gain * sw[1]);
+      }
+      CDt[dir * 12 + 3 * i + 0] = r0.d;
+      CDt[dir * 12 + 3 * i + 1] = r1.d;
+      CDt[dir * 12 + 3 * i + 2] = r2.d;
+      if (dir == 0) {
+        rowval[3 * i + 0] = r0.v;
+        rowval[3 * i + 1] = r1.v;
+        rowval[3 * i + 2] = r2.v;
+      }
+    }
+    Dual1 xm[HB_NX];
+#pragma unroll
+    for (int i = 0; i < HB_NX; ++i) xm[i] = xd[i] + dt * f1[i];
+    flow_map<Dual1>(M, xm, ud, f2);
+#pragma unroll
+    for (int i = 0; i < HB_NX; ++i) {
+      const Dual1 xp = xd[i] + (0.5 * dt) * (f1[i] + f2[i]);
+      ABt[dir * 22 + i] = xp.d;
+      if (dir == 0) xplus[i] = xp.v;
+    }
+  }
+  // slot classification (uniform)
+  int n_eq = 0, n_soft = 0, n_f = 0;
+  for (int i = 0; i < HB_NC; ++i) {
+    if (cf[i]) {
+      n_f += 3;
+      if (cx.lane == 0) { eqs[n_eq] = 3 * i; eqs[n_eq + 1] = 3 * i + 1; eqs[n_eq + 2] = 3 * i + 2; }
+      n_eq += 3;
+    } else {
+      if (cx.lane == 0) { eqs[n_eq] = 3 * i; softs[n_soft] = 3 * i + 1; softs[n_soft + 1] = 3 * i + 2; }
+      n_eq += 1;
+      n_soft += 2;
+    }
+  }
+  cx.sync();
+
+  // -------------------------------------------------------------- phase 2: G'G, G'[C e], pivoted Cholesky
+  // joint-velocity directions are 34..43
+  for (int idx = cx.lane; idx < 100; idx += cx.nlanes) {
+    const int k = idx / 10, l = idx % 10;
+    double s = 0;
+    for (int a = 0; a < n_eq; ++a) s += CDt[(34 + k) * 12 + eqs[a]] * CDt[(34 + l) * 12 + eqs[a]];
+    GtG[idx] = s;
+  }
+  for (int idx = cx.lane; idx < 230; idx += cx.nlanes) {
+    const int k = idx / 23, c = idx % 23;
+    double s = 0;
+    if (c < 22) {
+      for (int a = 0; a < n_eq; ++a) s += CDt[(34 + k) * 12 + eqs[a]] * CDt[c * 12 + eqs[a]];
+    } else {
+      for (int a = 0; a < n_eq; ++a) s += CDt[(34 + k) * 12 + eqs[a]] * rowval[eqs[a]];
+    }
+    W[idx] = s;
+  }
+  cx.sync();
+  if (cx.lane == 0) {
+    // diagonally pivoted Cholesky, in place in GtG (lower triangle, permuted ordering)
+    for (int i = 0; i < 10; ++i) perm[i] = i;
+    double dmax0 = 0;
+    for (int i = 0; i < 10; ++i) dmax0 = fmax(dmax0, GtG[i * 10 + i]);
+    const double tol = 1e-10 * dmax0;
+    int rank = 0;
+    for (int s = 0; s < 10; ++s) {
+      int pv = s;
+      double best = GtG[perm[s] * 10 + perm[s]];
+      for (int i = s + 1; i < 10; ++i) {
+        const double d = GtG[perm[i] * 10 + perm[i]];
+        if (d > best) { best = d; pv = i; }
+      }
+      if (!(best > tol)) break;
+      const int tmp = perm[s]; perm[s] = perm[pv]; perm[pv] = tmp;
+      const int ps = perm[s];
+      const double lss = sqrt(best);
+      // L(i,s) is stored at the symmetric position GtG[perm[i]*10 + perm[s]] (original indices), so later
+      // pivot swaps never move data.
+      GtG[ps * 10 + ps] = lss;
+      for (int i = s + 1; i < 10; ++i) {
+        const int pi = perm[i];
+        const double lis = GtG[pi * 10 + ps] / lss;
+        GtG[pi * 10 + ps] = lis;
+      }
+      // Schur update of the trailing block (both triangles kept symmetric)
+      for (int i = s + 1; i < 10; ++i) {
+        const int pi = perm[i];
+        const double lis = GtG[pi * 10 + ps];
+        for (int j = s + 1; j < 10; ++j) {
+          const int pj = perm[j];
+          GtG[pi * 10 + pj] -= lis * GtG[pj * 10 + ps];
+        }
+      }
+      rank = s + 1;
+    }
+    ints[10] = rank;
+  }
+  cx.sync();
+  const int rank = ints[10];
+  const int nz = 10 - rank;
+  // L(i,s) = GtG[perm[i]*10 + perm[s]] for i >= s.
+  // Solve A11 Y = -W1 (23 right-hand sides, one per lane), scatter into Kx rows perm[a].
+  for (int c = cx.lane; c < 23; c += cx.nlanes) {
+    double y[10];
+    for (int a = 0; a < rank; ++a) {
+      double s = -W[perm[a] * 23 + c];
+      for (int t = 0; t < a; ++t) s -= GtG[perm[a] * 10 + perm[t]] * y[t];
+      y[a] = s / GtG[perm[a] * 10 + perm[a]];
+    }
+    for (int a = rank - 1; a >= 0; --a) {
+      double s = y[a];
+      for (int t = a + 1; t < rank; ++t) s -= GtG[perm[t] * 10 + perm[a]] * y[t];
+      y[a] = s / GtG[perm[a] * 10 + perm[a]];
+    }
+    for (int a = 0; a < rank; ++a) Kx[perm[a] * 23 + c] = y[a];
+    for (int a = rank; a < 10; ++a) Kx[perm[a] * 23 + c] = 0.0;
+  }
+  // kernel basis: column b <-> free index perm[rank + b]:  z = e_free - P1 L11^-T L21[b]^T
+  for (int b = cx.lane; b < 6; b += cx.nlanes) {
+    if (b < nz) {
+      double y[10];
+      const int pf = perm[rank + b];
+      for (int a = rank - 1; a >= 0; --a) {
+        double s = GtG[pf * 10 + perm[a]];  // L21(b, a)
+        for (int t = a + 1; t < rank; ++t) s -= GtG[perm[t] * 10 + perm[a]] * y[t];
+        y[a] = s / GtG[perm[a] * 10 + perm[a]];
+      }
+      for (int k = 0; k < 10; ++k) Z[k * 6 + b] = 0.0;
+      for (int a = 0; a < rank; ++a) Z[perm[a] * 6 + b] = -y[a];
+      Z[pf * 6 + b] = 1.0;
+    } else {
+      for (int k = 0; k < 10; ++k) Z[k * 6 + b] = 0.0;
+    }
+  }
+
+  // -------------------------------------------------------------- phase 4a: cost pieces (lane 0: scalars/diagonals)
+  if (cx.lane == 0) {
+    double cost = 0;
+    double unom[12];
+    for (int i = 0; i < 12; ++i) unom[i] = 0;
+    int nc = 0;
+    for (int i = 0; i < HB_NC; ++i) nc += cf[i];
+    for (int i = 0; i < HB_NC; ++i)
+      if (cf[i]) unom[3 * i + 2] = M.total_mass * M.gravity / nc;
+    for (int i = 0; i < HB_NX; ++i) {
+      const double dx = in.x[i] - in.xref[i];
+      Qd[i] = C.Q_diag[i];
+      qx[i] = C.Q_diag[i] * dx;
+      cost += 0.5 * C.Q_diag[i] * dx * dx;
+    }
+    for (int i = 0; i < 12; ++i) {
+      const double du = in.u[i] - unom[i];
+      ru[i] = C.R_FF_diag[i] * du;
+      cost += 0.5 * C.R_FF_diag[i] * du * du;
+    }
+    for (int k = 0; k < HB_NJ; ++k) {
+      double s = 0;
+      for (int l = 0; l < HB_NJ; ++l) s += C.R_jj[k * 10 + l] * in.u[12 + l];
+      ru[12 + k] = s;
+      cost += 0.5 * in.u[12 + k] * s;
+    }
+    for (int i = 0; i < 36; ++i) RFF[i] = 0.0;
+    for (int i = 0; i < HB_NC; ++i)
+      for (int a = 0; a < 3; ++a) RFF[9 * i + 4 * a] = C.R_FF_diag[3 * i + a];
+    double shift_sum = 0;  // sum over contact feet of -p1 * shift, added to every Q and R diagonal entry
+    const RelaxedBarrierD fb{C.fb_mu, C.fb_delta};
+    for (int i = 0; i < HB_NC; ++i) {
+      if (!cf[i]) continue;
+      const double Fx = in.u[3 * i], Fy = in.u[3 * i + 1], Fz = in.u[3 * i + 2];
+      const double t2 = Fx * Fx + Fy * Fy + C.friction_reg, tn = sqrt(t2), t32 = tn * t2;
+      const double h = C.friction_mu * (Fz + C.friction_gripper) - tn;
+      const double g[3] = {-Fx / tn, -Fy / tn, C.friction_mu};
+      const double H00 = -(Fy * Fy + C.friction_reg) / t32, H01 = Fx * Fy / t32, H11 = -(Fx * Fx + C.friction_reg) / t32;
+      const double p1 = fb.d1(h), p2 = fb.d2(h);
+      cost += fb.value(h);
+      for (int a = 0; a < 3; ++a) {
+        ru[3 * i + a] += p1 * g[a];
+        for (int b = 0; b < 3; ++b) RFF[9 * i + 3 * a + b] += p2 * g[a] * g[b];
+      }
+      RFF[9 * i + 0] += p1 * H00; RFF[9 * i + 1] += p1 * H01; RFF[9 * i + 3] += p1 * H01; RFF[9 * i + 4] += p1 * H11;
+      shift_sum += -p1 * C.friction_shift;
+    }
+    for (int i = 0; i < HB_NX; ++i) Qd[i] += shift_sum;
+    for (int i = 0; i < HB_NC; ++i)
+      for (int a = 0; a < 3; ++a) RFF[9 * i + 4 * a] += shift_sum;
+    // limits (LeggedInterface.cpp:317-357)
+    const RelaxedBarrierD bp{C.pos_b[0], C.pos_b[1]}, bv{C.vel_b[0], C.vel_b[1]}, bf{C.force_b[0], C.force_b[1]};
+    for (int j = 0; j < HB_NJ; ++j) {
+      const double h = in.x[12 + j];
+      cost += bp.value(h - M.q_lower[j]) + bp.value(M.q_upper[j] - h);
+      qx[12 + j] += bp.d1(h - M.q_lower[j]) - bp.d1(M.q_upper[j] - h);
+      Qd[12 + j] += bp.d2(h - M.q_lower[j]) + bp.d2(M.q_upper[j] - h);
+      const double hv = in.u[12 + j], vl = M.qd_limit[j];
+      cost += bv.value(hv + vl) + bv.value(vl - hv);
+      ru[12 + j] += bv.d1(hv + vl) - bv.d1(vl - hv);
+      scal[4 + j] = bv.d2(hv + vl) + bv.d2(vl - hv) + shift_sum;  // joint diagonal additions to R_jj
+    }
+    for (int i = 0; i < HB_NC; ++i) {
+      const double h = in.u[3 * i + 2];
+      cost += bf.value(h - C.force_lim[0]) + bf.value(C.force_lim[1] - h);
+      ru[3 * i + 2] += bf.d1(h - C.force_lim[0]) - bf.d1(C.force_lim[1] - h);
+      RFF[9 * i + 8] += bf.d2(h - C.force_lim[0]) + bf.d2(C.force_lim[1] - h);
+    }
+    for (int s = 0; s < n_soft; ++s) cost += 0.5 * C.soft_w * rowval[softs[s]] * rowval[softs[s]];
+    scal[0] = cost;
+    // violation sums
+    double dyn = 0, eq = 0;
+    for (int i = 0; i < HB_NX; ++i) {
+      const double d = xplus[i] - in.xnext[i];
+      dyn += d * d;
+    }
+    for (int a = 0; a < n_eq; ++a) eq += rowval[eqs[a]] * rowval[eqs[a]];
+    for (int i = 0; i < HB_NC; ++i)
+      if (!cf[i])
+        for (int a = 0; a < 3; ++a) eq += in.u[3 * i + a] * in.u[3 * i + a];
+    scal[1] = dyn;
+    scal[2] = eq;
+  }
+  cx.sync();
+  // soft rows: gradients and the dense pieces P_j, R_jj
+  for (int c = cx.lane; c < 22; c += cx.nlanes) {
+    double s = 0;
+    for (int t = 0; t < n_soft; ++t) s += rowval[softs[t]] * CDt[c * 12 + softs[t]];
+    qx[c] += C.soft_w * s;
+  }
+  for (int k = cx.lane; k < 10; k += cx.nlanes) {
+    double s = 0;
+    for (int t = 0; t < n_soft; ++t) s += rowval[softs[t]] * CDt[(34 + k) * 12 + softs[t]];
+    ru[12 + k] += C.soft_w * s;
+  }
+  for (int idx = cx.lane; idx < 220; idx += cx.nlanes) {
+    const int k = idx / 22, c = idx % 22;
+    double s = 0;
+    for (int t = 0; t < n_soft; ++t) s += CDt[(34 + k) * 12 + softs[t]] * CDt[c * 12 + softs[t]];
+    Pj[idx] = C.soft_w * s;
+  }
+  for (int idx = cx.lane; idx < 100; idx += cx.nlanes) {
+    const int k = idx / 10, l = idx % 10;
+    double s = 0;
+    for (int t = 0; t < n_soft; ++t) s += CDt[(34 + k) * 12 + softs[t]] * CDt[(34 + l) * 12 + softs[t]];
+    Rjj[idx] = C.R_jj[idx] + C.soft_w * s + (k == l ? scal[4 + k] : 0.0);
+  }
+  cx.sync();
+  // M = P_j + R_jj Kx  (10x22),  and the vector R_jj ke + r_j -> W column reuse (10)
+  for (int idx = cx.lane; idx < 220; idx += cx.nlanes) {
+    const int k = idx / 22, c = idx % 22;
+    double s = Pj[idx];
+    for (int l = 0; l < 10; ++l) s += Rjj[k * 10 + l] * Kx[l * 23 + c];
+    Mm[idx] = s;
+  }
+  for (int k = cx.lane; k < 10; k += cx.nlanes) {
+    double s = ru[12 + k];
+    for (int l = 0; l < 10; ++l) s += Rjj[k * 10 + l] * Kx[l * 23 + 22];
+    W[k] = s;  // r_j + R_jj ke
+  }
+  cx.sync();
+
+  // -------------------------------------------------------------- phase 3+4b: write the projected record
+  const int ntil = n_f + nz;
+  // A~ = A + B_j Kx
+  for (int idx = cx.lane; idx < 484; idx += cx.nlanes) {
+    const int row = idx / 22, c = idx % 22;
+    double s = ABt[c * 22 + row];
+    for (int k = 0; k < 10; ++k) s += ABt[(34 + k) * 22 + row] * Kx[k * 23 + c];
+    rec[REC_AT + idx] = s;
+  }
+  // B~ columns: contact forces (foot order) then kernel directions, zero padded
+  for (int idx = cx.lane; idx < 22 * NU_T; idx += cx.nlanes) {
+    const int row = idx / NU_T, col = idx % NU_T;
+    double s = 0.0;
+    if (col < n_f) {
+      // map col -> force index of the (col/3)-th contact foot
+      int foot = -1, cnt = 0;
+      for (int i = 0; i < HB_NC; ++i)
+        if (cf[i]) { if (cnt == col / 3) foot = i; ++cnt; }
+      s = ABt[(22 + 3 * foot + col % 3) * 22 + row];
+    } else if (col < ntil) {
+      const int b = col - n_f;
+      for (int k = 0; k < 10; ++k) s += ABt[(34 + k) * 22 + row] * Z[k * 6 + b];
+    }
+    rec[REC_BT + idx] = s;
+  }
+  for (int row = cx.lane; row < 22; row += cx.nlanes) {
+    double s = xplus[row] - in.xnext[row];
+    for (int k = 0; k < 10; ++k) s += ABt[(34 + k) * 22 + row] * Kx[k * 23 + 22];
+    for (int i = 0; i < HB_NC; ++i)
+      if (!cf[i])
+        for (int a = 0; a < 3; ++a) s -= ABt[(22 + 3 * i + a) * 22 + row] * in.u[3 * i + a];
+    rec[REC_bT + row] = s;
+  }
+  // Q~ = Q + Kx' M + P_j' Kx ,  Q = diag(Qd) + w sum_soft c c'
+  for (int idx = cx.lane; idx < 484; idx += cx.nlanes) {
+    const int a = idx / 22, b = idx % 22;
+    double s = (a == b) ? Qd[a] : 0.0;
+    double ss = 0;
+    for (int t = 0; t < n_soft; ++t) ss += CDt[a * 12 + softs[t]] * CDt[b * 12 + softs[t]];
+    s += C.soft_w * ss;
+    for (int k = 0; k < 10; ++k) s += Kx[k * 23 + a] * Mm[k * 22 + b] + Pj[k * 22 + a] * Kx[k * 23 + b];
+    rec[REC_QT + idx] = dt * s;
+  }
+  // q~ = q + Kx' r_j + M' ke
+  for (int a = cx.lane; a < 22; a += cx.nlanes) {
+    double s = qx[a];
+    for (int k = 0; k < 10; ++k) s += Kx[k * 23 + a] * ru[12 + k] + Mm[k * 22 + a] * Kx[k * 23 + 22];
+    rec[REC_qT + a] = dt * s;
+    rec[REC_QF + a] = dt * qx[a];
+    rec[REC_RF + a] = dt * ru[a];
+  }
+  // P~ (12x22): force rows zero, kernel rows Z' M
+  for (int idx = cx.lane; idx < NU_T * 22; idx += cx.nlanes) {
+    const int col = idx / 22, c = idx % 22;
+    double s = 0.0;
+    if (col >= n_f && col < ntil) {
+      const int b = col - n_f;
+      for (int k = 0; k < 10; ++k) s += Z[k * 6 + b] * Mm[k * 22 + c];
+    }
+    rec[REC_PT + idx] = dt * s;
+  }
+  // R~ (12x12): contact-force blocks, Z' R_jj Z, identity on the padding
+  for (int idx = cx.lane; idx < NU_T * NU_T; idx += cx.nlanes) {
+    const int ca = idx / NU_T, cb = idx % NU_T;
+    double s = 0.0;
+    bool pad_diag = false;
+    if (ca < n_f && cb < n_f) {
+      if (ca / 3 == cb / 3) {
+        int foot = -1, cnt = 0;
+        for (int i = 0; i < HB_NC; ++i)
+          if (cf[i]) { if (cnt == ca / 3) foot = i; ++cnt; }
+        s = RFF[9 * foot + 3 * (ca % 3) + (cb % 3)];
+      }
+    } else if (ca >= n_f && ca < ntil && cb >= n_f && cb < ntil) {
+      const int ba = ca - n_f, bb = cb - n_f;
+      for (int k = 0; k < 10; ++k) {
+        double t = 0;
+        for (int l = 0; l < 10; ++l) t += Rjj[k * 10 + l] * Z[l * 6 + bb];
+        s += Z[k * 6 + ba] * t;
+      }
+    } else if (ca >= ntil && ca == cb) {
+      pad_diag = true;
+    }
+    rec[REC_RT + idx] = pad_diag ? 1.0 : dt * s;
+  }
+  // r~
+  for (int col = cx.lane; col < NU_T; col += cx.nlanes) {
+    double s = 0.0;
+    if (col < n_f) {
+      int foot = -1, cnt = 0;
+      for (int i = 0; i < HB_NC; ++i)
+        if (cf[i]) { if (cnt == col / 3) foot = i; ++cnt; }
+      s = ru[3 * foot + col % 3];
+    } else if (col < ntil) {
+      const int b = col - n_f;
+      for (int k = 0; k < 10; ++k) s += Z[k * 6 + b] * W[k];
+    }
+    rec[REC_rT + col] = dt * s;
+  }
+  // recovery data
+  for (int idx = cx.lane; idx < 220; idx += cx.nlanes) rec[REC_KX + idx] = Kx[(idx / 22) * 23 + idx % 22];
+  for (int k = cx.lane; k < 10; k += cx.nlanes) rec[REC_KE + k] = Kx[k * 23 + 22];
+  for (int idx = cx.lane; idx < 60; idx += cx.nlanes) rec[REC_Z + idx] = Z[idx];
+  for (int i = cx.lane; i < 12; i += cx.nlanes) rec[REC_DF + i] = cf[i / 3] ? 0.0 : -in.u[i];
+  if (cx.lane == 0) {
+    rec[REC_META + 0] = double(n_f);
+    rec[REC_META + 1] = double(nz);
+    rec[REC_META + 2] = double(in.mode);
+    rec[REC_META + 3] = dt * scal[0];
+    rec[REC_META + 4] = dt * scal[1];
+    rec[REC_META + 5] = dt * scal[2];
+  }
+}
+
+}  // namespace hb

@@ -1,0 +1,164 @@
+// Small fixed-size math used by every kernel: 3-vectors, 3x3 matrices, symmetric 3x3 and a one-tangent
+// dual number.  Everything is register-resident and fully unrolled; compiled for gfx950 by hipcc and, for the
+// host-side logic checks in tests/host_emu, by g++ (HB_HD collapses to `inline`).
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HB_HD __host__ __device__ __forceinline__
+#else
+#define HB_HD inline
+#endif
+
+namespace hb {
+
+// value + one tangent: lane l of the LQ kernel carries d/d(direction l)
+struct Dual1 {
+  double v, d;
+  HB_HD Dual1() : v(0.0), d(0.0) {}
+  HB_HD Dual1(double a) : v(a), d(0.0) {}  // NOLINT
+  HB_HD Dual1(double a, double b) : v(a), d(b) {}
+};
+HB_HD Dual1 operator+(Dual1 a, Dual1 b) { return {a.v + b.v, a.d + b.d}; }
+HB_HD Dual1 operator-(Dual1 a, Dual1 b) { return {a.v - b.v, a.d - b.d}; }
+HB_HD Dual1 operator-(Dual1 a) { return {-a.v, -a.d}; }
+HB_HD Dual1 operator*(Dual1 a, Dual1 b) { return {a.v * b.v, fma(a.v, b.d, a.d * b.v)}; }
+HB_HD Dual1 operator/(Dual1 a, Dual1 b) {
+  const double inv = 1.0 / b.v, q = a.v * inv;
+  return {q, (a.d - q * b.d) * inv};
+}
+HB_HD Dual1 operator*(double a, Dual1 b) { return {a * b.v, a * b.d}; }
+HB_HD Dual1 operator*(Dual1 b, double a) { return {a * b.v, a * b.d}; }
+HB_HD Dual1 operator+(Dual1 a, double b) { return {a.v + b, a.d}; }
+HB_HD Dual1 operator-(Dual1 a, double b) { return {a.v - b, a.d}; }
+HB_HD Dual1 operator-(double a, Dual1 b) { return {a - b.v, -b.d}; }
+HB_HD Dual1& operator+=(Dual1& a, Dual1 b) { a.v += b.v; a.d += b.d; return a; }
+HB_HD Dual1& operator-=(Dual1& a, Dual1 b) { a.v -= b.v; a.d -= b.d; return a; }
+HB_HD void sincos_t(double a, double& s, double& c) { s = sin(a); c = cos(a); }
+HB_HD void sincos_t(Dual1 a, Dual1& s, Dual1& c) {
+  const double sv = sin(a.v), cv = cos(a.v);
+  s = {sv, cv * a.d};
+  c = {cv, -sv * a.d};
+}
+HB_HD double sqrt_t(double a) { return sqrt(a); }
+HB_HD Dual1 sqrt_t(Dual1 a) {
+  const double r = sqrt(a.v);
+  return {r, 0.5 * a.d / r};
+}
+HB_HD double val(double a) { return a; }
+HB_HD double val(Dual1 a) { return a.v; }
+HB_HD double tan1(double) { return 0.0; }
+HB_HD double tan1(Dual1 a) { return a.d; }
+
+template <class T>
+struct Vec3 {
+  T x, y, z;
+  HB_HD Vec3() : x(0.0), y(0.0), z(0.0) {}
+  HB_HD Vec3(T a, T b, T c) : x(a), y(b), z(c) {}
+};
+template <class T> HB_HD Vec3<T> operator+(Vec3<T> a, Vec3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class T> HB_HD Vec3<T> operator-(Vec3<T> a, Vec3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T> HB_HD Vec3<T> operator*(T s, Vec3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <class T> HB_HD Vec3<T> cross(Vec3<T> a, Vec3<T> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <class T> HB_HD T dot(Vec3<T> a, Vec3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> HB_HD T comp(const Vec3<T>& a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+template <class T>
+struct Mat3 {  // row-major
+  T m[9];
+  HB_HD Mat3() {
+    for (int i = 0; i < 9; ++i) m[i] = T(0.0);
+  }
+  HB_HD static Mat3 identity() {
+    Mat3 r;
+    r.m[0] = r.m[4] = r.m[8] = T(1.0);
+    return r;
+  }
+};
+template <class T> HB_HD Mat3<T> operator*(const Mat3<T>& a, const Mat3<T>& b) {
+  Mat3<T> r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+  return r;
+}
+template <class T> HB_HD Vec3<T> operator*(const Mat3<T>& a, Vec3<T> v) {
+  return {a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z,
+          a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z};
+}
+template <class T> HB_HD Vec3<T> tmul(const Mat3<T>& a, Vec3<T> v) {  // a^T v
+  return {a.m[0] * v.x + a.m[3] * v.y + a.m[6] * v.z, a.m[1] * v.x + a.m[4] * v.y + a.m[7] * v.z,
+          a.m[2] * v.x + a.m[5] * v.y + a.m[8] * v.z};
+}
+
+// symmetric 3x3: xx xy xz yy yz zz
+template <class T>
+struct Sym3 {
+  T xx, xy, xz, yy, yz, zz;
+  HB_HD Sym3() : xx(0.0), xy(0.0), xz(0.0), yy(0.0), yz(0.0), zz(0.0) {}
+};
+template <class T> HB_HD Sym3<T> operator+(Sym3<T> a, Sym3<T> b) {
+  Sym3<T> r;
+  r.xx = a.xx + b.xx; r.xy = a.xy + b.xy; r.xz = a.xz + b.xz; r.yy = a.yy + b.yy; r.yz = a.yz + b.yz; r.zz = a.zz + b.zz;
+  return r;
+}
+template <class T> HB_HD Vec3<T> operator*(const Sym3<T>& s, Vec3<T> v) {
+  return {s.xx * v.x + s.xy * v.y + s.xz * v.z, s.xy * v.x + s.yy * v.y + s.yz * v.z, s.xz * v.x + s.yz * v.y + s.zz * v.z};
+}
+// m (|c|^2 I - c c^T): parallel-axis term for a point mass m at c
+template <class T> HB_HD Sym3<T> point_inertia(T m, Vec3<T> c) {
+  Sym3<T> r;
+  const T xx = c.x * c.x, yy = c.y * c.y, zz = c.z * c.z;
+  r.xx = m * (yy + zz); r.yy = m * (xx + zz); r.zz = m * (xx + yy);
+  r.xy = -(m * (c.x * c.y)); r.xz = -(m * (c.x * c.z)); r.yz = -(m * (c.y * c.z));
+  return r;
+}
+// R I R^T for a constant body inertia I (6 doubles) and rotation R
+template <class T> HB_HD Sym3<T> rotate_inertia(const Mat3<T>& R, const double* I) {
+  // columns of R scaled: M = R * I  (I symmetric constant)
+  T M[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    M[3 * i + 0] = R.m[3 * i] * I[0] + R.m[3 * i + 1] * I[1] + R.m[3 * i + 2] * I[2];
+    M[3 * i + 1] = R.m[3 * i] * I[1] + R.m[3 * i + 1] * I[3] + R.m[3 * i + 2] * I[4];
+    M[3 * i + 2] = R.m[3 * i] * I[2] + R.m[3 * i + 1] * I[4] + R.m[3 * i + 2] * I[5];
+  }
+  Sym3<T> r;
+  r.xx = M[0] * R.m[0] + M[1] * R.m[1] + M[2] * R.m[2];
+  r.xy = M[0] * R.m[3] + M[1] * R.m[4] + M[2] * R.m[5];
+  r.xz = M[0] * R.m[6] + M[1] * R.m[7] + M[2] * R.m[8];
+  r.yy = M[3] * R.m[3] + M[4] * R.m[4] + M[5] * R.m[5];
+  r.yz = M[3] * R.m[6] + M[4] * R.m[7] + M[5] * R.m[8];
+  r.zz = M[6] * R.m[6] + M[7] * R.m[7] + M[8] * R.m[8];
+  return r;
+}
+// solve S x = b for symmetric positive definite 3x3 (adjugate / determinant)
+template <class T> HB_HD Vec3<T> sym3_solve(const Sym3<T>& s, Vec3<T> b) {
+  const T c00 = s.yy * s.zz - s.yz * s.yz, c01 = s.xz * s.yz - s.xy * s.zz, c02 = s.xy * s.yz - s.xz * s.yy;
+  const T c11 = s.xx * s.zz - s.xz * s.xz, c12 = s.xy * s.xz - s.xx * s.yz, c22 = s.xx * s.yy - s.xy * s.xy;
+  const T det = s.xx * c00 + s.xy * c01 + s.xz * c02;
+  const T inv = T(1.0) / det;
+  return {inv * (c00 * b.x + c01 * b.y + c02 * b.z), inv * (c01 * b.x + c11 * b.y + c12 * b.z),
+          inv * (c02 * b.x + c12 * b.y + c22 * b.z)};
+}
+// rotation about a constant unit axis (Rodrigues)
+template <class T> HB_HD Mat3<T> axis_rot(const double* ax, T th) {
+  T s, c;
+  sincos_t(th, s, c);
+  const T oc = T(1.0) - c;
+  Mat3<T> r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[3 * i + j] = (ax[i] * ax[j]) * oc + (i == j ? c : T(0.0));
+  r.m[1] -= ax[2] * s; r.m[2] += ax[1] * s;
+  r.m[3] += ax[2] * s; r.m[5] -= ax[0] * s;
+  r.m[6] -= ax[1] * s; r.m[7] += ax[0] * s;
+  return r;
+}
+
+}  // namespace hb

@@ -1,0 +1,199 @@
+// Device-side model of the biped and the structured centroidal evaluation used by the MPC kernels.
+//
+// Design (differs from a generic rigid-body library on purpose): the robot is a floating base plus two
+// 5-joint chains, so everything is evaluated in the BASE frame with composite (mass, first moment, inertia
+// about the base origin) suffix sums along each leg, then rotated once into the world.  The centroidal
+// momentum matrix is never formed: only its action on the joint velocities and the closed-form inverse of its
+// base block (block upper-triangular for the Translation + ZYX base) are needed.
+// Replaces OCS2 PinocchioCentroidalDynamicsAD / PinocchioEndEffectorKinematicsCppAd as used by
+// legged_interface/src/dynamics/LeggedRobotDynamicsAD.cpp:57-70 and
+// legged_interface/src/constraint/EndEffectorLinearConstraint.cpp:87-129.
+#pragma once
+#include "../../include/hunter_hip.h"
+#include "hb_math.hpp"
+
+namespace hb {
+
+struct DevModel {
+  double origin[HB_NJ][3];
+  double axis[HB_NJ][3];
+  double mass[HB_NBODY];
+  double com[HB_NBODY][3];
+  double inertia[HB_NBODY][6];
+  double contact_offset[HB_NC][3];  // order L_f1 R_f1 L_f2 R_f2; contact i sits on the last link of leg (i & 1)
+  double q_lower[HB_NJ], q_upper[HB_NJ], qd_limit[HB_NJ];
+  double total_mass, gravity;
+};
+
+// Result of one centroidal evaluation (world frame unless noted).
+template <class T>
+struct Centroidal {
+  Vec3<T> v_lin;        // base linear velocity
+  Vec3<T> euler_rate;   // ZYX euler rates (yaw, pitch, roll)
+  Vec3<T> omega;        // base angular velocity, world
+  Vec3<T> foot_rel[HB_NC];  // contact point minus base origin, world
+  Vec3<T> foot_vel[HB_NC];  // contact point velocity, world
+  Vec3<T> com_rel;      // whole-body COM minus base origin, world
+};
+
+// One leg in the base frame: accumulates the leg's composite, the momentum its joint velocities carry
+// (about the base origin) and the two contact points with their joint-induced velocities.
+template <class T>
+struct LegOut {
+  T m;
+  Vec3<T> mc;
+  Sym3<T> IO;
+  Vec3<T> l_sum, L_sum;      // sum_k l_k qd_k, sum_k L_O,k qd_k
+  Vec3<T> foot[2], foot_vj[2];  // contact points (f1, f2) and sum_k (a_k x (p - o_k)) qd_k, base frame
+};
+
+template <class T>
+HB_HD void leg_eval(const DevModel& M, int leg, const T* qj, const T* qdj, LegOut<T>& out) {
+  const int j0 = 5 * leg;
+  Vec3<T> o[5], a[5];
+  T cm[5];
+  Vec3<T> cmc[5];
+  Sym3<T> cIO[5];
+  Mat3<T> R = Mat3<T>::identity();
+  Vec3<T> op;  // parent origin
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = j0 + k, b = j + 1;
+    o[k] = op + R * Vec3<T>(T(M.origin[j][0]), T(M.origin[j][1]), T(M.origin[j][2]));
+    a[k] = R * Vec3<T>(T(M.axis[j][0]), T(M.axis[j][1]), T(M.axis[j][2]));
+    R = R * axis_rot<T>(M.axis[j], qj[j]);
+    const Vec3<T> c = o[k] + R * Vec3<T>(T(M.com[b][0]), T(M.com[b][1]), T(M.com[b][2]));
+    const T mb = T(M.mass[b]);
+    cm[k] = mb;
+    cmc[k] = mb * c;
+    cIO[k] = rotate_inertia<T>(R, M.inertia[b]) + point_inertia<T>(mb, c);
+    op = o[k];
+  }
+  // contact points on the last link (f1 = contact index leg, f2 = contact index leg + 2)
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int ci = leg + 2 * f;
+    out.foot[f] = o[4] + R * Vec3<T>(T(M.contact_offset[ci][0]), T(M.contact_offset[ci][1]), T(M.contact_offset[ci][2]));
+    out.foot_vj[f] = Vec3<T>();
+  }
+  // suffix composites and momentum of the joint velocities
+  T m = T(0.0);
+  Vec3<T> mc;
+  Sym3<T> IO;
+  out.l_sum = Vec3<T>();
+  out.L_sum = Vec3<T>();
+#pragma unroll
+  for (int k = 4; k >= 0; --k) {
+    m = m + cm[k];
+    mc = mc + cmc[k];
+    IO = IO + cIO[k];
+    const T qd = qdj[j0 + k];
+    const Vec3<T> l = cross(a[k], mc - m * o[k]);
+    const Vec3<T> L = IO * a[k] - cross(mc, cross(a[k], o[k]));
+    out.l_sum = out.l_sum + qd * l;
+    out.L_sum = out.L_sum + qd * L;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) out.foot_vj[f] = out.foot_vj[f] + qd * cross(a[k], out.foot[f] - o[k]);
+  }
+  out.m = m;
+  out.mc = mc;
+  out.IO = IO;
+}
+
+// ZYX euler rates from the world angular velocity (inverse of omega = E(zyx) * rates).
+template <class T>
+HB_HD Vec3<T> euler_rates_from_omega(T sz, T cz, T sy, T cy, Vec3<T> w) {
+  const T roll_rate = (cz * w.x + sz * w.y) / cy;
+  const T pitch_rate = cz * w.y - sz * w.x;
+  const T yaw_rate = w.z + sy * roll_rate;
+  return {yaw_rate, pitch_rate, roll_rate};
+}
+
+// Centroidal evaluation at pinocchio coordinates q = [pos, zyx, joints] given normalised momentum hn(6)
+// and joint velocities qd(10): base velocity from  A_b v_b = m hn - A_j qd  in closed form.
+template <class T>
+HB_HD void centroidal_eval(const DevModel& M, const T* zyx, const T* qj, const T* hn, const T* qdj, Centroidal<T>& out) {
+  LegOut<T> L0, L1;
+  leg_eval<T>(M, 0, qj, qdj, L0);
+  leg_eval<T>(M, 1, qj, qdj, L1);
+  // whole-body composite in the base frame
+  const T mb = T(M.mass[0]);
+  const Vec3<T> cb(T(M.com[0][0]), T(M.com[0][1]), T(M.com[0][2]));
+  Sym3<T> Ib;
+  Ib.xx = T(M.inertia[0][0]); Ib.xy = T(M.inertia[0][1]); Ib.xz = T(M.inertia[0][2]);
+  Ib.yy = T(M.inertia[0][3]); Ib.yz = T(M.inertia[0][4]); Ib.zz = T(M.inertia[0][5]);
+  const T mt = mb + L0.m + L1.m;
+  const Vec3<T> mc = mb * cb + L0.mc + L1.mc;
+  const Sym3<T> IO = Ib + point_inertia<T>(mb, cb) + L0.IO + L1.IO;
+  const T inv_m = T(1.0) / mt;
+  const Vec3<T> P = inv_m * mc;  // COM in the base frame
+  Sym3<T> Icom = IO;
+  {
+    const Sym3<T> sh = point_inertia<T>(mt, P);
+    Icom.xx = Icom.xx - sh.xx; Icom.xy = Icom.xy - sh.xy; Icom.xz = Icom.xz - sh.xz;
+    Icom.yy = Icom.yy - sh.yy; Icom.yz = Icom.yz - sh.yz; Icom.zz = Icom.zz - sh.zz;
+  }
+  // base rotation R = Rz Ry Rx
+  T sz, cz, sy, cy, sx, cx;
+  sincos_t(zyx[0], sz, cz);
+  sincos_t(zyx[1], sy, cy);
+  sincos_t(zyx[2], sx, cx);
+  Mat3<T> R;
+  R.m[0] = cz * cy; R.m[1] = cz * sy * sx - sz * cx; R.m[2] = cz * sy * cx + sz * sx;
+  R.m[3] = sz * cy; R.m[4] = sz * sy * sx + cz * cx; R.m[5] = sz * sy * cx - cz * sx;
+  R.m[6] = -sy;     R.m[7] = cy * sx;                R.m[8] = cy * cx;
+  // momentum carried by the joint velocities, about the COM, base frame
+  const Vec3<T> lj = L0.l_sum + L1.l_sum;
+  const Vec3<T> Lj = (L0.L_sum + L1.L_sum) - cross(P, lj);
+  // angular: I_com w_b = R^T (m hn_ang) - Lj
+  const Vec3<T> hang_w(mt * hn[3], mt * hn[4], mt * hn[5]);
+  const Vec3<T> wb = sym3_solve<T>(Icom, tmul(R, hang_w) - Lj);
+  out.omega = R * wb;
+  out.euler_rate = euler_rates_from_omega<T>(sz, cz, sy, cy, out.omega);
+  // linear: m v_lin + m w x (R P) + R lj = m hn_lin
+  out.com_rel = R * P;
+  const Vec3<T> hlin(hn[0], hn[1], hn[2]);
+  out.v_lin = hlin - cross(out.omega, out.com_rel) - inv_m * (R * lj);
+  // contact points
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    out.foot_rel[0 + 2 * f] = R * L0.foot[f];
+    out.foot_rel[1 + 2 * f] = R * L1.foot[f];
+    out.foot_vel[0 + 2 * f] = out.v_lin + cross(out.omega, out.foot_rel[0 + 2 * f]) + R * L0.foot_vj[f];
+    out.foot_vel[1 + 2 * f] = out.v_lin + cross(out.omega, out.foot_rel[1 + 2 * f]) + R * L1.foot_vj[f];
+  }
+}
+
+// Flow map xdot = f(x,u) from a centroidal evaluation.
+template <class T>
+HB_HD void flow_from_centroidal(const DevModel& M, const Centroidal<T>& c, const T* u, T* f) {
+  Vec3<T> fs, ms;
+#pragma unroll
+  for (int i = 0; i < HB_NC; ++i) {
+    const Vec3<T> F(u[3 * i], u[3 * i + 1], u[3 * i + 2]);
+    fs = fs + F;
+    ms = ms + cross(c.foot_rel[i] - c.com_rel, F);
+  }
+  const double inv_m = 1.0 / M.total_mass;
+  f[0] = inv_m * fs.x; f[1] = inv_m * fs.y; f[2] = inv_m * fs.z - M.gravity;
+  f[3] = inv_m * ms.x; f[4] = inv_m * ms.y; f[5] = inv_m * ms.z;
+  f[6] = c.v_lin.x; f[7] = c.v_lin.y; f[8] = c.v_lin.z;
+  f[9] = c.euler_rate.x; f[10] = c.euler_rate.y; f[11] = c.euler_rate.z;
+#pragma unroll
+  for (int j = 0; j < HB_NJ; ++j) f[12 + j] = u[12 + j];
+}
+
+template <class T>
+HB_HD void flow_map(const DevModel& M, const T* x, const T* u, T* f, Centroidal<T>* keep = nullptr) {
+  Centroidal<T> c;
+  centroidal_eval<T>(M, x + 9, x + 12, x, u + 12, c);
+  flow_from_centroidal<T>(M, c, u, f);
+  if (keep) *keep = c;
+}
+
+HB_HD void mode_flags(int mode, bool* cf) {
+  const bool L = (mode == 2 || mode == 3), R = (mode == 1 || mode == 3);
+  cf[0] = L; cf[1] = R; cf[2] = L; cf[3] = R;
+}
+
+}  // namespace hb

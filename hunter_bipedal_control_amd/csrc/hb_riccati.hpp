@@ -1,0 +1,269 @@
+// Backward / forward Riccati sweep over the projected stage records of one robot instance, one 64-lane
+// workgroup per instance with the value function and the current stage resident in LDS.  This is the role HPIPM
+// plays inside OCS2's SqpSolver for the reference (no inequality rows reach the QP in the shipped configuration,
+// SURVEY.md B.5), followed by the node-level evaluation used by the filter line search.
+#pragma once
+#include "hb_lq.hpp"
+
+namespace hb {
+
+struct RicLds {
+  static constexpr int S = 0;             // 22x22
+  static constexpr int s = S + 484;       // 22 (+2 pad)
+  static constexpr int node = s + 24;     // REC_RICCATI_END doubles of the stage record
+  static constexpr int M1 = node + REC_RICCATI_END;  // 22x35 : S [A~ B~ b~] (+ s on the last column)
+  static constexpr int Hu = M1 + 770;     // 12x35 : [Hux | Huu | hu]
+  static constexpr int Kk = Hu + 420;     // 12x23 : [K~ | k~]
+  static constexpr int flag = Kk + 276;   // 4
+  static constexpr int total = flag + 4;
+};
+
+// One backward step. `node` already holds the stage record in LDS. Updates S, s in place; writes the gains.
+template <class Ctx>
+HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, double* gains) {
+  double* S = lds + RicLds::S;
+  double* sv = lds + RicLds::s;
+  double* nd = lds + RicLds::node;
+  double* M1 = lds + RicLds::M1;
+  double* Hu = lds + RicLds::Hu;
+  double* Kk = lds + RicLds::Kk;
+  const double* At = nd + REC_AT;
+  const double* Bt = nd + REC_BT;
+  const double* bt = nd + REC_bT;
+  // M1 = S [A~ B~ b~], last column += s
+  for (int idx = cx.lane; idx < 22 * 35; idx += cx.nlanes) {
+    const int i = idx / 35, c = idx % 35;
+    double acc = 0.0;
+    if (c < 22) {
+      for (int j = 0; j < 22; ++j) acc += S[i * 22 + j] * At[j * 22 + c];
+    } else if (c < 34) {
+      for (int j = 0; j < 22; ++j) acc += S[i * 22 + j] * Bt[j * NU_T + (c - 22)];
+    } else {
+      for (int j = 0; j < 22; ++j) acc += S[i * 22 + j] * bt[j];
+      acc += sv[i];
+    }
+    M1[idx] = acc;
+  }
+  cx.sync();
+  // Hu = B~' M1 + [P~ | R~ | r~]
+  for (int idx = cx.lane; idx < NU_T * 35; idx += cx.nlanes) {
+    const int a = idx / 35, c = idx % 35;
+    double acc = (c < 22) ? nd[REC_PT + a * 22 + c] : (c < 34 ? nd[REC_RT + a * NU_T + (c - 22)] : nd[REC_rT + a]);
+    for (int j = 0; j < 22; ++j) acc += Bt[j * NU_T + a] * M1[j * 35 + c];
+    Hu[idx] = acc;
+  }
+  cx.sync();
+  // Cholesky of Huu (in place, lower) by lane 0
+  if (cx.lane == 0) {
+    bool ok = true;
+    for (int j = 0; j < NU_T; ++j) {
+      double d = Hu[j * 35 + 22 + j];
+      for (int k = 0; k < j; ++k) d -= Hu[j * 35 + 22 + k] * Hu[j * 35 + 22 + k];
+      if (!(d > 0.0)) { ok = false; d = 1.0; }
+      const double l = sqrt(d);
+      Hu[j * 35 + 22 + j] = l;
+      for (int i = j + 1; i < NU_T; ++i) {
+        double sacc = Hu[i * 35 + 22 + j];
+        for (int k = 0; k < j; ++k) sacc -= Hu[i * 35 + 22 + k] * Hu[j * 35 + 22 + k];
+        Hu[i * 35 + 22 + j] = sacc / l;
+      }
+    }
+    if (!ok) lds[RicLds::flag] = 1.0;
+  }
+  cx.sync();
+  // K~ = -Huu^-1 [Hux | hu]: one right-hand side per lane
+  for (int c = cx.lane; c < 23; c += cx.nlanes) {
+    const int src = (c < 22) ? c : 34;
+    double y[NU_T];
+    for (int a = 0; a < NU_T; ++a) {
+      double sacc = -Hu[a * 35 + src];
+      for (int k = 0; k < a; ++k) sacc -= Hu[a * 35 + 22 + k] * y[k];
+      y[a] = sacc / Hu[a * 35 + 22 + a];
+    }
+    for (int a = NU_T - 1; a >= 0; --a) {
+      double sacc = y[a];
+      for (int k = a + 1; k < NU_T; ++k) sacc -= Hu[k * 35 + 22 + a] * y[k];
+      y[a] = sacc / Hu[a * 35 + 22 + a];
+    }
+    for (int a = 0; a < NU_T; ++a) Kk[a * 23 + c] = y[a];
+  }
+  cx.sync();
+  // T = Q~ + A~' M1_A + Hux' K~   (written over the Q~ slot of the node record), s_new likewise over q~
+  for (int idx = cx.lane; idx < 484 + 22; idx += cx.nlanes) {
+    if (idx < 484) {
+      const int i = idx / 22, c = idx % 22;
+      double acc = nd[REC_QT + idx];
+      for (int j = 0; j < 22; ++j) acc += At[j * 22 + i] * M1[j * 35 + c];
+      for (int a = 0; a < NU_T; ++a) acc += Hu[a * 35 + i] * Kk[a * 23 + c];
+      nd[REC_QT + idx] = acc;
+    } else {
+      const int i = idx - 484;
+      double acc = nd[REC_qT + i];
+      for (int j = 0; j < 22; ++j) acc += At[j * 22 + i] * M1[j * 35 + 34];
+      for (int a = 0; a < NU_T; ++a) acc += Hu[a * 35 + i] * Kk[a * 23 + 22];
+      nd[REC_qT + i] = acc;
+    }
+  }
+  for (int idx = cx.lane; idx < NU_T * 23; idx += cx.nlanes) {
+    const int a = idx / 23, c = idx % 23;
+    if (c < 22) gains[a * 22 + c] = Kk[idx];
+    else gains[264 + a] = Kk[idx];
+  }
+  cx.sync();
+  for (int idx = cx.lane; idx < 484 + 22; idx += cx.nlanes) {
+    if (idx < 484) {
+      const int i = idx / 22, c = idx % 22;
+      S[idx] = 0.5 * (nd[REC_QT + i * 22 + c] + nd[REC_QT + c * 22 + i]);
+    } else {
+      sv[idx - 484] = nd[REC_qT + idx - 484];
+    }
+  }
+  cx.sync();
+}
+
+struct FwdLds {
+  static constexpr int dx = 0;        // 22 (+2)
+  static constexpr int ut = 24;       // 12
+  static constexpr int du = 36;       // 22 (+2)
+  static constexpr int dxn = 60;      // 22 (+2)
+  static constexpr int acc = 84;      // 4: armijo, merit, dyn, eq
+  static constexpr int total = 88;
+};
+
+// One forward step: reads the stage record + gains from global memory, advances dx in LDS and writes the full
+// state/input step of this node.
+template <class Ctx>
+HB_HD void riccati_fwd_node(const Ctx& cx, double* lds, const double* rec, const double* gains, double* dx_out,
+                            double* du_out) {
+  double* dx = lds + FwdLds::dx;
+  double* ut = lds + FwdLds::ut;
+  double* du = lds + FwdLds::du;
+  double* dxn = lds + FwdLds::dxn;
+  double* acc = lds + FwdLds::acc;
+  const int n_f = int(rec[REC_META + 0]), nz = int(rec[REC_META + 1]), mode = int(rec[REC_META + 2]);
+  bool cf[HB_NC];
+  mode_flags(mode, cf);
+  for (int a = cx.lane; a < NU_T; a += cx.nlanes) {
+    double s = gains[264 + a];
+    for (int c = 0; c < 22; ++c) s += gains[a * 22 + c] * dx[c];
+    ut[a] = s;
+  }
+  cx.sync();
+  for (int i = cx.lane; i < 22 + 22; i += cx.nlanes) {
+    if (i < 22) {
+      double s = rec[REC_bT + i];
+      for (int c = 0; c < 22; ++c) s += rec[REC_AT + i * 22 + c] * dx[c];
+      for (int a = 0; a < NU_T; ++a) s += rec[REC_BT + i * NU_T + a] * ut[a];
+      dxn[i] = s;
+    } else {
+      const int m = i - 22;
+      double s;
+      if (m < 12) {
+        const int foot = m / 3;
+        if (cf[foot]) {
+          int col = 0;
+          for (int f = 0; f < foot; ++f) col += cf[f] ? 3 : 0;
+          s = ut[col + m % 3];
+        } else {
+          s = rec[REC_DF + m];
+        }
+      } else {
+        const int k = m - 12;
+        s = rec[REC_KE + k];
+        for (int c = 0; c < 22; ++c) s += rec[REC_KX + k * 22 + c] * dx[c];
+        for (int b = 0; b < nz; ++b) s += rec[REC_Z + k * 6 + b] * ut[n_f + b];
+      }
+      du[m] = s;
+    }
+  }
+  cx.sync();
+  if (cx.lane == 0) {
+    double a = 0;
+    for (int c = 0; c < 22; ++c) a += rec[REC_QF + c] * dx[c] + rec[REC_RF + c] * du[c];
+    acc[0] += a;
+    acc[1] += rec[REC_META + 3];
+    acc[2] += rec[REC_META + 4];
+    acc[3] += rec[REC_META + 5];
+  }
+  for (int i = cx.lane; i < 22; i += cx.nlanes) {
+    dx_out[i] = dx[i];
+    du_out[i] = du[i];
+  }
+  cx.sync();
+  for (int i = cx.lane; i < 22; i += cx.nlanes) dx[i] = dxn[i];
+  cx.sync();
+}
+
+// Value-only evaluation of one node for the line search (one thread per node):
+// returns dt * (stage cost), dt * |defect|^2, dt * |equality constraints|^2  (OCS2 PerformanceIndex).
+HB_HD void node_value(const DevModel& M, const DevConfig& C, const double* x, const double* u, const double* xnext,
+                      const double* xref, const double* swing, double dt, int mode, double* out3) {
+  bool cf[HB_NC];
+  mode_flags(mode, cf);
+  double f1[HB_NX], f2[HB_NX], xm[HB_NX];
+  Centroidal<double> c1;
+  flow_map<double>(M, x, u, f1, &c1);
+#pragma unroll
+  for (int i = 0; i < HB_NX; ++i) xm[i] = x[i] + dt * f1[i];
+  flow_map<double>(M, xm, u, f2);
+  double dyn = 0;
+#pragma unroll
+  for (int i = 0; i < HB_NX; ++i) {
+    const double d = x[i] + 0.5 * dt * (f1[i] + f2[i]) - xnext[i];
+    dyn += d * d;
+  }
+  double cost = 0, eq = 0;
+  int nc = 0;
+  for (int i = 0; i < HB_NC; ++i) nc += cf[i];
+  const double fz_nom = nc > 0 ? M.total_mass * M.gravity / nc : 0.0;
+  for (int i = 0; i < HB_NX; ++i) {
+    const double dx = x[i] - xref[i];
+    cost += 0.5 * C.Q_diag[i] * dx * dx;
+  }
+  for (int i = 0; i < 12; ++i) {
+    const double du = u[i] - ((i % 3 == 2 && cf[i / 3]) ? fz_nom : 0.0);
+    cost += 0.5 * C.R_FF_diag[i] * du * du;
+  }
+  for (int k = 0; k < HB_NJ; ++k) {
+    double s = 0;
+    for (int l = 0; l < HB_NJ; ++l) s += C.R_jj[k * 10 + l] * u[12 + l];
+    cost += 0.5 * u[12 + k] * s;
+  }
+  const RelaxedBarrierD fb{C.fb_mu, C.fb_delta};
+  const RelaxedBarrierD bp{C.pos_b[0], C.pos_b[1]}, bv{C.vel_b[0], C.vel_b[1]}, bf{C.force_b[0], C.force_b[1]};
+  for (int i = 0; i < HB_NC; ++i) {
+    const double Fx = u[3 * i], Fy = u[3 * i + 1], Fz = u[3 * i + 2];
+    const double pz = x[8] + c1.foot_rel[i].z;
+    if (cf[i]) {
+      const double h = C.friction_mu * (Fz + C.friction_gripper) - sqrt(Fx * Fx + Fy * Fy + C.friction_reg);
+      cost += fb.value(h);
+      const double r2 = c1.foot_vel[i].z + C.zv_gain * pz + C.zv_off;
+      eq += c1.foot_vel[i].x * c1.foot_vel[i].x + c1.foot_vel[i].y * c1.foot_vel[i].y + r2 * r2;
+    } else {
+      const double* sw = swing + 6 * i;
+      const double r0 = c1.foot_vel[i].z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
+      const double r1 = C.xy_gain * (x[6] + c1.foot_rel[i].x) + c1.foot_vel[i].x - (sw[3] + C.xy_gain * sw[0]);
+      const double r2 = C.xy_gain * (x[7] + c1.foot_rel[i].y) + c1.foot_vel[i].y - (sw[4] + C.xy_gain * sw[1]);
+      eq += r0 * r0 + Fx * Fx + Fy * Fy + Fz * Fz;
+      cost += 0.5 * C.soft_w * (r1 * r1 + r2 * r2);
+    }
+    cost += bf.value(Fz - C.force_lim[0]) + bf.value(C.force_lim[1] - Fz);
+  }
+  for (int j = 0; j < HB_NJ; ++j) {
+    cost += bp.value(x[12 + j] - M.q_lower[j]) + bp.value(M.q_upper[j] - x[12 + j]);
+    cost += bv.value(u[12 + j] + M.qd_limit[j]) + bv.value(M.qd_limit[j] - u[12 + j]);
+  }
+  out3[0] = dt * cost;
+  out3[1] = dt * dyn;
+  out3[2] = dt * eq;
+}
+
+// Filter line-search acceptance (OCS2 FilterLinesearch::acceptStep).
+HB_HD bool filter_accept(const DevConfig& C, double base_merit, double base_viol, double merit, double viol, double alpha,
+                         double armijo) {
+  if (viol > C.g_max) return viol < (1.0 - C.gamma_c) * base_viol;
+  if (viol < C.g_min && base_viol < C.g_min && armijo < 0.0) return merit < base_merit + C.armijo * alpha * armijo;
+  return (merit < base_merit - C.gamma_c * base_viol) || (viol < (1.0 - C.gamma_c) * base_viol);
+}
+
+}  // namespace hb

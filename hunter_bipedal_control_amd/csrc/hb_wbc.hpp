@@ -1,0 +1,733 @@
+// Whole-body controller on the device: one 64-lane workgroup per robot instance.
+//   * rigid-body quantities by recursive Newton–Euler / composite-rigid-body passes over the
+//     base + two 5-joint chains (replaces the pinocchio calls of legged_wbc/src/WbcBase.cpp:85-116,126-135)
+//   * task rows of legged_wbc/src/WbcBase.cpp:138-338 and the WeightedWbc stack (WeightedWbc.cpp:18-94);
+//     torque-limit / friction-pyramid / zero-force rows are never materialised (implicit sparse rows)
+//   * the dense QP  min 1/2|A_w x - b_w|^2 + eps/2 |x|^2  s.t. E x = e, D x <= f  by a lane-cooperative
+//     Goldfarb–Idnani dual active-set method with the factor of H + eps I built by Givens row insertion into
+//     sqrt(eps) I (never from H) — the role of qpOASES::QProblem::init at WeightedWbc.cpp:44-55.
+#pragma once
+#include "hb_lq.hpp"
+
+namespace hb {
+
+constexpr int NW = HB_NWBC;  // 38 decision variables [qdd(16) F(12) tau(10)]
+
+struct WbcBatch {
+  int B;
+  double* t_now;   // [B]
+  double* rbd;     // [B][32]
+  int* walk;       // [B]
+  double* xdes;    // [B][22]
+  double* udes;    // [B][22]
+  int* mode;       // [B]
+  int* stance;     // [B]
+  double* sol;     // [B][38]
+  int* status;     // [B]
+  int* iters;      // [B]
+  // published policy (PrimalSolution) read by the WBC stream
+  double* px;      // [B][Nmax+1][22]
+  double* pu;      // [B][Nmax][22]
+  double* pt;      // [B][Nmax+1]
+  int* pmode;      // [B][Nmax]
+  int* pn;         // [B]
+  bool policy_valid;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// rigid-body pass (single lane, double)
+struct BodyPass {
+  // base
+  double R0[9];
+  Vec3<double> E[3];         // world axes of yaw, pitch, roll coordinates
+  Vec3<double> omega0, alpha0;  // base angular velocity, bias angular acceleration (Edot * rates)
+  // legs: index [leg][k]
+  Vec3<double> o[2][5], a[2][5];       // joint origin minus base origin, joint axis (world)
+  Vec3<double> l[2][5], L[2][5];       // composite momentum per unit joint rate: linear, angular about base origin
+  Vec3<double> foot[HB_NC], foot_vel[HB_NC], foot_acc[HB_NC];  // contact point minus base origin, velocity, bias accel
+  double mass;
+  Vec3<double> mc;            // total first moment about the base origin
+  Sym3<double> IO;            // total inertia about the base origin, world axes
+  double nle[HB_NV];          // bias forces (only if want_dynamics)
+  Vec3<double> hdot_lin, hdot_ang;  // bias momentum rate about the COM (Adot v), gravity excluded
+};
+
+HB_HD Sym3<double> sym_from(const double* I) {
+  Sym3<double> s;
+  s.xx = I[0]; s.xy = I[1]; s.xz = I[2]; s.yy = I[3]; s.yz = I[4]; s.zz = I[5];
+  return s;
+}
+
+// q = [pos(3) zyx(3) joints(10)], v = qdot.  Accelerations are evaluated at qddot = 0.
+HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPass& P) {
+  double sz, cz, sy, cy, sx, cx;
+  sincos_t(q[3], sz, cz);
+  sincos_t(q[4], sy, cy);
+  sincos_t(q[5], sx, cx);
+  Mat3<double> R0;
+  R0.m[0] = cz * cy; R0.m[1] = cz * sy * sx - sz * cx; R0.m[2] = cz * sy * cx + sz * sx;
+  R0.m[3] = sz * cy; R0.m[4] = sz * sy * sx + cz * cx; R0.m[5] = sz * sy * cx - cz * sx;
+  R0.m[6] = -sy;     R0.m[7] = cy * sx;                R0.m[8] = cy * cx;
+  for (int i = 0; i < 9; ++i) P.R0[i] = R0.m[i];
+  P.E[0] = Vec3<double>(0.0, 0.0, 1.0);
+  P.E[1] = Vec3<double>(-sz, cz, 0.0);
+  P.E[2] = Vec3<double>(cz * cy, sz * cy, -sy);
+  const Vec3<double> w_yaw = v[3] * P.E[0];
+  const Vec3<double> w_yp = w_yaw + v[4] * P.E[1];
+  P.omega0 = w_yp + v[5] * P.E[2];
+  P.alpha0 = v[4] * cross(w_yaw, P.E[1]) + v[5] * cross(w_yp, P.E[2]);
+  const Vec3<double> grav(0.0, 0.0, M.gravity);  // gravity as a fictitious upward base acceleration
+  const Vec3<double> v0(v[0], v[1], v[2]);
+
+  // base body
+  const Vec3<double> c0 = R0 * Vec3<double>(M.com[0][0], M.com[0][1], M.com[0][2]);
+  const Sym3<double> I0 = rotate_inertia<double>(R0, M.inertia[0]);
+  const Vec3<double> ac0 = grav + cross(P.alpha0, c0) + cross(P.omega0, cross(P.omega0, c0));
+  const Vec3<double> F0 = M.mass[0] * ac0;
+  const Vec3<double> N0 = I0 * P.alpha0 + cross(P.omega0, I0 * P.omega0);
+  Vec3<double> f_base = F0;
+  Vec3<double> n_base = N0 + cross(c0, F0);
+  P.mass = M.mass[0];
+  P.mc = M.mass[0] * c0;
+  P.IO = I0 + point_inertia<double>(M.mass[0], c0);
+  // bias momentum rate (no gravity): linear sum m a, angular about base origin first, shifted to the COM later
+  Vec3<double> hl = M.mass[0] * (ac0 - grav);
+  Vec3<double> hO = N0 + cross(c0, M.mass[0] * (ac0 - grav));
+
+  for (int leg = 0; leg < 2; ++leg) {
+    Mat3<double> R = R0;
+    Vec3<double> op;                       // parent origin minus base origin
+    Vec3<double> w = P.omega0, al = P.alpha0, ao = grav, vo = v0;
+    Vec3<double> c[5], F[5], N[5];
+    double mb[5];
+    Sym3<double> Iw[5];
+    for (int k = 0; k < 5; ++k) {
+      const int j = 5 * leg + k, b = j + 1;
+      const Vec3<double> r = R * Vec3<double>(M.origin[j][0], M.origin[j][1], M.origin[j][2]);
+      const Vec3<double> ok = op + r;
+      const Vec3<double> ak = R * Vec3<double>(M.axis[j][0], M.axis[j][1], M.axis[j][2]);
+      ao = ao + cross(al, r) + cross(w, cross(w, r));
+      vo = vo + cross(w, r);
+      const double qd = v[6 + j];
+      al = al + qd * cross(w, ak);
+      w = w + qd * ak;
+      R = R * axis_rot<double>(M.axis[j], q[6 + j]);
+      const Vec3<double> rc = R * Vec3<double>(M.com[b][0], M.com[b][1], M.com[b][2]);
+      const Vec3<double> acc = ao + cross(al, rc) + cross(w, cross(w, rc));
+      P.o[leg][k] = ok;
+      P.a[leg][k] = ak;
+      c[k] = ok + rc;
+      mb[k] = M.mass[b];
+      Iw[k] = rotate_inertia<double>(R, M.inertia[b]);
+      F[k] = mb[k] * acc;
+      N[k] = Iw[k] * al + cross(w, Iw[k] * w);
+      hl = hl + mb[k] * (acc - grav);
+      hO = hO + N[k] + cross(c[k], mb[k] * (acc - grav));
+      op = ok;
+      if (k == 4) {
+        for (int f = 0; f < 2; ++f) {
+          const int ci = leg + 2 * f;
+          const Vec3<double> rp = R * Vec3<double>(M.contact_offset[ci][0], M.contact_offset[ci][1], M.contact_offset[ci][2]);
+          P.foot[ci] = ok + rp;
+          P.foot_vel[ci] = vo + cross(w, rp);
+          P.foot_acc[ci] = ao - grav + cross(al, rp) + cross(w, cross(w, rp));
+        }
+      }
+    }
+    // backward: forces / moments and composites
+    Vec3<double> f, n;  // force and moment (about joint origin k) transmitted through joint k
+    double mcomp = 0.0;
+    Vec3<double> mccomp;
+    Sym3<double> IOcomp;
+    Vec3<double> o_next;
+    for (int k = 4; k >= 0; --k) {
+      const Vec3<double> ok = P.o[leg][k];
+      Vec3<double> nk = N[k] + cross(c[k] - ok, F[k]);
+      if (k < 4) nk = nk + n + cross(o_next - ok, f);
+      f = (k < 4) ? f + F[k] : F[k];
+      n = nk;
+      o_next = ok;
+      P.nle[6 + 5 * leg + k] = dot(P.a[leg][k], n);
+      mcomp += mb[k];
+      mccomp = mccomp + mb[k] * c[k];
+      IOcomp = IOcomp + Iw[k] + point_inertia<double>(mb[k], c[k]);
+      P.l[leg][k] = cross(P.a[leg][k], mccomp - mcomp * ok);
+      P.L[leg][k] = IOcomp * P.a[leg][k] - cross(mccomp, cross(P.a[leg][k], ok));
+    }
+    f_base = f_base + f;
+    n_base = n_base + n + cross(o_next, f);
+    P.mass += mcomp;
+    P.mc = P.mc + mccomp;
+    P.IO = P.IO + IOcomp;
+  }
+  P.nle[0] = f_base.x; P.nle[1] = f_base.y; P.nle[2] = f_base.z;
+  for (int cdir = 0; cdir < 3; ++cdir) P.nle[3 + cdir] = dot(P.E[cdir], n_base);
+  const Vec3<double> com = (1.0 / P.mass) * P.mc;
+  P.hdot_lin = hl;
+  P.hdot_ang = hO - cross(com, hl);
+}
+
+// mass matrix entry helpers ------------------------------------------------------------------------------
+HB_HD void mass_matrix(const BodyPass& P, double* Mm /*16x16 row-major*/) {
+  for (int i = 0; i < 256; ++i) Mm[i] = 0.0;
+  for (int i = 0; i < 3; ++i) Mm[i * 16 + i] = P.mass;
+  for (int c = 0; c < 3; ++c) {
+    const Vec3<double> lin = cross(P.E[c], P.mc);
+    const Vec3<double> ang = P.IO * P.E[c];
+    for (int i = 0; i < 3; ++i) {
+      Mm[i * 16 + 3 + c] = comp(lin, i);
+      Mm[(3 + c) * 16 + i] = comp(lin, i);
+    }
+    for (int d = 0; d < 3; ++d) Mm[(3 + d) * 16 + 3 + c] = dot(P.E[d], ang);
+  }
+  for (int leg = 0; leg < 2; ++leg)
+    for (int k = 0; k < 5; ++k) {
+      const int col = 6 + 5 * leg + k;
+      const Vec3<double> l = P.l[leg][k], L = P.L[leg][k];
+      for (int i = 0; i < 3; ++i) Mm[i * 16 + col] = Mm[col * 16 + i] = comp(l, i);
+      for (int c = 0; c < 3; ++c) Mm[(3 + c) * 16 + col] = Mm[col * 16 + 3 + c] = dot(P.E[c], L);
+      for (int j = 0; j <= k; ++j) {
+        const int row = 6 + 5 * leg + j;
+        const double val = dot(P.a[leg][j], L - cross(P.o[leg][j], l));
+        Mm[row * 16 + col] = val;
+        Mm[col * 16 + row] = val;
+      }
+    }
+}
+// linear Jacobian entry of contact point ci w.r.t. coordinate col
+HB_HD Vec3<double> contact_jac(const BodyPass& P, int ci, int col) {
+  if (col < 3) return Vec3<double>(col == 0 ? 1.0 : 0.0, col == 1 ? 1.0 : 0.0, col == 2 ? 1.0 : 0.0);
+  if (col < 6) return cross(P.E[col - 3], P.foot[ci]);
+  const int leg = (col - 6) / 5, k = (col - 6) % 5;
+  if (leg != (ci & 1)) return Vec3<double>();
+  return cross(P.a[leg][k], P.foot[ci] - P.o[leg][k]);
+}
+
+HB_HD Vec3<double> rot_log(const double* Rl, const double* Rr) {  // rotation vector of Rl * Rr^T
+  double E[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) E[3 * i + j] = Rl[3 * i] * Rr[3 * j] + Rl[3 * i + 1] * Rr[3 * j + 1] + Rl[3 * i + 2] * Rr[3 * j + 2];
+  const Vec3<double> ax(E[7] - E[5], E[2] - E[6], E[3] - E[1]);
+  const double tr = E[0] + E[4] + E[8];
+  const double c = fmin(1.0, fmax(-1.0, 0.5 * (tr - 1.0)));
+  const double th = acos(c);
+  const double s2 = sqrt(dot(ax, ax));
+  const double scale = (th < 1e-8) ? 0.5 : th / s2;
+  return scale * ax;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS layout of the WBC workgroup (doubles)
+struct WbcLds {
+  static constexpr int J = 0;                    // 38x38
+  static constexpr int R = J + NW * NW;          // 38x38 upper triangular factor (also the initial R~)
+  static constexpr int Eeom = R + NW * NW;       // 16x38 floating-base equation of motion rows
+  static constexpr int Aw = Eeom + 16 * NW;      // 18x16 dense part of the cost rows (qdd columns)
+  static constexpr int bw = Aw + 18 * 16;        // 18
+  static constexpr int beom = bw + 18;           // 16
+  static constexpr int x = beom + 16;            // 38
+  static constexpr int np = x + NW;              // 38 dense normal of the constraint being added
+  static constexpr int d = np + NW;              // 38
+  static constexpr int z = d + NW;               // 38
+  static constexpr int r = z + NW;               // 38
+  static constexpr int lam = r + NW;             // 38 multipliers of the active set
+  static constexpr int red = lam + NW;           // 64 reduction scratch
+  static constexpr int misc = red + 64;          // 16 scalars
+  static constexpr int iact = misc + 16;         // 38 ints (active ids) + 64 ints (is_active) -> 51 doubles
+  static constexpr int total = iact + 52;
+};
+
+// constraint ids: [0,16) EoM rows, [16,16+3 nsw) zero force on swing feet, then inequalities:
+//   torque limits 20 rows (+tau_j <= lim, -tau_j <= lim), friction pyramid 5 rows per contact foot.
+struct WbcCons {
+  int n_eq, n_in;
+  int swing_feet[HB_NC], n_sw;
+  int contact_feet[HB_NC], n_c;
+};
+
+// sparse inequality / selector rows: returns up to 3 (index, coeff) pairs and the right-hand side
+HB_HD int sparse_row(const WbcCons& wc, const DevConfig& C, int cid, int* idx, double* cf, double* rhs) {
+  if (cid < 16 + 3 * wc.n_sw) {  // zero-force selector (equality)
+    const int s = cid - 16;
+    idx[0] = 16 + 3 * wc.swing_feet[s / 3] + s % 3;
+    cf[0] = 1.0;
+    *rhs = 0.0;
+    return 1;
+  }
+  const int c = cid - wc.n_eq;
+  if (c < 20) {
+    const int j = c % 10;
+    idx[0] = 28 + j;
+    cf[0] = c < 10 ? 1.0 : -1.0;
+    *rhs = C.torque_limits[j % 5];
+    return 1;
+  }
+  const int p = c - 20, foot = wc.contact_feet[p / 5], r = p % 5;
+  const int base = 16 + 3 * foot;
+  *rhs = 0.0;
+  if (r == 0) { idx[0] = base + 2; cf[0] = -1.0; return 1; }
+  idx[0] = base + (r <= 2 ? 0 : 1);
+  cf[0] = (r == 1 || r == 3) ? 1.0 : -1.0;
+  idx[1] = base + 2;
+  cf[1] = -C.wbc_mu;
+  return 2;
+}
+
+// One WBC solve.  xdes/udes/rbd: this instance's inputs; sol in/out (kept when the QP fails).
+template <class Ctx>
+HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const double* xdes, const double* udes,
+                     const double* rbd, int mode, bool stance_mode, double* lds, double* sol, int* status_out,
+                     int* iters_out) {
+  double* Jm = lds + WbcLds::J;
+  double* Rm = lds + WbcLds::R;
+  double* Ee = lds + WbcLds::Eeom;
+  double* Aw = lds + WbcLds::Aw;
+  double* bw = lds + WbcLds::bw;
+  double* beom = lds + WbcLds::beom;
+  double* x = lds + WbcLds::x;
+  double* np = lds + WbcLds::np;
+  double* d = lds + WbcLds::d;
+  double* z = lds + WbcLds::z;
+  double* r = lds + WbcLds::r;
+  double* lam = lds + WbcLds::lam;
+  double* red = lds + WbcLds::red;
+  double* misc = lds + WbcLds::misc;
+  int* act = reinterpret_cast<int*>(lds + WbcLds::iact);
+  int* is_active = act + 40;
+
+  bool cf[HB_NC];
+  mode_flags(mode, cf);
+  WbcCons wc;
+  wc.n_sw = 0;
+  wc.n_c = 0;
+  for (int i = 0; i < HB_NC; ++i) {
+    if (cf[i]) wc.contact_feet[wc.n_c++] = i;
+    else wc.swing_feet[wc.n_sw++] = i;
+  }
+  wc.n_eq = 16 + 3 * wc.n_sw;
+  wc.n_in = 20 + 5 * wc.n_c;
+  // number of dense cost rows: stance mode 6 (qdd_base = 0), else 3*n_sw swing + 6 base
+  const int n_aw = stance_mode ? 6 : 3 * wc.n_sw + 6;
+
+  // ------------------------------------------------------------------ phase A: rigid-body quantities (lane 0)
+  if (cx.lane == 0) {
+    double q[HB_NV], v[HB_NV];
+    for (int i = 0; i < 3; ++i) {
+      q[i] = rbd[3 + i];
+      q[3 + i] = rbd[i];
+      v[i] = rbd[HB_NV + 3 + i];
+    }
+    for (int j = 0; j < HB_NJ; ++j) {
+      q[6 + j] = rbd[6 + j];
+      v[6 + j] = rbd[HB_NV + 6 + j];
+    }
+    {
+      double sz, cz, sy, cy;
+      sincos_t(q[3], sz, cz);
+      sincos_t(q[4], sy, cy);
+      const Vec3<double> er = euler_rates_from_omega<double>(sz, cz, sy, cy, Vec3<double>(rbd[HB_NV], rbd[HB_NV + 1], rbd[HB_NV + 2]));
+      v[3] = er.x; v[4] = er.y; v[5] = er.z;
+    }
+    BodyPass P;
+    body_pass(M, q, v, P);
+    // EoM rows: [M, -J', -S'] x = -nle   (WbcBase.cpp:138-149)
+    mass_matrix(P, Rm);  // stage M in the R buffer (16x16)
+    for (int i = 0; i < 16; ++i) {
+      for (int j = 0; j < 16; ++j) Ee[i * NW + j] = Rm[i * 16 + j];
+      for (int ci = 0; ci < HB_NC; ++ci) {
+        const Vec3<double> jc = contact_jac(P, ci, i);
+        Ee[i * NW + 16 + 3 * ci + 0] = -jc.x;
+        Ee[i * NW + 16 + 3 * ci + 1] = -jc.y;
+        Ee[i * NW + 16 + 3 * ci + 2] = -jc.z;
+      }
+      for (int j = 0; j < HB_NJ; ++j) Ee[i * NW + 28 + j] = (i == 6 + j) ? -1.0 : 0.0;
+      beom[i] = -P.nle[i];
+    }
+    // cost rows (dense part over the 16 accelerations)
+    for (int i = 0; i < 18 * 16; ++i) Aw[i] = 0.0;
+    for (int i = 0; i < 18; ++i) bw[i] = 0.0;
+    if (stance_mode) {
+      for (int i = 0; i < 6; ++i) Aw[i * 16 + i] = C.w_base;  // WeightedWbc.cpp:83-94
+    } else {
+      // desired kinematics (WbcBase.cpp:122-136)
+      Centroidal<double> cd;
+      centroidal_eval<double>(M, xdes + 9, xdes + 12, xdes, udes + 12, cd);
+      double qd_[HB_NV], vd_[HB_NV];
+      for (int i = 0; i < HB_NV; ++i) qd_[i] = xdes[6 + i];
+      vd_[0] = cd.v_lin.x; vd_[1] = cd.v_lin.y; vd_[2] = cd.v_lin.z;
+      vd_[3] = cd.euler_rate.x; vd_[4] = cd.euler_rate.y; vd_[5] = cd.euler_rate.z;
+      for (int j = 0; j < HB_NJ; ++j) vd_[6 + j] = udes[12 + j];
+      BodyPass D;
+      body_pass(M, qd_, vd_, D);
+      // base acceleration desired: A_b qdd_b = m hdot_norm(x,u) - Adot v   (zero joint accelerations)
+      const Vec3<double> comr = (1.0 / D.mass) * D.mc;
+      Vec3<double> fs, ms;
+      for (int i = 0; i < HB_NC; ++i) {
+        const Vec3<double> F(udes[3 * i], udes[3 * i + 1], udes[3 * i + 2]);
+        fs = fs + F;
+        ms = ms + cross(D.foot[i] - comr, F);
+      }
+      const Vec3<double> ylin = Vec3<double>(fs.x, fs.y, fs.z - D.mass * M.gravity) - D.hdot_lin;
+      const Vec3<double> yang = ms - D.hdot_ang;
+      Sym3<double> Icom = D.IO;
+      {
+        const Sym3<double> sh = point_inertia<double>(D.mass, comr);
+        Icom.xx -= sh.xx; Icom.xy -= sh.xy; Icom.xz -= sh.xz; Icom.yy -= sh.yy; Icom.yz -= sh.yz; Icom.zz -= sh.zz;
+      }
+      const Vec3<double> wdot = sym3_solve<double>(Icom, yang);  // = E * euler_ddot
+      const Vec3<double> acc_lin = (1.0 / D.mass) * ylin - cross(wdot, comr);
+      const Vec3<double> acc_ang = wdot + D.alpha0;
+      // swing leg rows (WbcBase.cpp:297-323), weight w_swing
+      int row = 0;
+      for (int s = 0; s < wc.n_sw; ++s) {
+        const int i = wc.swing_feet[s];
+        const Vec3<double> pe = (Vec3<double>(xdes[6], xdes[7], xdes[8]) + D.foot[i]) - (Vec3<double>(q[0], q[1], q[2]) + P.foot[i]);
+        const Vec3<double> ve = D.foot_vel[i] - P.foot_vel[i];
+        for (int a = 0; a < 3; ++a) {
+          for (int col = 0; col < 16; ++col) Aw[row * 16 + col] = C.w_swing * comp(contact_jac(P, i, col), a);
+          bw[row] = C.w_swing * (C.swing_kp * comp(pe, a) + C.swing_kd * comp(ve, a) - comp(P.foot_acc[i], a));
+          ++row;
+        }
+      }
+      // base acceleration rows (WbcBase.cpp:228-295), weight w_base
+      Aw[row * 16 + 0] = C.w_base; bw[row] = C.w_base * acc_lin.x; ++row;
+      Aw[row * 16 + 1] = C.w_base; bw[row] = C.w_base * acc_lin.y; ++row;
+      Aw[row * 16 + 2] = C.w_base;
+      bw[row] = C.w_base * (acc_lin.z + C.bh_kp * (xdes[8] - q[2]) + C.bh_kd * (cd.v_lin.z - v[2]));
+      ++row;
+      const Vec3<double> err = rot_log(D.R0, P.R0);
+      for (int a = 0; a < 3; ++a) {
+        for (int cdir = 0; cdir < 3; ++cdir) Aw[row * 16 + 3 + cdir] = C.w_base * comp(P.E[cdir], a);
+        bw[row] = C.w_base * (comp(acc_ang, a) + C.ba_kp * comp(err, a) + C.ba_kd * (comp(D.omega0, a) - comp(P.omega0, a)) -
+                              comp(P.alpha0, a));
+        ++row;
+      }
+    }
+    misc[0] = 0.0;  // status
+  }
+  cx.sync();
+
+  // ------------------------------------------------------------------ phase B: R~ by Givens row insertion
+  const double se = sqrt(C.wbc_eps);
+  for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Rm[idx] = (idx / NW == idx % NW) ? se : 0.0;
+  cx.sync();
+  // contact-force cost rows (weight w_force, WbcBase.cpp:325-338) are diagonal: fold into the diagonal start
+  if (!stance_mode && C.w_force != 0.0) {
+    for (int i = cx.lane; i < 12; i += cx.nlanes) Rm[(16 + i) * NW + 16 + i] = sqrt(C.wbc_eps + C.w_force * C.w_force);
+    cx.sync();
+  }
+  // right-hand side g = A_w' b_w accumulates in d (dense over 38)
+  for (int i = cx.lane; i < NW; i += cx.nlanes) {
+    double s = 0.0;
+    if (i < 16)
+      for (int rw = 0; rw < n_aw; ++rw) s += Aw[rw * 16 + i] * bw[rw];
+    else if (i < 28 && !stance_mode)
+      s = C.w_force * C.w_force * udes[i - 16];
+    d[i] = s;
+  }
+  for (int rw = 0; rw < n_aw; ++rw) {
+    for (int i = cx.lane; i < NW; i += cx.nlanes) np[i] = (i < 16) ? Aw[rw * 16 + i] : 0.0;
+    cx.sync();
+    for (int k = 0; k < 16; ++k) {  // the row is zero beyond column 15 and stays so
+      const double a = Rm[k * NW + k], b = np[k];
+      cx.sync();
+      if (b != 0.0) {
+        const double h = sqrt(a * a + b * b), cc = a / h, ss = b / h;
+        for (int j = cx.lane; j < NW; j += cx.nlanes) {
+          if (j >= k) {
+            const double t1 = Rm[k * NW + j], t2 = np[j];
+            Rm[k * NW + j] = cc * t1 + ss * t2;
+            np[j] = -ss * t1 + cc * t2;
+          }
+        }
+      }
+      cx.sync();
+    }
+  }
+  // J = R~^-1 (upper triangular inverse), one column per lane
+  for (int col = cx.lane; col < NW; col += cx.nlanes) {
+    for (int i = NW - 1; i > col; --i) Jm[i * NW + col] = 0.0;
+    for (int i = col; i >= 0; --i) {
+      double s = (i == col) ? 1.0 : 0.0;
+      for (int k = i + 1; k <= col; ++k) s -= Rm[i * NW + k] * Jm[k * NW + col];
+      Jm[i * NW + col] = s / Rm[i * NW + i];
+    }
+  }
+  cx.sync();
+  // unconstrained minimiser x = J J' g
+  for (int k = cx.lane; k < NW; k += cx.nlanes) {
+    double s = 0.0;
+    for (int i = 0; i < NW; ++i) s += Jm[i * NW + k] * d[i];
+    z[k] = s;
+  }
+  cx.sync();
+  for (int i = cx.lane; i < NW; i += cx.nlanes) {
+    double s = 0.0;
+    for (int k = 0; k < NW; ++k) s += Jm[i * NW + k] * z[k];
+    x[i] = s;
+  }
+  for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Rm[idx] = 0.0;
+  for (int i = cx.lane; i < 64; i += cx.nlanes) is_active[i] = 0;
+  cx.sync();
+
+  // ------------------------------------------------------------------ phase C: Goldfarb–Idnani iterations
+  int q = 0, iter = 0, status = 0;
+  int next_eq = 0;
+  const int n_cons = wc.n_eq + wc.n_in;
+  const double inf = 1e300;
+  while (true) {
+    int p = -1;
+    double sp = 0.0;
+    if (next_eq < wc.n_eq) {
+      p = next_eq++;
+    } else {
+      // most violated inequality (lane-parallel scan + reduction through LDS)
+      double best = 0.0;
+      int bi = -1;
+      for (int c = wc.n_eq + cx.lane; c < n_cons; c += cx.nlanes) {
+        if (is_active[c]) continue;
+        int idx[3];
+        double cfv[3], rhs;
+        const int nn = sparse_row(wc, C, c, idx, cfv, &rhs);
+        double s = -rhs;
+        for (int t = 0; t < nn; ++t) s += cfv[t] * x[idx[t]];
+        if (s > 1e-9 * fmax(1.0, fabs(rhs)) && s > best) { best = s; bi = c; }
+      }
+      red[cx.lane] = best;
+      cx.sync();
+      // serial arg-max over lane partials (nlanes <= 64)
+      double gb = 0.0;
+      int gl = -1;
+      for (int l = 0; l < cx.nlanes; ++l)
+        if (red[l] > gb) { gb = red[l]; gl = l; }
+      cx.sync();
+      if (gl < 0) break;  // optimal
+      if (cx.lane == gl) misc[1] = double(bi);
+      cx.sync();
+      p = int(misc[1]);
+      cx.sync();
+    }
+    const bool p_is_eq = p < wc.n_eq;
+    // dense normal of p into np, rhs in prhs
+    double prhs;
+    if (p < 16) {
+      for (int i = cx.lane; i < NW; i += cx.nlanes) np[i] = Ee[p * NW + i];
+      prhs = beom[p];
+    } else {
+      int idx[3];
+      double cfv[3];
+      const int nn = sparse_row(wc, C, p, idx, cfv, &prhs);
+      for (int i = cx.lane; i < NW; i += cx.nlanes) {
+        double vv = 0.0;
+        for (int t = 0; t < nn; ++t)
+          if (idx[t] == i) vv = cfv[t];
+        np[i] = vv;
+      }
+    }
+    cx.sync();
+    double lam_p = 0.0;
+    bool done_p = false;
+    while (!done_p) {
+      if (++iter > C.wbc_max_iter) { status = HB_INST_MAXITER; break; }
+      // sp = n'x - rhs ; d = J' n
+      for (int k = cx.lane; k < NW; k += cx.nlanes) {
+        double s = 0.0;
+        for (int i = 0; i < NW; ++i) s += Jm[i * NW + k] * np[i];
+        d[k] = s;
+      }
+      cx.sync();
+      {
+        double s = -prhs;
+        for (int i = 0; i < NW; ++i) s += np[i] * x[i];
+        sp = s;
+      }
+      // z = J2 d2 ; r = R^-1 d1 (column-oriented back substitution on a copy)
+      for (int i = cx.lane; i < NW; i += cx.nlanes) {
+        double s = 0.0;
+        for (int j = q; j < NW; ++j) s += Jm[i * NW + j] * d[j];
+        z[i] = s;
+        if (i < q) r[i] = d[i];
+      }
+      cx.sync();
+      for (int i = q - 1; i >= 0; --i) {
+        const double ri = r[i] / Rm[i * NW + i];
+        cx.sync();
+        for (int k = cx.lane; k < i; k += cx.nlanes) r[k] -= Rm[k * NW + i] * ri;
+        if (cx.lane == 0) r[i] = ri;
+        cx.sync();
+      }
+      double zn = 0.0, nn2 = 0.0;
+      for (int i = 0; i < NW; ++i) { zn += z[i] * np[i]; nn2 += np[i] * np[i]; }
+      const double t2 = (zn > 1e-14 * (1.0 + nn2)) ? sp / zn : inf;
+      const double dir = (p_is_eq && sp < 0.0) ? -1.0 : 1.0;
+      double t1 = inf;
+      int l = -1;
+      for (int j = 0; j < q; ++j) {
+        if (act[j] < wc.n_eq) continue;
+        const double rj = dir * r[j];
+        if (rj > 0.0) {
+          const double tj = lam[j] / rj;
+          if (tj < t1) { t1 = tj; l = j; }
+        }
+      }
+      const double t2abs = fabs(t2);
+      const double t = fmin(t1, t2abs);
+      if (t >= inf) { status = HB_INST_INFEASIBLE; break; }
+      cx.sync();
+      if (t2 >= inf) {
+        for (int j = cx.lane; j < q; j += cx.nlanes) lam[j] -= t * dir * r[j];
+        lam_p += t;
+      } else {
+        for (int k = cx.lane; k < NW; k += cx.nlanes) x[k] -= dir * t * z[k];
+        for (int j = cx.lane; j < q; j += cx.nlanes) lam[j] -= t * dir * r[j];
+        lam_p += t;
+      }
+      cx.sync();
+      if (t2 < inf && t == t2abs) {
+        // full step: add constraint p (Givens on the columns of J, from the bottom up)
+        for (int j = NW - 1; j > q; --j) {
+          const double a = d[j - 1], b = d[j];
+          cx.sync();
+          if (b != 0.0) {
+            const double h = sqrt(a * a + b * b), cc = a / h, ss = b / h;
+            for (int k = cx.lane; k < NW; k += cx.nlanes) {
+              const double t1j = Jm[k * NW + j - 1], t2j = Jm[k * NW + j];
+              Jm[k * NW + j - 1] = cc * t1j + ss * t2j;
+              Jm[k * NW + j] = -ss * t1j + cc * t2j;
+            }
+            if (cx.lane == 0) { d[j - 1] = h; d[j] = 0.0; }
+          }
+          cx.sync();
+        }
+        if (fabs(d[q]) > 1e-13 * fmax(1.0, fabs(Rm[0]))) {
+          for (int i = cx.lane; i <= q; i += cx.nlanes) Rm[i * NW + q] = d[i];
+          if (cx.lane == 0) { act[q] = p; lam[q] = lam_p; is_active[p] = 1; }
+          ++q;
+        }
+        cx.sync();
+        done_p = true;
+      } else {
+        // partial (or dual-only) step: drop active constraint l
+        if (cx.lane == 0) is_active[act[l]] = 0;
+        cx.sync();
+        for (int j = l; j < q - 1; ++j) {
+          for (int i = cx.lane; i <= j + 1; i += cx.nlanes) Rm[i * NW + j] = Rm[i * NW + j + 1];
+          if (cx.lane == 0) { act[j] = act[j + 1]; lam[j] = lam[j + 1]; }
+          cx.sync();
+        }
+        for (int i = cx.lane; i < q; i += cx.nlanes) Rm[i * NW + q - 1] = 0.0;
+        --q;
+        cx.sync();
+        for (int j = l; j < q; ++j) {
+          const double a = Rm[j * NW + j], b = Rm[(j + 1) * NW + j];
+          cx.sync();
+          if (b != 0.0) {
+            const double h = sqrt(a * a + b * b), cc = a / h, ss = b / h;
+            for (int k = cx.lane; k < NW; k += cx.nlanes) {
+              if (k >= j && k < q) {
+                const double t1j = Rm[j * NW + k], t2j = Rm[(j + 1) * NW + k];
+                Rm[j * NW + k] = cc * t1j + ss * t2j;
+                Rm[(j + 1) * NW + k] = -ss * t1j + cc * t2j;
+              }
+              const double u1 = Jm[k * NW + j], u2 = Jm[k * NW + j + 1];
+              Jm[k * NW + j] = cc * u1 + ss * u2;
+              Jm[k * NW + j + 1] = -ss * u1 + cc * u2;
+            }
+          }
+          cx.sync();
+          if (cx.lane == 0) Rm[(j + 1) * NW + j] = 0.0;
+          cx.sync();
+        }
+      }
+    }
+    if (status != 0) break;
+  }
+  cx.sync();
+  if (status == 0)
+    for (int i = cx.lane; i < NW; i += cx.nlanes) sol[i] = x[i];
+  if (cx.lane == 0) {
+    *status_out = status;
+    *iters_out = iter;
+  }
+}
+
+// MPC_MRT_Interface::evaluatePolicy with a feed-forward controller: linear interpolation of the state and
+// input trajectories, mode of the interval containing t (LeggedController.cpp:151-173).
+HB_HD void policy_eval(const DevConfig& C, int n, const double* t, const double* px, const double* pu, const int* pmode, double tn,
+                       const double* rbd, bool walk, double* xdes, double* udes, int* mode, int* stance) {
+  if (!walk) {
+    for (int i = 0; i < HB_NX; ++i) xdes[i] = 0.0;
+    for (int i = 0; i < HB_NU; ++i) udes[i] = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      xdes[6 + i] = rbd[3 + i];
+      xdes[9 + i] = rbd[i];
+    }
+    for (int j = 0; j < HB_NJ; ++j) xdes[12 + j] = C.default_joint_state[j];
+    *mode = 3;
+    *stance = 1;
+    return;
+  }
+  int k = 0;
+  while (k < n - 1 && tn >= t[k + 1]) ++k;
+  double a = (tn - t[k]) / (t[k + 1] - t[k]);
+  a = fmin(1.0, fmax(0.0, a));
+  for (int i = 0; i < HB_NX; ++i) xdes[i] = (1.0 - a) * px[k * HB_NX + i] + a * px[(k + 1) * HB_NX + i];
+  const int k1 = (k + 1 < n) ? k + 1 : k;  // the input trajectory repeats its last sample
+  for (int i = 0; i < HB_NU; ++i) udes[i] = (1.0 - a) * pu[k * HB_NU + i] + a * pu[k1 * HB_NU + i];
+  *mode = pmode[k];
+  *stance = 0;
+}
+
+#if defined(__HIPCC__)
+__global__ void k_policy_eval(WbcBatch w, int Nmax, const DevConfig* __restrict__ C) {
+  const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= w.B) return;
+  policy_eval(*C, w.pn[inst], w.pt + size_t(inst) * (Nmax + 1), w.px + size_t(inst) * (Nmax + 1) * HB_NX,
+              w.pu + size_t(inst) * Nmax * HB_NU, w.pmode + size_t(inst) * Nmax, w.t_now[inst], w.rbd + size_t(inst) * HB_NRBD,
+              w.walk[inst] != 0, w.xdes + size_t(inst) * HB_NX, w.udes + size_t(inst) * HB_NU, w.mode + inst, w.stance + inst);
+}
+
+struct WbcDeviceCtx {
+  int lane, nlanes;
+  __device__ WbcDeviceCtx() : lane(threadIdx.x), nlanes(blockDim.x) {}
+  __device__ void sync() const { __syncthreads(); }
+};
+
+__global__ __launch_bounds__(64) void k_wbc(WbcBatch w, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
+  const int inst = blockIdx.x;
+  __shared__ double lds[WbcLds::total];
+  wbc_solve(WbcDeviceCtx(), *M, *C, w.xdes + size_t(inst) * HB_NX, w.udes + size_t(inst) * HB_NU, w.rbd + size_t(inst) * HB_NRBD,
+            w.mode[inst], w.stance[inst] != 0, lds, w.sol + size_t(inst) * NW, w.status + inst, w.iters + inst);
+}
+
+__global__ void k_rbd(int n, const DevModel* __restrict__ M, const double* rbd, double* Mo, double* nle, double* J, double* dJv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* rb = rbd + size_t(i) * HB_NRBD;
+  double q[HB_NV], v[HB_NV];
+  for (int a = 0; a < 3; ++a) { q[a] = rb[3 + a]; q[3 + a] = rb[a]; v[a] = rb[HB_NV + 3 + a]; }
+  for (int j = 0; j < HB_NJ; ++j) { q[6 + j] = rb[6 + j]; v[6 + j] = rb[HB_NV + 6 + j]; }
+  double sz, cz, sy, cy;
+  sincos_t(q[3], sz, cz);
+  sincos_t(q[4], sy, cy);
+  const Vec3<double> er = euler_rates_from_omega<double>(sz, cz, sy, cy, Vec3<double>(rb[HB_NV], rb[HB_NV + 1], rb[HB_NV + 2]));
+  v[3] = er.x; v[4] = er.y; v[5] = er.z;
+  BodyPass P;
+  body_pass(*M, q, v, P);
+  mass_matrix(P, Mo + size_t(i) * 256);
+  for (int a = 0; a < 16; ++a) nle[size_t(i) * 16 + a] = P.nle[a];
+  for (int ci = 0; ci < HB_NC; ++ci) {
+    for (int col = 0; col < 16; ++col) {
+      const Vec3<double> jc = contact_jac(P, ci, col);
+      J[(size_t(i) * 12 + 3 * ci + 0) * 16 + col] = jc.x;
+      J[(size_t(i) * 12 + 3 * ci + 1) * 16 + col] = jc.y;
+      J[(size_t(i) * 12 + 3 * ci + 2) * 16 + col] = jc.z;
+    }
+    dJv[size_t(i) * 12 + 3 * ci + 0] = P.foot_acc[ci].x;
+    dJv[size_t(i) * 12 + 3 * ci + 1] = P.foot_acc[ci].y;
+    dJv[size_t(i) * 12 + 3 * ci + 2] = P.foot_acc[ci].z;
+  }
+}
+#endif
+
+}  // namespace hb

@@ -1,0 +1,213 @@
+"""ctypes binding of libhunter_hip.so (the C-ABI in include/hunter_hip.h).
+
+This is the host-side mirror of the reference's solver surface for the hot path:
+``MPC_MRT_Interface::{advanceMpc, updatePolicy, evaluatePolicy}`` and ``WbcBase::update``
+(legged_controllers/src/LeggedController.cpp:144-185).  There is no CPU fallback: importing works anywhere
+(so the ABI can be inspected), but creating a solver without the HIP library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import abi
+
+_LIB_PATH = Path(__file__).resolve().parent / "libhunter_hip.so"
+_lib = None
+
+# every symbol include/hunter_hip.h declares
+ABI_SYMBOLS = [
+    "hb_create", "hb_destroy", "hb_last_error", "hb_mpc_set_references", "hb_mpc_reset", "hb_mpc_set_trajectory",
+    "hb_mpc_solve", "hb_mpc_publish", "hb_mpc_get_solution", "hb_mpc_get_performance", "hb_mpc_get_step",
+    "hb_wbc_update", "hb_wbc_update_direct", "hb_set_resident_inputs", "hb_step_resident", "hb_get_wbc_solution",
+    "hb_sync", "hb_get_stats", "hb_get_input_cost", "hb_version", "hb_eval_flow_map", "hb_eval_foot_kinematics",
+    "hb_eval_rbd", "hb_riccati_solve",
+]
+
+
+class HunterHipError(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    """Load the in-tree HIP library; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise HunterHipError(f"{_LIB_PATH} not found: build it with hunter_bipedal_control_amd/csrc/build.sh "
+                                 "(the solver has no CPU fallback)")
+        _lib = C.CDLL(str(_LIB_PATH))
+        _lib.hb_last_error.restype = C.c_char_p
+        _lib.hb_last_error.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+def _i32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if shape is not None:
+        assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+class HunterSolver:
+    """Batched NMPC + WBC solver bound to one GPU."""
+
+    def __init__(self, params: dict, batch: int, max_nodes: int, device: int = 0, **cfg_overrides):
+        self.lib = load_library()
+        self.model = abi.make_model(params)
+        self.config = abi.make_config(params, **cfg_overrides)
+        self.B, self.N = int(batch), int(max_nodes)
+        self.ctx = C.c_void_p()
+        rc = self.lib.hb_create(C.byref(self.model), C.byref(self.config), C.c_int32(self.B), C.c_int32(self.N),
+                                C.c_int32(device), C.byref(self.ctx))
+        if rc != 0:
+            raise HunterHipError(f"hb_create failed ({rc}): {self.lib.hb_last_error(None).decode()}")
+
+    def close(self):
+        if getattr(self, "ctx", None) is not None and self.ctx.value:
+            self.lib.hb_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise HunterHipError(f"{what} failed ({rc}): {self.lib.hb_last_error(self.ctx).decode()}")
+
+    # ---- MPC ------------------------------------------------------------------------------------
+    def set_references(self, refs: dict, inst_begin: int = 0):
+        n_nodes = _i32(refs["n_nodes"])
+        cnt = n_nodes.shape[0]
+        t = _f64(refs["t"], (cnt, self.N + 1))
+        mode = _i32(refs["mode"], (cnt, self.N))
+        x_ref = _f64(refs["x_ref"], (cnt, self.N, 22))
+        swing = _f64(refs["swing"], (cnt, self.N, 4, 6))
+        self._check(self.lib.hb_mpc_set_references(self.ctx, C.c_int32(inst_begin), C.c_int32(cnt), _p(n_nodes), _p(t),
+                                                   _p(mode), _p(x_ref), _p(swing)), "hb_mpc_set_references")
+
+    def reset(self, x0):
+        self._check(self.lib.hb_mpc_reset(self.ctx, _p(_f64(x0, (self.B, 22)))), "hb_mpc_reset")
+
+    def set_trajectory(self, x, u):
+        self._check(self.lib.hb_mpc_set_trajectory(self.ctx, _p(_f64(x, (self.B, self.N + 1, 22))),
+                                                   _p(_f64(u, (self.B, self.N, 22)))), "hb_mpc_set_trajectory")
+
+    def mpc_solve(self, x0=None):
+        x0 = None if x0 is None else _f64(x0, (self.B, 22))
+        self._check(self.lib.hb_mpc_solve(self.ctx, _p(x0)), "hb_mpc_solve")
+
+    def publish(self):
+        self._check(self.lib.hb_mpc_publish(self.ctx), "hb_mpc_publish")
+
+    def get_solution(self):
+        x = np.zeros((self.B, self.N + 1, 22))
+        u = np.zeros((self.B, self.N, 22))
+        self._check(self.lib.hb_mpc_get_solution(self.ctx, C.c_int32(0), C.c_int32(self.B), _p(x), _p(u)), "hb_mpc_get_solution")
+        return x, u
+
+    def get_step(self):
+        dx = np.zeros((self.B, self.N + 1, 22))
+        du = np.zeros((self.B, self.N, 22))
+        self._check(self.lib.hb_mpc_get_step(self.ctx, _p(dx), _p(du)), "hb_mpc_get_step")
+        return dx, du
+
+    def get_performance(self):
+        perf = np.zeros((self.B, 4))
+        self._check(self.lib.hb_mpc_get_performance(self.ctx, _p(perf)), "hb_mpc_get_performance")
+        return perf
+
+    # ---- WBC ------------------------------------------------------------------------------------
+    def wbc_update(self, t_now, rbd, walk_flag=None, dt=0.002):
+        t_now = _f64(t_now, (self.B,))
+        rbd = _f64(rbd, (self.B, 32))
+        walk = None if walk_flag is None else _i32(walk_flag, (self.B,))
+        sol, xd, ud = np.zeros((self.B, 38)), np.zeros((self.B, 22)), np.zeros((self.B, 22))
+        mode, status = np.zeros(self.B, dtype=np.int32), np.zeros(self.B, dtype=np.int32)
+        self._check(self.lib.hb_wbc_update(self.ctx, _p(t_now), _p(rbd), _p(walk), C.c_double(dt), _p(sol), _p(xd), _p(ud),
+                                           _p(mode), _p(status)), "hb_wbc_update")
+        return dict(sol=sol, x_des=xd, u_des=ud, mode=mode, status=status)
+
+    def wbc_update_direct(self, x_des, u_des, rbd, mode, stance_flag=None, dt=0.002):
+        x_des, u_des, rbd = _f64(x_des, (self.B, 22)), _f64(u_des, (self.B, 22)), _f64(rbd, (self.B, 32))
+        mode = _i32(mode, (self.B,))
+        stance = None if stance_flag is None else _i32(stance_flag, (self.B,))
+        sol, status = np.zeros((self.B, 38)), np.zeros(self.B, dtype=np.int32)
+        self._check(self.lib.hb_wbc_update_direct(self.ctx, _p(x_des), _p(u_des), _p(rbd), _p(mode), _p(stance), C.c_double(dt),
+                                                  _p(sol), _p(status)), "hb_wbc_update_direct")
+        return sol, status
+
+    # ---- device-resident stepping -----------------------------------------------------------------
+    def set_resident_inputs(self, x0, t_now, rbd, walk_flag=None):
+        walk = None if walk_flag is None else _i32(walk_flag, (self.B,))
+        self._check(self.lib.hb_set_resident_inputs(self.ctx, _p(_f64(x0, (self.B, 22))), _p(_f64(t_now, (self.B,))),
+                                                    _p(_f64(rbd, (self.B, 32))), _p(walk)), "hb_set_resident_inputs")
+
+    def step_resident(self, dt=0.002):
+        self._check(self.lib.hb_step_resident(self.ctx, C.c_double(dt)), "hb_step_resident")
+
+    def get_wbc_solution(self):
+        sol, status = np.zeros((self.B, 38)), np.zeros(self.B, dtype=np.int32)
+        self._check(self.lib.hb_get_wbc_solution(self.ctx, _p(sol), _p(status)), "hb_get_wbc_solution")
+        return sol, status
+
+    def sync(self):
+        self._check(self.lib.hb_sync(self.ctx), "hb_sync")
+
+    def stats(self) -> dict:
+        st = abi.HbStats()
+        self._check(self.lib.hb_get_stats(self.ctx, C.byref(st)), "hb_get_stats")
+        return {k: (list(getattr(st, k)) if k == "n_status" else getattr(st, k)) for k, _ in abi.HbStats._fields_}
+
+    def input_cost(self):
+        R = np.zeros((22, 22))
+        self._check(self.lib.hb_get_input_cost(self.ctx, _p(R)), "hb_get_input_cost")
+        return R
+
+    # ---- unit-level ---------------------------------------------------------------------------------
+    def eval_flow_map(self, x, u, jac=False):
+        x, u = _f64(np.atleast_2d(x)), _f64(np.atleast_2d(u))
+        n = x.shape[0]
+        f = np.zeros((n, 22))
+        A = np.zeros((n, 22, 22)) if jac else None
+        Bm = np.zeros((n, 22, 22)) if jac else None
+        self._check(self.lib.hb_eval_flow_map(self.ctx, C.c_int32(n), _p(x), _p(u), _p(f), _p(A), _p(Bm)), "hb_eval_flow_map")
+        return (f, A, Bm) if jac else f
+
+    def eval_foot_kinematics(self, x, u):
+        x, u = _f64(np.atleast_2d(x)), _f64(np.atleast_2d(u))
+        n = x.shape[0]
+        pos, vel = np.zeros((n, 4, 3)), np.zeros((n, 4, 3))
+        self._check(self.lib.hb_eval_foot_kinematics(self.ctx, C.c_int32(n), _p(x), _p(u), _p(pos), _p(vel)), "hb_eval_foot_kinematics")
+        return pos, vel
+
+    def eval_rbd(self, rbd):
+        rbd = _f64(np.atleast_2d(rbd))
+        n = rbd.shape[0]
+        M, nle, J, dJv = np.zeros((n, 16, 16)), np.zeros((n, 16)), np.zeros((n, 12, 16)), np.zeros((n, 12))
+        self._check(self.lib.hb_eval_rbd(self.ctx, C.c_int32(n), _p(rbd), _p(M), _p(nle), _p(J), _p(dJv)), "hb_eval_rbd")
+        return M, nle, J, dJv
+
+    def riccati_solve(self, A, Bm, b, Q, R, P, q, r, dx0):
+        A, Bm, b, Q, R, P, q, r, dx0 = map(_f64, (A, Bm, b, Q, R, P, q, r, dx0))
+        n, N, nu = A.shape[0], A.shape[1], Bm.shape[3]
+        dx, du = np.zeros((n, N + 1, 22)), np.zeros((n, N, nu))
+        self._check(self.lib.hb_riccati_solve(self.ctx, C.c_int32(n), C.c_int32(N), C.c_int32(nu), _p(A), _p(Bm), _p(b), _p(Q), _p(R),
+                                              _p(P), _p(q), _p(r), _p(dx0), _p(dx), _p(du)), "hb_riccati_solve")
+        return dx, du

@@ -198,11 +198,16 @@ int32_t hb_eval_foot_kinematics(hb_ctx* ctx, int32_t n, const double* x, const d
                                 double* pos /*[n][4][3]*/, double* vel /*[n][4][3]*/);
 /* Rigid-body quantities of WbcBase::updateMeasured (WbcBase.cpp:70-120): M[16][16], nle[16], J[12][16], dJv[12]. */
 int32_t hb_eval_rbd(hb_ctx* ctx, int32_t n, const double* rbd, double* M, double* nle, double* J, double* dJv);
-/* Solve a batch of equality-free LQ problems with the Riccati kernels (HPIPM's role):
- * stage data row-major, nu_k <= 22 inputs per stage given in nu[n][N]. */
-int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, const double* A, const double* B, const double* b,
-                         const double* Q, const double* R, const double* P, const double* q, const double* r,
-                         const double* dx0, double* dx /*[n][N+1][22]*/, double* du /*[n][N][22]*/);
+/* Solve a batch of equality-free LQ problems (n <= batch, N <= max_nodes, nu <= 12 inputs per stage) with the
+ * Riccati backward kernel (HPIPM's role).  Stage data row-major: A[n][N][22][22], B[n][N][22][nu],
+ * b[n][N][22], Q[n][N][22][22], R[n][N][nu][nu], P[n][N][nu][22], q[n][N][22], r[n][N][nu], dx0[n][22].
+ * Clobbers the MPC reference tables of the context (call hb_mpc_set_references again afterwards). */
+int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, int32_t nu, const double* A, const double* B,
+                         const double* b, const double* Q, const double* R, const double* P, const double* q,
+                         const double* r, const double* dx0, double* dx /*[n][N+1][22]*/, double* du /*[n][N][nu]*/);
+/* QP step of the last SQP iteration (before the line search scaled it): dx[batch][max_nodes+1][22],
+ * du[batch][max_nodes][22]; either may be NULL. */
+int32_t hb_mpc_get_step(hb_ctx* ctx, double* dx, double* du);
 
 #ifdef __cplusplus
 }

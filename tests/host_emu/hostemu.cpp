@@ -1,0 +1,127 @@
+// TEST HARNESS: compiles the device headers for the host (g++) so the per-thread math and the lane-cooperative
+// algorithms can be checked against the oracle in the CPU-only container (one emulated lane, barriers are
+// no-ops).  Not part of the product; the product path always runs the HIP kernels.
+#include <cstring>
+#include <vector>
+#include "../../hunter_bipedal_control_amd/csrc/hb_host.hpp"
+#include "../../hunter_bipedal_control_amd/csrc/hb_riccati.hpp"
+
+using namespace hb;
+namespace {
+struct HostCtx {
+  int lane = 0, nlanes = 1;
+  void sync() const {}
+};
+}  // namespace
+
+extern "C" {
+void emu_flow_map(const hb_model* m, const double* x, const double* u, double* f, double* foot_pos, double* foot_vel) {
+  DevModel d = make_dev_model(*m);
+  Centroidal<double> c;
+  flow_map<double>(d, x, u, f, &c);
+  for (int i = 0; i < 4; ++i) {
+    foot_pos[3 * i] = x[6] + c.foot_rel[i].x; foot_pos[3 * i + 1] = x[7] + c.foot_rel[i].y; foot_pos[3 * i + 2] = x[8] + c.foot_rel[i].z;
+    foot_vel[3 * i] = c.foot_vel[i].x; foot_vel[3 * i + 1] = c.foot_vel[i].y; foot_vel[3 * i + 2] = c.foot_vel[i].z;
+  }
+}
+void emu_flow_jac(const hb_model* m, const double* x, const double* u, double* jac) {
+  DevModel d = make_dev_model(*m);
+  for (int dir = 0; dir < 44; ++dir) {
+    Dual1 xd[22], ud[22], fd[22];
+    for (int i = 0; i < 22; ++i) { xd[i] = Dual1(x[i], dir == i ? 1.0 : 0.0); ud[i] = Dual1(u[i], dir == 22 + i ? 1.0 : 0.0); }
+    flow_map<Dual1>(d, xd, ud, fd);
+    for (int i = 0; i < 22; ++i) jac[i * 44 + dir] = fd[i].d;
+  }
+}
+void emu_input_cost(const hb_model* m, const hb_config* c, double* Rjj) {
+  DevModel d = make_dev_model(*m);
+  DevConfig dc = make_dev_config(*c, d);
+  std::memcpy(Rjj, dc.R_jj, sizeof(dc.R_jj));
+}
+// node record of one node
+void emu_lq_node(const hb_model* m, const hb_config* c, double dt, int mode, const double* xref, const double* swing,
+                 const double* x, const double* u, const double* xnext, double* rec) {
+  DevModel d = make_dev_model(*m);
+  DevConfig dc = make_dev_config(*c, d);
+  std::vector<double> lds(LqLds::total, 0.0);
+  NodeIn in{x, u, xnext, xref, swing, dt, mode};
+  lq_node(HostCtx{}, d, dc, in, lds.data(), rec);
+}
+// One full SQP iteration of one instance with the device algorithms. x,u in/out. Returns accepted step size.
+double emu_sqp_iteration(const hb_model* m, const hb_config* c, int N, const double* t, const int* mode, const double* xref,
+                         const double* swing, const double* x0, double* x, double* u, double* dx_out, double* du_out,
+                         double* perf4) {
+  DevModel d = make_dev_model(*m);
+  DevConfig dc = make_dev_config(*c, d);
+  HostCtx cx;
+  std::vector<double> recs(size_t(N) * REC_SIZE), gains(size_t(N) * GAIN_SIZE);
+  std::vector<double> lds(LqLds::total, 0.0);
+  for (int i = 0; i < 22; ++i) x[i] = x0[i];
+  for (int k = 0; k < N; ++k) {
+    NodeIn in{x + k * 22, u + k * 22, x + (k + 1) * 22, xref + k * 22, swing + k * 24, t[k + 1] - t[k], mode[k]};
+    lq_node(cx, d, dc, in, lds.data(), recs.data() + size_t(k) * REC_SIZE);
+  }
+  std::vector<double> rl(RicLds::total, 0.0);
+  for (int k = N - 1; k >= 0; --k) {
+    std::memcpy(rl.data() + RicLds::node, recs.data() + size_t(k) * REC_SIZE, sizeof(double) * REC_RICCATI_END);
+    riccati_bwd_node(cx, rl.data(), gains.data() + size_t(k) * GAIN_SIZE);
+  }
+  std::vector<double> fl(FwdLds::total, 0.0);
+  std::vector<double> dx(size_t(N + 1) * 22), du(size_t(N) * 22);
+  for (int k = 0; k < N; ++k)
+    riccati_fwd_node(cx, fl.data(), recs.data() + size_t(k) * REC_SIZE, gains.data() + size_t(k) * GAIN_SIZE, dx.data() + k * 22,
+                     du.data() + k * 22);
+  for (int i = 0; i < 22; ++i) dx[size_t(N) * 22 + i] = fl[FwdLds::dx + i];
+  const double armijo = fl[FwdLds::acc + 0], base_merit = fl[FwdLds::acc + 1];
+  const double base_viol = std::sqrt(fl[FwdLds::acc + 2] + fl[FwdLds::acc + 3]);
+  if (dx_out) std::memcpy(dx_out, dx.data(), dx.size() * 8);
+  if (du_out) std::memcpy(du_out, du.data(), du.size() * 8);
+  double alpha = 1.0;
+  std::vector<double> xt((N + 1) * 22), ut(N * 22);
+  perf4[0] = base_merit; perf4[1] = fl[FwdLds::acc + 2]; perf4[2] = fl[FwdLds::acc + 3]; perf4[3] = 0.0;
+  while (alpha >= dc.alpha_min) {
+    for (size_t i = 0; i < xt.size(); ++i) xt[i] = x[i] + alpha * dx[i];
+    for (size_t i = 0; i < ut.size(); ++i) ut[i] = u[i] + alpha * du[i];
+    double merit = 0, dyn = 0, eq = 0;
+    for (int k = 0; k < N; ++k) {
+      double o3[3];
+      node_value(d, dc, xt.data() + k * 22, ut.data() + k * 22, xt.data() + (k + 1) * 22, xref + k * 22, swing + k * 24,
+                 t[k + 1] - t[k], mode[k], o3);
+      merit += o3[0]; dyn += o3[1]; eq += o3[2];
+    }
+    if (filter_accept(dc, base_merit, base_viol, merit, std::sqrt(dyn + eq), alpha, armijo)) {
+      std::memcpy(x, xt.data(), xt.size() * 8);
+      std::memcpy(u, ut.data(), ut.size() * 8);
+      perf4[0] = merit; perf4[1] = dyn; perf4[2] = eq; perf4[3] = alpha;
+      return alpha;
+    }
+    alpha *= dc.alpha_decay;
+  }
+  return 0.0;
+}
+}
+
+#include "../../hunter_bipedal_control_amd/csrc/hb_wbc.hpp"
+extern "C" {
+void emu_rbd(const hb_model* m, const double* q, const double* v, double* Mo, double* nle, double* J, double* dJv) {
+  DevModel d = make_dev_model(*m);
+  BodyPass P;
+  body_pass(d, q, v, P);
+  mass_matrix(P, Mo);
+  for (int a = 0; a < 16; ++a) nle[a] = P.nle[a];
+  for (int ci = 0; ci < 4; ++ci) {
+    for (int col = 0; col < 16; ++col) {
+      const Vec3<double> jc = contact_jac(P, ci, col);
+      J[(3 * ci + 0) * 16 + col] = jc.x; J[(3 * ci + 1) * 16 + col] = jc.y; J[(3 * ci + 2) * 16 + col] = jc.z;
+    }
+    dJv[3 * ci] = P.foot_acc[ci].x; dJv[3 * ci + 1] = P.foot_acc[ci].y; dJv[3 * ci + 2] = P.foot_acc[ci].z;
+  }
+}
+void emu_wbc(const hb_model* m, const hb_config* c, const double* xdes, const double* udes, const double* rbd, int mode, int stance,
+             double* sol, int* status, int* iters) {
+  DevModel d = make_dev_model(*m);
+  DevConfig dc = make_dev_config(*c, d);
+  std::vector<double> lds(WbcLds::total, 0.0);
+  wbc_solve(HostCtx{}, d, dc, xdes, udes, rbd, mode, stance != 0, lds.data(), sol, status, iters);
+}
+}

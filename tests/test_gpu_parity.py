@@ -1,0 +1,209 @@
+"""GPU parity: HIP kernels (through the C-ABI) vs the CPU oracle on seeded inputs.
+
+Tolerances (f64 parity mode): model functions 1e-10, Riccati 1e-9, SQP trajectories 1e-7,
+WBC solution 1e-5 (regularised-minimiser rule) with EoM residual 1e-8.
+"""
+import numpy as np
+import pytest
+
+from hunter_bipedal_control_amd import refgen, workload
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver_small(params):
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    s = HunterSolver(params, batch=8, max_nodes=50)
+    yield s
+    s.close()
+
+
+def _rand_xu(params, n, seed):
+    rng = np.random.default_rng(seed)
+    x0 = np.array(params["config"]["initial_state"])
+    x = x0 + 0.2 * rng.standard_normal((n, 22))
+    u = rng.standard_normal((n, 22)) * np.r_[np.full(12, 20.0), np.full(10, 1.0)]
+    return x, u
+
+
+def test_flow_map_and_jacobian(params, oracle, solver_small):
+    x, u = _rand_xu(params, 16, 0)
+    f, A, B = solver_small.eval_flow_map(x, u, jac=True)
+    fo, Ao, Bo = oracle.flow_map(x, u, jac=True)
+    assert np.abs(f - fo).max() < 1e-10
+    assert np.abs(A - Ao).max() < 1e-10
+    assert np.abs(B - Bo).max() < 1e-10
+    pos, vel = solver_small.eval_foot_kinematics(x, u)
+    po, vo = oracle.foot_kinematics(x, u)
+    assert np.abs(pos - po).max() < 1e-12 and np.abs(vel - vo).max() < 1e-10
+
+
+def test_rbd(params, oracle, solver_small):
+    rng = np.random.default_rng(1)
+    x0 = np.array(params["config"]["initial_state"])
+    rbd = np.zeros((12, 32))
+    for i in range(12):
+        x = x0 + 0.1 * rng.standard_normal(22)
+        rbd[i] = workload.rbd_from_state(x, i)
+        rbd[i, 16:] = 0.5 * rng.standard_normal(16)
+    M, nle, J, dJv = solver_small.eval_rbd(rbd)
+    Mo, no, Jo, do = oracle.rbd(rbd)
+    assert np.abs(M - Mo).max() < 1e-12
+    assert np.abs(nle - no).max() < 1e-10
+    assert np.abs(J - Jo).max() < 1e-12
+    assert np.abs(dJv - do).max() < 1e-10
+
+
+def test_riccati(params, oracle, solver_small):
+    rng = np.random.default_rng(2)
+    n, N, nu = 3, 30, 9
+    A = np.eye(22) + 0.05 * rng.standard_normal((n, N, 22, 22))
+    B = 0.1 * rng.standard_normal((n, N, 22, nu))
+    b = 0.01 * rng.standard_normal((n, N, 22))
+    def spd(k, shape):
+        m = rng.standard_normal(shape + (k, k))
+        return m @ np.swapaxes(m, -1, -2) + 0.5 * np.eye(k)
+    Q, R = spd(22, (n, N)), spd(nu, (n, N))
+    P = 0.05 * rng.standard_normal((n, N, nu, 22))
+    q, r = rng.standard_normal((n, N, 22)), rng.standard_normal((n, N, nu))
+    dx0 = 0.1 * rng.standard_normal((n, 22))
+    dx, du = solver_small.riccati_solve(A, B, b, Q, R, P, q, r, dx0)
+    for i in range(n):
+        dxo, duo = oracle.riccati(A[i], B[i], b[i], Q[i], R[i], P[i], q[i], r[i], dx0[i])
+        scale = max(1.0, np.abs(dxo).max())
+        assert np.abs(dx[i] - dxo).max() < 1e-9 * scale
+        assert np.abs(du[i] - duo).max() < 1e-9 * scale
+
+
+def test_sqp_iterations_match_oracle(params, oracle, solver_small):
+    B, nmax = 8, 50
+    refs, x0, rbd, t_now = workload.trot_batch(params, B, n_intervals=50, cmd_vel=(0.3, 0.0, 0.0, 0.1), max_nodes=nmax)
+    s = solver_small
+    s.set_references(refs)
+    s.reset(x0)
+    xo = np.zeros((B, nmax + 1, 22))
+    uo = np.zeros((B, nmax, 22))
+    for i in range(B):
+        n = refs["n_nodes"][i]
+        xc, uc = oracle.cold_start(refs["mode"][i, :n], x0[i])
+        xo[i, :n + 1], uo[i, :n] = xc, uc
+    xg, ug = s.get_solution()
+    assert np.abs(xg - xo).max() == 0.0 and np.abs(ug - uo).max() < 1e-12
+    for it in range(4):
+        perf_o, dxo, duo = oracle.mpc_solve(refs, x0, xo, uo, iters=1, threads=4, want_step=True)
+        s.mpc_solve(x0)
+        dxg, dug = s.get_step()
+        xg, ug = s.get_solution()
+        perf_g = s.get_performance()
+        assert np.abs(dxg - dxo).max() < 1e-8, (it, np.abs(dxg - dxo).max())
+        assert np.abs(dug - duo).max() < 1e-6, (it, np.abs(dug - duo).max())
+        assert np.array_equal(perf_g[:, 3], perf_o[:, 3]), "accepted step sizes differ"
+        assert np.abs(xg - xo).max() < 1e-7 and np.abs(ug - uo).max() < 1e-6
+        assert np.allclose(perf_g[:, :3], perf_o[:, :3], rtol=1e-8, atol=1e-9)
+    # after 4 iterations the shooting defects are closed
+    assert perf_g[:, 1].max() < 1e-6
+
+
+def test_wbc_direct_matches_oracle(params, oracle):
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B = 64
+    rng = np.random.default_rng(7)
+    x0 = np.array(params["config"]["initial_state"])
+    mass = sum(params["model"]["mass"])
+    xd, ud, rbd = np.zeros((B, 22)), np.zeros((B, 22)), np.zeros((B, 32))
+    mode, stance = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+    for i in range(B):
+        mode[i] = [3, 3, 2, 1, 0][i % 5]
+        stance[i] = 1 if i % 5 == 0 else 0
+        cf = refgen.mode_to_contact_flags(int(mode[i]))
+        for k in range(4):
+            if cf[k]:
+                ud[i, 3 * k:3 * k + 3] = [3 * rng.standard_normal(), 3 * rng.standard_normal(), mass * 9.81 / max(sum(cf), 1)]
+        ud[i, 12:] = 0.5 * rng.standard_normal(10)
+        xd[i] = x0 + 0.05 * rng.standard_normal(22)
+        rbd[i] = workload.rbd_from_state(x0 + 0.03 * rng.standard_normal(22), i)
+        rbd[i, 16:] = 0.3 * rng.standard_normal(16)
+    s = HunterSolver(params, batch=B, max_nodes=4)
+    try:
+        sol, status = s.wbc_update_direct(xd, ud, rbd, mode, stance)
+    finally:
+        s.close()
+    so, sto, _ = oracle.wbc_update(xd, ud, rbd, mode, stance_flag=stance, threads=4)
+    assert np.array_equal(status, sto) and status.max() == 0
+    scale = np.maximum(1.0, np.abs(so).max(axis=1, keepdims=True))
+    assert (np.abs(sol - so) / scale).max() < 1e-7
+    assert np.abs(sol[:, 28:] - so[:, 28:]).max() < 1e-5  # torques, N m
+    # equation of motion residual and inequality feasibility on the GPU result itself
+    for i in range(0, B, 7):
+        pr = oracle.wbc_problem(xd[i], ud[i], rbd[i], int(mode[i]), bool(stance[i]))
+        assert np.abs(pr["Aeq"] @ sol[i] - pr["beq"]).max() < 1e-8
+        assert (pr["D"] @ sol[i] - pr["f"]).max() < 1e-8
+
+
+def test_full_update_through_policy(params, oracle, solver_small):
+    """hb_step_resident = MPC iteration + publish + policy evaluation + WBC, vs the same composition on the oracle."""
+    B, nmax = 8, 50
+    refs, x0, rbd, t_now = workload.trot_batch(params, B, n_intervals=50, max_nodes=nmax)
+    s = solver_small
+    s.set_references(refs)
+    s.reset(x0)
+    s.set_resident_inputs(x0, t_now, rbd)
+    s.step_resident()
+    sol, status = s.get_wbc_solution()
+    xg, ug = s.get_solution()
+    # oracle composition
+    xo = np.zeros((B, nmax + 1, 22)); uo = np.zeros((B, nmax, 22))
+    for i in range(B):
+        n = refs["n_nodes"][i]
+        xo[i, :n + 1], uo[i, :n] = oracle.cold_start(refs["mode"][i, :n], x0[i])
+    oracle.mpc_solve(refs, x0, xo, uo, iters=1, threads=4)
+    assert np.abs(xg - xo).max() < 1e-7
+    xd, ud, md = np.zeros((B, 22)), np.zeros((B, 22)), np.zeros(B, dtype=np.int32)
+    for i in range(B):
+        t = refs["t"][i]
+        k = 0
+        while k < refs["n_nodes"][i] - 1 and t_now[i] >= t[k + 1]:
+            k += 1
+        a = (t_now[i] - t[k]) / (t[k + 1] - t[k])
+        xd[i] = (1 - a) * xo[i, k] + a * xo[i, k + 1]
+        k1 = min(k + 1, refs["n_nodes"][i] - 1)
+        ud[i] = (1 - a) * uo[i, k] + a * uo[i, k1]
+        md[i] = refs["mode"][i, k]
+    so, sto, _ = oracle.wbc_update(xd, ud, rbd, md, stance_flag=np.zeros(B, dtype=np.int32), threads=4)
+    assert np.array_equal(status, sto)
+    scale = np.maximum(1.0, np.abs(so).max(axis=1, keepdims=True))
+    assert (np.abs(sol - so) / scale).max() < 1e-6
+
+
+def test_full_size_properties(params, oracle):
+    """BASELINE config sizes (batch 4096 is exercised by bench.py; here 512 x N=100): size-independent properties —
+    closed shooting defects, satisfied equality constraints, monotone merit, WBC feasibility."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B, N = 512, 100
+    refs1, x01, rbd1, tn1 = workload.trot_batch(params, 16, n_intervals=N)
+    reps = B // 16
+    refs = {k: np.concatenate([v] * reps) for k, v in refs1.items()}
+    x0, rbd, t_now = np.concatenate([x01] * reps), np.concatenate([rbd1] * reps), np.concatenate([tn1] * reps)
+    s = HunterSolver(params, batch=B, max_nodes=N)
+    try:
+        s.set_references(refs)
+        s.reset(x0)
+        s.set_resident_inputs(x0, t_now, rbd)
+        merits = []
+        for it in range(5):
+            s.step_resident()
+            merits.append(s.get_performance())
+        perf = merits[-1]
+        sol, status = s.get_wbc_solution()
+        x, u = s.get_solution()
+    finally:
+        s.close()
+    assert np.isfinite(x).all() and np.isfinite(u).all() and np.isfinite(sol).all()
+    assert (perf[:, 3] > 0).all(), "line search must accept a step"
+    assert perf[:, 1].max() < 1e-7 and perf[:, 2].max() < 1e-5, perf[:, 1:3].max(axis=0)
+    # replicas of the same instance give bit-identical results (no cross-instance coupling, deterministic kernels)
+    assert np.array_equal(x[:16], x[16:32]) and np.array_equal(sol[:16], sol[16:32])
+    assert status.max() == 0
+    tl = np.tile(np.array(params["config"]["torque_limits"]), 2)
+    assert (np.abs(sol[:, 28:]) <= tl + 1e-8).all()

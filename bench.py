@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MPC+WBC updates/sec on a batch of 4096 hunter instances (N = 100) per MI355X.
+
+One *update* = for one robot instance: 1 MPC solve (1 SQP iteration: LQ approximation + constraint projection +
+Riccati backward/forward + filter line search + policy write) **plus** 1 WBC solve (policy evaluation + rigid-body
+dynamics + task assembly + QP)  (SURVEY.md §8d).  A *step* = one such update for every instance of the batch, with all
+inputs already resident in HBM (hb_step_resident); nothing crosses PCIe inside the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: independent instances are sharded across ranks (weak scaling: 4096 instances per GPU, no data-path
+collective; RCCL only for the barrier / max-over-ranks of the timing).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# Algorithmic bytes per shooting node, f64 (restated per kernel in DESIGN.md §Roofline):
+BYTES_PER_NODE = {
+    "k_lq": 2486 * 8 + 88 * 8,              # LQ tensors written once + trajectory read
+    "k_ric_bwd": 2486 * 8 + 506 * 8,        # LQ tensors read once + gains written
+    "k_ric_fwd": 506 * 8 + 88 * 8,          # gains read + trajectory step written
+}
+BYTES_PER_UPDATE = lambda N: 48576 * N + 352 + 912  # noqa: E731  whole update
+
+
+def make_batch(params, batch, n_intervals, first_inst):
+    """Seeded synthetic batch; 64 distinct instances tiled to the batch size to keep host set-up short."""
+    from hunter_bipedal_control_amd import workload
+    distinct = min(batch, 64)
+    refs1, x01, rbd1, tn1 = workload.trot_batch(params, distinct, n_intervals=n_intervals, first_inst=first_inst)
+    reps = (batch + distinct - 1) // distinct
+    refs = {k: np.concatenate([v] * reps)[:batch] for k, v in refs1.items()}
+    cat = lambda a: np.concatenate([a] * reps)[:batch]  # noqa: E731
+    return refs, cat(x01), cat(rbd1), cat(tn1)
+
+
+def cpu_baseline(params, n_intervals, seconds_budget=20.0):
+    """Times the CPU oracle ("port": a restatement of OCS2 + qpOASES semantics, not the upstream binaries) on the
+    host cores for a bounded sample of the same workload."""
+    from oracle.pyoracle import Oracle
+    cores = os.cpu_count() or 1
+    o = Oracle(params)
+    n = cores  # one instance per core and repetition
+    refs, x0, rbd, t_now = make_batch(params, n, n_intervals, first_inst=0)
+    nmax = refs["mode"].shape[1]
+    x = np.zeros((n, nmax + 1, 22))
+    u = np.zeros((n, nmax, 22))
+    for i in range(n):
+        x[i], u[i] = o.cold_start(refs["mode"][i], x0[i])
+    o.mpc_solve(refs, x0, x, u, iters=1, threads=cores)  # warm-up (also warm start of the timed solves)
+    done, t_mpc, t_wbc = 0, 0.0, 0.0
+    t_start = time.perf_counter()
+    while done == 0 or (time.perf_counter() - t_start) < seconds_budget * 0.5:
+        t0 = time.perf_counter()
+        o.mpc_solve(refs, x0, x, u, iters=1, threads=cores)
+        t1 = time.perf_counter()
+        xd, ud, md = x[:, 0].copy(), u[:, 0].copy(), refs["mode"][:, 0].copy()
+        o.wbc_update(xd, ud, rbd, md, stance_flag=np.zeros(n, dtype=np.int32), threads=cores)
+        t2 = time.perf_counter()
+        t_mpc += t1 - t0
+        t_wbc += t2 - t1
+        done += n
+    total = t_mpc + t_wbc
+    return {
+        "value": done / total, "unit": "updates/s", "cores": cores, "kind": "port",
+        "sample": f"{done} updates ({n} instances x {done // n} repetitions, N={n_intervals}, warm-started) on {cores} threads; "
+                  f"MPC {1e3 * t_mpc / done * cores:.1f} ms and WBC {1e3 * t_wbc / done * cores:.3f} ms per instance per core",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--nodes", type=int, default=100, help="shooting intervals N")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from hunter_bipedal_control_amd import ingest
+    from hunter_bipedal_control_amd.solver import HunterSolver
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the solver has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl")  # RCCL
+
+    params = ingest.load_packaged()
+    B, N = args.batch, args.nodes
+    refs, x0, rbd, t_now = make_batch(params, B, N, first_inst=rank * B)
+    s = HunterSolver(params, batch=B, max_nodes=N, device=local_rank)
+    s.set_references(refs)
+    s.reset(x0)
+    s.set_resident_inputs(x0, t_now, rbd)
+
+    def barrier():
+        s.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        s.step_resident()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s.step_resident()
+    s.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+
+    # per-kernel device time: HIP events recorded on the library's own MPC / WBC streams (hb_get_stats), averaged
+    # over extra un-timed steps with a sync after each so the events are complete.
+    phases = {"k_lq": 0.0, "k_ric_bwd": 0.0, "k_ric_fwd": 0.0, "linesearch": 0.0, "k_wbc": 0.0}
+    n_prof = 5
+    for _ in range(n_prof):
+        s.step_resident()
+        st = s.stats()
+        phases["k_lq"] += st["ms_lq"] / n_prof
+        phases["k_ric_bwd"] += st["ms_riccati_bwd"] / n_prof
+        phases["k_ric_fwd"] += st["ms_riccati_fwd"] / n_prof
+        phases["linesearch"] += st["ms_linesearch"] / n_prof
+        phases["k_wbc"] += st["ms_wbc"] / n_prof
+    perf = s.get_performance()
+    sol, status = s.get_wbc_solution()
+    s.close()
+
+    if rank == 0:
+        dom = max(("k_lq", "k_ric_bwd", "k_ric_fwd"), key=lambda k: phases[k])
+        alg_bytes = BYTES_PER_NODE[dom] * N * B
+        achieved = alg_bytes / (phases[dom] * 1e-3) / 1e9
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_latest.json"
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPC+WBC updates/sec (batch=4096, N=100, 12-DoF)",
+            "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"batch={B}/GPU hunter instances, trot gait, N={N} shooting intervals (dt 0.015 s), "
+                                   "1 SQP iteration + WeightedWbc per update, inputs resident in HBM (BASELINE.json configs[2])",
+                       "batch_per_gpu": B, "horizon_nodes": N, "parallelism": f"instances sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": phases[dom],
+                         "whole_update_frac_of_hbm_roofline": (BYTES_PER_UPDATE(N) * value / world) / (HBM_PEAK_GBS * 1e9)},
+            "phase_ms": phases,
+            "solver_state": {"max_dyn_sse": float(perf[:, 1].max()), "max_eq_sse": float(perf[:, 2].max()),
+                             "wbc_status_nonzero": int((status != 0).sum())},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(params, N)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

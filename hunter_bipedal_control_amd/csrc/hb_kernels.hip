@@ -70,7 +70,7 @@ __global__ void k_cold_start(Batch b, const DevModel* __restrict__ M) {
   }
 }
 
-__global__ __launch_bounds__(64) void k_lq(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
+__global__ __launch_bounds__(64, 2) void k_lq(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
   const int k = blockIdx.x, inst = blockIdx.y;
   if (k >= b.n_nodes[inst]) return;
   __shared__ double lds[LqLds::total];
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
 }
 
 // line search: value of trial point (x + alpha dx, u + alpha du), one thread per node
-__global__ __launch_bounds__(64) void k_ls_eval(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C,
+__global__ __launch_bounds__(64, 2) void k_ls_eval(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C,
                                                 double alpha) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int inst = gid / b.Nmax, k = gid % b.Nmax;

@@ -127,51 +127,104 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   mode_flags(in.mode, cf);
 
   // -------------------------------------------------------------- phase 1: dual pass per direction
+  // Values of x,u are the same for every lane: they are staged in LDS and re-read where needed so that only
+  // tangents and the running state of the evaluation occupy registers.
+  double* xs = Kx;        // 22 (Kx/Z are not live yet)
+  double* us = Kx + 22;   // 22
+  for (int i = cx.lane; i < 22; i += cx.nlanes) {
+    xs[i] = in.x[i];
+    us[i] = in.u[i];
+  }
+  cx.sync();
   for (int dir = cx.lane; dir < 44; dir += cx.nlanes) {
-    Dual1 xd[HB_NX], ud[HB_NU], f1[HB_NX], f2[HB_NX];
+    Dual1 zyx[3], hn[6], f1[12];
 #pragma unroll
-    for (int i = 0; i < HB_NX; ++i) {
-      xd[i] = Dual1(in.x[i], dir == i ? 1.0 : 0.0);
-      ud[i] = Dual1(in.u[i], dir == HB_NX + i ? 1.0 : 0.0);
-    }
-    Centroidal<Dual1> c1;
-    flow_map<Dual1>(M, xd, ud, f1, &c1);
-    // constraint rows: slot 3i+a
+    for (int i = 0; i < 6; ++i) hn[i] = Dual1(xs[i], dir == i ? 1.0 : 0.0);
 #pragma unroll
-    for (int i = 0; i < HB_NC; ++i) {
-      const Dual1 pz = xd[8] + c1.foot_rel[i].z;
-      const Dual1 px = xd[6] + c1.foot_rel[i].x, py = xd[7] + c1.foot_rel[i].y;
-      Dual1 r0, r1, r2;
-      if (cf[i]) {  // zero velocity (LeggedInterface.cpp:436-444)
-        r0 = c1.foot_vel[i].x;
-        r1 = c1.foot_vel[i].y;
-        r2 = c1.foot_vel[i].z + C.zv_gain * pz + C.zv_off;
-      } else {      // normal velocity + xy soft reference (LeggedRobotPreComputation.cpp:96-117)
-        const double* sw = in.swing + 6 * i;
-        r0 = c1.foot_vel[i].z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
-        r1 = C.xy_gain * px + c1.foot_vel[i].x - (sw[3] + C.xy_gain * sw[0]);
-        r2 = C.xy_gain * py + c1.foot_vel[i].y - (sw[4] + C.xy_gain * sw[1]);
+    for (int i = 0; i < 3; ++i) zyx[i] = Dual1(xs[9 + i], dir == 9 + i ? 1.0 : 0.0);
+    const auto qd_acc = [us, dir](int j) { return Dual1(us[12 + j], dir == 34 + j ? 1.0 : 0.0); };
+    {
+      Centroidal<Dual1> c1;
+      centroidal_eval_f<Dual1>(M, zyx, [xs, dir](int j) { return Dual1(xs[12 + j], dir == 12 + j ? 1.0 : 0.0); }, hn, qd_acc, c1);
+      // flow map rows 0..11 (rows 12..21 are the joint velocities themselves)
+      Vec3<Dual1> fs, ms;
+#pragma unroll
+      for (int i = 0; i < HB_NC; ++i) {
+        const Vec3<Dual1> F(Dual1(us[3 * i], dir == 22 + 3 * i ? 1.0 : 0.0), Dual1(us[3 * i + 1], dir == 23 + 3 * i ? 1.0 : 0.0),
+                            Dual1(us[3 * i + 2], dir == 24 + 3 * i ? 1.0 : 0.0));
+        fs = fs + F;
+        ms = ms + cross(c1.foot_rel[i] - c1.com_rel, F);
       }
-      CDt[dir * 12 + 3 * i + 0] = r0.d;
-      CDt[dir * 12 + 3 * i + 1] = r1.d;
-      CDt[dir * 12 + 3 * i + 2] = r2.d;
-      if (dir == 0) {
-        rowval[3 * i + 0] = r0.v;
-        rowval[3 * i + 1] = r1.v;
-        rowval[3 * i + 2] = r2.v;
+      const double inv_m = 1.0 / M.total_mass;
+      f1[0] = inv_m * fs.x; f1[1] = inv_m * fs.y; f1[2] = inv_m * fs.z - M.gravity;
+      f1[3] = inv_m * ms.x; f1[4] = inv_m * ms.y; f1[5] = inv_m * ms.z;
+      f1[6] = c1.v_lin.x; f1[7] = c1.v_lin.y; f1[8] = c1.v_lin.z;
+      f1[9] = c1.euler_rate.x; f1[10] = c1.euler_rate.y; f1[11] = c1.euler_rate.z;
+      // constraint rows: slot 3i+a
+      const Dual1 bx(xs[6], dir == 6 ? 1.0 : 0.0), by(xs[7], dir == 7 ? 1.0 : 0.0), bz(xs[8], dir == 8 ? 1.0 : 0.0);
+#pragma unroll
+      for (int i = 0; i < HB_NC; ++i) {
+        const Dual1 pz = bz + c1.foot_rel[i].z;
+        Dual1 r0, r1, r2;
+        if (cf[i]) {  // zero velocity (LeggedInterface.cpp:436-444)
+          r0 = c1.foot_vel[i].x;
+          r1 = c1.foot_vel[i].y;
+          r2 = c1.foot_vel[i].z + C.zv_gain * pz + C.zv_off;
+        } else {      // normal velocity + xy soft reference (LeggedRobotPreComputation.cpp:96-117)
+          const double* sw = in.swing + 6 * i;
+          const Dual1 px = bx + c1.foot_rel[i].x, py = by + c1.foot_rel[i].y;
+          r0 = c1.foot_vel[i].z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
+          r1 = C.xy_gain * px + c1.foot_vel[i].x - (sw[3] + C.xy_gain * sw[0]);
+          r2 = C.xy_gain * py + c1.foot_vel[i].y - (sw[4] + C.xy_gain * sw[1]);
+        }
+        CDt[dir * 12 + 3 * i + 0] = r0.d;
+        CDt[dir * 12 + 3 * i + 1] = r1.d;
+        CDt[dir * 12 + 3 * i + 2] = r2.d;
+        if (dir == 0) {
+          rowval[3 * i + 0] = r0.v;
+          rowval[3 * i + 1] = r1.v;
+          rowval[3 * i + 2] = r2.v;
+        }
       }
     }
-    Dual1 xm[HB_NX];
+    // second stage of Heun at x + dt f1 (same input)
 #pragma unroll
-    for (int i = 0; i < HB_NX; ++i) xm[i] = xd[i] + dt * f1[i];
-    flow_map<Dual1>(M, xm, ud, f2);
+    for (int i = 0; i < 6; ++i) hn[i] = hn[i] + dt * f1[i];
 #pragma unroll
-    for (int i = 0; i < HB_NX; ++i) {
-      const Dual1 xp = xd[i] + (0.5 * dt) * (f1[i] + f2[i]);
+    for (int i = 0; i < 3; ++i) zyx[i] = zyx[i] + dt * f1[9 + i];
+    Dual1 f2[12];
+    {
+      Centroidal<Dual1> c2;
+      centroidal_eval_f<Dual1>(M, zyx, [xs, us, dir, dt](int j) {
+        return Dual1(xs[12 + j] + dt * us[12 + j], (dir == 12 + j ? 1.0 : 0.0) + (dir == 34 + j ? dt : 0.0));
+      }, hn, qd_acc, c2);
+      Vec3<Dual1> fs, ms;
+#pragma unroll
+      for (int i = 0; i < HB_NC; ++i) {
+        const Vec3<Dual1> F(Dual1(us[3 * i], dir == 22 + 3 * i ? 1.0 : 0.0), Dual1(us[3 * i + 1], dir == 23 + 3 * i ? 1.0 : 0.0),
+                            Dual1(us[3 * i + 2], dir == 24 + 3 * i ? 1.0 : 0.0));
+        fs = fs + F;
+        ms = ms + cross(c2.foot_rel[i] - c2.com_rel, F);
+      }
+      const double inv_m = 1.0 / M.total_mass;
+      f2[0] = inv_m * fs.x; f2[1] = inv_m * fs.y; f2[2] = inv_m * fs.z - M.gravity;
+      f2[3] = inv_m * ms.x; f2[4] = inv_m * ms.y; f2[5] = inv_m * ms.z;
+      f2[6] = c2.v_lin.x; f2[7] = c2.v_lin.y; f2[8] = c2.v_lin.z;
+      f2[9] = c2.euler_rate.x; f2[10] = c2.euler_rate.y; f2[11] = c2.euler_rate.z;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const Dual1 xp = Dual1(xs[i], dir == i ? 1.0 : 0.0) + (0.5 * dt) * (f1[i] + f2[i]);
       ABt[dir * 22 + i] = xp.d;
       if (dir == 0) xplus[i] = xp.v;
     }
+#pragma unroll
+    for (int j = 0; j < HB_NJ; ++j) {
+      ABt[dir * 22 + 12 + j] = (dir == 12 + j ? 1.0 : 0.0) + (dir == 34 + j ? dt : 0.0);
+      if (dir == 0) xplus[12 + j] = xs[12 + j] + dt * us[12 + j];
+    }
   }
+  cx.sync();  // xs/us alias Kx: all lanes must be done with them before phase 2 writes Kx
   // slot classification (uniform)
   int n_eq = 0, n_soft = 0, n_f = 0;
   for (int i = 0; i < HB_NC; ++i) {
@@ -206,45 +259,49 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     W[idx] = s;
   }
   cx.sync();
+  // diagonally pivoted Cholesky of G'G, lane-parallel, in place.  L(i,s) is stored at the symmetric position
+  // GtG[perm[i]*10 + perm[s]] (original indices), so pivot swaps never move data.
   if (cx.lane == 0) {
-    // diagonally pivoted Cholesky, in place in GtG (lower triangle, permuted ordering)
     for (int i = 0; i < 10; ++i) perm[i] = i;
+  }
+  double tol;
+  {
     double dmax0 = 0;
     for (int i = 0; i < 10; ++i) dmax0 = fmax(dmax0, GtG[i * 10 + i]);
-    const double tol = 1e-10 * dmax0;
-    int rank = 0;
-    for (int s = 0; s < 10; ++s) {
-      int pv = s;
-      double best = GtG[perm[s] * 10 + perm[s]];
-      for (int i = s + 1; i < 10; ++i) {
-        const double d = GtG[perm[i] * 10 + perm[i]];
-        if (d > best) { best = d; pv = i; }
-      }
-      if (!(best > tol)) break;
-      const int tmp = perm[s]; perm[s] = perm[pv]; perm[pv] = tmp;
-      const int ps = perm[s];
-      const double lss = sqrt(best);
-      // L(i,s) is stored at the symmetric position GtG[perm[i]*10 + perm[s]] (original indices), so later
-      // pivot swaps never move data.
-      GtG[ps * 10 + ps] = lss;
-      for (int i = s + 1; i < 10; ++i) {
-        const int pi = perm[i];
-        const double lis = GtG[pi * 10 + ps] / lss;
-        GtG[pi * 10 + ps] = lis;
-      }
-      // Schur update of the trailing block (both triangles kept symmetric)
-      for (int i = s + 1; i < 10; ++i) {
-        const int pi = perm[i];
-        const double lis = GtG[pi * 10 + ps];
-        for (int j = s + 1; j < 10; ++j) {
-          const int pj = perm[j];
-          GtG[pi * 10 + pj] -= lis * GtG[pj * 10 + ps];
-        }
-      }
-      rank = s + 1;
-    }
-    ints[10] = rank;
+    tol = 1e-10 * dmax0;
   }
+  cx.sync();
+  int rank_l = 0;
+  for (int st = 0; st < 10; ++st) {
+    // every lane finds the pivot redundantly (same values, same result)
+    int pv = st;
+    double best = GtG[perm[st] * 10 + perm[st]];
+    for (int i = st + 1; i < 10; ++i) {
+      const double dv = GtG[perm[i] * 10 + perm[i]];
+      if (dv > best) { best = dv; pv = i; }
+    }
+    if (!(best > tol)) break;
+    cx.sync();
+    if (cx.lane == 0) {
+      const int tmp = perm[st]; perm[st] = perm[pv]; perm[pv] = tmp;
+    }
+    cx.sync();
+    const int ps = perm[st];
+    const double lss = sqrt(best);
+    // scale the pivot column
+    for (int i = st + 1 + cx.lane; i < 10; i += cx.nlanes) GtG[perm[i] * 10 + ps] /= lss;
+    if (cx.lane == 0) GtG[ps * 10 + ps] = lss;
+    cx.sync();
+    // Schur update of the trailing block (both triangles)
+    const int nt = 9 - st;
+    for (int idx = cx.lane; idx < nt * nt; idx += cx.nlanes) {
+      const int pi = perm[st + 1 + idx / nt], pj = perm[st + 1 + idx % nt];
+      GtG[pi * 10 + pj] -= GtG[pi * 10 + ps] * GtG[pj * 10 + ps];
+    }
+    cx.sync();
+    rank_l = st + 1;
+  }
+  if (cx.lane == 0) ints[10] = rank_l;
   cx.sync();
   const int rank = ints[10];
   const int nz = 10 - rank;
@@ -283,88 +340,113 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     }
   }
 
-  // -------------------------------------------------------------- phase 4a: cost pieces (lane 0: scalars/diagonals)
-  if (cx.lane == 0) {
-    double cost = 0;
-    double unom[12];
-    for (int i = 0; i < 12; ++i) unom[i] = 0;
+  // -------------------------------------------------------------- phase 4a: cost pieces, one "role" per lane
+  // roles 0..21 state entries, 22..43 input entries, 44..55 constraint slots, 56..59 friction barrier values.
+  // Partial sums (cost, defect^2, equality^2) are reduced through LDS (scratch aliases Mm, not live yet).
+  double* red = Mm;  // 3 x 64
+  {
     int nc = 0;
     for (int i = 0; i < HB_NC; ++i) nc += cf[i];
-    for (int i = 0; i < HB_NC; ++i)
-      if (cf[i]) unom[3 * i + 2] = M.total_mass * M.gravity / nc;
-    for (int i = 0; i < HB_NX; ++i) {
-      const double dx = in.x[i] - in.xref[i];
-      Qd[i] = C.Q_diag[i];
-      qx[i] = C.Q_diag[i] * dx;
-      cost += 0.5 * C.Q_diag[i] * dx * dx;
-    }
-    for (int i = 0; i < 12; ++i) {
-      const double du = in.u[i] - unom[i];
-      ru[i] = C.R_FF_diag[i] * du;
-      cost += 0.5 * C.R_FF_diag[i] * du * du;
-    }
-    for (int k = 0; k < HB_NJ; ++k) {
-      double s = 0;
-      for (int l = 0; l < HB_NJ; ++l) s += C.R_jj[k * 10 + l] * in.u[12 + l];
-      ru[12 + k] = s;
-      cost += 0.5 * in.u[12 + k] * s;
-    }
-    for (int i = 0; i < 36; ++i) RFF[i] = 0.0;
-    for (int i = 0; i < HB_NC; ++i)
-      for (int a = 0; a < 3; ++a) RFF[9 * i + 4 * a] = C.R_FF_diag[3 * i + a];
-    double shift_sum = 0;  // sum over contact feet of -p1 * shift, added to every Q and R diagonal entry
+    const double fz_nom = nc > 0 ? M.total_mass * M.gravity / nc : 0.0;
     const RelaxedBarrierD fb{C.fb_mu, C.fb_delta};
-    for (int i = 0; i < HB_NC; ++i) {
-      if (!cf[i]) continue;
+    const RelaxedBarrierD bp{C.pos_b[0], C.pos_b[1]}, bv{C.vel_b[0], C.vel_b[1]}, bf{C.force_b[0], C.force_b[1]};
+    // friction-cone terms of foot i at the current forces (FrictionConeConstraint.cpp:70-233)
+    auto cone = [&](int i, double& h, double* g, double& H00, double& H01, double& H11) {
       const double Fx = in.u[3 * i], Fy = in.u[3 * i + 1], Fz = in.u[3 * i + 2];
       const double t2 = Fx * Fx + Fy * Fy + C.friction_reg, tn = sqrt(t2), t32 = tn * t2;
-      const double h = C.friction_mu * (Fz + C.friction_gripper) - tn;
-      const double g[3] = {-Fx / tn, -Fy / tn, C.friction_mu};
-      const double H00 = -(Fy * Fy + C.friction_reg) / t32, H01 = Fx * Fy / t32, H11 = -(Fx * Fx + C.friction_reg) / t32;
-      const double p1 = fb.d1(h), p2 = fb.d2(h);
-      cost += fb.value(h);
-      for (int a = 0; a < 3; ++a) {
-        ru[3 * i + a] += p1 * g[a];
-        for (int b = 0; b < 3; ++b) RFF[9 * i + 3 * a + b] += p2 * g[a] * g[b];
+      h = C.friction_mu * (Fz + C.friction_gripper) - tn;
+      g[0] = -Fx / tn; g[1] = -Fy / tn; g[2] = C.friction_mu;
+      H00 = -(Fy * Fy + C.friction_reg) / t32; H01 = Fx * Fy / t32; H11 = -(Fx * Fx + C.friction_reg) / t32;
+    };
+    // hessianDiagonalShift acts on every diagonal entry of the xx and uu blocks (FrictionConeConstraint.cpp:215-233)
+    double shift_sum = 0;
+    for (int i = 0; i < HB_NC; ++i)
+      if (cf[i]) {
+        double h, g[3], a0, a1, a2;
+        cone(i, h, g, a0, a1, a2);
+        shift_sum += -fb.d1(h) * C.friction_shift;
       }
-      RFF[9 * i + 0] += p1 * H00; RFF[9 * i + 1] += p1 * H01; RFF[9 * i + 3] += p1 * H01; RFF[9 * i + 4] += p1 * H11;
-      shift_sum += -p1 * C.friction_shift;
+    for (int role = cx.lane; role < 64; role += cx.nlanes) {
+      double pc = 0, pd = 0, pe = 0;
+      if (role < 22) {
+        const int i = role;
+        const double dxv = in.x[i] - in.xref[i];
+        double qd_ = C.Q_diag[i] + shift_sum, qg = C.Q_diag[i] * dxv;
+        pc += 0.5 * C.Q_diag[i] * dxv * dxv;
+        if (i >= 12) {
+          const int j = i - 12;
+          const double h = in.x[i];
+          pc += bp.value(h - M.q_lower[j]) + bp.value(M.q_upper[j] - h);
+          qg += bp.d1(h - M.q_lower[j]) - bp.d1(M.q_upper[j] - h);
+          qd_ += bp.d2(h - M.q_lower[j]) + bp.d2(M.q_upper[j] - h);
+        }
+        Qd[i] = qd_;
+        qx[i] = qg;
+        const double dd = xplus[i] - in.xnext[i];
+        pd += dd * dd;
+      } else if (role < 34) {
+        const int m = role - 22, foot = m / 3, a = m % 3;
+        const double du = in.u[m] - ((a == 2 && cf[foot]) ? fz_nom : 0.0);
+        double rg = C.R_FF_diag[m] * du;
+        pc += 0.5 * C.R_FF_diag[m] * du * du;
+        if (cf[foot]) {
+          double h, g[3], a0, a1, a2;
+          cone(foot, h, g, a0, a1, a2);
+          rg += fb.d1(h) * g[a];
+        } else {
+          pe += in.u[m] * in.u[m];  // zero-force equality value
+        }
+        if (a == 2) {
+          const double h = in.u[m];
+          pc += bf.value(h - C.force_lim[0]) + bf.value(C.force_lim[1] - h);
+          rg += bf.d1(h - C.force_lim[0]) - bf.d1(C.force_lim[1] - h);
+        }
+        ru[m] = rg;
+      } else if (role < 44) {
+        const int k = role - 34;
+        double sacc = 0;
+        for (int l = 0; l < HB_NJ; ++l) sacc += C.R_jj[k * 10 + l] * in.u[12 + l];
+        pc += 0.5 * in.u[12 + k] * sacc;
+        const double hv = in.u[12 + k], vl = M.qd_limit[k];
+        pc += bv.value(hv + vl) + bv.value(vl - hv);
+        ru[12 + k] = sacc + bv.d1(hv + vl) - bv.d1(vl - hv);
+        scal[4 + k] = bv.d2(hv + vl) + bv.d2(vl - hv) + shift_sum;  // joint diagonal additions to R_jj
+      } else if (role < 56) {
+        const int sl = role - 44, foot = sl / 3, a = sl % 3;
+        const double rv = rowval[sl];
+        if (cf[foot] || a == 0) pe += rv * rv;          // equality slot
+        else pc += 0.5 * C.soft_w * rv * rv;            // xy soft-reference slot
+      } else if (role < 60) {
+        const int foot = role - 56;
+        // R_FF block of this foot: diagonal weight + shift (+ F_z limit curvature) + friction-cone curvature
+        double blk[9];
+        for (int e = 0; e < 9; ++e) blk[e] = 0.0;
+        for (int a = 0; a < 3; ++a) blk[4 * a] = C.R_FF_diag[3 * foot + a] + shift_sum;
+        {
+          const double h = in.u[3 * foot + 2];
+          blk[8] += bf.d2(h - C.force_lim[0]) + bf.d2(C.force_lim[1] - h);
+        }
+        if (cf[foot]) {
+          double h, g[3], H00, H01, H11;
+          cone(foot, h, g, H00, H01, H11);
+          const double p1 = fb.d1(h), p2 = fb.d2(h);
+          pc += fb.value(h);
+          for (int a = 0; a < 3; ++a)
+            for (int bb = 0; bb < 3; ++bb) blk[3 * a + bb] += p2 * g[a] * g[bb];
+          blk[0] += p1 * H00; blk[1] += p1 * H01; blk[3] += p1 * H01; blk[4] += p1 * H11;
+        }
+        for (int e = 0; e < 9; ++e) RFF[9 * foot + e] = blk[e];
+      }
+      red[role] = pc;
+      red[64 + role] = pd;
+      red[128 + role] = pe;
     }
-    for (int i = 0; i < HB_NX; ++i) Qd[i] += shift_sum;
-    for (int i = 0; i < HB_NC; ++i)
-      for (int a = 0; a < 3; ++a) RFF[9 * i + 4 * a] += shift_sum;
-    // limits (LeggedInterface.cpp:317-357)
-    const RelaxedBarrierD bp{C.pos_b[0], C.pos_b[1]}, bv{C.vel_b[0], C.vel_b[1]}, bf{C.force_b[0], C.force_b[1]};
-    for (int j = 0; j < HB_NJ; ++j) {
-      const double h = in.x[12 + j];
-      cost += bp.value(h - M.q_lower[j]) + bp.value(M.q_upper[j] - h);
-      qx[12 + j] += bp.d1(h - M.q_lower[j]) - bp.d1(M.q_upper[j] - h);
-      Qd[12 + j] += bp.d2(h - M.q_lower[j]) + bp.d2(M.q_upper[j] - h);
-      const double hv = in.u[12 + j], vl = M.qd_limit[j];
-      cost += bv.value(hv + vl) + bv.value(vl - hv);
-      ru[12 + j] += bv.d1(hv + vl) - bv.d1(vl - hv);
-      scal[4 + j] = bv.d2(hv + vl) + bv.d2(vl - hv) + shift_sum;  // joint diagonal additions to R_jj
-    }
-    for (int i = 0; i < HB_NC; ++i) {
-      const double h = in.u[3 * i + 2];
-      cost += bf.value(h - C.force_lim[0]) + bf.value(C.force_lim[1] - h);
-      ru[3 * i + 2] += bf.d1(h - C.force_lim[0]) - bf.d1(C.force_lim[1] - h);
-      RFF[9 * i + 8] += bf.d2(h - C.force_lim[0]) + bf.d2(C.force_lim[1] - h);
-    }
-    for (int s = 0; s < n_soft; ++s) cost += 0.5 * C.soft_w * rowval[softs[s]] * rowval[softs[s]];
-    scal[0] = cost;
-    // violation sums
-    double dyn = 0, eq = 0;
-    for (int i = 0; i < HB_NX; ++i) {
-      const double d = xplus[i] - in.xnext[i];
-      dyn += d * d;
-    }
-    for (int a = 0; a < n_eq; ++a) eq += rowval[eqs[a]] * rowval[eqs[a]];
-    for (int i = 0; i < HB_NC; ++i)
-      if (!cf[i])
-        for (int a = 0; a < 3; ++a) eq += in.u[3 * i + a] * in.u[3 * i + a];
-    scal[1] = dyn;
-    scal[2] = eq;
+  }
+  cx.sync();
+  for (int w = cx.lane; w < 3; w += cx.nlanes) {
+    double sacc = 0;
+    for (int l = 0; l < 64; ++l) sacc += red[64 * w + l];
+    scal[w] = sacc;
   }
   cx.sync();
   // soft rows: gradients and the dense pieces P_j, R_jj

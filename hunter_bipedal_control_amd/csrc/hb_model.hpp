@@ -47,57 +47,95 @@ struct LegOut {
   Vec3<T> foot[2], foot_vj[2];  // contact points (f1, f2) and sum_k (a_k x (p - o_k)) qd_k, base frame
 };
 
-template <class T>
-HB_HD void leg_eval(const DevModel& M, int leg, const T* qj, const T* qdj, LegOut<T>& out) {
+// Tip-to-base recursion: the state carried from the foot towards the hip is only the composite of the outboard
+// links (mass, first moment, inertia about the current joint origin), the momentum its joint rates carry and the
+// two contact points with their joint-induced velocities, all expressed in the current link frame — 28 scalars —
+// so the evaluation stays in registers even with dual numbers.
+// Joint angles / rates come through accessors (uniform values live in LDS or global memory, tangents are
+// indicator functions of the lane's direction) and the joint loop is deliberately NOT unrolled: a compact loop keeps
+// the kernel inside the instruction cache and the model constants out of long-lived registers.
+template <class T, class QF, class QDF>
+HB_HD void leg_eval(const DevModel& M, int leg, QF qj, QDF qdj, LegOut<T>& out) {
   const int j0 = 5 * leg;
-  Vec3<T> o[5], a[5];
-  T cm[5];
-  Vec3<T> cmc[5];
-  Sym3<T> cIO[5];
-  Mat3<T> R = Mat3<T>::identity();
-  Vec3<T> op;  // parent origin
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int j = j0 + k, b = j + 1;
-    o[k] = op + R * Vec3<T>(T(M.origin[j][0]), T(M.origin[j][1]), T(M.origin[j][2]));
-    a[k] = R * Vec3<T>(T(M.axis[j][0]), T(M.axis[j][1]), T(M.axis[j][2]));
-    R = R * axis_rot<T>(M.axis[j], qj[j]);
-    const Vec3<T> c = o[k] + R * Vec3<T>(T(M.com[b][0]), T(M.com[b][1]), T(M.com[b][2]));
-    const T mb = T(M.mass[b]);
-    cm[k] = mb;
-    cmc[k] = mb * c;
-    cIO[k] = rotate_inertia<T>(R, M.inertia[b]) + point_inertia<T>(mb, c);
-    op = o[k];
-  }
-  // contact points on the last link (f1 = contact index leg, f2 = contact index leg + 2)
+  T m = T(0.0);
+  Vec3<T> mc, lin, ang;
+  Sym3<T> IO;
+  Vec3<T> rf[2], vf[2];
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const int ci = leg + 2 * f;
-    out.foot[f] = o[4] + R * Vec3<T>(T(M.contact_offset[ci][0]), T(M.contact_offset[ci][1]), T(M.contact_offset[ci][2]));
-    out.foot_vj[f] = Vec3<T>();
+    rf[f] = Vec3<T>(T(M.contact_offset[ci][0]), T(M.contact_offset[ci][1]), T(M.contact_offset[ci][2]));
   }
-  // suffix composites and momentum of the joint velocities
-  T m = T(0.0);
-  Vec3<T> mc;
-  Sym3<T> IO;
-  out.l_sum = Vec3<T>();
-  out.L_sum = Vec3<T>();
-#pragma unroll
+#pragma unroll 1
   for (int k = 4; k >= 0; --k) {
-    m = m + cm[k];
-    mc = mc + cmc[k];
-    IO = IO + cIO[k];
-    const T qd = qdj[j0 + k];
-    const Vec3<T> l = cross(a[k], mc - m * o[k]);
-    const Vec3<T> L = IO * a[k] - cross(mc, cross(a[k], o[k]));
-    out.l_sum = out.l_sum + qd * l;
-    out.L_sum = out.L_sum + qd * L;
+    const int j = j0 + k, b = j + 1;
+    // add link b (its own frame is the current frame)
+    {
+      const double mb = M.mass[b];
+      const Vec3<T> c(T(M.com[b][0]), T(M.com[b][1]), T(M.com[b][2]));
+      m = m + mb;
+      mc = mc + T(mb) * c;
+      Sym3<T> Ib;
+      Ib.xx = T(M.inertia[b][0]); Ib.xy = T(M.inertia[b][1]); Ib.xz = T(M.inertia[b][2]);
+      Ib.yy = T(M.inertia[b][3]); Ib.yz = T(M.inertia[b][4]); Ib.zz = T(M.inertia[b][5]);
+      IO = IO + Ib + point_inertia<T>(T(mb), c);
+    }
+    // joint j turns everything outboard about its axis (same components in the parent and child frames)
+    const Vec3<T> a(T(M.axis[j][0]), T(M.axis[j][1]), T(M.axis[j][2]));
+    const T qd = qdj(j);
+    lin = lin + qd * cross(a, mc);
+    ang = ang + qd * (IO * a);
 #pragma unroll
-    for (int f = 0; f < 2; ++f) out.foot_vj[f] = out.foot_vj[f] + qd * cross(a[k], out.foot[f] - o[k]);
+    for (int f = 0; f < 2; ++f) vf[f] = vf[f] + qd * cross(a, rf[f]);
+    // express in the parent frame: x_parent = origin + R x
+    const Mat3<T> R = axis_rot<T>(M.axis[j], qj(j));
+    const Vec3<T> o(T(M.origin[j][0]), T(M.origin[j][1]), T(M.origin[j][2]));
+    const Vec3<T> s = R * mc;
+    {
+      // R IO R^T, then shift the reference point from the joint origin to the parent origin
+      Mat3<T> A;
+      A.m[0] = IO.xx; A.m[1] = IO.xy; A.m[2] = IO.xz;
+      A.m[3] = IO.xy; A.m[4] = IO.yy; A.m[5] = IO.yz;
+      A.m[6] = IO.xz; A.m[7] = IO.yz; A.m[8] = IO.zz;
+      const Mat3<T> RA = R * A;
+      Sym3<T> n;
+      n.xx = RA.m[0] * R.m[0] + RA.m[1] * R.m[1] + RA.m[2] * R.m[2];
+      n.xy = RA.m[0] * R.m[3] + RA.m[1] * R.m[4] + RA.m[2] * R.m[5];
+      n.xz = RA.m[0] * R.m[6] + RA.m[1] * R.m[7] + RA.m[2] * R.m[8];
+      n.yy = RA.m[3] * R.m[3] + RA.m[4] * R.m[4] + RA.m[5] * R.m[5];
+      n.yz = RA.m[3] * R.m[6] + RA.m[4] * R.m[7] + RA.m[5] * R.m[8];
+      n.zz = RA.m[6] * R.m[6] + RA.m[7] * R.m[7] + RA.m[8] * R.m[8];
+      // (2 s.o + m |o|^2) I - (s o^T + o s^T + m o o^T)
+      const T so = dot(s, o), oo = m * dot(o, o);
+      const T tr = so + so + oo;
+      n.xx = n.xx + tr - (s.x * o.x + s.x * o.x + m * (o.x * o.x));
+      n.yy = n.yy + tr - (s.y * o.y + s.y * o.y + m * (o.y * o.y));
+      n.zz = n.zz + tr - (s.z * o.z + s.z * o.z + m * (o.z * o.z));
+      n.xy = n.xy - (s.x * o.y + o.x * s.y + m * (o.x * o.y));
+      n.xz = n.xz - (s.x * o.z + o.x * s.z + m * (o.x * o.z));
+      n.yz = n.yz - (s.y * o.z + o.y * s.z + m * (o.y * o.z));
+      IO = n;
+    }
+    mc = s + m * o;
+    const Vec3<T> rl = R * lin;
+    ang = R * ang + cross(o, rl);
+    lin = rl;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      rf[f] = o + R * rf[f];
+      vf[f] = R * vf[f];
+    }
   }
   out.m = m;
   out.mc = mc;
   out.IO = IO;
+  out.l_sum = lin;
+  out.L_sum = ang;
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    out.foot[f] = rf[f];
+    out.foot_vj[f] = vf[f];
+  }
 }
 
 // ZYX euler rates from the world angular velocity (inverse of omega = E(zyx) * rates).
@@ -111,8 +149,8 @@ HB_HD Vec3<T> euler_rates_from_omega(T sz, T cz, T sy, T cy, Vec3<T> w) {
 
 // Centroidal evaluation at pinocchio coordinates q = [pos, zyx, joints] given normalised momentum hn(6)
 // and joint velocities qd(10): base velocity from  A_b v_b = m hn - A_j qd  in closed form.
-template <class T>
-HB_HD void centroidal_eval(const DevModel& M, const T* zyx, const T* qj, const T* hn, const T* qdj, Centroidal<T>& out) {
+template <class T, class QF, class QDF>
+HB_HD void centroidal_eval_f(const DevModel& M, const T* zyx, QF qj, const T* hn, QDF qdj, Centroidal<T>& out) {
   LegOut<T> L0, L1;
   leg_eval<T>(M, 0, qj, qdj, L0);
   leg_eval<T>(M, 1, qj, qdj, L1);
@@ -162,6 +200,16 @@ HB_HD void centroidal_eval(const DevModel& M, const T* zyx, const T* qj, const T
     out.foot_vel[0 + 2 * f] = out.v_lin + cross(out.omega, out.foot_rel[0 + 2 * f]) + R * L0.foot_vj[f];
     out.foot_vel[1 + 2 * f] = out.v_lin + cross(out.omega, out.foot_rel[1 + 2 * f]) + R * L1.foot_vj[f];
   }
+}
+
+template <class T>
+struct PtrAccessor {
+  const T* p;
+  HB_HD T operator()(int j) const { return p[j]; }
+};
+template <class T>
+HB_HD void centroidal_eval(const DevModel& M, const T* zyx, const T* qj, const T* hn, const T* qdj, Centroidal<T>& out) {
+  centroidal_eval_f<T>(M, zyx, PtrAccessor<T>{qj}, hn, PtrAccessor<T>{qdj}, out);
 }
 
 // Flow map xdot = f(x,u) from a centroidal evaluation.

@@ -53,24 +53,26 @@ HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, double* gains) {
     Hu[idx] = acc;
   }
   cx.sync();
-  // Cholesky of Huu (in place, lower) by lane 0
-  if (cx.lane == 0) {
-    bool ok = true;
-    for (int j = 0; j < NU_T; ++j) {
-      double d = Hu[j * 35 + 22 + j];
-      for (int k = 0; k < j; ++k) d -= Hu[j * 35 + 22 + k] * Hu[j * 35 + 22 + k];
-      if (!(d > 0.0)) { ok = false; d = 1.0; }
-      const double l = sqrt(d);
+  // Cholesky of Huu (in place, lower), right-looking and lane-parallel
+  for (int j = 0; j < NU_T; ++j) {
+    double dj = Hu[j * 35 + 22 + j];
+    bool bad = !(dj > 0.0);
+    if (bad) dj = 1.0;
+    const double l = sqrt(dj);
+    cx.sync();
+    for (int i = j + 1 + cx.lane; i < NU_T; i += cx.nlanes) Hu[i * 35 + 22 + j] /= l;
+    if (cx.lane == 0) {
       Hu[j * 35 + 22 + j] = l;
-      for (int i = j + 1; i < NU_T; ++i) {
-        double sacc = Hu[i * 35 + 22 + j];
-        for (int k = 0; k < j; ++k) sacc -= Hu[i * 35 + 22 + k] * Hu[j * 35 + 22 + k];
-        Hu[i * 35 + 22 + j] = sacc / l;
-      }
+      if (bad) lds[RicLds::flag] = 1.0;
     }
-    if (!ok) lds[RicLds::flag] = 1.0;
+    cx.sync();
+    const int nt = NU_T - 1 - j;
+    for (int idx = cx.lane; idx < nt * nt; idx += cx.nlanes) {
+      const int i = j + 1 + idx / nt, k = j + 1 + idx % nt;
+      if (k <= i) Hu[i * 35 + 22 + k] -= Hu[i * 35 + 22 + j] * Hu[k * 35 + 22 + j];
+    }
+    cx.sync();
   }
-  cx.sync();
   // K~ = -Huu^-1 [Hux | hu]: one right-hand side per lane
   for (int c = cx.lane; c < 23; c += cx.nlanes) {
     const int src = (c < 22) ? c : 34;
@@ -200,16 +202,53 @@ HB_HD void node_value(const DevModel& M, const DevConfig& C, const double* x, co
                       const double* xref, const double* swing, double dt, int mode, double* out3) {
   bool cf[HB_NC];
   mode_flags(mode, cf);
-  double f1[HB_NX], f2[HB_NX], xm[HB_NX];
+  double f1[12], f2[12];
   Centroidal<double> c1;
-  flow_map<double>(M, x, u, f1, &c1);
+  const double inv_m = 1.0 / M.total_mass;
+  {
+    centroidal_eval<double>(M, x + 9, x + 12, x, u + 12, c1);
+    Vec3<double> fs, ms;
 #pragma unroll
-  for (int i = 0; i < HB_NX; ++i) xm[i] = x[i] + dt * f1[i];
-  flow_map<double>(M, xm, u, f2);
+    for (int i = 0; i < HB_NC; ++i) {
+      const Vec3<double> F(u[3 * i], u[3 * i + 1], u[3 * i + 2]);
+      fs = fs + F;
+      ms = ms + cross(c1.foot_rel[i] - c1.com_rel, F);
+    }
+    f1[0] = inv_m * fs.x; f1[1] = inv_m * fs.y; f1[2] = inv_m * fs.z - M.gravity;
+    f1[3] = inv_m * ms.x; f1[4] = inv_m * ms.y; f1[5] = inv_m * ms.z;
+    f1[6] = c1.v_lin.x; f1[7] = c1.v_lin.y; f1[8] = c1.v_lin.z;
+    f1[9] = c1.euler_rate.x; f1[10] = c1.euler_rate.y; f1[11] = c1.euler_rate.z;
+  }
+  {
+    double hn[6], zyx[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) hn[i] = x[i] + dt * f1[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) zyx[i] = x[9 + i] + dt * f1[9 + i];
+    Centroidal<double> c2;
+    centroidal_eval_f<double>(M, zyx, [x, u, dt](int j) { return x[12 + j] + dt * u[12 + j]; }, hn,
+                              [u](int j) { return u[12 + j]; }, c2);
+    Vec3<double> fs, ms;
+#pragma unroll
+    for (int i = 0; i < HB_NC; ++i) {
+      const Vec3<double> F(u[3 * i], u[3 * i + 1], u[3 * i + 2]);
+      fs = fs + F;
+      ms = ms + cross(c2.foot_rel[i] - c2.com_rel, F);
+    }
+    f2[0] = inv_m * fs.x; f2[1] = inv_m * fs.y; f2[2] = inv_m * fs.z - M.gravity;
+    f2[3] = inv_m * ms.x; f2[4] = inv_m * ms.y; f2[5] = inv_m * ms.z;
+    f2[6] = c2.v_lin.x; f2[7] = c2.v_lin.y; f2[8] = c2.v_lin.z;
+    f2[9] = c2.euler_rate.x; f2[10] = c2.euler_rate.y; f2[11] = c2.euler_rate.z;
+  }
   double dyn = 0;
 #pragma unroll
-  for (int i = 0; i < HB_NX; ++i) {
+  for (int i = 0; i < 12; ++i) {
     const double d = x[i] + 0.5 * dt * (f1[i] + f2[i]) - xnext[i];
+    dyn += d * d;
+  }
+#pragma unroll
+  for (int j = 0; j < HB_NJ; ++j) {
+    const double d = x[12 + j] + dt * u[12 + j] - xnext[12 + j];
     dyn += d * d;
   }
   double cost = 0, eq = 0;

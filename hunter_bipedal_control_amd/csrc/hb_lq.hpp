@@ -33,6 +33,8 @@ struct DevConfig {
   double wbc_mu, swing_kp, swing_kd, bh_kp, bh_kd, ba_kp, ba_kd, w_swing, w_base, w_force, wbc_eps;
   int wbc_max_iter, wbc_type;
   double default_joint_state[HB_NJ];
+  int debug_stop;  // >0: lq_node returns after that phase (profiling ablation only)
+  int pad_;
 };
 
 // ---- node record layout in HBM (doubles) ------------------------------------------------------------
@@ -86,7 +88,10 @@ struct LqLds {
   static constexpr int Qd = ru + 22;         // 22 diagonal of Q incl. barriers/shift
   static constexpr int scal = Qd + 22;       // 16 scalars (cost, sums, ...)
   static constexpr int ints = scal + 16;     // 32 ints packed in 16 doubles: perm[10], rank, eq slots...
-  static constexpr int total = ints + 16;
+  // phase-1 scratch (xs us xe fv FR LV LT J1 J2 = 1754 doubles) aliases everything from GtG on: none of those
+  // buffers is live before phase 2.
+  static constexpr int p1 = GtG;
+  static constexpr int total = (p1 + 1760 > ints + 16) ? p1 + 1760 : ints + 16;
 };
 
 struct NodeIn {
@@ -126,105 +131,190 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   bool cf[HB_NC];
   mode_flags(in.mode, cf);
 
-  // -------------------------------------------------------------- phase 1: dual pass per direction
-  // Values of x,u are the same for every lane: they are staged in LDS and re-read where needed so that only
-  // tangents and the running state of the evaluation occupy registers.
-  double* xs = Kx;        // 22 (Kx/Z are not live yet)
-  double* us = Kx + 22;   // 22
+  // -------------------------------------------------------------- phase 1: sensitivities of the RK2 step
+  // The only nonlinear dependence of f and of the foot kinematics is on (zyx, joints); per evaluation point:
+  //   stage 1  20 lanes = (leg, seed): one-tangent dual pass over ONE leg, seed on a joint angle or a joint rate
+  //   stage 2  lane = direction (44): directions h, zyx, joints, rates run the whole-body combine on duals built
+  //            from the stage-1 tangents; base-position and contact-force directions are closed form
+  // then [A_k | B_k] is composed from the two points' Jacobians (OCS2 RK2 sensitivity).
+  double* xs = lds + LqLds::p1;        // 22 values of x
+  double* us = xs + 22;                // 22 values of u
+  double* xe = us + 22;                // 22 state values of the current evaluation point
+  double* fv = xe + 22;                // 2 x 12 flow-map values (rows 0..11) of the two points
+  double* FR = fv + 24;                // 12: (contact point - COM) of the current point
+  double* LV = FR + 12;                // 2 x 27 leg values
+  double* LT = LV + 54;                // 2 x 10 x 27 leg tangents
+  double* J1 = LT + 540;               // 44 x 12: d f(rows 0..11) / d direction at point 1
+  double* J2 = J1 + 528;               // same at point 2
   for (int i = cx.lane; i < 22; i += cx.nlanes) {
     xs[i] = in.x[i];
     us[i] = in.u[i];
+    xe[i] = in.x[i];
   }
   cx.sync();
-  for (int dir = cx.lane; dir < 44; dir += cx.nlanes) {
-    Dual1 zyx[3], hn[6], f1[12];
+  for (int pt = 0; pt < 2; ++pt) {
+    double* Jp = pt == 0 ? J1 : J2;
+    // ---- stage 1: per-leg seeded dual passes
+    for (int r = cx.lane; r < 20; r += cx.nlanes) {
+      const int leg = r / 10, sd = r % 10;
+      const int jq = (sd < 5) ? 5 * leg + sd : -1, jr = (sd >= 5) ? 5 * leg + sd - 5 : -1;
+      LegOut<Dual1> lo;
+      leg_eval<Dual1>(M, leg, [xe, jq](int j) { return Dual1(xe[12 + j], j == jq ? 1.0 : 0.0); },
+                      [us, jr](int j) { return Dual1(us[12 + j], j == jr ? 1.0 : 0.0); }, lo);
+      double* t = LT + (leg * 10 + sd) * 27;
+      const Dual1 pack[27] = {lo.mc.x, lo.mc.y, lo.mc.z, lo.IO.xx, lo.IO.xy, lo.IO.xz, lo.IO.yy, lo.IO.yz, lo.IO.zz,
+                              lo.l_sum.x, lo.l_sum.y, lo.l_sum.z, lo.L_sum.x, lo.L_sum.y, lo.L_sum.z,
+                              lo.foot[0].x, lo.foot[0].y, lo.foot[0].z, lo.foot[1].x, lo.foot[1].y, lo.foot[1].z,
+                              lo.foot_vj[0].x, lo.foot_vj[0].y, lo.foot_vj[0].z, lo.foot_vj[1].x, lo.foot_vj[1].y, lo.foot_vj[1].z};
 #pragma unroll
-    for (int i = 0; i < 6; ++i) hn[i] = Dual1(xs[i], dir == i ? 1.0 : 0.0);
+      for (int e = 0; e < 27; ++e) t[e] = pack[e].d;
+      if (sd == 0) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) zyx[i] = Dual1(xs[9 + i], dir == 9 + i ? 1.0 : 0.0);
-    const auto qd_acc = [us, dir](int j) { return Dual1(us[12 + j], dir == 34 + j ? 1.0 : 0.0); };
-    {
-      Centroidal<Dual1> c1;
-      centroidal_eval_f<Dual1>(M, zyx, [xs, dir](int j) { return Dual1(xs[12 + j], dir == 12 + j ? 1.0 : 0.0); }, hn, qd_acc, c1);
-      // flow map rows 0..11 (rows 12..21 are the joint velocities themselves)
+        for (int e = 0; e < 27; ++e) LV[leg * 27 + e] = pack[e].v;
+      }
+    }
+    cx.sync();
+    // ---- stage 2: whole-body combine per direction
+    for (int dir = cx.lane; dir < 44; dir += cx.nlanes) {
+      const bool nonlinear = (dir < 6) || (dir >= 9 && dir < 22) || dir >= 34;
+      if (!nonlinear) continue;
+      // which leg tangent (if any) feeds this direction
+      int tl = -1, ts = 0;
+      if (dir >= 12 && dir < 22) { tl = (dir - 12) / 5; ts = (dir - 12) % 5; }
+      if (dir >= 34) { tl = (dir - 34) / 5; ts = 5 + (dir - 34) % 5; }
+      LegOut<Dual1> L[2];
+#pragma unroll
+      for (int leg = 0; leg < 2; ++leg) {
+        const double* v = LV + leg * 27;
+        const double* t = LT + (leg * 10 + ts) * 27;
+        const double w = (tl == leg) ? 1.0 : 0.0;
+        auto D = [v, t, w](int e) { return Dual1(v[e], w * t[e]); };
+        LegOut<Dual1>& o = L[leg];
+        o.m = Dual1(leg == 0 ? M.mass[1] + M.mass[2] + M.mass[3] + M.mass[4] + M.mass[5]
+                             : M.mass[6] + M.mass[7] + M.mass[8] + M.mass[9] + M.mass[10]);
+        o.mc = Vec3<Dual1>(D(0), D(1), D(2));
+        o.IO.xx = D(3); o.IO.xy = D(4); o.IO.xz = D(5); o.IO.yy = D(6); o.IO.yz = D(7); o.IO.zz = D(8);
+        o.l_sum = Vec3<Dual1>(D(9), D(10), D(11));
+        o.L_sum = Vec3<Dual1>(D(12), D(13), D(14));
+        o.foot[0] = Vec3<Dual1>(D(15), D(16), D(17));
+        o.foot[1] = Vec3<Dual1>(D(18), D(19), D(20));
+        o.foot_vj[0] = Vec3<Dual1>(D(21), D(22), D(23));
+        o.foot_vj[1] = Vec3<Dual1>(D(24), D(25), D(26));
+      }
+      Dual1 zyx[3], hn[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) hn[i] = Dual1(xe[i], dir == i ? 1.0 : 0.0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) zyx[i] = Dual1(xe[9 + i], dir == 9 + i ? 1.0 : 0.0);
+      Centroidal<Dual1> c;
+      centroidal_combine<Dual1>(M, L[0], L[1], zyx, hn, c);
       Vec3<Dual1> fs, ms;
 #pragma unroll
       for (int i = 0; i < HB_NC; ++i) {
-        const Vec3<Dual1> F(Dual1(us[3 * i], dir == 22 + 3 * i ? 1.0 : 0.0), Dual1(us[3 * i + 1], dir == 23 + 3 * i ? 1.0 : 0.0),
-                            Dual1(us[3 * i + 2], dir == 24 + 3 * i ? 1.0 : 0.0));
+        const Vec3<Dual1> F{Dual1(us[3 * i]), Dual1(us[3 * i + 1]), Dual1(us[3 * i + 2])};
         fs = fs + F;
-        ms = ms + cross(c1.foot_rel[i] - c1.com_rel, F);
+        ms = ms + cross(c.foot_rel[i] - c.com_rel, F);
       }
       const double inv_m = 1.0 / M.total_mass;
-      f1[0] = inv_m * fs.x; f1[1] = inv_m * fs.y; f1[2] = inv_m * fs.z - M.gravity;
-      f1[3] = inv_m * ms.x; f1[4] = inv_m * ms.y; f1[5] = inv_m * ms.z;
-      f1[6] = c1.v_lin.x; f1[7] = c1.v_lin.y; f1[8] = c1.v_lin.z;
-      f1[9] = c1.euler_rate.x; f1[10] = c1.euler_rate.y; f1[11] = c1.euler_rate.z;
-      // constraint rows: slot 3i+a
-      const Dual1 bx(xs[6], dir == 6 ? 1.0 : 0.0), by(xs[7], dir == 7 ? 1.0 : 0.0), bz(xs[8], dir == 8 ? 1.0 : 0.0);
+      const Dual1 f[12] = {inv_m * fs.x, inv_m * fs.y, inv_m * fs.z - M.gravity, inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
+                           c.v_lin.x, c.v_lin.y, c.v_lin.z, c.euler_rate.x, c.euler_rate.y, c.euler_rate.z};
 #pragma unroll
-      for (int i = 0; i < HB_NC; ++i) {
-        const Dual1 pz = bz + c1.foot_rel[i].z;
-        Dual1 r0, r1, r2;
-        if (cf[i]) {  // zero velocity (LeggedInterface.cpp:436-444)
-          r0 = c1.foot_vel[i].x;
-          r1 = c1.foot_vel[i].y;
-          r2 = c1.foot_vel[i].z + C.zv_gain * pz + C.zv_off;
-        } else {      // normal velocity + xy soft reference (LeggedRobotPreComputation.cpp:96-117)
-          const double* sw = in.swing + 6 * i;
-          const Dual1 px = bx + c1.foot_rel[i].x, py = by + c1.foot_rel[i].y;
-          r0 = c1.foot_vel[i].z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
-          r1 = C.xy_gain * px + c1.foot_vel[i].x - (sw[3] + C.xy_gain * sw[0]);
-          r2 = C.xy_gain * py + c1.foot_vel[i].y - (sw[4] + C.xy_gain * sw[1]);
+      for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = f[i].d;
+      if (dir == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) fv[pt * 12 + i] = f[i].v;
+#pragma unroll
+        for (int i = 0; i < HB_NC; ++i) {
+          const Vec3<Dual1> rr = c.foot_rel[i] - c.com_rel;
+          FR[3 * i] = rr.x.v; FR[3 * i + 1] = rr.y.v; FR[3 * i + 2] = rr.z.v;
         }
-        CDt[dir * 12 + 3 * i + 0] = r0.d;
-        CDt[dir * 12 + 3 * i + 1] = r1.d;
-        CDt[dir * 12 + 3 * i + 2] = r2.d;
-        if (dir == 0) {
-          rowval[3 * i + 0] = r0.v;
-          rowval[3 * i + 1] = r1.v;
-          rowval[3 * i + 2] = r2.v;
+      }
+      if (pt == 0) {
+        // constraint rows: slot 3i+a  (base position enters only through the closed-form lanes below)
+#pragma unroll
+        for (int i = 0; i < HB_NC; ++i) {
+          const Dual1 pz = Dual1(xs[8]) + c.foot_rel[i].z;
+          Dual1 r0, r1, r2;
+          if (cf[i]) {  // zero velocity (LeggedInterface.cpp:436-444)
+            r0 = c.foot_vel[i].x;
+            r1 = c.foot_vel[i].y;
+            r2 = c.foot_vel[i].z + C.zv_gain * pz + C.zv_off;
+          } else {      // normal velocity + xy soft reference (LeggedRobotPreComputation.cpp:96-117)
+            const double* sw = in.swing + 6 * i;
+            const Dual1 px = Dual1(xs[6]) + c.foot_rel[i].x, py = Dual1(xs[7]) + c.foot_rel[i].y;
+            r0 = c.foot_vel[i].z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
+            r1 = C.xy_gain * px + c.foot_vel[i].x - (sw[3] + C.xy_gain * sw[0]);
+            r2 = C.xy_gain * py + c.foot_vel[i].y - (sw[4] + C.xy_gain * sw[1]);
+          }
+          CDt[dir * 12 + 3 * i + 0] = r0.d;
+          CDt[dir * 12 + 3 * i + 1] = r1.d;
+          CDt[dir * 12 + 3 * i + 2] = r2.d;
+          if (dir == 0) {
+            rowval[3 * i + 0] = r0.v;
+            rowval[3 * i + 1] = r1.v;
+            rowval[3 * i + 2] = r2.v;
+          }
         }
       }
     }
-    // second stage of Heun at x + dt f1 (same input)
+    cx.sync();
+    // closed-form directions: base position (6..8) and contact forces (22..33)
+    for (int dir = cx.lane; dir < 44; dir += cx.nlanes) {
+      const bool is_pos = dir >= 6 && dir < 9, is_f = dir >= 22 && dir < 34;
+      if (!is_pos && !is_f) continue;
+      double col[12];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) hn[i] = hn[i] + dt * f1[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) zyx[i] = zyx[i] + dt * f1[9 + i];
-    Dual1 f2[12];
-    {
-      Centroidal<Dual1> c2;
-      centroidal_eval_f<Dual1>(M, zyx, [xs, us, dir, dt](int j) {
-        return Dual1(xs[12 + j] + dt * us[12 + j], (dir == 12 + j ? 1.0 : 0.0) + (dir == 34 + j ? dt : 0.0));
-      }, hn, qd_acc, c2);
-      Vec3<Dual1> fs, ms;
-#pragma unroll
-      for (int i = 0; i < HB_NC; ++i) {
-        const Vec3<Dual1> F(Dual1(us[3 * i], dir == 22 + 3 * i ? 1.0 : 0.0), Dual1(us[3 * i + 1], dir == 23 + 3 * i ? 1.0 : 0.0),
-                            Dual1(us[3 * i + 2], dir == 24 + 3 * i ? 1.0 : 0.0));
-        fs = fs + F;
-        ms = ms + cross(c2.foot_rel[i] - c2.com_rel, F);
+      for (int i = 0; i < 12; ++i) col[i] = 0.0;
+      if (is_f) {
+        const int i = (dir - 22) / 3, a = (dir - 22) % 3;
+        const double inv_m = 1.0 / M.total_mass;
+        col[a] = inv_m;
+        // (r x e_a) / m
+        const double rx = FR[3 * i], ry = FR[3 * i + 1], rz = FR[3 * i + 2];
+        if (a == 0) { col[4] = rz * inv_m; col[5] = -ry * inv_m; }
+        if (a == 1) { col[3] = -rz * inv_m; col[5] = rx * inv_m; }
+        if (a == 2) { col[3] = ry * inv_m; col[4] = -rx * inv_m; }
       }
-      const double inv_m = 1.0 / M.total_mass;
-      f2[0] = inv_m * fs.x; f2[1] = inv_m * fs.y; f2[2] = inv_m * fs.z - M.gravity;
-      f2[3] = inv_m * ms.x; f2[4] = inv_m * ms.y; f2[5] = inv_m * ms.z;
-      f2[6] = c2.v_lin.x; f2[7] = c2.v_lin.y; f2[8] = c2.v_lin.z;
-      f2[9] = c2.euler_rate.x; f2[10] = c2.euler_rate.y; f2[11] = c2.euler_rate.z;
-    }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const Dual1 xp = Dual1(xs[i], dir == i ? 1.0 : 0.0) + (0.5 * dt) * (f1[i] + f2[i]);
-      ABt[dir * 22 + i] = xp.d;
-      if (dir == 0) xplus[i] = xp.v;
+      for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = col[i];
+      if (pt == 0) {
+        for (int i = 0; i < HB_NC; ++i) {
+          double r0 = 0, r1 = 0, r2 = 0;
+          if (is_pos) {
+            if (cf[i]) { if (dir == 8) r2 = C.zv_gain; }
+            else { if (dir == 8) r0 = C.kp_normal; if (dir == 6) r1 = C.xy_gain; if (dir == 7) r2 = C.xy_gain; }
+          }
+          CDt[dir * 12 + 3 * i + 0] = r0;
+          CDt[dir * 12 + 3 * i + 1] = r1;
+          CDt[dir * 12 + 3 * i + 2] = r2;
+        }
+      }
     }
-#pragma unroll
-    for (int j = 0; j < HB_NJ; ++j) {
-      ABt[dir * 22 + 12 + j] = (dir == 12 + j ? 1.0 : 0.0) + (dir == 34 + j ? dt : 0.0);
-      if (dir == 0) xplus[12 + j] = xs[12 + j] + dt * us[12 + j];
+    if (pt == 0) {
+      cx.sync();
+      // second evaluation point of Heun's method: x + dt f(x,u), same input
+      for (int i = cx.lane; i < 22; i += cx.nlanes) xe[i] = xs[i] + dt * (i < 12 ? fv[i] : us[i]);
     }
+    cx.sync();
   }
-  cx.sync();  // xs/us alias Kx: all lanes must be done with them before phase 2 writes Kx
+  // ---- compose  x+ = x + dt/2 (f1 + f2(x + dt f1)) :
+  //   d x+_i / d dir = [dir==i] + dt/2 (J1 + J2)[dir][i] + dt^2/2 ( sum_{c<12} J2[c][i] J1[dir][c] + sum_j J2[12+j][i] [dir==34+j] )
+  for (int idx = cx.lane; idx < 44 * 22; idx += cx.nlanes) {
+    const int dir = idx / 22, i = idx % 22;
+    double v;
+    if (i < 12) {
+      double acc = 0.0;
+      for (int c = 0; c < 12; ++c) acc += J2[c * 12 + i] * J1[dir * 12 + c];
+      if (dir >= 34) acc += J2[(12 + dir - 34) * 12 + i];
+      v = (dir == i ? 1.0 : 0.0) + 0.5 * dt * (J1[dir * 12 + i] + J2[dir * 12 + i]) + 0.5 * dt * dt * acc;
+    } else {
+      v = (dir == i ? 1.0 : 0.0) + (dir == 22 + i ? dt : 0.0);
+    }
+    ABt[idx] = v;
+  }
+  for (int i = cx.lane; i < 22; i += cx.nlanes)
+    xplus[i] = (i < 12) ? xs[i] + 0.5 * dt * (fv[i] + fv[12 + i]) : xs[i] + dt * us[i];
+  cx.sync();
   // slot classification (uniform)
   int n_eq = 0, n_soft = 0, n_f = 0;
   for (int i = 0; i < HB_NC; ++i) {
@@ -303,6 +393,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   if (cx.lane == 0) ints[10] = rank_l;
   cx.sync();
+  if (C.debug_stop == 2) return;
   const int rank = ints[10];
   const int nz = 10 - rank;
   // L(i,s) = GtG[perm[i]*10 + perm[s]] for i >= s.
@@ -340,6 +431,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     }
   }
 
+  if (C.debug_stop == 3) return;
   // -------------------------------------------------------------- phase 4a: cost pieces, one "role" per lane
   // roles 0..21 state entries, 22..43 input entries, 44..55 constraint slots, 56..59 friction barrier values.
   // Partial sums (cost, defect^2, equality^2) are reduced through LDS (scratch aliases Mm, not live yet).
@@ -449,6 +541,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     scal[w] = sacc;
   }
   cx.sync();
+  if (C.debug_stop == 4) return;
   // soft rows: gradients and the dense pieces P_j, R_jj
   for (int c = cx.lane; c < 22; c += cx.nlanes) {
     double s = 0;
@@ -487,6 +580,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   cx.sync();
 
+  if (C.debug_stop == 5) return;
   // -------------------------------------------------------------- phase 3+4b: write the projected record
   const int ntil = n_f + nz;
   // A~ = A + B_j Kx

@@ -149,11 +149,10 @@ HB_HD Vec3<T> euler_rates_from_omega(T sz, T cz, T sy, T cy, Vec3<T> w) {
 
 // Centroidal evaluation at pinocchio coordinates q = [pos, zyx, joints] given normalised momentum hn(6)
 // and joint velocities qd(10): base velocity from  A_b v_b = m hn - A_j qd  in closed form.
-template <class T, class QF, class QDF>
-HB_HD void centroidal_eval_f(const DevModel& M, const T* zyx, QF qj, const T* hn, QDF qdj, Centroidal<T>& out) {
-  LegOut<T> L0, L1;
-  leg_eval<T>(M, 0, qj, qdj, L0);
-  leg_eval<T>(M, 1, qj, qdj, L1);
+// Whole-body part of the centroidal evaluation given the two leg results (base frame).
+template <class T>
+HB_HD void centroidal_combine(const DevModel& M, const LegOut<T>& L0, const LegOut<T>& L1, const T* zyx, const T* hn,
+                              Centroidal<T>& out) {
   // whole-body composite in the base frame
   const T mb = T(M.mass[0]);
   const Vec3<T> cb(T(M.com[0][0]), T(M.com[0][1]), T(M.com[0][2]));
@@ -200,6 +199,15 @@ HB_HD void centroidal_eval_f(const DevModel& M, const T* zyx, QF qj, const T* hn
     out.foot_vel[0 + 2 * f] = out.v_lin + cross(out.omega, out.foot_rel[0 + 2 * f]) + R * L0.foot_vj[f];
     out.foot_vel[1 + 2 * f] = out.v_lin + cross(out.omega, out.foot_rel[1 + 2 * f]) + R * L1.foot_vj[f];
   }
+}
+
+
+template <class T, class QF, class QDF>
+HB_HD void centroidal_eval_f(const DevModel& M, const T* zyx, QF qj, const T* hn, QDF qdj, Centroidal<T>& out) {
+  LegOut<T> L0, L1;
+  leg_eval<T>(M, 0, qj, qdj, L0);
+  leg_eval<T>(M, 1, qj, qdj, L1);
+  centroidal_combine<T>(M, L0, L1, zyx, hn, out);
 }
 
 template <class T>

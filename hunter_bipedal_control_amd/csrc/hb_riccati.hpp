@@ -18,7 +18,49 @@ struct RicLds {
   static constexpr int total = flag + 4;
 };
 
+// ---- small dense GEMM on one wavefront --------------------------------------------------------------------
+// C(M x N) = C0 + A(M x K) B(K x N) with element accessors (zero outside the logical ranges).  On the device it runs
+// on the matrix cores: v_mfma_f64_16x16x4_f64, A/B fragments one f64 per lane (A[i = l&15][k = l>>4],
+// B[k = l>>4][j = l&15]), accumulator rows (l>>4) + 4 r, column l&15 (cdna_hip_programming.md §3, f64 layout).
+// The host build (tests/host_emu only) uses plain loops.
+template <class Ctx, class FA, class FB, class FC, class FS>
+HB_HD void wave_gemm(const Ctx& cx, int Mr, int Nr, int Kr, FA a_at, FB b_at, FC c_init, FS store) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double double4_t __attribute__((ext_vector_type(4)));
+  const int l = cx.lane, li = l & 15, lk = l >> 4;
+  for (int tm = 0; tm < Mr; tm += 16)
+    for (int tn = 0; tn < Nr; tn += 16) {
+      double4_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = tm + lk + 4 * r, col = tn + li;
+        acc[r] = (row < Mr && col < Nr) ? c_init(row, col) : 0.0;
+      }
+      for (int k0 = 0; k0 < Kr; k0 += 4) {
+        const int ia = tm + li, ka = k0 + lk, jb = tn + li;
+        const double av = (ia < Mr && ka < Kr) ? a_at(ia, ka) : 0.0;
+        const double bv = (ka < Kr && jb < Nr) ? b_at(ka, jb) : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = tm + lk + 4 * r, col = tn + li;
+        if (row < Mr && col < Nr) store(row, col, acc[r]);
+      }
+    }
+#else
+  for (int idx = cx.lane; idx < Mr * Nr; idx += cx.nlanes) {
+    const int i = idx / Nr, j = idx % Nr;
+    double acc = c_init(i, j);
+    for (int k = 0; k < Kr; ++k) acc += a_at(i, k) * b_at(k, j);
+    store(i, j, acc);
+  }
+#endif
+}
+
 // One backward step. `node` already holds the stage record in LDS. Updates S, s in place; writes the gains.
+//   M1 = S [A~ B~ b~] (+ s),  Hu = B~' M1 + [P~ R~ r~],  K~ = -Huu^-1 [Hux hu],
+//   S <- sym(Q~ + A~' M1_A + Hux' K~),  s <- q~ + A~' M1_b + Hux' k~          
 template <class Ctx>
 HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, double* gains) {
   double* S = lds + RicLds::S;
@@ -30,82 +72,72 @@ HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, double* gains) {
   const double* At = nd + REC_AT;
   const double* Bt = nd + REC_BT;
   const double* bt = nd + REC_bT;
-  // M1 = S [A~ B~ b~], last column += s
-  for (int idx = cx.lane; idx < 22 * 35; idx += cx.nlanes) {
-    const int i = idx / 35, c = idx % 35;
-    double acc = 0.0;
-    if (c < 22) {
-      for (int j = 0; j < 22; ++j) acc += S[i * 22 + j] * At[j * 22 + c];
-    } else if (c < 34) {
-      for (int j = 0; j < 22; ++j) acc += S[i * 22 + j] * Bt[j * NU_T + (c - 22)];
-    } else {
-      for (int j = 0; j < 22; ++j) acc += S[i * 22 + j] * bt[j];
-      acc += sv[i];
+  wave_gemm(cx, 22, 35, 22,
+            [S](int i, int k) { return S[i * 22 + k]; },
+            [At, Bt, bt](int k, int c) { return c < 22 ? At[k * 22 + c] : (c < 34 ? Bt[k * NU_T + (c - 22)] : bt[k]); },
+            [sv](int i, int c) { return c == 34 ? sv[i] : 0.0; },
+            [M1](int i, int c, double v) { M1[i * 35 + c] = v; });
+  cx.sync();
+  wave_gemm(cx, NU_T, 35, 22,
+            [Bt](int a, int j) { return Bt[j * NU_T + a]; },
+            [M1](int j, int c) { return M1[j * 35 + c]; },
+            [nd](int a, int c) { return c < 22 ? nd[REC_PT + a * 22 + c] : (c < 34 ? nd[REC_RT + a * NU_T + (c - 22)] : nd[REC_rT + a]); },
+            [Hu](int a, int c, double v) { Hu[a * 35 + c] = v; });
+  cx.sync();
+  // Cholesky of Huu and the 23 triangular solves entirely in registers: every lane factors the (uniform) 12x12
+  // block redundantly, lane c < 23 then solves its own right-hand side — no LDS traffic, no barriers.
+  {
+    double L[NU_T * (NU_T + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < NU_T; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = Hu[i * 35 + 22 + j];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NU_T; ++j) {
+      double d = L[j * (j + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) d -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+      if (!(d > 0.0)) { bad = true; d = 1.0; }
+      const double inv = 1.0 / sqrt(d);
+      L[j * (j + 1) / 2 + j] = inv;  // store the reciprocal of the diagonal
+#pragma unroll
+      for (int i = j + 1; i < NU_T; ++i) {
+        double sacc = L[i * (i + 1) / 2 + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) sacc -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+        L[i * (i + 1) / 2 + j] = sacc * inv;
+      }
     }
-    M1[idx] = acc;
+    if (bad && cx.lane == 0) lds[RicLds::flag] = 1.0;
+    for (int c = cx.lane; c < 23; c += cx.nlanes) {
+      const int src = (c < 22) ? c : 34;
+      double y[NU_T];
+#pragma unroll
+      for (int a = 0; a < NU_T; ++a) {
+        double sacc = -Hu[a * 35 + src];
+#pragma unroll
+        for (int k = 0; k < a; ++k) sacc -= L[a * (a + 1) / 2 + k] * y[k];
+        y[a] = sacc * L[a * (a + 1) / 2 + a];
+      }
+#pragma unroll
+      for (int a = NU_T - 1; a >= 0; --a) {
+        double sacc = y[a];
+#pragma unroll
+        for (int k = a + 1; k < NU_T; ++k) sacc -= L[k * (k + 1) / 2 + a] * y[k];
+        y[a] = sacc * L[a * (a + 1) / 2 + a];
+      }
+#pragma unroll
+      for (int a = 0; a < NU_T; ++a) Kk[a * 23 + c] = y[a];
+    }
   }
   cx.sync();
-  // Hu = B~' M1 + [P~ | R~ | r~]
-  for (int idx = cx.lane; idx < NU_T * 35; idx += cx.nlanes) {
-    const int a = idx / 35, c = idx % 35;
-    double acc = (c < 22) ? nd[REC_PT + a * 22 + c] : (c < 34 ? nd[REC_RT + a * NU_T + (c - 22)] : nd[REC_rT + a]);
-    for (int j = 0; j < 22; ++j) acc += Bt[j * NU_T + a] * M1[j * 35 + c];
-    Hu[idx] = acc;
-  }
-  cx.sync();
-  // Cholesky of Huu (in place, lower), right-looking and lane-parallel
-  for (int j = 0; j < NU_T; ++j) {
-    double dj = Hu[j * 35 + 22 + j];
-    bool bad = !(dj > 0.0);
-    if (bad) dj = 1.0;
-    const double l = sqrt(dj);
-    cx.sync();
-    for (int i = j + 1 + cx.lane; i < NU_T; i += cx.nlanes) Hu[i * 35 + 22 + j] /= l;
-    if (cx.lane == 0) {
-      Hu[j * 35 + 22 + j] = l;
-      if (bad) lds[RicLds::flag] = 1.0;
-    }
-    cx.sync();
-    const int nt = NU_T - 1 - j;
-    for (int idx = cx.lane; idx < nt * nt; idx += cx.nlanes) {
-      const int i = j + 1 + idx / nt, k = j + 1 + idx % nt;
-      if (k <= i) Hu[i * 35 + 22 + k] -= Hu[i * 35 + 22 + j] * Hu[k * 35 + 22 + j];
-    }
-    cx.sync();
-  }
-  // K~ = -Huu^-1 [Hux | hu]: one right-hand side per lane
-  for (int c = cx.lane; c < 23; c += cx.nlanes) {
-    const int src = (c < 22) ? c : 34;
-    double y[NU_T];
-    for (int a = 0; a < NU_T; ++a) {
-      double sacc = -Hu[a * 35 + src];
-      for (int k = 0; k < a; ++k) sacc -= Hu[a * 35 + 22 + k] * y[k];
-      y[a] = sacc / Hu[a * 35 + 22 + a];
-    }
-    for (int a = NU_T - 1; a >= 0; --a) {
-      double sacc = y[a];
-      for (int k = a + 1; k < NU_T; ++k) sacc -= Hu[k * 35 + 22 + a] * y[k];
-      y[a] = sacc / Hu[a * 35 + 22 + a];
-    }
-    for (int a = 0; a < NU_T; ++a) Kk[a * 23 + c] = y[a];
-  }
-  cx.sync();
-  // T = Q~ + A~' M1_A + Hux' K~   (written over the Q~ slot of the node record), s_new likewise over q~
-  for (int idx = cx.lane; idx < 484 + 22; idx += cx.nlanes) {
-    if (idx < 484) {
-      const int i = idx / 22, c = idx % 22;
-      double acc = nd[REC_QT + idx];
-      for (int j = 0; j < 22; ++j) acc += At[j * 22 + i] * M1[j * 35 + c];
-      for (int a = 0; a < NU_T; ++a) acc += Hu[a * 35 + i] * Kk[a * 23 + c];
-      nd[REC_QT + idx] = acc;
-    } else {
-      const int i = idx - 484;
-      double acc = nd[REC_qT + i];
-      for (int j = 0; j < 22; ++j) acc += At[j * 22 + i] * M1[j * 35 + 34];
-      for (int a = 0; a < NU_T; ++a) acc += Hu[a * 35 + i] * Kk[a * 23 + 22];
-      nd[REC_qT + i] = acc;
-    }
-  }
+  // T = [Q~ q~] + [A~' Hux'] [M1_A M1_b ; K~ k~]  written over the Q~/q~ slots of the node record
+  wave_gemm(cx, 22, 23, 22 + NU_T,
+            [At, Hu](int i, int k) { return k < 22 ? At[k * 22 + i] : Hu[(k - 22) * 35 + i]; },
+            [M1, Kk](int k, int c) { return k < 22 ? M1[k * 35 + (c < 22 ? c : 34)] : Kk[(k - 22) * 23 + c]; },
+            [nd](int i, int c) { return c < 22 ? nd[REC_QT + i * 22 + c] : nd[REC_qT + i]; },
+            [nd](int i, int c, double v) { if (c < 22) nd[REC_QT + i * 22 + c] = v; else nd[REC_qT + i] = v; });
   for (int idx = cx.lane; idx < NU_T * 23; idx += cx.nlanes) {
     const int a = idx / 23, c = idx % 23;
     if (c < 22) gains[a * 22 + c] = Kk[idx];

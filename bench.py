@@ -49,11 +49,23 @@ def make_batch(params, batch, n_intervals, first_inst):
     return refs, cat(x01), cat(rbd1), cat(tn1)
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: scheduler affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(params, n_intervals, seconds_budget=20.0):
     """Times the CPU oracle ("port": a restatement of OCS2 + qpOASES semantics, not the upstream binaries) on the
     host cores for a bounded sample of the same workload."""
     from oracle.pyoracle import Oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     o = Oracle(params)
     n = cores  # one instance per core and repetition
     refs, x0, rbd, t_now = make_batch(params, n, n_intervals, first_inst=0)
@@ -94,7 +106,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from hunter_bipedal_control_amd import ingest
+    from hunter_bipedal_control_amd import ingest, sharding
     from hunter_bipedal_control_amd.solver import HunterSolver
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,12 +143,9 @@ def main():
     s.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = sharding.max_over_ranks(elapsed, dist, device="cuda")
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * B * args.steps / elapsed
+    value = sharding.aggregate_throughput(B, world, args.steps, elapsed)
 
     # per-kernel device time: HIP events recorded on the library's own MPC / WBC streams (hb_get_stats), averaged
     # over extra un-timed steps with a sync after each so the events are complete.
@@ -153,6 +162,7 @@ def main():
     perf = s.get_performance()
     sol, status = s.get_wbc_solution()
     s.close()
+    hist = sharding.sum_over_ranks([int((status == k).sum()) for k in range(4)], dist, device="cuda")
 
     if rank == 0:
         dom = max(("k_lq", "k_ric_bwd", "k_ric_fwd"), key=lambda k: phases[k])
@@ -179,7 +189,7 @@ def main():
                          "whole_update_frac_of_hbm_roofline": (BYTES_PER_UPDATE(N) * value / world) / (HBM_PEAK_GBS * 1e9)},
             "phase_ms": phases,
             "solver_state": {"max_dyn_sse": float(perf[:, 1].max()), "max_eq_sse": float(perf[:, 2].max()),
-                             "wbc_status_nonzero": int((status != 0).sum())},
+                             "wbc_status_histogram_all_ranks": hist},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(params, N)

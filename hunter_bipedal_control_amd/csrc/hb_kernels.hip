@@ -243,6 +243,8 @@ struct hb_ctx {
   std::string err;
   WbcBatch w{};
   hb_stats stats{};
+  double* x0_seq = nullptr;  // optional device-resident sequence of measured states for hb_step_resident
+  int n_seq = 0, seq_idx = 0;
 };
 
 static thread_local std::string g_create_error;
@@ -594,6 +596,23 @@ int32_t hb_set_resident_inputs(hb_ctx* ctx, const double* x0, const double* t_no
   return HB_OK;
 }
 
+int32_t hb_set_resident_x0_sequence(hb_ctx* ctx, int32_t n_seq, const double* x0_seq) {
+  if (!ctx || n_seq < 0 || (n_seq > 0 && !x0_seq)) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  ctx->n_seq = 0;
+  ctx->seq_idx = 0;
+  if (n_seq == 0) return HB_OK;
+  const size_t bytes = size_t(n_seq) * ctx->B * HB_NX * 8;
+  if (hipMalloc(reinterpret_cast<void**>(&ctx->x0_seq), bytes) != hipSuccess) {
+    ctx->err = "hb_set_resident_x0_sequence: hipMalloc failed";
+    return HB_ERR_DEVICE;
+  }
+  ctx->allocs.push_back(ctx->x0_seq);
+  HB_HIP(hipMemcpy(ctx->x0_seq, x0_seq, bytes, hipMemcpyHostToDevice));
+  ctx->n_seq = n_seq;
+  return HB_OK;
+}
+
 int32_t hb_step_resident(hb_ctx* ctx, double dt) {
   if (!ctx) return HB_ERR_ARG;
   if (!ctx->refs_set || !ctx->traj_set) {
@@ -601,6 +620,11 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
     return HB_ERR_STATE;
   }
   HB_HIP(hipSetDevice(ctx->device));
+  if (ctx->n_seq > 0) {
+    HB_HIP(hipMemcpyAsync(ctx->b.x0, ctx->x0_seq + size_t(ctx->seq_idx) * ctx->B * HB_NX, size_t(ctx->B) * HB_NX * 8,
+                          hipMemcpyDeviceToDevice, ctx->s_mpc));
+    ctx->seq_idx = (ctx->seq_idx + 1) % ctx->n_seq;
+  }
   int32_t rc = mpc_iterations(ctx);
   if (rc != HB_OK) return rc;
   rc = hb_mpc_publish(ctx);

@@ -179,6 +179,10 @@ int32_t hb_wbc_update_direct(hb_ctx* ctx, const double* x_des, const double* u_d
 int32_t hb_set_resident_inputs(hb_ctx* ctx, const double* x0, const double* t_now, const double* rbd,
                                const int32_t* walk_flag);
 int32_t hb_step_resident(hb_ctx* ctx, double dt);
+/* Optional: a device-resident cyclic sequence of measured states x0_seq[n_seq][batch][22]; step k of
+ * hb_step_resident starts its MPC solve from x0_seq[k % n_seq] (emulates the estimator feeding a new state each
+ * MPC call, LeggedController.cpp:141-144).  n_seq = 0 disables it. */
+int32_t hb_set_resident_x0_sequence(hb_ctx* ctx, int32_t n_seq, const double* x0_seq);
 int32_t hb_get_wbc_solution(hb_ctx* ctx, double* sol /*[batch][38]*/, int32_t* status /*[batch]*/);
 
 /* ---- misc ------------------------------------------------------------------------------------ */

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <thread>
 
+#include "hoqp.hpp"
 #include "sqp.hpp"
 #include "wbc.hpp"
 
@@ -280,6 +281,55 @@ int orc_lsqp(int n, int mA, const double* A, const double* b, double eps, int mE
   std::memcpy(x, r.x.data(), 8 * n);
   if (iters) *iters = r.iterations;
   return r.status;
+}
+
+
+// Generic hierarchical QP (property tests, legged_wbc/test/HoQp_test.cpp): L levels, highest priority first;
+// level l has mA[l] equality-type rows (A,b) and mD[l] inequality rows (D,f), all with n columns, concatenated.
+int orc_hoqp(int n, int L, const int* mA, const double* A, const double* b, const int* mD, const double* D, const double* f,
+             double eps, int max_iter, double* x, double* slack, int* n_slack_out) {
+  std::vector<Task> tasks(L);
+  size_t oa = 0, od = 0;
+  for (int l = 0; l < L; ++l) {
+    Task& t = tasks[l];
+    t.A = Mat(mA[l], n); t.D = Mat(mD[l], n);
+    if (mA[l]) std::memcpy(t.A.a.data(), A + oa * n, 8 * size_t(mA[l]) * n);
+    if (mD[l]) std::memcpy(t.D.a.data(), D + od * n, 8 * size_t(mD[l]) * n);
+    t.b.assign(b + oa, b + oa + mA[l]);
+    t.f.assign(f + od, f + od + mD[l]);
+    oa += mA[l]; od += mD[l];
+  }
+  const HoQpLevelResult r = hoqp_solve(tasks, n, eps, max_iter);
+  std::memcpy(x, r.x.data(), 8 * n);
+  if (slack) std::memcpy(slack, r.slack.data(), 8 * r.slack.size());
+  if (n_slack_out) *n_slack_out = int(r.slack.size());
+  return r.status;
+}
+
+// Batched HierarchicalWbc::update.
+void orc_hwbc_update(void* h, int n, const double* x_des, const double* u_des, const double* rbd, const int* mode, double* sol,
+                     int* status, int threads) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  parallel_for(n, threads, [&](int i) {
+    const HoQpLevelResult r = hierarchical_wbc(pb, x_des + size_t(i) * HB_NX, u_des + size_t(i) * HB_NU, rbd + size_t(i) * HB_NRBD, mode[i]);
+    std::memcpy(sol + size_t(i) * HB_NWBC, r.x.data(), 8 * HB_NWBC);
+    if (status) status[i] = r.status;
+  });
+}
+
+// Task rows of the three HierarchicalWbc levels of one instance (for property checks).
+int orc_hwbc_tasks(void* h, const double* x_des, const double* u_des, const double* rbd, int mode, int level, double* A, double* b,
+                   int* mA, double* D, double* f, int* mD) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  WbcWorkspace ws;
+  ws.update(pb, x_des, u_des, rbd, mode);
+  Task t;
+  if (level == 0) t = Task::stack(Task::stack(Task::stack(ws.eom(), ws.torque_limits()), ws.friction_cone()), ws.no_contact_motion());
+  else if (level == 1) t = ws.base_accel();
+  else t = Task::stack(ws.contact_force(u_des).scaled(0.1), ws.swing_leg());
+  copy_mat(t.A, A); std::memcpy(b, t.b.data(), t.b.size() * 8); *mA = t.A.r;
+  copy_mat(t.D, D); std::memcpy(f, t.f.data(), t.f.size() * 8); *mD = t.D.r;
+  return 0;
 }
 
 }  // extern "C"

@@ -200,3 +200,37 @@ class Oracle:
                                _opt(E), _opt(e), C.c_int(D.shape[0]), _opt(D), _opt(f), C.c_int(max_iter), _opt(x),
                                C.byref(it))
         return x, st, it.value
+
+    # ---- hierarchical QP / HierarchicalWbc ------------------------------------------------------------
+    def hoqp(self, tasks, eps=1e-8, max_iter=500):
+        """tasks: list (highest priority first) of dicts with optional A,b (A x = b) and D,f (D x <= f)."""
+        n = max(max(t["A"].shape[1] if "A" in t and t["A"].size else 0, t["D"].shape[1] if "D" in t and t["D"].size else 0) for t in tasks)
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        A = c(np.vstack([t.get("A", np.zeros((0, n))).reshape(-1, n) for t in tasks]))
+        b = c(np.concatenate([np.atleast_1d(t.get("b", np.zeros(0))) for t in tasks]))
+        D = c(np.vstack([t.get("D", np.zeros((0, n))).reshape(-1, n) for t in tasks]))
+        f = c(np.concatenate([np.atleast_1d(t.get("f", np.zeros(0))) for t in tasks]))
+        mA = np.array([t.get("A", np.zeros((0, n))).reshape(-1, n).shape[0] for t in tasks], dtype=np.int32)
+        mD = np.array([t.get("D", np.zeros((0, n))).reshape(-1, n).shape[0] for t in tasks], dtype=np.int32)
+        x, slack, ns = np.zeros(n), np.zeros(max(1, int(mD.sum()))), C.c_int()
+        st = self.lib.orc_hoqp(C.c_int(n), C.c_int(len(tasks)), _opt(mA), _opt(A), _opt(b), _opt(mD), _opt(D), _opt(f),
+                               C.c_double(eps), C.c_int(max_iter), _opt(x), _opt(slack), C.byref(ns))
+        return x, slack[: ns.value], st
+
+    def hwbc_update(self, x_des, u_des, rbd, mode, threads=1):
+        c = lambda a: np.ascontiguousarray(np.atleast_2d(a), dtype=np.float64)
+        x_des, u_des, rbd = c(x_des), c(u_des), c(rbd)
+        n = x_des.shape[0]
+        mode = np.ascontiguousarray(np.atleast_1d(mode), dtype=np.int32)
+        sol, status = np.zeros((n, 38)), np.zeros(n, dtype=np.int32)
+        self.lib.orc_hwbc_update(self.h, C.c_int(n), _opt(x_des), _opt(u_des), _opt(rbd), _opt(mode), _opt(sol), _opt(status), C.c_int(threads))
+        return sol, status
+
+    def hwbc_tasks(self, x_des, u_des, rbd, mode, level):
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        A, b, D, f = np.zeros((64, 38)), np.zeros(64), np.zeros((64, 38)), np.zeros(64)
+        mA, mD = C.c_int(), C.c_int()
+        self.lib.orc_hwbc_tasks(self.h, _opt(c(x_des)), _opt(c(u_des)), _opt(c(rbd)), C.c_int(mode), C.c_int(level), _opt(A), _opt(b),
+                                C.byref(mA), _opt(D), _opt(f), C.byref(mD))
+        r = lambda M, k: M.reshape(-1)[: k * 38].reshape(k, 38).copy()
+        return dict(A=r(A, mA.value), b=b[: mA.value].copy(), D=r(D, mD.value), f=f[: mD.value].copy())

@@ -182,69 +182,52 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       int tl = -1, ts = 0;
       if (dir >= 12 && dir < 22) { tl = (dir - 12) / 5; ts = (dir - 12) % 5; }
       if (dir >= 34) { tl = (dir - 34) / 5; ts = 5 + (dir - 34) % 5; }
-      LegOut<Dual1> L[2];
+      // leg sums (value of both legs, tangent of the one leg this direction seeds)
+      const double* t = LT + ((tl < 0 ? 0 : tl) * 10 + ts) * 27;
+      const double w = (tl >= 0) ? 1.0 : 0.0;
+      auto S = [LV, t, w](int e) { return Dual1(LV[e] + LV[27 + e], w * t[e]); };
+      CentroidalCore<Dual1> core;
+      {
+        Dual1 zyx[3], hn[6];
 #pragma unroll
-      for (int leg = 0; leg < 2; ++leg) {
-        const double* v = LV + leg * 27;
-        const double* t = LT + (leg * 10 + ts) * 27;
-        const double w = (tl == leg) ? 1.0 : 0.0;
-        auto D = [v, t, w](int e) { return Dual1(v[e], w * t[e]); };
-        LegOut<Dual1>& o = L[leg];
-        o.m = Dual1(leg == 0 ? M.mass[1] + M.mass[2] + M.mass[3] + M.mass[4] + M.mass[5]
-                             : M.mass[6] + M.mass[7] + M.mass[8] + M.mass[9] + M.mass[10]);
-        o.mc = Vec3<Dual1>(D(0), D(1), D(2));
-        o.IO.xx = D(3); o.IO.xy = D(4); o.IO.xz = D(5); o.IO.yy = D(6); o.IO.yz = D(7); o.IO.zz = D(8);
-        o.l_sum = Vec3<Dual1>(D(9), D(10), D(11));
-        o.L_sum = Vec3<Dual1>(D(12), D(13), D(14));
-        o.foot[0] = Vec3<Dual1>(D(15), D(16), D(17));
-        o.foot[1] = Vec3<Dual1>(D(18), D(19), D(20));
-        o.foot_vj[0] = Vec3<Dual1>(D(21), D(22), D(23));
-        o.foot_vj[1] = Vec3<Dual1>(D(24), D(25), D(26));
+        for (int i = 0; i < 6; ++i) hn[i] = Dual1(xe[i], dir == i ? 1.0 : 0.0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) zyx[i] = Dual1(xe[9 + i], dir == 9 + i ? 1.0 : 0.0);
+        Sym3<Dual1> IOs;
+        IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
+        centroidal_core<Dual1>(M, Vec3<Dual1>(S(0), S(1), S(2)), IOs, Vec3<Dual1>(S(9), S(10), S(11)),
+                               Vec3<Dual1>(S(12), S(13), S(14)), zyx, hn, core);
       }
-      Dual1 zyx[3], hn[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) hn[i] = Dual1(xe[i], dir == i ? 1.0 : 0.0);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) zyx[i] = Dual1(xe[9 + i], dir == 9 + i ? 1.0 : 0.0);
-      Centroidal<Dual1> c;
-      centroidal_combine<Dual1>(M, L[0], L[1], zyx, hn, c);
-      Vec3<Dual1> fs, ms;
-#pragma unroll
+      // contact points one at a time (rolled loop keeps the register footprint small)
+      Vec3<Dual1> ms;
+#pragma unroll 1
       for (int i = 0; i < HB_NC; ++i) {
+        const int leg = i & 1, f = i >> 1;
+        const double* v = LV + leg * 27 + 15 + 3 * f;
+        const double* tt = LT + (leg * 10 + ts) * 27 + 15 + 3 * f;
+        const double wl = (tl == leg) ? 1.0 : 0.0;
+        const Vec3<Dual1> fb{Dual1(v[0], wl * tt[0]), Dual1(v[1], wl * tt[1]), Dual1(v[2], wl * tt[2])};
+        const Vec3<Dual1> vb{Dual1(v[6], wl * tt[6]), Dual1(v[7], wl * tt[7]), Dual1(v[8], wl * tt[8])};
+        Vec3<Dual1> fr, fvel;
+        centroidal_foot<Dual1>(core, fb, vb, fr, fvel);
+        const Vec3<Dual1> rr = fr - core.com_rel;
         const Vec3<Dual1> F{Dual1(us[3 * i]), Dual1(us[3 * i + 1]), Dual1(us[3 * i + 2])};
-        fs = fs + F;
-        ms = ms + cross(c.foot_rel[i] - c.com_rel, F);
-      }
-      const double inv_m = 1.0 / M.total_mass;
-      const Dual1 f[12] = {inv_m * fs.x, inv_m * fs.y, inv_m * fs.z - M.gravity, inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
-                           c.v_lin.x, c.v_lin.y, c.v_lin.z, c.euler_rate.x, c.euler_rate.y, c.euler_rate.z};
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = f[i].d;
-      if (dir == 0) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) fv[pt * 12 + i] = f[i].v;
-#pragma unroll
-        for (int i = 0; i < HB_NC; ++i) {
-          const Vec3<Dual1> rr = c.foot_rel[i] - c.com_rel;
-          FR[3 * i] = rr.x.v; FR[3 * i + 1] = rr.y.v; FR[3 * i + 2] = rr.z.v;
-        }
-      }
-      if (pt == 0) {
-        // constraint rows: slot 3i+a  (base position enters only through the closed-form lanes below)
-#pragma unroll
-        for (int i = 0; i < HB_NC; ++i) {
-          const Dual1 pz = Dual1(xs[8]) + c.foot_rel[i].z;
+        ms = ms + cross(rr, F);
+        if (dir == 0) { FR[3 * i] = rr.x.v; FR[3 * i + 1] = rr.y.v; FR[3 * i + 2] = rr.z.v; }
+        if (pt == 0) {
+          // constraint rows: slot 3i+a  (base position enters only through the closed-form lanes below)
+          const Dual1 pz = Dual1(xs[8]) + fr.z;
           Dual1 r0, r1, r2;
           if (cf[i]) {  // zero velocity (LeggedInterface.cpp:436-444)
-            r0 = c.foot_vel[i].x;
-            r1 = c.foot_vel[i].y;
-            r2 = c.foot_vel[i].z + C.zv_gain * pz + C.zv_off;
+            r0 = fvel.x;
+            r1 = fvel.y;
+            r2 = fvel.z + C.zv_gain * pz + C.zv_off;
           } else {      // normal velocity + xy soft reference (LeggedRobotPreComputation.cpp:96-117)
             const double* sw = in.swing + 6 * i;
-            const Dual1 px = Dual1(xs[6]) + c.foot_rel[i].x, py = Dual1(xs[7]) + c.foot_rel[i].y;
-            r0 = c.foot_vel[i].z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
-            r1 = C.xy_gain * px + c.foot_vel[i].x - (sw[3] + C.xy_gain * sw[0]);
-            r2 = C.xy_gain * py + c.foot_vel[i].y - (sw[4] + C.xy_gain * sw[1]);
+            const Dual1 px = Dual1(xs[6]) + fr.x, py = Dual1(xs[7]) + fr.y;
+            r0 = fvel.z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
+            r1 = C.xy_gain * px + fvel.x - (sw[3] + C.xy_gain * sw[0]);
+            r2 = C.xy_gain * py + fvel.y - (sw[4] + C.xy_gain * sw[1]);
           }
           CDt[dir * 12 + 3 * i + 0] = r0.d;
           CDt[dir * 12 + 3 * i + 1] = r1.d;
@@ -255,6 +238,17 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
             rowval[3 * i + 2] = r2.v;
           }
         }
+      }
+      const double inv_m = 1.0 / M.total_mass;
+      double fsx = 0, fsy = 0, fsz = 0;
+      for (int i = 0; i < HB_NC; ++i) { fsx += us[3 * i]; fsy += us[3 * i + 1]; fsz += us[3 * i + 2]; }
+      const Dual1 f[12] = {Dual1(inv_m * fsx), Dual1(inv_m * fsy), Dual1(inv_m * fsz - M.gravity), inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
+                           core.v_lin.x, core.v_lin.y, core.v_lin.z, core.euler_rate.x, core.euler_rate.y, core.euler_rate.z};
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = f[i].d;
+      if (dir == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) fv[pt * 12 + i] = f[i].v;
       }
     }
     cx.sync();

@@ -149,58 +149,67 @@ HB_HD Vec3<T> euler_rates_from_omega(T sz, T cz, T sy, T cy, Vec3<T> w) {
 
 // Centroidal evaluation at pinocchio coordinates q = [pos, zyx, joints] given normalised momentum hn(6)
 // and joint velocities qd(10): base velocity from  A_b v_b = m hn - A_j qd  in closed form.
-// Whole-body part of the centroidal evaluation given the two leg results (base frame).
+// Whole-body part of the centroidal evaluation, split so that callers with tight register budgets can loop over
+// the contact points: `core` from the summed leg composites, then one contact point at a time.
 template <class T>
-HB_HD void centroidal_combine(const DevModel& M, const LegOut<T>& L0, const LegOut<T>& L1, const T* zyx, const T* hn,
-                              Centroidal<T>& out) {
-  // whole-body composite in the base frame
-  const T mb = T(M.mass[0]);
+struct CentroidalCore {
+  Mat3<T> R;            // base rotation
+  Vec3<T> omega, euler_rate, v_lin, com_rel;
+};
+// sums over both legs (base frame): mc, IO about the base origin, momentum of the joint rates (l, L about the origin)
+template <class T>
+HB_HD void centroidal_core(const DevModel& M, Vec3<T> mc_legs, Sym3<T> IO_legs, Vec3<T> lj, Vec3<T> Lj_O, const T* zyx,
+                           const T* hn, CentroidalCore<T>& out) {
+  const double mb = M.mass[0], mt = M.total_mass;
   const Vec3<T> cb(T(M.com[0][0]), T(M.com[0][1]), T(M.com[0][2]));
   Sym3<T> Ib;
   Ib.xx = T(M.inertia[0][0]); Ib.xy = T(M.inertia[0][1]); Ib.xz = T(M.inertia[0][2]);
   Ib.yy = T(M.inertia[0][3]); Ib.yz = T(M.inertia[0][4]); Ib.zz = T(M.inertia[0][5]);
-  const T mt = mb + L0.m + L1.m;
-  const Vec3<T> mc = mb * cb + L0.mc + L1.mc;
-  const Sym3<T> IO = Ib + point_inertia<T>(mb, cb) + L0.IO + L1.IO;
-  const T inv_m = T(1.0) / mt;
-  const Vec3<T> P = inv_m * mc;  // COM in the base frame
+  const Vec3<T> mc = T(mb) * cb + mc_legs;
+  const Sym3<T> IO = Ib + point_inertia<T>(T(mb), cb) + IO_legs;
+  const double inv_m = 1.0 / mt;
+  const Vec3<T> P = T(inv_m) * mc;  // COM in the base frame
   Sym3<T> Icom = IO;
   {
-    const Sym3<T> sh = point_inertia<T>(mt, P);
+    const Sym3<T> sh = point_inertia<T>(T(mt), P);
     Icom.xx = Icom.xx - sh.xx; Icom.xy = Icom.xy - sh.xy; Icom.xz = Icom.xz - sh.xz;
     Icom.yy = Icom.yy - sh.yy; Icom.yz = Icom.yz - sh.yz; Icom.zz = Icom.zz - sh.zz;
   }
-  // base rotation R = Rz Ry Rx
   T sz, cz, sy, cy, sx, cx;
   sincos_t(zyx[0], sz, cz);
   sincos_t(zyx[1], sy, cy);
   sincos_t(zyx[2], sx, cx);
-  Mat3<T> R;
+  Mat3<T>& R = out.R;
   R.m[0] = cz * cy; R.m[1] = cz * sy * sx - sz * cx; R.m[2] = cz * sy * cx + sz * sx;
   R.m[3] = sz * cy; R.m[4] = sz * sy * sx + cz * cx; R.m[5] = sz * sy * cx - cz * sx;
   R.m[6] = -sy;     R.m[7] = cy * sx;                R.m[8] = cy * cx;
-  // momentum carried by the joint velocities, about the COM, base frame
-  const Vec3<T> lj = L0.l_sum + L1.l_sum;
-  const Vec3<T> Lj = (L0.L_sum + L1.L_sum) - cross(P, lj);
-  // angular: I_com w_b = R^T (m hn_ang) - Lj
+  const Vec3<T> Lj = Lj_O - cross(P, lj);  // joint-rate momentum about the COM
   const Vec3<T> hang_w(mt * hn[3], mt * hn[4], mt * hn[5]);
   const Vec3<T> wb = sym3_solve<T>(Icom, tmul(R, hang_w) - Lj);
   out.omega = R * wb;
   out.euler_rate = euler_rates_from_omega<T>(sz, cz, sy, cy, out.omega);
-  // linear: m v_lin + m w x (R P) + R lj = m hn_lin
   out.com_rel = R * P;
   const Vec3<T> hlin(hn[0], hn[1], hn[2]);
-  out.v_lin = hlin - cross(out.omega, out.com_rel) - inv_m * (R * lj);
-  // contact points
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    out.foot_rel[0 + 2 * f] = R * L0.foot[f];
-    out.foot_rel[1 + 2 * f] = R * L1.foot[f];
-    out.foot_vel[0 + 2 * f] = out.v_lin + cross(out.omega, out.foot_rel[0 + 2 * f]) + R * L0.foot_vj[f];
-    out.foot_vel[1 + 2 * f] = out.v_lin + cross(out.omega, out.foot_rel[1 + 2 * f]) + R * L1.foot_vj[f];
-  }
+  out.v_lin = hlin - cross(out.omega, out.com_rel) - T(inv_m) * (R * lj);
+}
+template <class T>
+HB_HD void centroidal_foot(const CentroidalCore<T>& c, Vec3<T> foot_b, Vec3<T> vj_b, Vec3<T>& foot_rel, Vec3<T>& foot_vel) {
+  foot_rel = c.R * foot_b;
+  foot_vel = c.v_lin + cross(c.omega, foot_rel) + c.R * vj_b;
 }
 
+template <class T>
+HB_HD void centroidal_combine(const DevModel& M, const LegOut<T>& L0, const LegOut<T>& L1, const T* zyx, const T* hn,
+                              Centroidal<T>& out) {
+  CentroidalCore<T> c;
+  centroidal_core<T>(M, L0.mc + L1.mc, L0.IO + L1.IO, L0.l_sum + L1.l_sum, L0.L_sum + L1.L_sum, zyx, hn, c);
+  out.v_lin = c.v_lin; out.euler_rate = c.euler_rate; out.omega = c.omega; out.com_rel = c.com_rel;
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    centroidal_foot<T>(c, L0.foot[f], L0.foot_vj[f], out.foot_rel[0 + 2 * f], out.foot_vel[0 + 2 * f]);
+    centroidal_foot<T>(c, L1.foot[f], L1.foot_vj[f], out.foot_rel[1 + 2 * f], out.foot_vel[1 + 2 * f]);
+  }
+}
 
 template <class T, class QF, class QDF>
 HB_HD void centroidal_eval_f(const DevModel& M, const T* zyx, QF qj, const T* hn, QDF qdj, Centroidal<T>& out) {

@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--nodes", type=int, default=100, help="shooting intervals N")
+    ap.add_argument("--chunks", type=int, default=1, help="instance ranges pipelined on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -143,6 +144,7 @@ def main():
     s.reset(x0)
     s.set_resident_inputs(x0, t_now, rbd)
     s.set_resident_x0_sequence(x0_sequence(x0, rank))
+    s.set_chunks(args.chunks)
 
     def barrier():
         s.sync()
@@ -165,6 +167,7 @@ def main():
 
     # per-kernel device time: HIP events recorded on the library's own MPC / WBC streams (hb_get_stats), averaged
     # over extra un-timed steps with a sync after each so the events are complete.
+    s.set_chunks(1)  # phase times are recorded on one stream
     phases = {"k_lq": 0.0, "k_ric_bwd": 0.0, "k_ric_fwd": 0.0, "linesearch": 0.0, "k_wbc": 0.0}
     n_prof = 5
     for _ in range(n_prof):
@@ -198,7 +201,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"batch={B}/GPU hunter instances, trot gait, N={N} shooting intervals (dt 0.015 s), "
                                    "1 SQP iteration + WeightedWbc per update, inputs resident in HBM (BASELINE.json configs[2])",
-                       "batch_per_gpu": B, "horizon_nodes": N, "parallelism": f"instances sharded x{world}, no data-path collective"},
+                       "batch_per_gpu": B, "horizon_nodes": N, "parallelism": f"instances sharded x{world}, no data-path collective; {args.chunks} pipelined instance ranges per GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": phases[dom],

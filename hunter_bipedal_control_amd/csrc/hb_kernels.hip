@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "hb_host.hpp"
@@ -245,6 +246,10 @@ struct hb_ctx {
   hb_stats stats{};
   double* x0_seq = nullptr;  // optional device-resident sequence of measured states for hb_step_resident
   int n_seq = 0, seq_idx = 0;
+  // instance chunks pipelined on their own streams by hb_step_resident (independent instances: the latency-bound
+  // per-instance sweeps of one chunk overlap the per-node kernels of another)
+  int n_chunks = 1;
+  hipStream_t s_chunk[8]{};
 };
 
 static thread_local std::string g_create_error;
@@ -309,6 +314,8 @@ int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch,
   if ((e = hipStreamCreateWithFlags(&ctx->s_wbc, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
   for (auto& ev : ctx->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return fail("event", e);
+  for (auto& sc : ctx->s_chunk)
+    if ((e = hipStreamCreateWithFlags(&sc, hipStreamNonBlocking)) != hipSuccess) return fail("chunk stream", e);
   const size_t B = batch, N = max_nodes;
   Batch& b = ctx->b;
   b.B = batch;
@@ -368,6 +375,7 @@ void hb_destroy(hb_ctx* ctx) {
   for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(ctx->s_mpc);
   (void)hipStreamDestroy(ctx->s_wbc);
+  for (auto& sc : ctx->s_chunk) (void)hipStreamDestroy(sc);
   delete ctx;
 }
 
@@ -375,6 +383,7 @@ int32_t hb_sync(hb_ctx* ctx) {
   if (!ctx) return HB_ERR_ARG;
   HB_HIP(hipStreamSynchronize(ctx->s_mpc));
   HB_HIP(hipStreamSynchronize(ctx->s_wbc));
+  for (auto& sc : ctx->s_chunk) HB_HIP(hipStreamSynchronize(sc));
   return HB_OK;
 }
 
@@ -437,12 +446,34 @@ int32_t hb_mpc_set_trajectory(hb_ctx* ctx, const double* x, const double* u) {
   return HB_OK;
 }
 
-static int32_t mpc_iterations(hb_ctx* ctx) {
-  Batch& b = ctx->b;
-  hipStream_t s = ctx->s_mpc;
-  const int B = ctx->B, N = ctx->Nmax;
+// sub-batch [i0, i0 + cnt) of a batch: same layout, offset base pointers
+static Batch batch_view(const Batch& b, int i0, int cnt) {
+  Batch v = b;
+  const size_t N = b.Nmax, o = i0;
+  v.B = cnt;
+  v.n_nodes += o; v.t += o * (N + 1); v.mode += o * N; v.xref += o * N * HB_NX; v.swing += o * N * 24;
+  v.x += o * (N + 1) * HB_NX; v.u += o * N * HB_NU; v.x0 += o * HB_NX; v.recs += o * N * REC_SIZE; v.gains += o * N * GAIN_SIZE;
+  v.dx += o * (N + 1) * HB_NX; v.du += o * N * HB_NU; v.acc += o * 4; v.partial += o * N * 3; v.accepted += o; v.perf += o * 4;
+  v.ric_fail += o;
+  return v;
+}
+static WbcBatch wbc_view(const WbcBatch& w, int Nmax, int i0, int cnt) {
+  WbcBatch v = w;
+  const size_t N = Nmax, o = i0;
+  v.B = cnt;
+  v.t_now += o; v.rbd += o * HB_NRBD; v.walk += o; v.xdes += o * HB_NX; v.udes += o * HB_NU; v.mode += o; v.stance += o;
+  v.sol += o * HB_NWBC; v.status += o; v.iters += o;
+  v.px += o * (N + 1) * HB_NX; v.pu += o * N * HB_NU; v.pt += o * (N + 1); v.pmode += o * N; v.pn += o;
+  return v;
+}
+
+static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t stream = nullptr) {
+  const bool whole = cnt < 0;
+  const Batch b = whole ? ctx->b : batch_view(ctx->b, i0, cnt);
+  hipStream_t s = whole ? ctx->s_mpc : stream;
+  const int B = b.B, N = ctx->Nmax;
   for (int it = 0; it < ctx->config.sqp_iterations; ++it) {
-    const bool timed = (it == 0);
+    const bool timed = (it == 0) && whole;
     hipLaunchKernelGGL(k_set_x0, dim3((B * HB_NX + 255) / 256), dim3(256), 0, s, b);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[0], s));
     hipLaunchKernelGGL(k_lq, dim3(N, B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig);
@@ -460,7 +491,7 @@ static int32_t mpc_iterations(hb_ctx* ctx) {
     if (timed) HB_HIP(hipEventRecord(ctx->ev[4], s));
   }
   HB_HIP(hipGetLastError());
-  ctx->timed = true;
+  if (whole) ctx->timed = true;
   ctx->stats.n_mpc_solves += B;
   return HB_OK;
 }
@@ -625,14 +656,51 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
                           hipMemcpyDeviceToDevice, ctx->s_mpc));
     ctx->seq_idx = (ctx->seq_idx + 1) % ctx->n_seq;
   }
-  int32_t rc = mpc_iterations(ctx);
+  if (ctx->n_chunks <= 1) {
+    int32_t rc = mpc_iterations(ctx);
+    if (rc != HB_OK) return rc;
+    rc = hb_mpc_publish(ctx);
+    if (rc != HB_OK) return rc;
+    rc = wbc_launch(ctx, true, dt);
+    if (rc != HB_OK) return rc;
+    // the next MPC iteration must not overwrite the policy buffers while the WBC reads them
+    HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev[6], 0));
+    return HB_OK;
+  }
+  // pipelined: every chunk of instances is a linear sequence MPC -> publish -> policy evaluation -> WBC on its own stream
+  if (ctx->n_seq > 0) {
+    HB_HIP(hipEventRecord(ctx->ev[7], ctx->s_mpc));
+    for (int c = 0; c < ctx->n_chunks; ++c) HB_HIP(hipStreamWaitEvent(ctx->s_chunk[c], ctx->ev[7], 0));
+  }
+  const int per = (ctx->B + ctx->n_chunks - 1) / ctx->n_chunks;
+  const size_t N = ctx->Nmax;
+  for (int c = 0; c < ctx->n_chunks; ++c) {
+    const int i0 = c * per, cnt = std::min(per, ctx->B - i0);
+    if (cnt <= 0) break;
+    hipStream_t s = ctx->s_chunk[c];
+    int32_t rc = mpc_iterations(ctx, i0, cnt, s);
+    if (rc != HB_OK) return rc;
+    const Batch b = batch_view(ctx->b, i0, cnt);
+    const WbcBatch w = wbc_view(ctx->w, ctx->Nmax, i0, cnt);
+    HB_HIP(hipMemcpyAsync(w.px, b.x, size_t(cnt) * (N + 1) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemcpyAsync(w.pu, b.u, size_t(cnt) * N * HB_NU * 8, hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemcpyAsync(w.pt, b.t, size_t(cnt) * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemcpyAsync(w.pmode, b.mode, size_t(cnt) * N * sizeof(int), hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemcpyAsync(w.pn, b.n_nodes, size_t(cnt) * sizeof(int), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_policy_eval, dim3((cnt + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
+    hipLaunchKernelGGL(k_wbc, dim3(cnt), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
+    HB_HIP(hipGetLastError());
+  }
+  ctx->w.policy_valid = true;
+  ctx->stats.n_wbc_solves += ctx->B;
+  return HB_OK;
+}
+
+int32_t hb_set_chunks(hb_ctx* ctx, int32_t n_chunks) {
+  if (!ctx || n_chunks < 1 || n_chunks > 8) return HB_ERR_ARG;
+  int32_t rc = hb_sync(ctx);
   if (rc != HB_OK) return rc;
-  rc = hb_mpc_publish(ctx);
-  if (rc != HB_OK) return rc;
-  rc = wbc_launch(ctx, true, dt);
-  if (rc != HB_OK) return rc;
-  // the next MPC iteration must not overwrite the policy buffers while the WBC reads them
-  HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev[6], 0));
+  ctx->n_chunks = n_chunks;
   return HB_OK;
 }
 

@@ -174,6 +174,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       }
     }
     cx.sync();
+    if (C.debug_stop == 6 + 2 * pt) return;
     // ---- stage 2: whole-body combine per direction
     for (int dir = cx.lane; dir < 44; dir += cx.nlanes) {
       const bool nonlinear = (dir < 6) || (dir >= 9 && dir < 22) || dir >= 34;
@@ -252,6 +253,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       }
     }
     cx.sync();
+    if (C.debug_stop == 7 + 2 * pt) return;
     // closed-form directions: base position (6..8) and contact forces (22..33)
     for (int dir = cx.lane; dir < 44; dir += cx.nlanes) {
       const bool is_pos = dir >= 6 && dir < 9, is_f = dir >= 22 && dir < 34;
@@ -309,6 +311,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   for (int i = cx.lane; i < 22; i += cx.nlanes)
     xplus[i] = (i < 12) ? xs[i] + 0.5 * dt * (fv[i] + fv[12 + i]) : xs[i] + dt * us[i];
   cx.sync();
+  if (C.debug_stop == 1) return;
   // slot classification (uniform)
   int n_eq = 0, n_soft = 0, n_f = 0;
   for (int i = 0; i < HB_NC; ++i) {

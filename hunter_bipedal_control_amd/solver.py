@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "hb_create", "hb_destroy", "hb_last_error", "hb_mpc_set_references", "hb_mpc_reset", "hb_mpc_set_trajectory",
     "hb_mpc_solve", "hb_mpc_publish", "hb_mpc_get_solution", "hb_mpc_get_performance", "hb_mpc_get_step",
     "hb_wbc_update", "hb_wbc_update_direct", "hb_set_resident_inputs", "hb_step_resident", "hb_set_resident_x0_sequence",
-    "hb_get_wbc_solution",
+    "hb_get_wbc_solution", "hb_set_chunks",
     "hb_sync", "hb_get_stats", "hb_get_input_cost", "hb_version", "hb_eval_flow_map", "hb_eval_foot_kinematics",
     "hb_eval_rbd", "hb_riccati_solve",
 ]
@@ -164,6 +164,9 @@ class HunterSolver:
         x0_seq = _f64(x0_seq)
         assert x0_seq.ndim == 3 and x0_seq.shape[1:] == (self.B, 22)
         self._check(self.lib.hb_set_resident_x0_sequence(self.ctx, C.c_int32(x0_seq.shape[0]), _p(x0_seq)), "hb_set_resident_x0_sequence")
+
+    def set_chunks(self, n_chunks: int):
+        self._check(self.lib.hb_set_chunks(self.ctx, C.c_int32(n_chunks)), "hb_set_chunks")
 
     def step_resident(self, dt=0.002):
         self._check(self.lib.hb_step_resident(self.ctx, C.c_double(dt)), "hb_step_resident")

@@ -334,6 +334,16 @@ def trot_schedule(params: dict, t_start: float, t_final: float) -> ModeSchedule:
     return ModeSchedule(list(gs.s.event_times), list(gs.s.modes))
 
 
+def gait_schedule(params: dict, gait: str, t_start: float, t_final: float) -> ModeSchedule:
+    """STANCE until t_start, then the named gait template of gait.info (stance / trot / standing_trot / flying_trot)."""
+    c = params["config"]
+    tpl0 = ModeTemplate(c["default_mode_template"]["switching_times"], c["default_mode_template"]["modes"])
+    gs = GaitSchedule(ModeSchedule([], [STANCE]), tpl0, c["phase_transition_stance_time"])
+    g = c["gaits"][gait]
+    gs.insert_template(ModeTemplate(g["switching_times"], g["modes"]), t_start, t_final)
+    return ModeSchedule(list(gs.s.event_times), list(gs.s.modes))
+
+
 def stance_schedule() -> ModeSchedule:
     return ModeSchedule([], [STANCE])
 
@@ -363,10 +373,10 @@ def foot_positions(model: dict, x: np.ndarray) -> np.ndarray:
 
 
 def make_trot_problem(params: dict, t0: float, horizon: float, x0: np.ndarray, cmd_vel, max_nodes: int,
-                      t_gait_start: float = 0.1):
-    """Node tables for one instance walking with the trot template under a velocity command."""
+                      t_gait_start: float = 0.1, gait: str = "trot"):
+    """Node tables for one instance walking with a gait template (default trot) under a velocity command."""
     c = params["config"]
-    sched = trot_schedule(params, t_gait_start, t0 + 2 * horizon + 1.0)
+    sched = gait_schedule(params, gait, t_gait_start, t0 + 2 * horizon + 1.0)
     targets = cmd_vel_targets(t0, x0, cmd_vel, horizon, c["com_height"], c["default_joint_state"])
     planner = SwingTrajectoryPlanner(c["swing"])
     planner.body_vel_cmd = np.array([cmd_vel[0], cmd_vel[1], cmd_vel[2], 0.0, 0.0, cmd_vel[3]])

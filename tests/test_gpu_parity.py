@@ -207,3 +207,133 @@ def test_full_size_properties(params, oracle):
     assert status.max() == 0
     tl = np.tile(np.array(params["config"]["torque_limits"]), 2)
     assert (np.abs(sol[:, 28:]) <= tl + 1e-8).all()
+
+
+def _oracle_cold(oracle, refs, x0, nmax):
+    B = x0.shape[0]
+    xo = np.zeros((B, nmax + 1, 22)); uo = np.zeros((B, nmax, 22))
+    for i in range(B):
+        n = int(refs["n_nodes"][i])
+        xo[i, :n + 1], uo[i, :n] = oracle.cold_start(refs["mode"][i, :n], x0[i])
+    return xo, uo
+
+
+def test_ragged_horizons_all_modes_and_off_grid_events(params, oracle):
+    """Edge cases: per-instance horizon lengths (incl. a single interval), event times off the dt grid (variable
+    dt), every contact mode (STANCE / L / R / FLY: projected input widths 12 / 9 / 9 / 6)."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    nmax = 64
+    x0 = np.array(params["config"]["initial_state"])
+    specs = [("trot", 0.03, 0.75), ("standing_trot", 0.03, 0.7), ("flying_trot", 0.03, 0.7), ("trot", 0.1, 0.015),
+             ("flying_trot", 0.26, 0.2), ("stance", 0.0, 0.3), ("trot", 0.37, 0.9), ("standing_trot", 0.2, 0.33)]
+    tabs, xs = [], []
+    for i, (gait, t0, hor) in enumerate(specs):
+        xi = workload.perturbed_state(params, 100 + i)
+        tabs.append(refgen.make_trot_problem(params, t0, hor, xi, (0.25, 0.05, 0.0, 0.2), nmax, gait=gait))
+        xs.append(xi)
+    refs, x0b = refgen.stack_tables(tabs), np.stack(xs)
+    assert refs["n_nodes"].min() == 1 and len(set(refs["n_nodes"].tolist())) > 3
+    modes_seen = set()
+    for i in range(len(specs)):
+        modes_seen |= set(refs["mode"][i, :refs["n_nodes"][i]].tolist())
+        d = np.diff(refs["t"][i, :refs["n_nodes"][i] + 1])
+        assert (d > 0).all()
+    assert modes_seen == {0, 1, 2, 3}
+    s = HunterSolver(params, batch=len(specs), max_nodes=nmax)
+    try:
+        s.set_references(refs)
+        s.reset(x0b)
+        xo, uo = _oracle_cold(oracle, refs, x0b, nmax)
+        for it in range(3):
+            perf_o, dxo, duo = oracle.mpc_solve(refs, x0b, xo, uo, iters=1, threads=4, want_step=True)
+            s.mpc_solve(x0b)
+            xg, ug = s.get_solution()
+            perf_g = s.get_performance()
+            for i in range(len(specs)):
+                n = int(refs["n_nodes"][i])
+                assert np.abs(xg[i, :n + 1] - xo[i, :n + 1]).max() < 1e-7, (it, i)
+                assert np.abs(ug[i, :n] - uo[i, :n]).max() < 1e-6, (it, i)
+            assert np.array_equal(perf_g[:, 3], perf_o[:, 3])
+    finally:
+        s.close()
+
+
+def test_config1_stance_and_standstill_target(params, oracle):
+    """BASELINE config 1 (single instance, STANCE, N = 20) through the ABI, and the stand-still branch of
+    LeggedController::update (walk flag off: LeggedController.cpp:161-173) feeding the stance-mode WBC."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    refs, x0, rbd, t_now = workload.stance_batch(params, 1, n_intervals=20)
+    s = HunterSolver(params, batch=1, max_nodes=20)
+    try:
+        s.set_references(refs)
+        s.reset(x0)
+        xo, uo = _oracle_cold(oracle, refs, x0, 20)
+        for _ in range(3):
+            oracle.mpc_solve(refs, x0, xo, uo, iters=1)
+            s.mpc_solve(x0)
+        xg, ug = s.get_solution()
+        assert np.abs(xg - xo).max() < 1e-7 and np.abs(ug - uo).max() < 1e-6
+        s.publish()
+        out = s.wbc_update(t_now, rbd, walk_flag=np.zeros(1, dtype=np.int32))
+        xd = np.zeros(22)
+        xd[6:9], xd[9:12], xd[12:] = rbd[0, 3:6], rbd[0, 0:3], params["config"]["default_joint_state"]
+        assert out["mode"][0] == 3 and np.abs(out["x_des"][0] - xd).max() == 0 and np.abs(out["u_des"]).max() == 0
+        so, sto, _ = oracle.wbc_update(xd, np.zeros(22), rbd, [3], stance_flag=[1])
+        assert out["status"][0] == sto[0] == 0
+        assert np.abs(out["sol"] - so).max() < 1e-7 * max(1.0, np.abs(so).max())
+        # walking branch of the same call evaluates the published policy
+        out2 = s.wbc_update(t_now, rbd, walk_flag=np.ones(1, dtype=np.int32))
+        a = (t_now[0] - refs["t"][0, 0]) / (refs["t"][0, 1] - refs["t"][0, 0])
+        assert np.abs(out2["x_des"][0] - ((1 - a) * xo[0, 0] + a * xo[0, 1])).max() < 1e-7
+    finally:
+        s.close()
+
+
+def test_committed_golden_fixture(params):
+    """GPU against tests/golden/oracle_regression.npz (no live oracle involved)."""
+    from pathlib import Path
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    G = np.load(Path(__file__).parent / "golden" / "oracle_regression.npz")
+    refs = {k[4:]: G[k] for k in G.files if k.startswith("ref_")}
+    B, nmax = refs["mode"].shape
+    s = HunterSolver(params, batch=B, max_nodes=nmax)
+    try:
+        f, A, Bm = s.eval_flow_map(G["x"], G["u"], jac=True)
+        assert np.abs(f - G["f"]).max() < 1e-10 and np.abs(A - G["A"]).max() < 1e-10 and np.abs(Bm - G["B"]).max() < 1e-10
+        s.set_references(refs)
+        s.reset(G["mpc_x0"])
+        perf = []
+        for _ in range(3):
+            s.mpc_solve(G["mpc_x0"])
+            perf.append(s.get_performance())
+        x, u = s.get_solution()
+        assert np.abs(x - G["mpc_x"]).max() < 1e-7 and np.abs(u - G["mpc_u"]).max() < 1e-6
+        assert np.allclose(np.array(perf), G["mpc_perf"], rtol=1e-6, atol=1e-9)
+    finally:
+        s.close()
+    n = G["wbc_mode"].shape[0]
+    s = HunterSolver(params, batch=n, max_nodes=4)
+    try:
+        sol, st = s.wbc_update_direct(G["wbc_xd"], G["wbc_ud"], G["wbc_rbd"], G["wbc_mode"], G["wbc_stance"])
+    finally:
+        s.close()
+    assert np.array_equal(st, G["wbc_status"])
+    assert np.abs(sol - G["wbc_sol"]).max() < 1e-6 * max(1.0, np.abs(G["wbc_sol"]).max())
+
+
+def test_error_conventions(params):
+    from hunter_bipedal_control_amd.solver import HunterSolver, HunterHipError
+    s = HunterSolver(params, batch=2, max_nodes=8)
+    try:
+        with pytest.raises(HunterHipError, match="hb_mpc_set_references"):
+            s.mpc_solve(np.zeros((2, 22)))                       # HB_ERR_STATE: no references yet
+        refs, x0, rbd, t_now = workload.stance_batch(params, 2, n_intervals=8)
+        bad = dict(refs)
+        bad["n_nodes"] = np.array([8, 9], dtype=np.int32)
+        with pytest.raises(HunterHipError, match="n_nodes"):
+            s.set_references(bad)                                # HB_ERR_ARG
+        s.set_references(refs)
+        with pytest.raises(HunterHipError):
+            s.wbc_update(t_now, rbd)                             # HB_ERR_STATE: nothing published
+    finally:
+        s.close()

@@ -1,0 +1,535 @@
+// HierarchicalWbc on the device: the three-level HoQp cascade of legged_wbc/src/HierarchicalWbc.cpp:18-30 and
+// legged_wbc/src/HoQp.cpp:21-198, one 64-lane workgroup per robot instance.
+//
+//   level 0  EoM + zero swing force + no contact motion (equality-type, least squares) with torque limits and the
+//            friction pyramid as slacked inequalities.  The slack QP  min 1/2|A z - b|^2 + 1/2|v|^2, v >= 0,
+//            D z - v <= f  is the piecewise quadratic  min 1/2|A z - b|^2 + 1/2|(D z - f)_+|^2 : solved by
+//            re-factorising over the set of violated rows until it is stable (empty in normal operation), so the
+//            38 + 40 variable QP of the reference is never formed.  v0 = (D z - f)_+.
+//   kernels  orthonormal bases from a Householder QR with column pivoting of A'  (reference: Eigen FullPivLU
+//            kernel; only the subspace matters).
+//   level 1  base acceleration, level 2  0.1 * contact force + swing legs: small dense QPs (<= 12 variables, <= 40
+//            hard rows D Z z <= f - D x_prev + v0) by a serial Goldfarb–Idnani on one lane.
+#pragma once
+#include "hb_wbc.hpp"
+
+namespace hb {
+
+// ---------------------------------------------------------------------------------------------------------
+// Householder QR with column pivoting of T (n x m, row-major, leading dimension ldt), accumulating Q (n x n).
+// Returns the numerical rank; columns rank..n-1 of Q are an orthonormal basis of the kernel of T'.
+template <class Ctx>
+HB_HD int householder_qr_pivot(const Ctx& cx, double* T, int n, int m, int ldt, double* Q, double* work) {
+  double* nrm = work;       // m
+  double* v = work + 40;    // n
+  for (int idx = cx.lane; idx < n * n; idx += cx.nlanes) Q[idx] = (idx / n == idx % n) ? 1.0 : 0.0;
+  cx.sync();
+  double r00 = 0.0;
+  int rank = 0;
+  const int steps = n < m ? n : m;
+  for (int j = 0; j < steps; ++j) {
+    for (int c = j + cx.lane; c < m; c += cx.nlanes) {
+      double s = 0.0;
+      for (int i = j; i < n; ++i) s += T[i * ldt + c] * T[i * ldt + c];
+      nrm[c] = s;
+    }
+    cx.sync();
+    int pv = j;
+    double best = nrm[j];
+    for (int c = j + 1; c < m; ++c)
+      if (nrm[c] > best) { best = nrm[c]; pv = c; }
+    const double rjj = sqrt(best);
+    if (j == 0) r00 = rjj;
+    if (!(rjj > 1e-9 * r00) || rjj == 0.0) break;
+    cx.sync();
+    if (pv != j)
+      for (int i = cx.lane; i < n; i += cx.nlanes) {
+        const double t = T[i * ldt + j];
+        T[i * ldt + j] = T[i * ldt + pv];
+        T[i * ldt + pv] = t;
+      }
+    cx.sync();
+    // reflector from column j, rows j..n-1
+    const double x0 = T[j * ldt + j];
+    const double alpha = x0 > 0.0 ? -rjj : rjj;
+    for (int i = cx.lane; i < n; i += cx.nlanes) v[i] = (i < j) ? 0.0 : (i == j ? x0 - alpha : T[i * ldt + j]);
+    cx.sync();
+    const double vtv = best - x0 * x0 + (x0 - alpha) * (x0 - alpha);
+    const double beta = 2.0 / vtv;
+    for (int c = j + cx.lane; c < m; c += cx.nlanes) {
+      double s = 0.0;
+      for (int i = j; i < n; ++i) s += v[i] * T[i * ldt + c];
+      s *= beta;
+      for (int i = j; i < n; ++i) T[i * ldt + c] -= s * v[i];
+    }
+    for (int q = cx.lane; q < n; q += cx.nlanes) {
+      double s = 0.0;
+      for (int i = j; i < n; ++i) s += Q[q * n + i] * v[i];
+      s *= beta;
+      for (int i = j; i < n; ++i) Q[q * n + i] -= s * v[i];
+    }
+    cx.sync();
+    rank = j + 1;
+  }
+  cx.sync();
+  return rank;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Serial (one lane) least-squares QP  min 1/2|A x - b|^2 + eps/2|x|^2  s.t. D x <= f,  n <= 12, by Goldfarb–Idnani.
+// A: mA x n (ld 12), D: mD x n (ld 12).  Workspace ws >= 2*144 + 12*6 + 40 doubles.  Returns 0 / 1 (iteration limit) / 2.
+HB_HD int small_lsqp(int n, int mA, const double* A, const double* b, double eps, int mD, const double* D, const double* f,
+                     int max_iter, double* x, double* ws) {
+  constexpr int LD = 12;
+  double* J = ws;            // n x n
+  double* R = ws + 144;      // n x n upper
+  double* d = ws + 288;
+  double* z = d + 12;
+  double* r = z + 12;
+  double* lam = r + 12;
+  double* np = lam + 12;
+  double* g = np + 12;
+  int* act = reinterpret_cast<int*>(g + 12);  // 12 ints
+  int* is_act = act + 12;                     // mD <= 40 ints
+  // R~ by Givens row insertion into sqrt(eps) I (stored in R), then J = R~^-1
+  const double se = sqrt(eps);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) R[i * LD + j] = (i == j) ? se : 0.0;
+  for (int i = 0; i < n; ++i) g[i] = 0.0;
+  for (int rw = 0; rw < mA; ++rw) {
+    for (int j = 0; j < n; ++j) {
+      np[j] = A[rw * LD + j];
+      g[j] += A[rw * LD + j] * b[rw];
+    }
+    for (int k = 0; k < n; ++k) {
+      const double a = R[k * LD + k], bb = np[k];
+      if (bb == 0.0) continue;
+      const double h = sqrt(a * a + bb * bb), cc = a / h, ss = bb / h;
+      for (int j = k; j < n; ++j) {
+        const double t1 = R[k * LD + j], t2 = np[j];
+        R[k * LD + j] = cc * t1 + ss * t2;
+        np[j] = -ss * t1 + cc * t2;
+      }
+    }
+  }
+  for (int col = 0; col < n; ++col) {
+    for (int i = n - 1; i > col; --i) J[i * LD + col] = 0.0;
+    for (int i = col; i >= 0; --i) {
+      double s = (i == col) ? 1.0 : 0.0;
+      for (int k = i + 1; k <= col; ++k) s -= R[i * LD + k] * J[k * LD + col];
+      J[i * LD + col] = s / R[i * LD + i];
+    }
+  }
+  for (int k = 0; k < n; ++k) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += J[i * LD + k] * g[i];
+    z[k] = s;
+  }
+  for (int i = 0; i < n; ++i) {
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) s += J[i * LD + k] * z[k];
+    x[i] = s;
+  }
+  for (int i = 0; i < n * LD; ++i) R[i] = 0.0;
+  for (int c = 0; c < mD; ++c) is_act[c] = 0;
+  int q = 0, iter = 0;
+  const double inf = 1e300;
+  while (true) {
+    int p = -1;
+    double sp = 0.0;
+    for (int c = 0; c < mD; ++c) {
+      if (is_act[c]) continue;
+      double s = -f[c], nn = 0.0;
+      for (int j = 0; j < n; ++j) { s += D[c * LD + j] * x[j]; nn += D[c * LD + j] * D[c * LD + j]; }
+      if (nn == 0.0) continue;
+      if (s > 1e-9 * fmax(1.0, fabs(f[c])) && (p < 0 || s > sp)) { p = c; sp = s; }
+    }
+    if (p < 0) return 0;
+    for (int j = 0; j < n; ++j) np[j] = D[p * LD + j];
+    double lam_p = 0.0;
+    while (true) {
+      if (++iter > max_iter) return 1;
+      for (int k = 0; k < n; ++k) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += J[i * LD + k] * np[i];
+        d[k] = s;
+      }
+      for (int i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int j = q; j < n; ++j) s += J[i * LD + j] * d[j];
+        z[i] = s;
+      }
+      for (int i = q - 1; i >= 0; --i) {
+        double s = d[i];
+        for (int k = i + 1; k < q; ++k) s -= R[i * LD + k] * r[k];
+        r[i] = s / R[i * LD + i];
+      }
+      double zn = 0.0, nn2 = 0.0;
+      sp = -f[p];
+      for (int i = 0; i < n; ++i) { zn += z[i] * np[i]; nn2 += np[i] * np[i]; sp += np[i] * x[i]; }
+      const double t2 = (zn > 1e-14 * (1.0 + nn2)) ? sp / zn : inf;
+      double t1 = inf;
+      int l = -1;
+      for (int j = 0; j < q; ++j)
+        if (r[j] > 0.0) {
+          const double tj = lam[j] / r[j];
+          if (tj < t1) { t1 = tj; l = j; }
+        }
+      const double t = fmin(t1, t2);
+      if (t >= inf) return 2;
+      if (t2 < inf)
+        for (int k = 0; k < n; ++k) x[k] -= t * z[k];
+      for (int j = 0; j < q; ++j) lam[j] -= t * r[j];
+      lam_p += t;
+      if (t2 < inf && t == t2) {
+        for (int j = n - 1; j > q; --j) {
+          const double a = d[j - 1], bb = d[j];
+          if (bb == 0.0) continue;
+          const double h = sqrt(a * a + bb * bb), cc = a / h, ss = bb / h;
+          d[j - 1] = h;
+          d[j] = 0.0;
+          for (int k = 0; k < n; ++k) {
+            const double t1j = J[k * LD + j - 1], t2j = J[k * LD + j];
+            J[k * LD + j - 1] = cc * t1j + ss * t2j;
+            J[k * LD + j] = -ss * t1j + cc * t2j;
+          }
+        }
+        if (q < n && fabs(d[q]) > 1e-13 * fmax(1.0, fabs(R[0]))) {
+          for (int i = 0; i <= q; ++i) R[i * LD + q] = d[i];
+          act[q] = p;
+          lam[q] = lam_p;
+          is_act[p] = 1;
+          ++q;
+        }
+        break;
+      }
+      // partial / dual-only step: drop active constraint l
+      is_act[act[l]] = 0;
+      for (int j = l; j < q - 1; ++j) {
+        for (int i = 0; i <= j + 1; ++i) R[i * LD + j] = R[i * LD + j + 1];
+        act[j] = act[j + 1];
+        lam[j] = lam[j + 1];
+      }
+      for (int i = 0; i < q; ++i) R[i * LD + q - 1] = 0.0;
+      --q;
+      for (int j = l; j < q; ++j) {
+        const double a = R[j * LD + j], bb = R[(j + 1) * LD + j];
+        if (bb == 0.0) continue;
+        const double h = sqrt(a * a + bb * bb), cc = a / h, ss = bb / h;
+        for (int k = j; k < q; ++k) {
+          const double t1j = R[j * LD + k], t2j = R[(j + 1) * LD + k];
+          R[j * LD + k] = cc * t1j + ss * t2j;
+          R[(j + 1) * LD + k] = -ss * t1j + cc * t2j;
+        }
+        R[(j + 1) * LD + j] = 0.0;
+        for (int k = 0; k < n; ++k) {
+          const double u1 = J[k * LD + j], u2 = J[k * LD + j + 1];
+          J[k * LD + j] = cc * u1 + ss * u2;
+          J[k * LD + j + 1] = -ss * u1 + cc * u2;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct HoLds {
+  static constexpr int J = 0;                     // 38x38
+  static constexpr int R = J + NW * NW;           // 38x38
+  static constexpr int Q = R + NW * NW;           // 38x38 orthogonal factor / kernel bases
+  static constexpr int T = Q + NW * NW;           // 38x28 (A0') then scratch
+  static constexpr int Ee = T + NW * 28;          // 16x38
+  static constexpr int Jc = Ee + 16 * NW;         // 12x16
+  static constexpr int dJv = Jc + 192;            // 12
+  static constexpr int Aw = dJv + 12;             // 18x16
+  static constexpr int bw = Aw + 288;             // 18
+  static constexpr int beom = bw + 18;            // 16
+  static constexpr int x = beom + 16;             // 38
+  static constexpr int g = x + NW;                // 38
+  static constexpr int z = g + NW;                // 38
+  static constexpr int np = z + NW;               // 38
+  static constexpr int v0 = np + NW;              // 40 slack of level 0
+  static constexpr int Z1 = v0 + 40;              // 38x12
+  static constexpr int Z2 = Z1 + NW * 12;         // 38x6 (ld 12)
+  static constexpr int AZ = Z2 + NW * 12;         // 24x12
+  static constexpr int rhs = AZ + 288;            // 24
+  static constexpr int DZ = rhs + 24;             // 40x12
+  static constexpr int ft = DZ + 480;             // 40
+  static constexpr int zs = ft + 40;              // 12 small solution
+  static constexpr int qpw = zs + 12;             // small QP workspace 2*144 + 72 + 40
+  static constexpr int work = qpw + 400;          // 80 (householder)
+  static constexpr int ints = work + 80;          // 64 ints: violated flags (40), misc
+  static constexpr int total = ints + 32;
+};
+
+template <class Ctx>
+HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const double* xdes, const double* udes,
+                      const double* rbd, int mode, double* lds, double* sol, int* status_out, int max_level = 3) {
+  double* Jm = lds + HoLds::J;
+  double* Rm = lds + HoLds::R;
+  double* Qm = lds + HoLds::Q;
+  double* Tm = lds + HoLds::T;
+  double* Ee = lds + HoLds::Ee;
+  double* Jc = lds + HoLds::Jc;
+  double* dJv = lds + HoLds::dJv;
+  double* Aw = lds + HoLds::Aw;
+  double* bw = lds + HoLds::bw;
+  double* beom = lds + HoLds::beom;
+  double* x = lds + HoLds::x;
+  double* g = lds + HoLds::g;
+  double* z = lds + HoLds::z;
+  double* np = lds + HoLds::np;
+  double* v0 = lds + HoLds::v0;
+  double* Z1 = lds + HoLds::Z1;
+  double* Z2 = lds + HoLds::Z2;
+  double* AZ = lds + HoLds::AZ;
+  double* rhs = lds + HoLds::rhs;
+  double* DZ = lds + HoLds::DZ;
+  double* ft = lds + HoLds::ft;
+  double* zs = lds + HoLds::zs;
+  double* qpw = lds + HoLds::qpw;
+  double* work = lds + HoLds::work;
+  int* viol = reinterpret_cast<int*>(lds + HoLds::ints);  // [40] current violated set, [40..] misc
+  int* imisc = viol + 48;
+
+  bool cf[HB_NC];
+  mode_flags(mode, cf);
+  WbcCons wc;
+  wc.n_sw = 0;
+  wc.n_c = 0;
+  for (int i = 0; i < HB_NC; ++i) {
+    if (cf[i]) wc.contact_feet[wc.n_c++] = i;
+    else wc.swing_feet[wc.n_sw++] = i;
+  }
+  wc.n_eq = 16 + 3 * wc.n_sw;
+  wc.n_in = 20 + 5 * wc.n_c;
+  const int mA0 = 16 + 3 * wc.n_sw + 3 * wc.n_c;  // always 28
+  if (cx.lane == 0)
+    wbc_phase_a(M, C, xdes, udes, rbd, wc, false, 1.0, 1.0, Rm, Ee, beom, Aw, bw, Jc, dJv);
+  for (int c = cx.lane; c < 40; c += cx.nlanes) viol[c] = 0;
+  cx.sync();
+
+  // dense row r of the level-0 equality-type task and its right-hand side
+  auto a0_row = [&](int r, int col) -> double {
+    if (r < 16) return Ee[r * NW + col];
+    if (r < 16 + 3 * wc.n_sw) {
+      const int s = r - 16;
+      return (col == 16 + 3 * wc.swing_feet[s / 3] + s % 3) ? 1.0 : 0.0;
+    }
+    const int s = r - 16 - 3 * wc.n_sw;
+    const int foot = wc.contact_feet[s / 3];
+    return col < 16 ? Jc[(3 * foot + s % 3) * 16 + col] : 0.0;
+  };
+  auto a0_rhs = [&](int r) -> double {
+    if (r < 16) return beom[r];
+    if (r < 16 + 3 * wc.n_sw) return 0.0;
+    const int s = r - 16 - 3 * wc.n_sw;
+    return -dJv[3 * wc.contact_feet[s / 3] + s % 3];
+  };
+  auto ineq_row = [&](int c, int col, double* rhs_out) -> double {
+    int idx[3];
+    double cfv[3], rh;
+    const int nn = sparse_row(wc, C, wc.n_eq + c, idx, cfv, &rh);
+    if (rhs_out) *rhs_out = rh;
+    double vv = 0.0;
+    for (int t = 0; t < nn; ++t)
+      if (idx[t] == col) vv = cfv[t];
+    return vv;
+  };
+
+  // ------------------------------------------------------------------ level 0
+  int status = 0;
+  const double se = sqrt(C.wbc_eps);
+  for (int it = 0; it < 12; ++it) {
+    for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Rm[idx] = (idx / NW == idx % NW) ? se : 0.0;
+    for (int i = cx.lane; i < NW; i += cx.nlanes) g[i] = 0.0;
+    cx.sync();
+    const int n_rows = mA0 + wc.n_in;
+    for (int rw = 0; rw < n_rows; ++rw) {
+      const bool is_a = rw < mA0;
+      if (!is_a && !viol[rw - mA0]) continue;
+      double rh = 0.0;
+      if (is_a) rh = a0_rhs(rw);
+      else ineq_row(rw - mA0, 0, &rh);
+      for (int i = cx.lane; i < NW; i += cx.nlanes) {
+        const double a = is_a ? a0_row(rw, i) : ineq_row(rw - mA0, i, nullptr);
+        np[i] = a;
+        g[i] += a * rh;
+      }
+      cx.sync();
+      for (int k = 0; k < NW; ++k) {
+        const double a = Rm[k * NW + k], b = np[k];
+        cx.sync();
+        if (b != 0.0) {
+          const double h = sqrt(a * a + b * b), cc = a / h, ss = b / h;
+          for (int j = k + cx.lane; j < NW; j += cx.nlanes) {
+            const double t1 = Rm[k * NW + j], t2 = np[j];
+            Rm[k * NW + j] = cc * t1 + ss * t2;
+            np[j] = -ss * t1 + cc * t2;
+          }
+        }
+        cx.sync();
+      }
+    }
+    for (int col = cx.lane; col < NW; col += cx.nlanes) {
+      for (int i = NW - 1; i > col; --i) Jm[i * NW + col] = 0.0;
+      for (int i = col; i >= 0; --i) {
+        double s = (i == col) ? 1.0 : 0.0;
+        for (int k = i + 1; k <= col; ++k) s -= Rm[i * NW + k] * Jm[k * NW + col];
+        Jm[i * NW + col] = s / Rm[i * NW + i];
+      }
+    }
+    cx.sync();
+    for (int k = cx.lane; k < NW; k += cx.nlanes) {
+      double s = 0.0;
+      for (int i = 0; i < NW; ++i) s += Jm[i * NW + k] * g[i];
+      z[k] = s;
+    }
+    cx.sync();
+    for (int i = cx.lane; i < NW; i += cx.nlanes) {
+      double s = 0.0;
+      for (int k = 0; k < NW; ++k) s += Jm[i * NW + k] * z[k];
+      x[i] = s;
+    }
+    cx.sync();
+    // violated set of the new point
+    if (cx.lane == 0) imisc[0] = 0;
+    cx.sync();
+    for (int c = cx.lane; c < wc.n_in; c += cx.nlanes) {
+      double rh;
+      int idx[3];
+      double cfv[3];
+      const int nn = sparse_row(wc, C, wc.n_eq + c, idx, cfv, &rh);
+      double s = -rh;
+      for (int t = 0; t < nn; ++t) s += cfv[t] * x[idx[t]];
+      const int nv = (s > 1e-10 * fmax(1.0, fabs(rh))) ? 1 : 0;
+      v0[c] = s > 0.0 ? s : 0.0;
+      if (nv != viol[c]) { viol[c] = nv; imisc[0] = 1; }
+    }
+    cx.sync();
+    if (!imisc[0]) break;
+    if (it == 11) status = HB_INST_MAXITER;
+  }
+  if (max_level <= 1) {
+    for (int i = cx.lane; i < NW; i += cx.nlanes) sol[i] = x[i];
+    if (cx.lane == 0) *status_out = status;
+    return;
+  }
+  // ------------------------------------------------------------------ kernel of the level-0 task: Z1
+  for (int idx = cx.lane; idx < NW * 28; idx += cx.nlanes) Tm[idx] = a0_row(idx % 28, idx / 28);
+  cx.sync();
+  const int r0 = householder_qr_pivot(cx, Tm, NW, mA0, 28, Qm, work);
+  const int n1 = NW - r0;  // 10..12
+  for (int idx = cx.lane; idx < NW * 12; idx += cx.nlanes) {
+    const int i = idx / 12, j = idx % 12;
+    Z1[idx] = j < n1 ? Qm[i * NW + r0 + j] : 0.0;
+  }
+  cx.sync();
+  // ------------------------------------------------------------------ level 1: base acceleration
+  const double* A1 = Aw + 3 * wc.n_sw * 16;
+  const double* b1 = bw + 3 * wc.n_sw;
+  for (int idx = cx.lane; idx < 6 * 12; idx += cx.nlanes) {
+    const int i = idx / 12, j = idx % 12;
+    double s = 0.0;
+    for (int c = 0; c < 16; ++c) s += A1[i * 16 + c] * Z1[c * 12 + j];
+    AZ[idx] = s;
+  }
+  for (int i = cx.lane; i < 6; i += cx.nlanes) {
+    double s = b1[i];
+    for (int c = 0; c < 16; ++c) s -= A1[i * 16 + c] * x[c];
+    rhs[i] = s;
+  }
+  for (int idx = cx.lane; idx < wc.n_in * 12; idx += cx.nlanes) {
+    const int c = idx / 12, j = idx % 12;
+    int ix[3];
+    double cfv[3], rh;
+    const int nn = sparse_row(wc, C, wc.n_eq + c, ix, cfv, &rh);
+    double s = 0.0, dx = 0.0;
+    for (int t = 0; t < nn; ++t) { s += cfv[t] * Z1[ix[t] * 12 + j]; dx += cfv[t] * x[ix[t]]; }
+    DZ[idx] = s;
+    if (j == 0) ft[c] = rh - dx + v0[c];
+  }
+  cx.sync();
+  if (cx.lane == 0) {
+    imisc[1] = small_lsqp(n1, 6, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw);
+  }
+  cx.sync();
+  if (imisc[1] > status) status = imisc[1];
+  for (int i = cx.lane; i < NW; i += cx.nlanes) {
+    double s = x[i];
+    for (int j = 0; j < n1; ++j) s += Z1[i * 12 + j] * zs[j];
+    g[i] = s;  // x2
+  }
+  cx.sync();
+  for (int i = cx.lane; i < NW; i += cx.nlanes) x[i] = g[i];
+  // kernel of A1 Z1 (6 x n1): QR of its transpose (n1 x 6)
+  for (int idx = cx.lane; idx < n1 * 6; idx += cx.nlanes) Tm[idx] = AZ[(idx % 6) * 12 + idx / 6];
+  cx.sync();
+  const int r1 = householder_qr_pivot(cx, Tm, n1, 6, 6, Qm, work);
+  const int n2 = n1 - r1;
+  for (int idx = cx.lane; idx < NW * 12; idx += cx.nlanes) {
+    const int i = idx / 12, j = idx % 12;
+    double s = 0.0;
+    if (j < n2)
+      for (int k = 0; k < n1; ++k) s += Z1[i * 12 + k] * Qm[k * n1 + r1 + j];
+    Z2[idx] = s;
+  }
+  cx.sync();
+  // ------------------------------------------------------------------ level 2: 0.1 * contact force + swing legs
+  if (n2 > 0 && max_level >= 3) {
+    const int m2 = 12 + 3 * wc.n_sw;
+    for (int idx = cx.lane; idx < m2 * 12; idx += cx.nlanes) {
+      const int i = idx / 12, j = idx % 12;
+      double s = 0.0;
+      if (i < 12) s = 0.1 * Z2[(16 + i) * 12 + j];
+      else
+        for (int c = 0; c < 16; ++c) s += Aw[(i - 12) * 16 + c] * Z2[c * 12 + j];
+      AZ[idx] = s;
+    }
+    for (int i = cx.lane; i < m2; i += cx.nlanes) {
+      double s;
+      if (i < 12) s = 0.1 * (udes[i] - x[16 + i]);
+      else {
+        s = bw[i - 12];
+        for (int c = 0; c < 16; ++c) s -= Aw[(i - 12) * 16 + c] * x[c];
+      }
+      rhs[i] = s;
+    }
+    for (int idx = cx.lane; idx < wc.n_in * 12; idx += cx.nlanes) {
+      const int c = idx / 12, j = idx % 12;
+      int ix[3];
+      double cfv[3], rh;
+      const int nn = sparse_row(wc, C, wc.n_eq + c, ix, cfv, &rh);
+      double s = 0.0, dx = 0.0;
+      for (int t = 0; t < nn; ++t) { s += cfv[t] * Z2[ix[t] * 12 + j]; dx += cfv[t] * x[ix[t]]; }
+      DZ[idx] = s;
+      if (j == 0) ft[c] = rh - dx + v0[c];
+    }
+    cx.sync();
+    if (cx.lane == 0) imisc[1] = small_lsqp(n2, m2, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw);
+    cx.sync();
+    if (imisc[1] > status) status = imisc[1];
+    for (int i = cx.lane; i < NW; i += cx.nlanes) {
+      double s = x[i];
+      for (int j = 0; j < n2; ++j) s += Z2[i * 12 + j] * zs[j];
+      g[i] = s;
+    }
+    cx.sync();
+    for (int i = cx.lane; i < NW; i += cx.nlanes) x[i] = g[i];
+    cx.sync();
+  }
+  for (int i = cx.lane; i < NW; i += cx.nlanes) sol[i] = x[i];
+  if (cx.lane == 0) *status_out = status;
+}
+
+#if defined(__HIPCC__)
+__global__ __launch_bounds__(64) void k_hwbc(WbcBatch w, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
+  const int inst = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) double lds_h[];
+  hwbc_solve(WbcDeviceCtx(), *M, *C, w.xdes + size_t(inst) * HB_NX, w.udes + size_t(inst) * HB_NU, w.rbd + size_t(inst) * HB_NRBD,
+             w.mode[inst], lds_h, w.sol + size_t(inst) * NW, w.status + inst);
+  if (threadIdx.x == 0) w.iters[inst] = 0;
+}
+#endif
+
+}  // namespace hb

@@ -12,6 +12,7 @@
 #include "hb_host.hpp"
 #include "hb_riccati.hpp"
 #include "hb_wbc.hpp"
+#include "hb_hoqp.hpp"
 
 using namespace hb;
 
@@ -358,6 +359,9 @@ int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch,
   A(w.pmode, B * N);
   A(w.pn, B);
 #undef A
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hwbc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(HoLds::total * sizeof(double)))) != hipSuccess)
+    return fail("k_hwbc LDS size", e);
   if ((e = hipMemcpy(ctx->dmodel, &ctx->hmodel, sizeof(DevModel), hipMemcpyHostToDevice)) != hipSuccess) return fail("model", e);
   if ((e = hipMemcpy(ctx->dconfig, &ctx->hconfig, sizeof(DevConfig), hipMemcpyHostToDevice)) != hipSuccess) return fail("config", e);
   // walking by default
@@ -563,7 +567,10 @@ static int32_t wbc_launch(hb_ctx* ctx, bool from_policy, double dt) {
   if (from_policy) {
     hipLaunchKernelGGL(k_policy_eval, dim3((ctx->B + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
   }
-  hipLaunchKernelGGL(k_wbc, dim3(ctx->B), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
+  if (ctx->config.wbc_type == 1)
+    hipLaunchKernelGGL(k_hwbc, dim3(ctx->B), dim3(64), HoLds::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
+  else
+    hipLaunchKernelGGL(k_wbc, dim3(ctx->B), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
   HB_HIP(hipEventRecord(ctx->ev[6], s));
   HB_HIP(hipGetLastError());
   ctx->stats.n_wbc_solves += ctx->B;
@@ -688,7 +695,10 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
     HB_HIP(hipMemcpyAsync(w.pmode, b.mode, size_t(cnt) * N * sizeof(int), hipMemcpyDeviceToDevice, s));
     HB_HIP(hipMemcpyAsync(w.pn, b.n_nodes, size_t(cnt) * sizeof(int), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_policy_eval, dim3((cnt + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
-    hipLaunchKernelGGL(k_wbc, dim3(cnt), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
+    if (ctx->config.wbc_type == 1)
+      hipLaunchKernelGGL(k_hwbc, dim3(cnt), dim3(64), HoLds::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
+    else
+      hipLaunchKernelGGL(k_wbc, dim3(cnt), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
     HB_HIP(hipGetLastError());
   }
   ctx->w.policy_valid = true;

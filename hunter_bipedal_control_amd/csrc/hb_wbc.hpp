@@ -273,6 +273,118 @@ HB_HD int sparse_row(const WbcCons& wc, const DevConfig& C, int cid, int* idx, d
   return 2;
 }
 
+// Phase A of every WBC variant (one lane): rigid-body quantities of the measured state, desired kinematics from the
+// MPC state/input, EoM rows and the dense cost rows [swing legs (weight w_swing) ; base acceleration (weight w_base)]
+// or, in stance mode, qdd_base = 0.  Rm is a 16x16 scratch.  Jc/dJv (optional) receive the contact Jacobians (12x16)
+// and bias accelerations (12).
+HB_HD void wbc_phase_a(const DevModel& M, const DevConfig& C, const double* xdes, const double* udes, const double* rbd,
+                       const WbcCons& wc, bool stance_mode, double w_swing, double w_base, double* Rm, double* Ee,
+                       double* beom, double* Aw, double* bw, double* Jc, double* dJv) {
+  {
+    double q[HB_NV], v[HB_NV];
+    for (int i = 0; i < 3; ++i) {
+      q[i] = rbd[3 + i];
+      q[3 + i] = rbd[i];
+      v[i] = rbd[HB_NV + 3 + i];
+    }
+    for (int j = 0; j < HB_NJ; ++j) {
+      q[6 + j] = rbd[6 + j];
+      v[6 + j] = rbd[HB_NV + 6 + j];
+    }
+    {
+      double sz, cz, sy, cy;
+      sincos_t(q[3], sz, cz);
+      sincos_t(q[4], sy, cy);
+      const Vec3<double> er = euler_rates_from_omega<double>(sz, cz, sy, cy, Vec3<double>(rbd[HB_NV], rbd[HB_NV + 1], rbd[HB_NV + 2]));
+      v[3] = er.x; v[4] = er.y; v[5] = er.z;
+    }
+    BodyPass P;
+    body_pass(M, q, v, P);
+    // EoM rows: [M, -J', -S'] x = -nle   (WbcBase.cpp:138-149)
+    mass_matrix(P, Rm);  // stage M in the R buffer (16x16)
+    for (int i = 0; i < 16; ++i) {
+      for (int j = 0; j < 16; ++j) Ee[i * NW + j] = Rm[i * 16 + j];
+      for (int ci = 0; ci < HB_NC; ++ci) {
+        const Vec3<double> jc = contact_jac(P, ci, i);
+        Ee[i * NW + 16 + 3 * ci + 0] = -jc.x;
+        Ee[i * NW + 16 + 3 * ci + 1] = -jc.y;
+        Ee[i * NW + 16 + 3 * ci + 2] = -jc.z;
+      }
+      for (int j = 0; j < HB_NJ; ++j) Ee[i * NW + 28 + j] = (i == 6 + j) ? -1.0 : 0.0;
+      beom[i] = -P.nle[i];
+    }
+    if (Jc) {  // contact Jacobians and bias accelerations (no-contact-motion task, WbcBase.cpp:169-188)
+      for (int ci = 0; ci < HB_NC; ++ci) {
+        for (int col = 0; col < 16; ++col) {
+          const Vec3<double> jc = contact_jac(P, ci, col);
+          Jc[(3 * ci + 0) * 16 + col] = jc.x; Jc[(3 * ci + 1) * 16 + col] = jc.y; Jc[(3 * ci + 2) * 16 + col] = jc.z;
+        }
+        dJv[3 * ci] = P.foot_acc[ci].x; dJv[3 * ci + 1] = P.foot_acc[ci].y; dJv[3 * ci + 2] = P.foot_acc[ci].z;
+      }
+    }
+    // cost rows (dense part over the 16 accelerations)
+    for (int i = 0; i < 18 * 16; ++i) Aw[i] = 0.0;
+    for (int i = 0; i < 18; ++i) bw[i] = 0.0;
+    if (stance_mode) {
+      for (int i = 0; i < 6; ++i) Aw[i * 16 + i] = w_base;  // WeightedWbc.cpp:83-94
+    } else {
+      // desired kinematics (WbcBase.cpp:122-136)
+      Centroidal<double> cd;
+      centroidal_eval<double>(M, xdes + 9, xdes + 12, xdes, udes + 12, cd);
+      double qd_[HB_NV], vd_[HB_NV];
+      for (int i = 0; i < HB_NV; ++i) qd_[i] = xdes[6 + i];
+      vd_[0] = cd.v_lin.x; vd_[1] = cd.v_lin.y; vd_[2] = cd.v_lin.z;
+      vd_[3] = cd.euler_rate.x; vd_[4] = cd.euler_rate.y; vd_[5] = cd.euler_rate.z;
+      for (int j = 0; j < HB_NJ; ++j) vd_[6 + j] = udes[12 + j];
+      BodyPass D;
+      body_pass(M, qd_, vd_, D);
+      // base acceleration desired: A_b qdd_b = m hdot_norm(x,u) - Adot v   (zero joint accelerations)
+      const Vec3<double> comr = (1.0 / D.mass) * D.mc;
+      Vec3<double> fs, ms;
+      for (int i = 0; i < HB_NC; ++i) {
+        const Vec3<double> F(udes[3 * i], udes[3 * i + 1], udes[3 * i + 2]);
+        fs = fs + F;
+        ms = ms + cross(D.foot[i] - comr, F);
+      }
+      const Vec3<double> ylin = Vec3<double>(fs.x, fs.y, fs.z - D.mass * M.gravity) - D.hdot_lin;
+      const Vec3<double> yang = ms - D.hdot_ang;
+      Sym3<double> Icom = D.IO;
+      {
+        const Sym3<double> sh = point_inertia<double>(D.mass, comr);
+        Icom.xx -= sh.xx; Icom.xy -= sh.xy; Icom.xz -= sh.xz; Icom.yy -= sh.yy; Icom.yz -= sh.yz; Icom.zz -= sh.zz;
+      }
+      const Vec3<double> wdot = sym3_solve<double>(Icom, yang);  // = E * euler_ddot
+      const Vec3<double> acc_lin = (1.0 / D.mass) * ylin - cross(wdot, comr);
+      const Vec3<double> acc_ang = wdot + D.alpha0;
+      // swing leg rows (WbcBase.cpp:297-323), weight w_swing
+      int row = 0;
+      for (int s = 0; s < wc.n_sw; ++s) {
+        const int i = wc.swing_feet[s];
+        const Vec3<double> pe = (Vec3<double>(xdes[6], xdes[7], xdes[8]) + D.foot[i]) - (Vec3<double>(q[0], q[1], q[2]) + P.foot[i]);
+        const Vec3<double> ve = D.foot_vel[i] - P.foot_vel[i];
+        for (int a = 0; a < 3; ++a) {
+          for (int col = 0; col < 16; ++col) Aw[row * 16 + col] = w_swing * comp(contact_jac(P, i, col), a);
+          bw[row] = w_swing * (C.swing_kp * comp(pe, a) + C.swing_kd * comp(ve, a) - comp(P.foot_acc[i], a));
+          ++row;
+        }
+      }
+      // base acceleration rows (WbcBase.cpp:228-295), weight w_base
+      Aw[row * 16 + 0] = w_base; bw[row] = w_base * acc_lin.x; ++row;
+      Aw[row * 16 + 1] = w_base; bw[row] = w_base * acc_lin.y; ++row;
+      Aw[row * 16 + 2] = w_base;
+      bw[row] = w_base * (acc_lin.z + C.bh_kp * (xdes[8] - q[2]) + C.bh_kd * (cd.v_lin.z - v[2]));
+      ++row;
+      const Vec3<double> err = rot_log(D.R0, P.R0);
+      for (int a = 0; a < 3; ++a) {
+        for (int cdir = 0; cdir < 3; ++cdir) Aw[row * 16 + 3 + cdir] = w_base * comp(P.E[cdir], a);
+        bw[row] = w_base * (comp(acc_ang, a) + C.ba_kp * comp(err, a) + C.ba_kd * (comp(D.omega0, a) - comp(P.omega0, a)) -
+                              comp(P.alpha0, a));
+        ++row;
+      }
+    }
+  }
+}
+
 // One WBC solve.  xdes/udes/rbd: this instance's inputs; sol in/out (kept when the QP fails).
 template <class Ctx>
 HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const double* xdes, const double* udes,
@@ -311,98 +423,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
 
   // ------------------------------------------------------------------ phase A: rigid-body quantities (lane 0)
   if (cx.lane == 0) {
-    double q[HB_NV], v[HB_NV];
-    for (int i = 0; i < 3; ++i) {
-      q[i] = rbd[3 + i];
-      q[3 + i] = rbd[i];
-      v[i] = rbd[HB_NV + 3 + i];
-    }
-    for (int j = 0; j < HB_NJ; ++j) {
-      q[6 + j] = rbd[6 + j];
-      v[6 + j] = rbd[HB_NV + 6 + j];
-    }
-    {
-      double sz, cz, sy, cy;
-      sincos_t(q[3], sz, cz);
-      sincos_t(q[4], sy, cy);
-      const Vec3<double> er = euler_rates_from_omega<double>(sz, cz, sy, cy, Vec3<double>(rbd[HB_NV], rbd[HB_NV + 1], rbd[HB_NV + 2]));
-      v[3] = er.x; v[4] = er.y; v[5] = er.z;
-    }
-    BodyPass P;
-    body_pass(M, q, v, P);
-    // EoM rows: [M, -J', -S'] x = -nle   (WbcBase.cpp:138-149)
-    mass_matrix(P, Rm);  // stage M in the R buffer (16x16)
-    for (int i = 0; i < 16; ++i) {
-      for (int j = 0; j < 16; ++j) Ee[i * NW + j] = Rm[i * 16 + j];
-      for (int ci = 0; ci < HB_NC; ++ci) {
-        const Vec3<double> jc = contact_jac(P, ci, i);
-        Ee[i * NW + 16 + 3 * ci + 0] = -jc.x;
-        Ee[i * NW + 16 + 3 * ci + 1] = -jc.y;
-        Ee[i * NW + 16 + 3 * ci + 2] = -jc.z;
-      }
-      for (int j = 0; j < HB_NJ; ++j) Ee[i * NW + 28 + j] = (i == 6 + j) ? -1.0 : 0.0;
-      beom[i] = -P.nle[i];
-    }
-    // cost rows (dense part over the 16 accelerations)
-    for (int i = 0; i < 18 * 16; ++i) Aw[i] = 0.0;
-    for (int i = 0; i < 18; ++i) bw[i] = 0.0;
-    if (stance_mode) {
-      for (int i = 0; i < 6; ++i) Aw[i * 16 + i] = C.w_base;  // WeightedWbc.cpp:83-94
-    } else {
-      // desired kinematics (WbcBase.cpp:122-136)
-      Centroidal<double> cd;
-      centroidal_eval<double>(M, xdes + 9, xdes + 12, xdes, udes + 12, cd);
-      double qd_[HB_NV], vd_[HB_NV];
-      for (int i = 0; i < HB_NV; ++i) qd_[i] = xdes[6 + i];
-      vd_[0] = cd.v_lin.x; vd_[1] = cd.v_lin.y; vd_[2] = cd.v_lin.z;
-      vd_[3] = cd.euler_rate.x; vd_[4] = cd.euler_rate.y; vd_[5] = cd.euler_rate.z;
-      for (int j = 0; j < HB_NJ; ++j) vd_[6 + j] = udes[12 + j];
-      BodyPass D;
-      body_pass(M, qd_, vd_, D);
-      // base acceleration desired: A_b qdd_b = m hdot_norm(x,u) - Adot v   (zero joint accelerations)
-      const Vec3<double> comr = (1.0 / D.mass) * D.mc;
-      Vec3<double> fs, ms;
-      for (int i = 0; i < HB_NC; ++i) {
-        const Vec3<double> F(udes[3 * i], udes[3 * i + 1], udes[3 * i + 2]);
-        fs = fs + F;
-        ms = ms + cross(D.foot[i] - comr, F);
-      }
-      const Vec3<double> ylin = Vec3<double>(fs.x, fs.y, fs.z - D.mass * M.gravity) - D.hdot_lin;
-      const Vec3<double> yang = ms - D.hdot_ang;
-      Sym3<double> Icom = D.IO;
-      {
-        const Sym3<double> sh = point_inertia<double>(D.mass, comr);
-        Icom.xx -= sh.xx; Icom.xy -= sh.xy; Icom.xz -= sh.xz; Icom.yy -= sh.yy; Icom.yz -= sh.yz; Icom.zz -= sh.zz;
-      }
-      const Vec3<double> wdot = sym3_solve<double>(Icom, yang);  // = E * euler_ddot
-      const Vec3<double> acc_lin = (1.0 / D.mass) * ylin - cross(wdot, comr);
-      const Vec3<double> acc_ang = wdot + D.alpha0;
-      // swing leg rows (WbcBase.cpp:297-323), weight w_swing
-      int row = 0;
-      for (int s = 0; s < wc.n_sw; ++s) {
-        const int i = wc.swing_feet[s];
-        const Vec3<double> pe = (Vec3<double>(xdes[6], xdes[7], xdes[8]) + D.foot[i]) - (Vec3<double>(q[0], q[1], q[2]) + P.foot[i]);
-        const Vec3<double> ve = D.foot_vel[i] - P.foot_vel[i];
-        for (int a = 0; a < 3; ++a) {
-          for (int col = 0; col < 16; ++col) Aw[row * 16 + col] = C.w_swing * comp(contact_jac(P, i, col), a);
-          bw[row] = C.w_swing * (C.swing_kp * comp(pe, a) + C.swing_kd * comp(ve, a) - comp(P.foot_acc[i], a));
-          ++row;
-        }
-      }
-      // base acceleration rows (WbcBase.cpp:228-295), weight w_base
-      Aw[row * 16 + 0] = C.w_base; bw[row] = C.w_base * acc_lin.x; ++row;
-      Aw[row * 16 + 1] = C.w_base; bw[row] = C.w_base * acc_lin.y; ++row;
-      Aw[row * 16 + 2] = C.w_base;
-      bw[row] = C.w_base * (acc_lin.z + C.bh_kp * (xdes[8] - q[2]) + C.bh_kd * (cd.v_lin.z - v[2]));
-      ++row;
-      const Vec3<double> err = rot_log(D.R0, P.R0);
-      for (int a = 0; a < 3; ++a) {
-        for (int cdir = 0; cdir < 3; ++cdir) Aw[row * 16 + 3 + cdir] = C.w_base * comp(P.E[cdir], a);
-        bw[row] = C.w_base * (comp(acc_ang, a) + C.ba_kp * comp(err, a) + C.ba_kd * (comp(D.omega0, a) - comp(P.omega0, a)) -
-                              comp(P.alpha0, a));
-        ++row;
-      }
-    }
+    wbc_phase_a(M, C, xdes, udes, rbd, wc, stance_mode, C.w_swing, C.w_base, Rm, Ee, beom, Aw, bw, nullptr, nullptr);
     misc[0] = 0.0;  // status
   }
   cx.sync();

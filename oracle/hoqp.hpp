@@ -22,12 +22,12 @@ inline Mat kernel_basis(const Mat& A) {
   Mat V;
   sym_eig(G, w, V);
   const double wmax = std::max(w.back(), 0.0);
-  // singular values sigma = sqrt(w); rank threshold on sigma like FullPivLU: eps * max(m,n) * sigma_max,
-  // widened to 1e-9 because eig(A'A) resolves sigma only to sqrt(eps)
-  const double thr = 1e-9 * std::sqrt(wmax);
+  // eig(A'A) resolves the squared singular values only to ~1e-16 * wmax, so the rank decision is taken on w itself:
+  // w <= 1e-12 wmax  (sigma <= 1e-6 sigma_max).  The structural rank deficiencies of the WBC tasks are exact
+  // (two contact points per rigid foot), the smallest genuine singular values are ~1e-2 sigma_max.
   int nz = 0;
   for (int j = 0; j < n; ++j)
-    if (std::sqrt(std::max(w[j], 0.0)) <= thr) ++nz;
+    if (w[j] <= 1e-12 * wmax) ++nz;
   Mat Z(n, nz);
   for (int j = 0; j < nz; ++j)
     for (int i = 0; i < n; ++i) Z(i, j) = V(i, j);

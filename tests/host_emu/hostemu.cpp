@@ -125,3 +125,14 @@ void emu_wbc(const hb_model* m, const hb_config* c, const double* xdes, const do
   wbc_solve(HostCtx{}, d, dc, xdes, udes, rbd, mode, stance != 0, lds.data(), sol, status, iters);
 }
 }
+
+#include "../../hunter_bipedal_control_amd/csrc/hb_hoqp.hpp"
+extern "C" {
+void emu_hwbc(const hb_model* m, const hb_config* c, const double* xdes, const double* udes, const double* rbd, int mode,
+              double* sol, int* status, int max_level) {
+  DevModel d = make_dev_model(*m);
+  DevConfig dc = make_dev_config(*c, d);
+  std::vector<double> lds(HoLds::total, 0.0);
+  hwbc_solve(HostCtx{}, d, dc, xdes, udes, rbd, mode, lds.data(), sol, status, max_level);
+}
+}

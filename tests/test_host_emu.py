@@ -93,3 +93,25 @@ def test_device_wbc_matches_oracle(params, oracle, emu):
         lib.emu_wbc(C.byref(mdl), C.byref(cfg), _p(xd), _p(u), _p(rbd), C.c_int(mode), C.c_int(stance), _p(se), C.byref(ste), C.byref(ite))
         assert ste.value == st[0] == 0 and ite.value == it[0]
         assert np.abs(se - so[0]).max() < 1e-7 * max(1.0, np.abs(so[0]).max())
+
+
+def test_device_hierarchical_wbc_matches_oracle(params, oracle, emu):
+    lib, mdl, cfg = emu
+    rng = np.random.default_rng(11)
+    x0 = np.array(params["config"]["initial_state"])
+    m = sum(params["model"]["mass"])
+    for mode in (3, 2, 1, 0):
+        cf = refgen.mode_to_contact_flags(mode)
+        u = np.zeros(22)
+        for i in range(4):
+            if cf[i]:
+                u[3 * i:3 * i + 3] = [2 * rng.standard_normal(), 2 * rng.standard_normal(), m * 9.81 / max(sum(cf), 1)]
+        u[12:] = 0.3 * rng.standard_normal(10)
+        xd = x0 + 0.04 * rng.standard_normal(22)
+        rbd = workload.rbd_from_state(x0 + 0.03 * rng.standard_normal(22), 1)
+        rbd[16:] = 0.3 * rng.standard_normal(16)
+        so, st = oracle.hwbc_update(xd, u, rbd, mode)
+        se, ste = np.zeros(38), C.c_int()
+        lib.emu_hwbc(C.byref(mdl), C.byref(cfg), _p(xd), _p(u), _p(rbd), C.c_int(mode), _p(se), C.byref(ste), C.c_int(3))
+        assert ste.value == st[0] == 0
+        assert np.abs(se - so[0]).max() < 1e-6 * max(1.0, np.abs(so[0]).max())

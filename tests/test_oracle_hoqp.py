@@ -57,3 +57,29 @@ def test_hierarchical_wbc_properties(params, oracle):
         # support the friction pyramid / torque limits of level 0 may bind and the task is met only approximately
         t1 = oracle.hwbc_tasks(xd, ud, rbd, mode, 1)
         assert np.abs(t1["A"] @ x - t1["b"]).max() < (1e-4 if mode == 3 else 0.5)
+
+
+def test_hoqp_level1_against_scipy(params, oracle):
+    """Independent check of the cascade: level 1 (base acceleration) re-solved with scipy SLSQP inside the kernel of the
+    level-0 task, subject to the level-0 inequalities relaxed by their slack."""
+    from scipy.linalg import null_space
+    from scipy.optimize import minimize
+    rng = np.random.default_rng(5)
+    x0 = np.array(params["config"]["initial_state"])
+    for mode in (3, 2):
+        rbd = workload.rbd_from_state(x0, 1)
+        rbd[16:] = 0.3 * rng.standard_normal(16)
+        t = [oracle.hwbc_tasks(x0, np.zeros(22), rbd, mode, l) for l in range(3)]
+        x1, sl, _ = oracle.hoqp(t[:1])
+        x2, _, _ = oracle.hoqp(t[:2])
+        Z = null_space(t[0]["A"], rcond=1e-9)
+        assert Z.shape[1] == {3: 12, 2: 11}[mode]
+        A1, b1, D, f = t[1]["A"], t[1]["b"], t[0]["D"], t[0]["f"]
+        obj = lambda z: 0.5 * np.sum((A1 @ (x1 + Z @ z) - b1) ** 2)
+        cons = {"type": "ineq", "fun": lambda z: f + sl[:len(f)] - D @ (x1 + Z @ z), "jac": lambda z: -(D @ Z)}
+        r = minimize(obj, np.zeros(Z.shape[1]), jac=lambda z: (A1 @ Z).T @ (A1 @ (x1 + Z @ z) - b1), constraints=[cons],
+                     method="SLSQP", options=dict(maxiter=500, ftol=1e-15))
+        # SLSQP may stop on its iteration limit when the optimum is ~0; its objective value is what is compared
+        assert r.success or r.fun < 1e-10
+        assert abs(0.5 * np.sum((A1 @ x2 - b1) ** 2) - r.fun) < 1e-7 * max(1.0, r.fun)
+        assert np.abs(t[0]["A"] @ (x2 - x1)).max() < 1e-9          # stays in the kernel of the higher task

@@ -39,9 +39,10 @@ BYTES_PER_UPDATE = lambda N: 48576 * N + 352 + 912  # noqa: E731  whole update (
 
 
 def make_batch(params, batch, n_intervals, first_inst):
-    """Seeded synthetic batch; 64 distinct instances tiled to the batch size to keep host set-up short."""
+    """Seeded synthetic batch; 16 distinct instances tiled to the batch size to keep host set-up short (the reference
+    manager with per-knot IK runs on the host, ~0.4 s per instance)."""
     from hunter_bipedal_control_amd import workload
-    distinct = min(batch, 64)
+    distinct = min(batch, 16)
     refs1, x01, rbd1, tn1 = workload.trot_batch(params, distinct, n_intervals=n_intervals, first_inst=first_inst)
     reps = (batch + distinct - 1) // distinct
     refs = {k: np.concatenate([v] * reps)[:batch] for k, v in refs1.items()}

@@ -12,8 +12,9 @@ Restates (host logic, runs once per MPC call per instance in the reference):
   * OCS2 timeDiscretizationWithEvents ([OCS2-knowledge]); a pre/post event node pair is merged
     into one grid node whose interval carries the post-event mode (the jump map is the identity and there is no
     pre-jump cost in this problem, so the QP is unchanged; DESIGN.md "time grid").
-The per-knot IK joint reference (SwitchedModelReferenceManager.cpp:251-300) is not applied yet: joint targets
-stay at the default joint state.
+  * SwitchedModelReferenceManager::calculateJointRef + InverseKinematics::{computeTranslationIK, computeRotationIK}
+    (SwitchedModelReferenceManager.cpp:251-300, foot_planner/InverseKinematics.cpp:36-231): targets resampled every
+    0.15 s with per-knot IK joint references.
 """
 from __future__ import annotations
 
@@ -373,7 +374,7 @@ def foot_positions(model: dict, x: np.ndarray) -> np.ndarray:
 
 
 def make_trot_problem(params: dict, t0: float, horizon: float, x0: np.ndarray, cmd_vel, max_nodes: int,
-                      t_gait_start: float = 0.1, gait: str = "trot"):
+                      t_gait_start: float = 0.1, gait: str = "trot", joint_ik: bool = True):
     """Node tables for one instance walking with a gait template (default trot) under a velocity command."""
     c = params["config"]
     sched = gait_schedule(params, gait, t_gait_start, t0 + 2 * horizon + 1.0)
@@ -383,6 +384,8 @@ def make_trot_problem(params: dict, t0: float, horizon: float, x0: np.ndarray, c
     planner.current_feet = list(foot_positions(params["model"], x0))
     planner.latest_stance = [f.copy() for f in planner.current_feet]
     planner.update(sched, targets, t0)
+    if joint_ik:
+        targets = joint_reference_ik(params, targets, planner, t0, t0 + horizon, x0)
     return build_node_tables(t0, horizon, c["dt"], sched, targets, planner, max_nodes)
 
 
@@ -401,3 +404,109 @@ def stack_tables(tables: list) -> dict:
     return dict(n_nodes=np.array([t["n_nodes"] for t in tables], dtype=np.int32),
                 t=np.stack([t["t"] for t in tables]), mode=np.stack([t["mode"] for t in tables]),
                 x_ref=np.stack([t["x_ref"] for t in tables]), swing=np.stack([t["swing"] for t in tables]))
+
+
+# ----------------------------------------------------------------------------------------------
+# per-knot inverse kinematics of the joint reference (SwitchedModelReferenceManager::calculateJointRef,
+# SwitchedModelReferenceManager.cpp:251-300; InverseKinematics.cpp:36-231)
+# ----------------------------------------------------------------------------------------------
+def _leg_kinematics(model: dict, q16: np.ndarray, leg: int):
+    """Contact f1 of `leg`: world position, foot rotation, linear (world-aligned) and angular (LOCAL) Jacobians
+    with respect to the leg's five joints."""
+    R = zyx_to_rotation(q16[3:6])
+    p = np.asarray(q16[0:3], dtype=float)
+    axes, origins = [], []
+    for k in range(5):
+        j = 5 * leg + k
+        p = p + R @ np.asarray(model["joint_origin"][j])
+        axes.append(R @ np.asarray(model["joint_axis"][j], dtype=float))
+        origins.append(p.copy())
+        R = R @ _axis_rot(model["joint_axis"][j], q16[6 + j])
+    foot = p + R @ np.asarray(model["contact_offset"][leg])
+    Jl = np.stack([np.cross(axes[k], foot - origins[k]) for k in range(5)], axis=1)
+    Ja = R.T @ np.stack(axes, axis=1)
+    return foot, R, Jl, Ja
+
+
+def _colpiv_qr_solve(A: np.ndarray, b: np.ndarray, threshold: float = 0.01) -> np.ndarray:
+    """Eigen::ColPivHouseholderQR::solve with setThreshold(0.01) (InverseKinematics.h:26): basic solution of the
+    numerically full-rank leading block, free variables zero."""
+    from scipy.linalg import qr
+    Q, Rm, piv = qr(A, mode="economic", pivoting=True)
+    d = np.abs(np.diag(Rm))
+    rank = int((d > threshold * d[0]).sum()) if d.size and d[0] > 0 else 0
+    y = np.zeros(A.shape[1])
+    if rank:
+        c = Q[:, :rank].T @ b
+        y[piv[:rank]] = np.linalg.solve(Rm[:rank, :rank], c)
+    return y
+
+
+def _log3(R: np.ndarray) -> np.ndarray:
+    c = np.clip(0.5 * (np.trace(R) - 1.0), -1.0, 1.0)
+    th = np.arccos(c)
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return 0.5 * w if th < 1e-10 else th / (2.0 * np.sin(th)) * w
+
+
+def _ik_iterate(model, q, leg, err_fn, step_fn):
+    """Shared damped iteration of computeTranslationIK / computeRotationIK: step 0.7, at most 5 iterations, stop on
+    small error (0.01), stagnation (1e-3) or error increase; joint limits clamp every iterate."""
+    lo = np.asarray(model["q_lower"][5 * leg:5 * leg + 5])
+    hi = np.asarray(model["q_upper"][5 * leg:5 * leg + 5])
+    err = err_fn(q)
+    last = np.linalg.norm(err)
+    if last < 0.01:
+        return q
+    for _ in range(5):
+        v = step_fn(q, err)
+        new_q = q.copy()
+        new_q[6 + 5 * leg:11 + 5 * leg] = np.clip(q[6 + 5 * leg:11 + 5 * leg] + 0.7 * v, lo, hi)
+        err = err_fn(new_q)
+        n = np.linalg.norm(err)
+        if n > last or abs(n - last) < 1e-3:
+            break
+        last, q = n, new_q
+        if n < 0.01:
+            break
+    return q
+
+
+def compute_ik(model: dict, q16: np.ndarray, leg: int, foot_pos: np.ndarray, R_des: np.ndarray) -> np.ndarray:
+    """InverseKinematics::computeIK(init_q, leg, des_foot_linear_xyz, des_foot_R_des) -> 5 joint angles."""
+    from scipy.linalg import null_space
+    q = np.array(q16, dtype=float)
+    q = _ik_iterate(model, q, leg, lambda qq: _leg_kinematics(model, qq, leg)[0] - foot_pos,
+                    lambda qq, err: -_colpiv_qr_solve(_leg_kinematics(model, qq, leg)[2], err))
+
+    def rot_step(qq, err):
+        _, _, Jl, Ja = _leg_kinematics(model, qq, leg)
+        Nn = null_space(Jl, rcond=1e-12)
+        return -Nn @ _colpiv_qr_solve(Ja @ Nn, err) if Nn.size else np.zeros(5)
+
+    q = _ik_iterate(model, q, leg, lambda qq: _log3(R_des.T @ _leg_kinematics(model, qq, leg)[1]), rot_step)
+    return q[6 + 5 * leg:11 + 5 * leg]
+
+
+def joint_reference_ik(params: dict, targets: TargetTrajectories, planner: SwingTrajectoryPlanner, t0: float, tf: float,
+                       x_init: np.ndarray) -> TargetTrajectories:
+    """calculateJointRef: resample the targets every 0.15 s and replace the joint targets of every knot by the IK of the
+    planned foot positions (feet L_f1, R_f1), warm-started from the previous knot."""
+    model, c = params["model"], params["config"]
+    if len(targets.t) <= 1:
+        return targets
+    n = int(np.floor((tf - t0) / 0.15)) + 1
+    if n <= 2:
+        return targets
+    ts = np.linspace(t0, tf, n)
+    xs = [targets.state(t) for t in ts]
+    xs[0][12:] = c["default_joint_state"]
+    R_des = zyx_to_rotation(np.asarray(x_init)[9:12])
+    for i in range(n):
+        q_ref = np.zeros(16)
+        q_ref[:6] = xs[i][6:12]
+        q_ref[6:] = xs[max(i - 1, 0)][12:]
+        for leg in range(2):
+            des = planner.swing_ref(leg, ts[i])[:3]
+            xs[i][12 + 5 * leg:17 + 5 * leg] = compute_ik(model, q_ref, leg, des, R_des)
+    return TargetTrajectories(list(ts), xs)

@@ -95,5 +95,30 @@ def test_swing_reference_tables(params):
     assert z[0] == pytest.approx(0.02) and z.max() <= 0.02 + 0.04 + 1e-9 and z.max() > 0.05   # swingHeight 0.04 above next_position_z
     assert np.allclose(tb["swing"][20:N, 1, 2], 0.02)   # then it is a stance foot at the touch-down height
     assert tb["swing"][:N, 1, 0][19] > tb["swing"][:N, 1, 0][0] + 0.05      # it moved forward under cmd_vel 0.3
-    assert np.allclose(tb["x_ref"][0, 12:], params["config"]["default_joint_state"])
     assert tb["x_ref"][N - 1, 6] > tb["x_ref"][0, 6]   # target base x advances
+
+
+def test_joint_reference_inverse_kinematics(params):
+    """computeIK (translation then rotation stage): reaches the planned foot position to its 0.01 tolerance, keeps the
+    foot level with the base yaw frame, respects the URDF joint limits."""
+    model = params["model"]
+    x0 = np.array(params["config"]["initial_state"])
+    q = np.r_[x0[6:12], x0[12:]].copy()
+    q[2] = 0.63
+    for leg in range(2):
+        foot0, R0, _, _ = refgen._leg_kinematics(model, q, leg)
+        des = foot0 + np.array([0.06, 0.01 * (1 - 2 * leg), 0.03])
+        qj = refgen.compute_ik(model, q, leg, des, np.eye(3))
+        q2 = q.copy()
+        q2[6 + 5 * leg:11 + 5 * leg] = qj
+        foot, R, _, _ = refgen._leg_kinematics(model, q2, leg)
+        assert np.linalg.norm(foot - des) < 0.015
+        assert np.linalg.norm(refgen._log3(R)) < 0.2   # 5 joints: position (3) + 2 of 3 rotation DoF
+        lo, hi = np.array(model["q_lower"][5 * leg:5 * leg + 5]), np.array(model["q_upper"][5 * leg:5 * leg + 5])
+        assert (qj >= lo - 1e-12).all() and (qj <= hi + 1e-12).all()
+    # Eigen ColPivHouseholderQR semantics: basic solution, rank cut at 0.01 * largest pivot
+    A = np.array([[1.0, 0.0, 1e-5], [0.0, 2.0, 0.0]])
+    y = refgen._colpiv_qr_solve(A, np.array([1.0, 2.0]))
+    assert np.allclose(y, [1.0, 1.0, 0.0])
+    tb = refgen.make_trot_problem(params, 0.1, 0.6, x0, (0.3, 0.0, 0.0, 0.0), 40)
+    assert np.abs(tb["x_ref"][:40, 12:] - np.array(params["config"]["default_joint_state"])).max() > 0.02   # IK moved the joint targets

@@ -133,7 +133,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
 
   // -------------------------------------------------------------- phase 1: sensitivities of the RK2 step
   // The only nonlinear dependence of f and of the foot kinematics is on (zyx, joints); per evaluation point:
-  //   stage 1  20 lanes = (leg, seed): one-tangent dual pass over ONE leg, seed on a joint angle or a joint rate
+  //   stage 1  one value pass per leg, then 20 lanes = (leg, seed) evaluate closed-form tangents of the leg outputs
   //   stage 2  lane = direction (44): directions h, zyx, joints, rates run the whole-body combine on duals built
   //            from the stage-1 tangents; base-position and contact-force directions are closed form
   // then [A_k | B_k] is composed from the two points' Jacobians (OCS2 RK2 sensitivity).
@@ -154,27 +154,18 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   cx.sync();
   for (int pt = 0; pt < 2; ++pt) {
     double* Jp = pt == 0 ? J1 : J2;
-    // ---- stage 1: per-leg seeded dual passes
+    // ---- stage 1: leg sensitivities.  One lane per leg runs the value pass (base-frame suffix composites per joint,
+    // staged in LDS over the not-yet-written J2 buffer); 20 lanes = (leg, seed) then evaluate the closed-form tangents
+    // of the 27 leg outputs (rigid rotation of the outboard composite about the seeded joint axis).
+    double* LJ = J2;
+    for (int r = cx.lane; r < 2; r += cx.nlanes)
+      leg_value_pass(M, r, [xe](int j) { return xe[12 + j]; }, [us](int j) { return us[12 + j]; }, LJ + r * LEGJ_SIZE, LV + r * 27);
+    cx.sync();
     for (int r = cx.lane; r < 20; r += cx.nlanes) {
       const int leg = r / 10, sd = r % 10;
-      const int jq = (sd < 5) ? 5 * leg + sd : -1, jr = (sd >= 5) ? 5 * leg + sd - 5 : -1;
-      LegOut<Dual1> lo;
-      leg_eval<Dual1>(M, leg, [xe, jq](int j) { return Dual1(xe[12 + j], j == jq ? 1.0 : 0.0); },
-                      [us, jr](int j) { return Dual1(us[12 + j], j == jr ? 1.0 : 0.0); }, lo);
-      double* t = LT + (leg * 10 + sd) * 27;
-      const Dual1 pack[27] = {lo.mc.x, lo.mc.y, lo.mc.z, lo.IO.xx, lo.IO.xy, lo.IO.xz, lo.IO.yy, lo.IO.yz, lo.IO.zz,
-                              lo.l_sum.x, lo.l_sum.y, lo.l_sum.z, lo.L_sum.x, lo.L_sum.y, lo.L_sum.z,
-                              lo.foot[0].x, lo.foot[0].y, lo.foot[0].z, lo.foot[1].x, lo.foot[1].y, lo.foot[1].z,
-                              lo.foot_vj[0].x, lo.foot_vj[0].y, lo.foot_vj[0].z, lo.foot_vj[1].x, lo.foot_vj[1].y, lo.foot_vj[1].z};
-#pragma unroll
-      for (int e = 0; e < 27; ++e) t[e] = pack[e].d;
-      if (sd == 0) {
-#pragma unroll
-        for (int e = 0; e < 27; ++e) LV[leg * 27 + e] = pack[e].v;
-      }
+      leg_tangent(LJ + leg * LEGJ_SIZE, sd % 5, sd >= 5, LT + (leg * 10 + sd) * 27);
     }
     cx.sync();
-    if (C.debug_stop == 6 + 2 * pt) return;
     // ---- stage 2: whole-body combine per direction
     for (int dir = cx.lane; dir < 44; dir += cx.nlanes) {
       const bool nonlinear = (dir < 6) || (dir >= 9 && dir < 22) || dir >= 34;

@@ -138,6 +138,137 @@ HB_HD void leg_eval(const DevModel& M, int leg, QF qj, QDF qdj, LegOut<T>& out) 
   }
 }
 
+// ---- analytic leg sensitivities --------------------------------------------------------------------------
+// Turning joint s rotates the outboard composite rigidly about (a_s, o_s); every leg output therefore has a closed-form
+// derivative in terms of base-frame suffix quantities of the value pass:
+//   d foot   = a x (foot - o)                      d mc = l_s            (l_s = a x (mc_s - m_s o))
+//   d IO     = [a]x IO_s - IO_s [a]x + 2 (mc_s.t) I - t mc_s' - mc_s t',  t = o x a
+//   d l      = a x lin_s + om_p x l_s              (lin_s = sum_{k>=s} qd_k l_k, om_p = sum_{k<s} qd_k a_k)
+//   d L      = a x (ang_s - o x lin_s) + o x (a x lin_s) + dIO om_p - l_s x w_p     (w_p = sum_{k<s} qd_k a_k x o_k)
+//   d vj_f   = a x vj_s(f) + om_p x (a x (foot_f - o))
+// and with respect to the joint rate qd_s:  d l = l_s, d L = L_s, d vj_f = a x (foot_f - o).
+// Per-joint block written by the value pass (doubles, stride LEGJ_STRIDE):
+constexpr int LEGJ_A = 0, LEGJ_O = 3, LEGJ_l = 6, LEGJ_L = 9, LEGJ_MC = 12, LEGJ_IO = 15, LEGJ_LIN = 21, LEGJ_ANG = 24,
+              LEGJ_VJ = 27, LEGJ_OMP = 33, LEGJ_WP = 36, LEGJ_MS = 39, LEGJ_MCK = 40, LEGJ_IOK = 43, LEGJ_STRIDE = 50;
+constexpr int LEGJ_FEET = 5 * LEGJ_STRIDE;   // 6 doubles after the five joint blocks
+constexpr int LEGJ_SIZE = LEGJ_FEET + 6;
+
+HB_HD Vec3<double> ld3(const double* p) { return Vec3<double>(p[0], p[1], p[2]); }
+HB_HD void st3(double* p, Vec3<double> v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+HB_HD Sym3<double> ld6(const double* p) {
+  Sym3<double> s;
+  s.xx = p[0]; s.xy = p[1]; s.xz = p[2]; s.yy = p[3]; s.yz = p[4]; s.zz = p[5];
+  return s;
+}
+HB_HD void st6(double* p, const Sym3<double>& s) { p[0] = s.xx; p[1] = s.xy; p[2] = s.xz; p[3] = s.yy; p[4] = s.yz; p[5] = s.zz; }
+
+// Value pass of one leg in the base frame (double): forward for the joint frames, backward for the suffix sums.
+// Writes the per-joint blocks to `blk` (LEGJ_SIZE doubles) and the 27 leg outputs to `val`.
+template <class QF, class QDF>
+HB_HD void leg_value_pass(const DevModel& M, int leg, QF qj, QDF qdj, double* blk, double* val) {
+  const int j0 = 5 * leg;
+  Mat3<double> R = Mat3<double>::identity();
+  Vec3<double> op, om, w;
+#pragma unroll 1
+  for (int k = 0; k < 5; ++k) {
+    const int j = j0 + k, b = j + 1;
+    double* B = blk + k * LEGJ_STRIDE;
+    const Vec3<double> o = op + R * Vec3<double>(M.origin[j][0], M.origin[j][1], M.origin[j][2]);
+    const Vec3<double> a = R * Vec3<double>(M.axis[j][0], M.axis[j][1], M.axis[j][2]);
+    st3(B + LEGJ_A, a);
+    st3(B + LEGJ_O, o);
+    st3(B + LEGJ_OMP, om);
+    st3(B + LEGJ_WP, w);
+    const double qd = qdj(j);
+    om = om + qd * a;
+    w = w + qd * cross(a, o);
+    R = R * axis_rot<double>(M.axis[j], qj(j));
+    const double mb = M.mass[b];
+    const Vec3<double> c = o + R * Vec3<double>(M.com[b][0], M.com[b][1], M.com[b][2]);
+    st3(B + LEGJ_MCK, mb * c);
+    st6(B + LEGJ_IOK, rotate_inertia<double>(R, M.inertia[b]) + point_inertia<double>(mb, c));
+    B[LEGJ_MS] = mb;
+    op = o;
+  }
+  Vec3<double> pf[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int ci = leg + 2 * f;
+    pf[f] = op + R * Vec3<double>(M.contact_offset[ci][0], M.contact_offset[ci][1], M.contact_offset[ci][2]);
+    st3(blk + LEGJ_FEET + 3 * f, pf[f]);
+  }
+  double ms = 0.0;
+  Vec3<double> mc, lin, ang, vj[2];
+  Sym3<double> IO;
+#pragma unroll 1
+  for (int k = 4; k >= 0; --k) {
+    double* B = blk + k * LEGJ_STRIDE;
+    const Vec3<double> a = ld3(B + LEGJ_A), o = ld3(B + LEGJ_O);
+    ms += B[LEGJ_MS];
+    mc = mc + ld3(B + LEGJ_MCK);
+    IO = IO + ld6(B + LEGJ_IOK);
+    const Vec3<double> l = cross(a, mc - ms * o);
+    const Vec3<double> L = IO * a - cross(mc, cross(a, o));
+    const double qd = qdj(j0 + k);
+    lin = lin + qd * l;
+    ang = ang + qd * L;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) vj[f] = vj[f] + qd * cross(a, pf[f] - o);
+    st3(B + LEGJ_l, l);
+    st3(B + LEGJ_L, L);
+    st3(B + LEGJ_MC, mc);
+    st6(B + LEGJ_IO, IO);
+    st3(B + LEGJ_LIN, lin);
+    st3(B + LEGJ_ANG, ang);
+    st3(B + LEGJ_VJ, vj[0]);
+    st3(B + LEGJ_VJ + 3, vj[1]);
+    B[LEGJ_MS] = ms;
+  }
+  st3(val + 0, mc); st6(val + 3, IO); st3(val + 9, lin); st3(val + 12, ang);
+  st3(val + 15, pf[0]); st3(val + 18, pf[1]); st3(val + 21, vj[0]); st3(val + 24, vj[1]);
+}
+
+// 27 tangents of the leg outputs with respect to joint angle s (rate == false) or joint rate s (rate == true).
+HB_HD void leg_tangent(const double* blk, int s, bool rate, double* t) {
+  const double* B = blk + s * LEGJ_STRIDE;
+  const Vec3<double> a = ld3(B + LEGJ_A), o = ld3(B + LEGJ_O), ls = ld3(B + LEGJ_l), Ls = ld3(B + LEGJ_L);
+  const Vec3<double> p0 = ld3(blk + LEGJ_FEET), p1 = ld3(blk + LEGJ_FEET + 3);
+  const Vec3<double> ap0 = cross(a, p0 - o), ap1 = cross(a, p1 - o);
+  if (rate) {
+    for (int e = 0; e < 9; ++e) t[e] = 0.0;
+    st3(t + 9, ls);
+    st3(t + 12, Ls);
+    for (int e = 15; e < 21; ++e) t[e] = 0.0;
+    st3(t + 21, ap0);
+    st3(t + 24, ap1);
+    return;
+  }
+  const Vec3<double> mcs = ld3(B + LEGJ_MC), lin = ld3(B + LEGJ_LIN), ang = ld3(B + LEGJ_ANG);
+  const Vec3<double> omp = ld3(B + LEGJ_OMP), wp = ld3(B + LEGJ_WP);
+  const Sym3<double> IOs = ld6(B + LEGJ_IO);
+  // dIO = Y + Y' with Y = [a]x IO_s, plus the shift of the rotation axis away from the base origin
+  const Vec3<double> y0 = cross(a, Vec3<double>(IOs.xx, IOs.xy, IOs.xz));
+  const Vec3<double> y1 = cross(a, Vec3<double>(IOs.xy, IOs.yy, IOs.yz));
+  const Vec3<double> y2 = cross(a, Vec3<double>(IOs.xz, IOs.yz, IOs.zz));
+  const Vec3<double> tt = cross(o, a);
+  const double tr = 2.0 * dot(mcs, tt);
+  Sym3<double> dIO;
+  dIO.xx = y0.x + y0.x + tr - 2.0 * tt.x * mcs.x;
+  dIO.yy = y1.y + y1.y + tr - 2.0 * tt.y * mcs.y;
+  dIO.zz = y2.z + y2.z + tr - 2.0 * tt.z * mcs.z;
+  dIO.xy = y1.x + y0.y - (tt.x * mcs.y + mcs.x * tt.y);
+  dIO.xz = y2.x + y0.z - (tt.x * mcs.z + mcs.x * tt.z);
+  dIO.yz = y2.y + y1.z - (tt.y * mcs.z + mcs.y * tt.z);
+  st3(t + 0, ls);
+  st6(t + 3, dIO);
+  st3(t + 9, cross(a, lin) + cross(omp, ls));
+  st3(t + 12, cross(a, ang - cross(o, lin)) + cross(o, cross(a, lin)) + dIO * omp - cross(ls, wp));
+  st3(t + 15, ap0);
+  st3(t + 18, ap1);
+  st3(t + 21, cross(a, ld3(B + LEGJ_VJ)) + cross(omp, ap0));
+  st3(t + 24, cross(a, ld3(B + LEGJ_VJ + 3)) + cross(omp, ap1));
+}
+
 // ZYX euler rates from the world angular velocity (inverse of omega = E(zyx) * rates).
 template <class T>
 HB_HD Vec3<T> euler_rates_from_omega(T sz, T cz, T sy, T cy, Vec3<T> w) {

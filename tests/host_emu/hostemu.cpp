@@ -136,3 +136,32 @@ void emu_hwbc(const hb_model* m, const hb_config* c, const double* xdes, const d
   hwbc_solve(HostCtx{}, d, dc, xdes, udes, rbd, mode, lds.data(), sol, status, max_level);
 }
 }
+
+extern "C" {
+// max abs difference between the analytic leg tangents/values and the one-tangent dual pass (both legs, all 10 seeds)
+double emu_check_leg_tangents(const hb_model* m, const double* qj, const double* qd) {
+  DevModel d = make_dev_model(*m);
+  double worst = 0.0;
+  for (int leg = 0; leg < 2; ++leg) {
+    std::vector<double> blk(LEGJ_SIZE), val(27);
+    leg_value_pass(d, leg, [qj](int j) { return qj[j]; }, [qd](int j) { return qd[j]; }, blk.data(), val.data());
+    for (int sd = 0; sd < 10; ++sd) {
+      const int jq = sd < 5 ? 5 * leg + sd : -1, jr = sd >= 5 ? 5 * leg + sd - 5 : -1;
+      LegOut<Dual1> lo;
+      leg_eval<Dual1>(d, leg, [qj, jq](int j) { return Dual1(qj[j], j == jq ? 1.0 : 0.0); },
+                      [qd, jr](int j) { return Dual1(qd[j], j == jr ? 1.0 : 0.0); }, lo);
+      const Dual1 pack[27] = {lo.mc.x, lo.mc.y, lo.mc.z, lo.IO.xx, lo.IO.xy, lo.IO.xz, lo.IO.yy, lo.IO.yz, lo.IO.zz,
+                              lo.l_sum.x, lo.l_sum.y, lo.l_sum.z, lo.L_sum.x, lo.L_sum.y, lo.L_sum.z,
+                              lo.foot[0].x, lo.foot[0].y, lo.foot[0].z, lo.foot[1].x, lo.foot[1].y, lo.foot[1].z,
+                              lo.foot_vj[0].x, lo.foot_vj[0].y, lo.foot_vj[0].z, lo.foot_vj[1].x, lo.foot_vj[1].y, lo.foot_vj[1].z};
+      double t[27];
+      leg_tangent(blk.data(), sd % 5, sd >= 5, t);
+      for (int e = 0; e < 27; ++e) {
+        worst = std::max(worst, std::fabs(t[e] - pack[e].d));
+        worst = std::max(worst, std::fabs(val[e] - pack[e].v));
+      }
+    }
+  }
+  return worst;
+}
+}

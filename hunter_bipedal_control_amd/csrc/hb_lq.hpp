@@ -88,10 +88,10 @@ struct LqLds {
   static constexpr int Qd = ru + 22;         // 22 diagonal of Q incl. barriers/shift
   static constexpr int scal = Qd + 22;       // 16 scalars (cost, sums, ...)
   static constexpr int ints = scal + 16;     // 32 ints packed in 16 doubles: perm[10], rank, eq slots...
-  // phase-1 scratch (xs us xe fv FR LV LT J1 J2 = 1754 doubles) aliases everything from GtG on: none of those
+  // phase-1 scratch (xs us xe fv FR LV J1 J2 = 1214 doubles) aliases everything from GtG on: none of those
   // buffers is live before phase 2.
   static constexpr int p1 = GtG;
-  static constexpr int total = (p1 + 1760 > ints + 16) ? p1 + 1760 : ints + 16;
+  static constexpr int total = (p1 + 1216 > ints + 16) ? p1 + 1216 : ints + 16;
 };
 
 struct NodeIn {
@@ -143,8 +143,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* fv = xe + 22;                // 2 x 12 flow-map values (rows 0..11) of the two points
   double* FR = fv + 24;                // 12: (contact point - COM) of the current point
   double* LV = FR + 12;                // 2 x 27 leg values
-  double* LT = LV + 54;                // 2 x 10 x 27 leg tangents
-  double* J1 = LT + 540;               // 44 x 12: d f(rows 0..11) / d direction at point 1
+  double* J1 = LV + 54;                // 44 x 12: d f(rows 0..11) / d direction at point 1
   double* J2 = J1 + 528;               // same at point 2
   for (int i = cx.lane; i < 22; i += cx.nlanes) {
     xs[i] = in.x[i];
@@ -157,14 +156,9 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     // ---- stage 1: leg sensitivities.  One lane per leg runs the value pass (base-frame suffix composites per joint,
     // staged in LDS over the not-yet-written J2 buffer); 20 lanes = (leg, seed) then evaluate the closed-form tangents
     // of the 27 leg outputs (rigid rotation of the outboard composite about the seeded joint axis).
-    double* LJ = J2;
+    double* LJ = ABt;  // ABt is not written before the final compose
     for (int r = cx.lane; r < 2; r += cx.nlanes)
       leg_value_pass(M, r, [xe](int j) { return xe[12 + j]; }, [us](int j) { return us[12 + j]; }, LJ + r * LEGJ_SIZE, LV + r * 27);
-    cx.sync();
-    for (int r = cx.lane; r < 20; r += cx.nlanes) {
-      const int leg = r / 10, sd = r % 10;
-      leg_tangent(LJ + leg * LEGJ_SIZE, sd % 5, sd >= 5, LT + (leg * 10 + sd) * 27);
-    }
     cx.sync();
     // ---- stage 2: whole-body combine per direction
     for (int dir = cx.lane; dir < 44; dir += cx.nlanes) {
@@ -174,10 +168,15 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       int tl = -1, ts = 0;
       if (dir >= 12 && dir < 22) { tl = (dir - 12) / 5; ts = (dir - 12) % 5; }
       if (dir >= 34) { tl = (dir - 34) / 5; ts = 5 + (dir - 34) % 5; }
-      // leg sums (value of both legs, tangent of the one leg this direction seeds)
-      const double* t = LT + ((tl < 0 ? 0 : tl) * 10 + ts) * 27;
-      const double w = (tl >= 0) ? 1.0 : 0.0;
-      auto S = [LV, t, w](int e) { return Dual1(LV[e] + LV[27 + e], w * t[e]); };
+      // leg sums (value of both legs, tangent of the one leg this direction seeds — closed form, in registers)
+      double t[27];
+      if (tl >= 0) {
+        leg_tangent(LJ + tl * LEGJ_SIZE, ts % 5, ts >= 5, t);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 27; ++e) t[e] = 0.0;
+      }
+      auto S = [LV, &t](int e) { return Dual1(LV[e] + LV[27 + e], t[e]); };
       CentroidalCore<Dual1> core;
       {
         Dual1 zyx[3], hn[6];
@@ -196,10 +195,10 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       for (int i = 0; i < HB_NC; ++i) {
         const int leg = i & 1, f = i >> 1;
         const double* v = LV + leg * 27 + 15 + 3 * f;
-        const double* tt = LT + (leg * 10 + ts) * 27 + 15 + 3 * f;
         const double wl = (tl == leg) ? 1.0 : 0.0;
-        const Vec3<Dual1> fb{Dual1(v[0], wl * tt[0]), Dual1(v[1], wl * tt[1]), Dual1(v[2], wl * tt[2])};
-        const Vec3<Dual1> vb{Dual1(v[6], wl * tt[6]), Dual1(v[7], wl * tt[7]), Dual1(v[8], wl * tt[8])};
+        const int e0 = 15 + 3 * f;
+        const Vec3<Dual1> fb{Dual1(v[0], wl * t[e0]), Dual1(v[1], wl * t[e0 + 1]), Dual1(v[2], wl * t[e0 + 2])};
+        const Vec3<Dual1> vb{Dual1(v[6], wl * t[e0 + 6]), Dual1(v[7], wl * t[e0 + 7]), Dual1(v[8], wl * t[e0 + 8])};
         Vec3<Dual1> fr, fvel;
         centroidal_foot<Dual1>(core, fb, vb, fr, fvel);
         const Vec3<Dual1> rr = fr - core.com_rel;
@@ -384,22 +383,39 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   if (C.debug_stop == 2) return;
   const int rank = ints[10];
   const int nz = 10 - rank;
-  // L(i,s) = GtG[perm[i]*10 + perm[s]] for i >= s.
+  // L(i,s) = GtG[perm[i]*10 + perm[s]] for i >= s.  The factor is first gathered into registers (55 independent LDS
+  // reads) so that the substitutions below are pure FMA chains.
   // Solve A11 Y = -W1 (23 right-hand sides, one per lane), scatter into Kx rows perm[a].
-  for (int c = cx.lane; c < 23; c += cx.nlanes) {
-    double y[10];
-    for (int a = 0; a < rank; ++a) {
-      double s = -W[perm[a] * 23 + c];
-      for (int t = 0; t < a; ++t) s -= GtG[perm[a] * 10 + perm[t]] * y[t];
-      y[a] = s / GtG[perm[a] * 10 + perm[a]];
+  {
+    double Lr[55], dinv[10];
+    int pm[10];
+#pragma unroll
+    for (int a = 0; a < 10; ++a) pm[a] = perm[a];
+#pragma unroll
+    for (int a = 0; a < 10; ++a) {
+#pragma unroll
+      for (int t = 0; t <= a; ++t) Lr[a * (a + 1) / 2 + t] = GtG[pm[a] * 10 + pm[t]];
+      dinv[a] = (a < rank) ? 1.0 / Lr[a * (a + 1) / 2 + a] : 0.0;
     }
-    for (int a = rank - 1; a >= 0; --a) {
-      double s = y[a];
-      for (int t = a + 1; t < rank; ++t) s -= GtG[perm[t] * 10 + perm[a]] * y[t];
-      y[a] = s / GtG[perm[a] * 10 + perm[a]];
+    for (int c = cx.lane; c < 23; c += cx.nlanes) {
+      double y[10];
+#pragma unroll
+      for (int a = 0; a < 10; ++a) {
+        double sacc = -W[pm[a] * 23 + c];
+#pragma unroll
+        for (int t = 0; t < a; ++t) sacc -= Lr[a * (a + 1) / 2 + t] * y[t];
+        y[a] = (a < rank) ? sacc * dinv[a] : 0.0;
+      }
+#pragma unroll
+      for (int a = 9; a >= 0; --a) {
+        double sacc = y[a];
+#pragma unroll
+        for (int t = a + 1; t < 10; ++t) sacc -= ((t < rank) ? Lr[t * (t + 1) / 2 + a] : 0.0) * y[t];
+        y[a] = (a < rank) ? sacc * dinv[a] : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < 10; ++a) Kx[pm[a] * 23 + c] = y[a];
     }
-    for (int a = 0; a < rank; ++a) Kx[perm[a] * 23 + c] = y[a];
-    for (int a = rank; a < 10; ++a) Kx[perm[a] * 23 + c] = 0.0;
   }
   // kernel basis: column b <-> free index perm[rank + b]:  z = e_free - P1 L11^-T L21[b]^T
   for (int b = cx.lane; b < 6; b += cx.nlanes) {

@@ -428,6 +428,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   }
   cx.sync();
 
+  if (C.debug_stop == 11) return;
   // ------------------------------------------------------------------ phase B: R~ by Givens row insertion
   const double se = sqrt(C.wbc_eps);
   for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Rm[idx] = (idx / NW == idx % NW) ? se : 0.0;
@@ -491,9 +492,11 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   for (int i = cx.lane; i < 64; i += cx.nlanes) is_active[i] = 0;
   cx.sync();
 
+  if (C.debug_stop == 12) return;
   // ------------------------------------------------------------------ phase C: Goldfarb–Idnani iterations
   int q = 0, iter = 0, status = 0;
   int next_eq = 0;
+  int next_eq_active = 0;  // equalities in the active set (never dropped)
   const int n_cons = wc.n_eq + wc.n_in;
   const double inf = 1e300;
   while (true) {
@@ -570,20 +573,24 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
         if (i < q) r[i] = d[i];
       }
       cx.sync();
-      for (int i = q - 1; i >= 0; --i) {
-        const double ri = r[i] / Rm[i * NW + i];
-        cx.sync();
-        for (int k = cx.lane; k < i; k += cx.nlanes) r[k] -= Rm[k * NW + i] * ri;
-        if (cx.lane == 0) r[i] = ri;
-        cx.sync();
-      }
+      // the dual step direction r = R^-1 d1 only matters for active INEQUALITIES (their multipliers must stay >= 0);
+      // while only equalities are active (the whole first phase) it is skipped
+      const bool need_r = q > next_eq_active;
+      if (need_r)
+        for (int i = q - 1; i >= 0; --i) {
+          const double ri = r[i] / Rm[i * NW + i];
+          cx.sync();
+          for (int k = cx.lane; k < i; k += cx.nlanes) r[k] -= Rm[k * NW + i] * ri;
+          if (cx.lane == 0) r[i] = ri;
+          cx.sync();
+        }
       double zn = 0.0, nn2 = 0.0;
       for (int i = 0; i < NW; ++i) { zn += z[i] * np[i]; nn2 += np[i] * np[i]; }
       const double t2 = (zn > 1e-14 * (1.0 + nn2)) ? sp / zn : inf;
       const double dir = (p_is_eq && sp < 0.0) ? -1.0 : 1.0;
       double t1 = inf;
       int l = -1;
-      for (int j = 0; j < q; ++j) {
+      for (int j = 0; j < q && need_r; ++j) {
         if (act[j] < wc.n_eq) continue;
         const double rj = dir * r[j];
         if (rj > 0.0) {
@@ -596,27 +603,40 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       if (t >= inf) { status = HB_INST_INFEASIBLE; break; }
       cx.sync();
       if (t2 >= inf) {
-        for (int j = cx.lane; j < q; j += cx.nlanes) lam[j] -= t * dir * r[j];
+        if (need_r)
+          for (int j = cx.lane; j < q; j += cx.nlanes) lam[j] -= t * dir * r[j];
         lam_p += t;
       } else {
         for (int k = cx.lane; k < NW; k += cx.nlanes) x[k] -= dir * t * z[k];
-        for (int j = cx.lane; j < q; j += cx.nlanes) lam[j] -= t * dir * r[j];
+        if (need_r)
+          for (int j = cx.lane; j < q; j += cx.nlanes) lam[j] -= t * dir * r[j];
         lam_p += t;
       }
       cx.sync();
       if (t2 < inf && t == t2abs) {
-        // full step: add constraint p (Givens on the columns of J, from the bottom up)
-        for (int j = NW - 1; j > q; --j) {
-          const double a = d[j - 1], b = d[j];
-          cx.sync();
-          if (b != 0.0) {
-            const double h = sqrt(a * a + b * b), cc = a / h, ss = b / h;
+        // full step: add constraint p.  One Householder reflector H maps d2 = d[q:] onto (alpha, 0, ...); the trailing
+        // columns of J are updated as J2 <- J2 H, each lane owning rows of J (one barrier instead of one per rotation).
+        {
+          double nrm2 = 0.0;
+          for (int j = q; j < NW; ++j) nrm2 += d[j] * d[j];
+          const double dq = d[q];
+          const double alpha = dq > 0.0 ? -sqrt(nrm2) : sqrt(nrm2);
+          const double v0 = dq - alpha;
+          const double vtv = nrm2 - dq * dq + v0 * v0;
+          if (vtv > 0.0 && nrm2 > 0.0) {
+            const double beta = 2.0 / vtv;
             for (int k = cx.lane; k < NW; k += cx.nlanes) {
-              const double t1j = Jm[k * NW + j - 1], t2j = Jm[k * NW + j];
-              Jm[k * NW + j - 1] = cc * t1j + ss * t2j;
-              Jm[k * NW + j] = -ss * t1j + cc * t2j;
+              double sacc = Jm[k * NW + q] * v0;
+              for (int j = q + 1; j < NW; ++j) sacc += Jm[k * NW + j] * d[j];
+              sacc *= beta;
+              Jm[k * NW + q] -= sacc * v0;
+              for (int j = q + 1; j < NW; ++j) Jm[k * NW + j] -= sacc * d[j];
             }
-            if (cx.lane == 0) { d[j - 1] = h; d[j] = 0.0; }
+          }
+          cx.sync();
+          if (cx.lane == 0) {
+            d[q] = alpha;
+            for (int j = q + 1; j < NW; ++j) d[j] = 0.0;
           }
           cx.sync();
         }
@@ -624,6 +644,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
           for (int i = cx.lane; i <= q; i += cx.nlanes) Rm[i * NW + q] = d[i];
           if (cx.lane == 0) { act[q] = p; lam[q] = lam_p; is_active[p] = 1; }
           ++q;
+          if (p_is_eq) ++next_eq_active;
         }
         cx.sync();
         done_p = true;

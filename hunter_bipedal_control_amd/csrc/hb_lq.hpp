@@ -195,10 +195,13 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       for (int i = 0; i < HB_NC; ++i) {
         const int leg = i & 1, f = i >> 1;
         const double* v = LV + leg * 27 + 15 + 3 * f;
+        // tangent of contact point f of the seeded leg: selected with conditional moves — indexing t[] with the
+        // (rolled) loop counter would force the whole array into scratch memory
         const double wl = (tl == leg) ? 1.0 : 0.0;
-        const int e0 = 15 + 3 * f;
-        const Vec3<Dual1> fb{Dual1(v[0], wl * t[e0]), Dual1(v[1], wl * t[e0 + 1]), Dual1(v[2], wl * t[e0 + 2])};
-        const Vec3<Dual1> vb{Dual1(v[6], wl * t[e0 + 6]), Dual1(v[7], wl * t[e0 + 7]), Dual1(v[8], wl * t[e0 + 8])};
+        const double tp0 = f ? t[18] : t[15], tp1 = f ? t[19] : t[16], tp2 = f ? t[20] : t[17];
+        const double tv0 = f ? t[24] : t[21], tv1 = f ? t[25] : t[22], tv2 = f ? t[26] : t[23];
+        const Vec3<Dual1> fb{Dual1(v[0], wl * tp0), Dual1(v[1], wl * tp1), Dual1(v[2], wl * tp2)};
+        const Vec3<Dual1> vb{Dual1(v[6], wl * tv0), Dual1(v[7], wl * tv1), Dual1(v[8], wl * tv2)};
         Vec3<Dual1> fr, fvel;
         centroidal_foot<Dual1>(core, fb, vb, fr, fvel);
         const Vec3<Dual1> rr = fr - core.com_rel;

@@ -35,9 +35,39 @@ HB_HD Dual1 operator-(Dual1 a, double b) { return {a.v - b, a.d}; }
 HB_HD Dual1 operator-(double a, Dual1 b) { return {a - b.v, -b.d}; }
 HB_HD Dual1& operator+=(Dual1& a, Dual1 b) { a.v += b.v; a.d += b.d; return a; }
 HB_HD Dual1& operator-=(Dual1& a, Dual1 b) { a.v -= b.v; a.d -= b.d; return a; }
-HB_HD void sincos_t(double a, double& s, double& c) { s = sin(a); c = cos(a); }
+// sin and cos of one angle with a shared argument reduction.  Joint and Euler angles are a few radians, so the
+// reduction is three-constant Cody-Waite by pi/2 (exact products under FMA for |k| < 2^20) followed by the two
+// minimax kernels on [-pi/4, pi/4] (coefficients: the classic fdlibm __kernel_sin/__kernel_cos sets); absolute error
+// < 2e-16.  The generic library path — whose large-argument reduction made up a quarter of k_lq's instruction
+// stream — is only taken for |a| >= 1e5.
+HB_HD void sincos_t(double a, double& s, double& c) {
+  if (!(fabs(a) < 1.0e5)) { s = sin(a); c = cos(a); return; }
+  const double k = rint(a * 6.36619772367581382433e-01);
+  double r = fma(-k, 1.57079632673412561417e+00, a);
+  r = fma(-k, 6.07710050630396597660e-11, r);
+  r = fma(-k, 2.02226624871116645580e-21, r);
+  r = fma(-k, 8.47842766036889956997e-32, r);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = fma(z * r, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = int(k) & 3;
+  const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
 HB_HD void sincos_t(Dual1 a, Dual1& s, Dual1& c) {
-  const double sv = sin(a.v), cv = cos(a.v);
+  double sv, cv;
+  sincos_t(a.v, sv, cv);
   s = {sv, cv * a.d};
   c = {cv, -sv * a.d};
 }

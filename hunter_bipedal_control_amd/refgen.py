@@ -198,6 +198,37 @@ def cmd_vel_targets(t0: float, x_now: np.ndarray, cmd_vel, horizon: float, com_h
     return TargetTrajectories([t0, t0 + horizon], [cur, tgt])
 
 
+def command_speed(cmd_vel, target_state0: np.ndarray) -> float:
+    """velAbs of SwitchedModelReferenceManager::calculateVelAbs (SwitchedModelReferenceManager.cpp:229-249): the norm
+    of the mean of the commanded twist (rotated into the world by the first target's ZYX angles, z zeroed, yaw rate
+    / 3) and of the first target's normalised-momentum entries treated the same way.  The reference averages it over
+    the last 50 calls (velAvg_); a fresh instance has a history of one."""
+    vel_cmd = np.array([cmd_vel[0], cmd_vel[1], cmd_vel[2], cmd_vel[3]], dtype=float)
+    vel_cmd[:3] = zyx_to_rotation(target_state0[9:12]) @ vel_cmd[:3]
+    vel_cmd[2] = 0.0
+    vel_cmd[3] /= 3.0
+    vel_est = np.array(target_state0[0:4], dtype=float)
+    vel_est[2] = 0.0
+    vel_est[3] /= 3.0
+    return float(np.linalg.norm(0.5 * vel_cmd + 0.5 * vel_est))
+
+
+GAIT_LEVEL_NAME = {0: "stance", 1: "trot", 3: None}  # level 3 ("flying trot") inserts no template in the reference
+
+
+def walk_gait_level(vel_avg: float, level: int) -> int:
+    """Gait level chosen by SwitchedModelReferenceManager::walkGait (:185-217): stance at or below 0.02 m/s, trot
+    inside (0.03, 0.4), level 3 from 0.4 (which only prints — no template is inserted), unchanged in the hysteresis
+    gap (0.02, 0.03]."""
+    if vel_avg <= 0.02:
+        return 0
+    if 0.03 < vel_avg < 0.4:
+        return 1
+    if vel_avg >= 0.4:
+        return 3
+    return level
+
+
 class SwingTrajectoryPlanner:
     def __init__(self, swing_cfg: dict):
         c = swing_cfg
@@ -380,7 +411,9 @@ def make_trot_problem(params: dict, t0: float, horizon: float, x0: np.ndarray, c
     sched = gait_schedule(params, gait, t_gait_start, t0 + 2 * horizon + 1.0)
     targets = cmd_vel_targets(t0, x0, cmd_vel, horizon, c["com_height"], c["default_joint_state"])
     planner = SwingTrajectoryPlanner(c["swing"])
-    planner.body_vel_cmd = np.array([cmd_vel[0], cmd_vel[1], cmd_vel[2], 0.0, 0.0, cmd_vel[3]])
+    # the cmd_vel callback stores [linear x y z, angular z, 0, 0] (SwitchedModelReferenceManager.cpp:91-97) and the
+    # planner reads tail(3) as the angular command (SwingTrajectoryPlanner.cpp:299): the yaw rate lands on its x entry
+    planner.body_vel_cmd = np.array([cmd_vel[0], cmd_vel[1], cmd_vel[2], cmd_vel[3], 0.0, 0.0])
     planner.current_feet = list(foot_positions(params["model"], x0))
     planner.latest_stance = [f.copy() for f in planner.current_feet]
     planner.update(sched, targets, t0)

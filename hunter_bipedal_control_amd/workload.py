@@ -51,7 +51,11 @@ def trot_batch(params: dict, batch: int, n_intervals: int = 100, cmd_vel=(0.3, 0
         if cmd_vel_random:  # config 4: per-instance command
             rng = np.random.default_rng(4321 + inst)
             cv = (rng.uniform(-0.35, 0.35), rng.uniform(-0.15, 0.15), 0.0, rng.uniform(-0.5, 0.5))
-        tables.append(refgen.make_trot_problem(params, t0, horizon, x0, cv, max_nodes))
+        gait = "trot"
+        if cmd_vel_random:  # walkGait thresholds decide between stance and trot per instance (gaitLevel_ starts at 0)
+            tgt0 = refgen.cmd_vel_targets(t0, x0, cv, horizon, c["com_height"], c["default_joint_state"]).x[0]
+            gait = refgen.GAIT_LEVEL_NAME[refgen.walk_gait_level(refgen.command_speed(cv, tgt0), 0)] or "stance"
+        tables.append(refgen.make_trot_problem(params, t0, horizon, x0, cv, max_nodes, gait=gait))
         x0s.append(x0)
         rbds.append(rbd_from_state(x0, inst))
     refs = refgen.stack_tables(tables)

@@ -368,3 +368,106 @@ def test_hierarchical_wbc_matches_oracle(params, oracle):
     assert (np.abs(sol - so) / scale).max() < 1e-6
     tl = np.tile(np.array(params["config"]["torque_limits"]), 2)
     assert (np.abs(sol[:, 28:]) <= tl + 1e-7).all()
+
+
+def _oracle_policy(refs, t_now, xo, uo):
+    """Linear interpolation of the published solution at t_now and the planned mode (MPC_MRT evaluatePolicy)."""
+    B = xo.shape[0]
+    xd, ud, md = np.zeros((B, 22)), np.zeros((B, 22)), np.zeros(B, dtype=np.int32)
+    for i in range(B):
+        t = refs["t"][i]
+        n = refs["n_nodes"][i]
+        k = 0
+        while k < n - 1 and t_now[i] >= t[k + 1]:
+            k += 1
+        a = (t_now[i] - t[k]) / (t[k + 1] - t[k])
+        xd[i] = (1 - a) * xo[i, k] + a * xo[i, k + 1]
+        ud[i] = (1 - a) * uo[i, k] + a * uo[i, min(k + 1, n - 1)]
+        md[i] = refs["mode"][i, k]
+    return xd, ud, md
+
+
+def test_config4_per_instance_commands_and_gaits(params, oracle):
+    """SURVEY.md §8d config 4 (reduced batch): per-instance cmd_vel, stance/trot chosen by the walkGait thresholds —
+    mixed mode sequences and projected-input widths inside one launch."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B, N = 24, 60
+    # instances 200..223: seed 4321 + 212 draws a command below the 0.02 m/s stance threshold
+    refs, x0, rbd, t_now = workload.trot_batch(params, B, n_intervals=N, cmd_vel_random=True, first_inst=200, max_nodes=N + 4)
+    has_stance_only = any(set(refs["mode"][i, :refs["n_nodes"][i]]) == {3} for i in range(B))
+    assert has_stance_only, "the sample must contain a standing instance"
+    nmax = refs["mode"].shape[1]
+    s = HunterSolver(params, batch=B, max_nodes=nmax)
+    try:
+        s.set_references(refs)
+        s.reset(x0)
+        xo, uo = _oracle_cold(oracle, refs, x0, nmax)
+        for it in range(2):
+            perf_o, dxo, duo = oracle.mpc_solve(refs, x0, xo, uo, iters=1, threads=4, want_step=True)
+            s.mpc_solve(x0)
+            dxg, dug = s.get_step()
+            xg, ug = s.get_solution()
+            perf_g = s.get_performance()
+            assert np.abs(dxg - dxo).max() < 1e-8 and np.abs(dug - duo).max() < 1e-6
+            assert np.array_equal(perf_g[:, 3], perf_o[:, 3])
+            assert np.abs(xg - xo).max() < 1e-7 and np.abs(ug - uo).max() < 1e-6
+        s.publish()
+        out = s.wbc_update(t_now, rbd)
+    finally:
+        s.close()
+    xd, ud, md = _oracle_policy(refs, t_now, xo, uo)
+    assert np.array_equal(out["mode"], md)
+    assert np.abs(out["x_des"] - xd).max() < 1e-7 and np.abs(out["u_des"] - ud).max() < 1e-6
+    so, sto, _ = oracle.wbc_update(xd, ud, rbd, md, stance_flag=np.zeros(B, dtype=np.int32), threads=4)
+    assert np.array_equal(out["status"], sto)
+    scale = np.maximum(1.0, np.abs(so).max(axis=1, keepdims=True))
+    assert (np.abs(out["sol"] - so) / scale).max() < 1e-6
+
+
+def test_config5_long_horizon_hierarchical(params, oracle):
+    """SURVEY.md §8d config 5 (reduced batch): N = 200 (timeHorizon 3.0 s), swing constraints active,
+    HierarchicalWbc; parity on 4 instances, size-independent properties on 256."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    N = 200
+    refs4, x04, rbd4, tn4 = workload.trot_batch(params, 4, n_intervals=N)
+    nmax = refs4["mode"].shape[1]
+    s = HunterSolver(params, batch=4, max_nodes=nmax, wbc_type=1)
+    try:
+        s.set_references(refs4)
+        s.reset(x04)
+        xo, uo = _oracle_cold(oracle, refs4, x04, nmax)
+        oracle.mpc_solve(refs4, x04, xo, uo, iters=1, threads=4)
+        s.mpc_solve(x04)
+        xg, ug = s.get_solution()
+        assert np.abs(xg - xo).max() < 1e-7 and np.abs(ug - uo).max() < 1e-6
+        s.publish()
+        out = s.wbc_update(tn4, rbd4)
+    finally:
+        s.close()
+    xd, ud, md = _oracle_policy(refs4, tn4, xo, uo)
+    so, sto = oracle.hwbc_update(xd, ud, rbd4, md, threads=4)
+    assert np.array_equal(out["status"], sto) and sto.max() == 0
+    scale = np.maximum(1.0, np.abs(so).max(axis=1, keepdims=True))
+    assert (np.abs(out["sol"] - so) / scale).max() < 1e-6
+    # properties at a larger batch
+    B = 256
+    reps = B // 4
+    refs = {k: np.concatenate([v] * reps) for k, v in refs4.items()}
+    x0, rbd, t_now = np.concatenate([x04] * reps), np.concatenate([rbd4] * reps), np.concatenate([tn4] * reps)
+    s = HunterSolver(params, batch=B, max_nodes=nmax, wbc_type=1)
+    try:
+        s.set_references(refs)
+        s.reset(x0)
+        s.set_resident_inputs(x0, t_now, rbd)
+        for it in range(5):
+            s.step_resident()
+        perf = s.get_performance()
+        sol, status = s.get_wbc_solution()
+        x, u = s.get_solution()
+    finally:
+        s.close()
+    assert np.isfinite(x).all() and np.isfinite(sol).all() and status.max() == 0
+    assert perf[:, 1].max() < 1e-7 and perf[:, 2].max() < 1e-5, perf[:, 1:3].max(axis=0)
+    assert np.array_equal(x[:4], x[4:8]) and np.array_equal(sol[:4], sol[4:8])
+    tl = np.tile(np.array(params["config"]["torque_limits"]), 2)
+    assert (np.abs(sol[:, 28:]) <= tl + 1e-7).all()

@@ -5,7 +5,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from hunter_bipedal_control_amd import abi, ingest, refgen
+from hunter_bipedal_control_amd import abi, ingest, refgen, workload
 
 REF = Path("/root/reference")
 
@@ -122,3 +122,30 @@ def test_joint_reference_inverse_kinematics(params):
     assert np.allclose(y, [1.0, 1.0, 0.0])
     tb = refgen.make_trot_problem(params, 0.1, 0.6, x0, (0.3, 0.0, 0.0, 0.0), 40)
     assert np.abs(tb["x_ref"][:40, 12:] - np.array(params["config"]["default_joint_state"])).max() > 0.02   # IK moved the joint targets
+
+
+def test_walk_gait_thresholds_and_config4_workload(params):
+    """walkGait thresholds (SwitchedModelReferenceManager.cpp:185-217) and the per-instance command workload
+    (SURVEY.md §8d config 4)."""
+    assert refgen.walk_gait_level(0.0, 1) == 0 and refgen.walk_gait_level(0.02, 1) == 0
+    assert refgen.walk_gait_level(0.025, 1) == 1 and refgen.walk_gait_level(0.025, 0) == 0   # hysteresis gap
+    assert refgen.walk_gait_level(0.031, 0) == 1 and refgen.walk_gait_level(0.39, 0) == 1
+    assert refgen.walk_gait_level(0.4, 1) == 3
+    x = np.zeros(22)
+    x[0:3] = [0.3, 0.0, 0.0]
+    # cmd and target twist agree -> velAbs = |(vx, vy, 0, wz/3)| / 2 + |(v, 0, h_ang_x/3)| / 2
+    assert abs(refgen.command_speed((0.3, 0.0, 0.0, 0.0), x) - 0.3) < 1e-15
+    assert abs(refgen.command_speed((0.0, 0.0, 0.5, 0.3), np.zeros(22)) - 0.05) < 1e-15     # z ignored, yaw / 3 / 2
+    refs, x0, rbd, t_now = workload.trot_batch(params, 24, n_intervals=40, cmd_vel_random=True)
+    kinds = set()
+    for i in range(24):
+        n = refs["n_nodes"][i]
+        modes = set(int(m) for m in refs["mode"][i, :n])
+        kinds.add("stance" if modes == {3} else "trot")
+        rng = np.random.default_rng(4321 + i)
+        cv = (rng.uniform(-0.35, 0.35), rng.uniform(-0.15, 0.15), 0.0, rng.uniform(-0.5, 0.5))
+        if modes == {3}:
+            assert np.hypot(cv[0], cv[1]) < 0.05
+        else:
+            assert modes <= {1, 2, 3}
+    assert "trot" in kinds

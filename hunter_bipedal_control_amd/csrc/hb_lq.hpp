@@ -88,10 +88,10 @@ struct LqLds {
   static constexpr int Qd = ru + 22;         // 22 diagonal of Q incl. barriers/shift
   static constexpr int scal = Qd + 22;       // 16 scalars (cost, sums, ...)
   static constexpr int ints = scal + 16;     // 32 ints packed in 16 doubles: perm[10], rank, eq slots...
-  // phase-1 scratch (xs us xe fv FR LV J1 J2 = 1214 doubles) aliases everything from GtG on: none of those
+  // phase-1 scratch (xs us xe fv FR LV J1 J2 = 1266 doubles) aliases everything from GtG on: none of those
   // buffers is live before phase 2.
   static constexpr int p1 = GtG;
-  static constexpr int total = (p1 + 1216 > ints + 16) ? p1 + 1216 : ints + 16;
+  static constexpr int total = (p1 + 1268 > ints + 16) ? p1 + 1268 : ints + 16;
 };
 
 struct NodeIn {
@@ -142,8 +142,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* xe = us + 22;                // 22 state values of the current evaluation point
   double* fv = xe + 22;                // 2 x 12 flow-map values (rows 0..11) of the two points
   double* FR = fv + 24;                // 12: (contact point - COM) of the current point
-  double* LV = FR + 12;                // 2 x 27 leg values
-  double* J1 = LV + 54;                // 44 x 12: d f(rows 0..11) / d direction at point 1
+  double* LV_all = FR + 12;            // 2 points x 2 legs x 27 leg values
+  double* J1 = LV_all + 108;              // 44 x 12: d f(rows 0..11) / d direction at point 1
   double* J2 = J1 + 528;               // same at point 2
   for (int i = cx.lane; i < 22; i += cx.nlanes) {
     xs[i] = in.x[i];
@@ -151,15 +151,23 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     xe[i] = in.x[i];
   }
   cx.sync();
+  // ---- stage 1: leg value passes of BOTH evaluation points at once.  The legs are evaluated in the base frame and the
+  // joint block of the flow map is the input itself, so the joint state of the second RK2 point (q + dt qd) is known
+  // up front: four lanes = (point, leg) run the value pass (base-frame suffix composites per joint, staged in LDS over
+  // the not-yet-written ABt buffer); the direction lanes of stage 2 then evaluate the closed-form tangents of the 27
+  // leg outputs (rigid rotation of the outboard composite about the seeded joint axis).
+  double* LJ_all = ABt;  // 4 x LEGJ_SIZE; ABt is not written before the final compose
+  static_assert(4 * LEGJ_SIZE <= 968, "leg blocks must fit the ABt buffer");
+  for (int r = cx.lane; r < 4; r += cx.nlanes) {
+    const double h = (r >> 1) ? dt : 0.0;
+    leg_value_pass(M, r & 1, [xs, us, h](int j) { return xs[12 + j] + h * us[12 + j]; }, [us](int j) { return us[12 + j]; },
+                   LJ_all + r * LEGJ_SIZE, LV_all + r * 27);
+  }
+  cx.sync();
   for (int pt = 0; pt < 2; ++pt) {
     double* Jp = pt == 0 ? J1 : J2;
-    // ---- stage 1: leg sensitivities.  One lane per leg runs the value pass (base-frame suffix composites per joint,
-    // staged in LDS over the not-yet-written J2 buffer); 20 lanes = (leg, seed) then evaluate the closed-form tangents
-    // of the 27 leg outputs (rigid rotation of the outboard composite about the seeded joint axis).
-    double* LJ = ABt;  // ABt is not written before the final compose
-    for (int r = cx.lane; r < 2; r += cx.nlanes)
-      leg_value_pass(M, r, [xe](int j) { return xe[12 + j]; }, [us](int j) { return us[12 + j]; }, LJ + r * LEGJ_SIZE, LV + r * 27);
-    cx.sync();
+    const double* LJ = LJ_all + pt * 2 * LEGJ_SIZE;
+    const double* LV = LV_all + pt * 54;
     // ---- stage 2: whole-body combine per direction
     for (int dir = cx.lane; dir < 44; dir += cx.nlanes) {
       const bool nonlinear = (dir < 6) || (dir >= 9 && dir < 22) || dir >= 34;

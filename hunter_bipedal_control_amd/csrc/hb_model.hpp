@@ -148,8 +148,9 @@ HB_HD void leg_eval(const DevModel& M, int leg, QF qj, QDF qdj, LegOut<T>& out) 
 //   d vj_f   = a x vj_s(f) + om_p x (a x (foot_f - o))
 // and with respect to the joint rate qd_s:  d l = l_s, d L = L_s, d vj_f = a x (foot_f - o).
 // Per-joint block written by the value pass (doubles, stride LEGJ_STRIDE):
+// (the per-body first moment / inertia of the forward sweep share the slots of the suffix sums that replace them)
 constexpr int LEGJ_A = 0, LEGJ_O = 3, LEGJ_l = 6, LEGJ_L = 9, LEGJ_MC = 12, LEGJ_IO = 15, LEGJ_LIN = 21, LEGJ_ANG = 24,
-              LEGJ_VJ = 27, LEGJ_OMP = 33, LEGJ_WP = 36, LEGJ_MS = 39, LEGJ_MCK = 40, LEGJ_IOK = 43, LEGJ_STRIDE = 50;
+              LEGJ_VJ = 27, LEGJ_OMP = 33, LEGJ_WP = 36, LEGJ_MS = 39, LEGJ_MCK = LEGJ_MC, LEGJ_IOK = LEGJ_IO, LEGJ_STRIDE = 40;
 constexpr int LEGJ_FEET = 5 * LEGJ_STRIDE;   // 6 doubles after the five joint blocks
 constexpr int LEGJ_SIZE = LEGJ_FEET + 6;
 

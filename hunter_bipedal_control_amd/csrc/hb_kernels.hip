@@ -93,14 +93,36 @@ __global__ __launch_bounds__(64) void k_ric_bwd(Batch b) {
   const int inst = blockIdx.x;
   __shared__ double lds[RicLds::total];
   const DeviceCtx cx;
-  for (int i = cx.lane; i < 484 + 24; i += cx.nlanes) lds[RicLds::S + i] = 0.0;
-  if (cx.lane == 0) lds[RicLds::flag] = 0.0;
+  for (int i = cx.lane; i < RicLds::total; i += cx.nlanes) lds[i] = 0.0;  // S = 0, s = 0 and every padding zero
   __syncthreads();
   const int n = b.n_nodes[inst];
+  // Staging of a record: lane l owns the element pairs 2(l + 64 r); their padded LDS destinations do not depend on
+  // the stage.  All wide loads of a lane are issued before the first one is consumed.
+  constexpr int NR2 = REC_RICCATI_END / 2, NL = (NR2 + 63) / 64;
+  int dst[NL];
+#pragma unroll
+  for (int r = 0; r < NL; ++r) {
+    const int e = 2 * (cx.lane + 64 * r);
+    dst[r] = e < REC_RICCATI_END ? (RicLds::is_vector(e) ? -1 - e : RicLds::dst(e)) : 0;
+  }
   for (int k = n - 1; k >= 0; --k) {
-    const double* rec = b.recs + (size_t(inst) * b.Nmax + k) * REC_SIZE;
-    for (int i = cx.lane; i < REC_RICCATI_END / 2; i += cx.nlanes)
-      reinterpret_cast<double2*>(lds + RicLds::node)[i] = reinterpret_cast<const double2*>(rec)[i];
+    const double2* rec2 = reinterpret_cast<const double2*>(b.recs + (size_t(inst) * b.Nmax + k) * REC_SIZE);
+    double2 buf[NL];
+#pragma unroll
+    for (int r = 0; r < NL; ++r) { const int i = cx.lane + 64 * r; buf[r] = rec2[i < NR2 ? i : NR2 - 1]; }
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+      const int i = cx.lane + 64 * r;
+      if (i < NR2) {
+        if (dst[r] >= 0) {
+          *reinterpret_cast<double2*>(lds + dst[r]) = buf[r];
+        } else {  // two entries of b~ / q~ / r~: consecutive rows
+          const int e = -1 - dst[r];
+          lds[RicLds::dst(e)] = buf[r].x;
+          lds[RicLds::dst(e + 1)] = buf[r].y;
+        }
+      }
+    }
     __syncthreads();
     riccati_bwd_node(cx, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE);
   }

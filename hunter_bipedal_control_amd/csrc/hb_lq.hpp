@@ -164,6 +164,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
                    LJ_all + r * LEGJ_SIZE, LV_all + r * 27);
   }
   cx.sync();
+  if (C.debug_stop == 6) return;
   for (int pt = 0; pt < 2; ++pt) {
     double* Jp = pt == 0 ? J1 : J2;
     const double* LJ = LJ_all + pt * 2 * LEGJ_SIZE;

@@ -7,82 +7,146 @@
 
 namespace hb {
 
+// LDS of the backward sweep.  Every matrix is kept in a padded layout chosen so that each MFMA operand of the three
+// GEMM groups is "per-lane base + compile-time offset" (one address register per operand, offsets in the ds_read
+// immediates) and so that the K-padding of the 16x16x4 tiles is zeros on both sides:
+//   wide rows  (stride 36): [x block (22) | vector (1) | zero (1) | u block (12)]      [A~ b~ . B~], M1, [P~ r~ . R~], Hu
+//   narrow rows (stride 24): [x block (22) | vector (1) | zero (1)]                     S (cols 22,23 zero), [Q~ q~ .], [K~ k~ .]
+// ABb and M1 carry two extra all-zero rows (K = 22 -> 24).
 struct RicLds {
-  static constexpr int S = 0;             // 22x22
-  static constexpr int s = S + 484;       // 22 (+2 pad)
-  static constexpr int node = s + 24;     // REC_RICCATI_END doubles of the stage record
-  static constexpr int M1 = node + REC_RICCATI_END;  // 22x35 : S [A~ B~ b~] (+ s on the last column)
-  static constexpr int Hu = M1 + 770;     // 12x35 : [Hux | Huu | hu]
-  static constexpr int Kk = Hu + 420;     // 12x23 : [K~ | k~]
-  static constexpr int flag = Kk + 276;   // 4
-  static constexpr int total = flag + 4;
+  static constexpr int LDN = 24, LDW = 36, CV = 22, CU = 24;
+  static constexpr int S = 0;                    // 22 x 24
+  static constexpr int s = S + 22 * LDN;         // 24
+  static constexpr int ABb = s + 24;             // 24 x 36
+  static constexpr int M1 = ABb + 24 * LDW;      // 24 x 36 : S [A~ b~ . B~] (+ s on the vector column)
+  static constexpr int PRr = M1 + 24 * LDW;      // 12 x 36
+  static constexpr int Hu = PRr + 12 * LDW;      // 12 x 36 : [Hux | hu | . | Huu]
+  static constexpr int Qq = Hu + 12 * LDW;       // 22 x 24 : [Q~ | q~ | .], accumulates T
+  static constexpr int Kk = Qq + 22 * LDN;       // 12 x 24 : [K~ | k~ | .]
+  static constexpr int flag = Kk + 12 * LDN;     // 4
+  static constexpr int total = flag + 4 + 44;    // slack: padded tile reads run up to 40 doubles past Kk
+  // LDS offset of element e of the stage record (hb_lq.hpp REC_* layout); elements of one (even e, e+1) pair share a
+  // row except in the three vectors b~ q~ r~.
+  HB_HD static int dst(int e) {
+    if (e < REC_BT) { const int r = e / 22; return ABb + r * LDW + (e - r * 22); }
+    if (e < REC_bT) { const int x = e - REC_BT, r = x / NU_T; return ABb + r * LDW + CU + (x - r * NU_T); }
+    if (e < REC_QT) return ABb + (e - REC_bT) * LDW + CV;
+    if (e < REC_PT) { const int x = e - REC_QT, r = x / 22; return Qq + r * LDN + (x - r * 22); }
+    if (e < REC_RT) { const int x = e - REC_PT, r = x / 22; return PRr + r * LDW + (x - r * 22); }
+    if (e < REC_qT) { const int x = e - REC_RT, r = x / NU_T; return PRr + r * LDW + CU + (x - r * NU_T); }
+    if (e < REC_rT) return Qq + (e - REC_qT) * LDN + CV;
+    return PRr + (e - REC_rT) * LDW + CV;
+  }
+  HB_HD static bool is_vector(int e) { return (e >= REC_bT && e < REC_QT) || e >= REC_qT; }
 };
 
-// ---- small dense GEMM on one wavefront --------------------------------------------------------------------
-// C(M x N) = C0 + A(M x K) B(K x N) with element accessors (zero outside the logical ranges).  On the device it runs
-// on the matrix cores: v_mfma_f64_16x16x4_f64, A/B fragments one f64 per lane (A[i = l&15][k = l>>4],
-// B[k = l>>4][j = l&15]), accumulator rows (l>>4) + 4 r, column l&15 (cdna_hip_programming.md §3, f64 layout).
-// The host build (tests/host_emu only) uses plain loops.
-template <class Ctx, class FA, class FB, class FC, class FS>
-HB_HD void wave_gemm(const Ctx& cx, int Mr, int Nr, int Kr, FA a_at, FB b_at, FC c_init, FS store) {
+// ---- small dense GEMMs on one wavefront ---------------------------------------------------------------------
+// A block of MT x NT accumulator tiles (16 x 16 each) of v_mfma_f64_16x16x4_f64: A/B fragments are one f64 per lane
+// (A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]), accumulator rows (l>>4) + 4 r, column l&15
+// (cdna_hip_programming.md §3, f64 layout).  All tiles advance together over K, so consecutive MFMAs are independent
+// and each A/B fragment is read once per K-step.  The host build (tests/host_emu only) uses plain loops.
+template <int MT, int NT>
+struct WaveTile {
 #if defined(__HIP_DEVICE_COMPILE__)
-  typedef double double4_t __attribute__((ext_vector_type(4)));
-  const int l = cx.lane, li = l & 15, lk = l >> 4;
-  for (int tm = 0; tm < Mr; tm += 16)
-    for (int tn = 0; tn < Nr; tn += 16) {
-      double4_t acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = tm + lk + 4 * r, col = tn + li;
-        acc[r] = (row < Mr && col < Nr) ? c_init(row, col) : 0.0;
-      }
-      for (int k0 = 0; k0 < Kr; k0 += 4) {
-        const int ia = tm + li, ka = k0 + lk, jb = tn + li;
-        const double av = (ia < Mr && ka < Kr) ? a_at(ia, ka) : 0.0;
-        const double bv = (ka < Kr && jb < Nr) ? b_at(ka, jb) : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = tm + lk + 4 * r, col = tn + li;
-        if (row < Mr && col < Nr) store(row, col, acc[r]);
-      }
-    }
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 acc[MT][NT];
 #else
-  for (int idx = cx.lane; idx < Mr * Nr; idx += cx.nlanes) {
-    const int i = idx / Nr, j = idx % Nr;
-    double acc = c_init(i, j);
-    for (int k = 0; k < Kr; ++k) acc += a_at(i, k) * b_at(k, j);
-    store(i, j, acc);
+  double c[MT * 16][NT * 16];
+#endif
+};
+template <int MT, int NT, class Ctx, class FC>
+HB_HD void tile_init(const Ctx& cx, WaveTile<MT, NT>& t, int Mr, int Nr, FC c_init) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tm + lk + 4 * r, col = 16 * tn + li;
+        t.acc[tm][tn][r] = (row < Mr && col < Nr) ? c_init(row, col) : 0.0;
+      }
+#else
+  for (int i = 0; i < MT * 16; ++i)
+    for (int j = 0; j < NT * 16; ++j) t.c[i][j] = (i < Mr && j < Nr) ? c_init(i, j) : 0.0;
+#endif
+}
+// t += A B over K (a multiple of 4).  A(i,k) = TA ? A[k*LDA + i] : A[i*LDA + k],  B(k,j) = B[k*LDB + j].  No bounds
+// masks: the operands are padded (see RicLds) and out-of-range rows / columns only feed discarded outputs.
+template <int K, int LDA, bool TA, int LDB, int MT, int NT, class Ctx>
+HB_HD void tile_mma(const Ctx& cx, WaveTile<MT, NT>& t, const double* A, const double* B, int Mr, int Nr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)Mr; (void)Nr;
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+  const double* ap = A + (TA ? lk * LDA + li : li * LDA + lk);
+  const double* bp = B + lk * LDB + li;
+#pragma unroll
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    double av[MT], bv[NT];
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm) av[tm] = ap[TA ? k0 * LDA + 16 * tm : 16 * tm * LDA + k0];
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) bv[tn] = bp[k0 * LDB + 16 * tn];
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) t.acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tm], bv[tn], t.acc[tm][tn], 0, 0, 0);
   }
+#else
+  (void)cx;
+  for (int i = 0; i < Mr; ++i)
+    for (int j = 0; j < Nr; ++j) {
+      double acc = t.c[i][j];
+      for (int k = 0; k < K; ++k) acc += (TA ? A[k * LDA + i] : A[i * LDA + k]) * B[k * LDB + j];
+      t.c[i][j] = acc;
+    }
+#endif
+}
+template <int MT, int NT, class Ctx, class FS>
+HB_HD void tile_store(const Ctx& cx, const WaveTile<MT, NT>& t, int Mr, int Nr, FS store) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tm + lk + 4 * r, col = 16 * tn + li;
+        if (row < Mr && col < Nr) store(row, col, t.acc[tm][tn][r]);
+      }
+#else
+  (void)cx;
+  for (int i = 0; i < Mr; ++i)
+    for (int j = 0; j < Nr; ++j) store(i, j, t.c[i][j]);
 #endif
 }
 
-// One backward step. `node` already holds the stage record in LDS. Updates S, s in place; writes the gains.
-//   M1 = S [A~ B~ b~] (+ s),  Hu = B~' M1 + [P~ R~ r~],  K~ = -Huu^-1 [Hux hu],
+// One backward step on the staged record.  Updates S, s in place; writes the gains.
+//   M1 = S [A~ b~ B~] (+ s),  Hu = B~' M1 + [P~ r~ R~],  K~ = -Huu^-1 [Hux hu],
 //   S <- sym(Q~ + A~' M1_A + Hux' K~),  s <- q~ + A~' M1_b + Hux' k~          
 template <class Ctx>
-HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, double* gains) {
-  double* S = lds + RicLds::S;
-  double* sv = lds + RicLds::s;
-  double* nd = lds + RicLds::node;
+HB_HD void ric_phase1(const Ctx& cx, double* lds) {
+  const double* sv = lds + RicLds::s;
   double* M1 = lds + RicLds::M1;
+  WaveTile<2, 3> t;
+  tile_init(cx, t, 22, RicLds::LDW, [sv](int i, int c) { return c == RicLds::CV ? sv[i] : 0.0; });
+  tile_mma<24, RicLds::LDN, false, RicLds::LDW>(cx, t, lds + RicLds::S, lds + RicLds::ABb, 22, RicLds::LDW);
+  tile_store(cx, t, 22, RicLds::LDW, [M1](int i, int c, double v) { M1[i * RicLds::LDW + c] = v; });
+  cx.sync();
+}
+template <class Ctx>
+HB_HD void ric_phase2(const Ctx& cx, double* lds) {
+  const double* PRr = lds + RicLds::PRr;
   double* Hu = lds + RicLds::Hu;
   double* Kk = lds + RicLds::Kk;
-  const double* At = nd + REC_AT;
-  const double* Bt = nd + REC_BT;
-  const double* bt = nd + REC_bT;
-  wave_gemm(cx, 22, 35, 22,
-            [S](int i, int k) { return S[i * 22 + k]; },
-            [At, Bt, bt](int k, int c) { return c < 22 ? At[k * 22 + c] : (c < 34 ? Bt[k * NU_T + (c - 22)] : bt[k]); },
-            [sv](int i, int c) { return c == 34 ? sv[i] : 0.0; },
-            [M1](int i, int c, double v) { M1[i * 35 + c] = v; });
-  cx.sync();
-  wave_gemm(cx, NU_T, 35, 22,
-            [Bt](int a, int j) { return Bt[j * NU_T + a]; },
-            [M1](int j, int c) { return M1[j * 35 + c]; },
-            [nd](int a, int c) { return c < 22 ? nd[REC_PT + a * 22 + c] : (c < 34 ? nd[REC_RT + a * NU_T + (c - 22)] : nd[REC_rT + a]); },
-            [Hu](int a, int c, double v) { Hu[a * 35 + c] = v; });
+  {
+    WaveTile<1, 3> t;
+    tile_init(cx, t, NU_T, RicLds::LDW, [PRr](int a, int c) { return PRr[a * RicLds::LDW + c]; });
+    tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t, lds + RicLds::ABb + RicLds::CU, lds + RicLds::M1, NU_T, RicLds::LDW);
+    tile_store(cx, t, NU_T, RicLds::LDW, [Hu](int a, int c, double v) { Hu[a * RicLds::LDW + c] = v; });
+  }
   cx.sync();
   // Cholesky of Huu and the 23 triangular solves entirely in registers: every lane factors the (uniform) 12x12
   // block redundantly, lane c < 23 then solves its own right-hand side — no LDS traffic, no barriers.
@@ -91,7 +155,7 @@ HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, double* gains) {
 #pragma unroll
     for (int i = 0; i < NU_T; ++i)
 #pragma unroll
-      for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = Hu[i * 35 + 22 + j];
+      for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = Hu[i * RicLds::LDW + RicLds::CU + j];
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < NU_T; ++j) {
@@ -110,12 +174,11 @@ HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, double* gains) {
       }
     }
     if (bad && cx.lane == 0) lds[RicLds::flag] = 1.0;
-    for (int c = cx.lane; c < 23; c += cx.nlanes) {
-      const int src = (c < 22) ? c : 34;
+    for (int c = cx.lane; c < 23; c += cx.nlanes) {  // columns 0..21 = Hux, 22 = hu
       double y[NU_T];
 #pragma unroll
       for (int a = 0; a < NU_T; ++a) {
-        double sacc = -Hu[a * 35 + src];
+        double sacc = -Hu[a * RicLds::LDW + c];
 #pragma unroll
         for (int k = 0; k < a; ++k) sacc -= L[a * (a + 1) / 2 + k] * y[k];
         y[a] = sacc * L[a * (a + 1) / 2 + a];
@@ -128,31 +191,51 @@ HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, double* gains) {
         y[a] = sacc * L[a * (a + 1) / 2 + a];
       }
 #pragma unroll
-      for (int a = 0; a < NU_T; ++a) Kk[a * 23 + c] = y[a];
+      for (int a = 0; a < NU_T; ++a) Kk[a * RicLds::LDN + c] = y[a];
     }
   }
   cx.sync();
-  // T = [Q~ q~] + [A~' Hux'] [M1_A M1_b ; K~ k~]  written over the Q~/q~ slots of the node record
-  wave_gemm(cx, 22, 23, 22 + NU_T,
-            [At, Hu](int i, int k) { return k < 22 ? At[k * 22 + i] : Hu[(k - 22) * 35 + i]; },
-            [M1, Kk](int k, int c) { return k < 22 ? M1[k * 35 + (c < 22 ? c : 34)] : Kk[(k - 22) * 23 + c]; },
-            [nd](int i, int c) { return c < 22 ? nd[REC_QT + i * 22 + c] : nd[REC_qT + i]; },
-            [nd](int i, int c, double v) { if (c < 22) nd[REC_QT + i * 22 + c] = v; else nd[REC_qT + i] = v; });
+}
+template <class Ctx>
+HB_HD void ric_phase3(const Ctx& cx, double* lds, double* gains) {
+  double* S = lds + RicLds::S;
+  double* sv = lds + RicLds::s;
+  double* Qq = lds + RicLds::Qq;
+  const double* Kk = lds + RicLds::Kk;
+  // T = [Q~ q~] + A~' [M1_A M1_b] + Hux' [K~ k~], accumulated over the [Q~ q~] buffer
+  {
+    WaveTile<2, 2> t;
+    tile_init(cx, t, 22, 23, [Qq](int i, int c) { return Qq[i * RicLds::LDN + c]; });
+    tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t, lds + RicLds::ABb, lds + RicLds::M1, 22, 23);
+    tile_mma<NU_T, RicLds::LDW, true, RicLds::LDN>(cx, t, lds + RicLds::Hu, Kk, 22, 23);
+    tile_store(cx, t, 22, 23, [Qq](int i, int c, double v) { Qq[i * RicLds::LDN + c] = v; });
+  }
   for (int idx = cx.lane; idx < NU_T * 23; idx += cx.nlanes) {
-    const int a = idx / 23, c = idx % 23;
-    if (c < 22) gains[a * 22 + c] = Kk[idx];
-    else gains[264 + a] = Kk[idx];
+    const int a = idx / 23, c = idx - a * 23;
+    gains[c < 22 ? a * 22 + c : 264 + a] = Kk[a * RicLds::LDN + c];
   }
   cx.sync();
   for (int idx = cx.lane; idx < 484 + 22; idx += cx.nlanes) {
     if (idx < 484) {
-      const int i = idx / 22, c = idx % 22;
-      S[idx] = 0.5 * (nd[REC_QT + i * 22 + c] + nd[REC_QT + c * 22 + i]);
+      const int i = idx / 22, c = idx - i * 22;
+      S[i * RicLds::LDN + c] = 0.5 * (Qq[i * RicLds::LDN + c] + Qq[c * RicLds::LDN + i]);
     } else {
-      sv[idx - 484] = nd[REC_qT + idx - 484];
+      sv[idx - 484] = Qq[(idx - 484) * RicLds::LDN + RicLds::CV];
     }
   }
   cx.sync();
+}
+// Reference staging of one record (host emulation; the kernel batches its global loads instead).
+template <class Ctx>
+HB_HD void ric_stage(const Ctx& cx, double* lds, const double* rec) {
+  for (int e = cx.lane; e < REC_RICCATI_END; e += cx.nlanes) lds[RicLds::dst(e)] = rec[e];
+  cx.sync();
+}
+template <class Ctx>
+HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, double* gains) {
+  ric_phase1(cx, lds);
+  ric_phase2(cx, lds);
+  ric_phase3(cx, lds, gains);
 }
 
 struct FwdLds {

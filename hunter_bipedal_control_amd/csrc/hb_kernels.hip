@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64, 2) void k_lq(Batch b, const DevModel* __restric
   lq_node(DeviceCtx(), *M, *C, in, lds, b.recs + nd * REC_SIZE);
 }
 
-__global__ __launch_bounds__(64) void k_ric_bwd(Batch b) {
+__global__ __launch_bounds__(64) void k_ric_bwd(Batch b, int dbg) {
   const int inst = blockIdx.x;
   __shared__ double lds[RicLds::total];
   const DeviceCtx cx;
@@ -124,7 +124,8 @@ __global__ __launch_bounds__(64) void k_ric_bwd(Batch b) {
       }
     }
     __syncthreads();
-    riccati_bwd_node(cx, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE);
+    if (dbg == 20) continue;  // profiling ablation: staging only
+    riccati_bwd_node(cx, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE, dbg);
   }
   if (cx.lane == 0) b.ric_fail[inst] = lds[RicLds::flag] != 0.0 ? 1 : 0;
 }
@@ -504,7 +505,7 @@ static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t
     if (timed) HB_HIP(hipEventRecord(ctx->ev[0], s));
     hipLaunchKernelGGL(k_lq, dim3(N, B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[1], s));
-    hipLaunchKernelGGL(k_ric_bwd, dim3(B), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(k_ric_bwd, dim3(B), dim3(64), 0, s, b, ctx->hconfig.debug_stop);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[2], s));
     hipLaunchKernelGGL(k_ric_fwd, dim3(B), dim3(64), 0, s, b);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[3], s));
@@ -869,7 +870,7 @@ int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, int32_t nu, const do
   for (int i = 0; i < n; ++i) nn[i] = N;
   HB_HIP(hipMemcpy(ctx->b.n_nodes, nn.data(), size_t(ctx->B) * sizeof(int), hipMemcpyHostToDevice));
   HB_HIP(hipMemcpy(ctx->b.recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_ric_bwd, dim3(n), dim3(64), 0, ctx->s_mpc, ctx->b);
+  hipLaunchKernelGGL(k_ric_bwd, dim3(n), dim3(64), 0, ctx->s_mpc, ctx->b, 0);
   HB_HIP(hipStreamSynchronize(ctx->s_mpc));
   std::vector<double> gains(size_t(n) * Nm * GAIN_SIZE);
   HB_HIP(hipMemcpy(gains.data(), ctx->b.gains, gains.size() * 8, hipMemcpyDeviceToHost));

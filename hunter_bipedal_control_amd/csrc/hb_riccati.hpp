@@ -137,7 +137,7 @@ HB_HD void ric_phase1(const Ctx& cx, double* lds) {
   cx.sync();
 }
 template <class Ctx>
-HB_HD void ric_phase2(const Ctx& cx, double* lds) {
+HB_HD void ric_phase2(const Ctx& cx, double* lds, double* gains, int dbg = 0) {
   const double* PRr = lds + RicLds::PRr;
   double* Hu = lds + RicLds::Hu;
   double* Kk = lds + RicLds::Kk;
@@ -148,6 +148,7 @@ HB_HD void ric_phase2(const Ctx& cx, double* lds) {
     tile_store(cx, t, NU_T, RicLds::LDW, [Hu](int a, int c, double v) { Hu[a * RicLds::LDW + c] = v; });
   }
   cx.sync();
+  if (dbg == 22) return;
   // Cholesky of Huu and the 23 triangular solves entirely in registers: every lane factors the (uniform) 12x12
   // block redundantly, lane c < 23 then solves its own right-hand side — no LDS traffic, no barriers.
   {
@@ -191,13 +192,16 @@ HB_HD void ric_phase2(const Ctx& cx, double* lds) {
         y[a] = sacc * L[a * (a + 1) / 2 + a];
       }
 #pragma unroll
-      for (int a = 0; a < NU_T; ++a) Kk[a * RicLds::LDN + c] = y[a];
+      for (int a = 0; a < NU_T; ++a) {
+        Kk[a * RicLds::LDN + c] = y[a];
+        gains[c < 22 ? a * 22 + c : 264 + a] = y[a];  // straight from the registers: lanes 0..21 write one row segment
+      }
     }
   }
   cx.sync();
 }
 template <class Ctx>
-HB_HD void ric_phase3(const Ctx& cx, double* lds, double* gains) {
+HB_HD void ric_phase3(const Ctx& cx, double* lds) {
   double* S = lds + RicLds::S;
   double* sv = lds + RicLds::s;
   double* Qq = lds + RicLds::Qq;
@@ -209,10 +213,6 @@ HB_HD void ric_phase3(const Ctx& cx, double* lds, double* gains) {
     tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t, lds + RicLds::ABb, lds + RicLds::M1, 22, 23);
     tile_mma<NU_T, RicLds::LDW, true, RicLds::LDN>(cx, t, lds + RicLds::Hu, Kk, 22, 23);
     tile_store(cx, t, 22, 23, [Qq](int i, int c, double v) { Qq[i * RicLds::LDN + c] = v; });
-  }
-  for (int idx = cx.lane; idx < NU_T * 23; idx += cx.nlanes) {
-    const int a = idx / 23, c = idx - a * 23;
-    gains[c < 22 ? a * 22 + c : 264 + a] = Kk[a * RicLds::LDN + c];
   }
   cx.sync();
   for (int idx = cx.lane; idx < 484 + 22; idx += cx.nlanes) {
@@ -232,10 +232,12 @@ HB_HD void ric_stage(const Ctx& cx, double* lds, const double* rec) {
   cx.sync();
 }
 template <class Ctx>
-HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, double* gains) {
+HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, double* gains, int dbg = 0) {
   ric_phase1(cx, lds);
-  ric_phase2(cx, lds);
-  ric_phase3(cx, lds, gains);
+  if (dbg == 21) return;  // profiling ablation markers (hb_config.reserved)
+  ric_phase2(cx, lds, gains, dbg);
+  if (dbg == 22 || dbg == 23) return;
+  ric_phase3(cx, lds);
 }
 
 struct FwdLds {

@@ -594,6 +594,13 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     for (int l = 0; l < 10; ++l) s += Rjj[k * 10 + l] * Kx[l * 23 + 22];
     W[k] = s;  // r_j + R_jj ke
   }
+  double* RZ = W + 16;  // R_jj Z (10x6), for R~ = Z' R_jj Z
+  for (int idx = cx.lane; idx < 60; idx += cx.nlanes) {
+    const int k = idx / 6, b = idx - 6 * k;
+    double s = 0;
+    for (int l = 0; l < 10; ++l) s += Rjj[k * 10 + l] * Z[l * 6 + b];
+    RZ[idx] = s;
+  }
   cx.sync();
 
   if (C.debug_stop == 5) return;
@@ -672,11 +679,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       }
     } else if (ca >= n_f && ca < ntil && cb >= n_f && cb < ntil) {
       const int ba = ca - n_f, bb = cb - n_f;
-      for (int k = 0; k < 10; ++k) {
-        double t = 0;
-        for (int l = 0; l < 10; ++l) t += Rjj[k * 10 + l] * Z[l * 6 + bb];
-        s += Z[k * 6 + ba] * t;
-      }
+      for (int k = 0; k < 10; ++k) s += Z[k * 6 + ba] * RZ[k * 6 + bb];
     } else if (ca >= ntil && ca == cb) {
       pad_diag = true;
     }

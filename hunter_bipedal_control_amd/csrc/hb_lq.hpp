@@ -16,6 +16,7 @@
 // LeggedRobotPreComputation.cpp:96-119; FrictionConeConstraint.cpp:70-233; utils.h:75-93.
 #pragma once
 #include "hb_model.hpp"
+#include "hb_tile.hpp"
 
 namespace hb {
 
@@ -297,18 +298,19 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   // ---- compose  x+ = x + dt/2 (f1 + f2(x + dt f1)) :
   //   d x+_i / d dir = [dir==i] + dt/2 (J1 + J2)[dir][i] + dt^2/2 ( sum_{c<12} J2[c][i] J1[dir][c] + sum_j J2[12+j][i] [dir==34+j] )
-  for (int idx = cx.lane; idx < 44 * 22; idx += cx.nlanes) {
-    const int dir = idx / 22, i = idx % 22;
-    double v;
-    if (i < 12) {
-      double acc = 0.0;
-      for (int c = 0; c < 12; ++c) acc += J2[c * 12 + i] * J1[dir * 12 + c];
-      if (dir >= 34) acc += J2[(12 + dir - 34) * 12 + i];
-      v = (dir == i ? 1.0 : 0.0) + 0.5 * dt * (J1[dir * 12 + i] + J2[dir * 12 + i]) + 0.5 * dt * dt * acc;
-    } else {
-      v = (dir == i ? 1.0 : 0.0) + (dir == 22 + i ? dt : 0.0);
-    }
-    ABt[idx] = v;
+  // rows 0..11 of x+ : the 44 x 12 x 12 contraction runs on the matrix cores (9 MFMAs)
+  {
+    WaveTile<3, 1> tl;
+    tile_init(cx, tl, 44, 12, [J2](int dir, int i) { return dir >= 34 ? J2[(dir - 22) * 12 + i] : 0.0; });
+    tile_mma<12, 12, false, 12>(cx, tl, J1, J2, 44, 12);
+    tile_store(cx, tl, 44, 12, [ABt, J1, J2, dt](int dir, int i, double acc) {
+      ABt[dir * 22 + i] = (dir == i ? 1.0 : 0.0) + 0.5 * dt * (J1[dir * 12 + i] + J2[dir * 12 + i]) + 0.5 * dt * dt * acc;
+    });
+  }
+  // joint rows: q+ = q + dt qd
+  for (int idx = cx.lane; idx < 44 * 10; idx += cx.nlanes) {
+    const int dir = idx / 10, i = 12 + idx - 10 * dir;
+    ABt[dir * 22 + i] = (dir == i ? 1.0 : 0.0) + (dir == 22 + i ? dt : 0.0);
   }
   for (int i = cx.lane; i < 22; i += cx.nlanes)
     xplus[i] = (i < 12) ? xs[i] + 0.5 * dt * (fv[i] + fv[12 + i]) : xs[i] + dt * us[i];

@@ -332,22 +332,25 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   cx.sync();
 
   // -------------------------------------------------------------- phase 2: G'G, G'[C e], pivoted Cholesky
-  // joint-velocity directions are 34..43
-  for (int idx = cx.lane; idx < 100; idx += cx.nlanes) {
-    const int k = idx / 10, l = idx % 10;
-    double s = 0;
-    for (int a = 0; a < n_eq; ++a) s += CDt[(34 + k) * 12 + eqs[a]] * CDt[(34 + l) * 12 + eqs[a]];
-    GtG[idx] = s;
+  // joint-velocity directions are 34..43.  One masked Gram product on the matrix cores gives both:
+  //   out(k, d) = sum_{slot in eq} CDt[34+k][slot] CDt[d][slot]   ->  W(k, d) for d < 22,  G'G(k, d-34) for d >= 34
+  const int cfm = (cf[0] ? 1 : 0) | (cf[1] ? 2 : 0) | (cf[2] ? 4 : 0) | (cf[3] ? 8 : 0);
+  {
+    WaveTile<1, 3> tg;
+    tile_init(cx, tg, 10, 44, [](int, int) { return 0.0; });
+    tile_mma<12, 12, false, 12, true>(cx, tg, CDt + 34 * 12, CDt, 10, 44, [cfm](int slot) {
+      const int foot = slot / 3;
+      return (((cfm >> foot) & 1) || slot - 3 * foot == 0) ? 1.0 : 0.0;  // contact foot: 3 rows, swing foot: slot 3i
+    });
+    tile_store(cx, tg, 10, 44, [W, GtG](int k, int d, double v) {
+      if (d < 22) W[k * 23 + d] = v;
+      else if (d >= 34) GtG[k * 10 + d - 34] = v;
+    });
   }
-  for (int idx = cx.lane; idx < 230; idx += cx.nlanes) {
-    const int k = idx / 23, c = idx % 23;
+  for (int k = cx.lane; k < 10; k += cx.nlanes) {
     double s = 0;
-    if (c < 22) {
-      for (int a = 0; a < n_eq; ++a) s += CDt[(34 + k) * 12 + eqs[a]] * CDt[c * 12 + eqs[a]];
-    } else {
-      for (int a = 0; a < n_eq; ++a) s += CDt[(34 + k) * 12 + eqs[a]] * rowval[eqs[a]];
-    }
-    W[idx] = s;
+    for (int a = 0; a < n_eq; ++a) s += CDt[(34 + k) * 12 + eqs[a]] * rowval[eqs[a]];
+    W[k * 23 + 22] = s;
   }
   cx.sync();
   // diagonally pivoted Cholesky of G'G, lane-parallel, in place.  L(i,s) is stored at the symmetric position
@@ -571,30 +574,30 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     for (int t = 0; t < n_soft; ++t) s += rowval[softs[t]] * CDt[(34 + k) * 12 + softs[t]];
     ru[12 + k] += C.soft_w * s;
   }
-  for (int idx = cx.lane; idx < 220; idx += cx.nlanes) {
-    const int k = idx / 22, c = idx % 22;
-    double s = 0;
-    for (int t = 0; t < n_soft; ++t) s += CDt[(34 + k) * 12 + softs[t]] * CDt[c * 12 + softs[t]];
-    Pj[idx] = C.soft_w * s;
-  }
-  for (int idx = cx.lane; idx < 100; idx += cx.nlanes) {
-    const int k = idx / 10, l = idx % 10;
-    double s = 0;
-    for (int t = 0; t < n_soft; ++t) s += CDt[(34 + k) * 12 + softs[t]] * CDt[(34 + l) * 12 + softs[t]];
-    Rjj[idx] = C.R_jj[idx] + C.soft_w * s + (k == l ? scal[4 + k] : 0.0);
+  {
+    const double sw = C.soft_w;
+    const double* Rc = C.R_jj;
+    WaveTile<1, 3> tg;
+    tile_init(cx, tg, 10, 44, [Rc, scal](int k, int d) { return d >= 34 ? Rc[k * 10 + d - 34] + (d - 34 == k ? scal[4 + k] : 0.0) : 0.0; });
+    tile_mma<12, 12, false, 12, true>(cx, tg, CDt + 34 * 12, CDt, 10, 44, [cfm, sw](int slot) {
+      const int foot = slot / 3;
+      return (slot - 3 * foot != 0 && !((cfm >> foot) & 1)) ? sw : 0.0;
+    });
+    tile_store(cx, tg, 10, 44, [Pj, Rjj](int k, int d, double v) {
+      if (d < 22) Pj[k * 22 + d] = v;
+      else if (d >= 34) Rjj[k * 10 + d - 34] = v;
+    });
   }
   cx.sync();
   // M = P_j + R_jj Kx  (10x22),  and the vector R_jj ke + r_j -> W column reuse (10)
-  for (int idx = cx.lane; idx < 220; idx += cx.nlanes) {
-    const int k = idx / 22, c = idx % 22;
-    double s = Pj[idx];
-    for (int l = 0; l < 10; ++l) s += Rjj[k * 10 + l] * Kx[l * 23 + c];
-    Mm[idx] = s;
-  }
-  for (int k = cx.lane; k < 10; k += cx.nlanes) {
-    double s = ru[12 + k];
-    for (int l = 0; l < 10; ++l) s += Rjj[k * 10 + l] * Kx[l * 23 + 22];
-    W[k] = s;  // r_j + R_jj ke
+  {
+    WaveTile<1, 2> tm;
+    tile_init(cx, tm, 10, 23, [Pj, ru](int k, int c) { return c < 22 ? Pj[k * 22 + c] : ru[12 + k]; });
+    tile_mma<12, 10, false, 23, false, 10>(cx, tm, Rjj, Kx, 10, 23);
+    tile_store(cx, tm, 10, 23, [Mm, W](int k, int c, double v) {
+      if (c < 22) Mm[k * 22 + c] = v;
+      else W[k] = v;  // r_j + R_jj ke
+    });
   }
   double* RZ = W + 16;  // R_jj Z (10x6), for R~ = Z' R_jj Z
   for (int idx = cx.lane; idx < 60; idx += cx.nlanes) {
@@ -608,28 +611,29 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   if (C.debug_stop == 5) return;
   // -------------------------------------------------------------- phase 3+4b: write the projected record
   const int ntil = n_f + nz;
-  // A~ = A + B_j Kx
-  for (int idx = cx.lane; idx < 484; idx += cx.nlanes) {
-    const int row = idx / 22, c = idx % 22;
-    double s = ABt[c * 22 + row];
-    for (int k = 0; k < 10; ++k) s += ABt[(34 + k) * 22 + row] * Kx[k * 23 + c];
-    rec[REC_AT + idx] = s;
+  // A~ = A + B_j Kx   and the kernel columns of B~ = B_j Z
+  {
+    WaveTile<2, 2> ta;
+    tile_init(cx, ta, 22, 22, [ABt](int row, int c) { return ABt[c * 22 + row]; });
+    tile_mma<12, 22, true, 23, false, 10>(cx, ta, ABt + 34 * 22, Kx, 22, 22);
+    tile_store(cx, ta, 22, 22, [rec](int row, int c, double v) { rec[REC_AT + row * 22 + c] = v; });
+    WaveTile<2, 1> tb;
+    tile_init(cx, tb, 22, 6, [](int, int) { return 0.0; });
+    tile_mma<12, 22, true, 6, false, 10>(cx, tb, ABt + 34 * 22, Z, 22, 6);
+    tile_store(cx, tb, 22, 6, [rec, n_f, nz](int row, int b, double v) { if (b < nz) rec[REC_BT + row * NU_T + n_f + b] = v; });
   }
-  // B~ columns: contact forces (foot order) then kernel directions, zero padded
+  // B~ columns: contact forces (foot order) first, zero padding after the kernel directions
   for (int idx = cx.lane; idx < 22 * NU_T; idx += cx.nlanes) {
     const int row = idx / NU_T, col = idx % NU_T;
-    double s = 0.0;
     if (col < n_f) {
       // map col -> force index of the (col/3)-th contact foot
       int foot = -1, cnt = 0;
       for (int i = 0; i < HB_NC; ++i)
         if (cf[i]) { if (cnt == col / 3) foot = i; ++cnt; }
-      s = ABt[(22 + 3 * foot + col % 3) * 22 + row];
-    } else if (col < ntil) {
-      const int b = col - n_f;
-      for (int k = 0; k < 10; ++k) s += ABt[(34 + k) * 22 + row] * Z[k * 6 + b];
+      rec[REC_BT + idx] = ABt[(22 + 3 * foot + col % 3) * 22 + row];
+    } else if (col >= ntil) {
+      rec[REC_BT + idx] = 0.0;
     }
-    rec[REC_BT + idx] = s;
   }
   for (int row = cx.lane; row < 22; row += cx.nlanes) {
     double s = xplus[row] - in.xnext[row];
@@ -639,15 +643,19 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         for (int a = 0; a < 3; ++a) s -= ABt[(22 + 3 * i + a) * 22 + row] * in.u[3 * i + a];
     rec[REC_bT + row] = s;
   }
-  // Q~ = Q + Kx' M + P_j' Kx ,  Q = diag(Qd) + w sum_soft c c'
-  for (int idx = cx.lane; idx < 484; idx += cx.nlanes) {
-    const int a = idx / 22, b = idx % 22;
-    double s = (a == b) ? Qd[a] : 0.0;
-    double ss = 0;
-    for (int t = 0; t < n_soft; ++t) ss += CDt[a * 12 + softs[t]] * CDt[b * 12 + softs[t]];
-    s += C.soft_w * ss;
-    for (int k = 0; k < 10; ++k) s += Kx[k * 23 + a] * Mm[k * 22 + b] + Pj[k * 22 + a] * Kx[k * 23 + b];
-    rec[REC_QT + idx] = dt * s;
+  // Q~ = Q + Kx' M + P_j' Kx ,  Q = diag(Qd) + w sum_soft c c'      (three accumulating GEMMs on the matrix cores)
+  {
+    const double sw = C.soft_w;
+    WaveTile<2, 2> tq;
+    tile_init(cx, tq, 22, 22, [Qd](int a, int b) { return a == b ? Qd[a] : 0.0; });
+    // soft rows are slots 3i+1, 3i+2 of the swing feet
+    tile_mma<12, 12, false, 12, true>(cx, tq, CDt, CDt, 22, 22, [cfm, sw](int slot) {
+      const int foot = slot / 3;
+      return (slot - 3 * foot != 0 && !((cfm >> foot) & 1)) ? sw : 0.0;
+    });
+    tile_mma<12, 23, true, 22, false, 10>(cx, tq, Kx, Mm, 22, 22);
+    tile_mma<12, 22, true, 23, false, 10>(cx, tq, Pj, Kx, 22, 22);
+    tile_store(cx, tq, 22, 22, [rec, dt](int a, int b, double v) { rec[REC_QT + a * 22 + b] = dt * v; });
   }
   // q~ = q + Kx' r_j + M' ke
   for (int a = cx.lane; a < 22; a += cx.nlanes) {
@@ -658,14 +666,15 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     rec[REC_RF + a] = dt * ru[a];
   }
   // P~ (12x22): force rows zero, kernel rows Z' M
+  {
+    WaveTile<1, 2> tp;
+    tile_init(cx, tp, 6, 22, [](int, int) { return 0.0; });
+    tile_mma<12, 6, true, 22, false, 10>(cx, tp, Z, Mm, 6, 22);
+    tile_store(cx, tp, 6, 22, [rec, n_f, nz, dt](int b, int c, double v) { if (b < nz) rec[REC_PT + (n_f + b) * 22 + c] = dt * v; });
+  }
   for (int idx = cx.lane; idx < NU_T * 22; idx += cx.nlanes) {
-    const int col = idx / 22, c = idx % 22;
-    double s = 0.0;
-    if (col >= n_f && col < ntil) {
-      const int b = col - n_f;
-      for (int k = 0; k < 10; ++k) s += Z[k * 6 + b] * Mm[k * 22 + c];
-    }
-    rec[REC_PT + idx] = dt * s;
+    const int col = idx / 22;
+    if (col < n_f || col >= ntil) rec[REC_PT + idx] = 0.0;
   }
   // R~ (12x12): contact-force blocks, Z' R_jj Z, identity on the padding
   for (int idx = cx.lane; idx < NU_T * NU_T; idx += cx.nlanes) {

@@ -471,27 +471,62 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       g[0] = -Fx / tn; g[1] = -Fy / tn; g[2] = C.friction_mu;
       H00 = -(Fy * Fy + C.friction_reg) / t32; H01 = Fx * Fy / t32; H11 = -(Fx * Fx + C.friction_reg) / t32;
     };
+    // Friction-cone data once per contact foot (lane = foot), shared through LDS (R_jj is not live yet):
+    //   [h, g0, g1, g2, H00, H01, H11, p(h), p'(h), p''(h)]
+    double* coneb = Rjj;
+    for (int i = cx.lane; i < HB_NC; i += cx.nlanes) {
+      double h = 1.0, g[3] = {0.0, 0.0, 0.0}, H00 = 0.0, H01 = 0.0, H11 = 0.0, pv = 0.0, p1 = 0.0, p2 = 0.0;
+      if (cf[i]) {
+        cone(i, h, g, H00, H01, H11);
+        pv = fb.value(h); p1 = fb.d1(h); p2 = fb.d2(h);
+      }
+      double* cb = coneb + 12 * i;
+      cb[0] = h; cb[1] = g[0]; cb[2] = g[1]; cb[3] = g[2]; cb[4] = H00; cb[5] = H01; cb[6] = H11; cb[7] = pv; cb[8] = p1; cb[9] = p2;
+    }
+    cx.sync();
     // hessianDiagonalShift acts on every diagonal entry of the xx and uu blocks (FrictionConeConstraint.cpp:215-233)
     double shift_sum = 0;
     for (int i = 0; i < HB_NC; ++i)
-      if (cf[i]) {
-        double h, g[3], a0, a1, a2;
-        cone(i, h, g, a0, a1, a2);
-        shift_sum += -fb.d1(h) * C.friction_shift;
-      }
+      if (cf[i]) shift_sum += -coneb[12 * i + 8] * C.friction_shift;
     for (int role = cx.lane; role < 64; role += cx.nlanes) {
       double pc = 0, pd = 0, pe = 0;
+      // two-sided relaxed barrier of this role, evaluated once on a common path (joint position limits, F_z limits,
+      // joint velocity limits): value, first and second derivative sums
+      double bval = 0.0, bd1 = 0.0, bd2 = 0.0;
+      {
+        bool hasb = false;
+        double h1 = 1.0, h2 = 1.0, bmu = 0.0, bdel = 1.0;
+        if (role >= 12 && role < 22) {
+          const int j = role - 12;
+          const double h = in.x[role];
+          hasb = true; h1 = h - M.q_lower[j]; h2 = M.q_upper[j] - h; bmu = bp.mu; bdel = bp.delta;
+        } else if (role >= 22 && role < 34) {
+          const int m = role - 22;
+          if (m - 3 * (m / 3) == 2) {
+            const double h = in.u[m];
+            hasb = true; h1 = h - C.force_lim[0]; h2 = C.force_lim[1] - h; bmu = bf.mu; bdel = bf.delta;
+          }
+        } else if (role >= 34 && role < 44) {
+          const int k = role - 34;
+          const double hv = in.u[12 + k], vl = M.qd_limit[k];
+          hasb = true; h1 = hv + vl; h2 = vl - hv; bmu = bv.mu; bdel = bv.delta;
+        }
+        if (hasb) {
+          const RelaxedBarrierD rb{bmu, bdel};
+          bval = rb.value(h1) + rb.value(h2);
+          bd1 = rb.d1(h1) - rb.d1(h2);
+          bd2 = rb.d2(h1) + rb.d2(h2);
+        }
+      }
       if (role < 22) {
         const int i = role;
         const double dxv = in.x[i] - in.xref[i];
         double qd_ = C.Q_diag[i] + shift_sum, qg = C.Q_diag[i] * dxv;
         pc += 0.5 * C.Q_diag[i] * dxv * dxv;
         if (i >= 12) {
-          const int j = i - 12;
-          const double h = in.x[i];
-          pc += bp.value(h - M.q_lower[j]) + bp.value(M.q_upper[j] - h);
-          qg += bp.d1(h - M.q_lower[j]) - bp.d1(M.q_upper[j] - h);
-          qd_ += bp.d2(h - M.q_lower[j]) + bp.d2(M.q_upper[j] - h);
+          pc += bval;
+          qg += bd1;
+          qd_ += bd2;
         }
         Qd[i] = qd_;
         qx[i] = qg;
@@ -503,16 +538,13 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         double rg = C.R_FF_diag[m] * du;
         pc += 0.5 * C.R_FF_diag[m] * du * du;
         if (cf[foot]) {
-          double h, g[3], a0, a1, a2;
-          cone(foot, h, g, a0, a1, a2);
-          rg += fb.d1(h) * g[a];
+          rg += coneb[12 * foot + 8] * coneb[12 * foot + 1 + a];
         } else {
           pe += in.u[m] * in.u[m];  // zero-force equality value
         }
         if (a == 2) {
-          const double h = in.u[m];
-          pc += bf.value(h - C.force_lim[0]) + bf.value(C.force_lim[1] - h);
-          rg += bf.d1(h - C.force_lim[0]) - bf.d1(C.force_lim[1] - h);
+          pc += bval;
+          rg += bd1;
         }
         ru[m] = rg;
       } else if (role < 44) {
@@ -520,10 +552,9 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         double sacc = 0;
         for (int l = 0; l < HB_NJ; ++l) sacc += C.R_jj[k * 10 + l] * in.u[12 + l];
         pc += 0.5 * in.u[12 + k] * sacc;
-        const double hv = in.u[12 + k], vl = M.qd_limit[k];
-        pc += bv.value(hv + vl) + bv.value(vl - hv);
-        ru[12 + k] = sacc + bv.d1(hv + vl) - bv.d1(vl - hv);
-        scal[4 + k] = bv.d2(hv + vl) + bv.d2(vl - hv) + shift_sum;  // joint diagonal additions to R_jj
+        pc += bval;
+        ru[12 + k] = sacc + bd1;
+        scal[4 + k] = bd2 + shift_sum;  // joint diagonal additions to R_jj
       } else if (role < 56) {
         const int sl = role - 44, foot = sl / 3, a = sl % 3;
         const double rv = rowval[sl];
@@ -540,10 +571,10 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
           blk[8] += bf.d2(h - C.force_lim[0]) + bf.d2(C.force_lim[1] - h);
         }
         if (cf[foot]) {
-          double h, g[3], H00, H01, H11;
-          cone(foot, h, g, H00, H01, H11);
-          const double p1 = fb.d1(h), p2 = fb.d2(h);
-          pc += fb.value(h);
+          const double* cb = coneb + 12 * foot;
+          const double g[3] = {cb[1], cb[2], cb[3]}, H00 = cb[4], H01 = cb[5], H11 = cb[6];
+          const double p1 = cb[8], p2 = cb[9];
+          pc += cb[7];
           for (int a = 0; a < 3; ++a)
             for (int bb = 0; bb < 3; ++bb) blk[3 * a + bb] += p2 * g[a] * g[bb];
           blk[0] += p1 * H00; blk[1] += p1 * H01; blk[3] += p1 * H01; blk[4] += p1 * H11;

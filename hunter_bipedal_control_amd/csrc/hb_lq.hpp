@@ -353,102 +353,108 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     W[k * 23 + 22] = s;
   }
   cx.sync();
-  // diagonally pivoted Cholesky of G'G, lane-parallel, in place.  L(i,s) is stored at the symmetric position
-  // GtG[perm[i]*10 + perm[s]] (original indices), so pivot swaps never move data.
-  if (cx.lane == 0) {
-    for (int i = 0; i < 10; ++i) perm[i] = i;
-  }
+  // Diagonally pivoted Cholesky of G'G (lower triangle in LDS, one element per lane).  Pivots never move data:
+  // a bit mask marks the eliminated original indices, the pivot is found redundantly by every lane, and step st
+  // leaves column st of the factor, indexed by ORIGINAL row, in Lc[st][.] (zero on eliminated rows), its reciprocal
+  // diagonal in Linv[st] and the pivot index in perm[st].  Two barriers per step.  Lc / col / Linv overlay the Kx
+  // buffer, which is only written once the factor has been gathered into registers.
+  double* Lc = Kx;          // 10 x 10
+  double* col = Kx + 100;   // 10 (+2)
+  double* Linv = Kx + 112;  // 10 (+2)
   double tol;
   {
     double dmax0 = 0;
     for (int i = 0; i < 10; ++i) dmax0 = fmax(dmax0, GtG[i * 10 + i]);
     tol = 1e-10 * dmax0;
   }
+  for (int i = cx.lane; i < 124; i += cx.nlanes) Kx[i] = 0.0;
   cx.sync();
-  int rank_l = 0;
+  int rank_l = 0, donemask = 0;
   for (int st = 0; st < 10; ++st) {
-    // every lane finds the pivot redundantly (same values, same result)
-    int pv = st;
-    double best = GtG[perm[st] * 10 + perm[st]];
-    for (int i = st + 1; i < 10; ++i) {
-      const double dv = GtG[perm[i] * 10 + perm[i]];
-      if (dv > best) { best = dv; pv = i; }
+    int ps = -1;
+    double best = -1.0;
+    for (int i = 0; i < 10; ++i) {
+      const double dv = GtG[i * 11];
+      if (!((donemask >> i) & 1) && dv > best) { best = dv; ps = i; }
     }
     if (!(best > tol)) break;
-    cx.sync();
-    if (cx.lane == 0) {
-      const int tmp = perm[st]; perm[st] = perm[pv]; perm[pv] = tmp;
+    const double lss = sqrt(best), rinv = 1.0 / lss;
+    for (int k = cx.lane; k < 10; k += cx.nlanes) {
+      if (!((donemask >> k) & 1)) {
+        const double l = (k == ps) ? lss : GtG[(k > ps ? k * 10 + ps : ps * 10 + k)] * rinv;
+        col[k] = l;
+        Lc[st * 10 + k] = l;
+      }
     }
+    if (cx.lane == 0) { perm[st] = ps; Linv[st] = rinv; }
     cx.sync();
-    const int ps = perm[st];
-    const double lss = sqrt(best);
-    // scale the pivot column
-    for (int i = st + 1 + cx.lane; i < 10; i += cx.nlanes) GtG[perm[i] * 10 + ps] /= lss;
-    if (cx.lane == 0) GtG[ps * 10 + ps] = lss;
-    cx.sync();
-    // Schur update of the trailing block (both triangles)
-    const int nt = 9 - st;
-    for (int idx = cx.lane; idx < nt * nt; idx += cx.nlanes) {
-      const int pi = perm[st + 1 + idx / nt], pj = perm[st + 1 + idx % nt];
-      GtG[pi * 10 + pj] -= GtG[pi * 10 + ps] * GtG[pj * 10 + ps];
+    donemask |= 1 << ps;
+    for (int e = cx.lane; e < 55; e += cx.nlanes) {
+      int i = 0, j = e;
+      while (j > i) { j -= i + 1; ++i; }  // e -> (i, j), i >= j
+      if (!((donemask >> i) & 1) && !((donemask >> j) & 1)) GtG[i * 10 + j] -= col[i] * col[j];
     }
     cx.sync();
     rank_l = st + 1;
   }
-  if (cx.lane == 0) ints[10] = rank_l;
+  if (cx.lane == 0) {  // free indices in increasing order behind the pivots
+    int w = rank_l;
+    for (int i = 0; i < 10; ++i)
+      if (!((donemask >> i) & 1)) perm[w++] = i;
+  }
   cx.sync();
   if (C.debug_stop == 2) return;
-  const int rank = ints[10];
+  const int rank = rank_l;
   const int nz = 10 - rank;
-  // L(i,s) = GtG[perm[i]*10 + perm[s]] for i >= s.  The factor is first gathered into registers (55 independent LDS
-  // reads) so that the substitutions below are pure FMA chains.
-  // Solve A11 Y = -W1 (23 right-hand sides, one per lane), scatter into Kx rows perm[a].
-  {
-    double Lr[55], dinv[10];
-    int pm[10];
-#pragma unroll
-    for (int a = 0; a < 10; ++a) pm[a] = perm[a];
-#pragma unroll
-    for (int a = 0; a < 10; ++a) {
-#pragma unroll
-      for (int t = 0; t <= a; ++t) Lr[a * (a + 1) / 2 + t] = GtG[pm[a] * 10 + pm[t]];
-      dinv[a] = (a < rank) ? 1.0 / Lr[a * (a + 1) / 2 + a] : 0.0;
-    }
-    for (int c = cx.lane; c < 23; c += cx.nlanes) {
-      double y[10];
-#pragma unroll
-      for (int a = 0; a < 10; ++a) {
-        double sacc = -W[pm[a] * 23 + c];
-#pragma unroll
-        for (int t = 0; t < a; ++t) sacc -= Lr[a * (a + 1) / 2 + t] * y[t];
-        y[a] = (a < rank) ? sacc * dinv[a] : 0.0;
-      }
-#pragma unroll
-      for (int a = 9; a >= 0; --a) {
-        double sacc = y[a];
-#pragma unroll
-        for (int t = a + 1; t < 10; ++t) sacc -= ((t < rank) ? Lr[t * (t + 1) / 2 + a] : 0.0) * y[t];
-        y[a] = (a < rank) ? sacc * dinv[a] : 0.0;
-      }
-#pragma unroll
-      for (int a = 0; a < 10; ++a) Kx[pm[a] * 23 + c] = y[a];
-    }
-  }
   // kernel basis: column b <-> free index perm[rank + b]:  z = e_free - P1 L11^-T L21[b]^T
   for (int b = cx.lane; b < 6; b += cx.nlanes) {
     if (b < nz) {
       double y[10];
       const int pf = perm[rank + b];
       for (int a = rank - 1; a >= 0; --a) {
-        double s = GtG[pf * 10 + perm[a]];  // L21(b, a)
-        for (int t = a + 1; t < rank; ++t) s -= GtG[perm[t] * 10 + perm[a]] * y[t];
-        y[a] = s / GtG[perm[a] * 10 + perm[a]];
+        double s = Lc[a * 10 + pf];  // L21(b, a)
+        for (int t = a + 1; t < rank; ++t) s -= Lc[a * 10 + perm[t]] * y[t];
+        y[a] = s * Linv[a];
       }
       for (int k = 0; k < 10; ++k) Z[k * 6 + b] = 0.0;
       for (int a = 0; a < rank; ++a) Z[perm[a] * 6 + b] = -y[a];
       Z[pf * 6 + b] = 1.0;
     } else {
       for (int k = 0; k < 10; ++k) Z[k * 6 + b] = 0.0;
+    }
+  }
+  // Solve A11 Y = -W1 (23 right-hand sides, one per lane), scatter into Kx rows perm[a].  The factor is first gathered
+  // into registers so that the substitutions are pure FMA chains; rows beyond the rank have Linv = 0, which zeroes
+  // their unknowns without masks.
+  {
+    double Lr[45], dinv[10];
+    int pm[10];
+#pragma unroll
+    for (int a = 0; a < 10; ++a) { pm[a] = perm[a]; dinv[a] = Linv[a]; }
+#pragma unroll
+    for (int a = 1; a < 10; ++a) {
+#pragma unroll
+      for (int t = 0; t < a; ++t) Lr[a * (a - 1) / 2 + t] = Lc[t * 10 + pm[a]];
+    }
+    cx.sync();  // every lane holds the factor: Kx may now be overwritten
+    for (int c = cx.lane; c < 23; c += cx.nlanes) {
+      double y[10];
+#pragma unroll
+      for (int a = 0; a < 10; ++a) {
+        double sacc = -W[pm[a] * 23 + c];
+#pragma unroll
+        for (int t = 0; t < a; ++t) sacc -= Lr[a * (a - 1) / 2 + t] * y[t];
+        y[a] = sacc * dinv[a];
+      }
+#pragma unroll
+      for (int a = 9; a >= 0; --a) {
+        double sacc = y[a];
+#pragma unroll
+        for (int t = a + 1; t < 10; ++t) sacc -= Lr[t * (t - 1) / 2 + a] * y[t];
+        y[a] = sacc * dinv[a];
+      }
+#pragma unroll
+      for (int a = 0; a < 10; ++a) Kx[pm[a] * 23 + c] = y[a];
     }
   }
 

@@ -370,6 +370,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   for (int i = cx.lane; i < 124; i += cx.nlanes) Kx[i] = 0.0;
   cx.sync();
   int rank_l = 0, donemask = 0;
+  int ei0 = 0, ej0 = cx.lane;  // lower-triangle element of this lane: e -> (i, j), i >= j
+  while (ej0 > ei0) { ej0 -= ei0 + 1; ++ei0; }
   for (int st = 0; st < 10; ++st) {
     int ps = -1;
     double best = -1.0;
@@ -378,7 +380,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       if (!((donemask >> i) & 1) && dv > best) { best = dv; ps = i; }
     }
     if (!(best > tol)) break;
-    const double lss = sqrt(best), rinv = 1.0 / lss;
+    const double rinv = rsqrt_t(best), lss = best * rinv;
     for (int k = cx.lane; k < 10; k += cx.nlanes) {
       if (!((donemask >> k) & 1)) {
         const double l = (k == ps) ? lss : GtG[(k > ps ? k * 10 + ps : ps * 10 + k)] * rinv;
@@ -390,8 +392,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     cx.sync();
     donemask |= 1 << ps;
     for (int e = cx.lane; e < 55; e += cx.nlanes) {
-      int i = 0, j = e;
-      while (j > i) { j -= i + 1; ++i; }  // e -> (i, j), i >= j
+      int i = ei0, j = ej0;
+      if (e != cx.lane) { i = 0; j = e; while (j > i) { j -= i + 1; ++i; } }  // only when the wave is narrower than 55
       if (!((donemask >> i) & 1) && !((donemask >> j) & 1)) GtG[i * 10 + j] -= col[i] * col[j];
     }
     cx.sync();

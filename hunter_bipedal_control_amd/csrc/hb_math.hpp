@@ -71,6 +71,13 @@ HB_HD void sincos_t(Dual1 a, Dual1& s, Dual1& c) {
   s = {sv, cv * a.d};
   c = {cv, -sv * a.d};
 }
+HB_HD double rsqrt_t(double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return rsqrt(a);
+#else
+  return 1.0 / sqrt(a);
+#endif
+}
 HB_HD double sqrt_t(double a) { return sqrt(a); }
 HB_HD Dual1 sqrt_t(Dual1 a) {
   const double r = sqrt(a.v);

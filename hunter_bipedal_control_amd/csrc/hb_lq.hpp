@@ -650,6 +650,12 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   if (C.debug_stop == 5) return;
   // -------------------------------------------------------------- phase 3+4b: write the projected record
   const int ntil = n_f + nz;
+  int flist = 0;  // contact feet in foot order, two bits each: projected force column block j belongs to foot (flist >> 2j) & 3
+  {
+    int cnt = 0;
+    for (int i = 0; i < HB_NC; ++i)
+      if (cf[i]) { flist |= i << (2 * cnt); ++cnt; }
+  }
   // A~ = A + B_j Kx   and the kernel columns of B~ = B_j Z
   {
     WaveTile<2, 2> ta;
@@ -666,9 +672,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     const int row = idx / NU_T, col = idx % NU_T;
     if (col < n_f) {
       // map col -> force index of the (col/3)-th contact foot
-      int foot = -1, cnt = 0;
-      for (int i = 0; i < HB_NC; ++i)
-        if (cf[i]) { if (cnt == col / 3) foot = i; ++cnt; }
+      const int foot = (flist >> (2 * (col / 3))) & 3;
       rec[REC_BT + idx] = ABt[(22 + 3 * foot + col % 3) * 22 + row];
     } else if (col >= ntil) {
       rec[REC_BT + idx] = 0.0;
@@ -722,9 +726,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     bool pad_diag = false;
     if (ca < n_f && cb < n_f) {
       if (ca / 3 == cb / 3) {
-        int foot = -1, cnt = 0;
-        for (int i = 0; i < HB_NC; ++i)
-          if (cf[i]) { if (cnt == ca / 3) foot = i; ++cnt; }
+        const int foot = (flist >> (2 * (ca / 3))) & 3;
         s = RFF[9 * foot + 3 * (ca % 3) + (cb % 3)];
       }
     } else if (ca >= n_f && ca < ntil && cb >= n_f && cb < ntil) {
@@ -739,9 +741,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   for (int col = cx.lane; col < NU_T; col += cx.nlanes) {
     double s = 0.0;
     if (col < n_f) {
-      int foot = -1, cnt = 0;
-      for (int i = 0; i < HB_NC; ++i)
-        if (cf[i]) { if (cnt == col / 3) foot = i; ++cnt; }
+      const int foot = (flist >> (2 * (col / 3))) & 3;
       s = ru[3 * foot + col % 3];
     } else if (col < ntil) {
       const int b = col - n_f;

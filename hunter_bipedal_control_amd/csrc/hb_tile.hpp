@@ -1,0 +1,107 @@
+// Small dense GEMMs on one 64-lane wavefront with the f64 matrix cores (v_mfma_f64_16x16x4_f64), operands in LDS.
+#pragma once
+#include <type_traits>
+#include "hb_math.hpp"
+
+namespace hb {
+
+// ---- small dense GEMMs on one wavefront ---------------------------------------------------------------------
+// A block of MT x NT accumulator tiles (16 x 16 each) of v_mfma_f64_16x16x4_f64: A/B fragments are one f64 per lane
+// (A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]), accumulator rows (l>>4) + 4 r, column l&15
+// (cdna_hip_programming.md §3, f64 layout).  All tiles advance together over K, so consecutive MFMAs are independent
+// and each A/B fragment is read once per K-step.  The host build (tests/host_emu only) uses plain loops.
+template <int MT, int NT>
+struct WaveTile {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 acc[MT][NT];
+#else
+  double c[MT * 16][NT * 16];
+#endif
+};
+template <int MT, int NT, class Ctx, class FC>
+HB_HD void tile_init(const Ctx& cx, WaveTile<MT, NT>& t, int Mr, int Nr, FC c_init) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tm + lk + 4 * r, col = 16 * tn + li;
+        t.acc[tm][tn][r] = (row < Mr && col < Nr) ? c_init(row, col) : 0.0;
+      }
+#else
+  for (int i = 0; i < MT * 16; ++i)
+    for (int j = 0; j < NT * 16; ++j) t.c[i][j] = (i < Mr && j < Nr) ? c_init(i, j) : 0.0;
+#endif
+}
+// t += A B over K.  A(i,k) = TA ? A[k*LDA + i] : A[i*LDA + k],  B(k,j) = TB ? B[j*LDB + k] : B[k*LDB + j].
+// K is padded to a multiple of 4; KR <= K is the real depth.  With KR == K there are no masks at all: the operands
+// must then be zero-padded in k on both sides, and out-of-range rows / columns only feed discarded outputs.  With
+// KR < K the fragments of the last step are selected to zero beyond KR (the memory behind them only has to be mapped).
+struct NoScale { HB_HD double operator()(int) const { return 1.0; } };
+// `wk(k)` is an optional weight of the k-th term (diagonal scaling between A and B), e.g. a 0/1 row mask.
+template <int K, int LDA, bool TA, int LDB, bool TB = false, int KR = K, int MT, int NT, class Ctx, class FW = NoScale>
+HB_HD void tile_mma(const Ctx& cx, WaveTile<MT, NT>& t, const double* A, const double* B, int Mr, int Nr, FW wk = FW()) {
+  constexpr bool weighted = !std::is_same<FW, NoScale>::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)Mr; (void)Nr;
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+  const double* ap = A + (TA ? lk * LDA + li : li * LDA + lk);
+  const double* bp = B + (TB ? li * LDB + lk : lk * LDB + li);
+#pragma unroll
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    double av[MT], bv[NT];
+    const bool live = (k0 + 4 <= KR) || (k0 + lk < KR);
+    double w = 1.0;
+    if (weighted) w = wk(k0 + lk);
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm) {
+      av[tm] = ap[TA ? k0 * LDA + 16 * tm : 16 * tm * LDA + k0];
+      if (k0 + 4 > KR) av[tm] = live ? av[tm] : 0.0;
+      if (weighted) av[tm] *= w;
+    }
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      bv[tn] = bp[TB ? 16 * tn * LDB + k0 : k0 * LDB + 16 * tn];
+      if (k0 + 4 > KR) bv[tn] = live ? bv[tn] : 0.0;
+    }
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) t.acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tm], bv[tn], t.acc[tm][tn], 0, 0, 0);
+  }
+#else
+  (void)cx;
+  for (int i = 0; i < Mr; ++i)
+    for (int j = 0; j < Nr; ++j) {
+      double acc = t.c[i][j];
+      for (int k = 0; k < KR; ++k)
+        acc += (weighted ? wk(k) : 1.0) * (TA ? A[k * LDA + i] : A[i * LDA + k]) * (TB ? B[j * LDB + k] : B[k * LDB + j]);
+      t.c[i][j] = acc;
+    }
+#endif
+}
+template <int MT, int NT, class Ctx, class FS>
+HB_HD void tile_store(const Ctx& cx, const WaveTile<MT, NT>& t, int Mr, int Nr, FS store) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tm + lk + 4 * r, col = 16 * tn + li;
+        if (row < Mr && col < Nr) store(row, col, t.acc[tm][tn][r]);
+      }
+#else
+  (void)cx;
+  for (int i = 0; i < Mr; ++i)
+    for (int j = 0; j < Nr; ++j) store(i, j, t.c[i][j]);
+#endif
+}
+
+}  // namespace hb

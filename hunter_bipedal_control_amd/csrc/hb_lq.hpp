@@ -157,6 +157,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   // up front: four lanes = (point, leg) run the value pass (base-frame suffix composites per joint, staged in LDS over
   // the not-yet-written ABt buffer); the direction lanes of stage 2 then evaluate the closed-form tangents of the 27
   // leg outputs (rigid rotation of the outboard composite about the seeded joint axis).
+  if (C.debug_stop == 10) return;
   double* LJ_all = ABt;  // 4 x LEGJ_SIZE; ABt is not written before the final compose
   static_assert(4 * LEGJ_SIZE <= 968, "leg blocks must fit the ABt buffer");
   for (int r = cx.lane; r < 4; r += cx.nlanes) {

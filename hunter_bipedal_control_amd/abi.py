@@ -124,3 +124,17 @@ def make_config(params: dict, **overrides) -> HbConfig:
     for k, v in overrides.items():
         setattr(out, k, v)
     return out
+
+
+PARAMS_BLOB_MAGIC = 0x48423031  # "HB01"
+
+
+def write_params_blob(params: dict, path) -> None:
+    """Binary image {magic, sizeof(hb_model), sizeof(hb_config), 0, hb_model, hb_config} for C++ hosts
+    (include/hunter_hip.hpp loadPackagedParameters); defaults of make_config (WeightedWbc)."""
+    import struct
+    model, config = make_model(params), make_config(params)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4I", PARAMS_BLOB_MAGIC, C.sizeof(HbModel), C.sizeof(HbConfig), 0))
+        f.write(bytes(model))
+        f.write(bytes(config))

@@ -1,0 +1,236 @@
+// hunter_hip.hpp — header-only C++14 host adapter over the C ABI (hunter_hip.h).
+//
+// The reference's host code for this path is C++ (ROS1 / OCS2 / Eigen).  None of those are needed here: this
+// header mirrors the *operator interface* the reference's control loop talks to, with the same names, argument
+// order and error behaviour, over plain std::vector<double>:
+//
+//   legged::WbcBase::update(stateDesired, inputDesired, rbdStateMeasured, mode, period)
+//                                   legged_wbc/include/legged_wbc/WbcBase.h:43-44, WeightedWbc.cpp:18-66
+//   ocs2::MPC_MRT_Interface::{setCurrentObservation, advanceMpc, updatePolicy, evaluatePolicy, resetMpcNode}
+//                                   call sites legged_controllers/src/LeggedController.cpp:144-159,406,464
+//   LeggedController::update        legged_controllers/src/LeggedController.cpp:137-185 (policy + WBC part)
+//
+// Errors: the C ABI never throws and returns negative hb_status codes; the reference's C++ throws
+// std::runtime_error / std::invalid_argument (e.g. LeggedInterface.cpp:68-76) — this adapter converts.
+// A WBC QP that does not converge is NOT an exception in the reference: WeightedWbc::update prints
+// "ERROR: WeightWBC Not Solved!!!" and returns the previous solution (WeightedWbc.cpp:57-65); same here.
+//
+// One Context = one GPU = `batch` independent robot instances.  batch == 1 reproduces the reference's shapes.
+#pragma once
+
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "hunter_hip.h"
+
+namespace hunter_hip {
+
+using scalar_t = double;
+using vector_t = std::vector<double>;
+
+class Error : public std::runtime_error {
+ public:
+  Error(int32_t status, const std::string& what) : std::runtime_error(what), status_(status) {}
+  int32_t status() const { return status_; }
+
+ private:
+  int32_t status_;
+};
+
+// ocs2::SystemObservation restricted to what the path reads (LeggedController.cpp:280-349).
+struct SystemObservation {
+  scalar_t time = 0.0;
+  vector_t state = vector_t(HB_NX, 0.0);
+  vector_t input = vector_t(HB_NU, 0.0);
+  size_t mode = 3;
+};
+
+// Node tables of one batch (what SwitchedModelReferenceManager::modifyReferences + the OCS2 time discretisation
+// hand to the solver, see hb_mpc_set_references).  Strides are max_nodes (+1 for t).
+struct ReferenceTables {
+  std::vector<int32_t> nNodes;  // [batch]
+  vector_t t;                   // [batch][maxNodes + 1]
+  std::vector<int32_t> mode;    // [batch][maxNodes]
+  vector_t xRef;                // [batch][maxNodes][22]
+  vector_t swingRef;            // [batch][maxNodes][4][6]
+};
+
+// Binary image of {hb_model, hb_config} written by tools/make_hunter_params.py (data/hunter_params.bin): the
+// flattened URDF + task.info / reference.info the reference reads at LeggedController::init.
+inline void loadPackagedParameters(const std::string& path, hb_model& model, hb_config& config) {
+  std::FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) throw std::invalid_argument("[hunter_hip] parameter file not found: " + path);
+  uint32_t head[4] = {0, 0, 0, 0};
+  const bool ok = std::fread(head, sizeof(head), 1, f) == 1 && head[0] == 0x48423031u /* "HB01" */ &&
+                  head[1] == sizeof(hb_model) && head[2] == sizeof(hb_config) &&
+                  std::fread(&model, sizeof(hb_model), 1, f) == 1 && std::fread(&config, sizeof(hb_config), 1, f) == 1;
+  std::fclose(f);
+  if (!ok) throw std::invalid_argument("[hunter_hip] parameter file does not match this ABI: " + path);
+}
+
+class Context {
+ public:
+  Context(const hb_model& model, const hb_config& config, int batch, int maxNodes, int device = 0)
+      : batch_(batch), maxNodes_(maxNodes) {
+    hb_ctx* raw = nullptr;
+    const int32_t rc = hb_create(&model, &config, batch, maxNodes, device, &raw);
+    if (rc != HB_OK) throw Error(rc, std::string("[hunter_hip] hb_create failed: ") + hb_last_error(nullptr));
+    ctx_.reset(raw, [](hb_ctx* p) { hb_destroy(p); });
+  }
+  hb_ctx* get() const { return ctx_.get(); }
+  int batch() const { return batch_; }
+  int maxNodes() const { return maxNodes_; }
+  void check(int32_t rc, const char* what) const {
+    if (rc != HB_OK) throw Error(rc, std::string("[hunter_hip] ") + what + " failed: " + hb_last_error(ctx_.get()));
+  }
+  hb_stats stats() const {
+    hb_stats st;
+    check(hb_get_stats(ctx_.get(), &st), "hb_get_stats");
+    return st;
+  }
+
+ private:
+  std::shared_ptr<hb_ctx> ctx_;
+  int batch_, maxNodes_;
+};
+
+// ---- MPC side: the calls LeggedController makes on ocs2::MPC_MRT_Interface --------------------------------------
+class MpcMrtInterface {
+ public:
+  explicit MpcMrtInterface(Context ctx) : ctx_(std::move(ctx)), x0_(size_t(ctx_.batch()) * HB_NX, 0.0) {}
+
+  // reference manager output for the next solve (SwitchedModelReferenceManager::modifyReferences)
+  void setReferences(const ReferenceTables& r, int instBegin = 0) {
+    const int count = int(r.nNodes.size());
+    const size_t n = size_t(count), N = size_t(ctx_.maxNodes());
+    if (r.t.size() != n * (N + 1) || r.mode.size() != n * N || r.xRef.size() != n * N * HB_NX ||
+        r.swingRef.size() != n * N * HB_NC * HB_SWING_REF)
+      throw std::invalid_argument("[hunter_hip] reference tables do not match (batch, maxNodes)");
+    ctx_.check(hb_mpc_set_references(ctx_.get(), instBegin, count, r.nNodes.data(), r.t.data(), r.mode.data(), r.xRef.data(),
+                                     r.swingRef.data()),
+               "hb_mpc_set_references");
+  }
+  // MPC_MRT_Interface::resetMpcNode (LeggedController.cpp:464): cold start from the given states
+  void resetMpcNode(const vector_t& initialStates) {
+    requireSize(initialStates, size_t(ctx_.batch()) * HB_NX, "resetMpcNode");
+    ctx_.check(hb_mpc_reset(ctx_.get(), initialStates.data()), "hb_mpc_reset");
+    x0_ = initialStates;
+  }
+  // MPC_MRT_Interface::setCurrentObservation (LeggedController.cpp:144); one observation per instance
+  void setCurrentObservation(const std::vector<SystemObservation>& obs) {
+    if (int(obs.size()) != ctx_.batch()) throw std::invalid_argument("[hunter_hip] one observation per instance expected");
+    for (size_t i = 0; i < obs.size(); ++i) {
+      requireSize(obs[i].state, HB_NX, "setCurrentObservation");
+      std::memcpy(&x0_[i * HB_NX], obs[i].state.data(), HB_NX * sizeof(double));
+    }
+  }
+  void setCurrentObservation(const SystemObservation& obs) { setCurrentObservation(std::vector<SystemObservation>{obs}); }
+  // MPC_MRT_Interface::advanceMpc (LeggedController.cpp:406): one SQP solve from the current observation (asynchronous
+  // on the library's MPC stream, like the reference's MPC thread)
+  void advanceMpc() { ctx_.check(hb_mpc_solve(ctx_.get(), x0_.data()), "hb_mpc_solve"); }
+  // MPC_MRT_Interface::updatePolicy (LeggedController.cpp:154)
+  void updatePolicy() { ctx_.check(hb_mpc_publish(ctx_.get()), "hb_mpc_publish"); }
+  // PrimalSolution of the last solve (LeggedController.cpp:269, visualisation)
+  void getSolution(vector_t& stateTrajectory, vector_t& inputTrajectory) const {
+    const size_t B = size_t(ctx_.batch()), N = size_t(ctx_.maxNodes());
+    stateTrajectory.assign(B * (N + 1) * HB_NX, 0.0);
+    inputTrajectory.assign(B * N * HB_NU, 0.0);
+    ctx_.check(hb_mpc_get_solution(ctx_.get(), 0, ctx_.batch(), stateTrajectory.data(), inputTrajectory.data()), "hb_mpc_get_solution");
+  }
+  // OCS2 PerformanceIndex of the last iteration per instance: [merit, dynamics SSE, equality SSE, accepted step size]
+  vector_t getPerformanceIndices() const {
+    vector_t perf(size_t(ctx_.batch()) * 4, 0.0);
+    ctx_.check(hb_mpc_get_performance(ctx_.get(), perf.data()), "hb_mpc_get_performance");
+    return perf;
+  }
+  const Context& context() const { return ctx_; }
+
+ private:
+  static void requireSize(const vector_t& v, size_t n, const char* who) {
+    if (v.size() != n) throw std::invalid_argument(std::string("[hunter_hip] ") + who + ": wrong vector size");
+  }
+  Context ctx_;
+  vector_t x0_;
+};
+
+// ---- WBC side: legged::WbcBase / WeightedWbc / HierarchicalWbc ----------------------------------------------------
+// Which of the two the context runs is hb_config::wbc_type (LeggedController.cpp:85 constructs WeightedWbc).
+class Wbc {
+ public:
+  explicit Wbc(Context ctx)
+      : ctx_(std::move(ctx)), last_(size_t(ctx_.batch()) * HB_NWBC, 0.0), status_(size_t(ctx_.batch()), 0),
+        stance_(size_t(ctx_.batch()), 0) {}
+
+  void setStanceMode(bool stanceMode) { std::fill(stance_.begin(), stance_.end(), stanceMode ? 1 : 0); }  // WbcBase.h:73-76
+
+  // WbcBase::update for every instance of the batch: x = [qdd(16) F(12) tau(10)] per instance.
+  // stateDesired / inputDesired [batch][22], rbdStateMeasured [batch][32], mode [batch].
+  const vector_t& update(const vector_t& stateDesired, const vector_t& inputDesired, const vector_t& rbdStateMeasured,
+                         const std::vector<int32_t>& mode, scalar_t period) {
+    const size_t B = size_t(ctx_.batch());
+    if (stateDesired.size() != B * HB_NX || inputDesired.size() != B * HB_NU || rbdStateMeasured.size() != B * HB_NRBD ||
+        mode.size() != B)
+      throw std::invalid_argument("[hunter_hip] Wbc::update: wrong vector size");
+    ctx_.check(hb_wbc_update_direct(ctx_.get(), stateDesired.data(), inputDesired.data(), rbdStateMeasured.data(), mode.data(),
+                                    stance_.data(), period, last_.data(), status_.data()),
+               "hb_wbc_update_direct");
+    reportUnsolved();
+    return last_;
+  }
+  // the reference's single-robot signature (WbcBase.h:43-44)
+  vector_t update(const vector_t& stateDesired, const vector_t& inputDesired, const vector_t& rbdStateMeasured, size_t mode,
+                  scalar_t period) {
+    if (ctx_.batch() != 1) throw std::invalid_argument("[hunter_hip] single-instance update on a batched context");
+    return update(stateDesired, inputDesired, rbdStateMeasured, std::vector<int32_t>{int32_t(mode)}, period);
+  }
+  const std::vector<int32_t>& status() const { return status_; }
+  const Context& context() const { return ctx_; }
+
+ protected:
+  void reportUnsolved() const {
+    // instances that hit the iteration limit keep their previous solution on the device (WeightedWbc.cpp:57-65)
+    for (size_t i = 0; i < status_.size(); ++i)
+      if (status_[i] != HB_INST_OK) {
+        std::cout << "ERROR: WeightWBC Not Solved!!! (instance " << i << ", status " << status_[i] << ")" << std::endl;
+        break;
+      }
+  }
+  Context ctx_;
+  vector_t last_;
+  std::vector<int32_t> status_, stance_;
+};
+
+// ---- the hot part of LeggedController::update (LeggedController.cpp:151-185) --------------------------------------
+//   updatePolicy(); evaluatePolicy(t, x, optimizedState, optimizedInput, plannedMode); wbc_->update(...)
+// evaluatePolicy runs on the device and feeds the WBC without a host round trip; its outputs are returned because the
+// joint PD law that follows (:187-257) consumes optimizedState / optimizedInput.
+struct ControlOutput {
+  vector_t x;               // [batch][38] WBC solution
+  vector_t optimizedState;  // [batch][22]
+  vector_t optimizedInput;  // [batch][22]
+  std::vector<int32_t> plannedMode, status;
+};
+
+inline void controllerUpdate(MpcMrtInterface& mpcMrt, const vector_t& time, const vector_t& rbdStateMeasured,
+                             const std::vector<int32_t>* walkFlag, scalar_t period, ControlOutput& out) {
+  const Context& c = mpcMrt.context();
+  const size_t B = size_t(c.batch());
+  if (time.size() != B || rbdStateMeasured.size() != B * HB_NRBD || (walkFlag && walkFlag->size() != B))
+    throw std::invalid_argument("[hunter_hip] controllerUpdate: wrong vector size");
+  out.x.resize(B * HB_NWBC);
+  out.optimizedState.resize(B * HB_NX);
+  out.optimizedInput.resize(B * HB_NU);
+  out.plannedMode.resize(B);
+  out.status.resize(B);
+  mpcMrt.updatePolicy();
+  c.check(hb_wbc_update(c.get(), time.data(), rbdStateMeasured.data(), walkFlag ? walkFlag->data() : nullptr, period, out.x.data(),
+                        out.optimizedState.data(), out.optimizedInput.data(), out.plannedMode.data(), out.status.data()),
+          "hb_wbc_update");
+}
+
+}  // namespace hunter_hip

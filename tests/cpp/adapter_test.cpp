@@ -1,0 +1,101 @@
+// Exercises include/hunter_hip.hpp (the C++ host adapter) the way the reference's control loop drives its solver:
+//   adapter_test <params.bin> nogpu
+//       no device: the constructor must throw hunter_hip::Error(HB_ERR_NO_GPU) — the product has no CPU path.
+//   adapter_test <params.bin> run <problem.bin> <result.bin> <sqp_calls> <wbc_type>
+//       problem.bin (written by tests/test_cpp_adapter.py): int32 batch, maxNodes; nNodes[B]; t[B][N+1]; mode[B][N];
+//       xRef[B][N][22]; swingRef[B][N][4][6]; x0[B][22]; rbd[B][32]; tNow[B]
+//       result.bin: x[B][38], optimizedState[B][22], optimizedInput[B][22], plannedMode[B], status[B] (as doubles),
+//       direct[B][38] (Wbc::update on the evaluated policy), stateTrajectory, inputTrajectory
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "hunter_hip.hpp"
+
+using namespace hunter_hip;
+
+template <class T>
+static void readv(std::FILE* f, std::vector<T>& v, size_t n) {
+  v.resize(n);
+  if (n && std::fread(v.data(), sizeof(T), n, f) != n) { std::fprintf(stderr, "short read\n"); std::exit(2); }
+}
+static void writev(std::FILE* f, const vector_t& v) { std::fwrite(v.data(), sizeof(double), v.size(), f); }
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 64;
+  hb_model model;
+  hb_config config;
+  loadPackagedParameters(argv[1], model, config);
+  const std::string what = argv[2];
+  if (what == "nogpu") {
+    try {
+      Context ctx(model, config, 1, 20);
+    } catch (const Error& e) {
+      std::printf("threw status %d: %s\n", e.status(), e.what());
+      return e.status() == HB_ERR_NO_GPU ? 0 : 3;
+    }
+    std::printf("a context was created: a GPU is visible\n");
+    return 4;
+  }
+  if (what != "run" || argc < 7) return 64;
+  std::FILE* f = std::fopen(argv[3], "rb");
+  if (!f) return 66;
+  std::vector<int32_t> head;
+  readv(f, head, 2);
+  const size_t B = size_t(head[0]), N = size_t(head[1]);
+  ReferenceTables tables;
+  vector_t x0, rbd, tNow;
+  readv(f, tables.nNodes, B);
+  readv(f, tables.t, B * (N + 1));
+  readv(f, tables.mode, B * N);
+  readv(f, tables.xRef, B * N * HB_NX);
+  readv(f, tables.swingRef, B * N * HB_NC * HB_SWING_REF);
+  readv(f, x0, B * HB_NX);
+  readv(f, rbd, B * HB_NRBD);
+  readv(f, tNow, B);
+  std::fclose(f);
+  const int calls = std::atoi(argv[5]);
+  config.wbc_type = std::atoi(argv[6]);
+
+  Context ctx(model, config, int(B), int(N));
+  MpcMrtInterface mpcMrt(ctx);
+  mpcMrt.setReferences(tables);
+  mpcMrt.resetMpcNode(x0);
+  std::vector<SystemObservation> obs(B);
+  for (size_t i = 0; i < B; ++i) {
+    obs[i].time = tNow[i];
+    obs[i].state.assign(x0.begin() + i * HB_NX, x0.begin() + (i + 1) * HB_NX);
+  }
+  mpcMrt.setCurrentObservation(obs);
+  for (int k = 0; k < calls; ++k) mpcMrt.advanceMpc();   // MPC thread body (LeggedController.cpp:396-412)
+  ControlOutput out;
+  controllerUpdate(mpcMrt, tNow, rbd, nullptr, 0.002, out);  // control thread (LeggedController.cpp:151-185)
+  Wbc wbc(ctx);
+  const vector_t direct = wbc.update(out.optimizedState, out.optimizedInput, rbd, out.plannedMode, 0.002);
+  vector_t xs, us;
+  mpcMrt.getSolution(xs, us);
+
+  std::FILE* g = std::fopen(argv[4], "wb");
+  if (!g) return 73;
+  writev(g, out.x);
+  writev(g, out.optimizedState);
+  writev(g, out.optimizedInput);
+  vector_t tmp(out.plannedMode.begin(), out.plannedMode.end());
+  writev(g, tmp);
+  tmp.assign(out.status.begin(), out.status.end());
+  writev(g, tmp);
+  writev(g, direct);
+  writev(g, xs);
+  writev(g, us);
+  std::fclose(g);
+  const hb_stats st = ctx.stats();
+  std::printf("ok: %lld mpc solves, %lld wbc solves\n", (long long)st.n_mpc_solves, (long long)st.n_wbc_solves);
+  // error behaviour of the adapter: wrong sizes are std::invalid_argument, like the reference's loaders
+  try {
+    mpcMrt.resetMpcNode(vector_t(3, 0.0));
+    return 5;
+  } catch (const std::invalid_argument&) {
+  }
+  return 0;
+}

@@ -25,3 +25,9 @@ out = dict(
 dst = Path(__file__).resolve().parents[1] / "hunter_bipedal_control_amd/data/hunter_params.json"
 dst.write_text(json.dumps(out, indent=1))
 print("wrote", dst, "total mass", sum(out["model"]["mass"]))
+
+from hunter_bipedal_control_amd import abi  # noqa: E402
+
+blob = dst.with_suffix(".bin")
+abi.write_params_blob(out, blob)
+print("wrote", blob)

@@ -126,6 +126,19 @@ def make_config(params: dict, **overrides) -> HbConfig:
     return out
 
 
+class HbEstimatorConfig(C.Structure):
+    _fields_ = [(k, C.c_double) for k in (
+        "foot_radius", "imu_process_noise_position", "imu_process_noise_velocity", "foot_process_noise_position",
+        "foot_sensor_noise_position", "foot_sensor_noise_velocity", "foot_height_sensor_noise")]
+
+
+def make_estimator_config(params: dict, **overrides) -> HbEstimatorConfig:
+    out = HbEstimatorConfig()
+    for k, _ in HbEstimatorConfig._fields_:
+        setattr(out, k, overrides.get(k, params["config"]["kalman"][k]))
+    return out
+
+
 PARAMS_BLOB_MAGIC = 0x48423031  # "HB01"
 
 

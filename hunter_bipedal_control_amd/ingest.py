@@ -256,6 +256,16 @@ def read_config(task_file: str | Path, reference_file: str | Path, gait_file: st
         base_angular_kp=f("baseAngularTask.kp"), base_angular_kd=f("baseAngularTask.kd"),
         weight_swing_leg=f("weight.swingLeg"), weight_base_accel=f("weight.baseAccel"),
         weight_contact_force=f("weight.contactForce"),
+        # state estimator (task.info:336-345; defaults LinearKalmanFilter.h:50-56)
+        kalman=dict(
+            foot_radius=f("kalmanFilter.footRadius", 0.02),
+            imu_process_noise_position=f("kalmanFilter.imuProcessNoisePosition", 0.02),
+            imu_process_noise_velocity=f("kalmanFilter.imuProcessNoiseVelocity", 0.02),
+            foot_process_noise_position=f("kalmanFilter.footProcessNoisePosition", 0.002),
+            foot_sensor_noise_position=f("kalmanFilter.footSensorNoisePosition", 0.005),
+            foot_sensor_noise_velocity=f("kalmanFilter.footSensorNoiseVelocity", 0.1),
+            foot_height_sensor_noise=f("kalmanFilter.footHeightSensorNoise", 0.01),
+        ),
         # reference.info
         com_height=float(info_get(ref, "comHeight")),
         default_joint_state=info_matrix(ref, "defaultJointState", 10)[:, 0].tolist(),

@@ -190,6 +190,31 @@ int32_t hb_get_wbc_solution(hb_ctx* ctx, double* sol /*[batch][38]*/, int32_t* s
  * recorded with n_chunks = 1 (the default). */
 int32_t hb_set_chunks(hb_ctx* ctx, int32_t n_chunks);
 
+/* ---- state estimator (the step immediately before the path every tick) ------------------
+ * Batched KalmanFilterEstimate::update (legged_estimation/src/LinearKalmanFilter.cpp:72-184): 18-state
+ * [base pos, base vel, 4 foot positions] / 28-measurement linear Kalman filter on leg kinematics, preceded by the
+ * sensor packing of StateEstimateBase::{updateJointStates, updateImu} (StateEstimateBase.cpp:73-106) and followed by
+ * the centroidal-state conversion + yaw unwrapping of LeggedController::updateStateEstimation
+ * (LeggedController.cpp:331-334).  The filter state (xHat[18], P[18][18], last yaw) is device-resident per
+ * instance.  ROS topics / tf (updateFromTopic) and the contact-force estimator are not part of this entry point. */
+typedef struct hb_estimator_config {  /* task.info kalmanFilter block (:336-345); LinearKalmanFilter.h:50-56 */
+  double foot_radius;
+  double imu_process_noise_position, imu_process_noise_velocity, foot_process_noise_position;
+  double foot_sensor_noise_position, foot_sensor_noise_velocity, foot_height_sensor_noise;
+} hb_estimator_config;
+/* (Re)initialise: xHat = x_hat0 (or zeros if NULL), P = 100 I, last yaw = 0 (LinearKalmanFilter.cpp:31-60). */
+int32_t hb_estimator_reset(hb_ctx* ctx, const hb_estimator_config* cfg, const double* x_hat0 /*[batch][18] or NULL*/);
+/* One filter step for every instance.  Host in: quat[batch][4] (x y z w), ang_vel_local[batch][3],
+ * lin_acc_local[batch][3], joint_pos[batch][10], joint_vel[batch][10], contact_flag[batch][4] (contact order
+ * L_f1 R_f1 L_f2 R_f2).  Host out (either may be NULL): rbd[batch][32] (the vector WbcBase::update takes),
+ * x_state[batch][22] (the MPC observation state).  to_resident != 0 additionally stores both into the
+ * device-resident inputs of hb_step_resident, so that estimate -> MPC -> WBC never leaves the GPU. */
+int32_t hb_estimator_update(hb_ctx* ctx, double dt, const double* quat, const double* ang_vel_local,
+                            const double* lin_acc_local, const double* joint_pos, const double* joint_vel,
+                            const int32_t* contact_flag, int32_t to_resident, double* rbd, double* x_state);
+/* Filter state to the host (either may be NULL): x_hat[batch][18], P[batch][18][18]. */
+int32_t hb_estimator_get_filter(hb_ctx* ctx, double* x_hat, double* P);
+
 /* ---- misc ------------------------------------------------------------------------------------ */
 int32_t hb_sync(hb_ctx* ctx);
 int32_t hb_get_stats(hb_ctx* ctx, hb_stats* out);

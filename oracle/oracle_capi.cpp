@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <thread>
 
+#include "estimator.hpp"
 #include "hoqp.hpp"
 #include "sqp.hpp"
 #include "wbc.hpp"
@@ -330,6 +331,27 @@ int orc_hwbc_tasks(void* h, const double* x_des, const double* u_des, const doub
   copy_mat(t.A, A); std::memcpy(b, t.b.data(), t.b.size() * 8); *mA = t.A.r;
   copy_mat(t.D, D); std::memcpy(f, t.f.data(), t.f.size() * 8); *mD = t.D.r;
   return 0;
+}
+
+// Batched estimator tick.  Filter state arrays are in/out: xhat[n][18], P[n][18][18], yaw_last[n].
+void orc_kf_update(const hb_model* mdl, const hb_estimator_config* cfg, int n, double dt, double* xhat, double* P, double* yaw_last,
+                   const double* quat, const double* w_local, const double* a_local, const double* qj, const double* qdj,
+                   const int32_t* contact, double* rbd, double* x) {
+  for (int i = 0; i < n; ++i) {
+    KfState st;
+    std::memcpy(st.xhat, xhat + size_t(i) * 18, 18 * 8);
+    std::memcpy(st.P, P + size_t(i) * 324, 324 * 8);
+    st.yaw_last = yaw_last[i];
+    kf_update(*mdl, *cfg, st, dt, quat + 4 * i, w_local + 3 * i, a_local + 3 * i, qj + 10 * i, qdj + 10 * i, contact + 4 * i,
+              rbd + size_t(i) * HB_NRBD, x + size_t(i) * HB_NX);
+    std::memcpy(xhat + size_t(i) * 18, st.xhat, 18 * 8);
+    std::memcpy(P + size_t(i) * 324, st.P, 324 * 8);
+    yaw_last[i] = st.yaw_last;
+  }
+}
+
+void orc_centroidal_state_from_rbd(const hb_model* mdl, int n, const double* rbd, double* x) {
+  for (int i = 0; i < n; ++i) centroidal_state_from_rbd(*mdl, rbd + size_t(i) * HB_NRBD, x + size_t(i) * HB_NX);
 }
 
 }  // extern "C"

@@ -234,3 +234,26 @@ class Oracle:
                                 C.byref(mA), _opt(D), _opt(f), C.byref(mD))
         r = lambda M, k: M.reshape(-1)[: k * 38].reshape(k, 38).copy()
         return dict(A=r(A, mA.value), b=b[: mA.value].copy(), D=r(D, mD.value), f=f[: mD.value].copy())
+
+    # ---- state estimator (oracle/estimator.hpp) ---------------------------------------------------------------------
+    def kf_init(self, n):
+        """-> dict(xhat[n][18], P[n][18][18] = 100 I, yaw_last[n])."""
+        return dict(xhat=np.zeros((n, 18)), P=np.tile(100.0 * np.eye(18), (n, 1, 1)), yaw_last=np.zeros(n))
+
+    def kf_update(self, est_cfg, state, dt, quat, w_local, a_local, qj, qdj, contact):
+        """One estimator tick for n instances; `state` (from kf_init) is updated in place. -> rbd[n][32], x[n][22]."""
+        c = lambda a: np.ascontiguousarray(np.atleast_2d(a), dtype=np.float64)
+        quat, w_local, a_local, qj, qdj = c(quat), c(w_local), c(a_local), c(qj), c(qdj)
+        contact = np.ascontiguousarray(np.atleast_2d(contact), dtype=np.int32)
+        n = quat.shape[0]
+        rbd, x = np.zeros((n, 32)), np.zeros((n, 22))
+        self.lib.orc_kf_update(C.byref(self.model), C.byref(est_cfg), C.c_int(n), C.c_double(dt), _opt(state["xhat"]), _opt(state["P"]),
+                               _opt(state["yaw_last"]), _opt(quat), _opt(w_local), _opt(a_local), _opt(qj), _opt(qdj), _opt(contact),
+                               _opt(rbd), _opt(x))
+        return rbd, x
+
+    def centroidal_state_from_rbd(self, rbd):
+        rbd = np.ascontiguousarray(np.atleast_2d(rbd), dtype=np.float64)
+        x = np.zeros((rbd.shape[0], 22))
+        self.lib.orc_centroidal_state_from_rbd(C.byref(self.model), C.c_int(rbd.shape[0]), _opt(rbd), _opt(x))
+        return x

@@ -1,0 +1,161 @@
+"""Pins oracle/estimator.hpp (the restatement of KalmanFilterEstimate, legged_estimation/src/LinearKalmanFilter.cpp:72-184)
+against (i) an independent numpy implementation of the same filter equations with finite-difference foot velocities,
+(ii) rotation identities, (iii) the FK known answer of SURVEY.md §8c (standing height) and (iv) the inverse of the
+centroidal velocity map the MPC tests already pin."""
+import numpy as np
+import pytest
+
+from hunter_bipedal_control_amd import abi, refgen
+
+
+def _quat_from_zyx(zyx):
+    R = refgen.zyx_to_rotation(zyx)
+    w = 0.5 * np.sqrt(max(1e-300, 1 + np.trace(R)))
+    x = (R[2, 1] - R[1, 2]) / (4 * w)
+    y = (R[0, 2] - R[2, 0]) / (4 * w)
+    z = (R[1, 0] - R[0, 1]) / (4 * w)
+    return np.array([x, y, z, w])
+
+
+def _feet_rel(params, zyx, qj):
+    x = np.zeros(22)
+    x[9:12], x[12:] = zyx, qj
+    return refgen.foot_positions(params["model"], x)
+
+
+def _numpy_kf(params, cfg, st, dt, quat, w_local, a_local, qj, qdj, contact):
+    """Straight numpy transcription of the filter equations; foot velocities by central differences of the FK."""
+    x, y, z, w = quat
+    zyx = np.array([np.arctan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z), np.arcsin(min(-2 * (x * z - w * y), 0.99999)),
+                    np.arctan2(2 * (y * z + w * x), w * w - x * x - y * y + z * z)])
+    R = refgen.zyx_to_rotation(zyx)
+    w_glob = R @ w_local
+    pos = _feet_rel(params, zyx, qj)
+    # d(pos)/dt = d/dt [R(t) p_b(q(t))]: rotate by the world angular velocity, move the joints
+    h = 1e-6
+    def at(s):
+        dR = np.eye(3) + s * np.array([[0, -w_glob[2], w_glob[1]], [w_glob[2], 0, -w_glob[0]], [-w_glob[1], w_glob[0], 0]])
+        pb = (R.T @ _feet_rel(params, zyx, qj + s * qdj).T).T
+        return (dR @ R @ pb.T).T
+    vel = (at(h) - at(-h)) / (2 * h)
+    A = np.eye(18); A[0:3, 3:6] = dt * np.eye(3)
+    Bm = np.zeros((18, 3)); Bm[0:3] = 0.5 * dt * dt * np.eye(3); Bm[3:6] = dt * np.eye(3)
+    Cm = np.zeros((28, 18))
+    for f in range(4):
+        Cm[3 * f:3 * f + 3, 0:3] = np.eye(3)
+        Cm[3 * f:3 * f + 3, 6 + 3 * f:9 + 3 * f] = -np.eye(3)
+        Cm[12 + 3 * f:15 + 3 * f, 3:6] = np.eye(3)
+        Cm[24 + f, 8 + 3 * f] = 1.0
+    q = np.zeros(18)
+    q[0:3] = (dt / 20.0) * cfg.imu_process_noise_position
+    q[3:6] = (dt * float(np.float32(9.81)) / 20.0) * cfg.imu_process_noise_velocity
+    q[6:] = dt * cfg.foot_process_noise_position
+    r = np.concatenate([np.full(12, cfg.foot_sensor_noise_position), np.full(12, cfg.foot_sensor_noise_velocity),
+                        np.full(4, cfg.foot_height_sensor_noise)])
+    yv = np.zeros(28)
+    for f in range(4):
+        sus = 1.0 if contact[f] else 100.0
+        q[6 + 3 * f:9 + 3 * f] *= sus
+        r[3 * f:3 * f + 3] *= sus
+        r[12 + 3 * f:15 + 3 * f] *= sus
+        r[24 + f] *= sus
+        yv[3 * f:3 * f + 3] = -pos[f] + [0, 0, cfg.foot_radius]
+        yv[12 + 3 * f:15 + 3 * f] = -vel[f]
+    acc = R @ a_local + [0, 0, -9.81]
+    xh = A @ st["xhat"] + Bm @ acc
+    pm = A @ st["P"] @ A.T + np.diag(q)
+    S = Cm @ pm @ Cm.T + np.diag(r)
+    xh = xh + pm @ Cm.T @ np.linalg.solve(S, yv - Cm @ xh)
+    P = (np.eye(18) - pm @ Cm.T @ np.linalg.solve(S, Cm)) @ pm
+    P = 0.5 * (P + P.T)
+    if np.linalg.det(P[:2, :2]) > 1e-6:
+        P[:2, 2:] = 0; P[2:, :2] = 0; P[:2, :2] /= 10.0
+    st["xhat"], st["P"] = xh, P
+    return zyx, w_glob
+
+
+@pytest.fixture(scope="module")
+def est_cfg(params):
+    return abi.make_estimator_config(params)
+
+
+def test_kalman_config_is_the_task_info_block(params):
+    k = params["config"]["kalman"]
+    assert k["foot_radius"] == 0.02 and k["foot_process_noise_position"] == 0.5 and k["foot_sensor_noise_position"] == 0.5
+    assert k["foot_sensor_noise_velocity"] == 0.1 and k["foot_height_sensor_noise"] == 0.01
+
+
+def test_imu_packing_identities(params, oracle, est_cfg):
+    rng = np.random.default_rng(5)
+    n = 16
+    zyx = rng.uniform(-1, 1, (n, 3)) * [3.0, 1.2, 1.2]
+    quat = np.array([_quat_from_zyx(z) for z in zyx])
+    w_local = rng.standard_normal((n, 3))
+    qj = np.tile(params["config"]["default_joint_state"], (n, 1)) + 0.1 * rng.standard_normal((n, 10))
+    st = oracle.kf_init(n)
+    rbd, x = oracle.kf_update(est_cfg, st, 0.002, quat, w_local, np.tile([0, 0, 9.81], (n, 1)), qj, np.zeros((n, 10)), np.ones((n, 4)))
+    assert np.abs(rbd[:, 0:3] - zyx).max() < 1e-12                      # quatToZyx inverts the ZYX composition
+    for i in range(n):                                                    # omega_world = R omega_local
+        assert np.abs(rbd[i, 16:19] - refgen.zyx_to_rotation(zyx[i]) @ w_local[i]).max() < 1e-12
+    assert np.array_equal(rbd[:, 6:16], qj) and np.abs(x[:, 12:] - qj).max() == 0
+
+
+def test_filter_matches_independent_numpy_implementation(params, oracle, est_cfg):
+    rng = np.random.default_rng(11)
+    n = 6
+    st = oracle.kf_init(n)
+    st_np = [dict(xhat=np.zeros(18), P=100.0 * np.eye(18)) for _ in range(n)]
+    qj0 = np.array(params["config"]["default_joint_state"])
+    for tick in range(12):
+        zyx = 0.2 * rng.standard_normal((n, 3))
+        quat = np.array([_quat_from_zyx(z) for z in zyx])
+        w_local = 0.5 * rng.standard_normal((n, 3))
+        a_local = np.array([0, 0, 9.81]) + 0.5 * rng.standard_normal((n, 3))
+        qj = qj0 + 0.1 * rng.standard_normal((n, 10))
+        qdj = rng.standard_normal((n, 10))
+        contact = (rng.uniform(size=(n, 4)) < 0.7).astype(np.int32)
+        rbd, x = oracle.kf_update(est_cfg, st, 0.002, quat, w_local, a_local, qj, qdj, contact)
+        for i in range(n):
+            zyx_i, wg = _numpy_kf(params, est_cfg, st_np[i], 0.002, quat[i], w_local[i], a_local[i], qj[i], qdj[i], contact[i])
+            assert np.abs(st["xhat"][i] - st_np[i]["xhat"]).max() < 1e-7, tick     # FD foot velocities: 1e-9 relative
+            assert np.abs(st["P"][i] - st_np[i]["P"]).max() < 1e-9 * max(1.0, np.abs(st_np[i]["P"]).max())
+            assert np.abs(rbd[i, 3:6] - st["xhat"][i, 0:3]).max() == 0 and np.abs(rbd[i, 19:22] - st["xhat"][i, 3:6]).max() == 0
+
+
+def test_standing_height_known_answer(params, oracle, est_cfg):
+    """SURVEY.md §8c known answer: default stance puts the contact points 0.6285 (left) / 0.6287 m (right) below the
+    base; with footRadius 0.02 and zero measured foot height the filter settles at the mean + radius."""
+    st = oracle.kf_init(1)
+    qj = np.array(params["config"]["default_joint_state"])
+    for _ in range(3000):
+        rbd, x = oracle.kf_update(est_cfg, st, 0.002, [0, 0, 0, 1], np.zeros(3), [0, 0, 9.81], qj, np.zeros(10), np.ones(4))
+    assert abs(rbd[0, 5] - (0.5 * (0.6285 + 0.6287) + 0.02)) < 3e-4
+    assert np.abs(rbd[0, 19:22]).max() < 1e-6 and np.abs(x[0, 0:6]).max() < 1e-6   # at rest: zero twist, zero momentum
+    assert abs(x[0, 8] - rbd[0, 5]) == 0
+
+
+def test_centroidal_state_inverts_the_velocity_map(params, oracle):
+    """x[0:6] = A(q) v / m must invert v = pinocchio_velocity(x, u) (the map test_oracle_model.py pins)."""
+    rng = np.random.default_rng(3)
+    x0 = np.array(params["config"]["initial_state"])
+    for _ in range(8):
+        x = x0 + 0.1 * rng.standard_normal(22)
+        u = np.zeros(22); u[12:] = rng.standard_normal(10)
+        v = oracle.flow_map(x, u)[0, 6:]
+        rbd = np.zeros(32)
+        rbd[0:3], rbd[3:6], rbd[6:16] = x[9:12], x[6:9], x[12:]
+        z, yv = x[9], x[10]
+        E = np.array([[0, -np.sin(z), np.cos(yv) * np.cos(z)], [0, np.cos(z), np.cos(yv) * np.sin(z)], [1, 0, -np.sin(yv)]])
+        rbd[16:19], rbd[19:22], rbd[22:] = E @ v[3:6], v[0:3], v[6:]
+        assert np.abs(oracle.centroidal_state_from_rbd(rbd)[0] - x).max() < 1e-12
+
+
+def test_yaw_is_unwrapped_across_pi(params, oracle, est_cfg):
+    st = oracle.kf_init(1)
+    qj = np.array(params["config"]["default_joint_state"])
+    yaws = np.linspace(2.8, 3.6, 9)   # crosses +pi
+    out = []
+    for yaw in yaws:
+        rbd, x = oracle.kf_update(est_cfg, st, 0.002, _quat_from_zyx([yaw, 0, 0]), np.zeros(3), [0, 0, 9.81], qj, np.zeros(10), np.ones(4))
+        out.append(x[0, 9])
+    assert np.abs(np.array(out) - yaws).max() < 1e-12   # continuous, although quatToZyx wraps into (-pi, pi]

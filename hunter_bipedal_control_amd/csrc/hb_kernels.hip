@@ -13,6 +13,7 @@
 #include "hb_riccati.hpp"
 #include "hb_wbc.hpp"
 #include "hb_hoqp.hpp"
+#include "hb_estimator.hpp"
 
 using namespace hb;
 
@@ -247,6 +248,37 @@ __global__ __launch_bounds__(64) void k_flow_jac(const DevModel* __restrict__ M,
     for (int r = 0; r < HB_NX; ++r) dst[(size_t(i) * HB_NX + r) * HB_NX + col] = fd[r].d;
 }
 
+// ---- state estimator: one wave per instance ----------------------------------------------------------------------
+struct EstBatch {
+  int B;
+  double *xhat, *P, *yaw_last;                       // filter state [B][18], [B][18][18], [B]
+  const double *quat, *w_local, *a_local, *qj, *qdj;  // inputs [B][4|3|3|10|10]
+  const int* contact;                                 // [B][4]
+  double *rbd, *x;                                    // outputs [B][32], [B][22]
+  double *res_rbd, *res_x0;                           // resident inputs of hb_step_resident (or null)
+};
+
+__global__ __launch_bounds__(64) void k_estimator(EstBatch e, const DevModel* __restrict__ M, hb_estimator_config K, double dt) {
+  const int i = blockIdx.x;
+  __shared__ double lds[EstLds::total];
+  const DeviceCtx cx;
+  const EstIn in{e.quat + 4 * i, e.w_local + 3 * i, e.a_local + 3 * i, e.qj + 10 * i, e.qdj + 10 * i, e.contact + 4 * i};
+  estimator_update(cx, *M, K, dt, in, e.xhat + 18 * i, e.P + 324 * size_t(i), e.yaw_last + i, lds, e.rbd + HB_NRBD * i, e.x + HB_NX * i);
+  if (e.res_rbd) {
+    __syncthreads();  // lane 0 wrote the outputs
+    for (int c = cx.lane; c < HB_NRBD; c += 64) e.res_rbd[HB_NRBD * i + c] = e.rbd[HB_NRBD * i + c];
+    for (int c = cx.lane; c < HB_NX; c += 64) e.res_x0[HB_NX * i + c] = e.x[HB_NX * i + c];
+  }
+}
+__global__ void k_estimator_reset(int B, double* xhat, double* P, double* yaw_last, const double* xhat0) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * 324) return;
+  const int i = idx / 324, e = idx - 324 * i, r = e / 18, c = e - 18 * r;
+  P[idx] = r == c ? 100.0 : 0.0;  // LinearKalmanFilter.cpp:56-57
+  if (e < 18) xhat[18 * i + e] = xhat0 ? xhat0[18 * i + e] : 0.0;
+  if (e == 0) yaw_last[i] = 0.0;
+}
+
 }  // namespace
 
 // ===========================================================================================================
@@ -274,6 +306,10 @@ struct hb_ctx {
   // per-instance sweeps of one chunk overlap the per-node kernels of another)
   int n_chunks = 1;
   hipStream_t s_chunk[8]{};
+  // state estimator (allocated on the first hb_estimator_reset)
+  EstBatch est{};
+  hb_estimator_config est_cfg{};
+  bool est_ready = false;
 };
 
 static thread_local std::string g_create_error;
@@ -404,6 +440,83 @@ void hb_destroy(hb_ctx* ctx) {
   (void)hipStreamDestroy(ctx->s_wbc);
   for (auto& sc : ctx->s_chunk) (void)hipStreamDestroy(sc);
   delete ctx;
+}
+
+int32_t hb_estimator_reset(hb_ctx* ctx, const hb_estimator_config* cfg, const double* x_hat0) {
+  if (!ctx || !cfg) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  const size_t B = ctx->B;
+  EstBatch& e = ctx->est;
+  if (!e.xhat) {
+    double *quat, *wl, *al, *qj, *qdj;
+    int* contact;
+    HB_HIP(dalloc(ctx, &e.xhat, B * 18));
+    HB_HIP(dalloc(ctx, &e.P, B * 324));
+    HB_HIP(dalloc(ctx, &e.yaw_last, B));
+    HB_HIP(dalloc(ctx, &quat, B * 4));
+    HB_HIP(dalloc(ctx, &wl, B * 3));
+    HB_HIP(dalloc(ctx, &al, B * 3));
+    HB_HIP(dalloc(ctx, &qj, B * 10));
+    HB_HIP(dalloc(ctx, &qdj, B * 10));
+    HB_HIP(dalloc(ctx, &contact, B * 4));
+    HB_HIP(dalloc(ctx, &e.rbd, B * HB_NRBD));
+    HB_HIP(dalloc(ctx, &e.x, B * HB_NX));
+    e.quat = quat; e.w_local = wl; e.a_local = al; e.qj = qj; e.qdj = qdj; e.contact = contact;
+    e.B = ctx->B;
+  }
+  ctx->est_cfg = *cfg;
+  double* x0_dev = nullptr;
+  if (x_hat0) {  // staged through the (not yet used) output buffer: 22 >= 18 doubles per instance
+    x0_dev = e.x;
+    HB_HIP(hipMemcpy(x0_dev, x_hat0, B * 18 * 8, hipMemcpyHostToDevice));
+  }
+  const int n = int(B) * 324;
+  hipLaunchKernelGGL(k_estimator_reset, dim3((n + 255) / 256), dim3(256), 0, ctx->s_wbc, int(B), e.xhat, e.P, e.yaw_last, x0_dev);
+  HB_HIP(hipGetLastError());
+  HB_HIP(hipStreamSynchronize(ctx->s_wbc));
+  ctx->est_ready = true;
+  return HB_OK;
+}
+
+int32_t hb_estimator_update(hb_ctx* ctx, double dt, const double* quat, const double* ang_vel_local, const double* lin_acc_local,
+                            const double* joint_pos, const double* joint_vel, const int32_t* contact_flag, int32_t to_resident,
+                            double* rbd, double* x_state) {
+  if (!ctx || !quat || !ang_vel_local || !lin_acc_local || !joint_pos || !joint_vel || !contact_flag || !(dt > 0.0)) return HB_ERR_ARG;
+  if (!ctx->est_ready) {
+    ctx->err = "hb_estimator_update: call hb_estimator_reset first";
+    return HB_ERR_STATE;
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  const size_t B = ctx->B;
+  EstBatch e = ctx->est;
+  hipStream_t s = ctx->s_wbc;  // the estimator belongs to the control-thread side (LeggedController::update)
+  HB_HIP(hipMemcpyAsync(const_cast<double*>(e.quat), quat, B * 4 * 8, hipMemcpyHostToDevice, s));
+  HB_HIP(hipMemcpyAsync(const_cast<double*>(e.w_local), ang_vel_local, B * 3 * 8, hipMemcpyHostToDevice, s));
+  HB_HIP(hipMemcpyAsync(const_cast<double*>(e.a_local), lin_acc_local, B * 3 * 8, hipMemcpyHostToDevice, s));
+  HB_HIP(hipMemcpyAsync(const_cast<double*>(e.qj), joint_pos, B * 10 * 8, hipMemcpyHostToDevice, s));
+  HB_HIP(hipMemcpyAsync(const_cast<double*>(e.qdj), joint_vel, B * 10 * 8, hipMemcpyHostToDevice, s));
+  HB_HIP(hipMemcpyAsync(const_cast<int*>(e.contact), contact_flag, B * 4 * sizeof(int), hipMemcpyHostToDevice, s));
+  e.res_rbd = to_resident ? ctx->w.rbd : nullptr;
+  e.res_x0 = to_resident ? ctx->b.x0 : nullptr;
+  hipLaunchKernelGGL(k_estimator, dim3(ctx->B), dim3(64), 0, s, e, ctx->dmodel, ctx->est_cfg, dt);
+  HB_HIP(hipGetLastError());
+  if (rbd) HB_HIP(hipMemcpyAsync(rbd, e.rbd, B * HB_NRBD * 8, hipMemcpyDeviceToHost, s));
+  if (x_state) HB_HIP(hipMemcpyAsync(x_state, e.x, B * HB_NX * 8, hipMemcpyDeviceToHost, s));
+  HB_HIP(hipStreamSynchronize(s));
+  return HB_OK;
+}
+
+int32_t hb_estimator_get_filter(hb_ctx* ctx, double* x_hat, double* P) {
+  if (!ctx) return HB_ERR_ARG;
+  if (!ctx->est_ready) {
+    ctx->err = "hb_estimator_get_filter: call hb_estimator_reset first";
+    return HB_ERR_STATE;
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipStreamSynchronize(ctx->s_wbc));
+  if (x_hat) HB_HIP(hipMemcpy(x_hat, ctx->est.xhat, size_t(ctx->B) * 18 * 8, hipMemcpyDeviceToHost));
+  if (P) HB_HIP(hipMemcpy(P, ctx->est.P, size_t(ctx->B) * 324 * 8, hipMemcpyDeviceToHost));
+  return HB_OK;
 }
 
 int32_t hb_sync(hb_ctx* ctx) {

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "hb_wbc_update", "hb_wbc_update_direct", "hb_set_resident_inputs", "hb_step_resident", "hb_set_resident_x0_sequence",
     "hb_get_wbc_solution", "hb_set_chunks",
     "hb_sync", "hb_get_stats", "hb_get_input_cost", "hb_version", "hb_eval_flow_map", "hb_eval_foot_kinematics",
-    "hb_eval_rbd", "hb_riccati_solve",
+    "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
 ]
 
 
@@ -188,6 +188,26 @@ class HunterSolver:
         R = np.zeros((22, 22))
         self._check(self.lib.hb_get_input_cost(self.ctx, _p(R)), "hb_get_input_cost")
         return R
+
+    # ---- state estimator (KalmanFilterEstimate, legged_estimation/src/LinearKalmanFilter.cpp) ------------------------
+    def estimator_reset(self, est_cfg: "abi.HbEstimatorConfig", x_hat0=None):
+        x0 = None if x_hat0 is None else _f64(x_hat0, (self.B, 18))
+        self._est_cfg = est_cfg
+        self._check(self.lib.hb_estimator_reset(self.ctx, C.byref(est_cfg), _p(x0)), "hb_estimator_reset")
+
+    def estimator_update(self, dt, quat, ang_vel_local, lin_acc_local, joint_pos, joint_vel, contact_flag, to_resident=False):
+        """-> rbd[B][32], x_state[B][22] (what WbcBase::update and the MPC observation take)."""
+        rbd, x = np.zeros((self.B, 32)), np.zeros((self.B, 22))
+        self._check(self.lib.hb_estimator_update(
+            self.ctx, C.c_double(dt), _p(_f64(quat, (self.B, 4))), _p(_f64(ang_vel_local, (self.B, 3))),
+            _p(_f64(lin_acc_local, (self.B, 3))), _p(_f64(joint_pos, (self.B, 10))), _p(_f64(joint_vel, (self.B, 10))),
+            _p(_i32(contact_flag, (self.B, 4))), C.c_int32(1 if to_resident else 0), _p(rbd), _p(x)), "hb_estimator_update")
+        return rbd, x
+
+    def estimator_filter(self):
+        xh, P = np.zeros((self.B, 18)), np.zeros((self.B, 18, 18))
+        self._check(self.lib.hb_estimator_get_filter(self.ctx, _p(xh), _p(P)), "hb_estimator_get_filter")
+        return xh, P
 
     # ---- unit-level ---------------------------------------------------------------------------------
     def eval_flow_map(self, x, u, jac=False):

@@ -165,3 +165,17 @@ double emu_check_leg_tangents(const hb_model* m, const double* qj, const double*
   return worst;
 }
 }
+
+#include "../../hunter_bipedal_control_amd/csrc/hb_estimator.hpp"
+extern "C" {
+// one estimator tick of the device code on one emulated lane; xhat[18], P[324], yaw_last in/out
+void emu_kf_update(const hb_model* m, const hb_estimator_config* k, double dt, double* xhat, double* P, double* yaw_last,
+                   const double* quat, const double* w_local, const double* a_local, const double* qj, const double* qdj,
+                   const int* contact, double* rbd, double* x) {
+  DevModel d = make_dev_model(*m);
+  HostCtx cx;
+  std::vector<double> lds(EstLds::total, 0.0);
+  EstIn in{quat, w_local, a_local, qj, qdj, contact};
+  estimator_update(cx, d, *k, dt, in, xhat, P, yaw_last, lds.data(), rbd, x);
+}
+}

@@ -115,3 +115,30 @@ def test_device_hierarchical_wbc_matches_oracle(params, oracle, emu):
         lib.emu_hwbc(C.byref(mdl), C.byref(cfg), _p(xd), _p(u), _p(rbd), C.c_int(mode), _p(se), C.byref(ste), C.c_int(3))
         assert ste.value == st[0] == 0
         assert np.abs(se - so[0]).max() < 1e-6 * max(1.0, np.abs(so[0]).max())
+
+
+def test_device_estimator_matches_oracle(params, oracle, emu):
+    """hb_estimator.hpp (structured filter algebra, Cholesky instead of LU, forward momentum map) vs oracle/estimator.hpp."""
+    from hunter_bipedal_control_amd import abi as _abi
+    lib, mdl, cfg = emu
+    ecfg = _abi.make_estimator_config(params)
+    rng = np.random.default_rng(17)
+    st = oracle.kf_init(1)
+    xhat, P, yaw = np.zeros(18), 100.0 * np.eye(18), np.zeros(1)
+    qj0 = np.array(params["config"]["default_joint_state"])
+    for tick in range(15):
+        zyx = np.array([2.9 + 0.05 * tick, 0.1 * rng.standard_normal(), 0.1 * rng.standard_normal()])  # yaw crosses pi
+        R = refgen.zyx_to_rotation(zyx)
+        w = 0.5 * np.sqrt(1 + np.trace(R))
+        quat = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+        w_local, a_local = 0.5 * rng.standard_normal(3), np.array([0, 0, 9.81]) + 0.5 * rng.standard_normal(3)
+        qj, qdj = qj0 + 0.1 * rng.standard_normal(10), rng.standard_normal(10)
+        contact = (rng.uniform(size=4) < 0.7).astype(np.int32)
+        rbd_o, x_o = oracle.kf_update(ecfg, st, 0.002, quat, w_local, a_local, qj, qdj, contact)
+        rbd_e, x_e = np.zeros(32), np.zeros(22)
+        lib.emu_kf_update(C.byref(mdl), C.byref(ecfg), C.c_double(0.002), _p(xhat), _p(P), _p(yaw), _p(quat), _p(w_local), _p(a_local),
+                          _p(qj), _p(qdj), _p(contact), _p(rbd_e), _p(x_e))
+        assert np.abs(rbd_e - rbd_o[0]).max() < 1e-10, tick
+        assert np.abs(x_e - x_o[0]).max() < 1e-10, tick
+        assert np.abs(xhat - st["xhat"][0]).max() < 1e-10
+        assert np.abs(P - st["P"][0]).max() < 1e-9 * max(1.0, np.abs(P).max())

@@ -205,6 +205,39 @@ class Wbc {
   std::vector<int32_t> status_, stance_;
 };
 
+// ---- estimator side: legged::KalmanFilterEstimate / StateEstimateBase ---------------------------------------------
+// updateJointStates / updateContact / updateImu / update(time, period) (LeggedController.cpp:323-327) in one call per
+// tick for the whole batch; returns rbdState (what WbcBase::update takes) and fills the centroidal observation states
+// (LeggedController.cpp:331-334).
+class KalmanFilterEstimate {
+ public:
+  KalmanFilterEstimate(Context ctx, const hb_estimator_config& settings, const vector_t* xHat0 = nullptr) : ctx_(std::move(ctx)) {
+    if (xHat0 && xHat0->size() != size_t(ctx_.batch()) * 18) throw std::invalid_argument("[hunter_hip] xHat0: wrong vector size");
+    ctx_.check(hb_estimator_reset(ctx_.get(), &settings, xHat0 ? xHat0->data() : nullptr), "hb_estimator_reset");
+  }
+  // quat [batch][4] (x y z w), angularVelLocal / linearAccelLocal [batch][3], jointPos / jointVel [batch][10],
+  // contactFlag [batch][4].  toResident feeds the device-resident inputs of hb_step_resident.
+  const vector_t& update(scalar_t period, const vector_t& quat, const vector_t& angularVelLocal, const vector_t& linearAccelLocal,
+                         const vector_t& jointPos, const vector_t& jointVel, const std::vector<int32_t>& contactFlag,
+                         bool toResident = false) {
+    const size_t B = size_t(ctx_.batch());
+    if (quat.size() != B * 4 || angularVelLocal.size() != B * 3 || linearAccelLocal.size() != B * 3 || jointPos.size() != B * HB_NJ ||
+        jointVel.size() != B * HB_NJ || contactFlag.size() != B * HB_NC)
+      throw std::invalid_argument("[hunter_hip] KalmanFilterEstimate::update: wrong vector size");
+    rbdState_.resize(B * HB_NRBD);
+    observationState_.resize(B * HB_NX);
+    ctx_.check(hb_estimator_update(ctx_.get(), period, quat.data(), angularVelLocal.data(), linearAccelLocal.data(), jointPos.data(),
+                                   jointVel.data(), contactFlag.data(), toResident ? 1 : 0, rbdState_.data(), observationState_.data()),
+               "hb_estimator_update");
+    return rbdState_;
+  }
+  const vector_t& observationState() const { return observationState_; }  // currentObservation_.state per instance
+
+ private:
+  Context ctx_;
+  vector_t rbdState_, observationState_;
+};
+
 // ---- the hot part of LeggedController::update (LeggedController.cpp:151-185) --------------------------------------
 //   updatePolicy(); evaluatePolicy(t, x, optimizedState, optimizedInput, plannedMode); wbc_->update(...)
 // evaluatePolicy runs on the device and feeds the WBC without a host round trip; its outputs are returned because the

@@ -89,10 +89,10 @@ struct LqLds {
   static constexpr int Qd = ru + 22;         // 22 diagonal of Q incl. barriers/shift
   static constexpr int scal = Qd + 22;       // 16 scalars (cost, sums, ...)
   static constexpr int ints = scal + 16;     // 32 ints packed in 16 doubles: perm[10], rank, eq slots...
-  // phase-1 scratch (xs us xe fv FR LV J1 J2 = 1266 doubles) aliases everything from GtG on: none of those
+  // phase-1 scratch (xs us xe fv FR LV J1 J2 = 1278 doubles) aliases everything from GtG on: none of those
   // buffers is live before phase 2.
   static constexpr int p1 = GtG;
-  static constexpr int total = (p1 + 1268 > ints + 16) ? p1 + 1268 : ints + 16;
+  static constexpr int total = (p1 + 1280 > ints + 16) ? p1 + 1280 : ints + 16;
 };
 
 struct NodeIn {
@@ -142,8 +142,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* us = xs + 22;                // 22 values of u
   double* xe = us + 22;                // 22 state values of the current evaluation point
   double* fv = xe + 22;                // 2 x 12 flow-map values (rows 0..11) of the two points
-  double* FR = fv + 24;                // 12: (contact point - COM) of the current point
-  double* LV_all = FR + 12;            // 2 points x 2 legs x 27 leg values
+  double* FR = fv + 24;                // 2 x 12: (contact point - COM) at the two points
+  double* LV_all = FR + 24;            // 2 points x 2 legs x 27 leg values
   double* J1 = LV_all + 108;              // 44 x 12: d f(rows 0..11) / d direction at point 1
   double* J2 = J1 + 528;               // same at point 2
   for (int i = cx.lane; i < 22; i += cx.nlanes) {
@@ -167,14 +167,47 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   cx.sync();
   if (C.debug_stop == 6) return;
-  for (int pt = 0; pt < 2; ++pt) {
+  // ---- value of the flow map at the first RK2 point (one lane, plain doubles): the second point x + dt f(x, u) must be
+  // known before its directional pass can start, and a value-only evaluation costs well under half a dual pass.
+  for (int l = cx.lane; l < 1; l += cx.nlanes) {
+    const double* LV = LV_all;
+    auto S = [LV](int e) { return LV[e] + LV[27 + e]; };
+    CentroidalCore<double> core;
+    Sym3<double> IOs;
+    IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
+    centroidal_core<double>(M, Vec3<double>(S(0), S(1), S(2)), IOs, Vec3<double>(S(9), S(10), S(11)),
+                            Vec3<double>(S(12), S(13), S(14)), xs + 9, xs, core);
+    Vec3<double> msum;
+    double fsx = 0, fsy = 0, fsz = 0;
+#pragma unroll 1
+    for (int i = 0; i < HB_NC; ++i) {
+      const double* v = LV + (i & 1) * 27 + 15 + 3 * (i >> 1);
+      Vec3<double> fr, fvel;
+      centroidal_foot<double>(core, ld3(v), ld3(v + 6), fr, fvel);
+      const Vec3<double> F(us[3 * i], us[3 * i + 1], us[3 * i + 2]);
+      msum = msum + cross(fr - core.com_rel, F);
+      fsx += F.x; fsy += F.y; fsz += F.z;
+    }
+    const double inv_m = 1.0 / M.total_mass;
+    fv[0] = inv_m * fsx; fv[1] = inv_m * fsy; fv[2] = inv_m * fsz - M.gravity;
+    fv[3] = inv_m * msum.x; fv[4] = inv_m * msum.y; fv[5] = inv_m * msum.z;
+    fv[6] = core.v_lin.x; fv[7] = core.v_lin.y; fv[8] = core.v_lin.z;
+    fv[9] = core.euler_rate.x; fv[10] = core.euler_rate.y; fv[11] = core.euler_rate.z;
+    // second evaluation point of Heun's method: x + dt f(x,u), same input
+    for (int i = 0; i < 22; ++i) xe[i] = xs[i] + dt * (i < 12 ? fv[i] : us[i]);
+  }
+  cx.sync();
+  if (C.debug_stop == 7) return;
+  // ---- stage 2: whole-body combine per (point, direction).  Only 29 of the 44 directions are nonlinear (momentum 0..5,
+  // zyx 9..11, joints 12..21, joint rates 34..43), so both RK2 points fit ONE pass of the wave: task = 29 pt + index.
+  for (int task = cx.lane; task < 58; task += cx.nlanes) {
+    const int pt = task >= 29 ? 1 : 0, ti = task - 29 * pt;
+    const int dir = ti < 6 ? ti : (ti < 19 ? ti + 3 : ti + 15);
     double* Jp = pt == 0 ? J1 : J2;
     const double* LJ = LJ_all + pt * 2 * LEGJ_SIZE;
     const double* LV = LV_all + pt * 54;
-    // ---- stage 2: whole-body combine per direction
-    for (int dir = cx.lane; dir < 44; dir += cx.nlanes) {
-      const bool nonlinear = (dir < 6) || (dir >= 9 && dir < 22) || dir >= 34;
-      if (!nonlinear) continue;
+    const double* xb = pt == 0 ? xs : xe;
+    {
       // which leg tangent (if any) feeds this direction
       int tl = -1, ts = 0;
       if (dir >= 12 && dir < 22) { tl = (dir - 12) / 5; ts = (dir - 12) % 5; }
@@ -192,9 +225,9 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       {
         Dual1 zyx[3], hn[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) hn[i] = Dual1(xe[i], dir == i ? 1.0 : 0.0);
+        for (int i = 0; i < 6; ++i) hn[i] = Dual1(xb[i], dir == i ? 1.0 : 0.0);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) zyx[i] = Dual1(xe[9 + i], dir == 9 + i ? 1.0 : 0.0);
+        for (int i = 0; i < 3; ++i) zyx[i] = Dual1(xb[9 + i], dir == 9 + i ? 1.0 : 0.0);
         Sym3<Dual1> IOs;
         IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
         centroidal_core<Dual1>(M, Vec3<Dual1>(S(0), S(1), S(2)), IOs, Vec3<Dual1>(S(9), S(10), S(11)),
@@ -218,7 +251,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         const Vec3<Dual1> rr = fr - core.com_rel;
         const Vec3<Dual1> F{Dual1(us[3 * i]), Dual1(us[3 * i + 1]), Dual1(us[3 * i + 2])};
         ms = ms + cross(rr, F);
-        if (dir == 0) { FR[3 * i] = rr.x.v; FR[3 * i + 1] = rr.y.v; FR[3 * i + 2] = rr.z.v; }
+        if (dir == 0) { FR[12 * pt + 3 * i] = rr.x.v; FR[12 * pt + 3 * i + 1] = rr.y.v; FR[12 * pt + 3 * i + 2] = rr.z.v; }
         if (pt == 0) {
           // constraint rows: slot 3i+a  (base position enters only through the closed-form lanes below)
           const Dual1 pz = Dual1(xs[8]) + fr.z;
@@ -245,58 +278,56 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         }
       }
       const double inv_m = 1.0 / M.total_mass;
-      double fsx = 0, fsy = 0, fsz = 0;
-      for (int i = 0; i < HB_NC; ++i) { fsx += us[3 * i]; fsy += us[3 * i + 1]; fsz += us[3 * i + 2]; }
-      const Dual1 f[12] = {Dual1(inv_m * fsx), Dual1(inv_m * fsy), Dual1(inv_m * fsz - M.gravity), inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
+      const Dual1 f[12] = {Dual1(0.0), Dual1(0.0), Dual1(0.0), inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
                            core.v_lin.x, core.v_lin.y, core.v_lin.z, core.euler_rate.x, core.euler_rate.y, core.euler_rate.z};
 #pragma unroll
       for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = f[i].d;
-      if (dir == 0) {
+      if (dir == 0 && pt == 1) {  // values of the second point (the first point's come from the value pass above)
+        double fsx = 0, fsy = 0, fsz = 0;
+        for (int i = 0; i < HB_NC; ++i) { fsx += us[3 * i]; fsy += us[3 * i + 1]; fsz += us[3 * i + 2]; }
+        fv[12] = inv_m * fsx; fv[13] = inv_m * fsy; fv[14] = inv_m * fsz - M.gravity;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) fv[pt * 12 + i] = f[i].v;
+        for (int i = 3; i < 12; ++i) fv[12 + i] = f[i].v;
       }
     }
-    cx.sync();
-    if (C.debug_stop == 7 + 2 * pt) return;
-    // closed-form directions: base position (6..8) and contact forces (22..33)
-    for (int dir = cx.lane; dir < 44; dir += cx.nlanes) {
-      const bool is_pos = dir >= 6 && dir < 9, is_f = dir >= 22 && dir < 34;
-      if (!is_pos && !is_f) continue;
-      double col[12];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) col[i] = 0.0;
-      if (is_f) {
-        const int i = (dir - 22) / 3, a = (dir - 22) % 3;
-        const double inv_m = 1.0 / M.total_mass;
-        col[a] = inv_m;
-        // (r x e_a) / m
-        const double rx = FR[3 * i], ry = FR[3 * i + 1], rz = FR[3 * i + 2];
-        if (a == 0) { col[4] = rz * inv_m; col[5] = -ry * inv_m; }
-        if (a == 1) { col[3] = -rz * inv_m; col[5] = rx * inv_m; }
-        if (a == 2) { col[3] = ry * inv_m; col[4] = -rx * inv_m; }
-      }
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = col[i];
-      if (pt == 0) {
-        for (int i = 0; i < HB_NC; ++i) {
-          double r0 = 0, r1 = 0, r2 = 0;
-          if (is_pos) {
-            if (cf[i]) { if (dir == 8) r2 = C.zv_gain; }
-            else { if (dir == 8) r0 = C.kp_normal; if (dir == 6) r1 = C.xy_gain; if (dir == 7) r2 = C.xy_gain; }
-          }
-          CDt[dir * 12 + 3 * i + 0] = r0;
-          CDt[dir * 12 + 3 * i + 1] = r1;
-          CDt[dir * 12 + 3 * i + 2] = r2;
-        }
-      }
-    }
-    if (pt == 0) {
-      cx.sync();
-      // second evaluation point of Heun's method: x + dt f(x,u), same input
-      for (int i = cx.lane; i < 22; i += cx.nlanes) xe[i] = xs[i] + dt * (i < 12 ? fv[i] : us[i]);
-    }
-    cx.sync();
   }
+  cx.sync();
+  if (C.debug_stop == 9) return;
+  // closed-form directions of both points: base position (6..8) and contact forces (22..33); task = 15 pt + index
+  for (int task = cx.lane; task < 30; task += cx.nlanes) {
+    const int pt = task >= 15 ? 1 : 0, ti = task - 15 * pt;
+    const int dir = ti < 3 ? 6 + ti : 19 + ti;
+    double* Jp = pt == 0 ? J1 : J2;
+    const bool is_pos = dir < 9, is_f = !is_pos;
+    double col[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) col[i] = 0.0;
+    if (is_f) {
+      const int i = (dir - 22) / 3, a = (dir - 22) % 3;
+      const double inv_m = 1.0 / M.total_mass;
+      col[a] = inv_m;
+      // (r x e_a) / m
+      const double rx = FR[12 * pt + 3 * i], ry = FR[12 * pt + 3 * i + 1], rz = FR[12 * pt + 3 * i + 2];
+      if (a == 0) { col[4] = rz * inv_m; col[5] = -ry * inv_m; }
+      if (a == 1) { col[3] = -rz * inv_m; col[5] = rx * inv_m; }
+      if (a == 2) { col[3] = ry * inv_m; col[4] = -rx * inv_m; }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = col[i];
+    if (pt == 0) {
+      for (int i = 0; i < HB_NC; ++i) {
+        double r0 = 0, r1 = 0, r2 = 0;
+        if (is_pos) {
+          if (cf[i]) { if (dir == 8) r2 = C.zv_gain; }
+          else { if (dir == 8) r0 = C.kp_normal; if (dir == 6) r1 = C.xy_gain; if (dir == 7) r2 = C.xy_gain; }
+        }
+        CDt[dir * 12 + 3 * i + 0] = r0;
+        CDt[dir * 12 + 3 * i + 1] = r1;
+        CDt[dir * 12 + 3 * i + 2] = r2;
+      }
+    }
+  }
+  cx.sync();
   // ---- compose  x+ = x + dt/2 (f1 + f2(x + dt f1)) :
   //   d x+_i / d dir = [dir==i] + dt/2 (J1 + J2)[dir][i] + dt^2/2 ( sum_{c<12} J2[c][i] J1[dir][c] + sum_j J2[12+j][i] [dir==34+j] )
   // rows 0..11 of x+ : the 44 x 12 x 12 contraction runs on the matrix cores (9 MFMAs)

@@ -154,18 +154,16 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   cx.sync();
   // ---- stage 1: leg value passes of BOTH evaluation points at once.  The legs are evaluated in the base frame and the
   // joint block of the flow map is the input itself, so the joint state of the second RK2 point (q + dt qd) is known
-  // up front: four lanes = (point, leg) run the value pass (base-frame suffix composites per joint, staged in LDS over
-  // the not-yet-written ABt buffer); the direction lanes of stage 2 then evaluate the closed-form tangents of the 27
-  // leg outputs (rigid rotation of the outboard composite about the seeded joint axis).
+  // up front: the four (point, leg) value passes run together, one (evaluation, joint) pair per lane (base-frame suffix
+  // composites per joint, staged in LDS over the not-yet-written ABt buffer); the direction lanes of stage 2 then
+  // evaluate the closed-form tangents of the 27 leg outputs (rigid rotation of the outboard composite about the seeded
+  // joint axis).
   if (C.debug_stop == 10) return;
   double* LJ_all = ABt;  // 4 x LEGJ_SIZE; ABt is not written before the final compose
   static_assert(4 * LEGJ_SIZE <= 968, "leg blocks must fit the ABt buffer");
-  for (int r = cx.lane; r < 4; r += cx.nlanes) {
-    const double h = (r >> 1) ? dt : 0.0;
-    leg_value_pass(M, r & 1, [xs, us, h](int j) { return xs[12 + j] + h * us[12 + j]; }, [us](int j) { return us[12 + j]; },
-                   LJ_all + r * LEGJ_SIZE, LV_all + r * 27);
-  }
-  cx.sync();
+  leg_value_pass_coop(cx, M, 4, [](int g) { return g & 1; },
+                      [xs, us, dt](int g, int j) { return xs[12 + j] + ((g >> 1) ? dt : 0.0) * us[12 + j]; },
+                      [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all);
   if (C.debug_stop == 6) return;
   // ---- value of the flow map at the first RK2 point (one lane, plain doubles): the second point x + dt f(x, u) must be
   // known before its directional pass can start, and a value-only evaluation costs well under half a dual pass.

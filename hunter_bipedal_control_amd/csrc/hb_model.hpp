@@ -229,6 +229,126 @@ HB_HD void leg_value_pass(const DevModel& M, int leg, QF qj, QDF qdj, double* bl
   st3(val + 15, pf[0]); st3(val + 18, pf[1]); st3(val + 21, vj[0]); st3(val + 24, vj[1]);
 }
 
+// Lane-cooperative form of the value pass for `ngroups` legs at once (group g = one leg evaluation, lane = (g, joint)).
+// Same outputs and block layout as leg_value_pass.  Only the accumulation of the joint frames is a serial chain (one
+// lane per group, ~60 instructions per joint); the joint rotations, the body composites, the prefix sums of the
+// joint-rate twists and the suffix sums of masses / moments / momenta run one (group, joint) pair per lane.
+// QF/QDF: (group, joint index 0..9) -> joint angle / rate; LEG: group -> leg (0 left, 1 right).
+// Temporaries inside a joint block: E_k (local joint rotation) in slots 21..29, R_k^- (frame before the joint) in 6..14.
+template <class Ctx, class LEG, class QF, class QDF>
+HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LEG leg_of, QF qj, QDF qdj, double* blk_all, double* val_all) {
+  const int ntask = 5 * ngroups;
+  // A: local joint rotations
+  for (int r = cx.lane; r < ntask; r += cx.nlanes) {
+    const int g = r / 5, k = r - 5 * g, j = 5 * leg_of(g) + k;
+    const Mat3<double> E = axis_rot<double>(M.axis[j], qj(g, j));
+    double* B = blk_all + g * LEGJ_SIZE + k * LEGJ_STRIDE;
+    for (int e = 0; e < 9; ++e) B[21 + e] = E.m[e];
+  }
+  cx.sync();
+  // chain: frames before each joint and joint origins; contact points behind the last joint
+  for (int g = cx.lane; g < ngroups; g += cx.nlanes) {
+    const int leg = leg_of(g), j0 = 5 * leg;
+    double* blk = blk_all + g * LEGJ_SIZE;
+    Mat3<double> R = Mat3<double>::identity();
+    Vec3<double> o;
+#pragma unroll 1
+    for (int k = 0; k < 5; ++k) {
+      const int j = j0 + k;
+      double* B = blk + k * LEGJ_STRIDE;
+      o = o + R * Vec3<double>(M.origin[j][0], M.origin[j][1], M.origin[j][2]);
+      st3(B + LEGJ_O, o);
+      for (int e = 0; e < 9; ++e) B[6 + e] = R.m[e];
+      Mat3<double> E;
+      for (int e = 0; e < 9; ++e) E.m[e] = B[21 + e];
+      R = R * E;
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int ci = leg + 2 * f;
+      st3(blk + LEGJ_FEET + 3 * f, o + R * Vec3<double>(M.contact_offset[ci][0], M.contact_offset[ci][1], M.contact_offset[ci][2]));
+    }
+  }
+  cx.sync();
+  // B: per joint, axis and the body behind it (first moment, inertia about the base origin)
+  for (int r = cx.lane; r < ntask; r += cx.nlanes) {
+    const int g = r / 5, k = r - 5 * g, j = 5 * leg_of(g) + k, b = j + 1;
+    double* B = blk_all + g * LEGJ_SIZE + k * LEGJ_STRIDE;
+    Mat3<double> Rm, E;
+    for (int e = 0; e < 9; ++e) { Rm.m[e] = B[6 + e]; E.m[e] = B[21 + e]; }
+    const Vec3<double> o = ld3(B + LEGJ_O);
+    st3(B + LEGJ_A, Rm * Vec3<double>(M.axis[j][0], M.axis[j][1], M.axis[j][2]));
+    const Mat3<double> R = Rm * E;
+    const double mb = M.mass[b];
+    const Vec3<double> c = o + R * Vec3<double>(M.com[b][0], M.com[b][1], M.com[b][2]);
+    st3(B + LEGJ_MCK, mb * c);
+    st6(B + LEGJ_IOK, rotate_inertia<double>(R, M.inertia[b]) + point_inertia<double>(mb, c));
+    B[LEGJ_MS] = mb;
+  }
+  cx.sync();
+  // C + D: prefix sums of the joint-rate twist (omega, w) and suffix sums of mass / first moment / inertia; then l, L.
+  // Every lane finishes its reads of the per-body slots before any lane overwrites them with the suffix sums (a wave
+  // leaves a divergent loop together; a serial host walks the joints in increasing order, which only needs m >= k).
+  for (int r = cx.lane; r < ntask; r += cx.nlanes) {
+    const int g = r / 5, k = r - 5 * g, j0 = 5 * leg_of(g);
+    double* blk = blk_all + g * LEGJ_SIZE;
+    double* B = blk + k * LEGJ_STRIDE;
+    Vec3<double> om, w;
+    for (int m = 0; m < k; ++m) {
+      const double* Bm = blk + m * LEGJ_STRIDE;
+      const Vec3<double> am = ld3(Bm + LEGJ_A), omk = ld3(Bm + LEGJ_O);
+      const double qd = qdj(g, j0 + m);
+      om = om + qd * am;
+      w = w + qd * cross(am, omk);
+    }
+    double ms = 0.0;
+    Vec3<double> mc;
+    Sym3<double> IO;
+    for (int m = k; m < 5; ++m) {
+      const double* Bm = blk + m * LEGJ_STRIDE;
+      ms += Bm[LEGJ_MS];
+      mc = mc + ld3(Bm + LEGJ_MCK);
+      IO = IO + ld6(Bm + LEGJ_IOK);
+    }
+    const Vec3<double> a = ld3(B + LEGJ_A), o = ld3(B + LEGJ_O);
+    st3(B + LEGJ_OMP, om);
+    st3(B + LEGJ_WP, w);
+    st3(B + LEGJ_l, cross(a, mc - ms * o));
+    st3(B + LEGJ_L, IO * a - cross(mc, cross(a, o)));
+    st3(B + LEGJ_MC, mc);
+    st6(B + LEGJ_IO, IO);
+    B[LEGJ_MS] = ms;
+  }
+  cx.sync();
+  // E: suffix sums of the joint-rate momenta and of the joint-induced contact-point velocities
+  for (int r = cx.lane; r < ntask; r += cx.nlanes) {
+    const int g = r / 5, k = r - 5 * g, j0 = 5 * leg_of(g);
+    double* blk = blk_all + g * LEGJ_SIZE;
+    double* B = blk + k * LEGJ_STRIDE;
+    const Vec3<double> p0 = ld3(blk + LEGJ_FEET), p1 = ld3(blk + LEGJ_FEET + 3);
+    Vec3<double> lin, ang, v0, v1;
+    for (int m = k; m < 5; ++m) {
+      const double* Bm = blk + m * LEGJ_STRIDE;
+      const double qd = qdj(g, j0 + m);
+      const Vec3<double> am = ld3(Bm + LEGJ_A), omk = ld3(Bm + LEGJ_O);
+      lin = lin + qd * ld3(Bm + LEGJ_l);
+      ang = ang + qd * ld3(Bm + LEGJ_L);
+      v0 = v0 + qd * cross(am, p0 - omk);
+      v1 = v1 + qd * cross(am, p1 - omk);
+    }
+    st3(B + LEGJ_LIN, lin);
+    st3(B + LEGJ_ANG, ang);
+    st3(B + LEGJ_VJ, v0);
+    st3(B + LEGJ_VJ + 3, v1);
+    if (k == 0) {
+      double* val = val_all + 27 * g;
+      st3(val + 0, ld3(B + LEGJ_MC)); st6(val + 3, ld6(B + LEGJ_IO)); st3(val + 9, lin); st3(val + 12, ang);
+      st3(val + 15, p0); st3(val + 18, p1); st3(val + 21, v0); st3(val + 24, v1);
+    }
+  }
+  cx.sync();
+}
+
 // 27 tangents of the leg outputs with respect to joint angle s (rate == false) or joint rate s (rate == true).
 HB_HD void leg_tangent(const double* blk, int s, bool rate, double* t) {
   const double* B = blk + s * LEGJ_STRIDE;

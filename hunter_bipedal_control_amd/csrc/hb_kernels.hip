@@ -106,11 +106,15 @@ __global__ __launch_bounds__(64) void k_ric_bwd(Batch b, int dbg) {
     const int e = 2 * (cx.lane + 64 * r);
     dst[r] = e < REC_RICCATI_END ? (RicLds::is_vector(e) ? -1 - e : RicLds::dst(e)) : 0;
   }
-  for (int k = n - 1; k >= 0; --k) {
+  // software pipeline: the loads of stage k-1 are in flight while stage k is being processed
+  double2 buf[NL];
+  auto fetch = [&](int k) {
     const double2* rec2 = reinterpret_cast<const double2*>(b.recs + (size_t(inst) * b.Nmax + k) * REC_SIZE);
-    double2 buf[NL];
 #pragma unroll
     for (int r = 0; r < NL; ++r) { const int i = cx.lane + 64 * r; buf[r] = rec2[i < NR2 ? i : NR2 - 1]; }
+  };
+  if (n > 0) fetch(n - 1);
+  for (int k = n - 1; k >= 0; --k) {
 #pragma unroll
     for (int r = 0; r < NL; ++r) {
       const int i = cx.lane + 64 * r;
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(64) void k_ric_bwd(Batch b, int dbg) {
       }
     }
     __syncthreads();
+    if (k > 0) fetch(k - 1);
     if (dbg == 20) continue;  // profiling ablation: staging only
     riccati_bwd_node(cx, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE, dbg);
   }

@@ -139,6 +139,26 @@ def make_estimator_config(params: dict, **overrides) -> HbEstimatorConfig:
     return out
 
 
+HB_MAX_EVENTS = 64
+
+
+class RefgenConfig(C.Structure):
+    """hb_refgen_config (include/hunter_hip.h)."""
+    _fields_ = [("dt", C.c_double), ("com_height", C.c_double), ("next_position_z", C.c_double), ("swing_height", C.c_double),
+                ("swing_time_scale", C.c_double), ("feet_bias", (C.c_double * 3) * 4), ("default_joints", C.c_double * 10)]
+
+
+def make_refgen_config(params: dict) -> RefgenConfig:
+    c = params["config"]
+    sw = c["swing"]
+    out = RefgenConfig()
+    out.dt, out.com_height = c["dt"], c["com_height"]
+    out.next_position_z, out.swing_height, out.swing_time_scale = sw["next_position_z"], sw["swing_height"], sw["swing_time_scale"]
+    bias = [[sw["feet_bias_x1"], sw["feet_bias_y"], sw["feet_bias_z"]], [sw["feet_bias_x1"], -sw["feet_bias_y"], sw["feet_bias_z"]],
+            [sw["feet_bias_x2"], sw["feet_bias_y"], sw["feet_bias_z"]], [sw["feet_bias_x2"], -sw["feet_bias_y"], sw["feet_bias_z"]]]
+    _fill(out.feet_bias, bias)
+    _fill(out.default_joints, c["default_joint_state"])
+    return out
 PARAMS_BLOB_MAGIC = 0x48423031  # "HB01"
 
 

@@ -14,6 +14,7 @@
 #include "hb_wbc.hpp"
 #include "hb_hoqp.hpp"
 #include "hb_estimator.hpp"
+#include "hb_refgen.hpp"
 
 using namespace hb;
 
@@ -253,6 +254,43 @@ __global__ __launch_bounds__(64) void k_flow_jac(const DevModel* __restrict__ M,
     for (int r = 0; r < HB_NX; ++r) dst[(size_t(i) * HB_NX + r) * HB_NX + col] = fd[r].d;
 }
 
+// ---- reference generation: one thread per instance -------------------------------------------------------------
+struct RefgenBatch {
+  int B;
+  int* n_ev;        // [B]
+  double* ev;       // [B][HB_MAX_EVENTS]
+  int* modes;       // [B][HB_MAX_EVENTS + 1]
+  double* stance;   // [B][4][3]
+  double* phases;   // [B][4][HB_MAX_EVENTS + 1][RG_PHASE]
+  double* t0;       // [B]
+  double* cmd;      // [B][4]
+  int* status;      // [B]
+  int init_stance;  // take the current feet as latest stance positions (first update after a reset without state)
+};
+
+__global__ __launch_bounds__(64) void k_refgen(Batch b, RefgenBatch r, const DevModel* __restrict__ M, hb_refgen_config K, double horizon) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.B) return;
+  const double* x_now = b.x0 + size_t(i) * HB_NX;
+  double* stance = r.stance + size_t(i) * 12;
+  if (r.init_stance) {
+    const Mat3<double> R0 = rg_rot_zyx(x_now + 9);
+    const Vec3<double> p0(x_now[6], x_now[7], x_now[8]);
+    const double* qj = x_now + 12;
+    for (int leg = 0; leg < 2; ++leg) {
+      LegOut<double> L;
+      leg_eval<double>(*M, leg, [qj](int j) { return qj[j]; }, [](int) { return 0.0; }, L);
+      st3(stance + 3 * leg, p0 + R0 * L.foot[0]);
+      st3(stance + 3 * (leg + 2), p0 + R0 * L.foot[1]);
+    }
+  }
+  const size_t N = b.Nmax;
+  r.status[i] = refgen_instance(*M, K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.modes + size_t(i) * (HB_MAX_EVENTS + 1), r.t0[i], horizon,
+                                x_now, r.cmd + size_t(i) * 4, stance, r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, b.Nmax,
+                                b.n_nodes + i, b.t + size_t(i) * (N + 1), b.mode + size_t(i) * N, b.xref + size_t(i) * N * HB_NX,
+                                b.swing + size_t(i) * N * 24);
+}
+
 // ---- state estimator: one wave per instance ----------------------------------------------------------------------
 struct EstBatch {
   int B;
@@ -311,6 +349,11 @@ struct hb_ctx {
   // per-instance sweeps of one chunk overlap the per-node kernels of another)
   int n_chunks = 1;
   hipStream_t s_chunk[8]{};
+  // reference generation (allocated on the first hb_refgen_reset)
+  RefgenBatch rg{};
+  hb_refgen_config rg_cfg{};
+  bool rg_ready = false;
+  std::vector<int> rg_have_schedule;
   // state estimator (allocated on the first hb_estimator_reset)
   EstBatch est{};
   hb_estimator_config est_cfg{};
@@ -445,6 +488,105 @@ void hb_destroy(hb_ctx* ctx) {
   (void)hipStreamDestroy(ctx->s_wbc);
   for (auto& sc : ctx->s_chunk) (void)hipStreamDestroy(sc);
   delete ctx;
+}
+
+int32_t hb_refgen_reset(hb_ctx* ctx, const hb_refgen_config* cfg, const double* latest_stance) {
+  if (!ctx || !cfg || !(cfg->dt > 0.0)) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  const size_t B = ctx->B;
+  RefgenBatch& r = ctx->rg;
+  if (!r.n_ev) {
+    HB_HIP(dalloc(ctx, &r.n_ev, B));
+    HB_HIP(dalloc(ctx, &r.ev, B * HB_MAX_EVENTS));
+    HB_HIP(dalloc(ctx, &r.modes, B * (HB_MAX_EVENTS + 1)));
+    HB_HIP(dalloc(ctx, &r.stance, B * 12));
+    HB_HIP(dalloc(ctx, &r.phases, B * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE));
+    HB_HIP(dalloc(ctx, &r.t0, B));
+    HB_HIP(dalloc(ctx, &r.cmd, B * 4));
+    HB_HIP(dalloc(ctx, &r.status, B));
+    r.B = ctx->B;
+    ctx->rg_have_schedule.assign(B, 0);
+  }
+  ctx->rg_cfg = *cfg;
+  r.init_stance = latest_stance ? 0 : 1;
+  if (latest_stance) HB_HIP(hipMemcpy(r.stance, latest_stance, B * 12 * 8, hipMemcpyHostToDevice));
+  ctx->rg_ready = true;
+  return HB_OK;
+}
+
+int32_t hb_refgen_set_schedule(hb_ctx* ctx, int32_t i0, int32_t cnt, const int32_t* n_events, const double* event_times,
+                               const int32_t* modes) {
+  if (!ctx || !n_events || !event_times || !modes || i0 < 0 || cnt <= 0 || i0 + cnt > ctx->B) return HB_ERR_ARG;
+  if (!ctx->rg_ready) {
+    ctx->err = "hb_refgen_set_schedule: call hb_refgen_reset first";
+    return HB_ERR_STATE;
+  }
+  for (int i = 0; i < cnt; ++i) {
+    if (n_events[i] < 0 || n_events[i] > HB_MAX_EVENTS) {
+      ctx->err = "hb_refgen_set_schedule: n_events out of range";
+      return HB_ERR_ARG;
+    }
+    for (int e = 0; e <= n_events[i]; ++e) {
+      const int m = modes[size_t(i) * (HB_MAX_EVENTS + 1) + e];
+      if (m < 0 || m > 3) {
+        ctx->err = "hb_refgen_set_schedule: mode out of range";
+        return HB_ERR_ARG;
+      }
+    }
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  RefgenBatch& r = ctx->rg;
+  HB_HIP(hipMemcpy(r.n_ev + i0, n_events, cnt * sizeof(int), hipMemcpyHostToDevice));
+  HB_HIP(hipMemcpy(r.ev + size_t(i0) * HB_MAX_EVENTS, event_times, size_t(cnt) * HB_MAX_EVENTS * 8, hipMemcpyHostToDevice));
+  HB_HIP(hipMemcpy(r.modes + size_t(i0) * (HB_MAX_EVENTS + 1), modes, size_t(cnt) * (HB_MAX_EVENTS + 1) * sizeof(int), hipMemcpyHostToDevice));
+  for (int i = 0; i < cnt; ++i) ctx->rg_have_schedule[i0 + i] = 1;
+  return HB_OK;
+}
+
+int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const double* x_now, const double* cmd_vel, int32_t* status) {
+  if (!ctx || !t0 || !cmd_vel || !(horizon > 0.0)) return HB_ERR_ARG;
+  if (!ctx->rg_ready) {
+    ctx->err = "hb_refgen_update: call hb_refgen_reset first";
+    return HB_ERR_STATE;
+  }
+  for (int v : ctx->rg_have_schedule)
+    if (!v) {
+      ctx->err = "hb_refgen_update: an instance has no mode schedule (hb_refgen_set_schedule)";
+      return HB_ERR_STATE;
+    }
+  HB_HIP(hipSetDevice(ctx->device));
+  const size_t B = ctx->B;
+  RefgenBatch& r = ctx->rg;
+  hipStream_t s = ctx->s_mpc;  // the tables belong to the MPC side
+  HB_HIP(hipMemcpyAsync(r.t0, t0, B * 8, hipMemcpyHostToDevice, s));
+  HB_HIP(hipMemcpyAsync(r.cmd, cmd_vel, B * 4 * 8, hipMemcpyHostToDevice, s));
+  if (x_now) HB_HIP(hipMemcpyAsync(ctx->b.x0, x_now, B * HB_NX * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_refgen, dim3((ctx->B + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
+  HB_HIP(hipGetLastError());
+  r.init_stance = 0;
+  if (status) HB_HIP(hipMemcpyAsync(status, r.status, B * sizeof(int), hipMemcpyDeviceToHost, s));
+  HB_HIP(hipStreamSynchronize(s));
+  ctx->refs_set = true;
+  return HB_OK;
+}
+
+int32_t hb_mpc_get_references(hb_ctx* ctx, int32_t i0, int32_t cnt, int32_t* n_nodes, double* t, int32_t* mode, double* x_ref,
+                              double* swing_ref) {
+  if (!ctx || i0 < 0 || cnt <= 0 || i0 + cnt > ctx->B) return HB_ERR_ARG;
+  if (!ctx->refs_set) {
+    ctx->err = "hb_mpc_get_references: references not set";
+    return HB_ERR_STATE;
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  const size_t N = ctx->Nmax;
+  const Batch& b = ctx->b;
+  if (n_nodes) HB_HIP(hipMemcpy(n_nodes, b.n_nodes + i0, cnt * sizeof(int), hipMemcpyDeviceToHost));
+  if (t) HB_HIP(hipMemcpy(t, b.t + i0 * (N + 1), cnt * (N + 1) * 8, hipMemcpyDeviceToHost));
+  if (mode) HB_HIP(hipMemcpy(mode, b.mode + i0 * N, cnt * N * sizeof(int), hipMemcpyDeviceToHost));
+  if (x_ref) HB_HIP(hipMemcpy(x_ref, b.xref + i0 * N * HB_NX, cnt * N * HB_NX * 8, hipMemcpyDeviceToHost));
+  if (swing_ref) HB_HIP(hipMemcpy(swing_ref, b.swing + i0 * N * 24, cnt * N * 24 * 8, hipMemcpyDeviceToHost));
+  return HB_OK;
 }
 
 int32_t hb_estimator_reset(hb_ctx* ctx, const hb_estimator_config* cfg, const double* x_hat0) {

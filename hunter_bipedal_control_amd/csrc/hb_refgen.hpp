@@ -1,0 +1,232 @@
+// Reference generation on the device: what SwitchedModelReferenceManager::modifyReferences
+// (legged_interface/src/SwitchedModelReferenceManager.cpp:136-171) and the OCS2 time discretisation hand to the SQP
+// solver, one thread per robot instance, written straight into the node tables of the MPC kernels:
+//   * 2-knot target from the velocity command                       TargetTrajectoriesPublisher.h:101-131
+//   * shooting grid clipped to the event times                       OCS2 timeDiscretizationWithEvents
+//   * swing planner: footholds (calNextFootPos) and the x / y / z    SwingTrajectoryPlanner.cpp:164-358,
+//     multi-node cubic splines per foot and phase                    CubicSpline.cpp:46-124
+// The gait scheduler itself (tiling / insertion of mode templates, GaitSchedule.cpp:57-161) is integer / event logic on
+// a handful of numbers per instance and stays on the host: its output, the mode schedule, is an input here.
+// The per-knot joint reference IK (calculateJointRef, SwitchedModelReferenceManager.cpp:251-300) is not done here yet;
+// the joint targets are the defaultJointState (refgen.make_trot_problem(joint_ik=False) semantics).
+#pragma once
+#include "hb_lq.hpp"
+
+namespace hb {
+
+constexpr int RG_MAX_EVENTS = 64;
+constexpr int RG_PHASE = 8;  // per (foot, phase): ts, tf, p0[3], p1[3]; a stance (constant) phase is stored with ts > tf
+
+using RefgenConfig = hb_refgen_config;  // include/hunter_hip.h
+static_assert(RG_MAX_EVENTS == HB_MAX_EVENTS, "ABI constant");
+
+HB_HD bool rg_contact(int mode, int foot) {
+  const bool L = (mode == 2 || mode == 3), R = (mode == 1 || mode == 3);
+  return (foot & 1) ? R : L;
+}
+// index of the first event >= t (bisect_left)
+HB_HD int rg_bisect_left(const double* ev, int n, double t) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (ev[mid] < t) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+HB_HD Mat3<double> rg_rot_zyx(const double* zyx) {
+  double sz, cz, sy, cy, sx, cx;
+  sincos_t(zyx[0], sz, cz);
+  sincos_t(zyx[1], sy, cy);
+  sincos_t(zyx[2], sx, cx);
+  Mat3<double> R;
+  R.m[0] = cz * cy; R.m[1] = cz * sy * sx - sz * cx; R.m[2] = cz * sy * cx + sz * sx;
+  R.m[3] = sz * cy; R.m[4] = sz * sy * sx + cz * cx; R.m[5] = sz * sy * cx - cz * sx;
+  R.m[6] = -sy;     R.m[7] = cy * sx;                R.m[8] = cy * cx;
+  return R;
+}
+// Hermite cubic between (t0, p0, v0) and (t1, p1, v1): position and velocity at t (CubicSpline.cpp:46-124)
+HB_HD void rg_cubic(double t0, double p0, double v0, double t1, double p1, double v1, double t, double& pos, double& vel) {
+  const double dt = t1 - t0, dp = p1 - p0, dv = v1 - v0;
+  const double c0 = p0, c1 = v0 * dt, c2 = -(3.0 * v0 + dv) * dt + 3.0 * dp, c3 = (2.0 * v0 + dv) * dt - 2.0 * dp;
+  const double tn = (t - t0) / dt;
+  pos = c3 * tn * tn * tn + c2 * tn * tn + c1 * tn + c0;
+  vel = (3.0 * c3 * tn * tn + 2.0 * c2 * tn + c1) / dt;
+}
+// multi-node spline: nodes (tn[i], pn[i], vn[i]), i < n; segment [tn[i], tn[i+1]) containing t, first / last outside
+HB_HD void rg_multi_cubic(int n, const double* tn, const double* pn, const double* vn, double t, double& pos, double& vel) {
+  int seg = (t < tn[0]) ? 0 : n - 2;
+  for (int i = 0; i < n - 1; ++i)
+    if (tn[i] <= t && t < tn[i + 1]) { seg = i; break; }
+  rg_cubic(tn[seg], pn[seg], vn[seg], tn[seg + 1], pn[seg + 1], vn[seg + 1], t, pos, vel);
+}
+// swing reference of one phase record at time t -> [pos xyz, vel xyz]   (SwingTrajectoryPlanner::genSwingTrajs)
+HB_HD void rg_phase_eval(const RefgenConfig& K, const double* ph, double t, double* out6) {
+  const double t0 = ph[0], t1 = ph[1];
+  const double* p0 = ph + 2;
+  const double* p1 = ph + 5;
+  if (t0 > t1) {  // stance phase: two identical nodes with zero velocity
+    for (int a = 0; a < 3; ++a) { out6[a] = p1[a]; out6[3 + a] = 0.0; }
+    return;
+  }
+  const double a1 = 0.417, l1 = 0.650, k1 = 1.770;
+  for (int ax = 0; ax < 2; ++ax) {
+    const double tn[3] = {t0, (1 - a1) * t0 + a1 * t1, t1};
+    const double pn[3] = {p0[ax], (1 - l1) * p0[ax] + l1 * p1[ax], p1[ax]};
+    const double vn[3] = {0.0, k1 * (p1[ax] - p0[ax]) / (t1 - t0), 0.0};
+    rg_multi_cubic(3, tn, pn, vn, t, out6[ax], out6[3 + ax]);
+  }
+  const double scaling = fmin(1.0, (t1 - t0) / K.swing_time_scale);
+  const double max_z = fmax(p0[2], p1[2]) + scaling * K.swing_height;
+  const double za1 = 0.251, zl1 = 0.749, zk1 = 1.338, za2 = 0.630, zl2 = 0.570, zk2 = 1.633;
+  const double tn[4] = {t0, (1 - za1) * t0 + za1 * t1, (1 - za2) * t0 + za2 * t1, t1};
+  const double pn[4] = {p0[2], zl1 * max_z, zl2 * max_z + (1 - zl2) * p1[2], p1[2]};
+  const double vn[4] = {0.0, zk1 * (zl1 * (max_z - p0[2])) / (za1 * (t1 - t0)), zk2 * zl2 * (p1[2] - max_z) / ((1 - za2) * (t1 - t0)), 0.0};
+  rg_multi_cubic(4, tn, pn, vn, t, out6[2], out6[5]);
+}
+
+// Interface of one instance.  `phases` is scratch [4][RG_MAX_EVENTS + 1][RG_PHASE]; `latest_stance` [4][3] persists
+// between calls (SwingTrajectoryPlanner::latestStanceposition_).  Returns 0, or 1 if a swing phase has no take-off /
+// touch-down time inside the schedule, 2 if the grid needs more than max_nodes intervals.
+HB_HD int refgen_instance(const DevModel& M, const RefgenConfig& K, int n_ev, const double* ev, const int* modes, double t0,
+                          double horizon, const double* x_now, const double* cmd_vel, double* latest_stance, double* phases,
+                          int max_nodes, int* n_nodes_out, double* t_out, int* mode_out, double* xref_out, double* swing_out) {
+  const int n_ph = n_ev + 1;
+  // ---- 2-knot target (cmd_vel_targets) --------------------------------------------------------------------------
+  double cur[HB_NX], tgt[HB_NX];
+  {
+    const Mat3<double> Rn = rg_rot_zyx(x_now + 9);
+    const Vec3<double> vw = Rn * Vec3<double>(cmd_vel[0], cmd_vel[1], 0.0);
+    for (int i = 0; i < HB_NX; ++i) cur[i] = 0.0;
+    cur[6] = x_now[6]; cur[7] = x_now[7]; cur[8] = K.com_height;
+    cur[9] = x_now[9];
+    for (int j = 0; j < HB_NJ; ++j) cur[12 + j] = K.default_joints[j];
+    for (int i = 0; i < HB_NX; ++i) tgt[i] = cur[i];
+    tgt[6] += vw.x * horizon;
+    tgt[7] += vw.y * horizon;
+    tgt[9] += cmd_vel[3] * horizon;
+    cur[0] = vw.x; cur[1] = vw.y; cur[2] = vw.z;
+    tgt[0] = vw.x; tgt[1] = vw.y; tgt[2] = vw.z;
+  }
+  const double tf_h = t0 + horizon;
+  auto target = [&](double time, int i) {  // TargetTrajectories::getDesiredState, component i
+    if (time <= t0) return cur[i];
+    if (time >= tf_h) return tgt[i];
+    const double a = (time - t0) / (tf_h - t0);
+    return (1 - a) * cur[i] + a * tgt[i];
+  };
+  // ---- current feet (InverseKinematics::computeFootPos) ------------------------------------------------------------
+  Vec3<double> feet[HB_NC];
+  {
+    const Mat3<double> R0 = rg_rot_zyx(x_now + 9);
+    const Vec3<double> p0(x_now[6], x_now[7], x_now[8]);
+    const double* qj = x_now + 12;
+    for (int leg = 0; leg < 2; ++leg) {
+      LegOut<double> L;
+      leg_eval<double>(M, leg, [qj](int j) { return qj[j]; }, [](int) { return 0.0; }, L);
+      feet[leg] = p0 + R0 * L.foot[0];
+      feet[leg + 2] = p0 + R0 * L.foot[1];
+    }
+  }
+  // ---- swing planner update (SwingTrajectoryPlanner::update) ----------------------------------------------------------
+  const int mode_now = modes[rg_bisect_left(ev, n_ev, t0 + 0.001)];
+  int status = 0;
+  for (int j = 0; j < HB_NC; ++j) {
+    double* ls = latest_stance + 3 * j;
+    if (rg_contact(mode_now, j)) { ls[0] = feet[j].x; ls[1] = feet[j].y; }
+    ls[2] = K.next_position_z;
+    double last[3] = {ls[0], ls[1], ls[2]}, nxt[3] = {ls[0], ls[1], ls[2]};
+    int last_final = 0;
+    double* phj = phases + size_t(j) * (RG_MAX_EVENTS + 1) * RG_PHASE;
+    for (int p = 0; p < n_ph; ++p) {
+      const bool fp = rg_contact(modes[p], j);
+      // phase run [s_idx + 1 .. f_idx] of equal contact flag around p (SwingTrajectoryPlanner::findIndex)
+      int s_idx = 0, f_idx = n_ph - 2;
+      for (int ip = p - 1; ip >= 0; --ip)
+        if (rg_contact(modes[ip], j) != fp) { s_idx = ip; break; }
+      for (int ip = p + 1; ip < n_ph; ++ip)
+        if (rg_contact(modes[ip], j) != fp) { f_idx = ip - 1; break; }
+      double* ph = phj + p * RG_PHASE;
+      if (!fp) {
+        if (f_idx >= n_ph - 1 || n_ev == 0) { status = 1; f_idx = n_ev - 1 < 0 ? 0 : n_ev - 1; }
+        const double ts = ev[s_idx], tf = ev[f_idx];
+        if (t0 < tf && f_idx > last_final) {
+          for (int a = 0; a < 3; ++a) last[a] = nxt[a];
+          double t_mid = tf;
+          if (f_idx < n_ph - 1) {
+            int nf = n_ph - 2;
+            const bool fq = rg_contact(modes[f_idx + 1], j);
+            for (int ip = f_idx + 2; ip < n_ph; ++ip)
+              if (rg_contact(modes[ip], j) != fq) { nf = ip - 1; break; }
+            t_mid = 0.5 * (tf + ev[nf]);
+          }
+          // calNextFootPos
+          double bm[3] = {target(t_mid, 9), target(t_mid, 10), target(t_mid, 11)};
+          double bn[3] = {target(t0, 9), target(t0, 10), target(t0, 11)};
+          const Vec3<double> bias = rg_rot_zyx(bm) * Vec3<double>(K.feet_bias[j][0], K.feet_bias[j][1], K.feet_bias[j][2]);
+          const Mat3<double> rot = rg_rot_zyx(bn);
+          // cmd_vel callback layout [vx vy vz wz 0 0]; the planner reads tail(3) as the angular command
+          const Vec3<double> cl = rot * Vec3<double>(cmd_vel[0], cmd_vel[1], cmd_vel[2]);
+          const Vec3<double> ca = rot * Vec3<double>(cmd_vel[3], 0.0, 0.0);
+          const Vec3<double> v(cur[0], cur[1], 0.0);
+          const Vec3<double> body(target(t0, 6), target(t0, 7), target(t0, 8));
+          const Vec3<double> p_sh = (tf - t0) * (0.5 * v + 0.5 * cl) + bias;
+          const Vec3<double> p_sym = (t_mid - tf) * v + 0.03 * (v - cl);
+          const Vec3<double> p_cent = (0.5 * sqrt(body.z / 9.81)) * cross(v, ca);
+          const Vec3<double> pn = body + p_sh + p_sym + p_cent;
+          nxt[0] = pn.x; nxt[1] = pn.y; nxt[2] = K.next_position_z;
+          last_final = f_idx;
+        }
+        ph[0] = ts; ph[1] = tf;
+        for (int a = 0; a < 3; ++a) { ph[2 + a] = last[a]; ph[5 + a] = nxt[a]; }
+      } else {
+        ph[0] = 1.0; ph[1] = 0.0;  // ts > tf marks a constant phase
+        for (int a = 0; a < 3; ++a) { ph[2 + a] = nxt[a]; ph[5 + a] = nxt[a]; }
+      }
+    }
+  }
+  // ---- shooting grid with event clipping (refgen.time_discretization) ---------------------------------------------
+  const double dt = K.dt, dt_min = 1e-5;
+  int N = 0;
+  {
+    int ie = rg_bisect_left(ev, n_ev, t0 + dt_min);
+    double tl = t0;
+    t_out[0] = t0;
+    while (tl < tf_h - 1e-12) {
+      double nx = tl + dt;
+      if (ie < n_ev && nx >= ev[ie] - dt_min) { nx = ev[ie]; ++ie; }
+      if (nx >= tf_h - dt_min) nx = tf_h;
+      if (nx > tl + dt_min) {
+        if (N >= max_nodes) { status = 2; break; }
+        ++N;
+        t_out[N] = nx;
+      } else {
+        t_out[N] = nx;
+      }
+      tl = nx;
+    }
+    for (int k = N + 1; k <= max_nodes; ++k) t_out[k] = t_out[N];
+  }
+  *n_nodes_out = N;
+  // ---- node tables ---------------------------------------------------------------------------------------------------
+  const double eps = 1e-9;
+  for (int k = 0; k < max_nodes; ++k) {
+    double* xr = xref_out + size_t(k) * HB_NX;
+    double* sw = swing_out + size_t(k) * HB_NC * HB_SWING_REF;
+    if (k < N) {
+      const double tk = t_out[k];
+      mode_out[k] = modes[rg_bisect_left(ev, n_ev, tk + 1e-7 + eps)];
+      for (int i = 0; i < HB_NX; ++i) xr[i] = target(tk, i);
+      int idx = rg_bisect_left(ev, n_ev, tk + eps);
+      if (idx > n_ph - 1) idx = n_ph - 1;
+      for (int f = 0; f < HB_NC; ++f)
+        rg_phase_eval(K, phases + (size_t(f) * (RG_MAX_EVENTS + 1) + idx) * RG_PHASE, tk + eps, sw + HB_SWING_REF * f);
+    } else {
+      mode_out[k] = 3;
+      for (int i = 0; i < HB_NX; ++i) xr[i] = 0.0;
+      for (int i = 0; i < HB_NC * HB_SWING_REF; ++i) sw[i] = 0.0;
+    }
+  }
+  return status;
+}
+
+}  // namespace hb

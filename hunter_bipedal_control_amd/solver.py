@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "hb_get_wbc_solution", "hb_set_chunks",
     "hb_sync", "hb_get_stats", "hb_get_input_cost", "hb_version", "hb_eval_flow_map", "hb_eval_foot_kinematics",
     "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
+    "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references",
 ]
 
 
@@ -188,6 +189,40 @@ class HunterSolver:
         R = np.zeros((22, 22))
         self._check(self.lib.hb_get_input_cost(self.ctx, _p(R)), "hb_get_input_cost")
         return R
+
+    # ---- reference generation on the device (SwitchedModelReferenceManager::modifyReferences) -----------------------
+    def refgen_reset(self, rg_cfg: "abi.RefgenConfig", latest_stance=None):
+        ls = None if latest_stance is None else _f64(latest_stance, (self.B, 4, 3))
+        self._check(self.lib.hb_refgen_reset(self.ctx, C.byref(rg_cfg), _p(ls)), "hb_refgen_reset")
+
+    def refgen_set_schedule(self, schedules, inst_begin: int = 0):
+        """schedules: list of refgen.ModeSchedule, one per instance."""
+        cnt = len(schedules)
+        n_ev = np.array([len(s.event_times) for s in schedules], dtype=np.int32)
+        if n_ev.max(initial=0) > abi.HB_MAX_EVENTS:
+            raise ValueError("mode schedule longer than HB_MAX_EVENTS")
+        ev = np.zeros((cnt, abi.HB_MAX_EVENTS))
+        modes = np.full((cnt, abi.HB_MAX_EVENTS + 1), 3, dtype=np.int32)
+        for i, s in enumerate(schedules):
+            ev[i, :n_ev[i]] = s.event_times
+            modes[i, :n_ev[i] + 1] = s.modes
+        self._check(self.lib.hb_refgen_set_schedule(self.ctx, C.c_int32(inst_begin), C.c_int32(cnt), _p(n_ev), _p(ev), _p(modes)),
+                    "hb_refgen_set_schedule")
+
+    def refgen_update(self, t0, horizon, x_now, cmd_vel):
+        status = np.zeros(self.B, dtype=np.int32)
+        x = None if x_now is None else _f64(x_now, (self.B, 22))
+        self._check(self.lib.hb_refgen_update(self.ctx, _p(_f64(t0, (self.B,))), C.c_double(horizon), _p(x), _p(_f64(cmd_vel, (self.B, 4))),
+                                              _p(status)), "hb_refgen_update")
+        return status
+
+    def get_references(self):
+        n = np.zeros(self.B, dtype=np.int32)
+        t, mode = np.zeros((self.B, self.N + 1)), np.zeros((self.B, self.N), dtype=np.int32)
+        x_ref, swing = np.zeros((self.B, self.N, 22)), np.zeros((self.B, self.N, 4, 6))
+        self._check(self.lib.hb_mpc_get_references(self.ctx, C.c_int32(0), C.c_int32(self.B), _p(n), _p(t), _p(mode), _p(x_ref), _p(swing)),
+                    "hb_mpc_get_references")
+        return dict(n_nodes=n, t=t, mode=mode, x_ref=x_ref, swing=swing)
 
     # ---- state estimator (KalmanFilterEstimate, legged_estimation/src/LinearKalmanFilter.cpp) ------------------------
     def estimator_reset(self, est_cfg: "abi.HbEstimatorConfig", x_hat0=None):

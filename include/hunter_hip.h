@@ -215,6 +215,36 @@ int32_t hb_estimator_update(hb_ctx* ctx, double dt, const double* quat, const do
 /* Filter state to the host (either may be NULL): x_hat[batch][18], P[batch][18][18]. */
 int32_t hb_estimator_get_filter(hb_ctx* ctx, double* x_hat, double* P);
 
+/* ---- reference generation on the device ---------------------------------------------------
+ * What SwitchedModelReferenceManager::modifyReferences (SwitchedModelReferenceManager.cpp:136-171) produces before
+ * every MPC call, for the whole batch, written straight into the node tables hb_mpc_set_references would upload:
+ * 2-knot target from cmd_vel (TargetTrajectoriesPublisher.h:101-131), event-clipped shooting grid, swing planner
+ * (footholds: SwingTrajectoryPlanner::calNextFootPos; x/y/z multi-node cubic splines: genSwingTrajs,
+ * SwingTrajectoryPlanner.cpp:164-358).  The gait scheduler (GaitSchedule.cpp:57-161, a few integers and event times per
+ * instance) stays on the host: its output, the mode schedule, is an input.  Joint targets are defaultJointState
+ * (the per-knot IK of calculateJointRef is not part of this entry point yet). */
+#define HB_MAX_EVENTS 64
+typedef struct hb_refgen_config {  /* reference.info comHeight / defaultJointState, task.info swing_trajectory_config */
+  double dt, com_height, next_position_z, swing_height, swing_time_scale;
+  double feet_bias[HB_NC][3];      /* (feet_bias_x1|x2, +-feet_bias_y, feet_bias_z) in contact order */
+  double default_joints[HB_NJ];
+} hb_refgen_config;
+/* Planner state: latest_stance[batch][4][3] (SwingTrajectoryPlanner::latestStanceposition_), or NULL to take the
+ * current foot positions at the first hb_refgen_update. */
+int32_t hb_refgen_reset(hb_ctx* ctx, const hb_refgen_config* cfg, const double* latest_stance);
+/* Mode schedule of instances [inst_begin, inst_begin + inst_count): n_events[i] <= HB_MAX_EVENTS event times
+ * (strictly increasing) and n_events[i] + 1 modes; arrays strided by HB_MAX_EVENTS / HB_MAX_EVENTS + 1. */
+int32_t hb_refgen_set_schedule(hb_ctx* ctx, int32_t inst_begin, int32_t inst_count, const int32_t* n_events,
+                               const double* event_times, const int32_t* modes);
+/* Generate the references of every instance for the horizon [t0[i], t0[i] + horizon].  x_now[batch][22] is the
+ * observation (NULL: the device-resident x0, e.g. the estimator's output); cmd_vel[batch][4] = (vx, vy, vz, yaw rate).
+ * status[batch] (may be NULL): 0 ok, 1 a swing phase runs out of the schedule, 2 grid longer than max_nodes. */
+int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const double* x_now, const double* cmd_vel,
+                         int32_t* status);
+/* Node tables back to the host (any pointer may be NULL); layouts as in hb_mpc_set_references. */
+int32_t hb_mpc_get_references(hb_ctx* ctx, int32_t inst_begin, int32_t inst_count, int32_t* n_nodes, double* t,
+                              int32_t* mode, double* x_ref, double* swing_ref);
+
 /* ---- misc ------------------------------------------------------------------------------------ */
 int32_t hb_sync(hb_ctx* ctx);
 int32_t hb_get_stats(hb_ctx* ctx, hb_stats* out);

@@ -179,3 +179,16 @@ void emu_kf_update(const hb_model* m, const hb_estimator_config* k, double dt, d
   estimator_update(cx, d, *k, dt, in, xhat, P, yaw_last, lds.data(), rbd, x);
 }
 }
+
+#include "../../hunter_bipedal_control_amd/csrc/hb_refgen.hpp"
+extern "C" {
+// device reference generation of one instance on the host
+int emu_refgen(const hb_model* m, const hb::RefgenConfig* k, int n_ev, const double* ev, const int* modes, double t0, double horizon,
+               const double* x_now, const double* cmd_vel, double* latest_stance, int max_nodes, int* n_nodes, double* t, int* mode,
+               double* xref, double* swing) {
+  DevModel d = make_dev_model(*m);
+  std::vector<double> phases(size_t(4) * (RG_MAX_EVENTS + 1) * RG_PHASE, 0.0);
+  return refgen_instance(d, *k, n_ev, ev, modes, t0, horizon, x_now, cmd_vel, latest_stance, phases.data(), max_nodes, n_nodes, t, mode,
+                         xref, swing);
+}
+}

@@ -1,0 +1,103 @@
+"""-m gpu parity of the device reference generation against refgen.py, the host restatement of
+SwitchedModelReferenceManager::modifyReferences / SwingTrajectoryPlanner (joint targets = defaultJointState)."""
+import numpy as np
+import pytest
+
+from hunter_bipedal_control_amd import abi, refgen, workload
+
+pytestmark = pytest.mark.gpu
+GAITS = ["trot", "standing_trot", "flying_trot", "stance"]
+
+
+def _host_tables(params, planner, sched, t0, horizon, x_now, cv, nmax):
+    """One modifyReferences call with a persistent planner (what make_trot_problem does, minus the fresh planner)."""
+    c = params["config"]
+    targets = refgen.cmd_vel_targets(t0, x_now, cv, horizon, c["com_height"], c["default_joint_state"])
+    planner.body_vel_cmd = np.array([cv[0], cv[1], cv[2], cv[3], 0.0, 0.0])
+    planner.current_feet = list(refgen.foot_positions(params["model"], x_now))
+    planner.update(sched, targets, t0)
+    return refgen.build_node_tables(t0, horizon, c["dt"], sched, targets, planner, nmax)
+
+
+def test_device_reference_generation_matches_host_over_two_calls(params):
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B, N = 32, 60
+    c = params["config"]
+    horizon, nmax = N * c["dt"], N + 8
+    rng = np.random.default_rng(4)
+    gaits = [GAITS[i % 4] for i in range(B)]
+    cmds = np.stack([[rng.uniform(-0.35, 0.35), rng.uniform(-0.15, 0.15), 0.0, rng.uniform(-0.5, 0.5)] for _ in range(B)])
+    cmds[[3, 7]] = 0.0
+    t0 = 0.1 + rng.uniform(0, 0.6, B)
+    scheds = [refgen.gait_schedule(params, g, 0.1, 6.0) for g in gaits]
+    planners = []
+    x_a = np.stack([workload.perturbed_state(params, 300 + i) for i in range(B)])
+    x_b = x_a + 0.01 * rng.standard_normal((B, 22))            # the robot has moved a little by the second call
+    s = HunterSolver(params, batch=B, max_nodes=nmax)
+    try:
+        s.refgen_reset(abi.make_refgen_config(params))
+        s.refgen_set_schedule(scheds)
+        for call, (x_now, tt) in enumerate(((x_a, t0), (x_b, t0 + 0.23))):
+            status = s.refgen_update(tt, horizon, x_now, cmds)
+            got = s.get_references()
+            assert status.max() == 0
+            for i in range(B):
+                if call == 0:
+                    pl = refgen.SwingTrajectoryPlanner(c["swing"])
+                    pl.latest_stance = [f.copy() for f in refgen.foot_positions(params["model"], x_now[i])]
+                    planners.append(pl)
+                ref = _host_tables(params, planners[i], scheds[i], tt[i], horizon, x_now[i], cmds[i], nmax)
+                assert got["n_nodes"][i] == ref["n_nodes"], (call, i, gaits[i])
+                assert np.abs(got["t"][i] - ref["t"]).max() < 1e-12
+                assert np.array_equal(got["mode"][i], ref["mode"])
+                assert np.abs(got["x_ref"][i] - ref["x_ref"]).max() < 1e-12
+                assert np.abs(got["swing"][i] - ref["swing"]).max() < 1e-10, (call, i, gaits[i])
+    finally:
+        s.close()
+
+
+def test_mpc_on_device_generated_references_equals_uploaded_references(params):
+    """estimate/observe -> references -> MPC without the tables ever crossing PCIe."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B, N = 16, 50
+    c = params["config"]
+    horizon = N * c["dt"]
+    x0 = np.stack([workload.perturbed_state(params, i) for i in range(B)])
+    cmds = np.tile([0.3, 0.0, 0.0, 0.1], (B, 1))
+    t0 = np.full(B, 0.1)
+    scheds = [refgen.gait_schedule(params, "trot", 0.1, 6.0)] * B
+    tables = refgen.stack_tables([refgen.make_trot_problem(params, 0.1, horizon, x0[i], cmds[i], N, joint_ik=False) for i in range(B)])
+    sols = []
+    for device_refs in (True, False):
+        s = HunterSolver(params, batch=B, max_nodes=N)
+        try:
+            if device_refs:
+                s.refgen_reset(abi.make_refgen_config(params))
+                s.refgen_set_schedule(scheds)
+                assert s.refgen_update(t0, horizon, x0, cmds).max() == 0
+            else:
+                s.set_references(tables)
+            s.reset(x0)
+            s.mpc_solve(x0)
+            s.mpc_solve(x0)
+            sols.append(s.get_solution())
+        finally:
+            s.close()
+    assert np.abs(sols[0][0] - sols[1][0]).max() < 1e-9 and np.abs(sols[0][1] - sols[1][1]).max() < 1e-7
+
+
+def test_refgen_error_conventions(params):
+    from hunter_bipedal_control_amd.solver import HunterSolver, HunterHipError
+    s = HunterSolver(params, batch=2, max_nodes=10)
+    try:
+        with pytest.raises(HunterHipError):          # update before reset
+            s.refgen_update(np.zeros(2), 0.3, np.zeros((2, 22)), np.zeros((2, 4)))
+        s.refgen_reset(abi.make_refgen_config(params))
+        with pytest.raises(HunterHipError):          # no schedule yet
+            s.refgen_update(np.zeros(2), 0.3, np.zeros((2, 22)), np.zeros((2, 4)))
+        s.refgen_set_schedule([refgen.gait_schedule(params, "trot", 0.1, 6.0)] * 2)
+        x = np.stack([workload.perturbed_state(params, i) for i in range(2)])
+        st = s.refgen_update(np.full(2, 0.1), 100 * params["config"]["dt"], x, np.tile([0.3, 0, 0, 0], (2, 1)))
+        assert (st == 2).all()                        # 100 intervals do not fit max_nodes = 10
+    finally:
+        s.close()

@@ -285,10 +285,22 @@ __global__ __launch_bounds__(64) void k_refgen(Batch b, RefgenBatch r, const Dev
     }
   }
   const size_t N = b.Nmax;
-  r.status[i] = refgen_instance(*M, K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.modes + size_t(i) * (HB_MAX_EVENTS + 1), r.t0[i], horizon,
-                                x_now, r.cmd + size_t(i) * 4, stance, r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, b.Nmax,
-                                b.n_nodes + i, b.t + size_t(i) * (N + 1), b.mode + size_t(i) * N, b.xref + size_t(i) * N * HB_NX,
-                                b.swing + size_t(i) * N * 24);
+  r.status[i] = refgen_plan(*M, K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.modes + size_t(i) * (HB_MAX_EVENTS + 1), r.t0[i], horizon, x_now,
+                            r.cmd + size_t(i) * 4, stance, r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, b.Nmax, b.n_nodes + i,
+                            b.t + size_t(i) * (N + 1));
+}
+// node tables: one thread per (instance, node), consecutive lanes = consecutive nodes of one instance
+__global__ __launch_bounds__(64) void k_refgen_nodes(Batch b, RefgenBatch r, hb_refgen_config K, double horizon) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid / b.Nmax, k = gid - i * b.Nmax;
+  if (i >= b.B) return;
+  const size_t N = b.Nmax;
+  RgTarget T;
+  rg_make_target(K, r.t0[i], horizon, b.x0 + size_t(i) * HB_NX, r.cmd + size_t(i) * 4, T);
+  const size_t nd = size_t(i) * N + k;
+  refgen_node(K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.modes + size_t(i) * (HB_MAX_EVENTS + 1), T,
+              r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, k, b.n_nodes[i], b.t[size_t(i) * (N + 1) + k], b.mode + nd,
+              b.xref + nd * HB_NX, b.swing + nd * 24);
 }
 
 // ---- state estimator: one wave per instance ----------------------------------------------------------------------
@@ -562,6 +574,7 @@ int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const do
   HB_HIP(hipMemcpyAsync(r.cmd, cmd_vel, B * 4 * 8, hipMemcpyHostToDevice, s));
   if (x_now) HB_HIP(hipMemcpyAsync(ctx->b.x0, x_now, B * HB_NX * 8, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_refgen, dim3((ctx->B + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
+  hipLaunchKernelGGL(k_refgen_nodes, dim3((ctx->B * ctx->Nmax + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->rg_cfg, horizon);
   HB_HIP(hipGetLastError());
   r.init_stance = 0;
   if (status) HB_HIP(hipMemcpyAsync(status, r.status, B * sizeof(int), hipMemcpyDeviceToHost, s));

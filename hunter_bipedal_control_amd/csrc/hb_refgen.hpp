@@ -84,36 +84,44 @@ HB_HD void rg_phase_eval(const RefgenConfig& K, const double* ph, double t, doub
   rg_multi_cubic(4, tn, pn, vn, t, out6[2], out6[5]);
 }
 
-// Interface of one instance.  `phases` is scratch [4][RG_MAX_EVENTS + 1][RG_PHASE]; `latest_stance` [4][3] persists
-// between calls (SwingTrajectoryPlanner::latestStanceposition_).  Returns 0, or 1 if a swing phase has no take-off /
-// touch-down time inside the schedule, 2 if the grid needs more than max_nodes intervals.
-HB_HD int refgen_instance(const DevModel& M, const RefgenConfig& K, int n_ev, const double* ev, const int* modes, double t0,
-                          double horizon, const double* x_now, const double* cmd_vel, double* latest_stance, double* phases,
-                          int max_nodes, int* n_nodes_out, double* t_out, int* mode_out, double* xref_out, double* swing_out) {
-  const int n_ph = n_ev + 1;
-  // ---- 2-knot target (cmd_vel_targets) --------------------------------------------------------------------------
-  double cur[HB_NX], tgt[HB_NX];
-  {
-    const Mat3<double> Rn = rg_rot_zyx(x_now + 9);
-    const Vec3<double> vw = Rn * Vec3<double>(cmd_vel[0], cmd_vel[1], 0.0);
-    for (int i = 0; i < HB_NX; ++i) cur[i] = 0.0;
-    cur[6] = x_now[6]; cur[7] = x_now[7]; cur[8] = K.com_height;
-    cur[9] = x_now[9];
-    for (int j = 0; j < HB_NJ; ++j) cur[12 + j] = K.default_joints[j];
-    for (int i = 0; i < HB_NX; ++i) tgt[i] = cur[i];
-    tgt[6] += vw.x * horizon;
-    tgt[7] += vw.y * horizon;
-    tgt[9] += cmd_vel[3] * horizon;
-    cur[0] = vw.x; cur[1] = vw.y; cur[2] = vw.z;
-    tgt[0] = vw.x; tgt[1] = vw.y; tgt[2] = vw.z;
-  }
-  const double tf_h = t0 + horizon;
-  auto target = [&](double time, int i) {  // TargetTrajectories::getDesiredState, component i
+// 2-knot target of one instance (cmd_vel_targets, TargetTrajectoriesPublisher.h:101-131)
+struct RgTarget {
+  double t0, tf, cur[HB_NX], tgt[HB_NX];
+  HB_HD double at(double time, int i) const {  // TargetTrajectories::getDesiredState, component i
     if (time <= t0) return cur[i];
-    if (time >= tf_h) return tgt[i];
-    const double a = (time - t0) / (tf_h - t0);
+    if (time >= tf) return tgt[i];
+    const double a = (time - t0) / (tf - t0);
     return (1 - a) * cur[i] + a * tgt[i];
-  };
+  }
+};
+HB_HD void rg_make_target(const RefgenConfig& K, double t0, double horizon, const double* x_now, const double* cmd_vel, RgTarget& T) {
+  const Mat3<double> Rn = rg_rot_zyx(x_now + 9);
+  const Vec3<double> vw = Rn * Vec3<double>(cmd_vel[0], cmd_vel[1], 0.0);
+  T.t0 = t0;
+  T.tf = t0 + horizon;
+  for (int i = 0; i < HB_NX; ++i) T.cur[i] = 0.0;
+  T.cur[6] = x_now[6]; T.cur[7] = x_now[7]; T.cur[8] = K.com_height;
+  T.cur[9] = x_now[9];
+  for (int j = 0; j < HB_NJ; ++j) T.cur[12 + j] = K.default_joints[j];
+  for (int i = 0; i < HB_NX; ++i) T.tgt[i] = T.cur[i];
+  T.tgt[6] += vw.x * horizon;
+  T.tgt[7] += vw.y * horizon;
+  T.tgt[9] += cmd_vel[3] * horizon;
+  T.cur[0] = vw.x; T.cur[1] = vw.y; T.cur[2] = vw.z;
+  T.tgt[0] = vw.x; T.tgt[1] = vw.y; T.tgt[2] = vw.z;
+}
+
+// Planner step of one instance: swing phases of the four feet and the shooting grid.  `phases` is
+// [4][RG_MAX_EVENTS + 1][RG_PHASE]; `latest_stance` [4][3] persists between calls
+// (SwingTrajectoryPlanner::latestStanceposition_).  Returns 0, or 1 if a swing phase has no take-off / touch-down time
+// inside the schedule, 2 if the grid needs more than max_nodes intervals.
+HB_HD int refgen_plan(const DevModel& M, const RefgenConfig& K, int n_ev, const double* ev, const int* modes, double t0, double horizon,
+                      const double* x_now, const double* cmd_vel, double* latest_stance, double* phases, int max_nodes,
+                      int* n_nodes_out, double* t_out) {
+  const int n_ph = n_ev + 1;
+  RgTarget T;
+  rg_make_target(K, t0, horizon, x_now, cmd_vel, T);
+  const double tf_h = T.tf;
   // ---- current feet (InverseKinematics::computeFootPos) ------------------------------------------------------------
   Vec3<double> feet[HB_NC];
   {
@@ -160,15 +168,15 @@ HB_HD int refgen_instance(const DevModel& M, const RefgenConfig& K, int n_ev, co
             t_mid = 0.5 * (tf + ev[nf]);
           }
           // calNextFootPos
-          double bm[3] = {target(t_mid, 9), target(t_mid, 10), target(t_mid, 11)};
-          double bn[3] = {target(t0, 9), target(t0, 10), target(t0, 11)};
+          double bm[3] = {T.at(t_mid, 9), T.at(t_mid, 10), T.at(t_mid, 11)};
+          double bn[3] = {T.at(t0, 9), T.at(t0, 10), T.at(t0, 11)};
           const Vec3<double> bias = rg_rot_zyx(bm) * Vec3<double>(K.feet_bias[j][0], K.feet_bias[j][1], K.feet_bias[j][2]);
           const Mat3<double> rot = rg_rot_zyx(bn);
           // cmd_vel callback layout [vx vy vz wz 0 0]; the planner reads tail(3) as the angular command
           const Vec3<double> cl = rot * Vec3<double>(cmd_vel[0], cmd_vel[1], cmd_vel[2]);
           const Vec3<double> ca = rot * Vec3<double>(cmd_vel[3], 0.0, 0.0);
-          const Vec3<double> v(cur[0], cur[1], 0.0);
-          const Vec3<double> body(target(t0, 6), target(t0, 7), target(t0, 8));
+          const Vec3<double> v(T.cur[0], T.cur[1], 0.0);
+          const Vec3<double> body(T.at(t0, 6), T.at(t0, 7), T.at(t0, 8));
           const Vec3<double> p_sh = (tf - t0) * (0.5 * v + 0.5 * cl) + bias;
           const Vec3<double> p_sym = (t_mid - tf) * v + 0.03 * (v - cl);
           const Vec3<double> p_cent = (0.5 * sqrt(body.z / 9.81)) * cross(v, ca);
@@ -207,25 +215,37 @@ HB_HD int refgen_instance(const DevModel& M, const RefgenConfig& K, int n_ev, co
     for (int k = N + 1; k <= max_nodes; ++k) t_out[k] = t_out[N];
   }
   *n_nodes_out = N;
-  // ---- node tables ---------------------------------------------------------------------------------------------------
+  return status;
+}
+
+// Node k of the tables of one instance (independent of every other node).
+HB_HD void refgen_node(const RefgenConfig& K, int n_ev, const double* ev, const int* modes, const RgTarget& T, const double* phases,
+                       int k, int N, double tk, int* mode_k, double* xr, double* sw) {
   const double eps = 1e-9;
-  for (int k = 0; k < max_nodes; ++k) {
-    double* xr = xref_out + size_t(k) * HB_NX;
-    double* sw = swing_out + size_t(k) * HB_NC * HB_SWING_REF;
-    if (k < N) {
-      const double tk = t_out[k];
-      mode_out[k] = modes[rg_bisect_left(ev, n_ev, tk + 1e-7 + eps)];
-      for (int i = 0; i < HB_NX; ++i) xr[i] = target(tk, i);
-      int idx = rg_bisect_left(ev, n_ev, tk + eps);
-      if (idx > n_ph - 1) idx = n_ph - 1;
-      for (int f = 0; f < HB_NC; ++f)
-        rg_phase_eval(K, phases + (size_t(f) * (RG_MAX_EVENTS + 1) + idx) * RG_PHASE, tk + eps, sw + HB_SWING_REF * f);
-    } else {
-      mode_out[k] = 3;
-      for (int i = 0; i < HB_NX; ++i) xr[i] = 0.0;
-      for (int i = 0; i < HB_NC * HB_SWING_REF; ++i) sw[i] = 0.0;
-    }
+  if (k < N) {
+    *mode_k = modes[rg_bisect_left(ev, n_ev, tk + 1e-7 + eps)];
+    for (int i = 0; i < HB_NX; ++i) xr[i] = T.at(tk, i);
+    int idx = rg_bisect_left(ev, n_ev, tk + eps);
+    if (idx > n_ev) idx = n_ev;
+    for (int f = 0; f < HB_NC; ++f)
+      rg_phase_eval(K, phases + (size_t(f) * (RG_MAX_EVENTS + 1) + idx) * RG_PHASE, tk + eps, sw + HB_SWING_REF * f);
+  } else {
+    *mode_k = 3;
+    for (int i = 0; i < HB_NX; ++i) xr[i] = 0.0;
+    for (int i = 0; i < HB_NC * HB_SWING_REF; ++i) sw[i] = 0.0;
   }
+}
+
+// Both steps for one instance (host emulation).
+HB_HD int refgen_instance(const DevModel& M, const RefgenConfig& K, int n_ev, const double* ev, const int* modes, double t0,
+                          double horizon, const double* x_now, const double* cmd_vel, double* latest_stance, double* phases,
+                          int max_nodes, int* n_nodes_out, double* t_out, int* mode_out, double* xref_out, double* swing_out) {
+  const int status = refgen_plan(M, K, n_ev, ev, modes, t0, horizon, x_now, cmd_vel, latest_stance, phases, max_nodes, n_nodes_out, t_out);
+  RgTarget T;
+  rg_make_target(K, t0, horizon, x_now, cmd_vel, T);
+  for (int k = 0; k < max_nodes; ++k)
+    refgen_node(K, n_ev, ev, modes, T, phases, k, *n_nodes_out, t_out[k], mode_out + k, xref_out + size_t(k) * HB_NX,
+                swing_out + size_t(k) * HB_NC * HB_SWING_REF);
   return status;
 }
 

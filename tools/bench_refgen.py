@@ -1,0 +1,28 @@
+"""Throughput of hb_refgen_update at the bench batch size (run on the GPU box, optionally under rocprofv3)."""
+import sys
+import time
+sys.path.insert(0, '.')
+import numpy as np
+from hunter_bipedal_control_amd import abi, ingest, refgen, workload
+from hunter_bipedal_control_amd.solver import HunterSolver
+
+P = ingest.load_packaged()
+B, N = 4096, 100
+horizon = N * P["config"]["dt"]
+x0 = np.tile(np.stack([workload.perturbed_state(P, i) for i in range(16)]), (B // 16, 1))
+cmd = np.tile([0.3, 0.0, 0.0, 0.1], (B, 1))
+s = HunterSolver(P, batch=B, max_nodes=N + 8)
+s.refgen_reset(abi.make_refgen_config(P))
+s.refgen_set_schedule([refgen.gait_schedule(P, "trot", 0.1, 8.0)] * B)
+for k in range(3):
+    s.refgen_update(np.full(B, 0.1 + 0.015 * k), horizon, x0, cmd)
+t = time.perf_counter()
+for k in range(20):
+    st = s.refgen_update(np.full(B, 0.2 + 0.015 * k), horizon, x0, cmd)
+dt = (time.perf_counter() - t) / 20
+t = time.perf_counter()
+refgen.make_trot_problem(P, 0.1, horizon, x0[0], cmd[0], N, joint_ik=False)
+th = time.perf_counter() - t
+print(f"refgen: batch {B} x N {N}: {dt * 1e3:.3f} ms per call host-side = {B / dt:.0f} reference sets/s; status max {st.max()}; "
+      f"host refgen.py {th * 1e3:.1f} ms per instance")
+s.close()

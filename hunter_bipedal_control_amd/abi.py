@@ -145,10 +145,11 @@ HB_MAX_EVENTS = 64
 class RefgenConfig(C.Structure):
     """hb_refgen_config (include/hunter_hip.h)."""
     _fields_ = [("dt", C.c_double), ("com_height", C.c_double), ("next_position_z", C.c_double), ("swing_height", C.c_double),
-                ("swing_time_scale", C.c_double), ("feet_bias", (C.c_double * 3) * 4), ("default_joints", C.c_double * 10)]
+                ("swing_time_scale", C.c_double), ("feet_bias", (C.c_double * 3) * 4), ("default_joints", C.c_double * 10),
+                ("joint_ik", C.c_int32), ("reserved", C.c_int32)]
 
 
-def make_refgen_config(params: dict) -> RefgenConfig:
+def make_refgen_config(params: dict, joint_ik: bool = True) -> RefgenConfig:
     c = params["config"]
     sw = c["swing"]
     out = RefgenConfig()
@@ -158,7 +159,10 @@ def make_refgen_config(params: dict) -> RefgenConfig:
             [sw["feet_bias_x2"], sw["feet_bias_y"], sw["feet_bias_z"]], [sw["feet_bias_x2"], -sw["feet_bias_y"], sw["feet_bias_z"]]]
     _fill(out.feet_bias, bias)
     _fill(out.default_joints, c["default_joint_state"])
+    out.joint_ik = 1 if joint_ik else 0
     return out
+
+
 PARAMS_BLOB_MAGIC = 0x48423031  # "HB01"
 
 

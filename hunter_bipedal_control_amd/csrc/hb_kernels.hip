@@ -265,6 +265,9 @@ struct RefgenBatch {
   double* t0;       // [B]
   double* cmd;      // [B][4]
   int* status;      // [B]
+  int* n_knots;     // [B]
+  double* knot_t;   // [B][RG_MAX_KNOTS]
+  double* knot_x;   // [B][RG_MAX_KNOTS][22]
   int init_stance;  // take the current feet as latest stance positions (first update after a reset without state)
 };
 
@@ -287,18 +290,27 @@ __global__ __launch_bounds__(64) void k_refgen(Batch b, RefgenBatch r, const Dev
   const size_t N = b.Nmax;
   r.status[i] = refgen_plan(*M, K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.modes + size_t(i) * (HB_MAX_EVENTS + 1), r.t0[i], horizon, x_now,
                             r.cmd + size_t(i) * 4, stance, r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, b.Nmax, b.n_nodes + i,
-                            b.t + size_t(i) * (N + 1));
+                            b.t + size_t(i) * (N + 1), r.n_knots + i, r.knot_t + size_t(i) * RG_MAX_KNOTS,
+                            r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX);
+}
+// joint-reference IK: one thread per (instance, leg)
+__global__ __launch_bounds__(64) void k_refgen_ik(Batch b, RefgenBatch r, const DevModel* __restrict__ M, hb_refgen_config K, double horizon) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid >> 1, leg = gid & 1;
+  if (i >= b.B) return;
+  refgen_ik_leg(*M, K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.t0[i], horizon, b.x0 + size_t(i) * HB_NX,
+                r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, r.n_knots[i], r.knot_t + size_t(i) * RG_MAX_KNOTS,
+                r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX, leg);
 }
 // node tables: one thread per (instance, node), consecutive lanes = consecutive nodes of one instance
-__global__ __launch_bounds__(64) void k_refgen_nodes(Batch b, RefgenBatch r, hb_refgen_config K, double horizon) {
+__global__ __launch_bounds__(64) void k_refgen_nodes(Batch b, RefgenBatch r, hb_refgen_config K) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid / b.Nmax, k = gid - i * b.Nmax;
   if (i >= b.B) return;
   const size_t N = b.Nmax;
-  RgTarget T;
-  rg_make_target(K, r.t0[i], horizon, b.x0 + size_t(i) * HB_NX, r.cmd + size_t(i) * 4, T);
   const size_t nd = size_t(i) * N + k;
-  refgen_node(K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.modes + size_t(i) * (HB_MAX_EVENTS + 1), T,
+  refgen_node(K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.modes + size_t(i) * (HB_MAX_EVENTS + 1), r.n_knots[i],
+              r.knot_t + size_t(i) * RG_MAX_KNOTS, r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX,
               r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, k, b.n_nodes[i], b.t[size_t(i) * (N + 1) + k], b.mode + nd,
               b.xref + nd * HB_NX, b.swing + nd * 24);
 }
@@ -516,6 +528,9 @@ int32_t hb_refgen_reset(hb_ctx* ctx, const hb_refgen_config* cfg, const double* 
     HB_HIP(dalloc(ctx, &r.t0, B));
     HB_HIP(dalloc(ctx, &r.cmd, B * 4));
     HB_HIP(dalloc(ctx, &r.status, B));
+    HB_HIP(dalloc(ctx, &r.n_knots, B));
+    HB_HIP(dalloc(ctx, &r.knot_t, B * RG_MAX_KNOTS));
+    HB_HIP(dalloc(ctx, &r.knot_x, B * RG_MAX_KNOTS * HB_NX));
     r.B = ctx->B;
     ctx->rg_have_schedule.assign(B, 0);
   }
@@ -574,7 +589,9 @@ int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const do
   HB_HIP(hipMemcpyAsync(r.cmd, cmd_vel, B * 4 * 8, hipMemcpyHostToDevice, s));
   if (x_now) HB_HIP(hipMemcpyAsync(ctx->b.x0, x_now, B * HB_NX * 8, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_refgen, dim3((ctx->B + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
-  hipLaunchKernelGGL(k_refgen_nodes, dim3((ctx->B * ctx->Nmax + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->rg_cfg, horizon);
+  if (ctx->rg_cfg.joint_ik)
+    hipLaunchKernelGGL(k_refgen_ik, dim3((2 * ctx->B + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
+  hipLaunchKernelGGL(k_refgen_nodes, dim3((ctx->B * ctx->Nmax + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->rg_cfg);
   HB_HIP(hipGetLastError());
   r.init_stance = 0;
   if (status) HB_HIP(hipMemcpyAsync(status, r.status, B * sizeof(int), hipMemcpyDeviceToHost, s));

@@ -7,8 +7,8 @@
 //     multi-node cubic splines per foot and phase                    CubicSpline.cpp:46-124
 // The gait scheduler itself (tiling / insertion of mode templates, GaitSchedule.cpp:57-161) is integer / event logic on
 // a handful of numbers per instance and stays on the host: its output, the mode schedule, is an input here.
-// The per-knot joint reference IK (calculateJointRef, SwitchedModelReferenceManager.cpp:251-300) is not done here yet;
-// the joint targets are the defaultJointState (refgen.make_trot_problem(joint_ik=False) semantics).
+//   * per-knot joint reference by inverse kinematics (optional)    calculateJointRef, SwitchedModelReferenceManager.cpp:251-300;
+//                                                                    InverseKinematics.cpp:20-231
 #pragma once
 #include "hb_lq.hpp"
 
@@ -84,9 +84,13 @@ HB_HD void rg_phase_eval(const RefgenConfig& K, const double* ph, double t, doub
   rg_multi_cubic(4, tn, pn, vn, t, out6[2], out6[5]);
 }
 
-// 2-knot target of one instance (cmd_vel_targets, TargetTrajectoriesPublisher.h:101-131)
+// 2-knot target of one instance (cmd_vel_targets, TargetTrajectoriesPublisher.h:101-131).  The two states live in
+// caller-provided memory (the kernels keep them in the last two knot slots of the instance, in HBM): a thread-private
+// copy would be indexed dynamically and end up in scratch.
 struct RgTarget {
-  double t0, tf, cur[HB_NX], tgt[HB_NX];
+  double t0, tf;
+  const double* cur;
+  const double* tgt;
   HB_HD double at(double time, int i) const {  // TargetTrajectories::getDesiredState, component i
     if (time <= t0) return cur[i];
     if (time >= tf) return tgt[i];
@@ -94,21 +98,190 @@ struct RgTarget {
     return (1 - a) * cur[i] + a * tgt[i];
   }
 };
-HB_HD void rg_make_target(const RefgenConfig& K, double t0, double horizon, const double* x_now, const double* cmd_vel, RgTarget& T) {
+HB_HD void rg_make_target(const RefgenConfig& K, double t0, double horizon, const double* x_now, const double* cmd_vel, double* cur,
+                          double* tgt, RgTarget& T) {
   const Mat3<double> Rn = rg_rot_zyx(x_now + 9);
   const Vec3<double> vw = Rn * Vec3<double>(cmd_vel[0], cmd_vel[1], 0.0);
   T.t0 = t0;
   T.tf = t0 + horizon;
-  for (int i = 0; i < HB_NX; ++i) T.cur[i] = 0.0;
-  T.cur[6] = x_now[6]; T.cur[7] = x_now[7]; T.cur[8] = K.com_height;
-  T.cur[9] = x_now[9];
-  for (int j = 0; j < HB_NJ; ++j) T.cur[12 + j] = K.default_joints[j];
-  for (int i = 0; i < HB_NX; ++i) T.tgt[i] = T.cur[i];
-  T.tgt[6] += vw.x * horizon;
-  T.tgt[7] += vw.y * horizon;
-  T.tgt[9] += cmd_vel[3] * horizon;
-  T.cur[0] = vw.x; T.cur[1] = vw.y; T.cur[2] = vw.z;
-  T.tgt[0] = vw.x; T.tgt[1] = vw.y; T.tgt[2] = vw.z;
+  T.cur = cur;
+  T.tgt = tgt;
+  for (int i = 0; i < HB_NX; ++i) cur[i] = 0.0;
+  cur[0] = vw.x; cur[1] = vw.y; cur[2] = vw.z;
+  cur[6] = x_now[6]; cur[7] = x_now[7]; cur[8] = K.com_height;
+  cur[9] = x_now[9];
+  for (int j = 0; j < HB_NJ; ++j) cur[12 + j] = K.default_joints[j];
+  for (int i = 0; i < HB_NX; ++i) tgt[i] = cur[i];
+  tgt[6] = cur[6] + vw.x * horizon;
+  tgt[7] = cur[7] + vw.y * horizon;
+  tgt[9] = cur[9] + cmd_vel[3] * horizon;
+}
+
+// ---- joint reference by inverse kinematics (InverseKinematics.cpp:20-231 as restated in refgen.py) -----------------
+constexpr int RG_MAX_KNOTS = 24;  // targets resampled every 0.15 s: timeHorizon 3.0 s -> 21 knots; the last two slots hold the 2-knot target
+
+// Contact f1 of `leg` at q16 = [pos, zyx, joints]: position, foot rotation, linear (world-aligned) and angular (LOCAL)
+// Jacobians with respect to the leg's five joints.
+HB_HD void rg_leg_kin(const DevModel& M, const double* q16, int leg, Vec3<double>& foot, Mat3<double>& Rf, double Jl[3][5], double Ja[3][5]) {
+  Mat3<double> R = rg_rot_zyx(q16 + 3);
+  Vec3<double> p(q16[0], q16[1], q16[2]);
+  Vec3<double> ax[5], org[5];
+  for (int k = 0; k < 5; ++k) {
+    const int j = 5 * leg + k;
+    p = p + R * Vec3<double>(M.origin[j][0], M.origin[j][1], M.origin[j][2]);
+    ax[k] = R * Vec3<double>(M.axis[j][0], M.axis[j][1], M.axis[j][2]);
+    org[k] = p;
+    R = R * axis_rot<double>(M.axis[j], q16[6 + j]);
+  }
+  foot = p + R * Vec3<double>(M.contact_offset[leg][0], M.contact_offset[leg][1], M.contact_offset[leg][2]);
+  Rf = R;
+  for (int k = 0; k < 5; ++k) {
+    const Vec3<double> l = cross(ax[k], foot - org[k]), w = tmul(R, ax[k]);
+    Jl[0][k] = l.x; Jl[1][k] = l.y; Jl[2][k] = l.z;
+    Ja[0][k] = w.x; Ja[1][k] = w.y; Ja[2][k] = w.z;
+  }
+}
+// Householder QR with column pivoting of an m x n matrix (m, n <= 5), in place: R in the upper triangle, pivots in
+// perm; every reflector is also applied to the m x nb block Bm (right-hand sides, or the identity to accumulate Q').
+HB_HD void rg_qrcp(int m, int n, double a[5][5], int* perm, int nb, double Bm[5][5]) {
+  for (int j = 0; j < n; ++j) perm[j] = j;
+  const int steps = m < n ? m : n;
+  for (int j = 0; j < steps; ++j) {
+    int pv = j;
+    double best = -1.0;
+    for (int c = j; c < n; ++c) {
+      double nn = 0.0;
+      for (int r = j; r < m; ++r) nn += a[r][c] * a[r][c];
+      if (nn > best) { best = nn; pv = c; }
+    }
+    if (pv != j) {
+      for (int r = 0; r < m; ++r) { const double t = a[r][j]; a[r][j] = a[r][pv]; a[r][pv] = t; }
+      const int t = perm[j]; perm[j] = perm[pv]; perm[pv] = t;
+    }
+    const double nrm = sqrt(best);
+    if (!(nrm > 0.0)) continue;
+    const double alpha = a[j][j] > 0.0 ? -nrm : nrm;
+    double v[5];
+    double vv = 0.0;
+    for (int r = j; r < m; ++r) { v[r] = a[r][j] - (r == j ? alpha : 0.0); vv += v[r] * v[r]; }
+    if (!(vv > 0.0)) continue;
+    const double beta = 2.0 / vv;
+    for (int c = j; c < n; ++c) {
+      double d = 0.0;
+      for (int r = j; r < m; ++r) d += v[r] * a[r][c];
+      d *= beta;
+      for (int r = j; r < m; ++r) a[r][c] -= d * v[r];
+    }
+    for (int c = 0; c < nb; ++c) {
+      double d = 0.0;
+      for (int r = j; r < m; ++r) d += v[r] * Bm[r][c];
+      d *= beta;
+      for (int r = j; r < m; ++r) Bm[r][c] -= d * v[r];
+    }
+  }
+}
+// Eigen::ColPivHouseholderQR::solve with setThreshold(thr): basic solution of the numerically full-rank leading block,
+// free variables zero.  A is m x n (destroyed), b has m entries.
+HB_HD void rg_colpiv_solve(int m, int n, double a[5][5], const double* b, double thr, double* y) {
+  int perm[5];
+  double Bm[5][5];
+  for (int r = 0; r < m; ++r) Bm[r][0] = b[r];
+  rg_qrcp(m, n, a, perm, 1, Bm);
+  const int steps = m < n ? m : n;
+  int rank = 0;
+  const double d0 = fabs(a[0][0]);
+  if (d0 > 0.0)
+    for (int i = 0; i < steps; ++i)
+      if (fabs(a[i][i]) > thr * d0) ++rank;
+  for (int i = 0; i < n; ++i) y[i] = 0.0;
+  double z[5];
+  for (int i = rank - 1; i >= 0; --i) {
+    double sacc = Bm[i][0];
+    for (int k = i + 1; k < rank; ++k) sacc -= a[i][k] * z[k];
+    z[i] = sacc / a[i][i];
+  }
+  for (int i = 0; i < rank; ++i) y[perm[i]] = z[i];
+}
+HB_HD Vec3<double> rg_log3(const Mat3<double>& R) {
+  double c = 0.5 * (R.m[0] + R.m[4] + R.m[8] - 1.0);
+  c = fmin(1.0, fmax(-1.0, c));
+  const double th = acos(c);
+  const Vec3<double> w(R.m[7] - R.m[5], R.m[2] - R.m[6], R.m[3] - R.m[1]);
+  return th < 1e-10 ? 0.5 * w : (th / (2.0 * sin(th))) * w;
+}
+// InverseKinematics::computeIK: translation IK then rotation IK in the null space of the position Jacobian; both share
+// the damped iteration (step 0.7, at most 5 iterations, stop on small error 0.01, stagnation 1e-3 or error increase;
+// joint limits clamp every iterate).  q16 is updated in place for joints 5 leg .. 5 leg + 4.
+HB_HD void rg_compute_ik(const DevModel& M, double* q16, int leg, const Vec3<double>& des, const Mat3<double>& Rdes) {
+  for (int stage = 0; stage < 2; ++stage) {
+    Vec3<double> foot;
+    Mat3<double> Rf;
+    double Jl[3][5], Ja[3][5];
+    rg_leg_kin(M, q16, leg, foot, Rf, Jl, Ja);
+    auto error = [&](const Vec3<double>& f, const Mat3<double>& R) {
+      if (stage == 0) return f - des;
+      Mat3<double> Rt;  // Rdes' R
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Rt.m[3 * r + c] = Rdes.m[r] * R.m[c] + Rdes.m[3 + r] * R.m[3 + c] + Rdes.m[6 + r] * R.m[6 + c];
+      return rg_log3(Rt);
+    };
+    Vec3<double> err = error(foot, Rf);
+    double last = sqrt(dot(err, err));
+    if (last < 0.01) continue;
+    for (int it = 0; it < 5; ++it) {
+      double v[5];
+      const double eb[3] = {err.x, err.y, err.z};
+      if (stage == 0) {
+        double a[5][5];
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 5; ++c) a[r][c] = Jl[r][c];
+        double y[5];
+        rg_colpiv_solve(3, 5, a, eb, 0.01, y);
+        for (int c = 0; c < 5; ++c) v[c] = -y[c];
+      } else {
+        // orthonormal basis of null(Jl): trailing columns of Q from the pivoted QR of Jl' (5 x 3)
+        double at[5][5], Qt[5][5];
+        int perm[5];
+        for (int r = 0; r < 5; ++r) {
+          for (int c = 0; c < 3; ++c) at[r][c] = Jl[c][r];
+          for (int c = 0; c < 5; ++c) Qt[r][c] = r == c ? 1.0 : 0.0;
+        }
+        rg_qrcp(5, 3, at, perm, 5, Qt);  // Qt = Q'
+        int rank = 0;
+        const double d0 = fabs(at[0][0]);
+        if (d0 > 0.0)
+          for (int i = 0; i < 3; ++i)
+            if (fabs(at[i][i]) > 1e-12 * d0) ++rank;
+        const int nd = 5 - rank;  // null-space dimension; basis vectors are rows rank .. 4 of Q'
+        double a[5][5], y[5];
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < nd; ++c) {
+            double sacc = 0.0;
+            for (int k = 0; k < 5; ++k) sacc += Ja[r][k] * Qt[rank + c][k];
+            a[r][c] = sacc;
+          }
+        rg_colpiv_solve(3, nd, a, eb, 0.01, y);
+        for (int k = 0; k < 5; ++k) {
+          double sacc = 0.0;
+          for (int c = 0; c < nd; ++c) sacc += Qt[rank + c][k] * y[c];
+          v[k] = -sacc;
+        }
+      }
+      double qn[HB_NV];
+      for (int i = 0; i < HB_NV; ++i) qn[i] = q16[i];
+      for (int k = 0; k < 5; ++k) {
+        const int j = 5 * leg + k;
+        qn[6 + j] = fmin(M.q_upper[j], fmax(M.q_lower[j], q16[6 + j] + 0.7 * v[k]));
+      }
+      rg_leg_kin(M, qn, leg, foot, Rf, Jl, Ja);
+      err = error(foot, Rf);
+      const double nn = sqrt(dot(err, err));
+      if (nn > last || fabs(nn - last) < 1e-3) break;
+      last = nn;
+      for (int i = 0; i < HB_NV; ++i) q16[i] = qn[i];
+      if (nn < 0.01) break;
+    }
+  }
 }
 
 // Planner step of one instance: swing phases of the four feet and the shooting grid.  `phases` is
@@ -117,10 +290,10 @@ HB_HD void rg_make_target(const RefgenConfig& K, double t0, double horizon, cons
 // inside the schedule, 2 if the grid needs more than max_nodes intervals.
 HB_HD int refgen_plan(const DevModel& M, const RefgenConfig& K, int n_ev, const double* ev, const int* modes, double t0, double horizon,
                       const double* x_now, const double* cmd_vel, double* latest_stance, double* phases, int max_nodes,
-                      int* n_nodes_out, double* t_out) {
+                      int* n_nodes_out, double* t_out, int* n_knots_out, double* knot_t, double* knot_x) {
   const int n_ph = n_ev + 1;
   RgTarget T;
-  rg_make_target(K, t0, horizon, x_now, cmd_vel, T);
+  rg_make_target(K, t0, horizon, x_now, cmd_vel, knot_x + size_t(RG_MAX_KNOTS - 2) * HB_NX, knot_x + size_t(RG_MAX_KNOTS - 1) * HB_NX, T);
   const double tf_h = T.tf;
   // ---- current feet (InverseKinematics::computeFootPos) ------------------------------------------------------------
   Vec3<double> feet[HB_NC];
@@ -175,7 +348,7 @@ HB_HD int refgen_plan(const DevModel& M, const RefgenConfig& K, int n_ev, const 
           // cmd_vel callback layout [vx vy vz wz 0 0]; the planner reads tail(3) as the angular command
           const Vec3<double> cl = rot * Vec3<double>(cmd_vel[0], cmd_vel[1], cmd_vel[2]);
           const Vec3<double> ca = rot * Vec3<double>(cmd_vel[3], 0.0, 0.0);
-          const Vec3<double> v(T.cur[0], T.cur[1], 0.0);
+          const Vec3<double> v(T.cur[0], T.cur[1], 0.0);  // targets.x[0][0:3]
           const Vec3<double> body(T.at(t0, 6), T.at(t0, 7), T.at(t0, 8));
           const Vec3<double> p_sh = (tf - t0) * (0.5 * v + 0.5 * cl) + bias;
           const Vec3<double> p_sym = (t_mid - tf) * v + 0.03 * (v - cl);
@@ -215,16 +388,70 @@ HB_HD int refgen_plan(const DevModel& M, const RefgenConfig& K, int n_ev, const 
     for (int k = N + 1; k <= max_nodes; ++k) t_out[k] = t_out[N];
   }
   *n_nodes_out = N;
+  // ---- target knots: the 2-knot command target, or its 0.15 s resampling with IK joint references (calculateJointRef)
+  int nk = 2;
+  if (K.joint_ik) {
+    const int n = int(floor((tf_h - t0) / 0.15)) + 1;
+    if (n > 2) nk = n > RG_MAX_KNOTS - 2 ? RG_MAX_KNOTS - 2 : n;
+  }
+  if (nk == 2) {
+    knot_t[0] = t0; knot_t[1] = tf_h;
+    for (int i = 0; i < HB_NX; ++i) { knot_x[i] = T.cur[i]; knot_x[HB_NX + i] = T.tgt[i]; }
+  }  // else: refgen_ik_leg fills the knots, one call per leg
+  *n_knots_out = nk;
   return status;
 }
 
+// Knots of the resampled target with IK joint references for one leg (the two legs are independent kinematic chains, so
+// they run as separate threads): leg 0 also writes the knot times and the non-joint part of the knot states.
+HB_HD void refgen_ik_leg(const DevModel& M, const RefgenConfig& K, int n_ev, const double* ev, double t0, double horizon, const double* x_now,
+                         const double* phases, int nk, double* knot_t, double* knot_x, int leg) {
+  if (nk <= 2) return;
+  RgTarget T;
+  T.t0 = t0;
+  T.tf = t0 + horizon;
+  T.cur = knot_x + size_t(RG_MAX_KNOTS - 2) * HB_NX;
+  T.tgt = knot_x + size_t(RG_MAX_KNOTS - 1) * HB_NX;
+  const Mat3<double> Rdes = rg_rot_zyx(x_now + 9);
+  double qref[HB_NV];
+  for (int j = 0; j < HB_NJ; ++j) qref[6 + j] = K.default_joints[j];
+  const double step = (T.tf - t0) / (nk - 1);
+  for (int i = 0; i < nk; ++i) {
+    const double ti = i == nk - 1 ? T.tf : t0 + i * step;  // numpy.linspace
+    double* xk = knot_x + size_t(i) * HB_NX;
+    if (leg == 0) {
+      knot_t[i] = ti;
+      for (int c = 0; c < 12; ++c) xk[c] = T.at(ti, c);
+    }
+    for (int c = 0; c < 6; ++c) qref[c] = T.at(ti, 6 + c);
+    // planned position of contact f1 of this leg at the knot time (SwingTrajectoryPlanner getters)
+    int idx = rg_bisect_left(ev, n_ev, ti);
+    if (idx > n_ev) idx = n_ev;
+    double sw[6];
+    rg_phase_eval(K, phases + (size_t(leg) * (RG_MAX_EVENTS + 1) + idx) * RG_PHASE, ti, sw);
+    rg_compute_ik(M, qref, leg, Vec3<double>(sw[0], sw[1], sw[2]), Rdes);  // warm start: previous knot's solution
+    for (int k = 0; k < 5; ++k) xk[12 + 5 * leg + k] = qref[6 + 5 * leg + k];
+  }
+}
+
 // Node k of the tables of one instance (independent of every other node).
-HB_HD void refgen_node(const RefgenConfig& K, int n_ev, const double* ev, const int* modes, const RgTarget& T, const double* phases,
-                       int k, int N, double tk, int* mode_k, double* xr, double* sw) {
+HB_HD void refgen_node(const RefgenConfig& K, int n_ev, const double* ev, const int* modes, int nk, const double* knot_t,
+                       const double* knot_x, const double* phases, int k, int N, double tk, int* mode_k, double* xr, double* sw) {
   const double eps = 1e-9;
   if (k < N) {
     *mode_k = modes[rg_bisect_left(ev, n_ev, tk + 1e-7 + eps)];
-    for (int i = 0; i < HB_NX; ++i) xr[i] = T.at(tk, i);
+    // TargetTrajectories::getDesiredState(tk): linear interpolation between the knots, clamped
+    if (tk <= knot_t[0]) {
+      for (int i = 0; i < HB_NX; ++i) xr[i] = knot_x[i];
+    } else if (tk >= knot_t[nk - 1]) {
+      for (int i = 0; i < HB_NX; ++i) xr[i] = knot_x[size_t(nk - 1) * HB_NX + i];
+    } else {
+      int i0 = 0;
+      while (i0 + 1 < nk - 1 && knot_t[i0 + 1] <= tk) ++i0;  // bisect_right - 1
+      const double a = (tk - knot_t[i0]) / (knot_t[i0 + 1] - knot_t[i0]);
+      const double* x0 = knot_x + size_t(i0) * HB_NX;
+      for (int i = 0; i < HB_NX; ++i) xr[i] = (1 - a) * x0[i] + a * x0[HB_NX + i];
+    }
     int idx = rg_bisect_left(ev, n_ev, tk + eps);
     if (idx > n_ev) idx = n_ev;
     for (int f = 0; f < HB_NC; ++f)
@@ -240,11 +467,13 @@ HB_HD void refgen_node(const RefgenConfig& K, int n_ev, const double* ev, const 
 HB_HD int refgen_instance(const DevModel& M, const RefgenConfig& K, int n_ev, const double* ev, const int* modes, double t0,
                           double horizon, const double* x_now, const double* cmd_vel, double* latest_stance, double* phases,
                           int max_nodes, int* n_nodes_out, double* t_out, int* mode_out, double* xref_out, double* swing_out) {
-  const int status = refgen_plan(M, K, n_ev, ev, modes, t0, horizon, x_now, cmd_vel, latest_stance, phases, max_nodes, n_nodes_out, t_out);
-  RgTarget T;
-  rg_make_target(K, t0, horizon, x_now, cmd_vel, T);
+  int nk = 0;
+  double knot_t[RG_MAX_KNOTS], knot_x[RG_MAX_KNOTS * HB_NX];
+  const int status = refgen_plan(M, K, n_ev, ev, modes, t0, horizon, x_now, cmd_vel, latest_stance, phases, max_nodes, n_nodes_out, t_out,
+                                 &nk, knot_t, knot_x);
+  for (int leg = 0; leg < 2; ++leg) refgen_ik_leg(M, K, n_ev, ev, t0, horizon, x_now, phases, nk, knot_t, knot_x, leg);
   for (int k = 0; k < max_nodes; ++k)
-    refgen_node(K, n_ev, ev, modes, T, phases, k, *n_nodes_out, t_out[k], mode_out + k, xref_out + size_t(k) * HB_NX,
+    refgen_node(K, n_ev, ev, modes, nk, knot_t, knot_x, phases, k, *n_nodes_out, t_out[k], mode_out + k, xref_out + size_t(k) * HB_NX,
                 swing_out + size_t(k) * HB_NC * HB_SWING_REF);
   return status;
 }

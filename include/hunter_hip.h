@@ -221,13 +221,17 @@ int32_t hb_estimator_get_filter(hb_ctx* ctx, double* x_hat, double* P);
  * 2-knot target from cmd_vel (TargetTrajectoriesPublisher.h:101-131), event-clipped shooting grid, swing planner
  * (footholds: SwingTrajectoryPlanner::calNextFootPos; x/y/z multi-node cubic splines: genSwingTrajs,
  * SwingTrajectoryPlanner.cpp:164-358).  The gait scheduler (GaitSchedule.cpp:57-161, a few integers and event times per
- * instance) stays on the host: its output, the mode schedule, is an input.  Joint targets are defaultJointState
- * (the per-knot IK of calculateJointRef is not part of this entry point yet). */
+ * instance) stays on the host: its output, the mode schedule, is an input.  With joint_ik the targets are resampled
+ * every 0.15 s and their joint part replaced by the inverse kinematics of the planned foot positions
+ * (calculateJointRef), warm-started knot to knot. */
 #define HB_MAX_EVENTS 64
 typedef struct hb_refgen_config {  /* reference.info comHeight / defaultJointState, task.info swing_trajectory_config */
   double dt, com_height, next_position_z, swing_height, swing_time_scale;
   double feet_bias[HB_NC][3];      /* (feet_bias_x1|x2, +-feet_bias_y, feet_bias_z) in contact order */
   double default_joints[HB_NJ];
+  int32_t joint_ik;                /* 1: per-knot joint reference by inverse kinematics (calculateJointRef,
+                                      SwitchedModelReferenceManager.cpp:251-300; InverseKinematics.cpp:20-231), 0: defaultJointState */
+  int32_t reserved;
 } hb_refgen_config;
 /* Planner state: latest_stance[batch][4][3] (SwingTrajectoryPlanner::latestStanceposition_), or NULL to take the
  * current foot positions at the first hb_refgen_update. */

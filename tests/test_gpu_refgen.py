@@ -35,7 +35,7 @@ def test_device_reference_generation_matches_host_over_two_calls(params):
     x_b = x_a + 0.01 * rng.standard_normal((B, 22))            # the robot has moved a little by the second call
     s = HunterSolver(params, batch=B, max_nodes=nmax)
     try:
-        s.refgen_reset(abi.make_refgen_config(params))
+        s.refgen_reset(abi.make_refgen_config(params, joint_ik=False))
         s.refgen_set_schedule(scheds)
         for call, (x_now, tt) in enumerate(((x_a, t0), (x_b, t0 + 0.23))):
             status = s.refgen_update(tt, horizon, x_now, cmds)
@@ -66,15 +66,19 @@ def test_mpc_on_device_generated_references_equals_uploaded_references(params):
     cmds = np.tile([0.3, 0.0, 0.0, 0.1], (B, 1))
     t0 = np.full(B, 0.1)
     scheds = [refgen.gait_schedule(params, "trot", 0.1, 6.0)] * B
-    tables = refgen.stack_tables([refgen.make_trot_problem(params, 0.1, horizon, x0[i], cmds[i], N, joint_ik=False) for i in range(B)])
+    # host side with the per-knot IK joint references (calculateJointRef), as the workloads of bench.py use them
+    tables = refgen.stack_tables([refgen.make_trot_problem(params, 0.1, horizon, x0[i], cmds[i], N, joint_ik=True) for i in range(B)])
     sols = []
     for device_refs in (True, False):
         s = HunterSolver(params, batch=B, max_nodes=N)
         try:
             if device_refs:
-                s.refgen_reset(abi.make_refgen_config(params))
+                s.refgen_reset(abi.make_refgen_config(params, joint_ik=True))
                 s.refgen_set_schedule(scheds)
                 assert s.refgen_update(t0, horizon, x0, cmds).max() == 0
+                got = s.get_references()
+                assert np.abs(got["x_ref"] - tables["x_ref"]).max() < 1e-9 and np.abs(got["swing"] - tables["swing"]).max() < 1e-10
+                assert np.abs(got["x_ref"][:, :, 12:] - np.array(params["config"]["default_joint_state"])).max() > 0.01  # IK moved them
             else:
                 s.set_references(tables)
             s.reset(x0)

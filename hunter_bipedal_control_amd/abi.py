@@ -139,6 +139,21 @@ def make_estimator_config(params: dict, **overrides) -> HbEstimatorConfig:
     return out
 
 
+class HbJointGains(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("kp_big_stance", "kp_big_swing", "kd_big", "kp_small_stance", "kp_small_swing", "kd_small",
+                                          "kd_feet")]
+
+
+def make_joint_gains(**overrides) -> HbJointGains:
+    """Defaults of legged_controllers/cfg/Tutorials.cfg:6-16 (dynamic_reconfigure)."""
+    d = dict(kp_big_stance=40.0, kp_big_swing=30.0, kd_big=2.0, kp_small_stance=30.0, kp_small_swing=20.0, kd_small=2.0, kd_feet=0.01)
+    d.update(overrides)
+    out = HbJointGains()
+    for k, v in d.items():
+        setattr(out, k, v)
+    return out
+
+
 HB_MAX_EVENTS = 64
 
 

@@ -254,6 +254,32 @@ __global__ __launch_bounds__(64) void k_flow_jac(const DevModel* __restrict__ M,
     for (int r = 0; r < HB_NX; ++r) dst[(size_t(i) * HB_NX + r) * HB_NX + col] = fd[r].d;
 }
 
+// ---- joint command law: one thread per (instance, joint) ---------------------------------------------------------
+__global__ void k_joint_command(WbcBatch w, hb_joint_gains g, double dt, double* out /*[6][B][10]: posDes velDes kp kd ff torque*/) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= w.B * HB_NJ) return;
+  const int i = gid / HB_NJ, j = gid - HB_NJ * i;
+  const double qdd = w.sol[size_t(i) * HB_NWBC + 6 + j], ff = w.sol[size_t(i) * HB_NWBC + 28 + j];
+  const double pos = w.xdes[size_t(i) * HB_NX + 12 + j] + 0.5 * qdd * dt * dt;
+  const double vel = w.udes[size_t(i) * HB_NU + 12 + j] + qdd * dt;
+  bool cf[HB_NC];
+  mode_flags(w.mode[i], cf);
+  const bool contact = j < 5 ? cf[0] : cf[1];  // cmdContactFlag[int(j / 5)]
+  const int k = j < 5 ? j : j - 5;
+  double kp, kd;
+  if (k == 0 || k == 1) { kp = contact ? g.kp_small_stance : g.kp_small_swing; kd = g.kd_small; }
+  else if (k == 4) { kp = contact ? g.kp_small_stance : g.kp_small_swing; kd = g.kd_feet; }
+  else { kp = contact ? g.kp_big_stance : g.kp_big_swing; kd = g.kd_big; }
+  const double q = w.rbd[size_t(i) * HB_NRBD + 6 + j], qd = w.rbd[size_t(i) * HB_NRBD + 6 + HB_NV + j];
+  const size_t n = size_t(w.B) * HB_NJ;
+  out[gid] = pos;
+  out[n + gid] = vel;
+  out[2 * n + gid] = kp;
+  out[3 * n + gid] = kd;
+  out[4 * n + gid] = ff;
+  out[5 * n + gid] = ff + kp * (pos - q) + kd * (vel - qd);
+}
+
 // ---- reference generation: one thread per instance -------------------------------------------------------------
 struct RefgenBatch {
   int B;
@@ -373,6 +399,7 @@ struct hb_ctx {
   // per-instance sweeps of one chunk overlap the per-node kernels of another)
   int n_chunks = 1;
   hipStream_t s_chunk[8]{};
+  double* jc_out = nullptr;  // joint command outputs [6][B][10]
   // reference generation (allocated on the first hb_refgen_reset)
   RefgenBatch rg{};
   hb_refgen_config rg_cfg{};
@@ -512,6 +539,26 @@ void hb_destroy(hb_ctx* ctx) {
   (void)hipStreamDestroy(ctx->s_wbc);
   for (auto& sc : ctx->s_chunk) (void)hipStreamDestroy(sc);
   delete ctx;
+}
+
+int32_t hb_joint_command(hb_ctx* ctx, const hb_joint_gains* gains, double dt, double* pos_des, double* vel_des, double* kp, double* kd,
+                         double* tau_ff, double* torque) {
+  if (!ctx || !gains) return HB_ERR_ARG;
+  if (ctx->stats.n_wbc_solves == 0) {
+    ctx->err = "hb_joint_command: no WBC solution yet";
+    return HB_ERR_STATE;
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  const size_t n = size_t(ctx->B) * HB_NJ;
+  if (!ctx->jc_out) HB_HIP(dalloc(ctx, &ctx->jc_out, 6 * n));
+  hipStream_t s = ctx->s_wbc;
+  hipLaunchKernelGGL(k_joint_command, dim3((unsigned(n) + 255) / 256), dim3(256), 0, s, ctx->w, *gains, dt, ctx->jc_out);
+  HB_HIP(hipGetLastError());
+  double* outs[6] = {pos_des, vel_des, kp, kd, tau_ff, torque};
+  for (int a = 0; a < 6; ++a)
+    if (outs[a]) HB_HIP(hipMemcpyAsync(outs[a], ctx->jc_out + a * n, n * 8, hipMemcpyDeviceToHost, s));
+  HB_HIP(hipStreamSynchronize(s));
+  return HB_OK;
 }
 
 int32_t hb_refgen_reset(hb_ctx* ctx, const hb_refgen_config* cfg, const double* latest_stance) {

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "hb_get_wbc_solution", "hb_set_chunks",
     "hb_sync", "hb_get_stats", "hb_get_input_cost", "hb_version", "hb_eval_flow_map", "hb_eval_foot_kinematics",
     "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
-    "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references",
+    "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command",
 ]
 
 
@@ -154,6 +154,13 @@ class HunterSolver:
         self._check(self.lib.hb_wbc_update_direct(self.ctx, _p(x_des), _p(u_des), _p(rbd), _p(mode), _p(stance), C.c_double(dt),
                                                   _p(sol), _p(status)), "hb_wbc_update_direct")
         return sol, status
+
+    def joint_command(self, gains: "abi.HbJointGains", dt=0.002):
+        """Joint command law of LeggedController::update on the last WBC result -> dict of [B][10] arrays."""
+        out = {k: np.zeros((self.B, 10)) for k in ("pos_des", "vel_des", "kp", "kd", "tau_ff", "torque")}
+        self._check(self.lib.hb_joint_command(self.ctx, C.byref(gains), C.c_double(dt), *[_p(out[k]) for k in
+                                              ("pos_des", "vel_des", "kp", "kd", "tau_ff", "torque")]), "hb_joint_command")
+        return out
 
     # ---- device-resident stepping -----------------------------------------------------------------
     def set_resident_inputs(self, x0, t_now, rbd, walk_flag=None):

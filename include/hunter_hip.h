@@ -173,6 +173,22 @@ int32_t hb_wbc_update_direct(hb_ctx* ctx, const double* x_des, const double* u_d
                              const int32_t* mode, const int32_t* stance_flag, double dt, double* sol,
                              int32_t* status);
 
+/* ---- joint command law ------------------------------------------------------------------------
+ * The per-joint command of LeggedController::update after the WBC (LeggedController.cpp:186-257, the
+ * loadControllerFlag_ branch), evaluated on the results of the last hb_wbc_update / hb_wbc_update_direct /
+ * hb_step_resident that are still on the device:
+ *   posDes = joints(optimizedState) + 0.5 qdd_wbc dt^2,  velDes = jointVel(optimizedInput) + qdd_wbc dt   (:186-191)
+ *   (kp, kd) by joint: hip roll / yaw (0,1,5,6) small gains, ankle (4,9) small kp with kd_feet, others big gains;
+ *   stance or swing kp by the planned contact flag of the leg (:223-245);  feed-forward = WBC torque
+ *   torque = ff + kp (posDes - q) + kd (velDes - qd)                                                       (:252-256)
+ * Limit protection / emergency stop (:196-208,247-250) need the hardware handles and stay with the caller.
+ * Outputs (any may be NULL) are [batch][10]. Gains default to legged_controllers/cfg/Tutorials.cfg:6-16. */
+typedef struct hb_joint_gains {
+  double kp_big_stance, kp_big_swing, kd_big, kp_small_stance, kp_small_swing, kd_small, kd_feet;
+} hb_joint_gains;
+int32_t hb_joint_command(hb_ctx* ctx, const hb_joint_gains* gains, double dt, double* pos_des, double* vel_des,
+                         double* kp, double* kd, double* tau_ff, double* torque);
+
 /* ---- device-resident stepping (bench / rollouts; inputs already in HBM) ------------------------
  * hb_step_resident runs hb_mpc_solve(NULL) + hb_mpc_publish + WBC on device-resident t_now/rbd that
  * were uploaded once with hb_set_resident_inputs; nothing crosses PCIe. */

@@ -40,6 +40,45 @@ HB_HD void est_c_row(int i, int& plus, int& minus) {
   else { plus = 8 + 3 * (i - 24); minus = -1; }
 }
 
+// CentroidalModelRbdConversions::computeCentroidalStateFromRbdModel (LeggedController.cpp:332): MPC state
+// x = [A(q) v / m, base pose, joints] from rbd = [zyx, pos, q_j, omega_world, v_lin, qd_j]; registers only (one thread).
+HB_HD void centroidal_state_from_rbd(const DevModel& M, const double* rbd, double* x) {
+  const double* qj = rbd + 6;
+  const double* qdj = rbd + 6 + HB_NV;
+  LegOut<double> L0, L1;
+  leg_eval<double>(M, 0, [qj](int j) { return qj[j]; }, [qdj](int j) { return qdj[j]; }, L0);
+  leg_eval<double>(M, 1, [qj](int j) { return qj[j]; }, [qdj](int j) { return qdj[j]; }, L1);
+  double sz, cz, sy, cy, sx, cxr;
+  sincos_t(rbd[0], sz, cz);
+  sincos_t(rbd[1], sy, cy);
+  sincos_t(rbd[2], sx, cxr);
+  Mat3<double> R;
+  R.m[0] = cz * cy; R.m[1] = cz * sy * sx - sz * cxr; R.m[2] = cz * sy * cxr + sz * sx;
+  R.m[3] = sz * cy; R.m[4] = sz * sy * sx + cz * cxr; R.m[5] = sz * sy * cxr - cz * sx;
+  R.m[6] = -sy;     R.m[7] = cy * sx;                 R.m[8] = cy * cxr;
+  const double mb = M.mass[0], mt = M.total_mass, inv_m = 1.0 / mt;
+  const Vec3<double> cb(M.com[0][0], M.com[0][1], M.com[0][2]);
+  const Vec3<double> mc = mb * cb + L0.mc + L1.mc;
+  Sym3<double> Ib;
+  Ib.xx = M.inertia[0][0]; Ib.xy = M.inertia[0][1]; Ib.xz = M.inertia[0][2];
+  Ib.yy = M.inertia[0][3]; Ib.yz = M.inertia[0][4]; Ib.zz = M.inertia[0][5];
+  const Sym3<double> IO = Ib + point_inertia<double>(mb, cb) + L0.IO + L1.IO;
+  const Vec3<double> Pc = inv_m * mc;
+  Sym3<double> Icom = IO;
+  {
+    const Sym3<double> sh = point_inertia<double>(mt, Pc);
+    Icom.xx -= sh.xx; Icom.xy -= sh.xy; Icom.xz -= sh.xz; Icom.yy -= sh.yy; Icom.yz -= sh.yz; Icom.zz -= sh.zz;
+  }
+  const Vec3<double> lj = L0.l_sum + L1.l_sum;
+  const Vec3<double> Lj = L0.L_sum + L1.L_sum - cross(Pc, lj);
+  const Vec3<double> wg(rbd[HB_NV], rbd[HB_NV + 1], rbd[HB_NV + 2]), vlin(rbd[HB_NV + 3], rbd[HB_NV + 4], rbd[HB_NV + 5]);
+  const Vec3<double> hl = vlin + cross(wg, R * Pc) + inv_m * (R * lj);
+  const Vec3<double> ha = inv_m * (R * (Icom * tmul(R, wg) + Lj));
+  x[0] = hl.x; x[1] = hl.y; x[2] = hl.z; x[3] = ha.x; x[4] = ha.y; x[5] = ha.z;
+  x[6] = rbd[3]; x[7] = rbd[4]; x[8] = rbd[5]; x[9] = rbd[0]; x[10] = rbd[1]; x[11] = rbd[2];
+  for (int j = 0; j < HB_NJ; ++j) x[12 + j] = qj[j];
+}
+
 struct EstIn {
   const double* quat;     // 4: x y z w
   const double* w_local;  // 3

@@ -254,6 +254,11 @@ __global__ __launch_bounds__(64) void k_flow_jac(const DevModel* __restrict__ M,
     for (int r = 0; r < HB_NX; ++r) dst[(size_t(i) * HB_NX + r) * HB_NX + col] = fd[r].d;
 }
 
+__global__ void k_centroidal_state(int n, const DevModel* __restrict__ M, const double* rbd, double* x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) centroidal_state_from_rbd(*M, rbd + size_t(i) * HB_NRBD, x + size_t(i) * HB_NX);
+}
+
 // ---- joint command law: one thread per (instance, joint) ---------------------------------------------------------
 __global__ void k_joint_command(WbcBatch w, hb_joint_gains g, double dt, double* out /*[6][B][10]: posDes velDes kp kd ff torque*/) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1170,6 +1175,25 @@ int32_t hb_eval_rbd(hb_ctx* ctx, int32_t n, const double* rbd, double* Mo, doubl
   if (J) HB_HIP(hipMemcpy(J, dJ, size_t(n) * 192 * 8, hipMemcpyDeviceToHost));
   if (dJv) HB_HIP(hipMemcpy(dJv, dd, size_t(n) * 12 * 8, hipMemcpyDeviceToHost));
   (void)hipFree(dr); (void)hipFree(dM); (void)hipFree(dn); (void)hipFree(dJ); (void)hipFree(dd);
+  return HB_OK;
+}
+
+int32_t hb_centroidal_state_from_rbd(hb_ctx* ctx, int32_t n, const double* rbd, double* x) {
+  if (!ctx || !rbd || !x || n <= 0) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  double *drbd = nullptr, *dx = nullptr;
+  HB_HIP(hipMalloc(reinterpret_cast<void**>(&drbd), size_t(n) * HB_NRBD * 8));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&dx), size_t(n) * HB_NX * 8);
+  if (e != hipSuccess) { (void)hipFree(drbd); ctx->err = "hb_centroidal_state_from_rbd: hipMalloc failed"; return HB_ERR_DEVICE; }
+  e = hipMemcpy(drbd, rbd, size_t(n) * HB_NRBD * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_centroidal_state, dim3((n + 63) / 64), dim3(64), 0, ctx->s_wbc, n, ctx->dmodel, drbd, dx);
+    e = hipStreamSynchronize(ctx->s_wbc);
+  }
+  if (e == hipSuccess) e = hipMemcpy(x, dx, size_t(n) * HB_NX * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(drbd);
+  (void)hipFree(dx);
+  if (e != hipSuccess) { ctx->err = std::string("hb_centroidal_state_from_rbd: ") + hipGetErrorString(e); return HB_ERR_DEVICE; }
   return HB_OK;
 }
 

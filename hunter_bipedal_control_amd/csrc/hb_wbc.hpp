@@ -208,11 +208,13 @@ HB_HD Vec3<double> rot_log(const double* Rl, const double* Rr) {  // rotation ve
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) E[3 * i + j] = Rl[3 * i] * Rr[3 * j] + Rl[3 * i + 1] * Rr[3 * j + 1] + Rl[3 * i + 2] * Rr[3 * j + 2];
   const Vec3<double> ax(E[7] - E[5], E[2] - E[6], E[3] - E[1]);
+  // theta from atan2(sin, cos): acos(cos) loses half the digits near theta = 0 and, when the two rotations are equal to
+  // the last bit (the policy evaluated at the observation time returns the observed state), gave theta ~ 1e-8 with
+  // |ax| = 0 exactly and 0 * inf = NaN
   const double tr = E[0] + E[4] + E[8];
-  const double c = fmin(1.0, fmax(-1.0, 0.5 * (tr - 1.0)));
-  const double th = acos(c);
-  const double s2 = sqrt(dot(ax, ax));
-  const double scale = (th < 1e-8) ? 0.5 : th / s2;
+  const double s2 = sqrt(dot(ax, ax));  // 2 sin(theta)
+  const double th = atan2(0.5 * s2, 0.5 * (tr - 1.0));
+  const double scale = (s2 < 1e-12) ? 0.5 : th / s2;
   return scale * ax;
 }
 

@@ -1,0 +1,83 @@
+"""Closed-loop batched rollouts through the C ABI: plant -> observation -> references -> MPC ->
+policy -> WBC -> joint command -> plant, the loop of LeggedController::update (legged_controllers/src/LeggedController.cpp:
+137-278) and its MPC thread (:396-412), for every instance of a HunterSolver.
+
+Everything between the plant's state and the joint torque runs on the device (reference generation, SQP, policy
+evaluation, WBC, joint command law); the plant stub (plant.py) integrates on the host with the device's rigid-body
+terms.  The observation is the plant's true state (no estimator noise); `hb_estimator_update` can be put in its place.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import abi, refgen
+from .plant import Plant
+
+
+def standing_configuration(params: dict, batch: int) -> np.ndarray:
+    """q[B][16]: initialState of task.info with the base lowered so that the mean contact-point height is zero."""
+    x0 = np.array(params["config"]["initial_state"], dtype=float)
+    q = np.zeros((batch, 16))
+    q[:, 0:3], q[:, 3:6], q[:, 6:] = x0[6:9], x0[9:12], x0[12:]
+    q[:, 2] -= refgen.foot_positions(params["model"], x0)[:, 2].mean()
+    return q
+
+
+def schedule_window(ms: refgen.ModeSchedule, lower: float, upper: float) -> refgen.ModeSchedule:
+    """The part of a mode schedule with event times inside (lower, upper) and the modes around them."""
+    ev = np.asarray(ms.event_times, dtype=float)
+    i0 = int(np.searchsorted(ev, lower, side="right"))
+    i1 = int(np.searchsorted(ev, upper, side="left"))
+    return refgen.ModeSchedule(list(ev[i0:i1]), list(ms.modes[i0:i1 + 1]))
+
+
+class DeviceLoop:
+    """One HunterSolver driven in closed loop.  `gait` per instance (names of gait.info), `cmd_vel` [B][4]."""
+
+    def __init__(self, solver, params: dict, gaits, cmd_vel, n_intervals: int = 100, mpc_every: int = 8, dt: float = 0.002,
+                 t_gait_start: float = 0.3, joint_ik: bool = True):
+        self.s, self.params = solver, params
+        self.B = solver.B
+        c = params["config"]
+        self.horizon = n_intervals * c["dt"]
+        self.dt, self.mpc_every = dt, mpc_every
+        self.cmd = np.ascontiguousarray(cmd_vel, dtype=float).reshape(self.B, 4)
+        self.gains = abi.make_joint_gains()
+        self.t, self.tick = 0.0, 0
+        solver.refgen_reset(abi.make_refgen_config(params, joint_ik=joint_ik))
+        # GaitSchedule output per instance; each MPC call hands the device the window [t - 1, t + horizon + 1.5] of it
+        # (the reference asks its gait schedule for [t - T, t + 2T], SwitchedModelReferenceManager.cpp:147)
+        self.schedules = [refgen.gait_schedule(params, g, t_gait_start, 1.0e3 if g == "stance" else 60.0) for g in gaits]
+        zeros_u = np.zeros((1, 22))
+
+        def foot_fn(q):
+            x = np.zeros((q.shape[0], 22))
+            x[:, 6:9], x[:, 9:12], x[:, 12:] = q[:, 0:3], q[:, 3:6], q[:, 6:]
+            return solver.eval_foot_kinematics(x, np.repeat(zeros_u, q.shape[0], axis=0))[0]
+
+        self.plant = Plant(lambda rbd: solver.eval_rbd(rbd), foot_fn, standing_configuration(params, self.B))
+        self.started = False
+        self.last = {}
+
+    def step(self):
+        s, B = self.s, self.B
+        rbd = self.plant.rbd()
+        x_obs = s.centroidal_state_from_rbd(rbd)
+        if self.tick % self.mpc_every == 0:                       # MPC thread: references, one SQP iteration, publish
+            s.refgen_set_schedule([schedule_window(ms, self.t - 1.0, self.t + self.horizon + 1.5) for ms in self.schedules])
+            status = s.refgen_update(np.full(B, self.t), self.horizon, x_obs, self.cmd)
+            if status.max() != 0:
+                raise RuntimeError(f"reference generation failed: {status}")
+            if not self.started:
+                s.reset(x_obs)                                    # cold start (LeggedRobotInitializer)
+                self.started = True
+            s.mpc_solve(x_obs)
+            s.publish()
+        out = s.wbc_update(np.full(B, self.t), rbd, dt=self.dt)   # control thread: policy, WBC, joint command
+        cmd = s.joint_command(self.gains, self.dt)
+        contact = np.array([refgen.mode_to_contact_flags(int(m)) for m in out["mode"]])
+        self.plant.step(cmd["torque"], contact, self.dt)
+        self.t += self.dt
+        self.tick += 1
+        self.last = dict(out=out, cmd=cmd, contact=contact, x_obs=x_obs)
+        return self.plant.q, self.plant.v

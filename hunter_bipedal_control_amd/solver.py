@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "hb_get_wbc_solution", "hb_set_chunks",
     "hb_sync", "hb_get_stats", "hb_get_input_cost", "hb_version", "hb_eval_flow_map", "hb_eval_foot_kinematics",
     "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
-    "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command",
+    "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd",
 ]
 
 
@@ -274,6 +274,12 @@ class HunterSolver:
         M, nle, J, dJv = np.zeros((n, 16, 16)), np.zeros((n, 16)), np.zeros((n, 12, 16)), np.zeros((n, 12))
         self._check(self.lib.hb_eval_rbd(self.ctx, C.c_int32(n), _p(rbd), _p(M), _p(nle), _p(J), _p(dJv)), "hb_eval_rbd")
         return M, nle, J, dJv
+
+    def centroidal_state_from_rbd(self, rbd):
+        rbd = _f64(np.atleast_2d(rbd))
+        x = np.zeros((rbd.shape[0], 22))
+        self._check(self.lib.hb_centroidal_state_from_rbd(self.ctx, C.c_int32(rbd.shape[0]), _p(rbd), _p(x)), "hb_centroidal_state_from_rbd")
+        return x
 
     def riccati_solve(self, A, Bm, b, Q, R, P, q, r, dx0):
         A, Bm, b, Q, R, P, q, r, dx0 = map(_f64, (A, Bm, b, Q, R, P, q, r, dx0))

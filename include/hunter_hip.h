@@ -282,6 +282,10 @@ int32_t hb_eval_foot_kinematics(hb_ctx* ctx, int32_t n, const double* x, const d
                                 double* pos /*[n][4][3]*/, double* vel /*[n][4][3]*/);
 /* Rigid-body quantities of WbcBase::updateMeasured (WbcBase.cpp:70-120): M[16][16], nle[16], J[12][16], dJv[12]. */
 int32_t hb_eval_rbd(hb_ctx* ctx, int32_t n, const double* rbd, double* M, double* nle, double* J, double* dJv);
+/* MPC observation state from the rbd state: x = [A(q) v / m, base pose, joints]
+ * (CentroidalModelRbdConversions::computeCentroidalStateFromRbdModel, call site LeggedController.cpp:332); no yaw
+ * unwrapping. */
+int32_t hb_centroidal_state_from_rbd(hb_ctx* ctx, int32_t n, const double* rbd /*[n][32]*/, double* x /*[n][22]*/);
 /* Solve a batch of equality-free LQ problems (n <= batch, N <= max_nodes, nu <= 12 inputs per stage) with the
  * Riccati backward kernel (HPIPM's role).  Stage data row-major: A[n][N][22][22], B[n][N][22][nu],
  * b[n][N][22], Q[n][N][22][22], R[n][N][nu][nu], P[n][N][nu][22], q[n][N][22], r[n][N][nu], dx0[n][22].

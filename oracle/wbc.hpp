@@ -174,13 +174,11 @@ inline M3<double> zyx_to_rotation(const double* zyx) {
 inline V3<double> rotation_error_world(const M3<double>& Rl, const M3<double>& Rr) {
   const M3<double> E = Rl * transpose(Rr);
   const V3<double> ax(E.m[2][1] - E.m[1][2], E.m[0][2] - E.m[2][0], E.m[1][0] - E.m[0][1]);
+  // theta = atan2(sin, cos); acos(cos) is ill-conditioned at theta = 0 and produced 0 * inf when Rl == Rr to the last bit
   const double tr = E.m[0][0] + E.m[1][1] + E.m[2][2];
-  const double c = std::min(1.0, std::max(-1.0, 0.5 * (tr - 1.0)));
-  const double th = std::acos(c);
   const double s2 = std::sqrt(dot3(ax, ax));  // 2 sin(theta)
-  double scale;
-  if (th < 1e-8) scale = 0.5;
-  else scale = th / s2;
+  const double th = std::atan2(0.5 * s2, 0.5 * (tr - 1.0));
+  const double scale = (s2 < 1e-12) ? 0.5 : th / s2;
   return scale * ax;
 }
 

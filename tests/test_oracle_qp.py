@@ -74,3 +74,21 @@ def test_weighted_wbc_solution_properties(params, oracle):
             else:
                 assert x[16 + 3 * k + 2] >= -1e-9
         _check_kkt(pr["Aw"], pr["bw"], 1e-8, pr["Aeq"], pr["beq"], pr["D"], pr["f"], x, tol=1e-8)
+
+
+def test_wbc_rotation_error_is_finite_when_desired_equals_measured_orientation(params, oracle):
+    """Found by the closed-loop rollout: at an MPC tick the policy returns the observed state itself, the two rotation
+    matrices agree to the last bit, and theta = acos(.) ~ 1e-8 over |axis| = 0 used to give NaN."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    x0 = np.array(params["config"]["initial_state"])
+    mass = sum(params["model"]["mass"])
+    for trial in range(200):
+        xd = x0 + 0.02 * rng.standard_normal(22)
+        xd[9:12] = 0.05 * rng.standard_normal(3)
+        rbd = np.zeros(32)
+        rbd[0:3], rbd[3:6], rbd[6:16] = xd[9:12], xd[6:9], xd[12:]
+        ud = np.zeros(22)
+        ud[2:12:3] = mass * 9.81 / 4
+        sol, st, _ = oracle.wbc_update(xd[None], ud[None], rbd[None], np.array([3], dtype=np.int32), stance_flag=np.zeros(1, dtype=np.int32))
+        assert st[0] == 0 and np.isfinite(sol).all(), trial

@@ -392,7 +392,8 @@ struct hb_ctx {
   DevConfig* dconfig = nullptr;
   Batch b{};
   hipStream_t s_mpc = nullptr, s_wbc = nullptr;
-  hipEvent_t ev[8]{};
+  hipEvent_t ev[9]{};  // 0..4 MPC phases, 5/6 WBC begin/end, 7 publish, 8 policy buffers consumed by the last policy evaluation
+  bool policy_read_pending = false;
   bool refs_set = false, traj_set = false, timed = false;
   std::vector<void*> allocs;
   std::string err;
@@ -913,6 +914,12 @@ int32_t hb_mpc_publish(hb_ctx* ctx) {
   HB_HIP(hipSetDevice(ctx->device));
   // device-to-device copy of the solution into the policy buffers read by the WBC stream
   hipStream_t s = ctx->s_mpc;
+  // only the copies below touch the policy buffers: they wait for the last policy evaluation on the WBC stream, the SQP
+  // kernels of the next solve do not (so a WBC solve overlaps the next LQ approximation)
+  if (ctx->policy_read_pending) {
+    HB_HIP(hipStreamWaitEvent(s, ctx->ev[8], 0));
+    ctx->policy_read_pending = false;
+  }
   HB_HIP(hipMemcpyAsync(ctx->w.px, ctx->b.x, B * (N + 1) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
   HB_HIP(hipMemcpyAsync(ctx->w.pu, ctx->b.u, B * N * HB_NU * 8, hipMemcpyDeviceToDevice, s));
   HB_HIP(hipMemcpyAsync(ctx->w.pt, ctx->b.t, B * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
@@ -931,6 +938,8 @@ static int32_t wbc_launch(hb_ctx* ctx, bool from_policy, double dt) {
   HB_HIP(hipEventRecord(ctx->ev[5], s));
   if (from_policy) {
     hipLaunchKernelGGL(k_policy_eval, dim3((ctx->B + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
+    HB_HIP(hipEventRecord(ctx->ev[8], s));  // the policy buffers are free again once this has run
+    ctx->policy_read_pending = true;
   }
   if (ctx->config.wbc_type == 1)
     hipLaunchKernelGGL(k_hwbc, dim3(ctx->B), dim3(64), HoLds::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
@@ -1035,9 +1044,7 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
     if (rc != HB_OK) return rc;
     rc = wbc_launch(ctx, true, dt);
     if (rc != HB_OK) return rc;
-    // the next MPC iteration must not overwrite the policy buffers while the WBC reads them
-    HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev[6], 0));
-    return HB_OK;
+    return HB_OK;  // hb_mpc_publish orders the next policy write after this step's policy evaluation
   }
   // pipelined: every chunk of instances is a linear sequence MPC -> publish -> policy evaluation -> WBC on its own stream
   if (ctx->n_seq > 0) {

@@ -205,6 +205,128 @@ class Wbc {
   std::vector<int32_t> status_, stance_;
 };
 
+// ---- reference side: ocs2::legged_robot::GaitSchedule + SwitchedModelReferenceManager ------------------------------
+// The gait scheduler is a handful of integers and event times per robot; it stays on the host, in C++ like the
+// reference's (legged_interface/src/gait/GaitSchedule.cpp:57-161).  Everything it feeds — targets, time grid, swing
+// planner, joint-reference IK — runs on the device (hb_refgen_*).
+struct ModeSequenceTemplate {       // legged_interface/include/legged_interface/gait/ModeSequenceTemplate.h
+  std::vector<scalar_t> switchingTimes;  // N + 1 phase boundaries of one period
+  std::vector<int32_t> modeSequence;     // N modes
+};
+struct ModeSchedule {               // ocs2::ModeSchedule
+  std::vector<scalar_t> eventTimes;
+  std::vector<int32_t> modeSequence{3};
+  int32_t modeAtTime(scalar_t t) const {  // lower_bound, like ModeSchedule::modeAtTime
+    size_t i = 0;
+    while (i < eventTimes.size() && eventTimes[i] < t) ++i;
+    return modeSequence[i];
+  }
+};
+class GaitSchedule {
+ public:
+  GaitSchedule(ModeSchedule initModeSchedule, ModeSequenceTemplate initModeSequenceTemplate, scalar_t phaseTransitionStanceTime)
+      : modeSchedule_(std::move(initModeSchedule)), modeSequenceTemplate_(std::move(initModeSequenceTemplate)),
+        phaseTransitionStanceTime_(phaseTransitionStanceTime) {}
+  // GaitSchedule::insertModeSequenceTemplate (GaitSchedule.cpp:57-89)
+  void insertModeSequenceTemplate(const ModeSequenceTemplate& modeSequenceTemplate, scalar_t startTime, scalar_t finalTime) {
+    modeSequenceTemplate_ = modeSequenceTemplate;
+    auto& ev = modeSchedule_.eventTimes;
+    auto& md = modeSchedule_.modeSequence;
+    size_t idx = 0;
+    while (idx < ev.size() && ev[idx] < startTime) ++idx;  // lower_bound
+    if (idx < ev.size()) {
+      ev.erase(ev.begin() + idx, ev.end());
+      md.erase(md.begin() + idx + 1, md.end());
+    }
+    scalar_t pts = phaseTransitionStanceTime_;
+    if (!md.empty() && md.back() == kStance) pts = 0.0;
+    if (pts > 0.0) {
+      ev.push_back(startTime);
+      md.push_back(kStance);
+    }
+    tileModeSequenceTemplate(startTime + pts, finalTime);
+  }
+  // GaitSchedule::getModeSchedule (GaitSchedule.cpp:94-120): drops the past, tiles the template up to the upper bound
+  ModeSchedule getModeSchedule(scalar_t lowerBoundTime, scalar_t upperBoundTime) {
+    auto& ev = modeSchedule_.eventTimes;
+    auto& md = modeSchedule_.modeSequence;
+    size_t idx = 0;
+    while (idx < ev.size() && ev[idx] < lowerBoundTime) ++idx;
+    if (idx > 0) {
+      ev.erase(ev.begin(), ev.begin() + (idx - 1));
+      md.erase(md.begin(), md.begin() + (idx - 1));
+      md.front() = kStance;
+    }
+    const scalar_t start = ev.empty() ? lowerBoundTime : ev.back();
+    if (!ev.empty()) ev.pop_back();
+    md.pop_back();
+    tileModeSequenceTemplate(start, upperBoundTime);
+    return modeSchedule_;
+  }
+
+ private:
+  enum : int32_t { kStance = 3 };  // STANCE (MotionPhaseDefinition.h:55-95)
+  // GaitSchedule::tileModeSequenceTemplate (GaitSchedule.cpp:125-161)
+  void tileModeSequenceTemplate(scalar_t startTime, scalar_t finalTime) {
+    auto& ev = modeSchedule_.eventTimes;
+    auto& md = modeSchedule_.modeSequence;
+    const auto& tp = modeSequenceTemplate_;
+    if (tp.modeSequence.empty()) return;
+    if (!ev.empty() && startTime <= ev.back())
+      throw std::runtime_error("The initial time for template-tiling is not greater than the last event time.");
+    ev.push_back(startTime);
+    while (ev.back() < finalTime)
+      for (size_t i = 0; i < tp.modeSequence.size(); ++i) {
+        md.push_back(tp.modeSequence[i]);
+        ev.push_back(ev.back() + tp.switchingTimes[i + 1] - tp.switchingTimes[i]);
+      }
+    md.push_back(kStance);
+  }
+  ModeSchedule modeSchedule_;
+  ModeSequenceTemplate modeSequenceTemplate_;
+  scalar_t phaseTransitionStanceTime_;
+};
+
+// SwitchedModelReferenceManager::modifyReferences (SwitchedModelReferenceManager.cpp:136-171) for the whole batch: the
+// pre-solver hook the MPC thread runs before every advanceMpc().  One GaitSchedule per instance.
+class ReferenceManager {
+ public:
+  ReferenceManager(Context ctx, const hb_refgen_config& settings, std::vector<GaitSchedule> gaitSchedules)
+      : ctx_(std::move(ctx)), gaits_(std::move(gaitSchedules)) {
+    if (int(gaits_.size()) != ctx_.batch()) throw std::invalid_argument("[hunter_hip] one GaitSchedule per instance expected");
+    ctx_.check(hb_refgen_reset(ctx_.get(), &settings, nullptr), "hb_refgen_reset");
+  }
+  GaitSchedule& gaitSchedule(int instance) { return gaits_.at(size_t(instance)); }
+  // initTime [batch], cmdVel [batch][4] = (vx, vy, vz, yaw rate); observation [batch][22] or nullptr = the resident one
+  void preSolverRun(const vector_t& initTime, scalar_t timeHorizon, const vector_t& cmdVel, const vector_t* observation = nullptr) {
+    const size_t B = size_t(ctx_.batch());
+    if (initTime.size() != B || cmdVel.size() != B * 4 || (observation && observation->size() != B * HB_NX))
+      throw std::invalid_argument("[hunter_hip] ReferenceManager::preSolverRun: wrong vector size");
+    std::vector<int32_t> nEvents(B), modes(B * (HB_MAX_EVENTS + 1), 3);
+    vector_t events(B * HB_MAX_EVENTS, 0.0);
+    for (size_t i = 0; i < B; ++i) {
+      // the reference asks for [t - T, t + 2T] (SwitchedModelReferenceManager.cpp:147)
+      const ModeSchedule ms = gaits_[i].getModeSchedule(initTime[i] - timeHorizon, initTime[i] + 2.0 * timeHorizon);
+      if (ms.eventTimes.size() > size_t(HB_MAX_EVENTS)) throw std::invalid_argument("[hunter_hip] mode schedule longer than HB_MAX_EVENTS");
+      nEvents[i] = int32_t(ms.eventTimes.size());
+      for (size_t e = 0; e < ms.eventTimes.size(); ++e) events[i * HB_MAX_EVENTS + e] = ms.eventTimes[e];
+      for (size_t e = 0; e < ms.modeSequence.size(); ++e) modes[i * (HB_MAX_EVENTS + 1) + e] = ms.modeSequence[e];
+    }
+    ctx_.check(hb_refgen_set_schedule(ctx_.get(), 0, ctx_.batch(), nEvents.data(), events.data(), modes.data()), "hb_refgen_set_schedule");
+    status_.resize(B);
+    ctx_.check(hb_refgen_update(ctx_.get(), initTime.data(), timeHorizon, observation ? observation->data() : nullptr, cmdVel.data(),
+                                status_.data()),
+               "hb_refgen_update");
+    for (size_t i = 0; i < B; ++i)
+      if (status_[i] != 0) throw std::runtime_error("[hunter_hip] reference generation failed for instance " + std::to_string(i));
+  }
+
+ private:
+  Context ctx_;
+  std::vector<GaitSchedule> gaits_;
+  std::vector<int32_t> status_;
+};
+
 // ---- estimator side: legged::KalmanFilterEstimate / StateEstimateBase ---------------------------------------------
 // updateJointStates / updateContact / updateImu / update(time, period) (LeggedController.cpp:323-327) in one call per
 // tick for the whole batch; returns rbdState (what WbcBase::update takes) and fills the centroidal observation states

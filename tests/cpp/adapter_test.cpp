@@ -38,6 +38,70 @@ int main(int argc, char** argv) {
     std::printf("a context was created: a GPU is visible\n");
     return 4;
   }
+  if (what == "gait") {
+    // adapter_test <params.bin> gait <t_start> <lower> <upper> [<lower2> <upper2>]: trot template inserted at t_start,
+    // then getModeSchedule windows; prints "n ev... | modes..." per window (compared with refgen.GaitSchedule)
+    ModeSchedule init;
+    init.modeSequence = {3};
+    GaitSchedule gs(init, ModeSequenceTemplate{{0.0, 1.0}, {3}}, 0.1);
+    gs.insertModeSequenceTemplate(ModeSequenceTemplate{{0.0, 0.3, 0.6}, {2, 1}}, std::atof(argv[3]), std::atof(argv[3]) + 2.0);
+    for (int a = 4; a + 1 < argc; a += 2) {
+      const ModeSchedule ms = gs.getModeSchedule(std::atof(argv[a]), std::atof(argv[a + 1]));
+      std::printf("%zu", ms.eventTimes.size());
+      for (double e : ms.eventTimes) std::printf(" %.17g", e);
+      std::printf(" |");
+      for (int m : ms.modeSequence) std::printf(" %d", m);
+      std::printf("\n");
+    }
+    return 0;
+  }
+  if (what == "refs" && argc >= 5) {
+    // adapter_test <params.bin> refs <problem.bin> <result.bin>: GaitSchedule + ReferenceManager + two SQP solves in C++
+    std::FILE* f = std::fopen(argv[3], "rb");
+    if (!f) return 66;
+    std::vector<int32_t> head;
+    readv(f, head, 2);
+    const size_t B = size_t(head[0]), N = size_t(head[1]);
+    vector_t x0, cmd, t0;
+    readv(f, x0, B * HB_NX);
+    readv(f, cmd, B * 4);
+    readv(f, t0, B);
+    std::vector<double> rg;  // hb_refgen_config as doubles (5 + 12 + 10) + joint_ik
+    readv(f, rg, 28);
+    std::fclose(f);
+    hb_refgen_config rcfg;
+    rcfg.dt = rg[0]; rcfg.com_height = rg[1]; rcfg.next_position_z = rg[2]; rcfg.swing_height = rg[3]; rcfg.swing_time_scale = rg[4];
+    for (int i = 0; i < 12; ++i) rcfg.feet_bias[i / 3][i % 3] = rg[5 + i];
+    for (int i = 0; i < 10; ++i) rcfg.default_joints[i] = rg[17 + i];
+    rcfg.joint_ik = int32_t(rg[27]);
+    rcfg.reserved = 0;
+    Context ctx(model, config, int(B), int(N));
+    std::vector<GaitSchedule> gaits;
+    for (size_t i = 0; i < B; ++i) {
+      ModeSchedule init;
+      init.modeSequence = {3};
+      GaitSchedule gs(init, ModeSequenceTemplate{{0.0, 1.0}, {3}}, 0.1);
+      gs.insertModeSequenceTemplate(ModeSequenceTemplate{{0.0, 0.3, 0.6}, {2, 1}}, 0.1, 3.0);   // "trot" of gait.info
+      gaits.push_back(gs);
+    }
+    ReferenceManager refs(ctx, rcfg, gaits);
+    MpcMrtInterface mpcMrt(ctx);
+    const double horizon = (double(N) - 8.0) * rcfg.dt;
+    refs.preSolverRun(t0, horizon, cmd, &x0);
+    mpcMrt.resetMpcNode(x0);
+    mpcMrt.advanceMpc();
+    refs.preSolverRun(t0, horizon, cmd, &x0);   // second call: planner state persists on the device
+    mpcMrt.advanceMpc();
+    vector_t xs, us;
+    mpcMrt.getSolution(xs, us);
+    std::FILE* g = std::fopen(argv[4], "wb");
+    if (!g) return 73;
+    writev(g, xs);
+    writev(g, us);
+    std::fclose(g);
+    std::printf("ok refs\n");
+    return 0;
+  }
   if (what != "run" || argc < 7) return 64;
   std::FILE* f = std::fopen(argv[3], "rb");
   if (!f) return 66;

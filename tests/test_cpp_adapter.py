@@ -98,3 +98,70 @@ def test_cpp_adapter_control_loop_matches_ctypes_path(params, tmp_path, wbc_type
     assert np.array_equal(mode.astype(np.int32), out["mode"]) and np.array_equal(status.astype(np.int32), out["status"])
     assert np.array_equal(sol.reshape(B, 38), out["sol"])
     assert np.array_equal(direct.reshape(B, 38), sol_direct)
+
+
+def test_cpp_gait_schedule_matches_host_reference_manager(params):
+    """hunter_hip::GaitSchedule (C++) vs refgen.GaitSchedule (the Python restatement of GaitSchedule.cpp:57-161)."""
+    from hunter_bipedal_control_amd import refgen
+    exe = _build()
+    windows = [(-1.4, 3.1), (0.05, 4.6), (0.41, 4.9), (2.0, 6.5)]
+    args = [str(v) for w in windows for v in w]
+    r = subprocess.run([str(exe), str(PARAMS_BIN), "gait", "0.1"] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    c = params["config"]
+    gs = refgen.GaitSchedule(refgen.ModeSchedule([], [3]), refgen.ModeTemplate([0.0, 1.0], [3]), c["phase_transition_stance_time"])
+    trot = c["gaits"]["trot"]
+    gs.insert_template(refgen.ModeTemplate(trot["switching_times"], trot["modes"]), 0.1, 2.1)
+    for line, (lo, hi) in zip(r.stdout.strip().splitlines(), windows):
+        ms = gs.get_mode_schedule(lo, hi)
+        left, right = line.split("|")
+        vals = left.split()
+        assert int(vals[0]) == len(ms.event_times)
+        assert np.allclose([float(v) for v in vals[1:]], ms.event_times, rtol=0, atol=1e-15)
+        assert [int(v) for v in right.split()] == list(ms.modes)
+
+
+@pytest.mark.gpu
+def test_cpp_reference_manager_and_mpc_match_python_path(params, tmp_path):
+    """GaitSchedule + ReferenceManager::preSolverRun + advanceMpc in C++ == the same through Python (device refgen)."""
+    from hunter_bipedal_control_amd import abi, refgen
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    exe = _build()
+    B, N = 4, 40
+    nmax = N + 8
+    c = params["config"]
+    horizon = N * c["dt"]
+    x0 = np.stack([workload.perturbed_state(params, 500 + i) for i in range(B)])
+    cmd = np.tile([0.25, 0.05, 0.0, 0.2], (B, 1))
+    t0 = np.full(B, 0.15)
+    rcfg = abi.make_refgen_config(params, joint_ik=True)
+    flat = [rcfg.dt, rcfg.com_height, rcfg.next_position_z, rcfg.swing_height, rcfg.swing_time_scale]
+    flat += [rcfg.feet_bias[i][j] for i in range(4) for j in range(3)] + list(rcfg.default_joints) + [float(rcfg.joint_ik)]
+    prob, res = tmp_path / "refs_problem.bin", tmp_path / "refs_result.bin"
+    with open(prob, "wb") as f:
+        np.array([B, nmax], dtype=np.int32).tofile(f)
+        for a in (x0, cmd, t0, np.array(flat)):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(f)
+    r = subprocess.run([str(exe), str(PARAMS_BIN), "refs", str(prob), str(res)], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok refs" in r.stdout, r.stdout + r.stderr
+    raw = np.fromfile(res, dtype=np.float64)
+    xs, us = np.split(raw, [B * (nmax + 1) * 22])
+    s = HunterSolver(params, batch=B, max_nodes=nmax)
+    try:
+        s.refgen_reset(rcfg)
+        gaits = []
+        for _ in range(B):
+            gs = refgen.GaitSchedule(refgen.ModeSchedule([], [3]), refgen.ModeTemplate([0.0, 1.0], [3]), c["phase_transition_stance_time"])
+            trot = c["gaits"]["trot"]
+            gs.insert_template(refgen.ModeTemplate(trot["switching_times"], trot["modes"]), 0.1, 3.0)
+            gaits.append(gs)
+        for call in range(2):
+            s.refgen_set_schedule([g.get_mode_schedule(0.15 - horizon, 0.15 + 2 * horizon) for g in gaits])
+            assert s.refgen_update(t0, horizon, x0, cmd).max() == 0
+            if call == 0:
+                s.reset(x0)
+            s.mpc_solve(x0)
+        xg, ug = s.get_solution()
+    finally:
+        s.close()
+    assert np.array_equal(xs.reshape(xg.shape), xg) and np.array_equal(us.reshape(ug.shape), ug)

@@ -1044,7 +1044,11 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
     if (rc != HB_OK) return rc;
     rc = wbc_launch(ctx, true, dt);
     if (rc != HB_OK) return rc;
-    return HB_OK;  // hb_mpc_publish orders the next policy write after this step's policy evaluation
+    // hb_mpc_publish already orders the next policy write after this step's policy evaluation.  The next step's SQP
+    // kernels are additionally held back until this WBC has finished: letting them time-slice the CUs with the WBC
+    // gave no throughput (the LQ kernel fills every CU's LDS) and only blurred the per-kernel timings.
+    HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev[6], 0));
+    return HB_OK;
   }
   // pipelined: every chunk of instances is a linear sequence MPC -> publish -> policy evaluation -> WBC on its own stream
   if (ctx->n_seq > 0) {

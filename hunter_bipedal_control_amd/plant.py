@@ -42,6 +42,7 @@ class Plant:
         self.anchor = self.foot_fn(self.q)
         self.pinned = np.zeros((self.B, 4), dtype=bool)
         self.last_lambda = np.zeros((self.B, 12))
+        self.last_vdot = np.zeros((self.B, 16))
 
     def rbd(self):
         out = np.zeros((self.B, 32))
@@ -78,4 +79,19 @@ class Plant:
             self.v = self.v + h * vdot               # semi-implicit Euler
             self.q = self.q + h * self.v
             self.last_lambda = lam
+            self.last_vdot = vdot
         return self.q, self.v
+
+    def imu(self):
+        """Ideal IMU of the base link for the state estimator: quaternion (x y z w), body-frame angular velocity and
+        specific force (world linear acceleration minus gravity, rotated into the body), from the last step."""
+        from .refgen import zyx_to_rotation
+        quat, w_loc, a_loc = np.zeros((self.B, 4)), np.zeros((self.B, 3)), np.zeros((self.B, 3))
+        w_world = np.einsum("bij,bj->bi", _E(self.q[:, 3:6]), self.v[:, 3:6])
+        for i in range(self.B):
+            R = zyx_to_rotation(self.q[i, 3:6])
+            w = 0.5 * np.sqrt(max(1e-300, 1.0 + np.trace(R)))
+            quat[i] = [(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w]
+            w_loc[i] = R.T @ w_world[i]
+            a_loc[i] = R.T @ (self.last_vdot[i, 0:3] + np.array([0.0, 0.0, 9.81]))
+        return quat, w_loc, a_loc

@@ -35,7 +35,7 @@ class DeviceLoop:
     """One HunterSolver driven in closed loop.  `gait` per instance (names of gait.info), `cmd_vel` [B][4]."""
 
     def __init__(self, solver, params: dict, gaits, cmd_vel, n_intervals: int = 100, mpc_every: int = 8, dt: float = 0.002,
-                 t_gait_start: float = 0.3, joint_ik: bool = True):
+                 t_gait_start: float = 0.3, joint_ik: bool = True, use_estimator: bool = False):
         self.s, self.params = solver, params
         self.B = solver.B
         c = params["config"]
@@ -58,11 +58,26 @@ class DeviceLoop:
         self.plant = Plant(lambda rbd: solver.eval_rbd(rbd), foot_fn, standing_configuration(params, self.B))
         self.started = False
         self.last = {}
+        # use_estimator: the observation comes from hb_estimator_update fed with the plant's ideal IMU, joint encoders and
+        # the commanded contact flags (LeggedController::updateStateEstimation) instead of the plant's true state
+        self.use_estimator = use_estimator
+        self.contact = np.ones((self.B, 4), dtype=np.int32)
+        if use_estimator:
+            q = self.plant.q
+            xh0 = np.zeros((self.B, 18))
+            xh0[:, 0:3] = q[:, 0:3]
+            feet = self.plant.foot_fn(q)
+            xh0[:, 6:18] = feet.reshape(self.B, 12)
+            solver.estimator_reset(abi.make_estimator_config(params), xh0)
 
     def step(self):
         s, B = self.s, self.B
-        rbd = self.plant.rbd()
-        x_obs = s.centroidal_state_from_rbd(rbd)
+        if self.use_estimator:
+            quat, w_loc, a_loc = self.plant.imu()
+            rbd, x_obs = s.estimator_update(self.dt, quat, w_loc, a_loc, self.plant.q[:, 6:], self.plant.v[:, 6:], self.contact)
+        else:
+            rbd = self.plant.rbd()
+            x_obs = s.centroidal_state_from_rbd(rbd)
         if self.tick % self.mpc_every == 0:                       # MPC thread: references, one SQP iteration, publish
             s.refgen_set_schedule([schedule_window(ms, self.t - 1.0, self.t + self.horizon + 1.5) for ms in self.schedules])
             status = s.refgen_update(np.full(B, self.t), self.horizon, x_obs, self.cmd)
@@ -77,6 +92,7 @@ class DeviceLoop:
         cmd = s.joint_command(self.gains, self.dt)
         contact = np.array([refgen.mode_to_contact_flags(int(m)) for m in out["mode"]])
         self.plant.step(cmd["torque"], contact, self.dt)
+        self.contact = contact.astype(np.int32)
         self.t += self.dt
         self.tick += 1
         self.last = dict(out=out, cmd=cmd, contact=contact, x_obs=x_obs)

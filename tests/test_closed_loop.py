@@ -49,3 +49,30 @@ def test_device_closed_loop_matches_oracle_loop_then_trots(params, oracle):
     straight = [0, 1, 2]                                                # instance 3 turns: compare its path length only
     assert np.abs(travelled[straight] - expect[straight]).max() < 0.12, (travelled, expect)
     assert abs(q[3, 3] - 0.25 * 1.7) < 0.2                              # yaw follows the commanded rate
+
+
+@pytest.mark.gpu
+def test_device_closed_loop_with_the_state_estimator_in_the_loop(params):
+    """estimate -> references -> MPC -> WBC -> joint command with hb_estimator_update as the only source of the state
+    (ideal IMU + encoders + commanded contacts from the plant): the robot trots as with the true state, and the filter
+    tracks the plant's base position / velocity."""
+    from hunter_bipedal_control_amd.rollout import DeviceLoop
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B = 2
+    cmds = np.array([[0.2, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0]])
+    s = HunterSolver(params, batch=B, max_nodes=108)
+    try:
+        dev = DeviceLoop(s, params, ["trot", "stance"], cmds, use_estimator=True)
+        err_p, err_v = 0.0, 0.0
+        for k in range(750):                                   # 1.5 s
+            q, v = dev.step()
+            if k > 100:
+                xh, _ = s.estimator_filter()
+                err_p = max(err_p, np.abs(xh[:, 0:3] - q[:, 0:3]).max())
+                err_v = max(err_v, np.abs(xh[:, 3:6] - v[:, 0:3]).max())
+        assert dev.last["out"]["status"].max() == 0
+    finally:
+        s.close()
+    assert np.isfinite(q).all() and (np.abs(q[:, 2] - 0.63) < 0.04).all() and np.abs(q[:, 4:6]).max() < 0.15
+    assert abs(q[0, 0] - 0.2 * 1.2) < 0.1 and abs(q[1, 0]) < 0.05
+    assert err_p < 0.03 and err_v < 0.15, (err_p, err_v)

@@ -15,6 +15,7 @@
 #include "hb_hoqp.hpp"
 #include "hb_estimator.hpp"
 #include "hb_refgen.hpp"
+#include "hb_plant.hpp"
 
 using namespace hb;
 
@@ -259,6 +260,59 @@ __global__ void k_centroidal_state(int n, const DevModel* __restrict__ M, const 
   if (i < n) centroidal_state_from_rbd(*M, rbd + size_t(i) * HB_NRBD, x + size_t(i) * HB_NX);
 }
 
+// ---- plant stub: one wave per instance -----------------------------------------------------------------------------
+struct PlantBatch {
+  int B;
+  double *q, *v, *anchor;  // [B][16], [B][16], [B][12]
+  int* pinned;             // [B][4]
+  double *lambda, *vdot;   // [B][12], [B][16]
+  double* tau;             // [B][10] staging of host torques
+  int* contact;            // [B][4] staging of host contact flags
+  double* rbd;             // [B][32] repacked state
+  double baum, eps;
+};
+
+__global__ __launch_bounds__(64) void k_plant(PlantBatch p, const DevModel* __restrict__ M, const double* tau, const int* contact,
+                                               const int* mode, double dt, int substeps, double* res_rbd, double* res_x0,
+                                               double* res_t) {
+  const int i = blockIdx.x;
+  __shared__ double lds[PLANT_LDS_TOTAL];
+  __shared__ int cflag[HB_NC];
+  const DeviceCtx cx;
+  if (cx.lane < HB_NC) {
+    if (contact) cflag[cx.lane] = contact[4 * i + cx.lane];
+    else { bool cf[HB_NC]; mode_flags(mode[i], cf); cflag[cx.lane] = cf[cx.lane] ? 1 : 0; }
+  }
+  __syncthreads();
+  plant_step(cx, *M, p.q + 16 * i, p.v + 16 * i, p.anchor + 12 * i, p.pinned + 4 * i, tau + 10 * i, cflag, p.baum, p.eps, dt, substeps, lds,
+             p.lambda + 12 * i, p.vdot + 16 * i);
+  if (cx.lane == 0) {
+    const double* q = p.q + 16 * i;
+    const double* v = p.v + 16 * i;
+    double* rbd = p.rbd + HB_NRBD * i;
+    double sz, cz, sy, cy;
+    sincos_t(q[3], sz, cz);
+    sincos_t(q[4], sy, cy);
+    for (int a = 0; a < 3; ++a) { rbd[a] = q[3 + a]; rbd[3 + a] = q[a]; rbd[HB_NV + 3 + a] = v[a]; }
+    for (int j = 0; j < HB_NJ; ++j) { rbd[6 + j] = q[6 + j]; rbd[6 + HB_NV + j] = v[6 + j]; }
+    // omega_world = E(zyx) rates
+    rbd[HB_NV + 0] = -sz * v[4] + cy * cz * v[5];
+    rbd[HB_NV + 1] = cz * v[4] + cy * sz * v[5];
+    rbd[HB_NV + 2] = v[3] - sy * v[5];
+    if (res_rbd) {
+      for (int c = 0; c < HB_NRBD; ++c) res_rbd[HB_NRBD * i + c] = rbd[c];
+      centroidal_state_from_rbd(*M, rbd, res_x0 + HB_NX * i);
+      res_t[i] += dt;
+    }
+  }
+}
+__global__ void k_plant_reset(PlantBatch p, const DevModel* __restrict__ M) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.B) return;
+  plant_feet(*M, p.q + 16 * i, p.anchor + 12 * i);
+  for (int c = 0; c < HB_NC; ++c) p.pinned[4 * i + c] = 0;
+}
+
 // ---- joint command law: one thread per (instance, joint) ---------------------------------------------------------
 __global__ void k_joint_command(WbcBatch w, hb_joint_gains g, double dt, double* out /*[6][B][10]: posDes velDes kp kd ff torque*/) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,6 +460,8 @@ struct hb_ctx {
   int n_chunks = 1;
   hipStream_t s_chunk[8]{};
   double* jc_out = nullptr;  // joint command outputs [6][B][10]
+  PlantBatch plant{};
+  bool plant_ready = false;
   // reference generation (allocated on the first hb_refgen_reset)
   RefgenBatch rg{};
   hb_refgen_config rg_cfg{};
@@ -564,6 +620,85 @@ int32_t hb_joint_command(hb_ctx* ctx, const hb_joint_gains* gains, double dt, do
   for (int a = 0; a < 6; ++a)
     if (outs[a]) HB_HIP(hipMemcpyAsync(outs[a], ctx->jc_out + a * n, n * 8, hipMemcpyDeviceToHost, s));
   HB_HIP(hipStreamSynchronize(s));
+  return HB_OK;
+}
+
+int32_t hb_plant_reset(hb_ctx* ctx, const double* q0, const double* v0, double baumgarte, double eps) {
+  if (!ctx || !q0 || !(baumgarte >= 0.0) || !(eps >= 0.0)) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  const size_t B = ctx->B;
+  PlantBatch& p = ctx->plant;
+  if (!p.q) {
+    HB_HIP(dalloc(ctx, &p.q, B * 16));
+    HB_HIP(dalloc(ctx, &p.v, B * 16));
+    HB_HIP(dalloc(ctx, &p.anchor, B * 12));
+    HB_HIP(dalloc(ctx, &p.pinned, B * 4));
+    HB_HIP(dalloc(ctx, &p.lambda, B * 12));
+    HB_HIP(dalloc(ctx, &p.vdot, B * 16));
+    HB_HIP(dalloc(ctx, &p.tau, B * 10));
+    HB_HIP(dalloc(ctx, &p.contact, B * 4));
+    HB_HIP(dalloc(ctx, &p.rbd, B * HB_NRBD));
+    p.B = ctx->B;
+  }
+  p.baum = baumgarte;
+  p.eps = eps;
+  HB_HIP(hipMemcpy(p.q, q0, B * 16 * 8, hipMemcpyHostToDevice));
+  if (v0) HB_HIP(hipMemcpy(p.v, v0, B * 16 * 8, hipMemcpyHostToDevice));
+  else HB_HIP(hipMemset(p.v, 0, B * 16 * 8));
+  hipLaunchKernelGGL(k_plant_reset, dim3((ctx->B + 63) / 64), dim3(64), 0, ctx->s_wbc, p, ctx->dmodel);
+  HB_HIP(hipGetLastError());
+  HB_HIP(hipStreamSynchronize(ctx->s_wbc));
+  ctx->plant_ready = true;
+  return HB_OK;
+}
+
+int32_t hb_plant_step(hb_ctx* ctx, const double* tau, const int32_t* contact, double dt, int32_t substeps, int32_t to_resident) {
+  if (!ctx || !(dt > 0.0) || substeps < 1) return HB_ERR_ARG;
+  if (!ctx->plant_ready) {
+    ctx->err = "hb_plant_step: call hb_plant_reset first";
+    return HB_ERR_STATE;
+  }
+  if ((!tau && !ctx->jc_out) || (!contact && ctx->stats.n_wbc_solves == 0)) {
+    ctx->err = "hb_plant_step: no device-resident torque / contact flags yet (hb_joint_command after a WBC call)";
+    return HB_ERR_STATE;
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  const size_t B = ctx->B;
+  PlantBatch& p = ctx->plant;
+  hipStream_t s = ctx->s_wbc;  // the plant follows the control thread
+  if (tau) HB_HIP(hipMemcpyAsync(p.tau, tau, B * 10 * 8, hipMemcpyHostToDevice, s));
+  if (contact) HB_HIP(hipMemcpyAsync(p.contact, contact, B * 4 * sizeof(int), hipMemcpyHostToDevice, s));
+  const double* dtau = tau ? p.tau : ctx->jc_out + 5 * B * HB_NJ;
+  if (to_resident) {
+    // the resident observation feeds the next hb_mpc_solve(NULL) / hb_refgen_update(NULL) on the MPC stream
+    HB_HIP(hipEventRecord(ctx->ev[7], ctx->s_mpc));
+    HB_HIP(hipStreamWaitEvent(s, ctx->ev[7], 0));
+  }
+  hipLaunchKernelGGL(k_plant, dim3(ctx->B), dim3(64), 0, s, p, ctx->dmodel, dtau, contact ? p.contact : nullptr, ctx->w.mode, dt, substeps,
+                     to_resident ? ctx->w.rbd : nullptr, to_resident ? ctx->b.x0 : nullptr, to_resident ? ctx->w.t_now : nullptr);
+  HB_HIP(hipGetLastError());
+  if (to_resident) {
+    HB_HIP(hipEventRecord(ctx->ev[6], s));
+    HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev[6], 0));
+  }
+  return HB_OK;
+}
+
+int32_t hb_plant_get_state(hb_ctx* ctx, double* q, double* v, double* rbd, double* lambda, double* vdot) {
+  if (!ctx) return HB_ERR_ARG;
+  if (!ctx->plant_ready) {
+    ctx->err = "hb_plant_get_state: call hb_plant_reset first";
+    return HB_ERR_STATE;
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipStreamSynchronize(ctx->s_wbc));
+  const size_t B = ctx->B;
+  const PlantBatch& p = ctx->plant;
+  if (q) HB_HIP(hipMemcpy(q, p.q, B * 16 * 8, hipMemcpyDeviceToHost));
+  if (v) HB_HIP(hipMemcpy(v, p.v, B * 16 * 8, hipMemcpyDeviceToHost));
+  if (rbd) HB_HIP(hipMemcpy(rbd, p.rbd, B * HB_NRBD * 8, hipMemcpyDeviceToHost));
+  if (lambda) HB_HIP(hipMemcpy(lambda, p.lambda, B * 12 * 8, hipMemcpyDeviceToHost));
+  if (vdot) HB_HIP(hipMemcpy(vdot, p.vdot, B * 16 * 8, hipMemcpyDeviceToHost));
   return HB_OK;
 }
 
@@ -791,13 +926,13 @@ int32_t hb_mpc_set_references(hb_ctx* ctx, int32_t i0, int32_t cnt, const int32_
 }
 
 int32_t hb_mpc_reset(hb_ctx* ctx, const double* x0) {
-  if (!ctx || !x0) return HB_ERR_ARG;
+  if (!ctx) return HB_ERR_ARG;
   if (!ctx->refs_set) {
     ctx->err = "hb_mpc_reset: references not set";
     return HB_ERR_STATE;
   }
   HB_HIP(hipSetDevice(ctx->device));
-  HB_HIP(hipMemcpyAsync(ctx->b.x0, x0, size_t(ctx->B) * HB_NX * 8, hipMemcpyHostToDevice, ctx->s_mpc));
+  if (x0) HB_HIP(hipMemcpyAsync(ctx->b.x0, x0, size_t(ctx->B) * HB_NX * 8, hipMemcpyHostToDevice, ctx->s_mpc));
   hipLaunchKernelGGL(k_cold_start, dim3(ctx->Nmax + 1, ctx->B), dim3(64), 0, ctx->s_mpc, ctx->b, ctx->dmodel);
   HB_HIP(hipGetLastError());
   HB_HIP(hipStreamSynchronize(ctx->s_mpc));
@@ -953,7 +1088,7 @@ static int32_t wbc_launch(hb_ctx* ctx, bool from_policy, double dt) {
 
 int32_t hb_wbc_update(hb_ctx* ctx, const double* t_now, const double* rbd, const int32_t* walk_flag, double dt,
                       double* sol, double* x_des, double* u_des, int32_t* planned_mode, int32_t* status) {
-  if (!ctx || !t_now || !rbd) return HB_ERR_ARG;
+  if (!ctx || ((t_now == nullptr) != (rbd == nullptr))) return HB_ERR_ARG;
   if (!ctx->w.policy_valid) {
     ctx->err = "hb_wbc_update: no published policy (hb_mpc_publish)";
     return HB_ERR_STATE;
@@ -962,8 +1097,10 @@ int32_t hb_wbc_update(hb_ctx* ctx, const double* t_now, const double* rbd, const
   WbcBatch& w = ctx->w;
   hipStream_t s = ctx->s_wbc;
   HB_HIP(hipSetDevice(ctx->device));
-  HB_HIP(hipMemcpyAsync(w.t_now, t_now, B * 8, hipMemcpyHostToDevice, s));
-  HB_HIP(hipMemcpyAsync(w.rbd, rbd, B * HB_NRBD * 8, hipMemcpyHostToDevice, s));
+  if (t_now) {  // otherwise: the device-resident time / rbd (hb_set_resident_inputs, hb_estimator_update, hb_plant_step)
+    HB_HIP(hipMemcpyAsync(w.t_now, t_now, B * 8, hipMemcpyHostToDevice, s));
+    HB_HIP(hipMemcpyAsync(w.rbd, rbd, B * HB_NRBD * 8, hipMemcpyHostToDevice, s));
+  }
   if (walk_flag) HB_HIP(hipMemcpyAsync(w.walk, walk_flag, B * sizeof(int), hipMemcpyHostToDevice, s));
   int32_t rc = wbc_launch(ctx, true, dt);
   if (rc != HB_OK) return rc;

@@ -97,3 +97,50 @@ class DeviceLoop:
         self.tick += 1
         self.last = dict(out=out, cmd=cmd, contact=contact, x_obs=x_obs)
         return self.plant.q, self.plant.v
+
+
+class ResidentLoop:
+    """The same loop with the plant stub on the device too (hb_plant_step): nothing but the reference-generation time
+    stamps, the commands and the mode-schedule windows crosses PCIe."""
+
+    def __init__(self, solver, params: dict, gaits, cmd_vel, n_intervals: int = 100, mpc_every: int = 8, dt: float = 0.002,
+                 t_gait_start: float = 0.3, joint_ik: bool = True, substeps: int = 4, static_schedule_until: float = 0.0):
+        """static_schedule_until > 0: the mode schedules are uploaded once for [-1, static_schedule_until] (at most
+        HB_MAX_EVENTS events) instead of a sliding window per MPC call — no per-call host work for large batches."""
+        self.s, self.params, self.B = solver, params, solver.B
+        self.horizon = n_intervals * params["config"]["dt"]
+        self.dt, self.mpc_every, self.substeps = dt, mpc_every, substeps
+        self.cmd = np.ascontiguousarray(cmd_vel, dtype=float).reshape(self.B, 4)
+        self.gains = abi.make_joint_gains()
+        self.t, self.tick = 0.0, 0
+        solver.refgen_reset(abi.make_refgen_config(params, joint_ik=joint_ik))
+        self.schedules = [refgen.gait_schedule(params, g, t_gait_start, 1.0e3 if g == "stance" else 60.0) for g in gaits]
+        q0 = standing_configuration(params, self.B)
+        solver.plant_reset(q0)
+        # resident observation of the initial state
+        rbd = np.zeros((self.B, 32))
+        rbd[:, 0:3], rbd[:, 3:6], rbd[:, 6:16] = q0[:, 3:6], q0[:, 0:3], q0[:, 6:]
+        solver.set_resident_inputs(solver.centroidal_state_from_rbd(rbd), np.zeros(self.B), rbd)
+        self.started = False
+        self.static = static_schedule_until > 0.0
+        if self.static:
+            solver.refgen_set_schedule([schedule_window(ms, -1.0, static_schedule_until) for ms in self.schedules])
+
+    def step(self):
+        s = self.s
+        if self.tick % self.mpc_every == 0:
+            if not self.static:
+                s.refgen_set_schedule([schedule_window(ms, self.t - 1.0, self.t + self.horizon + 1.5) for ms in self.schedules])
+            status = s.refgen_update(np.full(self.B, self.t), self.horizon, None, self.cmd)
+            if status.max() != 0:
+                raise RuntimeError(f"reference generation failed: {status}")
+            if not self.started:
+                s.reset_resident()
+                self.started = True
+            s.mpc_solve(None)
+            s.publish()
+        s.wbc_update_resident(self.dt)
+        s.joint_command_resident(self.gains, self.dt)
+        s.plant_step(None, None, self.dt, self.substeps, to_resident=True)
+        self.t += self.dt
+        self.tick += 1

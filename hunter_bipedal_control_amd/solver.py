@@ -25,7 +25,8 @@ ABI_SYMBOLS = [
     "hb_get_wbc_solution", "hb_set_chunks",
     "hb_sync", "hb_get_stats", "hb_get_input_cost", "hb_version", "hb_eval_flow_map", "hb_eval_foot_kinematics",
     "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
-    "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd",
+    "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd", "hb_plant_reset", "hb_plant_step",
+    "hb_plant_get_state",
 ]
 
 
@@ -136,9 +137,10 @@ class HunterSolver:
         return perf
 
     # ---- WBC ------------------------------------------------------------------------------------
-    def wbc_update(self, t_now, rbd, walk_flag=None, dt=0.002):
-        t_now = _f64(t_now, (self.B,))
-        rbd = _f64(rbd, (self.B, 32))
+    def wbc_update(self, t_now=None, rbd=None, walk_flag=None, dt=0.002):
+        """t_now / rbd None: the device-resident time and rbd state."""
+        t_now = None if t_now is None else _f64(t_now, (self.B,))
+        rbd = None if rbd is None else _f64(rbd, (self.B, 32))
         walk = None if walk_flag is None else _i32(walk_flag, (self.B,))
         sol, xd, ud = np.zeros((self.B, 38)), np.zeros((self.B, 22)), np.zeros((self.B, 22))
         mode, status = np.zeros(self.B, dtype=np.int32), np.zeros(self.B, dtype=np.int32)
@@ -160,6 +162,35 @@ class HunterSolver:
         out = {k: np.zeros((self.B, 10)) for k in ("pos_des", "vel_des", "kp", "kd", "tau_ff", "torque")}
         self._check(self.lib.hb_joint_command(self.ctx, C.byref(gains), C.c_double(dt), *[_p(out[k]) for k in
                                               ("pos_des", "vel_des", "kp", "kd", "tau_ff", "torque")]), "hb_joint_command")
+        return out
+
+    def wbc_update_resident(self, dt=0.002):
+        """hb_wbc_update on the device-resident time / rbd, results left on the device."""
+        self._check(self.lib.hb_wbc_update(self.ctx, None, None, None, C.c_double(dt), None, None, None, None, None), "hb_wbc_update")
+
+    def joint_command_resident(self, gains: "abi.HbJointGains", dt=0.002):
+        self._check(self.lib.hb_joint_command(self.ctx, C.byref(gains), C.c_double(dt), None, None, None, None, None, None), "hb_joint_command")
+
+    def reset_resident(self):
+        """Cold start of the MPC iterate from the device-resident observation (hb_mpc_reset with x0 = NULL)."""
+        self._check(self.lib.hb_mpc_reset(self.ctx, None), "hb_mpc_reset")
+
+    # ---- plant stub (closed-loop rollouts) -----------------------------------------------------------------------------
+    def plant_reset(self, q0, v0=None, baumgarte=30.0, eps=1e-8):
+        v = None if v0 is None else _f64(v0, (self.B, 16))
+        self._check(self.lib.hb_plant_reset(self.ctx, _p(_f64(q0, (self.B, 16))), _p(v), C.c_double(baumgarte), C.c_double(eps)), "hb_plant_reset")
+
+    def plant_step(self, tau=None, contact=None, dt=0.002, substeps=4, to_resident=False):
+        tau = None if tau is None else _f64(tau, (self.B, 10))
+        contact = None if contact is None else _i32(contact, (self.B, 4))
+        self._check(self.lib.hb_plant_step(self.ctx, _p(tau), _p(contact), C.c_double(dt), C.c_int32(substeps), C.c_int32(1 if to_resident else 0)),
+                    "hb_plant_step")
+
+    def plant_state(self):
+        out = dict(q=np.zeros((self.B, 16)), v=np.zeros((self.B, 16)), rbd=np.zeros((self.B, 32)), lam=np.zeros((self.B, 12)),
+                   vdot=np.zeros((self.B, 16)))
+        self._check(self.lib.hb_plant_get_state(self.ctx, _p(out["q"]), _p(out["v"]), _p(out["rbd"]), _p(out["lam"]), _p(out["vdot"])),
+                    "hb_plant_get_state")
         return out
 
     # ---- device-resident stepping -----------------------------------------------------------------

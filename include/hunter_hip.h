@@ -137,7 +137,7 @@ int32_t hb_mpc_set_references(hb_ctx* ctx, int32_t inst_begin, int32_t inst_coun
                               const double* swing_ref);
 
 /* Cold start: x_k = x0, u_k = weight compensation of mode_k (LeggedRobotInitializer.cpp:67-77). */
-int32_t hb_mpc_reset(hb_ctx* ctx, const double* x0 /*[batch][22]*/);
+int32_t hb_mpc_reset(hb_ctx* ctx, const double* x0 /*[batch][22], or NULL: the device-resident observation*/);
 /* Warm start from caller-provided trajectories (x [batch][max_nodes+1][22], u [batch][max_nodes][22]). */
 int32_t hb_mpc_set_trajectory(hb_ctx* ctx, const double* x, const double* u);
 
@@ -161,7 +161,8 @@ int32_t hb_mpc_get_performance(hb_ctx* ctx, double* perf /*[batch][4]*/);
  * unless walk_flag[i]==0, in which case the stand-still target of LeggedController.cpp:161-173 is used;
  * then runs WbcBase::update + WeightedWbc::update (legged_wbc/src/WeightedWbc.cpp:18-66) or
  * HierarchicalWbc::update (legged_wbc/src/HierarchicalWbc.cpp:18-30) for every instance.
- * Host in: t_now[batch], rbd[batch][32], walk_flag[batch] (NULL = all walking).
+ * Host in: t_now[batch], rbd[batch][32] (both NULL: the device-resident time / rbd), walk_flag[batch] (NULL = all
+ * walking).
  * Host out (any may be NULL): sol[batch][38], x_des[batch][22], u_des[batch][22], planned_mode[batch],
  * status[batch].  Synchronous with respect to the WBC stream when an output pointer is given. */
 int32_t hb_wbc_update(hb_ctx* ctx, const double* t_now, const double* rbd, const int32_t* walk_flag,
@@ -188,6 +189,25 @@ typedef struct hb_joint_gains {
 } hb_joint_gains;
 int32_t hb_joint_command(hb_ctx* ctx, const hb_joint_gains* gains, double dt, double* pos_des, double* vel_des,
                          double* kp, double* kd, double* tau_ff, double* torque);
+
+/* ---- plant stub for closed-loop rollouts ---------------------------------------------------
+ * The reference closes its loop through Gazebo / MuJoCo (legged_gazebo/src/LeggedHWSim.cpp:166-192,
+ * mujoco/src/main.cc:247).  This stub integrates M(q) vdot + nle = S' tau + Jc' lambda with the contact points of the
+ * commanded mode pinned by acceleration-level constraints (Baumgarte gain `baumgarte`, damped normal equations with
+ * relative damping `eps`), semi-implicit Euler; it does NOT enforce unilateral contact or friction limits.
+ * Coordinates: q = [pos, zyx, joints], v = [v_lin (world), ZYX rates, joint rates]. */
+int32_t hb_plant_reset(hb_ctx* ctx, const double* q0 /*[batch][16]*/, const double* v0 /*[batch][16] or NULL*/,
+                       double baumgarte, double eps);
+/* Advance every instance by dt in `substeps` substeps.  tau[batch][10] / contact[batch][4] may be NULL: the torque of the
+ * last hb_joint_command and the planned contact flags of the last WBC call, still on the device, are used.
+ * to_resident != 0 repacks the new state as rbd + MPC observation into the resident inputs and advances the resident time
+ * by dt, so that hb_refgen_update(x_now = NULL), hb_mpc_solve(NULL), hb_wbc_update(t_now = NULL, rbd = NULL),
+ * hb_joint_command and hb_plant_step(NULL, NULL) close the loop without a host round trip. */
+int32_t hb_plant_step(hb_ctx* ctx, const double* tau, const int32_t* contact, double dt, int32_t substeps,
+                      int32_t to_resident);
+/* State to the host (any may be NULL): q[batch][16], v[batch][16], rbd[batch][32], lambda[batch][12] (last contact
+ * forces), vdot[batch][16] (last acceleration). */
+int32_t hb_plant_get_state(hb_ctx* ctx, double* q, double* v, double* rbd, double* lambda, double* vdot);
 
 /* ---- device-resident stepping (bench / rollouts; inputs already in HBM) ------------------------
  * hb_step_resident runs hb_mpc_solve(NULL) + hb_mpc_publish + WBC on device-resident t_now/rbd that

@@ -192,3 +192,15 @@ int emu_refgen(const hb_model* m, const hb::RefgenConfig* k, int n_ev, const dou
                          xref, swing);
 }
 }
+
+#include "../../hunter_bipedal_control_amd/csrc/hb_plant.hpp"
+extern "C" {
+// one plant tick of the device code on one emulated lane; q[16], v[16], anchor[12], pinned[4] in/out
+void emu_plant_step(const hb_model* m, double* q, double* v, double* anchor, int* pinned, const double* tau, const int* contact,
+                    double baum, double eps, double dt, int substeps, double* lambda, double* vdot) {
+  DevModel d = make_dev_model(*m);
+  HostCtx cx;
+  std::vector<double> lds(PLANT_LDS_TOTAL, 0.0);
+  plant_step(cx, d, q, v, anchor, pinned, tau, contact, baum, eps, dt, substeps, lds.data(), lambda, vdot);
+}
+}

@@ -76,3 +76,54 @@ def test_device_closed_loop_with_the_state_estimator_in_the_loop(params):
     assert np.isfinite(q).all() and (np.abs(q[:, 2] - 0.63) < 0.04).all() and np.abs(q[:, 4:6]).max() < 0.15
     assert abs(q[0, 0] - 0.2 * 1.2) < 0.1 and abs(q[1, 0]) < 0.05
     assert err_p < 0.03 and err_v < 0.15, (err_p, err_v)
+
+
+@pytest.mark.gpu
+def test_device_plant_matches_numpy_plant_and_resident_loop_trots(params):
+    """hb_plant_step vs plant.py on the same torque sequence; then the fully device-resident loop (plant included) against
+    the loop with the host-side plant."""
+    from hunter_bipedal_control_amd.plant import Plant
+    from hunter_bipedal_control_amd.rollout import DeviceLoop, ResidentLoop, standing_configuration
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B = 4
+    rng = np.random.default_rng(3)
+    s = HunterSolver(params, batch=B, max_nodes=108)
+    try:
+        q0 = standing_configuration(params, B)
+        q0[:, 3:6] = 0.03 * rng.standard_normal((B, 3))
+        v0 = 0.05 * rng.standard_normal((B, 16))
+        zeros_u = np.zeros((B, 22))
+
+        def foot_fn(q):
+            x = np.zeros((q.shape[0], 22))
+            x[:, 6:9], x[:, 9:12], x[:, 12:] = q[:, 0:3], q[:, 3:6], q[:, 6:]
+            return s.eval_foot_kinematics(x, zeros_u[:q.shape[0]])[0]
+
+        host = Plant(lambda rbd: s.eval_rbd(rbd), foot_fn, q0.copy(), v0.copy())
+        s.plant_reset(q0, v0)
+        for tick in range(10):
+            contact = np.tile([1, 1, 1, 1] if tick < 4 else [0, 1, 0, 1], (B, 1)).astype(np.int32)
+            tau = 3.0 * rng.standard_normal((B, 10))
+            host.step(tau, contact.astype(bool), 0.002, substeps=4)
+            s.plant_step(tau, contact, 0.002, 4)
+            st = s.plant_state()
+            assert np.abs(st["q"] - host.q).max() < 1e-10 and np.abs(st["v"] - host.v).max() < 1e-8, tick
+            assert np.abs(st["rbd"] - host.rbd()).max() < 1e-8
+    finally:
+        s.close()
+    cmds = np.array([[0.2, 0.0, 0.0, 0.0], [0.3, 0.0, 0.0, 0.0], [0.15, 0.08, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0]])
+    gaits = ["trot", "trot", "trot", "stance"]
+    finals = []
+    for resident in (True, False):
+        s = HunterSolver(params, batch=B, max_nodes=108)
+        try:
+            loop = (ResidentLoop if resident else DeviceLoop)(s, params, gaits, cmds)
+            for k in range(600):                               # 1.2 s
+                loop.step()
+            finals.append(s.plant_state()["q"] if resident else loop.plant.q.copy())
+        finally:
+            s.close()
+    q_res, q_host = finals
+    assert np.isfinite(q_res).all() and (np.abs(q_res[:, 2] - 0.63) < 0.04).all() and np.abs(q_res[:, 4:6]).max() < 0.15
+    assert np.abs(q_res[:3, 0] - cmds[:3, 0] * 0.9).max() < 0.1 and abs(q_res[3, 0]) < 0.05
+    assert np.abs(q_res - q_host).max() < 5e-3          # same loop, plant on the device vs on the host

@@ -183,3 +183,37 @@ def test_device_reference_generation_matches_host_reference_manager(params, emu)
             # joint references: same damped iteration, QR least squares instead of LAPACK/SVD -> rounding-level differences
             assert np.abs(got["x_ref"][:, 12:] - ref["x_ref"][:, 12:]).max() < 1e-9, (gait, ik, np.abs(got["x_ref"] - ref["x_ref"]).max())
             assert np.abs(got["swing"] - ref["swing"]).max() < 1e-10, (gait, np.abs(got["swing"] - ref["swing"]).max())
+
+
+def test_device_plant_step_matches_numpy_plant(params, oracle, emu):
+    """csrc/hb_plant.hpp vs plant.py (numpy, rigid-body terms from the oracle) over a short torque-driven sequence with
+    a contact switch."""
+    from hunter_bipedal_control_amd.plant import Plant
+    from hunter_bipedal_control_amd.rollout import standing_configuration
+    lib, mdl, cfg = emu
+    rng = np.random.default_rng(12)
+
+    def foot_fn(q):
+        out = np.zeros((q.shape[0], 4, 3))
+        for i in range(q.shape[0]):
+            x = np.zeros(22)
+            x[6:9], x[9:12], x[12:] = q[i, 0:3], q[i, 3:6], q[i, 6:]
+            out[i] = refgen.foot_positions(params["model"], x)
+        return out
+
+    q0 = standing_configuration(params, 1)
+    q0[0, 3:6] = [0.05, -0.02, 0.03]
+    v0 = 0.05 * rng.standard_normal((1, 16))
+    pl = Plant(lambda rbd: oracle.rbd(rbd), foot_fn, q0.copy(), v0.copy())
+    q, v = q0[0].copy(), v0[0].copy()
+    anchor = foot_fn(q0)[0].reshape(12).copy()
+    pinned = np.zeros(4, dtype=np.int32)
+    lam, vdot = np.zeros(12), np.zeros(16)
+    for tick in range(12):
+        contact = np.array([1, 1, 1, 1] if tick < 5 else [1, 0, 1, 0], dtype=np.int32)
+        tau = 3.0 * rng.standard_normal(10)
+        pl.step(tau[None], contact[None].astype(bool), 0.002, substeps=4)
+        lib.emu_plant_step(C.byref(mdl), _p(q), _p(v), _p(anchor), _p(pinned), _p(tau), _p(contact), C.c_double(30.0), C.c_double(1e-8),
+                           C.c_double(0.002), C.c_int(4), _p(lam), _p(vdot))
+        assert np.abs(q - pl.q[0]).max() < 1e-10 and np.abs(v - pl.v[0]).max() < 1e-8, tick
+        assert np.abs(lam - pl.last_lambda[0]).max() < 1e-6 * max(1.0, np.abs(lam).max())

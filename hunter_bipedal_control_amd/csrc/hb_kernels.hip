@@ -170,7 +170,12 @@ __global__ __launch_bounds__(64, 2) void k_ls_eval(Batch b, const DevModel* __re
   if (b.accepted[inst] || k >= b.n_nodes[inst]) return;
   const size_t nd = size_t(inst) * b.Nmax + k;
   const size_t xo = (size_t(inst) * (b.Nmax + 1) + k) * HB_NX;
-  double x[HB_NX], xn[HB_NX], u[HB_NU];
+  // trial point in LDS (stride 67: conflict-free): thread-private arrays would be indexed by the rolled joint loops of
+  // the model and live in scratch
+  __shared__ double tp[64 * 67];
+  double* x = tp + threadIdx.x * 67;
+  double* xn = x + HB_NX;
+  double* u = xn + HB_NX;
 #pragma unroll
   for (int i = 0; i < HB_NX; ++i) {
     x[i] = b.x[xo + i] + alpha * b.dx[xo + i];

@@ -58,8 +58,18 @@ HB_HD Sym3<double> sym_from(const double* I) {
   return s;
 }
 
+// per-leg work arrays of body_pass: indexed by the joint loops, so wherever they live is addressed dynamically — the
+// kernels place them (and the BodyPass results) in LDS; as thread-private arrays they sit in scratch memory
+struct BodyWork {
+  Vec3<double> c[5], F[5], N[5];
+  double mb[5];
+  Sym3<double> Iw[5];
+};
+
 // q = [pos(3) zyx(3) joints(10)], v = qdot.  Accelerations are evaluated at qddot = 0.
-HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPass& P) {
+HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPass& P, BodyWork* work = nullptr) {
+  BodyWork local_work;
+  BodyWork& Wk = work ? *work : local_work;
   double sz, cz, sy, cy, sx, cx;
   sincos_t(q[3], sz, cz);
   sincos_t(q[4], sy, cy);
@@ -98,9 +108,11 @@ HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPa
     Mat3<double> R = R0;
     Vec3<double> op;                       // parent origin minus base origin
     Vec3<double> w = P.omega0, al = P.alpha0, ao = grav, vo = v0;
-    Vec3<double> c[5], F[5], N[5];
-    double mb[5];
-    Sym3<double> Iw[5];
+    Vec3<double>* c = Wk.c;
+    Vec3<double>* F = Wk.F;
+    Vec3<double>* N = Wk.N;
+    double* mb = Wk.mb;
+    Sym3<double>* Iw = Wk.Iw;
     for (int k = 0; k < 5; ++k) {
       const int j = 5 * leg + k, b = j + 1;
       const Vec3<double> r = R * Vec3<double>(M.origin[j][0], M.origin[j][1], M.origin[j][2]);
@@ -279,11 +291,23 @@ HB_HD int sparse_row(const WbcCons& wc, const DevConfig& C, int cid, int* idx, d
 // MPC state/input, EoM rows and the dense cost rows [swing legs (weight w_swing) ; base acceleration (weight w_base)]
 // or, in stance mode, qdd_base = 0.  Rm is a 16x16 scratch.  Jc/dJv (optional) receive the contact Jacobians (12x16)
 // and bias accelerations (12).
+struct PhaseAWork {
+  BodyPass P, D;
+  BodyWork W;
+  double q[HB_NV], v[HB_NV], qd[HB_NV], vd[HB_NV];
+};
+constexpr int PHASE_A_WORK_DOUBLES = (sizeof(PhaseAWork) + 7) / 8;
+
+// `ws` (optional, PHASE_A_WORK_DOUBLES doubles, e.g. an LDS buffer that is not live yet) holds the rigid-body results
+// and work arrays; without it they are thread-private (scratch).
 HB_HD void wbc_phase_a(const DevModel& M, const DevConfig& C, const double* xdes, const double* udes, const double* rbd,
                        const WbcCons& wc, bool stance_mode, double w_swing, double w_base, double* Rm, double* Ee,
-                       double* beom, double* Aw, double* bw, double* Jc, double* dJv) {
+                       double* beom, double* Aw, double* bw, double* Jc, double* dJv, double* ws = nullptr) {
+  PhaseAWork local_ws;
+  PhaseAWork& K = ws ? *reinterpret_cast<PhaseAWork*>(ws) : local_ws;
   {
-    double q[HB_NV], v[HB_NV];
+    double* q = K.q;
+    double* v = K.v;
     for (int i = 0; i < 3; ++i) {
       q[i] = rbd[3 + i];
       q[3 + i] = rbd[i];
@@ -300,8 +324,8 @@ HB_HD void wbc_phase_a(const DevModel& M, const DevConfig& C, const double* xdes
       const Vec3<double> er = euler_rates_from_omega<double>(sz, cz, sy, cy, Vec3<double>(rbd[HB_NV], rbd[HB_NV + 1], rbd[HB_NV + 2]));
       v[3] = er.x; v[4] = er.y; v[5] = er.z;
     }
-    BodyPass P;
-    body_pass(M, q, v, P);
+    BodyPass& P = K.P;
+    body_pass(M, q, v, P, &K.W);
     // EoM rows: [M, -J', -S'] x = -nle   (WbcBase.cpp:138-149)
     mass_matrix(P, Rm);  // stage M in the R buffer (16x16)
     for (int i = 0; i < 16; ++i) {
@@ -333,13 +357,14 @@ HB_HD void wbc_phase_a(const DevModel& M, const DevConfig& C, const double* xdes
       // desired kinematics (WbcBase.cpp:122-136)
       Centroidal<double> cd;
       centroidal_eval<double>(M, xdes + 9, xdes + 12, xdes, udes + 12, cd);
-      double qd_[HB_NV], vd_[HB_NV];
+      double* qd_ = K.qd;
+      double* vd_ = K.vd;
       for (int i = 0; i < HB_NV; ++i) qd_[i] = xdes[6 + i];
       vd_[0] = cd.v_lin.x; vd_[1] = cd.v_lin.y; vd_[2] = cd.v_lin.z;
       vd_[3] = cd.euler_rate.x; vd_[4] = cd.euler_rate.y; vd_[5] = cd.euler_rate.z;
       for (int j = 0; j < HB_NJ; ++j) vd_[6 + j] = udes[12 + j];
-      BodyPass D;
-      body_pass(M, qd_, vd_, D);
+      BodyPass& D = K.D;
+      body_pass(M, qd_, vd_, D, &K.W);
       // base acceleration desired: A_b qdd_b = m hdot_norm(x,u) - Adot v   (zero joint accelerations)
       const Vec3<double> comr = (1.0 / D.mass) * D.mc;
       Vec3<double> fs, ms;
@@ -425,7 +450,8 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
 
   // ------------------------------------------------------------------ phase A: rigid-body quantities (lane 0)
   if (cx.lane == 0) {
-    wbc_phase_a(M, C, xdes, udes, rbd, wc, stance_mode, C.w_swing, C.w_base, Rm, Ee, beom, Aw, bw, nullptr, nullptr);
+    static_assert(PHASE_A_WORK_DOUBLES <= NW * NW, "phase-A workspace must fit the J buffer");
+    wbc_phase_a(M, C, xdes, udes, rbd, wc, stance_mode, C.w_swing, C.w_base, Rm, Ee, beom, Aw, bw, nullptr, nullptr, Jm);
     misc[0] = 0.0;  // status
   }
   cx.sync();

@@ -384,13 +384,18 @@ __global__ __launch_bounds__(64) void k_refgen(Batch b, RefgenBatch r, const Dev
                             r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX);
 }
 // joint-reference IK: one thread per (instance, leg)
-__global__ __launch_bounds__(64) void k_refgen_ik(Batch b, RefgenBatch r, const DevModel* __restrict__ M, hb_refgen_config K, double horizon) {
+constexpr int RG_IK_BLOCK = 32;  // threads per block: one LDS work area each (60 KB per block)
+__global__ __launch_bounds__(RG_IK_BLOCK) void k_refgen_ik(Batch b, RefgenBatch r, const DevModel* __restrict__ M, hb_refgen_config K,
+                                                             double horizon) {
+  static_assert(sizeof(RgIkWork) % 8 == 0, "work area is a whole number of doubles");
+  __shared__ double work_raw[RG_IK_BLOCK * (sizeof(RgIkWork) / 8)];
+  RgIkWork* work = reinterpret_cast<RgIkWork*>(work_raw);
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid >> 1, leg = gid & 1;
   if (i >= b.B) return;
   refgen_ik_leg(*M, K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.t0[i], horizon, b.x0 + size_t(i) * HB_NX,
                 r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, r.n_knots[i], r.knot_t + size_t(i) * RG_MAX_KNOTS,
-                r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX, leg);
+                r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX, leg, work[threadIdx.x]);
 }
 // node tables: one thread per (instance, node), consecutive lanes = consecutive nodes of one instance
 __global__ __launch_bounds__(64) void k_refgen_nodes(Batch b, RefgenBatch r, hb_refgen_config K) {
@@ -783,7 +788,8 @@ int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const do
   if (x_now) HB_HIP(hipMemcpyAsync(ctx->b.x0, x_now, B * HB_NX * 8, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_refgen, dim3((ctx->B + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
   if (ctx->rg_cfg.joint_ik)
-    hipLaunchKernelGGL(k_refgen_ik, dim3((2 * ctx->B + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
+    hipLaunchKernelGGL(k_refgen_ik, dim3((2 * ctx->B + RG_IK_BLOCK - 1) / RG_IK_BLOCK), dim3(RG_IK_BLOCK), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg,
+                       horizon);
   hipLaunchKernelGGL(k_refgen_nodes, dim3((ctx->B * ctx->Nmax + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->rg_cfg);
   HB_HIP(hipGetLastError());
   r.init_stance = 0;

@@ -120,12 +120,27 @@ HB_HD void rg_make_target(const RefgenConfig& K, double t0, double horizon, cons
 // ---- joint reference by inverse kinematics (InverseKinematics.cpp:20-231 as restated in refgen.py) -----------------
 constexpr int RG_MAX_KNOTS = 24;  // targets resampled every 0.15 s: timeHorizon 3.0 s -> 21 knots; the last two slots hold the 2-knot target
 
+// Work arrays of the IK of one (instance, leg).  They are indexed by loop counters, so as thread-private arrays they sit in
+// scratch memory; the kernel gives every thread one of these in LDS instead.
+struct RgIkWork {
+  double Jl[3][5], Ja[3][5];
+  double a[5][5], Bm[5][5], Qt[5][5], at[5][5];
+  double v[5], y[5], z[5], hv[5];
+  double qn[HB_NV], qref[HB_NV];
+  Vec3<double> ax[5], org[5];
+  int perm[5], perm2[5];
+  double pad;  // odd number of doubles per thread: consecutive threads start in different LDS banks
+};
+
 // Contact f1 of `leg` at q16 = [pos, zyx, joints]: position, foot rotation, linear (world-aligned) and angular (LOCAL)
 // Jacobians with respect to the leg's five joints.
-HB_HD void rg_leg_kin(const DevModel& M, const double* q16, int leg, Vec3<double>& foot, Mat3<double>& Rf, double Jl[3][5], double Ja[3][5]) {
+HB_HD void rg_leg_kin(const DevModel& M, const double* q16, int leg, Vec3<double>& foot, Mat3<double>& Rf, RgIkWork& W) {
+  double (*Jl)[5] = W.Jl;
+  double (*Ja)[5] = W.Ja;
+  Vec3<double>* ax = W.ax;
+  Vec3<double>* org = W.org;
   Mat3<double> R = rg_rot_zyx(q16 + 3);
   Vec3<double> p(q16[0], q16[1], q16[2]);
-  Vec3<double> ax[5], org[5];
   for (int k = 0; k < 5; ++k) {
     const int j = 5 * leg + k;
     p = p + R * Vec3<double>(M.origin[j][0], M.origin[j][1], M.origin[j][2]);
@@ -143,7 +158,7 @@ HB_HD void rg_leg_kin(const DevModel& M, const double* q16, int leg, Vec3<double
 }
 // Householder QR with column pivoting of an m x n matrix (m, n <= 5), in place: R in the upper triangle, pivots in
 // perm; every reflector is also applied to the m x nb block Bm (right-hand sides, or the identity to accumulate Q').
-HB_HD void rg_qrcp(int m, int n, double a[5][5], int* perm, int nb, double Bm[5][5]) {
+HB_HD void rg_qrcp(int m, int n, double a[5][5], int* perm, int nb, double Bm[5][5], double* v) {
   for (int j = 0; j < n; ++j) perm[j] = j;
   const int steps = m < n ? m : n;
   for (int j = 0; j < steps; ++j) {
@@ -161,7 +176,6 @@ HB_HD void rg_qrcp(int m, int n, double a[5][5], int* perm, int nb, double Bm[5]
     const double nrm = sqrt(best);
     if (!(nrm > 0.0)) continue;
     const double alpha = a[j][j] > 0.0 ? -nrm : nrm;
-    double v[5];
     double vv = 0.0;
     for (int r = j; r < m; ++r) { v[r] = a[r][j] - (r == j ? alpha : 0.0); vv += v[r] * v[r]; }
     if (!(vv > 0.0)) continue;
@@ -182,11 +196,11 @@ HB_HD void rg_qrcp(int m, int n, double a[5][5], int* perm, int nb, double Bm[5]
 }
 // Eigen::ColPivHouseholderQR::solve with setThreshold(thr): basic solution of the numerically full-rank leading block,
 // free variables zero.  A is m x n (destroyed), b has m entries.
-HB_HD void rg_colpiv_solve(int m, int n, double a[5][5], const double* b, double thr, double* y) {
-  int perm[5];
-  double Bm[5][5];
+HB_HD void rg_colpiv_solve(int m, int n, double a[5][5], const double* b, double thr, double* y, RgIkWork& W) {
+  int* perm = W.perm;
+  double (*Bm)[5] = W.Bm;
   for (int r = 0; r < m; ++r) Bm[r][0] = b[r];
-  rg_qrcp(m, n, a, perm, 1, Bm);
+  rg_qrcp(m, n, a, perm, 1, Bm, W.hv);
   const int steps = m < n ? m : n;
   int rank = 0;
   const double d0 = fabs(a[0][0]);
@@ -194,7 +208,7 @@ HB_HD void rg_colpiv_solve(int m, int n, double a[5][5], const double* b, double
     for (int i = 0; i < steps; ++i)
       if (fabs(a[i][i]) > thr * d0) ++rank;
   for (int i = 0; i < n; ++i) y[i] = 0.0;
-  double z[5];
+  double* z = W.z;
   for (int i = rank - 1; i >= 0; --i) {
     double sacc = Bm[i][0];
     for (int k = i + 1; k < rank; ++k) sacc -= a[i][k] * z[k];
@@ -212,12 +226,13 @@ HB_HD Vec3<double> rg_log3(const Mat3<double>& R) {
 // InverseKinematics::computeIK: translation IK then rotation IK in the null space of the position Jacobian; both share
 // the damped iteration (step 0.7, at most 5 iterations, stop on small error 0.01, stagnation 1e-3 or error increase;
 // joint limits clamp every iterate).  q16 is updated in place for joints 5 leg .. 5 leg + 4.
-HB_HD void rg_compute_ik(const DevModel& M, double* q16, int leg, const Vec3<double>& des, const Mat3<double>& Rdes) {
+HB_HD void rg_compute_ik(const DevModel& M, double* q16, int leg, const Vec3<double>& des, const Mat3<double>& Rdes, RgIkWork& W) {
+  double (*Jl)[5] = W.Jl;
+  double (*Ja)[5] = W.Ja;
   for (int stage = 0; stage < 2; ++stage) {
     Vec3<double> foot;
     Mat3<double> Rf;
-    double Jl[3][5], Ja[3][5];
-    rg_leg_kin(M, q16, leg, foot, Rf, Jl, Ja);
+    rg_leg_kin(M, q16, leg, foot, Rf, W);
     auto error = [&](const Vec3<double>& f, const Mat3<double>& R) {
       if (stage == 0) return f - des;
       Mat3<double> Rt;  // Rdes' R
@@ -229,51 +244,51 @@ HB_HD void rg_compute_ik(const DevModel& M, double* q16, int leg, const Vec3<dou
     double last = sqrt(dot(err, err));
     if (last < 0.01) continue;
     for (int it = 0; it < 5; ++it) {
-      double v[5];
+      double* v = W.v;
+      double (*a)[5] = W.a;
+      double* y = W.y;
       const double eb[3] = {err.x, err.y, err.z};
       if (stage == 0) {
-        double a[5][5];
         for (int r = 0; r < 3; ++r)
           for (int c = 0; c < 5; ++c) a[r][c] = Jl[r][c];
-        double y[5];
-        rg_colpiv_solve(3, 5, a, eb, 0.01, y);
+        rg_colpiv_solve(3, 5, a, eb, 0.01, y, W);
         for (int c = 0; c < 5; ++c) v[c] = -y[c];
       } else {
         // orthonormal basis of null(Jl): trailing columns of Q from the pivoted QR of Jl' (5 x 3)
-        double at[5][5], Qt[5][5];
-        int perm[5];
+        double (*at)[5] = W.at;
+        double (*Qt)[5] = W.Qt;
+        int* perm = W.perm2;
         for (int r = 0; r < 5; ++r) {
           for (int c = 0; c < 3; ++c) at[r][c] = Jl[c][r];
           for (int c = 0; c < 5; ++c) Qt[r][c] = r == c ? 1.0 : 0.0;
         }
-        rg_qrcp(5, 3, at, perm, 5, Qt);  // Qt = Q'
+        rg_qrcp(5, 3, at, perm, 5, Qt, W.hv);  // Qt = Q'
         int rank = 0;
         const double d0 = fabs(at[0][0]);
         if (d0 > 0.0)
           for (int i = 0; i < 3; ++i)
             if (fabs(at[i][i]) > 1e-12 * d0) ++rank;
         const int nd = 5 - rank;  // null-space dimension; basis vectors are rows rank .. 4 of Q'
-        double a[5][5], y[5];
         for (int r = 0; r < 3; ++r)
           for (int c = 0; c < nd; ++c) {
             double sacc = 0.0;
             for (int k = 0; k < 5; ++k) sacc += Ja[r][k] * Qt[rank + c][k];
             a[r][c] = sacc;
           }
-        rg_colpiv_solve(3, nd, a, eb, 0.01, y);
+        rg_colpiv_solve(3, nd, a, eb, 0.01, y, W);
         for (int k = 0; k < 5; ++k) {
           double sacc = 0.0;
           for (int c = 0; c < nd; ++c) sacc += Qt[rank + c][k] * y[c];
           v[k] = -sacc;
         }
       }
-      double qn[HB_NV];
+      double* qn = W.qn;
       for (int i = 0; i < HB_NV; ++i) qn[i] = q16[i];
       for (int k = 0; k < 5; ++k) {
         const int j = 5 * leg + k;
         qn[6 + j] = fmin(M.q_upper[j], fmax(M.q_lower[j], q16[6 + j] + 0.7 * v[k]));
       }
-      rg_leg_kin(M, qn, leg, foot, Rf, Jl, Ja);
+      rg_leg_kin(M, qn, leg, foot, Rf, W);
       err = error(foot, Rf);
       const double nn = sqrt(dot(err, err));
       if (nn > last || fabs(nn - last) < 1e-3) break;
@@ -405,7 +420,7 @@ HB_HD int refgen_plan(const DevModel& M, const RefgenConfig& K, int n_ev, const 
 // Knots of the resampled target with IK joint references for one leg (the two legs are independent kinematic chains, so
 // they run as separate threads): leg 0 also writes the knot times and the non-joint part of the knot states.
 HB_HD void refgen_ik_leg(const DevModel& M, const RefgenConfig& K, int n_ev, const double* ev, double t0, double horizon, const double* x_now,
-                         const double* phases, int nk, double* knot_t, double* knot_x, int leg) {
+                         const double* phases, int nk, double* knot_t, double* knot_x, int leg, RgIkWork& W) {
   if (nk <= 2) return;
   RgTarget T;
   T.t0 = t0;
@@ -413,7 +428,7 @@ HB_HD void refgen_ik_leg(const DevModel& M, const RefgenConfig& K, int n_ev, con
   T.cur = knot_x + size_t(RG_MAX_KNOTS - 2) * HB_NX;
   T.tgt = knot_x + size_t(RG_MAX_KNOTS - 1) * HB_NX;
   const Mat3<double> Rdes = rg_rot_zyx(x_now + 9);
-  double qref[HB_NV];
+  double* qref = W.qref;
   for (int j = 0; j < HB_NJ; ++j) qref[6 + j] = K.default_joints[j];
   const double step = (T.tf - t0) / (nk - 1);
   for (int i = 0; i < nk; ++i) {
@@ -429,7 +444,7 @@ HB_HD void refgen_ik_leg(const DevModel& M, const RefgenConfig& K, int n_ev, con
     if (idx > n_ev) idx = n_ev;
     double sw[6];
     rg_phase_eval(K, phases + (size_t(leg) * (RG_MAX_EVENTS + 1) + idx) * RG_PHASE, ti, sw);
-    rg_compute_ik(M, qref, leg, Vec3<double>(sw[0], sw[1], sw[2]), Rdes);  // warm start: previous knot's solution
+    rg_compute_ik(M, qref, leg, Vec3<double>(sw[0], sw[1], sw[2]), Rdes, W);  // warm start: previous knot's solution
     for (int k = 0; k < 5; ++k) xk[12 + 5 * leg + k] = qref[6 + 5 * leg + k];
   }
 }
@@ -471,7 +486,8 @@ HB_HD int refgen_instance(const DevModel& M, const RefgenConfig& K, int n_ev, co
   double knot_t[RG_MAX_KNOTS], knot_x[RG_MAX_KNOTS * HB_NX];
   const int status = refgen_plan(M, K, n_ev, ev, modes, t0, horizon, x_now, cmd_vel, latest_stance, phases, max_nodes, n_nodes_out, t_out,
                                  &nk, knot_t, knot_x);
-  for (int leg = 0; leg < 2; ++leg) refgen_ik_leg(M, K, n_ev, ev, t0, horizon, x_now, phases, nk, knot_t, knot_x, leg);
+  RgIkWork work;
+  for (int leg = 0; leg < 2; ++leg) refgen_ik_leg(M, K, n_ev, ev, t0, horizon, x_now, phases, nk, knot_t, knot_x, leg, work);
   for (int k = 0; k < max_nodes; ++k)
     refgen_node(K, n_ev, ev, modes, nk, knot_t, knot_x, phases, k, *n_nodes_out, t_out[k], mode_out + k, xref_out + size_t(k) * HB_NX,
                 swing_out + size_t(k) * HB_NC * HB_SWING_REF);

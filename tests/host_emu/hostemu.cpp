@@ -193,6 +193,17 @@ int emu_refgen(const hb_model* m, const hb::RefgenConfig* k, int n_ev, const dou
 }
 }
 
+extern "C" {
+// swing reference of one phase record {t0, t1, p0[3], p1[3]} at m query times -> out[m][6] = [pos xyz, vel xyz]
+void emu_phase_eval(const hb::RefgenConfig* k, const double* ph, const double* t, int m, double* out) {
+  for (int j = 0; j < m; ++j) rg_phase_eval(*k, ph, t[j], out + 6 * j);
+}
+// generic multi-node spline of the device code
+void emu_multi_cubic(int n, const double* tn, const double* pn, const double* vn, const double* t, int m, double* out) {
+  for (int j = 0; j < m; ++j) rg_multi_cubic(n, tn, pn, vn, t[j], out[2 * j], out[2 * j + 1]);
+}
+}
+
 #include "../../hunter_bipedal_control_amd/csrc/hb_plant.hpp"
 extern "C" {
 // one plant tick of the device code on one emulated lane; q[16], v[16], anchor[12], pinned[4] in/out

@@ -1,0 +1,82 @@
+"""CPU: swing-spline evaluation pinned to the REFERENCE's own arithmetic.
+
+tests/golden/ref_splines.json holds outputs of the reference's CubicSpline / MultiCubicSpline classes
+(legged_interface/src/foot_planner/{CubicSpline,MultiCubicSpline}.cpp compiled in place into oracle/_ref by oracle/Makefile,
+fixture written by tests/golden/make_ref_splines.py). Checked here: the host reference manager (refgen.MultiCubic, what the
+device reference generation is tested against) and the device code itself (csrc/hb_refgen.hpp on the host emulator).
+The same arithmetic in a different association order: tolerance 1e-13 relative to the magnitude of the value.
+"""
+import ctypes as C
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from hunter_bipedal_control_amd import abi, ingest, refgen
+
+HERE = Path(__file__).resolve().parent
+TOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return json.loads((HERE / "golden/ref_splines.json").read_text())
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    so = HERE / "host_emu/libhostemu.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", str(so), str(HERE / "host_emu/hostemu.cpp")])
+    return C.CDLL(str(so))
+
+
+def _close(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max())
+
+
+def test_fixture_is_the_reference_at_the_nodes(golden):
+    # Hermite property of the reference's own outputs (CubicSpline.cpp:55-66): at node i the value is (p_i, v_i)
+    for g in golden["generic"]:
+        nodes, ts, out = g["nodes"], np.array(g["t"]), np.array(g["out"])
+        for (tn, pn, vn) in nodes:
+            j = int(np.where(ts == tn)[0][0])
+            assert abs(out[j, 0] - pn) < 1e-12 and abs(out[j, 1] - vn) < 1e-11
+
+
+def test_host_reference_manager_splines_match_the_reference(golden):
+    for g in golden["generic"]:
+        s = refgen.MultiCubic([tuple(n) for n in g["nodes"]])
+        got = np.array([[s.position(t), s.velocity(t)] for t in g["t"]])
+        assert _close(got, np.array(g["out"])[:, :2])
+    sw = golden["swing"]
+    planner = refgen.SwingTrajectoryPlanner(dict(ingest.load_packaged()["config"]["swing"], **sw))
+    for ph in golden["phases"]:
+        sx, sy, sz = planner._swing_splines(ph["t0"], ph["t1"], np.array(ph["p0"]), np.array(ph["p1"]))
+        for s, key in ((sx, "x"), (sy, "y"), (sz, "z")):
+            assert np.allclose(np.array(s.nodes), np.array(ph["nodes"][key]), rtol=0, atol=0)
+            got = np.array([[s.position(t), s.velocity(t)] for t in ph["t"]])
+            assert _close(got, np.array(ph[key])[:, :2]), key
+
+
+def test_device_spline_code_matches_the_reference(golden, emu_lib):
+    _p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for g in golden["generic"]:
+        nodes = np.array(g["nodes"])
+        tn, pn, vn = (np.ascontiguousarray(nodes[:, k]) for k in range(3))
+        ts = np.array(g["t"])
+        out = np.zeros((len(ts), 2))
+        emu_lib.emu_multi_cubic(C.c_int(len(tn)), _p(tn), _p(pn), _p(vn), _p(ts), C.c_int(len(ts)), _p(out))
+        assert _close(out, np.array(g["out"])[:, :2])
+    params = ingest.load_packaged()
+    rcfg = abi.make_refgen_config(params, joint_ik=False)
+    rcfg.swing_height, rcfg.swing_time_scale = golden["swing"]["swing_height"], golden["swing"]["swing_time_scale"]
+    for ph in golden["phases"]:
+        rec = np.array([ph["t0"], ph["t1"], *ph["p0"], *ph["p1"]], dtype=np.float64)
+        ts = np.array(ph["t"])
+        out = np.zeros((len(ts), 6))
+        emu_lib.emu_phase_eval(C.byref(rcfg), _p(rec), _p(ts), C.c_int(len(ts)), _p(out))
+        ref = np.concatenate([np.array(ph[k])[:, 0:1] for k in "xyz"] + [np.array(ph[k])[:, 1:2] for k in "xyz"], axis=1)
+        assert _close(out, ref)

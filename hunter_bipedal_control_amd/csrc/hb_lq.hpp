@@ -70,13 +70,19 @@ struct RelaxedBarrierD {
   HB_HD double d2(double h) const { return h > delta ? mu / (h * h) : mu / (delta * delta); }
 };
 
-// LDS carve (doubles)
+// LDS carve (doubles).  2522 doubles = 20 176 B per node -> 8 single-wave workgroups per CU (two per SIMD).
+//   fixed:     CDt [32][12] (constraint-row derivatives; the 12 contact-force directions are identically zero and are not
+//              stored: direction d < 22 -> row d, joint-rate direction 34 + k -> row 22 + k), xplus, rowval
+//   phase 1:   LJ (4 leg blocks) | J1 | J2 | small values             (LJ is dead once stage 2 is done)
+//   compose:   ABt [44][12] over the head of LJ.  Only rows 0..11 of x+ are stored; the joint rows q+ = q + dt qd are
+//              the closed form  d q+_j / d dir = [dir == 12 + j] + dt [dir == 34 + j]  and are expanded where used
+//   phase 2+:  every later buffer aliases the rest of the phase-1 region (dead after the compose)
 struct LqLds {
-  static constexpr int ABt = 0;              // [44][22]
-  static constexpr int CDt = ABt + 968;      // [44][12]
-  static constexpr int xplus = CDt + 528;    // 22
+  static constexpr int CDt = 0;              // [32][12]
+  static constexpr int xplus = CDt + 384;    // 22
   static constexpr int rowval = xplus + 22;  // 12
-  static constexpr int GtG = rowval + 12;    // 10x10 (becomes L)
+  static constexpr int ABt = rowval + 12;    // [44][12]
+  static constexpr int GtG = ABt + 528;      // 10x10 (becomes L)
   static constexpr int W = GtG + 100;        // 10x23 (G'C | G'e), then reused
   static constexpr int Kx = W + 230;         // 10x23 (Kx | ke)
   static constexpr int Z = Kx + 230;         // 10x6
@@ -89,11 +95,17 @@ struct LqLds {
   static constexpr int Qd = ru + 22;         // 22 diagonal of Q incl. barriers/shift
   static constexpr int scal = Qd + 22;       // 16 scalars (cost, sums, ...)
   static constexpr int ints = scal + 16;     // 32 ints packed in 16 doubles: perm[10], rank, eq slots...
-  // phase-1 scratch (xs us xe fv FR LV J1 J2 = 1278 doubles) aliases everything from GtG on: none of those
-  // buffers is live before phase 2.
-  static constexpr int p1 = GtG;
-  static constexpr int total = (p1 + 1280 > ints + 16) ? p1 + 1280 : ints + 16;
+  // phase-1 view of the aliased region
+  static constexpr int LJ = ABt;             // 4 x LEGJ_SIZE (824)
+  static constexpr int J1 = LJ + 4 * LEGJ_SIZE;  // [44][12]
+  static constexpr int J2 = J1 + 528;        // [44][12]
+  static constexpr int p1 = J2 + 528;        // xs us xe fv FR LV = 222 doubles
+  static constexpr int total = (p1 + 222 > ints + 16) ? p1 + 222 : ints + 16;
 };
+static_assert(LqLds::GtG >= LqLds::ABt + 528 && LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are still being read");
+static_assert(LqLds::total * 8 <= 20480, "k_lq: LDS per node must allow 8 workgroups per CU");
+// row of CDt that holds direction d (d < 22 or d >= 34)
+HB_HD int cd_row(int dir) { return dir < 22 ? dir : dir - 12; }
 
 struct NodeIn {
   const double* x;      // 22
@@ -144,8 +156,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* fv = xe + 22;                // 2 x 12 flow-map values (rows 0..11) of the two points
   double* FR = fv + 24;                // 2 x 12: (contact point - COM) at the two points
   double* LV_all = FR + 24;            // 2 points x 2 legs x 27 leg values
-  double* J1 = LV_all + 108;              // 44 x 12: d f(rows 0..11) / d direction at point 1
-  double* J2 = J1 + 528;               // same at point 2
+  double* J1 = lds + LqLds::J1;        // 44 x 12: d f(rows 0..11) / d direction at point 1
+  double* J2 = lds + LqLds::J2;        // same at point 2
   for (int i = cx.lane; i < 22; i += cx.nlanes) {
     xs[i] = in.x[i];
     us[i] = in.u[i];
@@ -155,12 +167,11 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   // ---- stage 1: leg value passes of BOTH evaluation points at once.  The legs are evaluated in the base frame and the
   // joint block of the flow map is the input itself, so the joint state of the second RK2 point (q + dt qd) is known
   // up front: the four (point, leg) value passes run together, one (evaluation, joint) pair per lane (base-frame suffix
-  // composites per joint, staged in LDS over the not-yet-written ABt buffer); the direction lanes of stage 2 then
+  // composites per joint, staged in LDS); the direction lanes of stage 2 then
   // evaluate the closed-form tangents of the 27 leg outputs (rigid rotation of the outboard composite about the seeded
   // joint axis).
   if (C.debug_stop == 10) return;
-  double* LJ_all = ABt;  // 4 x LEGJ_SIZE; ABt is not written before the final compose
-  static_assert(4 * LEGJ_SIZE <= 968, "leg blocks must fit the ABt buffer");
+  double* LJ_all = lds + LqLds::LJ;  // 4 x LEGJ_SIZE; its head is overwritten by ABt in the final compose
   leg_value_pass_coop(cx, M, 4, [](int g) { return g & 1; },
                       [xs, us, dt](int g, int j) { return xs[12 + j] + ((g >> 1) ? dt : 0.0) * us[12 + j]; },
                       [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all);
@@ -265,9 +276,10 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
             r1 = C.xy_gain * px + fvel.x - (sw[3] + C.xy_gain * sw[0]);
             r2 = C.xy_gain * py + fvel.y - (sw[4] + C.xy_gain * sw[1]);
           }
-          CDt[dir * 12 + 3 * i + 0] = r0.d;
-          CDt[dir * 12 + 3 * i + 1] = r1.d;
-          CDt[dir * 12 + 3 * i + 2] = r2.d;
+          const int cdr = cd_row(dir);
+          CDt[cdr * 12 + 3 * i + 0] = r0.d;
+          CDt[cdr * 12 + 3 * i + 1] = r1.d;
+          CDt[cdr * 12 + 3 * i + 2] = r2.d;
           if (dir == 0) {
             rowval[3 * i + 0] = r0.v;
             rowval[3 * i + 1] = r1.v;
@@ -312,13 +324,11 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = col[i];
-    if (pt == 0) {
+    if (pt == 0 && is_pos) {  // the constraint rows do not depend on the contact forces: those directions are not stored
       for (int i = 0; i < HB_NC; ++i) {
         double r0 = 0, r1 = 0, r2 = 0;
-        if (is_pos) {
-          if (cf[i]) { if (dir == 8) r2 = C.zv_gain; }
-          else { if (dir == 8) r0 = C.kp_normal; if (dir == 6) r1 = C.xy_gain; if (dir == 7) r2 = C.xy_gain; }
-        }
+        if (cf[i]) { if (dir == 8) r2 = C.zv_gain; }
+        else { if (dir == 8) r0 = C.kp_normal; if (dir == 6) r1 = C.xy_gain; if (dir == 7) r2 = C.xy_gain; }
         CDt[dir * 12 + 3 * i + 0] = r0;
         CDt[dir * 12 + 3 * i + 1] = r1;
         CDt[dir * 12 + 3 * i + 2] = r2;
@@ -334,14 +344,10 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     tile_init(cx, tl, 44, 12, [J2](int dir, int i) { return dir >= 34 ? J2[(dir - 22) * 12 + i] : 0.0; });
     tile_mma<12, 12, false, 12>(cx, tl, J1, J2, 44, 12);
     tile_store(cx, tl, 44, 12, [ABt, J1, J2, dt](int dir, int i, double acc) {
-      ABt[dir * 22 + i] = (dir == i ? 1.0 : 0.0) + 0.5 * dt * (J1[dir * 12 + i] + J2[dir * 12 + i]) + 0.5 * dt * dt * acc;
+      ABt[dir * 12 + i] = (dir == i ? 1.0 : 0.0) + 0.5 * dt * (J1[dir * 12 + i] + J2[dir * 12 + i]) + 0.5 * dt * dt * acc;
     });
   }
-  // joint rows: q+ = q + dt qd
-  for (int idx = cx.lane; idx < 44 * 10; idx += cx.nlanes) {
-    const int dir = idx / 10, i = 12 + idx - 10 * dir;
-    ABt[dir * 22 + i] = (dir == i ? 1.0 : 0.0) + (dir == 22 + i ? dt : 0.0);
-  }
+  // joint rows q+ = q + dt qd: closed form, never stored (see LqLds)
   for (int i = cx.lane; i < 22; i += cx.nlanes)
     xplus[i] = (i < 12) ? xs[i] + 0.5 * dt * (fv[i] + fv[12 + i]) : xs[i] + dt * us[i];
   cx.sync();
@@ -363,23 +369,23 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
 
   // -------------------------------------------------------------- phase 2: G'G, G'[C e], pivoted Cholesky
   // joint-velocity directions are 34..43.  One masked Gram product on the matrix cores gives both:
-  //   out(k, d) = sum_{slot in eq} CDt[34+k][slot] CDt[d][slot]   ->  W(k, d) for d < 22,  G'G(k, d-34) for d >= 34
+  //   out(k, r) = sum_{slot in eq} CDt[22+k][slot] CDt[r][slot]   ->  W(k, r) for r < 22,  G'G(k, r-22) for r >= 22
   const int cfm = (cf[0] ? 1 : 0) | (cf[1] ? 2 : 0) | (cf[2] ? 4 : 0) | (cf[3] ? 8 : 0);
   {
-    WaveTile<1, 3> tg;
-    tile_init(cx, tg, 10, 44, [](int, int) { return 0.0; });
-    tile_mma<12, 12, false, 12, true>(cx, tg, CDt + 34 * 12, CDt, 10, 44, [cfm](int slot) {
+    WaveTile<1, 2> tg;
+    tile_init(cx, tg, 10, 32, [](int, int) { return 0.0; });
+    tile_mma<12, 12, false, 12, true>(cx, tg, CDt + 22 * 12, CDt, 10, 32, [cfm](int slot) {
       const int foot = slot / 3;
       return (((cfm >> foot) & 1) || slot - 3 * foot == 0) ? 1.0 : 0.0;  // contact foot: 3 rows, swing foot: slot 3i
     });
-    tile_store(cx, tg, 10, 44, [W, GtG](int k, int d, double v) {
-      if (d < 22) W[k * 23 + d] = v;
-      else if (d >= 34) GtG[k * 10 + d - 34] = v;
+    tile_store(cx, tg, 10, 32, [W, GtG](int k, int r, double v) {
+      if (r < 22) W[k * 23 + r] = v;
+      else GtG[k * 10 + r - 22] = v;
     });
   }
   for (int k = cx.lane; k < 10; k += cx.nlanes) {
     double s = 0;
-    for (int a = 0; a < n_eq; ++a) s += CDt[(34 + k) * 12 + eqs[a]] * rowval[eqs[a]];
+    for (int a = 0; a < n_eq; ++a) s += CDt[(22 + k) * 12 + eqs[a]] * rowval[eqs[a]];
     W[k * 23 + 22] = s;
   }
   cx.sync();
@@ -640,21 +646,21 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   for (int k = cx.lane; k < 10; k += cx.nlanes) {
     double s = 0;
-    for (int t = 0; t < n_soft; ++t) s += rowval[softs[t]] * CDt[(34 + k) * 12 + softs[t]];
+    for (int t = 0; t < n_soft; ++t) s += rowval[softs[t]] * CDt[(22 + k) * 12 + softs[t]];
     ru[12 + k] += C.soft_w * s;
   }
   {
     const double sw = C.soft_w;
     const double* Rc = C.R_jj;
-    WaveTile<1, 3> tg;
-    tile_init(cx, tg, 10, 44, [Rc, scal](int k, int d) { return d >= 34 ? Rc[k * 10 + d - 34] + (d - 34 == k ? scal[4 + k] : 0.0) : 0.0; });
-    tile_mma<12, 12, false, 12, true>(cx, tg, CDt + 34 * 12, CDt, 10, 44, [cfm, sw](int slot) {
+    WaveTile<1, 2> tg;
+    tile_init(cx, tg, 10, 32, [Rc, scal](int k, int r) { return r >= 22 ? Rc[k * 10 + r - 22] + (r - 22 == k ? scal[4 + k] : 0.0) : 0.0; });
+    tile_mma<12, 12, false, 12, true>(cx, tg, CDt + 22 * 12, CDt, 10, 32, [cfm, sw](int slot) {
       const int foot = slot / 3;
       return (slot - 3 * foot != 0 && !((cfm >> foot) & 1)) ? sw : 0.0;
     });
-    tile_store(cx, tg, 10, 44, [Pj, Rjj](int k, int d, double v) {
-      if (d < 22) Pj[k * 22 + d] = v;
-      else if (d >= 34) Rjj[k * 10 + d - 34] = v;
+    tile_store(cx, tg, 10, 32, [Pj, Rjj](int k, int r, double v) {
+      if (r < 22) Pj[k * 22 + r] = v;
+      else Rjj[k * 10 + r - 22] = v;
     });
   }
   cx.sync();
@@ -686,16 +692,21 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     for (int i = 0; i < HB_NC; ++i)
       if (cf[i]) { flist |= i << (2 * cnt); ++cnt; }
   }
-  // A~ = A + B_j Kx   and the kernel columns of B~ = B_j Z
+  // A~ = A + B_j Kx   and the kernel columns of B~ = B_j Z.  Momentum / base rows (0..11) on the matrix cores; the joint
+  // rows are the closed form  A~ = [0 I] + dt Kx,  B~ = dt Z  (no force columns),  b~ = defect + dt ke.
   {
-    WaveTile<2, 2> ta;
-    tile_init(cx, ta, 22, 22, [ABt](int row, int c) { return ABt[c * 22 + row]; });
-    tile_mma<12, 22, true, 23, false, 10>(cx, ta, ABt + 34 * 22, Kx, 22, 22);
-    tile_store(cx, ta, 22, 22, [rec](int row, int c, double v) { rec[REC_AT + row * 22 + c] = v; });
-    WaveTile<2, 1> tb;
-    tile_init(cx, tb, 22, 6, [](int, int) { return 0.0; });
-    tile_mma<12, 22, true, 6, false, 10>(cx, tb, ABt + 34 * 22, Z, 22, 6);
-    tile_store(cx, tb, 22, 6, [rec, n_f, nz](int row, int b, double v) { if (b < nz) rec[REC_BT + row * NU_T + n_f + b] = v; });
+    WaveTile<1, 2> ta;
+    tile_init(cx, ta, 12, 22, [ABt](int row, int c) { return ABt[c * 12 + row]; });
+    tile_mma<12, 12, true, 23, false, 10>(cx, ta, ABt + 34 * 12, Kx, 12, 22);
+    tile_store(cx, ta, 12, 22, [rec](int row, int c, double v) { rec[REC_AT + row * 22 + c] = v; });
+    WaveTile<1, 1> tb;
+    tile_init(cx, tb, 12, 6, [](int, int) { return 0.0; });
+    tile_mma<12, 12, true, 6, false, 10>(cx, tb, ABt + 34 * 12, Z, 12, 6);
+    tile_store(cx, tb, 12, 6, [rec, n_f, nz](int row, int b, double v) { if (b < nz) rec[REC_BT + row * NU_T + n_f + b] = v; });
+  }
+  for (int idx = cx.lane; idx < 220; idx += cx.nlanes) {
+    const int j = idx / 22, c = idx - 22 * j;
+    rec[REC_AT + 264 + idx] = (c == 12 + j ? 1.0 : 0.0) + dt * Kx[j * 23 + c];
   }
   // B~ columns: contact forces (foot order) first, zero padding after the kernel directions
   for (int idx = cx.lane; idx < 22 * NU_T; idx += cx.nlanes) {
@@ -703,17 +714,23 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     if (col < n_f) {
       // map col -> force index of the (col/3)-th contact foot
       const int foot = (flist >> (2 * (col / 3))) & 3;
-      rec[REC_BT + idx] = ABt[(22 + 3 * foot + col % 3) * 22 + row];
+      rec[REC_BT + idx] = row < 12 ? ABt[(22 + 3 * foot + col % 3) * 12 + row] : 0.0;
     } else if (col >= ntil) {
       rec[REC_BT + idx] = 0.0;
+    } else if (row >= 12) {
+      rec[REC_BT + idx] = dt * Z[(row - 12) * 6 + col - n_f];
     }
   }
   for (int row = cx.lane; row < 22; row += cx.nlanes) {
     double s = xplus[row] - in.xnext[row];
-    for (int k = 0; k < 10; ++k) s += ABt[(34 + k) * 22 + row] * Kx[k * 23 + 22];
-    for (int i = 0; i < HB_NC; ++i)
-      if (!cf[i])
-        for (int a = 0; a < 3; ++a) s -= ABt[(22 + 3 * i + a) * 22 + row] * in.u[3 * i + a];
+    if (row < 12) {
+      for (int k = 0; k < 10; ++k) s += ABt[(34 + k) * 12 + row] * Kx[k * 23 + 22];
+      for (int i = 0; i < HB_NC; ++i)
+        if (!cf[i])
+          for (int a = 0; a < 3; ++a) s -= ABt[(22 + 3 * i + a) * 12 + row] * in.u[3 * i + a];
+    } else {
+      s += dt * Kx[(row - 12) * 23 + 22];
+    }
     rec[REC_bT + row] = s;
   }
   // Q~ = Q + Kx' M + P_j' Kx ,  Q = diag(Qd) + w sum_soft c c'      (three accumulating GEMMs on the matrix cores)

@@ -26,6 +26,20 @@ struct DeviceCtx {
   __device__ DeviceCtx() : lane(threadIdx.x), nlanes(blockDim.x) {}
   __device__ void sync() const { __syncthreads(); }
 };
+// Context of the kernels whose workgroup is exactly one wavefront and whose lanes exchange data through LDS only.  The
+// LDS unit executes the DS instructions of one wave in order, so "every lane's earlier LDS writes are visible to every
+// lane's later LDS reads" needs no hardware barrier and, unlike __syncthreads() (a workgroup-scope fence: s_waitcnt
+// vmcnt(0)), does not drain the global loads / stores in flight — software-pipelined prefetches stay in flight across
+// the phases of a stage.  What remains is a compiler-level ordering point.
+struct WaveCtx {
+  int lane;
+  static constexpr int nlanes = 64;
+  __device__ WaveCtx() : lane(threadIdx.x) {}
+  __device__ void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+};
 
 // ---------------------------------------------------------------------------------------------------------
 // device-resident problem data of a batch
@@ -92,49 +106,85 @@ __global__ __launch_bounds__(64, 2) void k_lq(Batch b, const DevModel* __restric
   lq_node(DeviceCtx(), *M, *C, in, lds, b.recs + nd * REC_SIZE);
 }
 
-__global__ __launch_bounds__(64) void k_ric_bwd(Batch b, int dbg) {
+__global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
   const int inst = blockIdx.x;
   __shared__ double lds[RicLds::total];
-  const DeviceCtx cx;
+  const WaveCtx cx;
   for (int i = cx.lane; i < RicLds::total; i += cx.nlanes) lds[i] = 0.0;  // S = 0, s = 0 and every padding zero
-  __syncthreads();
+  cx.sync();
   const int n = b.n_nodes[inst];
-  // Staging of a record: lane l owns the element pairs 2(l + 64 r); their padded LDS destinations do not depend on
-  // the stage.  All wide loads of a lane are issued before the first one is consumed.
-  constexpr int NR2 = REC_RICCATI_END / 2, NL = (NR2 + 63) / 64;
-  int dst[NL];
-#pragma unroll
-  for (int r = 0; r < NL; ++r) {
-    const int e = 2 * (cx.lane + 64 * r);
-    dst[r] = e < REC_RICCATI_END ? (RicLds::is_vector(e) ? -1 - e : RicLds::dst(e)) : 0;
+  // Staging of a stage record (hb_lq.hpp REC_* layout) through registers, 16-byte loads, every load of a lane issued
+  // before the first is consumed:
+  //   buf[r], r < 6    pairs l + 64 r          of [A~ | B~]  (374 pairs, elements 0..747)
+  //   buf[r], r >= 6   pairs l + 64 (r - 6)    of [P~ | R~]  (204 pairs, elements REC_PT..REC_qT-1)
+  //   bufv             b~ (lanes 0..21) / r~ (lanes 22..33): the vectors go to a column of the padded layouts
+  //   bufq[r], bufqv   [Q~ | q~], dropped over the dead A~ block at the end of the stage (RicLds::Qs)
+  // Slots beyond a block read a few doubles further inside the same 2048-double record and are never stored.
+  // Software pipeline (WaveCtx::sync does not drain global loads): [Q~ q~] of stage k and the staged part of stage k-1
+  // are requested between the factorisation and the last GEMM of stage k — requested earlier they would be live across
+  // the register-resident Cholesky, the register peak of the kernel.
+  constexpr int NL = 10, NQ = 4;
+  static_assert(REC_BT + 22 * NU_T == REC_bT && REC_bT == 748 && REC_RT + NU_T * NU_T == REC_qT && REC_qT - REC_PT == 408, "record layout");
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 buf[NL], bufq[NQ];
+  double bufv, bufqv;
+  // (plain macros: with the loads inside lambdas capturing the buffers by reference they stayed in scratch memory)
+#define HB_RIC_FETCH(kk, l)                                                                              \
+  {                                                                                                      \
+    const double* rec_ = b.recs + (size_t(inst) * b.Nmax + (kk)) * REC_SIZE;                             \
+    const d2* rec2_ = reinterpret_cast<const d2*>(rec_) + (l);                                 \
+    _Pragma("unroll") for (int r = 0; r < NL; ++r) buf[r] = rec2_[r < 6 ? 64 * r : REC_PT / 2 + 64 * (r - 6)]; \
+    bufv = rec_[(l) < 22 ? REC_bT + (l) : REC_rT - 22 + (l)];                                            \
   }
-  // software pipeline: the loads of stage k-1 are in flight while stage k is being processed
-  double2 buf[NL];
-  auto fetch = [&](int k) {
-    const double2* rec2 = reinterpret_cast<const double2*>(b.recs + (size_t(inst) * b.Nmax + k) * REC_SIZE);
-#pragma unroll
-    for (int r = 0; r < NL; ++r) { const int i = cx.lane + 64 * r; buf[r] = rec2[i < NR2 ? i : NR2 - 1]; }
-  };
-  if (n > 0) fetch(n - 1);
+#define HB_RIC_FETCH_Q(kk, l)                                                                            \
+  {                                                                                                      \
+    const double* rec_ = b.recs + (size_t(inst) * b.Nmax + (kk)) * REC_SIZE;                             \
+    const d2* rec2_ = reinterpret_cast<const d2*>(rec_) + REC_QT / 2 + (l);                    \
+    _Pragma("unroll") for (int r = 0; r < NQ; ++r) bufq[r] = rec2_[64 * r];                              \
+    bufqv = rec_[REC_qT + (l)];                                                                          \
+  }
+  if (n > 0) HB_RIC_FETCH(n - 1, cx.lane);
   for (int k = n - 1; k >= 0; --k) {
+    // The per-lane staging offsets are recomputed every stage from an opaque copy of the lane id: as loop invariants
+    // the compiler hoisted ~100 of them out of the loop and then spilled them to scratch around the Cholesky, and every
+    // scratch reload drains the prefetch (s_waitcnt vmcnt(0)).
+    int l = cx.lane;
+    asm volatile("" : "+v"(l));
+    WaveCtx cxk = cx;  // lane id the compiler cannot trace back to threadIdx: nothing derived from it is loop invariant
+    cxk.lane = l;
 #pragma unroll
     for (int r = 0; r < NL; ++r) {
-      const int i = cx.lane + 64 * r;
-      if (i < NR2) {
-        if (dst[r] >= 0) {
-          *reinterpret_cast<double2*>(lds + dst[r]) = buf[r];
-        } else {  // two entries of b~ / q~ / r~: consecutive rows
-          const int e = -1 - dst[r];
-          lds[RicLds::dst(e)] = buf[r].x;
-          lds[RicLds::dst(e + 1)] = buf[r].y;
-        }
-      }
+      const int q = l + 64 * (r < 6 ? r : r - 6), e = 2 * q;  // element index inside the block
+      const int nx = r < 6 ? 484 : 264;                       // elements of the 22-wide part ([A~] / [P~])
+      const int base = r < 6 ? RicLds::ABb : RicLds::PRr;
+      int row, col;
+      if (e < nx) { row = e / 22; col = e - 22 * row; }
+      else { const int x = e - nx; row = x / NU_T; col = RicLds::CU + x - NU_T * row; }
+      if (q < (r < 6 ? 374 : 204)) *reinterpret_cast<d2*>(lds + base + row * RicLds::LDW + col) = buf[r];
     }
-    __syncthreads();
-    if (k > 0) fetch(k - 1);
-    if (dbg == 20) continue;  // profiling ablation: staging only
-    riccati_bwd_node(cx, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE, dbg);
+    if (l < 34) lds[(l < 22 ? RicLds::ABb + l * RicLds::LDW : RicLds::PRr + (l - 22) * RicLds::LDW) + RicLds::CV] = bufv;
+    cx.sync();
+    if (dbg == 20) { if (k > 0) HB_RIC_FETCH(k - 1, l); continue; }  // profiling ablation: staging only
+    ric_phase1(cxk, lds);
+    if (dbg != 21) ric_phase2(cxk, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE, dbg);
+    asm volatile("" : "+v"(l));
+    cxk.lane = l;
+    HB_RIC_FETCH_Q(k, l);
+    if (k > 0) HB_RIC_FETCH(k - 1, l);
+    if (dbg == 21 || dbg == 22 || dbg == 23) continue;
+    WaveTile<2, 2> t;
+    ric_phase3_mma(cxk, lds, t);
+    {
+      d2* Qs2 = reinterpret_cast<d2*>(lds + RicLds::Qs) + l;
+#pragma unroll
+      for (int r = 0; r < NQ; ++r)
+        if (l + 64 * r < 242) Qs2[64 * r] = bufq[r];
+      if (l < 22) lds[RicLds::Qs + 484 + l] = bufqv;
+    }
+    ric_phase3_finish(cxk, lds, t);
   }
+#undef HB_RIC_FETCH
+#undef HB_RIC_FETCH_Q
   if (cx.lane == 0) b.ric_fail[inst] = lds[RicLds::flag] != 0.0 ? 1 : 0;
 }
 

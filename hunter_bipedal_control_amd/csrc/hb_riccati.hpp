@@ -7,38 +7,44 @@
 
 namespace hb {
 
-// LDS of the backward sweep.  Every matrix is kept in a padded layout chosen so that each MFMA operand of the three
-// GEMM groups is "per-lane base + compile-time offset" (one address register per operand, offsets in the ds_read
-// immediates) and so that the K-padding of the 16x16x4 tiles is zeros on both sides:
+// LDS of the backward sweep: 2496 doubles = 19 968 B per instance -> 8 single-wave workgroups per CU (two per SIMD).
+// Every matrix is kept in a padded layout chosen so that each MFMA operand of the three GEMM groups is "per-lane base +
+// compile-time offset" (one address register per operand, offsets in the ds_read immediates) and so that the K-padding
+// of the 16x16x4 tiles is zeros on both sides:
 //   wide rows  (stride 36): [x block (22) | vector (1) | zero (1) | u block (12)]      [A~ b~ . B~], M1, [P~ r~ . R~], Hu
-//   narrow rows (stride 24): [x block (22) | vector (1) | zero (1)]                     S (cols 22,23 zero), [Q~ q~ .], [K~ k~ .]
-// ABb and M1 carry two extra all-zero rows (K = 22 -> 24).
+//   narrow rows (stride 24): [x block (22) | vector (1) | zero (1)]                     S (cols 22,23 zero), T, [K~ k~ .]
+// ABb and M1 carry two extra all-zero rows (K = 22 -> 24).  Buffers with disjoint lifetimes share storage (the
+// workgroup is one wave: its LDS accesses complete in program order):
+//   X   S | s (node start .. GEMM 1)  ->  M1 (GEMM 1 .. GEMM 3)  ->  T = new S | s (written by GEMM 3, symmetrised in place)
+//   PH  [P~ r~ . R~] (staged .. accumulator init of GEMM 2)  ->  Hu
+// [Q~ q~] has no buffer of its own: it is dropped over the dead A~ block once GEMM 3 has read its operands.
 struct RicLds {
   static constexpr int LDN = 24, LDW = 36, CV = 22, CU = 24;
-  static constexpr int S = 0;                    // 22 x 24
+  static constexpr int X = 0;                    // 24 x 36
+  static constexpr int S = X;                    // 22 x 24
   static constexpr int s = S + 22 * LDN;         // 24
-  static constexpr int ABb = s + 24;             // 24 x 36
-  static constexpr int M1 = ABb + 24 * LDW;      // 24 x 36 : S [A~ b~ . B~] (+ s on the vector column)
-  static constexpr int PRr = M1 + 24 * LDW;      // 12 x 36
-  static constexpr int Hu = PRr + 12 * LDW;      // 12 x 36 : [Hux | hu | . | Huu]
-  static constexpr int Qq = Hu + 12 * LDW;       // 22 x 24 : [Q~ | q~ | .], accumulates T
-  static constexpr int Kk = Qq + 22 * LDN;       // 12 x 24 : [K~ | k~ | .]
+  static constexpr int M1 = X;                   // 24 x 36 : S [A~ b~ . B~] (+ s on the vector column); rows 22, 23 stay zero
+  static constexpr int ABb = X + 24 * LDW;       // 24 x 36
+  static constexpr int PRr = ABb + 24 * LDW;     // 12 x 36
+  static constexpr int Hu = PRr;                 // 12 x 36 : [Hux | hu | . | Huu]
+  static constexpr int Kk = PRr + 12 * LDW;      // 12 x 24 : [K~ | k~ | .]
+  static constexpr int Qs = ABb;                 // [Q~ | q~] 506, dropped over A~ between GEMM 3 and the store of T
   static constexpr int flag = Kk + 12 * LDN;     // 4
   static constexpr int total = flag + 4 + 44;    // slack: padded tile reads run up to 40 doubles past Kk
-  // LDS offset of element e of the stage record (hb_lq.hpp REC_* layout); elements of one (even e, e+1) pair share a
-  // row except in the three vectors b~ q~ r~.
+  // Staged part of the stage record (hb_lq.hpp REC_* layout): everything but [Q~ q~]
+  HB_HD static bool staged(int e) { return e < REC_QT || (e >= REC_PT && e < REC_qT) || e >= REC_rT; }
+  // LDS offset of element e (reference mapping; the kernel computes the same offsets per element pair)
   HB_HD static int dst(int e) {
     if (e < REC_BT) { const int r = e / 22; return ABb + r * LDW + (e - r * 22); }
     if (e < REC_bT) { const int x = e - REC_BT, r = x / NU_T; return ABb + r * LDW + CU + (x - r * NU_T); }
     if (e < REC_QT) return ABb + (e - REC_bT) * LDW + CV;
-    if (e < REC_PT) { const int x = e - REC_QT, r = x / 22; return Qq + r * LDN + (x - r * 22); }
     if (e < REC_RT) { const int x = e - REC_PT, r = x / 22; return PRr + r * LDW + (x - r * 22); }
     if (e < REC_qT) { const int x = e - REC_RT, r = x / NU_T; return PRr + r * LDW + CU + (x - r * NU_T); }
-    if (e < REC_rT) return Qq + (e - REC_qT) * LDN + CV;
     return PRr + (e - REC_rT) * LDW + CV;
   }
-  HB_HD static bool is_vector(int e) { return (e >= REC_bT && e < REC_QT) || e >= REC_qT; }
 };
+static_assert(REC_QT % 2 == 0 && REC_PT % 2 == 0 && REC_qT % 2 == 0 && REC_rT % 2 == 0, "pair staging");
+static_assert(RicLds::total * 8 <= 20480, "k_ric_bwd: LDS per instance must allow 8 workgroups per CU");
 
 // One backward step on the staged record.  Updates S, s in place; writes the gains.
 //   M1 = S [A~ b~ B~] (+ s),  Hu = B~' M1 + [P~ r~ R~],  K~ = -Huu^-1 [Hux hu],
@@ -50,6 +56,7 @@ HB_HD void ric_phase1(const Ctx& cx, double* lds) {
   WaveTile<2, 3> t;
   tile_init(cx, t, 22, RicLds::LDW, [sv](int i, int c) { return c == RicLds::CV ? sv[i] : 0.0; });
   tile_mma<24, RicLds::LDN, false, RicLds::LDW>(cx, t, lds + RicLds::S, lds + RicLds::ABb, 22, RicLds::LDW);
+  // M1 overwrites S | s: every operand read above precedes these stores in the wave's program order
   tile_store(cx, t, 22, RicLds::LDW, [M1](int i, int c, double v) { M1[i * RicLds::LDW + c] = v; });
   cx.sync();
 }
@@ -62,7 +69,7 @@ HB_HD void ric_phase2(const Ctx& cx, double* lds, double* gains, int dbg = 0) {
     WaveTile<1, 3> t;
     tile_init(cx, t, NU_T, RicLds::LDW, [PRr](int a, int c) { return PRr[a * RicLds::LDW + c]; });
     tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t, lds + RicLds::ABb + RicLds::CU, lds + RicLds::M1, NU_T, RicLds::LDW);
-    tile_store(cx, t, NU_T, RicLds::LDW, [Hu](int a, int c, double v) { Hu[a * RicLds::LDW + c] = v; });
+    tile_store(cx, t, NU_T, RicLds::LDW, [Hu](int a, int c, double v) { Hu[a * RicLds::LDW + c] = v; });  // over [P~ r~ R~]
   }
   cx.sync();
   if (dbg == 22) return;
@@ -81,7 +88,7 @@ HB_HD void ric_phase2(const Ctx& cx, double* lds, double* gains, int dbg = 0) {
 #pragma unroll
       for (int k = 0; k < j; ++k) d -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
       if (!(d > 0.0)) { bad = true; d = 1.0; }
-      const double inv = 1.0 / sqrt(d);
+      const double inv = rsqrt_t(d);
       L[j * (j + 1) / 2 + j] = inv;  // store the reciprocal of the diagonal
 #pragma unroll
       for (int i = j + 1; i < NU_T; ++i) {
@@ -92,52 +99,80 @@ HB_HD void ric_phase2(const Ctx& cx, double* lds, double* gains, int dbg = 0) {
       }
     }
     if (bad && cx.lane == 0) lds[RicLds::flag] = 1.0;
+    // The factor (lane-uniform) goes back to LDS over the lower triangle of Huu, which is dead from here on: the solves
+    // then read it through broadcast loads and the 156 registers are free again (explicit "spill" to LDS; a register
+    // file that still held L here pushed the kernel's loop invariants into scratch memory).
+    if (cx.lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NU_T; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Hu[i * RicLds::LDW + RicLds::CU + j] = L[i * (i + 1) / 2 + j];
+    }
+  }
+  cx.sync();
+  {
+    const double* Lm = Hu + RicLds::CU;  // L(i, j) = Lm[i * LDW + j], j <= i; diagonal holds the reciprocals
     for (int c = cx.lane; c < 23; c += cx.nlanes) {  // columns 0..21 = Hux, 22 = hu
       double y[NU_T];
 #pragma unroll
       for (int a = 0; a < NU_T; ++a) {
         double sacc = -Hu[a * RicLds::LDW + c];
 #pragma unroll
-        for (int k = 0; k < a; ++k) sacc -= L[a * (a + 1) / 2 + k] * y[k];
-        y[a] = sacc * L[a * (a + 1) / 2 + a];
+        for (int k = 0; k < a; ++k) sacc -= Lm[a * RicLds::LDW + k] * y[k];
+        y[a] = sacc * Lm[a * RicLds::LDW + a];
       }
 #pragma unroll
       for (int a = NU_T - 1; a >= 0; --a) {
         double sacc = y[a];
 #pragma unroll
-        for (int k = a + 1; k < NU_T; ++k) sacc -= L[k * (k + 1) / 2 + a] * y[k];
-        y[a] = sacc * L[a * (a + 1) / 2 + a];
+        for (int k = a + 1; k < NU_T; ++k) sacc -= Lm[k * RicLds::LDW + a] * y[k];
+        y[a] = sacc * Lm[a * RicLds::LDW + a];
       }
+      double* gp = gains + (c < 22 ? c : 264);  // straight from the registers: lanes 0..21 write one row segment
+      const int gs = c < 22 ? 22 : 1;
 #pragma unroll
       for (int a = 0; a < NU_T; ++a) {
         Kk[a * RicLds::LDN + c] = y[a];
-        gains[c < 22 ? a * 22 + c : 264 + a] = y[a];  // straight from the registers: lanes 0..21 write one row segment
+        gp[a * gs] = y[a];
       }
     }
   }
   cx.sync();
 }
+// GEMM 3 in two halves: `ric_phase3_mma` accumulates T - [Q~ q~] = A~' [M1_A M1_b] + Hux' [K~ k~]; the caller then drops
+// [Q~ (22 x 22 row-major) | q~ (22)] at RicLds::Qs — it has no buffer of its own and goes over the A~ block, dead once
+// the operand reads are done — and `ric_phase3_finish` adds it, stores T and symmetrises.
 template <class Ctx>
-HB_HD void ric_phase3(const Ctx& cx, double* lds) {
+HB_HD void ric_phase3_mma(const Ctx& cx, double* lds, WaveTile<2, 2>& t) {
+  tile_init(cx, t, 22, 23, [](int, int) { return 0.0; });
+  tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t, lds + RicLds::ABb, lds + RicLds::M1, 22, 23);
+  tile_mma<NU_T, RicLds::LDW, true, RicLds::LDN>(cx, t, lds + RicLds::Hu, lds + RicLds::Kk, 22, 23);
+  cx.sync();
+}
+template <class Ctx>
+HB_HD void ric_phase3_finish(const Ctx& cx, double* lds, const WaveTile<2, 2>& t) {
   double* S = lds + RicLds::S;
   double* sv = lds + RicLds::s;
-  double* Qq = lds + RicLds::Qq;
-  const double* Kk = lds + RicLds::Kk;
-  // T = [Q~ q~] + A~' [M1_A M1_b] + Hux' [K~ k~], accumulated over the [Q~ q~] buffer
-  {
-    WaveTile<2, 2> t;
-    tile_init(cx, t, 22, 23, [Qq](int i, int c) { return Qq[i * RicLds::LDN + c]; });
-    tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t, lds + RicLds::ABb, lds + RicLds::M1, 22, 23);
-    tile_mma<NU_T, RicLds::LDW, true, RicLds::LDN>(cx, t, lds + RicLds::Hu, Kk, 22, 23);
-    tile_store(cx, t, 22, 23, [Qq](int i, int c, double v) { Qq[i * RicLds::LDN + c] = v; });
-  }
+  const double* Qs = lds + RicLds::Qs;
   cx.sync();
+  // T overwrites M1 (narrow rows): every operand read of the GEMMs precedes these stores in the wave's program order
+  tile_store(cx, t, 22, 23, [S, Qs](int i, int c, double v) { S[i * RicLds::LDN + c] = v + (c < 22 ? Qs[i * 22 + c] : Qs[484 + i]); });
+  cx.sync();
+  // symmetrise in place (pair (i, c), i < c, owned by one lane), move s out of column 22 and restore the zero K-padding
+  // of S (columns 22, 23 were covered by M1)
   for (int idx = cx.lane; idx < 484 + 22; idx += cx.nlanes) {
     if (idx < 484) {
       const int i = idx / 22, c = idx - i * 22;
-      S[i * RicLds::LDN + c] = 0.5 * (Qq[i * RicLds::LDN + c] + Qq[c * RicLds::LDN + i]);
+      if (i < c) {
+        const double m = 0.5 * (S[i * RicLds::LDN + c] + S[c * RicLds::LDN + i]);
+        S[i * RicLds::LDN + c] = m;
+        S[c * RicLds::LDN + i] = m;
+      }
     } else {
-      sv[idx - 484] = Qq[(idx - 484) * RicLds::LDN + RicLds::CV];
+      const int i = idx - 484;
+      sv[i] = S[i * RicLds::LDN + RicLds::CV];
+      S[i * RicLds::LDN + RicLds::CV] = 0.0;
+      S[i * RicLds::LDN + RicLds::CV + 1] = 0.0;
     }
   }
   cx.sync();
@@ -145,16 +180,21 @@ HB_HD void ric_phase3(const Ctx& cx, double* lds) {
 // Reference staging of one record (host emulation; the kernel batches its global loads instead).
 template <class Ctx>
 HB_HD void ric_stage(const Ctx& cx, double* lds, const double* rec) {
-  for (int e = cx.lane; e < REC_RICCATI_END; e += cx.nlanes) lds[RicLds::dst(e)] = rec[e];
+  for (int e = cx.lane; e < REC_RICCATI_END; e += cx.nlanes)
+    if (RicLds::staged(e)) lds[RicLds::dst(e)] = rec[e];
   cx.sync();
 }
 template <class Ctx>
-HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, double* gains, int dbg = 0) {
+HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, const double* rec, double* gains, int dbg = 0) {
   ric_phase1(cx, lds);
   if (dbg == 21) return;  // profiling ablation markers (hb_config.reserved)
   ric_phase2(cx, lds, gains, dbg);
   if (dbg == 22 || dbg == 23) return;
-  ric_phase3(cx, lds);
+  WaveTile<2, 2> t;
+  ric_phase3_mma(cx, lds, t);
+  double* Qs = lds + RicLds::Qs;
+  for (int e = cx.lane; e < 506; e += cx.nlanes) Qs[e] = rec[e < 484 ? REC_QT + e : REC_qT + e - 484];
+  ric_phase3_finish(cx, lds, t);
 }
 
 struct FwdLds {

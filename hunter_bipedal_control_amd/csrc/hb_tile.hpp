@@ -84,6 +84,19 @@ HB_HD void tile_mma(const Ctx& cx, WaveTile<MT, NT>& t, const double* A, const d
     }
 #endif
 }
+// t += o, element by element
+template <int MT, int NT>
+HB_HD void tile_add(WaveTile<MT, NT>& t, const WaveTile<MT, NT>& o) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) t.acc[tm][tn] += o.acc[tm][tn];
+#else
+  for (int i = 0; i < MT * 16; ++i)
+    for (int j = 0; j < NT * 16; ++j) t.c[i][j] += o.c[i][j];
+#endif
+}
 template <int MT, int NT, class Ctx, class FS>
 HB_HD void tile_store(const Ctx& cx, const WaveTile<MT, NT>& t, int Mr, int Nr, FS store) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -64,7 +64,7 @@ double emu_sqp_iteration(const hb_model* m, const hb_config* c, int N, const dou
   std::vector<double> rl(RicLds::total, 0.0);
   for (int k = N - 1; k >= 0; --k) {
     ric_stage(cx, rl.data(), recs.data() + size_t(k) * REC_SIZE);
-    riccati_bwd_node(cx, rl.data(), gains.data() + size_t(k) * GAIN_SIZE);
+    riccati_bwd_node(cx, rl.data(), recs.data() + size_t(k) * REC_SIZE, gains.data() + size_t(k) * GAIN_SIZE);
   }
   std::vector<double> fl(FwdLds::total, 0.0);
   std::vector<double> dx(size_t(N + 1) * 22), du(size_t(N) * 22);

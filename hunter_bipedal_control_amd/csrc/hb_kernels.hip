@@ -113,56 +113,48 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
   for (int i = cx.lane; i < RicLds::total; i += cx.nlanes) lds[i] = 0.0;  // S = 0, s = 0 and every padding zero
   cx.sync();
   const int n = b.n_nodes[inst];
-  // Staging of a stage record (hb_lq.hpp REC_* layout) through registers, 16-byte loads, every load of a lane issued
-  // before the first is consumed:
-  //   buf[r], r < 6    pairs l + 64 r          of [A~ | B~]  (374 pairs, elements 0..747)
-  //   buf[r], r >= 6   pairs l + 64 (r - 6)    of [P~ | R~]  (204 pairs, elements REC_PT..REC_qT-1)
-  //   bufv             b~ (lanes 0..21) / r~ (lanes 22..33): the vectors go to a column of the padded layouts
-  //   bufq[r], bufqv   [Q~ | q~], dropped over the dead A~ block at the end of the stage (RicLds::Qs)
-  // Slots beyond a block read a few doubles further inside the same 2048-double record and are never stored.
+  // Staging of a stage record through registers, 16-byte loads, every load of a lane issued before the first is
+  // consumed.  The Riccati part of the record is the LDS image (hb_lq.hpp REC_* layout), so staging is two straight copies:
+  //   buf[r]    pair l + 64 r of doubles [0, REC_QT): rows of [A~ b~ . B~] -> RicLds::ABb, rows of [P~ r~ . R~] -> RicLds::PRr
+  //   bufq[r]   pair l + 64 r of [Q~ | q~] (253 pairs), dropped over the dead A~ block at the end of the stage (RicLds::Qs)
+  // Slots beyond a block read a few doubles further inside the same record and are never stored.
   // Software pipeline (WaveCtx::sync does not drain global loads): [Q~ q~] of stage k and the staged part of stage k-1
   // are requested between the factorisation and the last GEMM of stage k — requested earlier they would be live across
   // the register-resident Cholesky, the register peak of the kernel.
-  constexpr int NL = 10, NQ = 4;
-  static_assert(REC_BT + 22 * NU_T == REC_bT && REC_bT == 748 && REC_RT + NU_T * NU_T == REC_qT && REC_qT - REC_PT == 408, "record layout");
-  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int NL = 10, NQ = 4, NP_AB = REC_PR / 2, NP = REC_QT / 2;  // 396 pairs of [A~ b~ . B~], 612 pairs staged
+  static_assert(NP <= 64 * NL && 64 * NL * 2 + 2 * 64 * NQ <= REC_SIZE && REC_QT % 2 == 0 && REC_PR % 2 == 0, "record layout");
+  typedef double d2 __attribute__((ext_vector_type(2)));  // (HIP's double2 struct kept the buffers in scratch memory)
   d2 buf[NL], bufq[NQ];
-  double bufv, bufqv;
-  // (plain macros: with the loads inside lambdas capturing the buffers by reference they stayed in scratch memory)
-#define HB_RIC_FETCH(kk, l)                                                                              \
-  {                                                                                                      \
-    const double* rec_ = b.recs + (size_t(inst) * b.Nmax + (kk)) * REC_SIZE;                             \
-    const d2* rec2_ = reinterpret_cast<const d2*>(rec_) + (l);                                 \
-    _Pragma("unroll") for (int r = 0; r < NL; ++r) buf[r] = rec2_[r < 6 ? 64 * r : REC_PT / 2 + 64 * (r - 6)]; \
-    bufv = rec_[(l) < 22 ? REC_bT + (l) : REC_rT - 22 + (l)];                                            \
+#define HB_RIC_FETCH(kk, l)                                                                                        \
+  {                                                                                                                \
+    const d2* rec2_ = reinterpret_cast<const d2*>(b.recs + (size_t(inst) * b.Nmax + (kk)) * REC_SIZE) + (l);       \
+    _Pragma("unroll") for (int r = 0; r < NL; ++r) buf[r] = rec2_[64 * r];                                         \
   }
-#define HB_RIC_FETCH_Q(kk, l)                                                                            \
-  {                                                                                                      \
-    const double* rec_ = b.recs + (size_t(inst) * b.Nmax + (kk)) * REC_SIZE;                             \
-    const d2* rec2_ = reinterpret_cast<const d2*>(rec_) + REC_QT / 2 + (l);                    \
-    _Pragma("unroll") for (int r = 0; r < NQ; ++r) bufq[r] = rec2_[64 * r];                              \
-    bufqv = rec_[REC_qT + (l)];                                                                          \
+#define HB_RIC_FETCH_Q(kk, l)                                                                                      \
+  {                                                                                                                \
+    const d2* rec2_ = reinterpret_cast<const d2*>(b.recs + (size_t(inst) * b.Nmax + (kk)) * REC_SIZE) + NP + (l);  \
+    _Pragma("unroll") for (int r = 0; r < NQ; ++r) bufq[r] = rec2_[64 * r];                                        \
   }
   if (n > 0) HB_RIC_FETCH(n - 1, cx.lane);
   for (int k = n - 1; k >= 0; --k) {
-    // The per-lane staging offsets are recomputed every stage from an opaque copy of the lane id: as loop invariants
-    // the compiler hoisted ~100 of them out of the loop and then spilled them to scratch around the Cholesky, and every
-    // scratch reload drains the prefetch (s_waitcnt vmcnt(0)).
+    // Per-lane addresses are rebuilt every stage from an opaque copy of the lane id: as loop invariants the compiler
+    // hoisted ~100 of them out of the loop and then spilled them to scratch around the Cholesky, and every scratch
+    // reload drains the prefetch (s_waitcnt vmcnt(0)).
     int l = cx.lane;
     asm volatile("" : "+v"(l));
     WaveCtx cxk = cx;  // lane id the compiler cannot trace back to threadIdx: nothing derived from it is loop invariant
     cxk.lane = l;
+    {
+      d2* st = reinterpret_cast<d2*>(lds + RicLds::ABb) + l;
 #pragma unroll
-    for (int r = 0; r < NL; ++r) {
-      const int q = l + 64 * (r < 6 ? r : r - 6), e = 2 * q;  // element index inside the block
-      const int nx = r < 6 ? 484 : 264;                       // elements of the 22-wide part ([A~] / [P~])
-      const int base = r < 6 ? RicLds::ABb : RicLds::PRr;
-      int row, col;
-      if (e < nx) { row = e / 22; col = e - 22 * row; }
-      else { const int x = e - nx; row = x / NU_T; col = RicLds::CU + x - NU_T * row; }
-      if (q < (r < 6 ? 374 : 204)) *reinterpret_cast<d2*>(lds + base + row * RicLds::LDW + col) = buf[r];
+      for (int r = 0; r < NL; ++r) {
+        const int p = l + 64 * r;  // rows of [P~ r~ . R~] start 2 x 36 doubles further (K-padding rows of the A~ block)
+        const int shift = (RicLds::PRr - RicLds::ABb - REC_PR) / 2;
+        if (64 * r + 63 < NP_AB) st[64 * r] = buf[r];
+        else if (64 * r >= NP_AB) { if (p < NP) st[64 * r + shift] = buf[r]; }
+        else st[64 * r + (p < NP_AB ? 0 : shift)] = buf[r];
+      }
     }
-    if (l < 34) lds[(l < 22 ? RicLds::ABb + l * RicLds::LDW : RicLds::PRr + (l - 22) * RicLds::LDW) + RicLds::CV] = bufv;
     cx.sync();
     if (dbg == 20) { if (k > 0) HB_RIC_FETCH(k - 1, l); continue; }  // profiling ablation: staging only
     ric_phase1(cxk, lds);
@@ -178,8 +170,7 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
       d2* Qs2 = reinterpret_cast<d2*>(lds + RicLds::Qs) + l;
 #pragma unroll
       for (int r = 0; r < NQ; ++r)
-        if (l + 64 * r < 242) Qs2[64 * r] = bufq[r];
-      if (l < 22) lds[RicLds::Qs + 484 + l] = bufqv;
+        if (l + 64 * r < 253) Qs2[64 * r] = bufq[r];
     }
     ric_phase3_finish(cxk, lds, t);
   }
@@ -1417,18 +1408,18 @@ int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, int32_t nu, const do
     for (int k = 0; k < N; ++k) {
       double* rec = recs.data() + (size_t(i) * Nm + k) * REC_SIZE;
       const size_t sk = size_t(i) * N + k;
-      std::memcpy(rec + REC_AT, A + sk * 484, 484 * 8);
+      for (int row = 0; row < 22; ++row) std::memcpy(rec + rec_A(row, 0), A + sk * 484 + row * 22, 22 * 8);
       std::memcpy(rec + REC_QT, Q + sk * 484, 484 * 8);
-      std::memcpy(rec + REC_bT, bv + sk * 22, 22 * 8);
+      for (int row = 0; row < 22; ++row) rec[rec_b(row)] = bv[sk * 22 + row];
       std::memcpy(rec + REC_qT, q + sk * 22, 22 * 8);
       for (int row = 0; row < 22; ++row)
-        for (int c = 0; c < nu; ++c) rec[REC_BT + row * NU_T + c] = Bm[(sk * 22 + row) * nu + c];
+        for (int c = 0; c < nu; ++c) rec[rec_B(row, c)] = Bm[(sk * 22 + row) * nu + c];
       for (int a = 0; a < NU_T; ++a) {
         for (int c = 0; c < NU_T; ++c)
-          rec[REC_RT + a * NU_T + c] = (a < nu && c < nu) ? R[(sk * nu + a) * nu + c] : (a == c ? 1.0 : 0.0);
+          rec[rec_R(a, c)] = (a < nu && c < nu) ? R[(sk * nu + a) * nu + c] : (a == c ? 1.0 : 0.0);
         if (a < nu) {
-          std::memcpy(rec + REC_PT + a * 22, P + (sk * nu + a) * 22, 22 * 8);
-          rec[REC_rT + a] = r[sk * nu + a];
+          std::memcpy(rec + rec_P(a, 0), P + (sk * nu + a) * 22, 22 * 8);
+          rec[rec_r(a)] = r[sk * nu + a];
         }
       }
       rec[REC_META + 0] = 0.0;  // forward pass: treat all inputs as "kernel" columns is not needed here

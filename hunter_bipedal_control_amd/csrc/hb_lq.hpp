@@ -39,25 +39,32 @@ struct DevConfig {
 };
 
 // ---- node record layout in HBM (doubles) ------------------------------------------------------------
+// The Riccati part of the record is the LDS image of the backward sweep (hb_riccati.hpp RicLds): rows of 36
+//   [x block (22) | vector (1) | unused (1) | u block (12)]
+// so that k_ric_bwd stages it with straight 16-byte copies (lane * 16 + constant) and no index arithmetic.  The unused
+// column is never written (the allocation is zeroed once) and only ever feeds discarded outputs of the tile GEMMs.
 constexpr int NU_T = 12;                 // projected input width (padded)
-constexpr int REC_AT = 0;                // 22x22
-constexpr int REC_BT = 484;              // 22x12
-constexpr int REC_bT = 748;              // 22
-constexpr int REC_QT = 770;              // 22x22
-constexpr int REC_PT = 1254;             // 12x22
-constexpr int REC_RT = 1518;             // 12x12
-constexpr int REC_qT = 1662;             // 22
-constexpr int REC_rT = 1684;             // 12
-constexpr int REC_RICCATI_END = 1696;
-constexpr int REC_KX = 1696;             // 10x22
-constexpr int REC_KE = 1916;             // 10
-constexpr int REC_Z = 1926;              // 10x6
-constexpr int REC_DF = 1986;             // 12: constant part of dF (= -F on swing feet)
-constexpr int REC_QF = 1998;             // 22 unprojected cost gradient wrt x (x dt)
-constexpr int REC_RF = 2020;             // 22 unprojected cost gradient wrt u (x dt)
-constexpr int REC_META = 2042;           // nf, nz, mode, cost*dt, dyn_sse*dt, eq_sse*dt
-constexpr int REC_SIZE = 2048;
+constexpr int REC_LD = 36, REC_CV = 22, REC_CU = 24;
+constexpr int REC_AB = 0;                // 22 rows: [A~ | b~ | . | B~]
+constexpr int REC_PR = 792;              // 12 rows: [P~ | r~ | . | R~]
+constexpr int REC_QT = 1224;             // 22x22
+constexpr int REC_qT = 1708;             // 22
+constexpr int REC_RICCATI_END = 1730;
+constexpr int REC_KX = 1730;             // 10x22
+constexpr int REC_KE = 1950;             // 10
+constexpr int REC_Z = 1960;              // 10x6
+constexpr int REC_DF = 2020;             // 12: constant part of dF (= -F on swing feet)
+constexpr int REC_QF = 2032;             // 22 unprojected cost gradient wrt x (x dt)
+constexpr int REC_RF = 2054;             // 22 unprojected cost gradient wrt u (x dt)
+constexpr int REC_META = 2076;           // nf, nz, mode, cost*dt, dyn_sse*dt, eq_sse*dt
+constexpr int REC_SIZE = 2112;           // 16.5 KiB, a multiple of 512 B
 constexpr int GAIN_SIZE = 288;           // K~ 12x22 (264) + k~ 12 + pad
+HB_HD constexpr int rec_A(int i, int c) { return REC_AB + i * REC_LD + c; }            // A~(i, c)
+HB_HD constexpr int rec_B(int i, int a) { return REC_AB + i * REC_LD + REC_CU + a; }   // B~(i, a)
+HB_HD constexpr int rec_b(int i) { return REC_AB + i * REC_LD + REC_CV; }              // b~(i)
+HB_HD constexpr int rec_P(int a, int c) { return REC_PR + a * REC_LD + c; }            // P~(a, c)
+HB_HD constexpr int rec_R(int a, int c) { return REC_PR + a * REC_LD + REC_CU + c; }   // R~(a, c)
+HB_HD constexpr int rec_r(int a) { return REC_PR + a * REC_LD + REC_CV; }              // r~(a)
 
 struct RelaxedBarrierD {
   double mu, delta;
@@ -698,15 +705,15 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     WaveTile<1, 2> ta;
     tile_init(cx, ta, 12, 22, [ABt](int row, int c) { return ABt[c * 12 + row]; });
     tile_mma<12, 12, true, 23, false, 10>(cx, ta, ABt + 34 * 12, Kx, 12, 22);
-    tile_store(cx, ta, 12, 22, [rec](int row, int c, double v) { rec[REC_AT + row * 22 + c] = v; });
+    tile_store(cx, ta, 12, 22, [rec](int row, int c, double v) { rec[rec_A(row, c)] = v; });
     WaveTile<1, 1> tb;
     tile_init(cx, tb, 12, 6, [](int, int) { return 0.0; });
     tile_mma<12, 12, true, 6, false, 10>(cx, tb, ABt + 34 * 12, Z, 12, 6);
-    tile_store(cx, tb, 12, 6, [rec, n_f, nz](int row, int b, double v) { if (b < nz) rec[REC_BT + row * NU_T + n_f + b] = v; });
+    tile_store(cx, tb, 12, 6, [rec, n_f, nz](int row, int b, double v) { if (b < nz) rec[rec_B(row, n_f + b)] = v; });
   }
   for (int idx = cx.lane; idx < 220; idx += cx.nlanes) {
     const int j = idx / 22, c = idx - 22 * j;
-    rec[REC_AT + 264 + idx] = (c == 12 + j ? 1.0 : 0.0) + dt * Kx[j * 23 + c];
+    rec[rec_A(12 + j, c)] = (c == 12 + j ? 1.0 : 0.0) + dt * Kx[j * 23 + c];
   }
   // B~ columns: contact forces (foot order) first, zero padding after the kernel directions
   for (int idx = cx.lane; idx < 22 * NU_T; idx += cx.nlanes) {
@@ -714,11 +721,11 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     if (col < n_f) {
       // map col -> force index of the (col/3)-th contact foot
       const int foot = (flist >> (2 * (col / 3))) & 3;
-      rec[REC_BT + idx] = row < 12 ? ABt[(22 + 3 * foot + col % 3) * 12 + row] : 0.0;
+      rec[rec_B(row, col)] = row < 12 ? ABt[(22 + 3 * foot + col % 3) * 12 + row] : 0.0;
     } else if (col >= ntil) {
-      rec[REC_BT + idx] = 0.0;
+      rec[rec_B(row, col)] = 0.0;
     } else if (row >= 12) {
-      rec[REC_BT + idx] = dt * Z[(row - 12) * 6 + col - n_f];
+      rec[rec_B(row, col)] = dt * Z[(row - 12) * 6 + col - n_f];
     }
   }
   for (int row = cx.lane; row < 22; row += cx.nlanes) {
@@ -731,7 +738,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     } else {
       s += dt * Kx[(row - 12) * 23 + 22];
     }
-    rec[REC_bT + row] = s;
+    rec[rec_b(row)] = s;
   }
   // Q~ = Q + Kx' M + P_j' Kx ,  Q = diag(Qd) + w sum_soft c c'      (three accumulating GEMMs on the matrix cores)
   {
@@ -760,11 +767,11 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     WaveTile<1, 2> tp;
     tile_init(cx, tp, 6, 22, [](int, int) { return 0.0; });
     tile_mma<12, 6, true, 22, false, 10>(cx, tp, Z, Mm, 6, 22);
-    tile_store(cx, tp, 6, 22, [rec, n_f, nz, dt](int b, int c, double v) { if (b < nz) rec[REC_PT + (n_f + b) * 22 + c] = dt * v; });
+    tile_store(cx, tp, 6, 22, [rec, n_f, nz, dt](int b, int c, double v) { if (b < nz) rec[rec_P(n_f + b, c)] = dt * v; });
   }
   for (int idx = cx.lane; idx < NU_T * 22; idx += cx.nlanes) {
     const int col = idx / 22;
-    if (col < n_f || col >= ntil) rec[REC_PT + idx] = 0.0;
+    if (col < n_f || col >= ntil) rec[rec_P(col, idx - 22 * col)] = 0.0;
   }
   // R~ (12x12): contact-force blocks, Z' R_jj Z, identity on the padding
   for (int idx = cx.lane; idx < NU_T * NU_T; idx += cx.nlanes) {
@@ -782,7 +789,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     } else if (ca >= ntil && ca == cb) {
       pad_diag = true;
     }
-    rec[REC_RT + idx] = pad_diag ? 1.0 : dt * s;
+    rec[rec_R(ca, cb)] = pad_diag ? 1.0 : dt * s;
   }
   // r~
   for (int col = cx.lane; col < NU_T; col += cx.nlanes) {
@@ -794,7 +801,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       const int b = col - n_f;
       for (int k = 0; k < 10; ++k) s += Z[k * 6 + b] * W[k];
     }
-    rec[REC_rT + col] = dt * s;
+    rec[rec_r(col)] = dt * s;
   }
   // recovery data
   for (int idx = cx.lane; idx < 220; idx += cx.nlanes) rec[REC_KX + idx] = Kx[(idx / 22) * 23 + idx % 22];

@@ -31,19 +31,9 @@ struct RicLds {
   static constexpr int Qs = ABb;                 // [Q~ | q~] 506, dropped over A~ between GEMM 3 and the store of T
   static constexpr int flag = Kk + 12 * LDN;     // 4
   static constexpr int total = flag + 4 + 44;    // slack: padded tile reads run up to 40 doubles past Kk
-  // Staged part of the stage record (hb_lq.hpp REC_* layout): everything but [Q~ q~]
-  HB_HD static bool staged(int e) { return e < REC_QT || (e >= REC_PT && e < REC_qT) || e >= REC_rT; }
-  // LDS offset of element e (reference mapping; the kernel computes the same offsets per element pair)
-  HB_HD static int dst(int e) {
-    if (e < REC_BT) { const int r = e / 22; return ABb + r * LDW + (e - r * 22); }
-    if (e < REC_bT) { const int x = e - REC_BT, r = x / NU_T; return ABb + r * LDW + CU + (x - r * NU_T); }
-    if (e < REC_QT) return ABb + (e - REC_bT) * LDW + CV;
-    if (e < REC_RT) { const int x = e - REC_PT, r = x / 22; return PRr + r * LDW + (x - r * 22); }
-    if (e < REC_qT) { const int x = e - REC_RT, r = x / NU_T; return PRr + r * LDW + CU + (x - r * NU_T); }
-    return PRr + (e - REC_rT) * LDW + CV;
-  }
 };
-static_assert(REC_QT % 2 == 0 && REC_PT % 2 == 0 && REC_qT % 2 == 0 && REC_rT % 2 == 0, "pair staging");
+static_assert(RicLds::LDW == REC_LD && RicLds::CV == REC_CV && RicLds::CU == REC_CU, "the record is the LDS image");
+static_assert(RicLds::PRr == RicLds::ABb + 24 * RicLds::LDW && REC_PR == REC_AB + 22 * REC_LD, "two straight copies");
 static_assert(RicLds::total * 8 <= 20480, "k_ric_bwd: LDS per instance must allow 8 workgroups per CU");
 
 // One backward step on the staged record.  Updates S, s in place; writes the gains.
@@ -180,8 +170,7 @@ HB_HD void ric_phase3_finish(const Ctx& cx, double* lds, const WaveTile<2, 2>& t
 // Reference staging of one record (host emulation; the kernel batches its global loads instead).
 template <class Ctx>
 HB_HD void ric_stage(const Ctx& cx, double* lds, const double* rec) {
-  for (int e = cx.lane; e < REC_RICCATI_END; e += cx.nlanes)
-    if (RicLds::staged(e)) lds[RicLds::dst(e)] = rec[e];
+  for (int e = cx.lane; e < REC_QT; e += cx.nlanes) lds[e < REC_PR ? RicLds::ABb + e : RicLds::PRr + e - REC_PR] = rec[e];
   cx.sync();
 }
 template <class Ctx>
@@ -227,9 +216,9 @@ HB_HD void riccati_fwd_node(const Ctx& cx, double* lds, const double* rec, const
   cx.sync();
   for (int i = cx.lane; i < 22 + 22; i += cx.nlanes) {
     if (i < 22) {
-      double s = rec[REC_bT + i];
-      for (int c = 0; c < 22; ++c) s += rec[REC_AT + i * 22 + c] * dx[c];
-      for (int a = 0; a < NU_T; ++a) s += rec[REC_BT + i * NU_T + a] * ut[a];
+      double s = rec[rec_b(i)];
+      for (int c = 0; c < 22; ++c) s += rec[rec_A(i, c)] * dx[c];
+      for (int a = 0; a < NU_T; ++a) s += rec[rec_B(i, a)] * ut[a];
       dxn[i] = s;
     } else {
       const int m = i - 22;

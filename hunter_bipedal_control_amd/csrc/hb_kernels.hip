@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64, 2) void k_lq(Batch b, const DevModel* __restric
   in.swing = b.swing + nd * 24;
   in.dt = tt[k + 1] - tt[k];
   in.mode = b.mode[nd];
-  lq_node(DeviceCtx(), *M, *C, in, lds, b.recs + nd * REC_SIZE);
+  lq_node(WaveCtx(), *M, *C, in, lds, b.recs + nd * REC_SIZE);
 }
 
 __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {

@@ -182,15 +182,49 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
 __global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
   const int inst = blockIdx.x;
   __shared__ double lds[FwdLds::total];
-  const DeviceCtx cx;
-  for (int i = cx.lane; i < FwdLds::total; i += cx.nlanes) lds[i] = 0.0;  // dx0 = 0: x[0] is the measured state
-  __syncthreads();
+  const WaveCtx cx;
+  for (int i = cx.lane; i < FwdLds::small; i += cx.nlanes) lds[i] = 0.0;  // dx0 = 0: x[0] is the measured state
+  cx.sync();
   const int n = b.n_nodes[inst];
+  // What a step reads — the [A~ b~ . B~] rows and the recovery part of the stage record, the gains — is staged into LDS
+  // with coalesced 16-byte loads, one stage ahead (WaveCtx::sync does not drain the loads in flight): the matrix-vector
+  // products then run out of LDS instead of waiting for scattered global loads on the dx -> dx+ dependency chain.
+  constexpr int P_AB = REC_PR / 2, P_RX = (REC_META + 6 - REC_KX) / 2, P_G = GAIN_SIZE / 2;  // 396, 176, 144 pairs
+  constexpr int N_AB = (P_AB + 63) / 64, N_RX = (P_RX + 63) / 64, N_G = (P_G + 63) / 64;     // 7, 3, 3 loads per lane
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 bab[N_AB], brx[N_RX], bg[N_G];
+  const int l = cx.lane;
+#define HB_FWD_FETCH(kk)                                                                                  \
+  {                                                                                                       \
+    const size_t nd_ = size_t(inst) * b.Nmax + (kk);                                                      \
+    const d2* pab_ = reinterpret_cast<const d2*>(b.recs + nd_ * REC_SIZE + REC_AB) + l;                   \
+    const d2* prx_ = reinterpret_cast<const d2*>(b.recs + nd_ * REC_SIZE + REC_KX) + l;                   \
+    const d2* pg_ = reinterpret_cast<const d2*>(b.gains + nd_ * GAIN_SIZE) + l;                           \
+    _Pragma("unroll") for (int r = 0; r < N_AB; ++r) bab[r] = pab_[64 * r]; /* slots past 396 stay inside the record */ \
+    _Pragma("unroll") for (int r = 0; r < N_RX; ++r) brx[r] = (64 * r + 63 < P_RX || l + 64 * r < P_RX) ? prx_[64 * r] : d2{0.0, 0.0}; \
+    _Pragma("unroll") for (int r = 0; r < N_G; ++r) bg[r] = (64 * r + 63 < P_G || l + 64 * r < P_G) ? pg_[64 * r] : d2{0.0, 0.0}; \
+  }
+  if (n > 0) HB_FWD_FETCH(0);
   for (int k = 0; k < n; ++k) {
+    {
+      d2* sab = reinterpret_cast<d2*>(lds + FwdLds::AB) + l;
+      d2* srx = reinterpret_cast<d2*>(lds + FwdLds::RX) + l;
+      d2* sg = reinterpret_cast<d2*>(lds + FwdLds::G) + l;
+#pragma unroll
+      for (int r = 0; r < N_AB; ++r) if (64 * r + 63 < P_AB || l + 64 * r < P_AB) sab[64 * r] = bab[r];
+#pragma unroll
+      for (int r = 0; r < N_RX; ++r) if (64 * r + 63 < P_RX || l + 64 * r < P_RX) srx[64 * r] = brx[r];
+#pragma unroll
+      for (int r = 0; r < N_G; ++r) if (64 * r + 63 < P_G || l + 64 * r < P_G) sg[64 * r] = bg[r];
+    }
+    cx.sync();
+    if (k + 1 < n) HB_FWD_FETCH(k + 1);
     const size_t nd = size_t(inst) * b.Nmax + k;
-    riccati_fwd_node(cx, lds, b.recs + nd * REC_SIZE, b.gains + nd * GAIN_SIZE,
+    riccati_fwd_node(cx, lds, lds + FwdLds::AB, lds + FwdLds::RX, lds + FwdLds::G,
                      b.dx + (size_t(inst) * (b.Nmax + 1) + k) * HB_NX, b.du + nd * HB_NU);
   }
+#undef HB_FWD_FETCH
+  riccati_fwd_finish(cx, lds);
   if (cx.lane < HB_NX) b.dx[(size_t(inst) * (b.Nmax + 1) + n) * HB_NX + cx.lane] = lds[FwdLds::dx + cx.lane];
   if (cx.lane < 4) b.acc[inst * 4 + cx.lane] = lds[FwdLds::acc + cx.lane];
   if (cx.lane == 0) {

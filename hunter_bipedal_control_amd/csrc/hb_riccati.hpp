@@ -191,21 +191,37 @@ struct FwdLds {
   static constexpr int ut = 24;       // 12
   static constexpr int du = 36;       // 22 (+2)
   static constexpr int dxn = 60;      // 22 (+2)
-  static constexpr int acc = 84;      // 4: armijo, merit, dyn, eq
-  static constexpr int total = 88;
+  static constexpr int acc = 84;      // 4: armijo (filled by riccati_fwd_finish), merit, dyn, eq
+  static constexpr int accp = 88;     // 22 (+2): per-entry partial sums of the Armijo directional derivative
+  static constexpr int small = 112;
+  // staged copy of what one forward step reads (device kernel): [A~ b~ . B~] rows | recovery data | gains
+  static constexpr int AB = small;                 // REC_PR doubles (22 rows of 36)
+  static constexpr int RX = AB + REC_PR;           // record elements [REC_KX, REC_META + 6)
+  static constexpr int G = RX + (REC_META + 6 - REC_KX);
+  static constexpr int total = G + GAIN_SIZE;
 };
+static_assert((REC_META + 6 - REC_KX) % 2 == 0 && REC_KX % 2 == 0 && FwdLds::AB % 2 == 0, "16-byte staging");
 
-// One forward step: reads the stage record + gains from global memory, advances dx in LDS and writes the full
-// state/input step of this node.
+// One forward step.  `ab` = rows [A~ b~ . B~] of the stage record (stride REC_LD), `rx` = its recovery part (element
+// REC_KX onwards), `gains` = [K~ | k~]: pointers into global memory (host emulation) or into the staged LDS copy (kernel).
+// Advances dx in LDS and writes the full state/input step of this node.
 template <class Ctx>
-HB_HD void riccati_fwd_node(const Ctx& cx, double* lds, const double* rec, const double* gains, double* dx_out,
+HB_HD void riccati_fwd_node(const Ctx& cx, double* lds, const double* ab, const double* rx, const double* gains, double* dx_out,
                             double* du_out) {
   double* dx = lds + FwdLds::dx;
   double* ut = lds + FwdLds::ut;
   double* du = lds + FwdLds::du;
   double* dxn = lds + FwdLds::dxn;
   double* acc = lds + FwdLds::acc;
-  const int n_f = int(rec[REC_META + 0]), nz = int(rec[REC_META + 1]), mode = int(rec[REC_META + 2]);
+  double* accp = lds + FwdLds::accp;
+  const double* KX = rx;
+  const double* KE = rx + (REC_KE - REC_KX);
+  const double* Zk = rx + (REC_Z - REC_KX);
+  const double* DF = rx + (REC_DF - REC_KX);
+  const double* QF = rx + (REC_QF - REC_KX);
+  const double* RF = rx + (REC_RF - REC_KX);
+  const double* META = rx + (REC_META - REC_KX);
+  const int n_f = int(META[0]), nz = int(META[1]), mode = int(META[2]);
   bool cf[HB_NC];
   mode_flags(mode, cf);
   for (int a = cx.lane; a < NU_T; a += cx.nlanes) {
@@ -216,9 +232,10 @@ HB_HD void riccati_fwd_node(const Ctx& cx, double* lds, const double* rec, const
   cx.sync();
   for (int i = cx.lane; i < 22 + 22; i += cx.nlanes) {
     if (i < 22) {
-      double s = rec[rec_b(i)];
-      for (int c = 0; c < 22; ++c) s += rec[rec_A(i, c)] * dx[c];
-      for (int a = 0; a < NU_T; ++a) s += rec[rec_B(i, a)] * ut[a];
+      const double* row = ab + i * REC_LD;
+      double s = row[REC_CV];
+      for (int c = 0; c < 22; ++c) s += row[c] * dx[c];
+      for (int a = 0; a < NU_T; ++a) s += row[REC_CU + a] * ut[a];
       dxn[i] = s;
     } else {
       const int m = i - 22;
@@ -230,32 +247,39 @@ HB_HD void riccati_fwd_node(const Ctx& cx, double* lds, const double* rec, const
           for (int f = 0; f < foot; ++f) col += cf[f] ? 3 : 0;
           s = ut[col + m % 3];
         } else {
-          s = rec[REC_DF + m];
+          s = DF[m];
         }
       } else {
         const int k = m - 12;
-        s = rec[REC_KE + k];
-        for (int c = 0; c < 22; ++c) s += rec[REC_KX + k * 22 + c] * dx[c];
-        for (int b = 0; b < nz; ++b) s += rec[REC_Z + k * 6 + b] * ut[n_f + b];
+        s = KE[k];
+        for (int c = 0; c < 22; ++c) s += KX[k * 22 + c] * dx[c];
+        for (int b = 0; b < nz; ++b) s += Zk[k * 6 + b] * ut[n_f + b];
       }
       du[m] = s;
     }
   }
   cx.sync();
-  if (cx.lane == 0) {
-    double a = 0;
-    for (int c = 0; c < 22; ++c) a += rec[REC_QF + c] * dx[c] + rec[REC_RF + c] * du[c];
-    acc[0] += a;
-    acc[1] += rec[REC_META + 3];
-    acc[2] += rec[REC_META + 4];
-    acc[3] += rec[REC_META + 5];
-  }
-  for (int i = cx.lane; i < 22; i += cx.nlanes) {
-    dx_out[i] = dx[i];
-    du_out[i] = du[i];
+  // Armijo directional derivative: one partial sum per entry, reduced once at the end of the sweep
+  for (int c = cx.lane; c < 22 + 3; c += cx.nlanes) {
+    if (c < 22) {
+      accp[c] += QF[c] * dx[c] + RF[c] * du[c];
+      dx_out[c] = dx[c];
+      du_out[c] = du[c];
+    } else {
+      acc[c - 21] += META[c - 19];  // merit, dyn, eq  <-  cost*dt, dyn_sse*dt, eq_sse*dt
+    }
   }
   cx.sync();
   for (int i = cx.lane; i < 22; i += cx.nlanes) dx[i] = dxn[i];
+  cx.sync();
+}
+template <class Ctx>
+HB_HD void riccati_fwd_finish(const Ctx& cx, double* lds) {
+  if (cx.lane == 0) {
+    double a = 0;
+    for (int c = 0; c < 22; ++c) a += lds[FwdLds::accp + c];
+    lds[FwdLds::acc] = a;
+  }
   cx.sync();
 }
 

@@ -69,8 +69,9 @@ double emu_sqp_iteration(const hb_model* m, const hb_config* c, int N, const dou
   std::vector<double> fl(FwdLds::total, 0.0);
   std::vector<double> dx(size_t(N + 1) * 22), du(size_t(N) * 22);
   for (int k = 0; k < N; ++k)
-    riccati_fwd_node(cx, fl.data(), recs.data() + size_t(k) * REC_SIZE, gains.data() + size_t(k) * GAIN_SIZE, dx.data() + k * 22,
-                     du.data() + k * 22);
+    riccati_fwd_node(cx, fl.data(), recs.data() + size_t(k) * REC_SIZE + REC_AB, recs.data() + size_t(k) * REC_SIZE + REC_KX,
+                     gains.data() + size_t(k) * GAIN_SIZE, dx.data() + k * 22, du.data() + k * 22);
+  riccati_fwd_finish(cx, fl.data());
   for (int i = 0; i < 22; ++i) dx[size_t(N) * 22 + i] = fl[FwdLds::dx + i];
   const double armijo = fl[FwdLds::acc + 0], base_merit = fl[FwdLds::acc + 1];
   const double base_viol = std::sqrt(fl[FwdLds::acc + 2] + fl[FwdLds::acc + 3]);

@@ -40,7 +40,7 @@ HB_HD void plant_substep(const Ctx& cx, const DevModel& Mdl, double* q, double* 
     // results and work arrays in LDS (the X / A buffers are not live yet): thread-private they would sit in scratch
     static_assert((sizeof(BodyPass) + sizeof(BodyWork) + 7) / 8 <= 208 + 144 + 12, "rigid-body workspace must fit X | A | b");
     BodyPass& P = *reinterpret_cast<BodyPass*>(X);
-    body_pass(Mdl, q, v, P, reinterpret_cast<BodyWork*>(X + (sizeof(BodyPass) + 7) / 8));
+    body_pass(Mdl, q, v, P, *reinterpret_cast<BodyWork*>(X + (sizeof(BodyPass) + 7) / 8));
     mass_matrix(P, Mm);
     for (int a = 0; a < 16; ++a) nle[a] = P.nle[a];
     for (int ci = 0; ci < HB_NC; ++ci) {

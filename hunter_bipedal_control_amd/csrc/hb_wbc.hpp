@@ -67,9 +67,13 @@ struct BodyWork {
 };
 
 // q = [pos(3) zyx(3) joints(10)], v = qdot.  Accelerations are evaluated at qddot = 0.
-HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPass& P, BodyWork* work = nullptr) {
+HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPass& P, BodyWork& Wk);
+// convenience form with thread-private work arrays (unit entry points only: they end up in scratch memory)
+HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPass& P) {
   BodyWork local_work;
-  BodyWork& Wk = work ? *work : local_work;
+  body_pass(M, q, v, P, local_work);
+}
+HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPass& P, BodyWork& Wk) {
   double sz, cz, sy, cy, sx, cx;
   sincos_t(q[3], sz, cz);
   sincos_t(q[4], sy, cy);
@@ -298,13 +302,13 @@ struct PhaseAWork {
 };
 constexpr int PHASE_A_WORK_DOUBLES = (sizeof(PhaseAWork) + 7) / 8;
 
-// `ws` (optional, PHASE_A_WORK_DOUBLES doubles, e.g. an LDS buffer that is not live yet) holds the rigid-body results
-// and work arrays; without it they are thread-private (scratch).
+// `ws` (PHASE_A_WORK_DOUBLES doubles, e.g. an LDS buffer that is not live yet) holds the rigid-body results and work
+// arrays.  It is mandatory: an optional thread-private fallback made the compiler reserve 4.6 KB of scratch per lane in
+// every kernel that inlines this function, used or not.
 HB_HD void wbc_phase_a(const DevModel& M, const DevConfig& C, const double* xdes, const double* udes, const double* rbd,
                        const WbcCons& wc, bool stance_mode, double w_swing, double w_base, double* Rm, double* Ee,
-                       double* beom, double* Aw, double* bw, double* Jc, double* dJv, double* ws = nullptr) {
-  PhaseAWork local_ws;
-  PhaseAWork& K = ws ? *reinterpret_cast<PhaseAWork*>(ws) : local_ws;
+                       double* beom, double* Aw, double* bw, double* Jc, double* dJv, double* ws) {
+  PhaseAWork& K = *reinterpret_cast<PhaseAWork*>(ws);
   {
     double* q = K.q;
     double* v = K.v;
@@ -325,7 +329,7 @@ HB_HD void wbc_phase_a(const DevModel& M, const DevConfig& C, const double* xdes
       v[3] = er.x; v[4] = er.y; v[5] = er.z;
     }
     BodyPass& P = K.P;
-    body_pass(M, q, v, P, &K.W);
+    body_pass(M, q, v, P, K.W);
     // EoM rows: [M, -J', -S'] x = -nle   (WbcBase.cpp:138-149)
     mass_matrix(P, Rm);  // stage M in the R buffer (16x16)
     for (int i = 0; i < 16; ++i) {
@@ -364,7 +368,7 @@ HB_HD void wbc_phase_a(const DevModel& M, const DevConfig& C, const double* xdes
       vd_[3] = cd.euler_rate.x; vd_[4] = cd.euler_rate.y; vd_[5] = cd.euler_rate.z;
       for (int j = 0; j < HB_NJ; ++j) vd_[6 + j] = udes[12 + j];
       BodyPass& D = K.D;
-      body_pass(M, qd_, vd_, D, &K.W);
+      body_pass(M, qd_, vd_, D, K.W);
       // base acceleration desired: A_b qdd_b = m hdot_norm(x,u) - Adot v   (zero joint accelerations)
       const Vec3<double> comr = (1.0 / D.mass) * D.mc;
       Vec3<double> fs, ms;
@@ -757,10 +761,15 @@ __global__ void k_policy_eval(WbcBatch w, int Nmax, const DevConfig* __restrict_
               w.walk[inst] != 0, w.xdes + size_t(inst) * HB_NX, w.udes + size_t(inst) * HB_NU, w.mode + inst, w.stance + inst);
 }
 
+// one wavefront per instance, lanes exchange data through LDS only: wave-scope ordering point (see WaveCtx, hb_kernels.hip)
 struct WbcDeviceCtx {
-  int lane, nlanes;
-  __device__ WbcDeviceCtx() : lane(threadIdx.x), nlanes(blockDim.x) {}
-  __device__ void sync() const { __syncthreads(); }
+  int lane;
+  static constexpr int nlanes = 64;
+  __device__ WbcDeviceCtx() : lane(threadIdx.x) {}
+  __device__ void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 };
 
 __global__ __launch_bounds__(64) void k_wbc(WbcBatch w, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {

@@ -156,9 +156,12 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
       }
     }
     cx.sync();
+    // number of projected inputs of this stage (uniform; back long before the factorisation needs it)
+    const double* meta = b.recs + (size_t(inst) * b.Nmax + k) * REC_SIZE + REC_META;
+    const double m_nf = meta[0], m_nz = meta[1];
     if (dbg == 20) { if (k > 0) HB_RIC_FETCH(k - 1, l); continue; }  // profiling ablation: staging only
     ric_phase1(cxk, lds);
-    if (dbg != 21) ric_phase2(cxk, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE, dbg);
+    if (dbg != 21) ric_phase2(cxk, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE, int(m_nf) + int(m_nz), dbg);
     asm volatile("" : "+v"(l));
     cxk.lane = l;
     HB_RIC_FETCH_Q(k, l);
@@ -1456,7 +1459,8 @@ int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, int32_t nu, const do
           rec[rec_r(a)] = r[sk * nu + a];
         }
       }
-      rec[REC_META + 0] = 0.0;  // forward pass: treat all inputs as "kernel" columns is not needed here
+      rec[REC_META + 0] = double(nu);  // number of real inputs (the backward sweep picks its factor width from it)
+      rec[REC_META + 1] = 0.0;
     }
   // The forward kernel reconstructs du through the projection data; for this unit entry point the reduced input
   // is returned directly, so run backward on the device and the (cheap) forward recursion on the host.

@@ -50,30 +50,27 @@ HB_HD void ric_phase1(const Ctx& cx, double* lds) {
   tile_store(cx, t, 22, RicLds::LDW, [M1](int i, int c, double v) { M1[i * RicLds::LDW + c] = v; });
   cx.sync();
 }
-template <class Ctx>
-HB_HD void ric_phase2(const Ctx& cx, double* lds, double* gains, int dbg = 0) {
-  const double* PRr = lds + RicLds::PRr;
+// Cholesky of the leading NT x NT block of Huu and the 23 triangular solves.  Every lane factors the (uniform) block
+// redundantly in registers, lane c < 23 then solves its own right-hand side.  NT = 9 serves every stage with at most
+// 9 projected inputs (single support: 6 contact-force + 3 kernel coordinates; flight: 6) — the padding rows of the
+// record are R~ = I, B~ = 0, P~ = 0, r~ = 0, so their gains are exactly zero and the factor work drops by ~(9/12)^3.
+template <int NT, class Ctx>
+HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
   double* Hu = lds + RicLds::Hu;
   double* Kk = lds + RicLds::Kk;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // keep the loads of this width's triangle inside its branch: hoisted above the 9 / 12 dispatch they were spilled
+  asm volatile("" ::: "memory");
+#endif
   {
-    WaveTile<1, 3> t;
-    tile_init(cx, t, NU_T, RicLds::LDW, [PRr](int a, int c) { return PRr[a * RicLds::LDW + c]; });
-    tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t, lds + RicLds::ABb + RicLds::CU, lds + RicLds::M1, NU_T, RicLds::LDW);
-    tile_store(cx, t, NU_T, RicLds::LDW, [Hu](int a, int c, double v) { Hu[a * RicLds::LDW + c] = v; });  // over [P~ r~ R~]
-  }
-  cx.sync();
-  if (dbg == 22) return;
-  // Cholesky of Huu and the 23 triangular solves entirely in registers: every lane factors the (uniform) 12x12
-  // block redundantly, lane c < 23 then solves its own right-hand side — no LDS traffic, no barriers.
-  {
-    double L[NU_T * (NU_T + 1) / 2];
+    double L[NT * (NT + 1) / 2];
 #pragma unroll
-    for (int i = 0; i < NU_T; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = Hu[i * RicLds::LDW + RicLds::CU + j];
     bool bad = false;
 #pragma unroll
-    for (int j = 0; j < NU_T; ++j) {
+    for (int j = 0; j < NT; ++j) {
       double d = L[j * (j + 1) / 2 + j];
 #pragma unroll
       for (int k = 0; k < j; ++k) d -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
@@ -81,7 +78,7 @@ HB_HD void ric_phase2(const Ctx& cx, double* lds, double* gains, int dbg = 0) {
       const double inv = rsqrt_t(d);
       L[j * (j + 1) / 2 + j] = inv;  // store the reciprocal of the diagonal
 #pragma unroll
-      for (int i = j + 1; i < NU_T; ++i) {
+      for (int i = j + 1; i < NT; ++i) {
         double sacc = L[i * (i + 1) / 2 + j];
 #pragma unroll
         for (int k = 0; k < j; ++k) sacc -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
@@ -90,11 +87,11 @@ HB_HD void ric_phase2(const Ctx& cx, double* lds, double* gains, int dbg = 0) {
     }
     if (bad && cx.lane == 0) lds[RicLds::flag] = 1.0;
     // The factor (lane-uniform) goes back to LDS over the lower triangle of Huu, which is dead from here on: the solves
-    // then read it through broadcast loads and the 156 registers are free again (explicit "spill" to LDS; a register
+    // then read it through broadcast loads and the registers are free again (explicit "spill" to LDS; a register
     // file that still held L here pushed the kernel's loop invariants into scratch memory).
     if (cx.lane == 0) {
 #pragma unroll
-      for (int i = 0; i < NU_T; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) Hu[i * RicLds::LDW + RicLds::CU + j] = L[i * (i + 1) / 2 + j];
     }
@@ -105,19 +102,21 @@ HB_HD void ric_phase2(const Ctx& cx, double* lds, double* gains, int dbg = 0) {
     for (int c = cx.lane; c < 23; c += cx.nlanes) {  // columns 0..21 = Hux, 22 = hu
       double y[NU_T];
 #pragma unroll
-      for (int a = 0; a < NU_T; ++a) {
+      for (int a = 0; a < NT; ++a) {
         double sacc = -Hu[a * RicLds::LDW + c];
 #pragma unroll
         for (int k = 0; k < a; ++k) sacc -= Lm[a * RicLds::LDW + k] * y[k];
         y[a] = sacc * Lm[a * RicLds::LDW + a];
       }
 #pragma unroll
-      for (int a = NU_T - 1; a >= 0; --a) {
+      for (int a = NT - 1; a >= 0; --a) {
         double sacc = y[a];
 #pragma unroll
-        for (int k = a + 1; k < NU_T; ++k) sacc -= Lm[k * RicLds::LDW + a] * y[k];
+        for (int k = a + 1; k < NT; ++k) sacc -= Lm[k * RicLds::LDW + a] * y[k];
         y[a] = sacc * Lm[a * RicLds::LDW + a];
       }
+#pragma unroll
+      for (int a = NT; a < NU_T; ++a) y[a] = 0.0;
       double* gp = gains + (c < 22 ? c : 264);  // straight from the registers: lanes 0..21 write one row segment
       const int gs = c < 22 ? 22 : 1;
 #pragma unroll
@@ -128,6 +127,22 @@ HB_HD void ric_phase2(const Ctx& cx, double* lds, double* gains, int dbg = 0) {
     }
   }
   cx.sync();
+}
+// `n_til` = number of projected inputs of the stage (contact-force + kernel coordinates, REC_META)
+template <class Ctx>
+HB_HD void ric_phase2(const Ctx& cx, double* lds, double* gains, int n_til, int dbg = 0) {
+  const double* PRr = lds + RicLds::PRr;
+  double* Hu = lds + RicLds::Hu;
+  {
+    WaveTile<1, 3> t;
+    tile_init(cx, t, NU_T, RicLds::LDW, [PRr](int a, int c) { return PRr[a * RicLds::LDW + c]; });
+    tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t, lds + RicLds::ABb + RicLds::CU, lds + RicLds::M1, NU_T, RicLds::LDW);
+    tile_store(cx, t, NU_T, RicLds::LDW, [Hu](int a, int c, double v) { Hu[a * RicLds::LDW + c] = v; });  // over [P~ r~ R~]
+  }
+  cx.sync();
+  if (dbg == 22) return;
+  if (n_til <= 9) ric_factor_solve<9>(cx, lds, gains);
+  else ric_factor_solve<NU_T>(cx, lds, gains);
 }
 // GEMM 3 in two halves: `ric_phase3_mma` accumulates T - [Q~ q~] = A~' [M1_A M1_b] + Hux' [K~ k~]; the caller then drops
 // [Q~ (22 x 22 row-major) | q~ (22)] at RicLds::Qs — it has no buffer of its own and goes over the A~ block, dead once
@@ -177,7 +192,7 @@ template <class Ctx>
 HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, const double* rec, double* gains, int dbg = 0) {
   ric_phase1(cx, lds);
   if (dbg == 21) return;  // profiling ablation markers (hb_config.reserved)
-  ric_phase2(cx, lds, gains, dbg);
+  ric_phase2(cx, lds, gains, int(rec[REC_META]) + int(rec[REC_META + 1]), dbg);
   if (dbg == 22 || dbg == 23) return;
   WaveTile<2, 2> t;
   ric_phase3_mma(cx, lds, t);

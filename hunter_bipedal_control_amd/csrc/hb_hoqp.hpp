@@ -304,8 +304,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   wc.n_eq = 16 + 3 * wc.n_sw;
   wc.n_in = 20 + 5 * wc.n_c;
   const int mA0 = 16 + 3 * wc.n_sw + 3 * wc.n_c;  // always 28
-  if (cx.lane == 0)
-    wbc_phase_a(M, C, xdes, udes, rbd, wc, false, 1.0, 1.0, Rm, Ee, beom, Aw, bw, Jc, dJv, Jm);
+  wbc_phase_a(cx, M, C, xdes, udes, rbd, wc, false, 1.0, 1.0, Rm, Ee, beom, Aw, bw, Jc, dJv, Jm);
   for (int c = cx.lane; c < 40; c += cx.nlanes) viol[c] = 0;
   cx.sync();
 

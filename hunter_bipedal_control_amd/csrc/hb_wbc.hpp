@@ -210,6 +210,22 @@ HB_HD void mass_matrix(const BodyPass& P, double* Mm /*16x16 row-major*/) {
       }
     }
 }
+// one entry of the mass matrix (same formulas as mass_matrix, addressed by (row, col) so that lanes can share the fill)
+HB_HD double mass_entry(const BodyPass& P, int r, int c) {
+  if (r > c) { const int t = r; r = c; c = t; }  // symmetric: evaluate the upper triangle
+  if (c < 3) return r == c ? P.mass : 0.0;
+  if (c < 6) {
+    if (r < 3) return comp(cross(P.E[c - 3], P.mc), r);
+    return dot(P.E[r - 3], P.IO * P.E[c - 3]);
+  }
+  const int leg = (c - 6) / 5, k = (c - 6) - 5 * leg;
+  const Vec3<double> l = P.l[leg][k], L = P.L[leg][k];
+  if (r < 3) return comp(l, r);
+  if (r < 6) return dot(P.E[r - 3], L);
+  const int legr = (r - 6) / 5, j = (r - 6) - 5 * legr;
+  if (legr != leg) return 0.0;
+  return dot(P.a[leg][j], L - cross(P.o[leg][j], l));  // j <= k
+}
 // linear Jacobian entry of contact point ci w.r.t. coordinate col
 HB_HD Vec3<double> contact_jac(const BodyPass& P, int ci, int col) {
   if (col < 3) return Vec3<double>(col == 0 ? 1.0 : 0.0, col == 1 ? 1.0 : 0.0, col == 2 ? 1.0 : 0.0);
@@ -297,68 +313,48 @@ HB_HD int sparse_row(const WbcCons& wc, const DevConfig& C, int cid, int* idx, d
 // and bias accelerations (12).
 struct PhaseAWork {
   BodyPass P, D;
-  BodyWork W;
+  BodyWork W, W2;
   double q[HB_NV], v[HB_NV], qd[HB_NV], vd[HB_NV];
+  double sc[16];  // acc_lin(3) acc_ang(3) err(3) of the base task
 };
 constexpr int PHASE_A_WORK_DOUBLES = (sizeof(PhaseAWork) + 7) / 8;
 
+// Phase A of every WBC variant: rigid-body quantities of the measured state, desired kinematics from the MPC
+// state/input, EoM rows and the dense cost rows [swing legs (weight w_swing) ; base acceleration (weight w_base)] or, in
+// stance mode, qdd_base = 0.  Rm is a 16x16 scratch.  Jc/dJv (optional) receive the contact Jacobians (12x16) and bias
+// accelerations (12).  Lane-cooperative: the two rigid-body passes (measured / desired state) run side by side on two
+// lanes, every matrix fill is shared by the wave (one entry per lane and round).
 // `ws` (PHASE_A_WORK_DOUBLES doubles, e.g. an LDS buffer that is not live yet) holds the rigid-body results and work
 // arrays.  It is mandatory: an optional thread-private fallback made the compiler reserve 4.6 KB of scratch per lane in
 // every kernel that inlines this function, used or not.
-HB_HD void wbc_phase_a(const DevModel& M, const DevConfig& C, const double* xdes, const double* udes, const double* rbd,
+template <class Ctx>
+HB_HD void wbc_phase_a(const Ctx& cx, const DevModel& M, const DevConfig& C, const double* xdes, const double* udes, const double* rbd,
                        const WbcCons& wc, bool stance_mode, double w_swing, double w_base, double* Rm, double* Ee,
                        double* beom, double* Aw, double* bw, double* Jc, double* dJv, double* ws) {
   PhaseAWork& K = *reinterpret_cast<PhaseAWork*>(ws);
-  {
-    double* q = K.q;
-    double* v = K.v;
-    for (int i = 0; i < 3; ++i) {
-      q[i] = rbd[3 + i];
-      q[3 + i] = rbd[i];
-      v[i] = rbd[HB_NV + 3 + i];
-    }
-    for (int j = 0; j < HB_NJ; ++j) {
-      q[6 + j] = rbd[6 + j];
-      v[6 + j] = rbd[HB_NV + 6 + j];
-    }
-    {
+  double* q = K.q;
+  double* v = K.v;
+  BodyPass& P = K.P;
+  BodyPass& D = K.D;
+  // ---- step 1: rigid-body passes, task 0 = measured state, task 1 = desired state (WbcBase.cpp:85-136)
+  for (int task = cx.lane; task < 2; task += cx.nlanes) {
+    if (task == 0) {
+      for (int i = 0; i < 3; ++i) {
+        q[i] = rbd[3 + i];
+        q[3 + i] = rbd[i];
+        v[i] = rbd[HB_NV + 3 + i];
+      }
+      for (int j = 0; j < HB_NJ; ++j) {
+        q[6 + j] = rbd[6 + j];
+        v[6 + j] = rbd[HB_NV + 6 + j];
+      }
       double sz, cz, sy, cy;
       sincos_t(q[3], sz, cz);
       sincos_t(q[4], sy, cy);
       const Vec3<double> er = euler_rates_from_omega<double>(sz, cz, sy, cy, Vec3<double>(rbd[HB_NV], rbd[HB_NV + 1], rbd[HB_NV + 2]));
       v[3] = er.x; v[4] = er.y; v[5] = er.z;
-    }
-    BodyPass& P = K.P;
-    body_pass(M, q, v, P, K.W);
-    // EoM rows: [M, -J', -S'] x = -nle   (WbcBase.cpp:138-149)
-    mass_matrix(P, Rm);  // stage M in the R buffer (16x16)
-    for (int i = 0; i < 16; ++i) {
-      for (int j = 0; j < 16; ++j) Ee[i * NW + j] = Rm[i * 16 + j];
-      for (int ci = 0; ci < HB_NC; ++ci) {
-        const Vec3<double> jc = contact_jac(P, ci, i);
-        Ee[i * NW + 16 + 3 * ci + 0] = -jc.x;
-        Ee[i * NW + 16 + 3 * ci + 1] = -jc.y;
-        Ee[i * NW + 16 + 3 * ci + 2] = -jc.z;
-      }
-      for (int j = 0; j < HB_NJ; ++j) Ee[i * NW + 28 + j] = (i == 6 + j) ? -1.0 : 0.0;
-      beom[i] = -P.nle[i];
-    }
-    if (Jc) {  // contact Jacobians and bias accelerations (no-contact-motion task, WbcBase.cpp:169-188)
-      for (int ci = 0; ci < HB_NC; ++ci) {
-        for (int col = 0; col < 16; ++col) {
-          const Vec3<double> jc = contact_jac(P, ci, col);
-          Jc[(3 * ci + 0) * 16 + col] = jc.x; Jc[(3 * ci + 1) * 16 + col] = jc.y; Jc[(3 * ci + 2) * 16 + col] = jc.z;
-        }
-        dJv[3 * ci] = P.foot_acc[ci].x; dJv[3 * ci + 1] = P.foot_acc[ci].y; dJv[3 * ci + 2] = P.foot_acc[ci].z;
-      }
-    }
-    // cost rows (dense part over the 16 accelerations)
-    for (int i = 0; i < 18 * 16; ++i) Aw[i] = 0.0;
-    for (int i = 0; i < 18; ++i) bw[i] = 0.0;
-    if (stance_mode) {
-      for (int i = 0; i < 6; ++i) Aw[i * 16 + i] = w_base;  // WeightedWbc.cpp:83-94
-    } else {
-      // desired kinematics (WbcBase.cpp:122-136)
+      body_pass(M, q, v, P, K.W);
+    } else if (!stance_mode) {
       Centroidal<double> cd;
       centroidal_eval<double>(M, xdes + 9, xdes + 12, xdes, udes + 12, cd);
       double* qd_ = K.qd;
@@ -367,8 +363,7 @@ HB_HD void wbc_phase_a(const DevModel& M, const DevConfig& C, const double* xdes
       vd_[0] = cd.v_lin.x; vd_[1] = cd.v_lin.y; vd_[2] = cd.v_lin.z;
       vd_[3] = cd.euler_rate.x; vd_[4] = cd.euler_rate.y; vd_[5] = cd.euler_rate.z;
       for (int j = 0; j < HB_NJ; ++j) vd_[6 + j] = udes[12 + j];
-      BodyPass& D = K.D;
-      body_pass(M, qd_, vd_, D, K.W);
+      body_pass(M, qd_, vd_, D, K.W2);
       // base acceleration desired: A_b qdd_b = m hdot_norm(x,u) - Adot v   (zero joint accelerations)
       const Vec3<double> comr = (1.0 / D.mass) * D.mc;
       Vec3<double> fs, ms;
@@ -387,33 +382,71 @@ HB_HD void wbc_phase_a(const DevModel& M, const DevConfig& C, const double* xdes
       const Vec3<double> wdot = sym3_solve<double>(Icom, yang);  // = E * euler_ddot
       const Vec3<double> acc_lin = (1.0 / D.mass) * ylin - cross(wdot, comr);
       const Vec3<double> acc_ang = wdot + D.alpha0;
-      // swing leg rows (WbcBase.cpp:297-323), weight w_swing
-      int row = 0;
-      for (int s = 0; s < wc.n_sw; ++s) {
-        const int i = wc.swing_feet[s];
+      K.sc[0] = acc_lin.x; K.sc[1] = acc_lin.y; K.sc[2] = acc_lin.z;
+      K.sc[3] = acc_ang.x; K.sc[4] = acc_ang.y; K.sc[5] = acc_ang.z;
+    }
+  }
+  cx.sync();
+  // ---- step 2: fills shared by the wave.  EoM rows: [M, -J', -S'] x = -nle   (WbcBase.cpp:138-149)
+  for (int idx = cx.lane; idx < 16 * NW; idx += cx.nlanes) {
+    const int i = idx / NW, j = idx - NW * i;
+    double val;
+    if (j < 16) {
+      val = mass_entry(P, i, j);
+      Rm[i * 16 + j] = val;
+    } else if (j < 28) {
+      const int ci = (j - 16) / 3, a = (j - 16) - 3 * ci;
+      val = -comp(contact_jac(P, ci, i), a);
+    } else {
+      val = (i == j - 22) ? -1.0 : 0.0;
+    }
+    Ee[idx] = val;
+  }
+  for (int i = cx.lane; i < 16; i += cx.nlanes) beom[i] = -P.nle[i];
+  if (Jc) {  // contact Jacobians and bias accelerations (no-contact-motion task, WbcBase.cpp:169-188)
+    for (int idx = cx.lane; idx < 12 * 16; idx += cx.nlanes) {
+      const int r = idx / 16, col = idx - 16 * r, ci = r / 3, a = r - 3 * ci;
+      Jc[idx] = comp(contact_jac(P, ci, col), a);
+    }
+    for (int r = cx.lane; r < 12; r += cx.nlanes) dJv[r] = comp(P.foot_acc[r / 3], r % 3);
+  }
+  // cost rows (dense part over the 16 accelerations)
+  for (int i = cx.lane; i < 18 * 16; i += cx.nlanes) Aw[i] = 0.0;
+  for (int i = cx.lane; i < 18; i += cx.nlanes) bw[i] = 0.0;
+  cx.sync();
+  if (stance_mode) {
+    for (int i = cx.lane; i < 6; i += cx.nlanes) Aw[i * 16 + i] = w_base;  // WeightedWbc.cpp:83-94
+  } else {
+    // swing leg rows (WbcBase.cpp:297-323), weight w_swing: row 3 s + a, one (row, column) entry per lane
+    for (int idx = cx.lane; idx < 3 * wc.n_sw * 17; idx += cx.nlanes) {
+      const int row = idx / 17, col = idx - 17 * row, sidx = row / 3, a = row - 3 * sidx;
+      const int i = wc.swing_feet[sidx];
+      if (col < 16) {
+        Aw[row * 16 + col] = w_swing * comp(contact_jac(P, i, col), a);
+      } else {
         const Vec3<double> pe = (Vec3<double>(xdes[6], xdes[7], xdes[8]) + D.foot[i]) - (Vec3<double>(q[0], q[1], q[2]) + P.foot[i]);
         const Vec3<double> ve = D.foot_vel[i] - P.foot_vel[i];
-        for (int a = 0; a < 3; ++a) {
-          for (int col = 0; col < 16; ++col) Aw[row * 16 + col] = w_swing * comp(contact_jac(P, i, col), a);
-          bw[row] = w_swing * (C.swing_kp * comp(pe, a) + C.swing_kd * comp(ve, a) - comp(P.foot_acc[i], a));
-          ++row;
-        }
+        bw[row] = w_swing * (C.swing_kp * comp(pe, a) + C.swing_kd * comp(ve, a) - comp(P.foot_acc[i], a));
       }
-      // base acceleration rows (WbcBase.cpp:228-295), weight w_base
-      Aw[row * 16 + 0] = w_base; bw[row] = w_base * acc_lin.x; ++row;
-      Aw[row * 16 + 1] = w_base; bw[row] = w_base * acc_lin.y; ++row;
-      Aw[row * 16 + 2] = w_base;
-      bw[row] = w_base * (acc_lin.z + C.bh_kp * (xdes[8] - q[2]) + C.bh_kd * (cd.v_lin.z - v[2]));
-      ++row;
-      const Vec3<double> err = rot_log(D.R0, P.R0);
-      for (int a = 0; a < 3; ++a) {
+    }
+    // base acceleration rows (WbcBase.cpp:228-295), weight w_base: rows 3 n_sw .. 3 n_sw + 5
+    const int row0 = 3 * wc.n_sw;
+    for (int r = cx.lane; r < 6; r += cx.nlanes) {
+      const int row = row0 + r;
+      if (r < 3) {
+        Aw[row * 16 + r] = w_base;
+        double rhs = K.sc[r];
+        if (r == 2) rhs += C.bh_kp * (xdes[8] - q[2]) + C.bh_kd * (K.vd[2] - v[2]);
+        bw[row] = w_base * rhs;
+      } else {
+        const int a = r - 3;
+        const Vec3<double> err = rot_log(D.R0, P.R0);
         for (int cdir = 0; cdir < 3; ++cdir) Aw[row * 16 + 3 + cdir] = w_base * comp(P.E[cdir], a);
-        bw[row] = w_base * (comp(acc_ang, a) + C.ba_kp * comp(err, a) + C.ba_kd * (comp(D.omega0, a) - comp(P.omega0, a)) -
-                              comp(P.alpha0, a));
-        ++row;
+        bw[row] = w_base * (K.sc[3 + a] + C.ba_kp * comp(err, a) + C.ba_kd * (comp(D.omega0, a) - comp(P.omega0, a)) - comp(P.alpha0, a));
       }
     }
   }
+  cx.sync();
 }
 
 // One WBC solve.  xdes/udes/rbd: this instance's inputs; sol in/out (kept when the QP fails).
@@ -452,12 +485,10 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   // number of dense cost rows: stance mode 6 (qdd_base = 0), else 3*n_sw swing + 6 base
   const int n_aw = stance_mode ? 6 : 3 * wc.n_sw + 6;
 
-  // ------------------------------------------------------------------ phase A: rigid-body quantities (lane 0)
-  if (cx.lane == 0) {
-    static_assert(PHASE_A_WORK_DOUBLES <= NW * NW, "phase-A workspace must fit the J buffer");
-    wbc_phase_a(M, C, xdes, udes, rbd, wc, stance_mode, C.w_swing, C.w_base, Rm, Ee, beom, Aw, bw, nullptr, nullptr, Jm);
-    misc[0] = 0.0;  // status
-  }
+  // ------------------------------------------------------------------ phase A: rigid-body quantities
+  static_assert(PHASE_A_WORK_DOUBLES <= NW * NW, "phase-A workspace must fit the J buffer");
+  wbc_phase_a(cx, M, C, xdes, udes, rbd, wc, stance_mode, C.w_swing, C.w_base, Rm, Ee, beom, Aw, bw, nullptr, nullptr, Jm);
+  if (cx.lane == 0) misc[0] = 0.0;  // status
   cx.sync();
 
   if (C.debug_stop == 11) return;

@@ -70,11 +70,11 @@ struct RelaxedBarrierD {
   double mu, delta;
   HB_HD double value(double h) const {
     if (h > delta) return -mu * log(h);
-    const double z = (h - 2.0 * delta) / delta;
+    const double z = (h - 2.0 * delta) * rcp_t(delta);
     return mu * (-log(delta) + 0.5 * z * z - 0.5);
   }
-  HB_HD double d1(double h) const { return h > delta ? -mu / h : mu * (h - 2.0 * delta) / (delta * delta); }
-  HB_HD double d2(double h) const { return h > delta ? mu / (h * h) : mu / (delta * delta); }
+  HB_HD double d1(double h) const { const double r = rcp_t(h > delta ? h : delta); return h > delta ? -mu * r : mu * (h - 2.0 * delta) * r * r; }
+  HB_HD double d2(double h) const { const double r = rcp_t(h > delta ? h : delta); return mu * r * r; }
 };
 
 // LDS carve (doubles).  2522 doubles = 20 176 B per node -> 8 single-wave workgroups per CU (two per SIMD).
@@ -204,7 +204,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       msum = msum + cross(fr - core.com_rel, F);
       fsx += F.x; fsy += F.y; fsz += F.z;
     }
-    const double inv_m = 1.0 / M.total_mass;
+    const double inv_m = rcp_t(M.total_mass);
     fv[0] = inv_m * fsx; fv[1] = inv_m * fsy; fv[2] = inv_m * fsz - M.gravity;
     fv[3] = inv_m * msum.x; fv[4] = inv_m * msum.y; fv[5] = inv_m * msum.z;
     fv[6] = core.v_lin.x; fv[7] = core.v_lin.y; fv[8] = core.v_lin.z;
@@ -294,7 +294,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
           }
         }
       }
-      const double inv_m = 1.0 / M.total_mass;
+      const double inv_m = rcp_t(M.total_mass);
       const Dual1 f[12] = {Dual1(0.0), Dual1(0.0), Dual1(0.0), inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
                            core.v_lin.x, core.v_lin.y, core.v_lin.z, core.euler_rate.x, core.euler_rate.y, core.euler_rate.z};
 #pragma unroll
@@ -321,7 +321,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     for (int i = 0; i < 12; ++i) col[i] = 0.0;
     if (is_f) {
       const int i = (dir - 22) / 3, a = (dir - 22) % 3;
-      const double inv_m = 1.0 / M.total_mass;
+      const double inv_m = rcp_t(M.total_mass);
       col[a] = inv_m;
       // (r x e_a) / m
       const double rx = FR[12 * pt + 3 * i], ry = FR[12 * pt + 3 * i + 1], rz = FR[12 * pt + 3 * i + 2];
@@ -519,8 +519,9 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       const double Fx = in.u[3 * i], Fy = in.u[3 * i + 1], Fz = in.u[3 * i + 2];
       const double t2 = Fx * Fx + Fy * Fy + C.friction_reg, tn = sqrt(t2), t32 = tn * t2;
       h = C.friction_mu * (Fz + C.friction_gripper) - tn;
-      g[0] = -Fx / tn; g[1] = -Fy / tn; g[2] = C.friction_mu;
-      H00 = -(Fy * Fy + C.friction_reg) / t32; H01 = Fx * Fy / t32; H11 = -(Fx * Fx + C.friction_reg) / t32;
+      const double itn = rcp_t(tn), it32 = rcp_t(t32);
+      g[0] = -Fx * itn; g[1] = -Fy * itn; g[2] = C.friction_mu;
+      H00 = -(Fy * Fy + C.friction_reg) * it32; H01 = Fx * Fy * it32; H11 = -(Fx * Fx + C.friction_reg) * it32;
     };
     // Friction-cone data once per contact foot (lane = foot), shared through LDS (R_jj is not live yet):
     //   [h, g0, g1, g2, H00, H01, H11, p(h), p'(h), p''(h)]

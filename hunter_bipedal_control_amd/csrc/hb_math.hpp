@@ -24,9 +24,25 @@ HB_HD Dual1 operator+(Dual1 a, Dual1 b) { return {a.v + b.v, a.d + b.d}; }
 HB_HD Dual1 operator-(Dual1 a, Dual1 b) { return {a.v - b.v, a.d - b.d}; }
 HB_HD Dual1 operator-(Dual1 a) { return {-a.v, -a.d}; }
 HB_HD Dual1 operator*(Dual1 a, Dual1 b) { return {a.v * b.v, fma(a.v, b.d, a.d * b.v)}; }
+// Reciprocal by v_rcp_f64 + two Newton steps (within 1 ulp; the IEEE division sequence costs twice the instructions).
+// Arguments on this path are masses, determinants of inertia tensors, cos(pitch), barrier arguments: normal, non-zero.
+HB_HD double rcp_t(double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(a);
+  r = fma(fma(-a, r, 1.0), r, r);
+  r = fma(fma(-a, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / a;
+#endif
+}
 HB_HD Dual1 operator/(Dual1 a, Dual1 b) {
-  const double inv = 1.0 / b.v, q = a.v * inv;
+  const double inv = rcp_t(b.v), q = a.v * inv;
   return {q, (a.d - q * b.d) * inv};
+}
+HB_HD Dual1 rcp_t(Dual1 a) {
+  const double r = rcp_t(a.v);
+  return {r, -a.d * r * r};
 }
 HB_HD Dual1 operator*(double a, Dual1 b) { return {a * b.v, a * b.d}; }
 HB_HD Dual1 operator*(Dual1 b, double a) { return {a * b.v, a * b.d}; }
@@ -81,7 +97,7 @@ HB_HD double rsqrt_t(double a) {
 HB_HD double sqrt_t(double a) { return sqrt(a); }
 HB_HD Dual1 sqrt_t(Dual1 a) {
   const double r = sqrt(a.v);
-  return {r, 0.5 * a.d / r};
+  return {r, 0.5 * a.d * rcp_t(r)};
 }
 HB_HD double val(double a) { return a; }
 HB_HD double val(Dual1 a) { return a.v; }
@@ -178,7 +194,7 @@ template <class T> HB_HD Vec3<T> sym3_solve(const Sym3<T>& s, Vec3<T> b) {
   const T c00 = s.yy * s.zz - s.yz * s.yz, c01 = s.xz * s.yz - s.xy * s.zz, c02 = s.xy * s.yz - s.xz * s.yy;
   const T c11 = s.xx * s.zz - s.xz * s.xz, c12 = s.xy * s.xz - s.xx * s.yz, c22 = s.xx * s.yy - s.xy * s.xy;
   const T det = s.xx * c00 + s.xy * c01 + s.xz * c02;
-  const T inv = T(1.0) / det;
+  const T inv = rcp_t(det);
   return {inv * (c00 * b.x + c01 * b.y + c02 * b.z), inv * (c01 * b.x + c11 * b.y + c12 * b.z),
           inv * (c02 * b.x + c12 * b.y + c22 * b.z)};
 }

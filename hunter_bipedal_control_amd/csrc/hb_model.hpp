@@ -393,7 +393,7 @@ HB_HD void leg_tangent(const double* blk, int s, bool rate, double* t) {
 // ZYX euler rates from the world angular velocity (inverse of omega = E(zyx) * rates).
 template <class T>
 HB_HD Vec3<T> euler_rates_from_omega(T sz, T cz, T sy, T cy, Vec3<T> w) {
-  const T roll_rate = (cz * w.x + sz * w.y) / cy;
+  const T roll_rate = (cz * w.x + sz * w.y) * rcp_t(cy);
   const T pitch_rate = cz * w.y - sz * w.x;
   const T yaw_rate = w.z + sy * roll_rate;
   return {yaw_rate, pitch_rate, roll_rate};
@@ -419,7 +419,7 @@ HB_HD void centroidal_core(const DevModel& M, Vec3<T> mc_legs, Sym3<T> IO_legs, 
   Ib.yy = T(M.inertia[0][3]); Ib.yz = T(M.inertia[0][4]); Ib.zz = T(M.inertia[0][5]);
   const Vec3<T> mc = T(mb) * cb + mc_legs;
   const Sym3<T> IO = Ib + point_inertia<T>(T(mb), cb) + IO_legs;
-  const double inv_m = 1.0 / mt;
+  const double inv_m = rcp_t(mt);
   const Vec3<T> P = T(inv_m) * mc;  // COM in the base frame
   Sym3<T> Icom = IO;
   {
@@ -491,7 +491,7 @@ HB_HD void flow_from_centroidal(const DevModel& M, const Centroidal<T>& c, const
     fs = fs + F;
     ms = ms + cross(c.foot_rel[i] - c.com_rel, F);
   }
-  const double inv_m = 1.0 / M.total_mass;
+  const double inv_m = rcp_t(M.total_mass);
   f[0] = inv_m * fs.x; f[1] = inv_m * fs.y; f[2] = inv_m * fs.z - M.gravity;
   f[3] = inv_m * ms.x; f[4] = inv_m * ms.y; f[5] = inv_m * ms.z;
   f[6] = c.v_lin.x; f[7] = c.v_lin.y; f[8] = c.v_lin.z;

@@ -11,6 +11,7 @@
 
 #include "hb_host.hpp"
 #include "hb_riccati.hpp"
+#include "hb_lcm.hpp"
 #include "hb_wbc.hpp"
 #include "hb_hoqp.hpp"
 #include "hb_estimator.hpp"
@@ -548,6 +549,10 @@ struct hb_ctx {
   int n_chunks = 1;
   hipStream_t s_chunk[8]{};
   double* jc_out = nullptr;  // joint command outputs [6][B][10]
+  uint64_t* lcm_cmd = nullptr;    // [B][62] low_cmd_t wire images
+  uint64_t* lcm_state = nullptr;  // [B][42] low_state_t wire images
+  long long* lcm_ts = nullptr;    // [B]
+  int* lcm_bad = nullptr;
   PlantBatch plant{};
   bool plant_ready = false;
   // reference generation (allocated on the first hb_refgen_reset)
@@ -932,6 +937,21 @@ int32_t hb_estimator_reset(hb_ctx* ctx, const hb_estimator_config* cfg, const do
   return HB_OK;
 }
 
+// filter step on the inputs already in ctx->est (device), outputs as in hb_estimator_update
+static int32_t estimator_run(hb_ctx* ctx, double dt, int32_t to_resident, double* rbd, double* x_state) {
+  const size_t B = ctx->B;
+  EstBatch e = ctx->est;
+  hipStream_t s = ctx->s_wbc;
+  e.res_rbd = to_resident ? ctx->w.rbd : nullptr;
+  e.res_x0 = to_resident ? ctx->b.x0 : nullptr;
+  hipLaunchKernelGGL(k_estimator, dim3(ctx->B), dim3(64), 0, s, e, ctx->dmodel, ctx->est_cfg, dt);
+  HB_HIP(hipGetLastError());
+  if (rbd) HB_HIP(hipMemcpyAsync(rbd, e.rbd, B * HB_NRBD * 8, hipMemcpyDeviceToHost, s));
+  if (x_state) HB_HIP(hipMemcpyAsync(x_state, e.x, B * HB_NX * 8, hipMemcpyDeviceToHost, s));
+  HB_HIP(hipStreamSynchronize(s));
+  return HB_OK;
+}
+
 int32_t hb_estimator_update(hb_ctx* ctx, double dt, const double* quat, const double* ang_vel_local, const double* lin_acc_local,
                             const double* joint_pos, const double* joint_vel, const int32_t* contact_flag, int32_t to_resident,
                             double* rbd, double* x_state) {
@@ -950,14 +970,107 @@ int32_t hb_estimator_update(hb_ctx* ctx, double dt, const double* quat, const do
   HB_HIP(hipMemcpyAsync(const_cast<double*>(e.qj), joint_pos, B * 10 * 8, hipMemcpyHostToDevice, s));
   HB_HIP(hipMemcpyAsync(const_cast<double*>(e.qdj), joint_vel, B * 10 * 8, hipMemcpyHostToDevice, s));
   HB_HIP(hipMemcpyAsync(const_cast<int*>(e.contact), contact_flag, B * 4 * sizeof(int), hipMemcpyHostToDevice, s));
-  e.res_rbd = to_resident ? ctx->w.rbd : nullptr;
-  e.res_x0 = to_resident ? ctx->b.x0 : nullptr;
-  hipLaunchKernelGGL(k_estimator, dim3(ctx->B), dim3(64), 0, s, e, ctx->dmodel, ctx->est_cfg, dt);
+  return estimator_run(ctx, dt, to_resident, rbd, x_state);
+}
+
+// ---- LCM wire format (include/hunter_lcm.h) -----------------------------------------------------------------------
+uint64_t hb_lcm_fingerprint(int32_t type) { return (type < 0 || type > 2) ? 0 : lcm_fingerprint(type); }
+int32_t hb_lcm_field_count(int32_t type) { return (type < 0 || type > 2) ? HB_ERR_ARG : lcm_type(type).n_fields; }
+int32_t hb_lcm_encoded_size(int32_t type) { return (type < 0 || type > 2) ? HB_ERR_ARG : 16 + 8 * lcm_type(type).n_fields; }
+
+int32_t hb_lcm_encode(int32_t type, int32_t n, const int64_t* timestamp, const double* fields, uint8_t* out) {
+  if (type < 0 || type > 2 || n < 0 || !timestamp || !fields || !out) return HB_ERR_ARG;
+  const int nf = lcm_type(type).n_fields, sz = 16 + 8 * nf;
+  const uint64_t fp = lcm_fingerprint(type);
+  for (int i = 0; i < n; ++i) {
+    uint8_t* p = out + size_t(i) * sz;
+    lcm_put64(p, fp);
+    lcm_put64(p + 8, uint64_t(timestamp[i]));
+    for (int k = 0; k < nf; ++k) {
+      uint64_t bits;
+      std::memcpy(&bits, fields + size_t(i) * nf + k, 8);
+      lcm_put64(p + 16 + 8 * k, bits);
+    }
+  }
+  return HB_OK;
+}
+
+int32_t hb_lcm_decode(int32_t type, int32_t n, const uint8_t* in, int64_t* timestamp, double* fields) {
+  if (type < 0 || type > 2 || n < 0 || !in || !timestamp || !fields) return HB_ERR_ARG;
+  const int nf = lcm_type(type).n_fields, sz = 16 + 8 * nf;
+  const uint64_t fp = lcm_fingerprint(type);
+  for (int i = 0; i < n; ++i)
+    if (lcm_get64(in + size_t(i) * sz) != fp) return HB_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    const uint8_t* p = in + size_t(i) * sz;
+    timestamp[i] = int64_t(lcm_get64(p + 8));
+    for (int k = 0; k < nf; ++k) {
+      const uint64_t bits = lcm_get64(p + 16 + 8 * k);
+      std::memcpy(fields + size_t(i) * nf + k, &bits, 8);
+    }
+  }
+  return HB_OK;
+}
+
+int32_t hb_lcm_frame(const char* channel, uint32_t seq, const uint8_t* payload, int32_t payload_len, uint8_t* out, int32_t maxlen) {
+  if (!channel || !payload || !out || payload_len < 0) return HB_ERR_ARG;
+  const size_t cl = std::strlen(channel) + 1;
+  const size_t total = 8 + cl + size_t(payload_len);
+  if (cl > 64 || total > size_t(maxlen) || total > 65499) return HB_ERR_ARG;  // LCM_MAX_CHANNEL_NAME_LENGTH 63, short-message limit
+  const uint32_t magic = 0x4c433032u;
+  for (int b = 0; b < 4; ++b) { out[b] = uint8_t(magic >> (24 - 8 * b)); out[4 + b] = uint8_t(seq >> (24 - 8 * b)); }
+  std::memcpy(out + 8, channel, cl);
+  std::memcpy(out + 8 + cl, payload, size_t(payload_len));
+  return int32_t(total);
+}
+
+int32_t hb_joint_command_lcm(hb_ctx* ctx, const hb_joint_gains* gains, double dt, int64_t timestamp_ns, uint8_t* low_cmd) {
+  if (!ctx || !gains || !low_cmd) return HB_ERR_ARG;
+  int32_t rc = hb_joint_command(ctx, gains, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (rc != HB_OK) return rc;
+  const size_t B = ctx->B, words = B * 62;
+  if (!ctx->lcm_cmd) HB_HIP(dalloc(ctx, &ctx->lcm_cmd, words));
+  hipStream_t s = ctx->s_wbc;
+  hipLaunchKernelGGL(k_lcm_pack_cmd, dim3((unsigned(words) + 255) / 256), dim3(256), 0, s, ctx->B, ctx->jc_out,
+                     lcm_fingerprint(HB_LCM_LOW_CMD), timestamp_ns, ctx->lcm_cmd);
   HB_HIP(hipGetLastError());
-  if (rbd) HB_HIP(hipMemcpyAsync(rbd, e.rbd, B * HB_NRBD * 8, hipMemcpyDeviceToHost, s));
-  if (x_state) HB_HIP(hipMemcpyAsync(x_state, e.x, B * HB_NX * 8, hipMemcpyDeviceToHost, s));
+  HB_HIP(hipMemcpyAsync(low_cmd, ctx->lcm_cmd, words * 8, hipMemcpyDeviceToHost, s));
   HB_HIP(hipStreamSynchronize(s));
   return HB_OK;
+}
+
+int32_t hb_estimator_update_lcm(hb_ctx* ctx, double dt, const uint8_t* low_state, const int32_t* contact_flag, int32_t to_resident,
+                                double* rbd, double* x_state, int64_t* timestamp) {
+  if (!ctx || !low_state || !contact_flag || !(dt > 0.0)) return HB_ERR_ARG;
+  if (!ctx->est_ready) {
+    ctx->err = "hb_estimator_update_lcm: call hb_estimator_reset first";
+    return HB_ERR_STATE;
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  const size_t B = ctx->B, words = B * 42;
+  if (!ctx->lcm_state) {
+    HB_HIP(dalloc(ctx, &ctx->lcm_state, words));
+    HB_HIP(dalloc(ctx, &ctx->lcm_ts, B));
+    HB_HIP(dalloc(ctx, &ctx->lcm_bad, size_t(1)));
+  }
+  EstBatch e = ctx->est;
+  hipStream_t s = ctx->s_wbc;
+  HB_HIP(hipMemcpyAsync(ctx->lcm_state, low_state, words * 8, hipMemcpyHostToDevice, s));
+  HB_HIP(hipMemsetAsync(ctx->lcm_bad, 0, sizeof(int), s));
+  HB_HIP(hipMemcpyAsync(const_cast<int*>(e.contact), contact_flag, B * 4 * sizeof(int), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_lcm_unpack_state, dim3((unsigned(words) + 255) / 256), dim3(256), 0, s, ctx->B, ctx->lcm_state,
+                     lcm_fingerprint(HB_LCM_LOW_STATE), const_cast<double*>(e.quat), const_cast<double*>(e.w_local),
+                     const_cast<double*>(e.a_local), const_cast<double*>(e.qj), const_cast<double*>(e.qdj), ctx->lcm_ts, ctx->lcm_bad);
+  HB_HIP(hipGetLastError());
+  int bad = 0;
+  HB_HIP(hipMemcpyAsync(&bad, ctx->lcm_bad, sizeof(int), hipMemcpyDeviceToHost, s));
+  HB_HIP(hipStreamSynchronize(s));
+  if (bad) {
+    ctx->err = "hb_estimator_update_lcm: a message does not carry the low_state_t fingerprint";
+    return HB_ERR_ARG;
+  }
+  if (timestamp) HB_HIP(hipMemcpy(timestamp, ctx->lcm_ts, B * 8, hipMemcpyDeviceToHost));
+  return estimator_run(ctx, dt, to_resident, rbd, x_state);
 }
 
 int32_t hb_estimator_get_filter(hb_ctx* ctx, double* x_hat, double* P) {

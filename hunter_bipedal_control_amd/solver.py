@@ -28,6 +28,9 @@ ABI_SYMBOLS = [
     "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd", "hb_plant_reset", "hb_plant_step",
     "hb_plant_get_state",
 ]
+# include/hunter_lcm.h
+LCM_SYMBOLS = ["hb_lcm_fingerprint", "hb_lcm_encoded_size", "hb_lcm_field_count", "hb_lcm_encode", "hb_lcm_decode", "hb_lcm_frame",
+               "hb_joint_command_lcm", "hb_estimator_update_lcm"]
 
 
 class HunterHipError(RuntimeError):
@@ -276,6 +279,21 @@ class HunterSolver:
             _p(_f64(lin_acc_local, (self.B, 3))), _p(_f64(joint_pos, (self.B, 10))), _p(_f64(joint_vel, (self.B, 10))),
             _p(_i32(contact_flag, (self.B, 4))), C.c_int32(1 if to_resident else 0), _p(rbd), _p(x)), "hb_estimator_update")
         return rbd, x
+
+    def estimator_update_lcm(self, dt, low_state, contact_flag, to_resident=False):
+        """hb_estimator_update_lcm: low_state[B][336] wire images of low_state_t -> rbd, x_state, timestamps."""
+        rbd, x, ts = np.zeros((self.B, 32)), np.zeros((self.B, 22)), np.zeros(self.B, dtype=np.int64)
+        wire = np.ascontiguousarray(low_state, dtype=np.uint8)
+        assert wire.shape == (self.B, 336)
+        self._check(self.lib.hb_estimator_update_lcm(self.ctx, C.c_double(dt), _p(wire), _p(_i32(contact_flag, (self.B, 4))),
+                                                     C.c_int32(1 if to_resident else 0), _p(rbd), _p(x), _p(ts)), "hb_estimator_update_lcm")
+        return rbd, x, ts
+
+    def joint_command_lcm(self, gains: "abi.HbJointGains", dt, timestamp_ns: int):
+        """hb_joint_command_lcm: the joint command of the last WBC result as low_cmd_t wire images [B][496]."""
+        wire = np.zeros((self.B, 496), dtype=np.uint8)
+        self._check(self.lib.hb_joint_command_lcm(self.ctx, C.byref(gains), C.c_double(dt), C.c_int64(timestamp_ns), _p(wire)), "hb_joint_command_lcm")
+        return wire
 
     def estimator_filter(self):
         xh, P = np.zeros((self.B, 18)), np.zeros((self.B, 18, 18))

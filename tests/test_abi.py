@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library loads and exports every symbol include/hunter_hip.h declares (no compute without a GPU)."""
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares (no compute without a GPU)."""
 import ctypes as C
 import re
 from pathlib import Path
@@ -20,6 +20,11 @@ def test_header_and_library_symbols_agree():
         assert hasattr(lib, name), f"libhunter_hip.so does not export {name}"
     lib.hb_version.restype = C.c_int32
     assert lib.hb_version() >= 100
+    lcm_header = (ROOT / "include" / "hunter_lcm.h").read_text()
+    lcm_declared = sorted(set(re.findall(r"\b(hb_[a-z_0-9]+)\s*\(", lcm_header.split("extern \"C\"", 1)[1])))
+    assert lcm_declared == sorted(solver.LCM_SYMBOLS)
+    for name in lcm_declared:
+        assert hasattr(lib, name), f"libhunter_hip.so does not export {name}"
 
 
 def test_struct_sizes_match_the_header():

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
 }
 
 // line search: value of trial point (x + alpha dx, u + alpha du), one thread per node
-__global__ __launch_bounds__(64, 2) void k_ls_eval(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C,
+__global__ __launch_bounds__(64) void k_ls_eval(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C,
                                                 double alpha) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int inst = gid / b.Nmax, k = gid % b.Nmax;
@@ -249,21 +249,23 @@ __global__ __launch_bounds__(64, 2) void k_ls_eval(Batch b, const DevModel* __re
   if (b.accepted[inst] || k >= b.n_nodes[inst]) return;
   const size_t nd = size_t(inst) * b.Nmax + k;
   const size_t xo = (size_t(inst) * (b.Nmax + 1) + k) * HB_NX;
-  // trial point in LDS (stride 67: conflict-free): thread-private arrays would be indexed by the rolled joint loops of
-  // the model and live in scratch
-  __shared__ double tp[64 * 67];
-  double* x = tp + threadIdx.x * 67;
-  double* xn = x + HB_NX;
-  double* u = xn + HB_NX;
+  // trial point in LDS (stride 45: conflict-free per half-wave): thread-private arrays would be indexed by the rolled
+  // joint loops of the model and live in scratch.  The next node's trial state is only read once per entry (defect) and
+  // is formed from global memory there: 34 -> 23 KB per block, 4 -> 6 blocks per CU for this latency-bound kernel.
+  __shared__ double tp[64 * 45];
+  double* x = tp + threadIdx.x * 45;
+  double* u = x + HB_NX;
 #pragma unroll
   for (int i = 0; i < HB_NX; ++i) {
     x[i] = b.x[xo + i] + alpha * b.dx[xo + i];
-    xn[i] = b.x[xo + HB_NX + i] + alpha * b.dx[xo + HB_NX + i];
     u[i] = b.u[nd * HB_NU + i] + alpha * b.du[nd * HB_NU + i];
   }
   const double* tt = b.t + size_t(inst) * (b.Nmax + 1);
+  const double* xn0 = b.x + xo + HB_NX;
+  const double* dxn = b.dx + xo + HB_NX;
   double o3[3];
-  node_value(*M, *C, x, u, xn, b.xref + nd * HB_NX, b.swing + nd * 24, tt[k + 1] - tt[k], b.mode[nd], o3);
+  node_value(*M, *C, x, u, [xn0, dxn, alpha](int i) { return xn0[i] + alpha * dxn[i]; }, b.xref + nd * HB_NX, b.swing + nd * 24,
+             tt[k + 1] - tt[k], b.mode[nd], o3);
   b.partial[nd * 3 + 0] = o3[0];
   b.partial[nd * 3 + 1] = o3[1];
   b.partial[nd * 3 + 2] = o3[2];

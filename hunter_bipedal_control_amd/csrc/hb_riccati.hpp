@@ -300,13 +300,16 @@ HB_HD void riccati_fwd_finish(const Ctx& cx, double* lds) {
 
 // Value-only evaluation of one node for the line search (one thread per node):
 // returns dt * (stage cost), dt * |defect|^2, dt * |equality constraints|^2  (OCS2 PerformanceIndex).
-HB_HD void node_value(const DevModel& M, const DevConfig& C, const double* x, const double* u, const double* xnext,
+// `xnext(i)` delivers entry i of the next node's state (only the defect reads it, once per entry: the kernel forms the
+// trial value from global memory on the fly instead of staging it next to x and u).
+template <class XN>
+HB_HD void node_value(const DevModel& M, const DevConfig& C, const double* x, const double* u, XN xnext,
                       const double* xref, const double* swing, double dt, int mode, double* out3) {
   bool cf[HB_NC];
   mode_flags(mode, cf);
   double f1[12], f2[12];
   Centroidal<double> c1;
-  const double inv_m = 1.0 / M.total_mass;
+  const double inv_m = rcp_t(M.total_mass);
   {
     centroidal_eval<double>(M, x + 9, x + 12, x, u + 12, c1);
     Vec3<double> fs, ms;
@@ -345,12 +348,12 @@ HB_HD void node_value(const DevModel& M, const DevConfig& C, const double* x, co
   double dyn = 0;
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
-    const double d = x[i] + 0.5 * dt * (f1[i] + f2[i]) - xnext[i];
+    const double d = x[i] + 0.5 * dt * (f1[i] + f2[i]) - xnext(i);
     dyn += d * d;
   }
 #pragma unroll
   for (int j = 0; j < HB_NJ; ++j) {
-    const double d = x[12 + j] + dt * u[12 + j] - xnext[12 + j];
+    const double d = x[12 + j] + dt * u[12 + j] - xnext(12 + j);
     dyn += d * d;
   }
   double cost = 0, eq = 0;

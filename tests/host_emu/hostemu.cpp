@@ -86,7 +86,7 @@ double emu_sqp_iteration(const hb_model* m, const hb_config* c, int N, const dou
     double merit = 0, dyn = 0, eq = 0;
     for (int k = 0; k < N; ++k) {
       double o3[3];
-      node_value(d, dc, xt.data() + k * 22, ut.data() + k * 22, xt.data() + (k + 1) * 22, xref + k * 22, swing + k * 24,
+      node_value(d, dc, xt.data() + k * 22, ut.data() + k * 22, [&xt, k](int i) { return xt[(k + 1) * 22 + i]; }, xref + k * 22, swing + k * 24,
                  t[k + 1] - t[k], mode[k], o3);
       merit += o3[0]; dyn += o3[1]; eq += o3[2];
     }

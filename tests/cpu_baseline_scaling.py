@@ -1,3 +1,4 @@
+"""CPU-baseline scaling probe (oracle port, threads 1..32): test-side measurement helper, run on the GPU box by hand."""
 import sys, time, os; sys.path.insert(0,'.')
 import numpy as np
 from hunter_bipedal_control_amd import ingest

@@ -404,6 +404,45 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* Lc = Kx;          // 10 x 10
   double* col = Kx + 100;   // 10 (+2)
   double* Linv = Kx + 112;  // 10 (+2)
+  int rank_l = 0, donemask = 0;
+  int ei0 = 0, ej0 = cx.lane;  // lower-triangle element of this lane: e -> (i, j), i >= j
+  while (ej0 > ei0) { ej0 -= ei0 + 1; ++ei0; }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Device: the triangle lives in registers (55 of the 64 lanes own one element each), so the rank-1 update touches no
+  // LDS; the pivot is a wave maximum over the lanes that own a live diagonal element (DPP, no LDS either) and the owner
+  // is found with a ballot (lowest lane = lowest index on ties, like the serial search of the host version below).
+  {
+    static_assert(Ctx::nlanes == 64, "one triangle element per lane");
+    const bool own = cx.lane < 55;
+    const bool diag = own && ei0 == ej0;
+    double g = own ? GtG[ei0 * 10 + ej0] : 0.0;
+    const double tol = 1e-10 * fmax(wave_max_f64(diag ? g : 0.0), 0.0);
+    for (int i = cx.lane; i < 124; i += cx.nlanes) Kx[i] = 0.0;
+    cx.sync();
+    for (int st = 0; st < 10; ++st) {
+      const double v = (diag && !((donemask >> ei0) & 1)) ? g : -1.0;
+      const double best = wave_max_f64(v);
+      if (!(best > tol)) break;
+      const unsigned long long hit = __ballot(v == best);
+      const int ps = __builtin_amdgcn_readlane(ei0, __ffsll(hit) - 1);
+      const double rinv = rsqrt_t(best), lss = best * rinv;
+      if (own && (ei0 == ps || ej0 == ps)) {  // column ps of the remaining matrix: elements (k, ps), k >= ps, and (ps, k), k < ps
+        const int k = (ei0 == ps) ? ej0 : ei0;
+        if (!((donemask >> k) & 1)) {
+          const double l = (k == ps) ? lss : g * rinv;
+          col[k] = l;
+          Lc[st * 10 + k] = l;
+        }
+      }
+      if (cx.lane == 0) { perm[st] = ps; Linv[st] = rinv; }
+      cx.sync();
+      donemask |= 1 << ps;
+      if (own && !((donemask >> ei0) & 1) && !((donemask >> ej0) & 1)) g -= col[ei0] * col[ej0];
+      cx.sync();
+      rank_l = st + 1;
+    }
+  }
+#else
   double tol;
   {
     double dmax0 = 0;
@@ -412,9 +451,6 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   for (int i = cx.lane; i < 124; i += cx.nlanes) Kx[i] = 0.0;
   cx.sync();
-  int rank_l = 0, donemask = 0;
-  int ei0 = 0, ej0 = cx.lane;  // lower-triangle element of this lane: e -> (i, j), i >= j
-  while (ej0 > ei0) { ej0 -= ei0 + 1; ++ei0; }
   for (int st = 0; st < 10; ++st) {
     int ps = -1;
     double best = -1.0;
@@ -442,6 +478,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     cx.sync();
     rank_l = st + 1;
   }
+#endif
   if (cx.lane == 0) {  // free indices in increasing order behind the pivots
     int w = rank_l;
     for (int i = 0; i < 10; ++i)

@@ -87,6 +87,27 @@ HB_HD void sincos_t(Dual1 a, Dual1& s, Dual1& c) {
   s = {sv, cv * a.d};
   c = {cv, -sv * a.d};
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// Maximum over the 64 lanes of a wavefront, returned uniformly: DPP row shifts inside the rows of 16, row broadcasts
+// across them (gfx9 row_bcast:15 / :31), lane 63 read back — 18 VALU instructions, no LDS traffic.
+__device__ __forceinline__ double wave_max_f64(double v) {
+#define HB_DPP_MAX(ctrl, rmask)                                                              \
+  {                                                                                          \
+    const int lo_ = __double2loint(v), hi_ = __double2hiint(v);                              \
+    const int lo2_ = __builtin_amdgcn_update_dpp(lo_, lo_, ctrl, rmask, 0xf, false);         \
+    const int hi2_ = __builtin_amdgcn_update_dpp(hi_, hi_, ctrl, rmask, 0xf, false);         \
+    v = fmax(v, __hiloint2double(hi2_, lo2_));                                               \
+  }
+  HB_DPP_MAX(0x111, 0xf)  // row_shr:1
+  HB_DPP_MAX(0x112, 0xf)  // row_shr:2
+  HB_DPP_MAX(0x114, 0xf)  // row_shr:4
+  HB_DPP_MAX(0x118, 0xf)  // row_shr:8   -> lane 15 of every row holds the row maximum
+  HB_DPP_MAX(0x142, 0xa)  // row_bcast:15 into rows 1, 3
+  HB_DPP_MAX(0x143, 0xc)  // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave maximum
+#undef HB_DPP_MAX
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+#endif
 HB_HD double rsqrt_t(double a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return rsqrt(a);

@@ -11,6 +11,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import abi, refgen
+from . import solver as _solver
 from .plant import Plant
 
 
@@ -35,7 +36,13 @@ class DeviceLoop:
     """One HunterSolver driven in closed loop.  `gait` per instance (names of gait.info), `cmd_vel` [B][4]."""
 
     def __init__(self, solver, params: dict, gaits, cmd_vel, n_intervals: int = 100, mpc_every: int = 8, dt: float = 0.002,
-                 t_gait_start: float = 0.3, joint_ik: bool = True, use_estimator: bool = False):
+                 t_gait_start: float = 0.3, joint_ik: bool = True, use_estimator: bool = False, use_lcm: bool = False):
+        """use_lcm (with use_estimator): sensors and commands cross the controller boundary as LCM wire images — the
+        plant side encodes low_state_t / applies the PD + feed-forward law of a decoded low_cmd_t like the MuJoCo bridge
+        (mujoco/src/main.cc), the controller side uses hb_estimator_update_lcm / hb_joint_command_lcm."""
+        assert not (use_lcm and not use_estimator)
+        self.use_lcm = use_lcm
+        self.tau_applied = np.zeros((solver.B, 10))
         self.s, self.params = solver, params
         self.B = solver.B
         c = params["config"]
@@ -74,7 +81,13 @@ class DeviceLoop:
         s, B = self.s, self.B
         if self.use_estimator:
             quat, w_loc, a_loc = self.plant.imu()
-            rbd, x_obs = s.estimator_update(self.dt, quat, w_loc, a_loc, self.plant.q[:, 6:], self.plant.v[:, 6:], self.contact)
+            if self.use_lcm:   # LcmInterface.cpp:54-70: quaternion (w x y z), gyroscope, accelerometer, joint pos / vel / torque
+                fields = np.concatenate([quat[:, 3:4], quat[:, 0:3], w_loc, a_loc, self.plant.q[:, 6:], self.plant.v[:, 6:],
+                                         self.tau_applied], axis=1)
+                wire = _solver.lcm_encode(_solver.LCM_LOW_STATE, int(round(self.t * 1e9)), fields)
+                rbd, x_obs, _ = s.estimator_update_lcm(self.dt, wire, self.contact)
+            else:
+                rbd, x_obs = s.estimator_update(self.dt, quat, w_loc, a_loc, self.plant.q[:, 6:], self.plant.v[:, 6:], self.contact)
         else:
             rbd = self.plant.rbd()
             x_obs = s.centroidal_state_from_rbd(rbd)
@@ -89,7 +102,14 @@ class DeviceLoop:
             s.mpc_solve(x_obs)
             s.publish()
         out = s.wbc_update(np.full(B, self.t), rbd, dt=self.dt)   # control thread: policy, WBC, joint command
-        cmd = s.joint_command(self.gains, self.dt)
+        if self.use_lcm:
+            wire = s.joint_command_lcm(self.gains, self.dt, int(round(self.t * 1e9)))
+            _, f = _solver.lcm_decode(_solver.LCM_LOW_CMD, wire)      # plant side: PD + feed-forward on the decoded command
+            cmd = dict(pos_des=f[:, 0:10], vel_des=f[:, 10:20], tau_ff=f[:, 30:40], kp=f[:, 40:50], kd=f[:, 50:60])
+            cmd["torque"] = cmd["tau_ff"] + cmd["kp"] * (cmd["pos_des"] - self.plant.q[:, 6:]) + cmd["kd"] * (cmd["vel_des"] - self.plant.v[:, 6:])
+            self.tau_applied = cmd["torque"]
+        else:
+            cmd = s.joint_command(self.gains, self.dt)
         contact = np.array([refgen.mode_to_contact_flags(int(m)) for m in out["mode"]])
         self.plant.step(cmd["torque"], contact, self.dt)
         self.contact = contact.astype(np.int32)

@@ -33,6 +33,34 @@ LCM_SYMBOLS = ["hb_lcm_fingerprint", "hb_lcm_encoded_size", "hb_lcm_field_count"
                "hb_joint_command_lcm", "hb_estimator_update_lcm"]
 
 
+LCM_LOW_CMD, LCM_LOW_STATE, LCM_FULL_STATE = 0, 1, 2
+
+
+def lcm_encode(msg_type: int, timestamp, fields) -> np.ndarray:
+    """Host codec of include/hunter_lcm.h: fields[n][60|40|56] -> wire images [n][496|336|464] (uint8)."""
+    lib = load_library()
+    nf, sz = lib.hb_lcm_field_count(msg_type), lib.hb_lcm_encoded_size(msg_type)
+    f = np.ascontiguousarray(fields, dtype=np.float64).reshape(-1, nf)
+    ts = np.ascontiguousarray(np.broadcast_to(np.asarray(timestamp, dtype=np.int64), (f.shape[0],)))
+    out = np.zeros((f.shape[0], sz), dtype=np.uint8)
+    rc = lib.hb_lcm_encode(C.c_int32(msg_type), C.c_int32(f.shape[0]), _p(ts), _p(f), _p(out))
+    if rc != 0:
+        raise ValueError(f"hb_lcm_encode failed ({rc})")
+    return out
+
+
+def lcm_decode(msg_type: int, wire):
+    """-> (timestamp[n], fields[n][60|40|56]); raises if a message carries a foreign fingerprint."""
+    lib = load_library()
+    nf, sz = lib.hb_lcm_field_count(msg_type), lib.hb_lcm_encoded_size(msg_type)
+    w = np.ascontiguousarray(wire, dtype=np.uint8).reshape(-1, sz)
+    ts, f = np.zeros(w.shape[0], dtype=np.int64), np.zeros((w.shape[0], nf))
+    rc = lib.hb_lcm_decode(C.c_int32(msg_type), C.c_int32(w.shape[0]), _p(w), _p(ts), _p(f))
+    if rc != 0:
+        raise ValueError(f"hb_lcm_decode failed ({rc}): fingerprint mismatch")
+    return ts, f
+
+
 class HunterHipError(RuntimeError):
     pass
 

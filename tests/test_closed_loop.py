@@ -79,6 +79,34 @@ def test_device_closed_loop_with_the_state_estimator_in_the_loop(params):
 
 
 @pytest.mark.gpu
+def test_closed_loop_over_the_lcm_wire_format_equals_the_array_loop(params):
+    """The same estimator-in-the-loop rollout with sensors and commands crossing the controller boundary as LCM wire
+    images (low_state_t in through hb_estimator_update_lcm, low_cmd_t out through hb_joint_command_lcm, the plant side
+    applying the PD + feed-forward law of the decoded command like the reference's MuJoCo bridge).  The codec is exact, so
+    the two loops may only differ by the rounding of the torque law evaluated on the host instead of the device."""
+    from hunter_bipedal_control_amd.rollout import DeviceLoop
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B = 2
+    cmds = np.array([[0.2, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.1]])
+    traj = {}
+    for use_lcm in (False, True):
+        s = HunterSolver(params, batch=B, max_nodes=108)
+        try:
+            dev = DeviceLoop(s, params, ["trot", "stance"], cmds, use_estimator=True, use_lcm=use_lcm)
+            qs = []
+            for k in range(200):                               # 0.4 s: stance, then the first swing phase
+                q, v = dev.step()
+                qs.append(np.concatenate([q, v], axis=1).copy())
+            assert dev.last["out"]["status"].max() == 0
+            traj[use_lcm] = np.array(qs)
+        finally:
+            s.close()
+    assert np.isfinite(traj[True]).all()
+    assert np.abs(traj[True][:100] - traj[False][:100]).max() < 1e-9
+    assert np.abs(traj[True] - traj[False]).max() < 1e-6
+
+
+@pytest.mark.gpu
 def test_device_plant_matches_numpy_plant_and_resident_loop_trots(params):
     """hb_plant_step vs plant.py on the same torque sequence; then the fully device-resident loop (plant included) against
     the loop with the host-side plant."""

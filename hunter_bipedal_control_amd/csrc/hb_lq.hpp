@@ -488,26 +488,12 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   if (C.debug_stop == 2) return;
   const int rank = rank_l;
   const int nz = 10 - rank;
-  // kernel basis: column b <-> free index perm[rank + b]:  z = e_free - P1 L11^-T L21[b]^T
-  for (int b = cx.lane; b < 6; b += cx.nlanes) {
-    if (b < nz) {
-      double y[10];
-      const int pf = perm[rank + b];
-      for (int a = rank - 1; a >= 0; --a) {
-        double s = Lc[a * 10 + pf];  // L21(b, a)
-        for (int t = a + 1; t < rank; ++t) s -= Lc[a * 10 + perm[t]] * y[t];
-        y[a] = s * Linv[a];
-      }
-      for (int k = 0; k < 10; ++k) Z[k * 6 + b] = 0.0;
-      for (int a = 0; a < rank; ++a) Z[perm[a] * 6 + b] = -y[a];
-      Z[pf * 6 + b] = 1.0;
-    } else {
-      for (int k = 0; k < 10; ++k) Z[k * 6 + b] = 0.0;
-    }
-  }
-  // Solve A11 Y = -W1 (23 right-hand sides, one per lane), scatter into Kx rows perm[a].  The factor is first gathered
-  // into registers so that the substitutions are pure FMA chains; rows beyond the rank have Linv = 0, which zeroes
-  // their unknowns without masks.
+  // Solve A11 Y = -W1 (23 right-hand sides) and, in the same instruction stream, the kernel basis
+  //   column b <-> free index pf = perm[rank + b]:  z = e_pf - P1 L11^-T L21[b]^T
+  // whose back substitution is the one of the right-hand sides with y = L21[b] in place of the forward result: lane
+  // 28 - c handles column c, c < 23 a right-hand side (scattered into Kx rows perm[a]), c = 23 + b a kernel column.  The
+  // factor is first gathered into registers so that the substitutions are pure FMA chains; rows beyond the rank have
+  // Linv = 0, which zeroes their unknowns without masks.
   {
     double Lr[45], dinv[10];
     int pm[10];
@@ -518,15 +504,24 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
 #pragma unroll
       for (int t = 0; t < a; ++t) Lr[a * (a - 1) / 2 + t] = Lc[t * 10 + pm[a]];
     }
-    cx.sync();  // every lane holds the factor: Kx may now be overwritten
-    for (int c = cx.lane; c < 23; c += cx.nlanes) {
+    cx.sync();
+    for (int cc = cx.lane; cc < 29; cc += cx.nlanes) {
+      const int c = 28 - cc;  // kernel columns first: a serial host reads L21 out of Lc before Kx (same storage) is written
+      const bool isz = c >= 23;
+      const int bz = c - 23;
+      const bool zlive = isz && bz < nz;
+      const int pf = zlive ? perm[rank + bz] : 0;
       double y[10];
 #pragma unroll
       for (int a = 0; a < 10; ++a) {
-        double sacc = -W[pm[a] * 23 + c];
+        double sacc = -W[pm[a] * 23 + (isz ? 0 : c)];
 #pragma unroll
         for (int t = 0; t < a; ++t) sacc -= Lr[a * (a - 1) / 2 + t] * y[t];
         y[a] = sacc * dinv[a];
+      }
+      if (isz) {  // L21(b, a), a < rank (rows of Lc beyond the rank are zero)
+#pragma unroll
+        for (int a = 0; a < 10; ++a) y[a] = zlive ? Lc[a * 10 + pf] : 0.0;
       }
 #pragma unroll
       for (int a = 9; a >= 0; --a) {
@@ -535,8 +530,13 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         for (int t = a + 1; t < 10; ++t) sacc -= Lr[t * (t - 1) / 2 + a] * y[t];
         y[a] = sacc * dinv[a];
       }
+      if (!isz) {
 #pragma unroll
-      for (int a = 0; a < 10; ++a) Kx[pm[a] * 23 + c] = y[a];
+        for (int a = 0; a < 10; ++a) Kx[pm[a] * 23 + c] = y[a];
+      } else {
+#pragma unroll
+        for (int a = 0; a < 10; ++a) Z[pm[a] * 6 + bz] = zlive ? (a < rank ? -y[a] : (pm[a] == pf ? 1.0 : 0.0)) : 0.0;
+      }
     }
   }
 
@@ -670,18 +670,28 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         }
         for (int e = 0; e < 9; ++e) RFF[9 * foot + e] = blk[e];
       }
+#if defined(__HIP_DEVICE_COMPILE__)
+      // 64 roles = 64 lanes: the three partial sums are wave reductions (DPP), no LDS staging and no serial 64-term loop
+      pc = wave_sum_f64(pc);
+      pd = wave_sum_f64(pd);
+      pe = wave_sum_f64(pe);
+      if (role == 0) { scal[0] = pc; scal[1] = pd; scal[2] = pe; }
+#else
       red[role] = pc;
       red[64 + role] = pd;
       red[128 + role] = pe;
+#endif
     }
   }
   cx.sync();
+#if !defined(__HIP_DEVICE_COMPILE__)
   for (int w = cx.lane; w < 3; w += cx.nlanes) {
     double sacc = 0;
     for (int l = 0; l < 64; ++l) sacc += red[64 * w + l];
     scal[w] = sacc;
   }
   cx.sync();
+#endif
   if (C.debug_stop == 4) return;
   // soft rows: gradients and the dense pieces P_j, R_jj
   for (int c = cx.lane; c < 22; c += cx.nlanes) {

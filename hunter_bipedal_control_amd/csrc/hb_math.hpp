@@ -107,6 +107,23 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 #undef HB_DPP_MAX
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+// Sum over the 64 lanes of a wavefront, returned uniformly (same DPP ladder; lanes without a source add zero).
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#define HB_DPP_ADD(ctrl, rmask)                                                              \
+  {                                                                                          \
+    const int lo2_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, false); \
+    const int hi2_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, false); \
+    v += __hiloint2double(hi2_, lo2_);                                                       \
+  }
+  HB_DPP_ADD(0x111, 0xf)
+  HB_DPP_ADD(0x112, 0xf)
+  HB_DPP_ADD(0x114, 0xf)
+  HB_DPP_ADD(0x118, 0xf)
+  HB_DPP_ADD(0x142, 0xa)
+  HB_DPP_ADD(0x143, 0xc)
+#undef HB_DPP_ADD
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 #endif
 HB_HD double rsqrt_t(double a) {
 #if defined(__HIP_DEVICE_COMPILE__)

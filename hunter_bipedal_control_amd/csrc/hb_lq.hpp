@@ -106,8 +106,8 @@ struct LqLds {
   static constexpr int LJ = ABt;             // 4 x LEGJ_SIZE (824)
   static constexpr int J1 = LJ + 4 * LEGJ_SIZE;  // [44][12]
   static constexpr int J2 = J1 + 528;        // [44][12]
-  static constexpr int p1 = J2 + 528;        // xs us xe fv FR LV = 222 doubles
-  static constexpr int total = (p1 + 222 > ints + 16) ? p1 + 222 : ints + 16;
+  static constexpr int p1 = J2 + 528;        // xs us xe fv FR LV = 222 doubles, (sin, cos) of zyx at both RK2 points = 12
+  static constexpr int total = (p1 + 234 > ints + 16) ? p1 + 234 : ints + 16;
 };
 static_assert(LqLds::GtG >= LqLds::ABt + 528 && LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are still being read");
 static_assert(LqLds::total * 8 <= 20480, "k_lq: LDS per node must allow 8 workgroups per CU");
@@ -163,6 +163,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* fv = xe + 22;                // 2 x 12 flow-map values (rows 0..11) of the two points
   double* FR = fv + 24;                // 2 x 12: (contact point - COM) at the two points
   double* LV_all = FR + 24;            // 2 points x 2 legs x 27 leg values
+  double* SC = LV_all + 108;           // 2 x 6: sin / cos of the ZYX angles at the two RK2 points
   double* J1 = lds + LqLds::J1;        // 44 x 12: d f(rows 0..11) / d direction at point 1
   double* J2 = lds + LqLds::J2;        // same at point 2
   for (int i = cx.lane; i < 22; i += cx.nlanes) {
@@ -181,7 +182,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* LJ_all = lds + LqLds::LJ;  // 4 x LEGJ_SIZE; its head is overwritten by ABt in the final compose
   leg_value_pass_coop(cx, M, 4, [](int g) { return g & 1; },
                       [xs, us, dt](int g, int j) { return xs[12 + j] + ((g >> 1) ? dt : 0.0) * us[12 + j]; },
-                      [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all);
+                      [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all, 3, [xs](int i) { return xs[9 + i]; }, SC);
   if (C.debug_stop == 6) return;
   // ---- value of the flow map at the first RK2 point (one lane, plain doubles): the second point x + dt f(x, u) must be
   // known before its directional pass can start, and a value-only evaluation costs well under half a dual pass.
@@ -192,7 +193,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     Sym3<double> IOs;
     IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
     centroidal_core<double>(M, Vec3<double>(S(0), S(1), S(2)), IOs, Vec3<double>(S(9), S(10), S(11)),
-                            Vec3<double>(S(12), S(13), S(14)), xs + 9, xs, core);
+                            Vec3<double>(S(12), S(13), S(14)), xs + 9, xs, core, SC);
     Vec3<double> msum;
     double fsx = 0, fsy = 0, fsz = 0;
 #pragma unroll 1
@@ -212,6 +213,9 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     // second evaluation point of Heun's method: x + dt f(x,u), same input
     for (int i = 0; i < 22; ++i) xe[i] = xs[i] + dt * (i < 12 ? fv[i] : us[i]);
   }
+  cx.sync();
+  // sine / cosine of the ZYX angles at the second point, one angle per lane: the 58 lanes of stage 2 then only add tangents
+  for (int i = cx.lane; i < 3; i += cx.nlanes) sincos_t(xe[9 + i], SC[6 + 2 * i], SC[6 + 2 * i + 1]);
   cx.sync();
   if (C.debug_stop == 7) return;
   // ---- stage 2: whole-body combine per (point, direction).  Only 29 of the 44 directions are nonlinear (momentum 0..5,
@@ -247,7 +251,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         Sym3<Dual1> IOs;
         IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
         centroidal_core<Dual1>(M, Vec3<Dual1>(S(0), S(1), S(2)), IOs, Vec3<Dual1>(S(9), S(10), S(11)),
-                               Vec3<Dual1>(S(12), S(13), S(14)), zyx, hn, core);
+                               Vec3<Dual1>(S(12), S(13), S(14)), zyx, hn, core, SC + 6 * pt);
       }
       // contact points one at a time (rolled loop keeps the register footprint small)
       Vec3<Dual1> ms;

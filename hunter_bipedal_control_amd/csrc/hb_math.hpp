@@ -87,6 +87,12 @@ HB_HD void sincos_t(Dual1 a, Dual1& s, Dual1& c) {
   s = {sv, cv * a.d};
   c = {cv, -sv * a.d};
 }
+// sine / cosine of an angle whose VALUE pair (sv, cv) is already known: the dual version only adds the tangents
+HB_HD void sincos_known(double sv, double cv, double, double& s, double& c) { s = sv; c = cv; }
+HB_HD void sincos_known(double sv, double cv, Dual1 a, Dual1& s, Dual1& c) {
+  s = {sv, cv * a.d};
+  c = {cv, -sv * a.d};
+}
 #if defined(__HIP_DEVICE_COMPILE__)
 // Maximum over the 64 lanes of a wavefront, returned uniformly: DPP row shifts inside the rows of 16, row broadcasts
 // across them (gfx9 row_bcast:15 / :31), lane 63 read back — 18 VALU instructions, no LDS traffic.
@@ -237,9 +243,13 @@ template <class T> HB_HD Vec3<T> sym3_solve(const Sym3<T>& s, Vec3<T> b) {
           inv * (c02 * b.x + c12 * b.y + c22 * b.z)};
 }
 // rotation about a constant unit axis (Rodrigues)
+template <class T> HB_HD Mat3<T> axis_rot_sc(const double* ax, T s, T c);
 template <class T> HB_HD Mat3<T> axis_rot(const double* ax, T th) {
   T s, c;
   sincos_t(th, s, c);
+  return axis_rot_sc<T>(ax, s, c);
+}
+template <class T> HB_HD Mat3<T> axis_rot_sc(const double* ax, T s, T c) {
   const T oc = T(1.0) - c;
   Mat3<T> r;
 #pragma unroll

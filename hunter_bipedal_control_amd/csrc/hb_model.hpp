@@ -235,15 +235,27 @@ HB_HD void leg_value_pass(const DevModel& M, int leg, QF qj, QDF qdj, double* bl
 // joint-rate twists and the suffix sums of masses / moments / momenta run one (group, joint) pair per lane.
 // QF/QDF: (group, joint index 0..9) -> joint angle / rate; LEG: group -> leg (0 left, 1 right).
 // Temporaries inside a joint block: E_k (local joint rotation) in slots 21..29, R_k^- (frame before the joint) in 6..14.
-template <class Ctx, class LEG, class QF, class QDF>
-HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LEG leg_of, QF qj, QDF qdj, double* blk_all, double* val_all) {
+// `extra(i)`, i < n_extra: further angles whose (sin, cos) pairs are wanted (written to extra_sc[2 i], [2 i + 1]); they
+// ride along in the sine / cosine evaluation of stage A on otherwise idle lanes.
+struct NoExtraAngles { HB_HD double operator()(int) const { return 0.0; } };
+template <class Ctx, class LEG, class QF, class QDF, class XA = NoExtraAngles>
+HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LEG leg_of, QF qj, QDF qdj, double* blk_all, double* val_all,
+                               int n_extra = 0, XA extra = XA(), double* extra_sc = nullptr) {
   const int ntask = 5 * ngroups;
   // A: local joint rotations
-  for (int r = cx.lane; r < ntask; r += cx.nlanes) {
-    const int g = r / 5, k = r - 5 * g, j = 5 * leg_of(g) + k;
-    const Mat3<double> E = axis_rot<double>(M.axis[j], qj(g, j));
-    double* B = blk_all + g * LEGJ_SIZE + k * LEGJ_STRIDE;
-    for (int e = 0; e < 9; ++e) B[21 + e] = E.m[e];
+  for (int r = cx.lane; r < ntask + n_extra; r += cx.nlanes) {
+    const bool ex = r >= ntask;
+    const int g = ex ? 0 : r / 5, k = ex ? 0 : r - 5 * g, j = 5 * leg_of(g) + k;
+    double sv, cv;
+    sincos_t(ex ? extra(r - ntask) : qj(g, j), sv, cv);
+    if (ex) {
+      extra_sc[2 * (r - ntask)] = sv;
+      extra_sc[2 * (r - ntask) + 1] = cv;
+    } else {
+      const Mat3<double> E = axis_rot_sc<double>(M.axis[j], sv, cv);
+      double* B = blk_all + g * LEGJ_SIZE + k * LEGJ_STRIDE;
+      for (int e = 0; e < 9; ++e) B[21 + e] = E.m[e];
+    }
   }
   cx.sync();
   // chain: frames before each joint and joint origins; contact points behind the last joint
@@ -411,7 +423,7 @@ struct CentroidalCore {
 // sums over both legs (base frame): mc, IO about the base origin, momentum of the joint rates (l, L about the origin)
 template <class T>
 HB_HD void centroidal_core(const DevModel& M, Vec3<T> mc_legs, Sym3<T> IO_legs, Vec3<T> lj, Vec3<T> Lj_O, const T* zyx,
-                           const T* hn, CentroidalCore<T>& out) {
+                           const T* hn, CentroidalCore<T>& out, const double* sc = nullptr /* (sin, cos) values of zyx, if known */) {
   const double mb = M.mass[0], mt = M.total_mass;
   const Vec3<T> cb(T(M.com[0][0]), T(M.com[0][1]), T(M.com[0][2]));
   Sym3<T> Ib;
@@ -428,9 +440,15 @@ HB_HD void centroidal_core(const DevModel& M, Vec3<T> mc_legs, Sym3<T> IO_legs, 
     Icom.yy = Icom.yy - sh.yy; Icom.yz = Icom.yz - sh.yz; Icom.zz = Icom.zz - sh.zz;
   }
   T sz, cz, sy, cy, sx, cx;
-  sincos_t(zyx[0], sz, cz);
-  sincos_t(zyx[1], sy, cy);
-  sincos_t(zyx[2], sx, cx);
+  if (sc) {
+    sincos_known(sc[0], sc[1], zyx[0], sz, cz);
+    sincos_known(sc[2], sc[3], zyx[1], sy, cy);
+    sincos_known(sc[4], sc[5], zyx[2], sx, cx);
+  } else {
+    sincos_t(zyx[0], sz, cz);
+    sincos_t(zyx[1], sy, cy);
+    sincos_t(zyx[2], sx, cx);
+  }
   Mat3<T>& R = out.R;
   R.m[0] = cz * cy; R.m[1] = cz * sy * sx - sz * cx; R.m[2] = cz * sy * cx + sz * sx;
   R.m[3] = sz * cy; R.m[4] = sz * sy * sx + cz * cx; R.m[5] = sz * sy * cx - cz * sx;

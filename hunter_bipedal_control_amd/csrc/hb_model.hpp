@@ -259,27 +259,34 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
   }
   cx.sync();
   // chain: frames before each joint and joint origins; contact points behind the last joint
-  for (int g = cx.lane; g < ngroups; g += cx.nlanes) {
-    const int leg = leg_of(g), j0 = 5 * leg;
-    double* blk = blk_all + g * LEGJ_SIZE;
-    Mat3<double> R = Mat3<double>::identity();
-    Vec3<double> o;
+  // nine lanes per group: lane (g, e) owns entry e = 3 row + col of the frame.  Step k reads only what step k-1 wrote
+  // (R_k^-, E_k, o_{k-1}) and writes R_{k+1}^- (the frame behind the last joint goes to slots 30..38 of the last block,
+  // free until stage C) and o_k: one ordering point per joint instead of a serial 5-joint chain on one lane per group.
+  for (int r = cx.lane; r < 9 * ngroups; r += cx.nlanes) {
+    const int g = r / 9, e = r - 9 * g;
+    blk_all[g * LEGJ_SIZE + 6 + e] = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
+  }
+  cx.sync();
 #pragma unroll 1
-    for (int k = 0; k < 5; ++k) {
-      const int j = j0 + k;
-      double* B = blk + k * LEGJ_STRIDE;
-      o = o + R * Vec3<double>(M.origin[j][0], M.origin[j][1], M.origin[j][2]);
-      st3(B + LEGJ_O, o);
-      for (int e = 0; e < 9; ++e) B[6 + e] = R.m[e];
-      Mat3<double> E;
-      for (int e = 0; e < 9; ++e) E.m[e] = B[21 + e];
-      R = R * E;
+  for (int k = 0; k < 5; ++k) {
+    for (int r = cx.lane; r < 9 * ngroups; r += cx.nlanes) {
+      const int g = r / 9, e = r - 9 * g, row = e / 3, col = e - 3 * row, j = 5 * leg_of(g) + k;
+      double* B = blk_all + g * LEGJ_SIZE + k * LEGJ_STRIDE;
+      const double r0 = B[6 + 3 * row], r1 = B[6 + 3 * row + 1], r2 = B[6 + 3 * row + 2];
+      double* Rn = (k < 4) ? B + LEGJ_STRIDE + 6 : B + 30;
+      Rn[e] = r0 * B[21 + col] + r1 * B[21 + 3 + col] + r2 * B[21 + 6 + col];
+      if (col == 0) {  // origin of joint k, component `row`
+        const double prev = (k > 0) ? B[LEGJ_O - LEGJ_STRIDE + row] : 0.0;
+        B[LEGJ_O + row] = prev + r0 * M.origin[j][0] + r1 * M.origin[j][1] + r2 * M.origin[j][2];
+      }
     }
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int ci = leg + 2 * f;
-      st3(blk + LEGJ_FEET + 3 * f, o + R * Vec3<double>(M.contact_offset[ci][0], M.contact_offset[ci][1], M.contact_offset[ci][2]));
-    }
+    cx.sync();
+  }
+  for (int r = cx.lane; r < 6 * ngroups; r += cx.nlanes) {  // contact points behind the last joint: lane (g, f, axis)
+    const int g = r / 6, fa = r - 6 * g, f = fa / 3, a = fa - 3 * f, ci = leg_of(g) + 2 * f;
+    const double* B4 = blk_all + g * LEGJ_SIZE + 4 * LEGJ_STRIDE;
+    blk_all[g * LEGJ_SIZE + LEGJ_FEET + fa] = B4[LEGJ_O + a] + B4[30 + 3 * a] * M.contact_offset[ci][0] +
+                                              B4[30 + 3 * a + 1] * M.contact_offset[ci][1] + B4[30 + 3 * a + 2] * M.contact_offset[ci][2];
   }
   cx.sync();
   // B: per joint, axis and the body behind it (first moment, inertia about the base origin)

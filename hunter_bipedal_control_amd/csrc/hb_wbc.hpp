@@ -580,6 +580,12 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
         for (int t = 0; t < nn; ++t) s += cfv[t] * x[idx[t]];
         if (s > 1e-9 * fmax(1.0, fabs(rhs)) && s > best) { best = s; bi = c; }
       }
+#if defined(__HIP_DEVICE_COMPILE__)
+      // wave arg-max (DPP maximum + ballot, lowest lane on ties like the serial scan of the host version)
+      const double gb = wave_max_f64(best);
+      if (!(gb > 0.0)) break;  // optimal
+      p = __builtin_amdgcn_readlane(bi, __ffsll(__ballot(best == gb)) - 1);
+#else
       red[cx.lane] = best;
       cx.sync();
       // serial arg-max over lane partials (nlanes <= 64)
@@ -593,6 +599,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       cx.sync();
       p = int(misc[1]);
       cx.sync();
+#endif
     }
     const bool p_is_eq = p < wc.n_eq;
     // dense normal of p into np, rhs in prhs
@@ -623,11 +630,15 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
         d[k] = s;
       }
       cx.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+      sp = wave_sum_f64(cx.lane < NW ? np[cx.lane] * x[cx.lane] : 0.0) - prhs;  // one product per lane, DPP sum
+#else
       {
         double s = -prhs;
         for (int i = 0; i < NW; ++i) s += np[i] * x[i];
         sp = s;
       }
+#endif
       // z = J2 d2 ; r = R^-1 d1 (column-oriented back substitution on a copy)
       for (int i = cx.lane; i < NW; i += cx.nlanes) {
         double s = 0.0;
@@ -648,7 +659,15 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
           cx.sync();
         }
       double zn = 0.0, nn2 = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+      {
+        const double npi = cx.lane < NW ? np[cx.lane] : 0.0, zi = cx.lane < NW ? z[cx.lane] : 0.0;
+        zn = wave_sum_f64(zi * npi);
+        nn2 = wave_sum_f64(npi * npi);
+      }
+#else
       for (int i = 0; i < NW; ++i) { zn += z[i] * np[i]; nn2 += np[i] * np[i]; }
+#endif
       const double t2 = (zn > 1e-14 * (1.0 + nn2)) ? sp / zn : inf;
       const double dir = (p_is_eq && sp < 0.0) ? -1.0 : 1.0;
       double t1 = inf;
@@ -681,7 +700,14 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
         // columns of J are updated as J2 <- J2 H, each lane owning rows of J (one barrier instead of one per rotation).
         {
           double nrm2 = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+          {
+            const double dj = (cx.lane >= q && cx.lane < NW) ? d[cx.lane] : 0.0;
+            nrm2 = wave_sum_f64(dj * dj);
+          }
+#else
           for (int j = q; j < NW; ++j) nrm2 += d[j] * d[j];
+#endif
           const double dq = d[q];
           const double alpha = dq > 0.0 ? -sqrt(nrm2) : sqrt(nrm2);
           const double v0 = dq - alpha;

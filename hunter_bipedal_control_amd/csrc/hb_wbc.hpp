@@ -668,7 +668,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
 #else
       for (int i = 0; i < NW; ++i) { zn += z[i] * np[i]; nn2 += np[i] * np[i]; }
 #endif
-      const double t2 = (zn > 1e-14 * (1.0 + nn2)) ? sp / zn : inf;
+      const double t2 = (zn > 1e-14 * (1.0 + nn2)) ? sp * rcp_t(zn) : inf;
       const double dir = (p_is_eq && sp < 0.0) ? -1.0 : 1.0;
       double t1 = inf;
       int l = -1;
@@ -713,7 +713,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
           const double v0 = dq - alpha;
           const double vtv = nrm2 - dq * dq + v0 * v0;
           if (vtv > 0.0 && nrm2 > 0.0) {
-            const double beta = 2.0 / vtv;
+            const double beta = 2.0 * rcp_t(vtv);
             for (int k = cx.lane; k < NW; k += cx.nlanes) {
               double sacc = Jm[k * NW + q] * v0;
               for (int j = q + 1; j < NW; ++j) sacc += Jm[k * NW + j] * d[j];
@@ -723,10 +723,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
             }
           }
           cx.sync();
-          if (cx.lane == 0) {
-            d[q] = alpha;
-            for (int j = q + 1; j < NW; ++j) d[j] = 0.0;
-          }
+          for (int j = q + cx.lane; j < NW; j += cx.nlanes) d[j] = (j == q) ? alpha : 0.0;
           cx.sync();
         }
         if (fabs(d[q]) > 1e-13 * fmax(1.0, fabs(Rm[0]))) {

@@ -517,8 +517,8 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       const double a = Rm[k * NW + k], b = np[k];
       cx.sync();
       if (b != 0.0) {
-        const double h = sqrt(a * a + b * b), cc = a / h, ss = b / h;
-        for (int j = cx.lane; j < NW; j += cx.nlanes) {
+        const double rh = rsqrt_t(a * a + b * b), cc = a * rh, ss = b * rh;
+        for (int j = cx.lane; j < 16; j += cx.nlanes) {  // the row and the rows of R~ it meets are zero beyond column 15
           if (j >= k) {
             const double t1 = Rm[k * NW + j], t2 = np[j];
             Rm[k * NW + j] = cc * t1 + ss * t2;
@@ -529,13 +529,19 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       cx.sync();
     }
   }
-  // J = R~^-1 (upper triangular inverse), one column per lane
+  // J = R~^-1 (upper triangular inverse), one column per lane.  R~ is a dense 16 x 16 triangle (the cost rows only
+  // involve the accelerations) followed by a diagonal: columns >= 16 of the inverse are the reciprocal diagonal.
+  for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Jm[idx] = 0.0;
+  cx.sync();
   for (int col = cx.lane; col < NW; col += cx.nlanes) {
-    for (int i = NW - 1; i > col; --i) Jm[i * NW + col] = 0.0;
-    for (int i = col; i >= 0; --i) {
-      double s = (i == col) ? 1.0 : 0.0;
-      for (int k = i + 1; k <= col; ++k) s -= Rm[i * NW + k] * Jm[k * NW + col];
-      Jm[i * NW + col] = s / Rm[i * NW + i];
+    if (col >= 16) {
+      Jm[col * NW + col] = rcp_t(Rm[col * NW + col]);
+    } else {
+      for (int i = col; i >= 0; --i) {
+        double s = (i == col) ? 1.0 : 0.0;
+        for (int k = i + 1; k <= col; ++k) s -= Rm[i * NW + k] * Jm[k * NW + col];
+        Jm[i * NW + col] = s * rcp_t(Rm[i * NW + i]);
+      }
     }
   }
   cx.sync();
@@ -750,7 +756,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
           const double a = Rm[j * NW + j], b = Rm[(j + 1) * NW + j];
           cx.sync();
           if (b != 0.0) {
-            const double h = sqrt(a * a + b * b), cc = a / h, ss = b / h;
+            const double rh = rsqrt_t(a * a + b * b), cc = a * rh, ss = b * rh;
             for (int k = cx.lane; k < NW; k += cx.nlanes) {
               if (k >= j && k < q) {
                 const double t1j = Rm[j * NW + k], t2j = Rm[(j + 1) * NW + k];

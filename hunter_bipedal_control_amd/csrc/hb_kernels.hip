@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
     HB_RIC_FETCH_Q(k, l);
     if (k > 0) HB_RIC_FETCH(k - 1, l);
     if (dbg == 21 || dbg == 22 || dbg == 23) continue;
-    WaveTile<2, 2> t;
+    RicT3 t;
     ric_phase3_mma(cxk, lds, t);
     {
       d2* Qs2 = reinterpret_cast<d2*>(lds + RicLds::Qs) + l;

@@ -146,40 +146,44 @@ HB_HD void ric_phase2(const Ctx& cx, double* lds, double* gains, int n_til, int 
 }
 // GEMM 3 in two halves: `ric_phase3_mma` accumulates T - [Q~ q~] = A~' [M1_A M1_b] + Hux' [K~ k~]; the caller then drops
 // [Q~ (22 x 22 row-major) | q~ (22)] at RicLds::Qs — it has no buffer of its own and goes over the A~ block, dead once
-// the operand reads are done — and `ric_phase3_finish` adds it, stores T and symmetrises.
+// the operand reads are done — and `ric_phase3_finish` adds it and stores the new S | s.
+// T is symmetric up to rounding, so only its upper block triangle is formed — tiles (0,0), (0,1) and (1,1): 27 MFMAs
+// instead of 36 — and the new S is the upper triangle of T mirrored (exactly symmetric, no separate symmetrisation pass).
+struct RicT3 {
+  WaveTile<1, 2> t0;  // rows 0..15, columns 0..31
+  WaveTile<1, 1> t1;  // rows 16..31, columns 16..31
+};
 template <class Ctx>
-HB_HD void ric_phase3_mma(const Ctx& cx, double* lds, WaveTile<2, 2>& t) {
-  tile_init(cx, t, 22, 23, [](int, int) { return 0.0; });
-  tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t, lds + RicLds::ABb, lds + RicLds::M1, 22, 23);
-  tile_mma<NU_T, RicLds::LDW, true, RicLds::LDN>(cx, t, lds + RicLds::Hu, lds + RicLds::Kk, 22, 23);
+HB_HD void ric_phase3_mma(const Ctx& cx, double* lds, RicT3& t) {
+  tile_init(cx, t.t0, 16, 23, [](int, int) { return 0.0; });
+  tile_init(cx, t.t1, 6, 7, [](int, int) { return 0.0; });
+  tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t.t0, lds + RicLds::ABb, lds + RicLds::M1, 16, 23);
+  tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t.t1, lds + RicLds::ABb + 16, lds + RicLds::M1 + 16, 6, 7);
+  tile_mma<NU_T, RicLds::LDW, true, RicLds::LDN>(cx, t.t0, lds + RicLds::Hu, lds + RicLds::Kk, 16, 23);
+  tile_mma<NU_T, RicLds::LDW, true, RicLds::LDN>(cx, t.t1, lds + RicLds::Hu + 16, lds + RicLds::Kk + 16, 6, 7);
   cx.sync();
 }
 template <class Ctx>
-HB_HD void ric_phase3_finish(const Ctx& cx, double* lds, const WaveTile<2, 2>& t) {
+HB_HD void ric_phase3_finish(const Ctx& cx, double* lds, const RicT3& t) {
   double* S = lds + RicLds::S;
   double* sv = lds + RicLds::s;
   const double* Qs = lds + RicLds::Qs;
   cx.sync();
-  // T overwrites M1 (narrow rows): every operand read of the GEMMs precedes these stores in the wave's program order
-  tile_store(cx, t, 22, 23, [S, Qs](int i, int c, double v) { S[i * RicLds::LDN + c] = v + (c < 22 ? Qs[i * 22 + c] : Qs[484 + i]); });
-  cx.sync();
-  // symmetrise in place (pair (i, c), i < c, owned by one lane), move s out of column 22 and restore the zero K-padding
-  // of S (columns 22, 23 were covered by M1)
-  for (int idx = cx.lane; idx < 484 + 22; idx += cx.nlanes) {
-    if (idx < 484) {
-      const int i = idx / 22, c = idx - i * 22;
-      if (i < c) {
-        const double m = 0.5 * (S[i * RicLds::LDN + c] + S[c * RicLds::LDN + i]);
-        S[i * RicLds::LDN + c] = m;
-        S[c * RicLds::LDN + i] = m;
-      }
-    } else {
-      const int i = idx - 484;
-      sv[i] = S[i * RicLds::LDN + RicLds::CV];
-      S[i * RicLds::LDN + RicLds::CV] = 0.0;
-      S[i * RicLds::LDN + RicLds::CV + 1] = 0.0;
+  // The new S | s overwrite M1 (narrow rows): every operand read of the GEMMs precedes these stores in the wave's program
+  // order.  Element (i, c), i <= c < 22, goes to S(i, c) and S(c, i); column 22 is the vector s.
+  auto put = [S, sv, Qs](int i, int c, double v) {
+    if (c == RicLds::CV) {
+      sv[i] = v + Qs[484 + i];
+    } else if (i <= c) {
+      const double w = v + Qs[i * 22 + c];
+      S[i * RicLds::LDN + c] = w;
+      S[c * RicLds::LDN + i] = w;
     }
-  }
+  };
+  tile_store(cx, t.t0, 16, 23, put);
+  tile_store(cx, t.t1, 6, 7, [put](int i, int c, double v) { put(16 + i, 16 + c, v); });
+  // restore the zero K-padding of S (columns 22, 23 were covered by M1)
+  for (int idx = cx.lane; idx < 44; idx += cx.nlanes) S[(idx >> 1) * RicLds::LDN + RicLds::CV + (idx & 1)] = 0.0;
   cx.sync();
 }
 // Reference staging of one record (host emulation; the kernel batches its global loads instead).
@@ -194,7 +198,7 @@ HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, const double* rec, doubl
   if (dbg == 21) return;  // profiling ablation markers (hb_config.reserved)
   ric_phase2(cx, lds, gains, int(rec[REC_META]) + int(rec[REC_META + 1]), dbg);
   if (dbg == 22 || dbg == 23) return;
-  WaveTile<2, 2> t;
+  RicT3 t;
   ric_phase3_mma(cx, lds, t);
   double* Qs = lds + RicLds::Qs;
   for (int e = cx.lane; e < 506; e += cx.nlanes) Qs[e] = rec[e < 484 ? REC_QT + e : REC_qT + e - 484];

@@ -308,6 +308,60 @@ __global__ __launch_bounds__(64) void k_ls_decide(Batch b, const DevConfig* __re
   }
 }
 
+// Backtracking tail of the filter line search in ONE launch: an instance that did not accept the full step walks the
+// remaining step sizes alpha0, alpha0 * decay, ... >= alpha_min by itself (block = instance, thread = node, same node
+// evaluation, same summation order and acceptance test as k_ls_eval + k_ls_decide).  Instances that accepted alpha = 1 —
+// nearly all, in steady state — leave at once; the 26 mostly empty launches of the per-alpha loop are gone.
+__global__ __launch_bounds__(64) void k_ls_tail(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C, double alpha0,
+                                                double decay, double alpha_min) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  if (b.accepted[inst]) return;
+  const int n = b.n_nodes[inst];
+  __shared__ double tp[64 * 45];
+  double* x = tp + lane * 45;
+  double* u = x + HB_NX;
+  const double* tt = b.t + size_t(inst) * (b.Nmax + 1);
+  const double armijo = b.acc[inst * 4 + 0], base_merit = b.acc[inst * 4 + 1];
+  const double base_viol = sqrt(b.acc[inst * 4 + 2] + b.acc[inst * 4 + 3]);
+  const bool ric_ok = !b.ric_fail[inst];
+  for (double alpha = alpha0; alpha >= alpha_min; alpha *= decay) {
+    double m = 0, d = 0, e = 0;
+    for (int k = lane; k < n; k += 64) {
+      const size_t nd = size_t(inst) * b.Nmax + k;
+      const size_t xo = (size_t(inst) * (b.Nmax + 1) + k) * HB_NX;
+#pragma unroll
+      for (int i = 0; i < HB_NX; ++i) {
+        x[i] = b.x[xo + i] + alpha * b.dx[xo + i];
+        u[i] = b.u[nd * HB_NU + i] + alpha * b.du[nd * HB_NU + i];
+      }
+      const double* xn0 = b.x + xo + HB_NX;
+      const double* dxn = b.dx + xo + HB_NX;
+      double o3[3];
+      node_value(*M, *C, x, u, [xn0, dxn, alpha](int i) { return xn0[i] + alpha * dxn[i]; }, b.xref + nd * HB_NX, b.swing + nd * 24,
+                 tt[k + 1] - tt[k], b.mode[nd], o3);
+      m += o3[0];
+      d += o3[1];
+      e += o3[2];
+    }
+    m = wave_sum(m);
+    d = wave_sum(d);
+    e = wave_sum(e);
+    if (filter_accept(*C, base_merit, base_viol, m, sqrt(d + e), alpha, armijo) && ric_ok) {
+      const size_t xo = size_t(inst) * (b.Nmax + 1) * HB_NX, uo = size_t(inst) * b.Nmax * HB_NU;
+      for (int i = lane; i < (n + 1) * HB_NX; i += 64) b.x[xo + i] += alpha * b.dx[xo + i];
+      for (int i = lane; i < n * HB_NU; i += 64) b.u[uo + i] += alpha * b.du[uo + i];
+      if (lane == 0) {
+        b.accepted[inst] = 1;
+        b.perf[inst * 4 + 0] = m;
+        b.perf[inst * 4 + 1] = d;
+        b.perf[inst * 4 + 2] = e;
+        b.perf[inst * 4 + 3] = alpha;
+      }
+      return;
+    }
+  }
+}
+
 // ---- unit-level kernels -----------------------------------------------------------------------------------
 __global__ void k_flow_map(int n, const DevModel* __restrict__ M, const double* x, const double* u, double* f,
                            double* pos, double* vel) {
@@ -1191,12 +1245,12 @@ static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t
     if (timed) HB_HIP(hipEventRecord(ctx->ev[2], s));
     hipLaunchKernelGGL(k_ric_fwd, dim3(B), dim3(64), 0, s, b);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[3], s));
-    double alpha = 1.0;
-    while (alpha >= ctx->config.alpha_min) {
-      hipLaunchKernelGGL(k_ls_eval, dim3((B * N + 63) / 64), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, alpha);
-      hipLaunchKernelGGL(k_ls_decide, dim3(B), dim3(64), 0, s, b, ctx->dconfig, alpha);
-      alpha *= ctx->config.alpha_decay;
-    }
+    // filter line search: the full step for every instance, node-parallel; then the backtracking tail in one launch
+    hipLaunchKernelGGL(k_ls_eval, dim3((B * N + 63) / 64), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, 1.0);
+    hipLaunchKernelGGL(k_ls_decide, dim3(B), dim3(64), 0, s, b, ctx->dconfig, 1.0);
+    if (ctx->config.alpha_decay > 0.0 && ctx->config.alpha_decay < 1.0 && ctx->config.alpha_decay >= ctx->config.alpha_min)
+      hipLaunchKernelGGL(k_ls_tail, dim3(B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, ctx->config.alpha_decay,
+                         ctx->config.alpha_decay, ctx->config.alpha_min);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[4], s));
   }
   HB_HIP(hipGetLastError());

@@ -67,13 +67,20 @@ struct BodyWork {
 };
 
 // q = [pos(3) zyx(3) joints(10)], v = qdot.  Accelerations are evaluated at qddot = 0.
-HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPass& P, BodyWork& Wk);
-// convenience form with thread-private work arrays (unit entry points only: they end up in scratch memory)
-HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPass& P) {
-  BodyWork local_work;
-  body_pass(M, q, v, P, local_work);
-}
-HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPass& P, BodyWork& Wk) {
+// The pass is split so that the two legs can run on two lanes: `body_pass_base` (base frame, base body), `body_pass_leg`
+// (one kinematic chain: outward velocities / accelerations, inward forces and composites; reads only base results and
+// writes its own slots of P plus a LegAcc), `body_pass_finish` (sums).  `body_pass` runs them in sequence on one lane.
+struct LegAcc {
+  Vec3<double> f, n_o;     // force through the hip joint, its moment about the base origin
+  Vec3<double> hl, hO;     // bias momentum rate of the chain (linear, angular about the base origin), gravity excluded
+  double mcomp;
+  Vec3<double> mccomp;
+  Sym3<double> IOcomp;
+};
+struct BaseAcc {
+  Vec3<double> f, n, hl, hO;
+};
+HB_HD void body_pass_base(const DevModel& M, const double* q, const double* v, BodyPass& P, BaseAcc& A) {
   double sz, cz, sy, cy, sx, cx;
   sincos_t(q[3], sz, cz);
   sincos_t(q[4], sy, cy);
@@ -91,96 +98,119 @@ HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPa
   P.omega0 = w_yp + v[5] * P.E[2];
   P.alpha0 = v[4] * cross(w_yaw, P.E[1]) + v[5] * cross(w_yp, P.E[2]);
   const Vec3<double> grav(0.0, 0.0, M.gravity);  // gravity as a fictitious upward base acceleration
-  const Vec3<double> v0(v[0], v[1], v[2]);
-
   // base body
   const Vec3<double> c0 = R0 * Vec3<double>(M.com[0][0], M.com[0][1], M.com[0][2]);
   const Sym3<double> I0 = rotate_inertia<double>(R0, M.inertia[0]);
   const Vec3<double> ac0 = grav + cross(P.alpha0, c0) + cross(P.omega0, cross(P.omega0, c0));
   const Vec3<double> F0 = M.mass[0] * ac0;
   const Vec3<double> N0 = I0 * P.alpha0 + cross(P.omega0, I0 * P.omega0);
-  Vec3<double> f_base = F0;
-  Vec3<double> n_base = N0 + cross(c0, F0);
+  A.f = F0;
+  A.n = N0 + cross(c0, F0);
   P.mass = M.mass[0];
   P.mc = M.mass[0] * c0;
   P.IO = I0 + point_inertia<double>(M.mass[0], c0);
   // bias momentum rate (no gravity): linear sum m a, angular about base origin first, shifted to the COM later
-  Vec3<double> hl = M.mass[0] * (ac0 - grav);
-  Vec3<double> hO = N0 + cross(c0, M.mass[0] * (ac0 - grav));
-
-  for (int leg = 0; leg < 2; ++leg) {
-    Mat3<double> R = R0;
-    Vec3<double> op;                       // parent origin minus base origin
-    Vec3<double> w = P.omega0, al = P.alpha0, ao = grav, vo = v0;
-    Vec3<double>* c = Wk.c;
-    Vec3<double>* F = Wk.F;
-    Vec3<double>* N = Wk.N;
-    double* mb = Wk.mb;
-    Sym3<double>* Iw = Wk.Iw;
-    for (int k = 0; k < 5; ++k) {
-      const int j = 5 * leg + k, b = j + 1;
-      const Vec3<double> r = R * Vec3<double>(M.origin[j][0], M.origin[j][1], M.origin[j][2]);
-      const Vec3<double> ok = op + r;
-      const Vec3<double> ak = R * Vec3<double>(M.axis[j][0], M.axis[j][1], M.axis[j][2]);
-      ao = ao + cross(al, r) + cross(w, cross(w, r));
-      vo = vo + cross(w, r);
-      const double qd = v[6 + j];
-      al = al + qd * cross(w, ak);
-      w = w + qd * ak;
-      R = R * axis_rot<double>(M.axis[j], q[6 + j]);
-      const Vec3<double> rc = R * Vec3<double>(M.com[b][0], M.com[b][1], M.com[b][2]);
-      const Vec3<double> acc = ao + cross(al, rc) + cross(w, cross(w, rc));
-      P.o[leg][k] = ok;
-      P.a[leg][k] = ak;
-      c[k] = ok + rc;
-      mb[k] = M.mass[b];
-      Iw[k] = rotate_inertia<double>(R, M.inertia[b]);
-      F[k] = mb[k] * acc;
-      N[k] = Iw[k] * al + cross(w, Iw[k] * w);
-      hl = hl + mb[k] * (acc - grav);
-      hO = hO + N[k] + cross(c[k], mb[k] * (acc - grav));
-      op = ok;
-      if (k == 4) {
-        for (int f = 0; f < 2; ++f) {
-          const int ci = leg + 2 * f;
-          const Vec3<double> rp = R * Vec3<double>(M.contact_offset[ci][0], M.contact_offset[ci][1], M.contact_offset[ci][2]);
-          P.foot[ci] = ok + rp;
-          P.foot_vel[ci] = vo + cross(w, rp);
-          P.foot_acc[ci] = ao - grav + cross(al, rp) + cross(w, cross(w, rp));
-        }
+  A.hl = M.mass[0] * (ac0 - grav);
+  A.hO = N0 + cross(c0, M.mass[0] * (ac0 - grav));
+}
+HB_HD void body_pass_leg(const DevModel& M, const double* q, const double* v, BodyPass& P, BodyWork& Wk, int leg, LegAcc& A) {
+  const Vec3<double> grav(0.0, 0.0, M.gravity);
+  Mat3<double> R;
+  for (int i = 0; i < 9; ++i) R.m[i] = P.R0[i];
+  Vec3<double> op;                       // parent origin minus base origin
+  Vec3<double> w = P.omega0, al = P.alpha0, ao = grav, vo(v[0], v[1], v[2]);
+  Vec3<double>* c = Wk.c;
+  Vec3<double>* F = Wk.F;
+  Vec3<double>* N = Wk.N;
+  double* mb = Wk.mb;
+  Sym3<double>* Iw = Wk.Iw;
+  Vec3<double> hl, hO;
+  for (int k = 0; k < 5; ++k) {
+    const int j = 5 * leg + k, b = j + 1;
+    const Vec3<double> r = R * Vec3<double>(M.origin[j][0], M.origin[j][1], M.origin[j][2]);
+    const Vec3<double> ok = op + r;
+    const Vec3<double> ak = R * Vec3<double>(M.axis[j][0], M.axis[j][1], M.axis[j][2]);
+    ao = ao + cross(al, r) + cross(w, cross(w, r));
+    vo = vo + cross(w, r);
+    const double qd = v[6 + j];
+    al = al + qd * cross(w, ak);
+    w = w + qd * ak;
+    R = R * axis_rot<double>(M.axis[j], q[6 + j]);
+    const Vec3<double> rc = R * Vec3<double>(M.com[b][0], M.com[b][1], M.com[b][2]);
+    const Vec3<double> acc = ao + cross(al, rc) + cross(w, cross(w, rc));
+    P.o[leg][k] = ok;
+    P.a[leg][k] = ak;
+    c[k] = ok + rc;
+    mb[k] = M.mass[b];
+    Iw[k] = rotate_inertia<double>(R, M.inertia[b]);
+    F[k] = mb[k] * acc;
+    N[k] = Iw[k] * al + cross(w, Iw[k] * w);
+    hl = hl + mb[k] * (acc - grav);
+    hO = hO + N[k] + cross(c[k], mb[k] * (acc - grav));
+    op = ok;
+    if (k == 4) {
+      for (int f = 0; f < 2; ++f) {
+        const int ci = leg + 2 * f;
+        const Vec3<double> rp = R * Vec3<double>(M.contact_offset[ci][0], M.contact_offset[ci][1], M.contact_offset[ci][2]);
+        P.foot[ci] = ok + rp;
+        P.foot_vel[ci] = vo + cross(w, rp);
+        P.foot_acc[ci] = ao - grav + cross(al, rp) + cross(w, cross(w, rp));
       }
     }
-    // backward: forces / moments and composites
-    Vec3<double> f, n;  // force and moment (about joint origin k) transmitted through joint k
-    double mcomp = 0.0;
-    Vec3<double> mccomp;
-    Sym3<double> IOcomp;
-    Vec3<double> o_next;
-    for (int k = 4; k >= 0; --k) {
-      const Vec3<double> ok = P.o[leg][k];
-      Vec3<double> nk = N[k] + cross(c[k] - ok, F[k]);
-      if (k < 4) nk = nk + n + cross(o_next - ok, f);
-      f = (k < 4) ? f + F[k] : F[k];
-      n = nk;
-      o_next = ok;
-      P.nle[6 + 5 * leg + k] = dot(P.a[leg][k], n);
-      mcomp += mb[k];
-      mccomp = mccomp + mb[k] * c[k];
-      IOcomp = IOcomp + Iw[k] + point_inertia<double>(mb[k], c[k]);
-      P.l[leg][k] = cross(P.a[leg][k], mccomp - mcomp * ok);
-      P.L[leg][k] = IOcomp * P.a[leg][k] - cross(mccomp, cross(P.a[leg][k], ok));
-    }
-    f_base = f_base + f;
-    n_base = n_base + n + cross(o_next, f);
-    P.mass += mcomp;
-    P.mc = P.mc + mccomp;
-    P.IO = P.IO + IOcomp;
   }
+  // backward: forces / moments and composites
+  Vec3<double> f, n;  // force and moment (about joint origin k) transmitted through joint k
+  double mcomp = 0.0;
+  Vec3<double> mccomp;
+  Sym3<double> IOcomp;
+  Vec3<double> o_next;
+  for (int k = 4; k >= 0; --k) {
+    const Vec3<double> ok = P.o[leg][k];
+    Vec3<double> nk = N[k] + cross(c[k] - ok, F[k]);
+    if (k < 4) nk = nk + n + cross(o_next - ok, f);
+    f = (k < 4) ? f + F[k] : F[k];
+    n = nk;
+    o_next = ok;
+    P.nle[6 + 5 * leg + k] = dot(P.a[leg][k], n);
+    mcomp += mb[k];
+    mccomp = mccomp + mb[k] * c[k];
+    IOcomp = IOcomp + Iw[k] + point_inertia<double>(mb[k], c[k]);
+    P.l[leg][k] = cross(P.a[leg][k], mccomp - mcomp * ok);
+    P.L[leg][k] = IOcomp * P.a[leg][k] - cross(mccomp, cross(P.a[leg][k], ok));
+  }
+  A.f = f;
+  A.n_o = n + cross(o_next, f);
+  A.hl = hl;
+  A.hO = hO;
+  A.mcomp = mcomp;
+  A.mccomp = mccomp;
+  A.IOcomp = IOcomp;
+}
+HB_HD void body_pass_finish(BodyPass& P, const BaseAcc& B, const LegAcc& L0, const LegAcc& L1) {
+  const Vec3<double> f_base = B.f + L0.f + L1.f;
+  const Vec3<double> n_base = B.n + L0.n_o + L1.n_o;
+  P.mass += L0.mcomp + L1.mcomp;
+  P.mc = P.mc + L0.mccomp + L1.mccomp;
+  P.IO = P.IO + L0.IOcomp + L1.IOcomp;
   P.nle[0] = f_base.x; P.nle[1] = f_base.y; P.nle[2] = f_base.z;
   for (int cdir = 0; cdir < 3; ++cdir) P.nle[3 + cdir] = dot(P.E[cdir], n_base);
-  const Vec3<double> com = (1.0 / P.mass) * P.mc;
+  const Vec3<double> com = rcp_t(P.mass) * P.mc;
+  const Vec3<double> hl = B.hl + L0.hl + L1.hl;
   P.hdot_lin = hl;
-  P.hdot_ang = hO - cross(com, hl);
+  P.hdot_ang = (B.hO + L0.hO + L1.hO) - cross(com, hl);
+}
+HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPass& P, BodyWork& Wk) {
+  BaseAcc B;
+  LegAcc L0, L1;
+  body_pass_base(M, q, v, P, B);
+  body_pass_leg(M, q, v, P, Wk, 0, L0);
+  body_pass_leg(M, q, v, P, Wk, 1, L1);
+  body_pass_finish(P, B, L0, L1);
+}
+// convenience form with thread-private work arrays (unit entry points only: they end up in scratch memory)
+HB_HD void body_pass(const DevModel& M, const double* q, const double* v, BodyPass& P) {
+  BodyWork local_work;
+  body_pass(M, q, v, P, local_work);
 }
 
 // mass matrix entry helpers ------------------------------------------------------------------------------
@@ -313,7 +343,9 @@ HB_HD int sparse_row(const WbcCons& wc, const DevConfig& C, int cid, int* idx, d
 // and bias accelerations (12).
 struct PhaseAWork {
   BodyPass P, D;
-  BodyWork W, W2;
+  BodyWork W[4];   // (pass, leg): measured left / right, desired left / right
+  BaseAcc BA[2];
+  LegAcc LA[4];
   double q[HB_NV], v[HB_NV], qd[HB_NV], vd[HB_NV];
   double sc[16];  // acc_lin(3) acc_ang(3) err(3) of the base task
 };
@@ -336,7 +368,8 @@ HB_HD void wbc_phase_a(const Ctx& cx, const DevModel& M, const DevConfig& C, con
   double* v = K.v;
   BodyPass& P = K.P;
   BodyPass& D = K.D;
-  // ---- step 1: rigid-body passes, task 0 = measured state, task 1 = desired state (WbcBase.cpp:85-136)
+  // ---- step 1: rigid-body passes of the measured and of the desired state (WbcBase.cpp:85-136), split over lanes:
+  // 1a base frames (2 lanes), 1b the four kinematic chains (4 lanes), 1c sums and the desired base acceleration (2 lanes)
   for (int task = cx.lane; task < 2; task += cx.nlanes) {
     if (task == 0) {
       for (int i = 0; i < 3; ++i) {
@@ -353,7 +386,7 @@ HB_HD void wbc_phase_a(const Ctx& cx, const DevModel& M, const DevConfig& C, con
       sincos_t(q[4], sy, cy);
       const Vec3<double> er = euler_rates_from_omega<double>(sz, cz, sy, cy, Vec3<double>(rbd[HB_NV], rbd[HB_NV + 1], rbd[HB_NV + 2]));
       v[3] = er.x; v[4] = er.y; v[5] = er.z;
-      body_pass(M, q, v, P, K.W);
+      body_pass_base(M, q, v, P, K.BA[0]);
     } else if (!stance_mode) {
       Centroidal<double> cd;
       centroidal_eval<double>(M, xdes + 9, xdes + 12, xdes, udes + 12, cd);
@@ -363,7 +396,21 @@ HB_HD void wbc_phase_a(const Ctx& cx, const DevModel& M, const DevConfig& C, con
       vd_[0] = cd.v_lin.x; vd_[1] = cd.v_lin.y; vd_[2] = cd.v_lin.z;
       vd_[3] = cd.euler_rate.x; vd_[4] = cd.euler_rate.y; vd_[5] = cd.euler_rate.z;
       for (int j = 0; j < HB_NJ; ++j) vd_[6 + j] = udes[12 + j];
-      body_pass(M, qd_, vd_, D, K.W2);
+      body_pass_base(M, qd_, vd_, D, K.BA[1]);
+    }
+  }
+  cx.sync();
+  for (int task = cx.lane; task < 4; task += cx.nlanes) {
+    const int pass = task >> 1, leg = task & 1;
+    if (pass == 0) body_pass_leg(M, q, v, P, K.W[task], leg, K.LA[task]);
+    else if (!stance_mode) body_pass_leg(M, K.qd, K.vd, D, K.W[task], leg, K.LA[task]);
+  }
+  cx.sync();
+  for (int task = cx.lane; task < 2; task += cx.nlanes) {
+    if (task == 0) {
+      body_pass_finish(P, K.BA[0], K.LA[0], K.LA[1]);
+    } else if (!stance_mode) {
+      body_pass_finish(D, K.BA[1], K.LA[2], K.LA[3]);
       // base acceleration desired: A_b qdd_b = m hdot_norm(x,u) - Adot v   (zero joint accelerations)
       const Vec3<double> comr = (1.0 / D.mass) * D.mc;
       Vec3<double> fs, ms;

@@ -793,18 +793,29 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     rec[rec_b(row)] = s;
   }
   // Q~ = Q + Kx' M + P_j' Kx ,  Q = diag(Qd) + w sum_soft c c'      (three accumulating GEMMs on the matrix cores)
+  // Q~ is symmetric up to rounding: only its upper block triangle is formed — tiles (0,0), (0,1) and (1,1), 27 MFMAs
+  // instead of 36 — and the off-diagonal tile is stored twice (k_ric_bwd mirrors the upper triangle anyway).
   {
     const double sw = C.soft_w;
-    WaveTile<2, 2> tq;
-    tile_init(cx, tq, 22, 22, [Qd](int a, int b) { return a == b ? Qd[a] : 0.0; });
-    // soft rows are slots 3i+1, 3i+2 of the swing feet
-    tile_mma<12, 12, false, 12, true>(cx, tq, CDt, CDt, 22, 22, [cfm, sw](int slot) {
+    auto soft = [cfm, sw](int slot) {  // soft rows are slots 3i+1, 3i+2 of the swing feet
       const int foot = slot / 3;
       return (slot - 3 * foot != 0 && !((cfm >> foot) & 1)) ? sw : 0.0;
+    };
+    WaveTile<1, 2> t0;  // rows 0..15
+    WaveTile<1, 1> t1;  // rows 16..21, columns 16..21
+    tile_init(cx, t0, 16, 22, [Qd](int a, int b) { return a == b ? Qd[a] : 0.0; });
+    tile_init(cx, t1, 6, 6, [Qd](int a, int b) { return a == b ? Qd[16 + a] : 0.0; });
+    tile_mma<12, 12, false, 12, true>(cx, t0, CDt, CDt, 16, 22, soft);
+    tile_mma<12, 12, false, 12, true>(cx, t1, CDt + 16 * 12, CDt + 16 * 12, 6, 6, soft);
+    tile_mma<12, 23, true, 22, false, 10>(cx, t0, Kx, Mm, 16, 22);
+    tile_mma<12, 23, true, 22, false, 10>(cx, t1, Kx + 16, Mm + 16, 6, 6);
+    tile_mma<12, 22, true, 23, false, 10>(cx, t0, Pj, Kx, 16, 22);
+    tile_mma<12, 22, true, 23, false, 10>(cx, t1, Pj + 16, Kx + 16, 6, 6);
+    tile_store(cx, t0, 16, 22, [rec, dt](int a, int b, double v) {
+      rec[REC_QT + a * 22 + b] = dt * v;
+      if (b >= 16) rec[REC_QT + b * 22 + a] = dt * v;
     });
-    tile_mma<12, 23, true, 22, false, 10>(cx, tq, Kx, Mm, 22, 22);
-    tile_mma<12, 22, true, 23, false, 10>(cx, tq, Pj, Kx, 22, 22);
-    tile_store(cx, tq, 22, 22, [rec, dt](int a, int b, double v) { rec[REC_QT + a * 22 + b] = dt * v; });
+    tile_store(cx, t1, 6, 6, [rec, dt](int a, int b, double v) { rec[REC_QT + (16 + a) * 22 + 16 + b] = dt * v; });
   }
   // q~ = q + Kx' r_j + M' ke
   for (int a = cx.lane; a < 22; a += cx.nlanes) {

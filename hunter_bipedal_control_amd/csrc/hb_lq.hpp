@@ -166,6 +166,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* SC = LV_all + 108;           // 2 x 6: sin / cos of the ZYX angles at the two RK2 points
   double* J1 = lds + LqLds::J1;        // 44 x 12: d f(rows 0..11) / d direction at point 1
   double* J2 = lds + LqLds::J2;        // same at point 2
+  // (xs, us stay valid to the end of the kernel — no later buffer reaches them — and every later phase reads x and u from
+  // these LDS copies instead of going back to global memory)
   for (int i = cx.lane; i < 22; i += cx.nlanes) {
     xs[i] = in.x[i];
     us[i] = in.u[i];
@@ -557,7 +559,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     const RelaxedBarrierD bp{C.pos_b[0], C.pos_b[1]}, bv{C.vel_b[0], C.vel_b[1]}, bf{C.force_b[0], C.force_b[1]};
     // friction-cone terms of foot i at the current forces (FrictionConeConstraint.cpp:70-233)
     auto cone = [&](int i, double& h, double* g, double& H00, double& H01, double& H11) {
-      const double Fx = in.u[3 * i], Fy = in.u[3 * i + 1], Fz = in.u[3 * i + 2];
+      const double Fx = us[3 * i], Fy = us[3 * i + 1], Fz = us[3 * i + 2];
       const double t2 = Fx * Fx + Fy * Fy + C.friction_reg, tn = sqrt(t2), t32 = tn * t2;
       h = C.friction_mu * (Fz + C.friction_gripper) - tn;
       const double itn = rcp_t(tn), it32 = rcp_t(t32);
@@ -591,17 +593,17 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         double h1 = 1.0, h2 = 1.0, bmu = 0.0, bdel = 1.0;
         if (role >= 12 && role < 22) {
           const int j = role - 12;
-          const double h = in.x[role];
+          const double h = xs[role];
           hasb = true; h1 = h - M.q_lower[j]; h2 = M.q_upper[j] - h; bmu = bp.mu; bdel = bp.delta;
         } else if (role >= 22 && role < 34) {
           const int m = role - 22;
           if (m - 3 * (m / 3) == 2) {
-            const double h = in.u[m];
+            const double h = us[m];
             hasb = true; h1 = h - C.force_lim[0]; h2 = C.force_lim[1] - h; bmu = bf.mu; bdel = bf.delta;
           }
         } else if (role >= 34 && role < 44) {
           const int k = role - 34;
-          const double hv = in.u[12 + k], vl = M.qd_limit[k];
+          const double hv = us[12 + k], vl = M.qd_limit[k];
           hasb = true; h1 = hv + vl; h2 = vl - hv; bmu = bv.mu; bdel = bv.delta;
         }
         if (hasb) {
@@ -613,7 +615,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       }
       if (role < 22) {
         const int i = role;
-        const double dxv = in.x[i] - in.xref[i];
+        const double dxv = xs[i] - in.xref[i];
         double qd_ = C.Q_diag[i] + shift_sum, qg = C.Q_diag[i] * dxv;
         pc += 0.5 * C.Q_diag[i] * dxv * dxv;
         if (i >= 12) {
@@ -627,13 +629,13 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         pd += dd * dd;
       } else if (role < 34) {
         const int m = role - 22, foot = m / 3, a = m % 3;
-        const double du = in.u[m] - ((a == 2 && cf[foot]) ? fz_nom : 0.0);
+        const double du = us[m] - ((a == 2 && cf[foot]) ? fz_nom : 0.0);
         double rg = C.R_FF_diag[m] * du;
         pc += 0.5 * C.R_FF_diag[m] * du * du;
         if (cf[foot]) {
           rg += coneb[12 * foot + 8] * coneb[12 * foot + 1 + a];
         } else {
-          pe += in.u[m] * in.u[m];  // zero-force equality value
+          pe += us[m] * us[m];  // zero-force equality value
         }
         if (a == 2) {
           pc += bval;
@@ -643,8 +645,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       } else if (role < 44) {
         const int k = role - 34;
         double sacc = 0;
-        for (int l = 0; l < HB_NJ; ++l) sacc += C.R_jj[k * 10 + l] * in.u[12 + l];
-        pc += 0.5 * in.u[12 + k] * sacc;
+        for (int l = 0; l < HB_NJ; ++l) sacc += C.R_jj[k * 10 + l] * us[12 + l];
+        pc += 0.5 * us[12 + k] * sacc;
         pc += bval;
         ru[12 + k] = sacc + bd1;
         scal[4 + k] = bd2 + shift_sum;  // joint diagonal additions to R_jj
@@ -660,7 +662,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         for (int e = 0; e < 9; ++e) blk[e] = 0.0;
         for (int a = 0; a < 3; ++a) blk[4 * a] = C.R_FF_diag[3 * foot + a] + shift_sum;
         {
-          const double h = in.u[3 * foot + 2];
+          const double h = us[3 * foot + 2];
           blk[8] += bf.d2(h - C.force_lim[0]) + bf.d2(C.force_lim[1] - h);
         }
         if (cf[foot]) {
@@ -786,7 +788,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       for (int k = 0; k < 10; ++k) s += ABt[(34 + k) * 12 + row] * Kx[k * 23 + 22];
       for (int i = 0; i < HB_NC; ++i)
         if (!cf[i])
-          for (int a = 0; a < 3; ++a) s -= ABt[(22 + 3 * i + a) * 12 + row] * in.u[3 * i + a];
+          for (int a = 0; a < 3; ++a) s -= ABt[(22 + 3 * i + a) * 12 + row] * us[3 * i + a];
     } else {
       s += dt * Kx[(row - 12) * 23 + 22];
     }
@@ -870,7 +872,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   for (int idx = cx.lane; idx < 220; idx += cx.nlanes) rec[REC_KX + idx] = Kx[(idx / 22) * 23 + idx % 22];
   for (int k = cx.lane; k < 10; k += cx.nlanes) rec[REC_KE + k] = Kx[k * 23 + 22];
   for (int idx = cx.lane; idx < 60; idx += cx.nlanes) rec[REC_Z + idx] = Z[idx];
-  for (int i = cx.lane; i < 12; i += cx.nlanes) rec[REC_DF + i] = cf[i / 3] ? 0.0 : -in.u[i];
+  for (int i = cx.lane; i < 12; i += cx.nlanes) rec[REC_DF + i] = cf[i / 3] ? 0.0 : -us[i];
   if (cx.lane == 0) {
     rec[REC_META + 0] = double(n_f);
     rec[REC_META + 1] = double(nz);

@@ -106,8 +106,8 @@ struct LqLds {
   static constexpr int LJ = ABt;             // 4 x LEGJ_SIZE (824)
   static constexpr int J1 = LJ + 4 * LEGJ_SIZE;  // [44][12]
   static constexpr int J2 = J1 + 528;        // [44][12]
-  static constexpr int p1 = J2 + 528;        // xs us xe fv FR LV = 222 doubles, (sin, cos) of zyx at both RK2 points = 12
-  static constexpr int total = (p1 + 234 > ints + 16) ? p1 + 234 : ints + 16;
+  static constexpr int p1 = J2 + 528;        // xs us xe fv FR LV = 222 doubles, (sin, cos) of zyx at both RK2 points = 12, swing refs 24
+  static constexpr int total = (p1 + 258 > ints + 16) ? p1 + 258 : ints + 16;
 };
 static_assert(LqLds::GtG >= LqLds::ABt + 528 && LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are still being read");
 static_assert(LqLds::total * 8 <= 20480, "k_lq: LDS per node must allow 8 workgroups per CU");
@@ -164,6 +164,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* FR = fv + 24;                // 2 x 12: (contact point - COM) at the two points
   double* LV_all = FR + 24;            // 2 points x 2 legs x 27 leg values
   double* SC = LV_all + 108;           // 2 x 6: sin / cos of the ZYX angles at the two RK2 points
+  double* SW = SC + 12;                // 4 x 6 swing references of the node
   double* J1 = lds + LqLds::J1;        // 44 x 12: d f(rows 0..11) / d direction at point 1
   double* J2 = lds + LqLds::J2;        // same at point 2
   // (xs, us stay valid to the end of the kernel — no later buffer reaches them — and every later phase reads x and u from
@@ -173,6 +174,17 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     us[i] = in.u[i];
     xe[i] = in.x[i];
   }
+  for (int i = cx.lane; i < 24; i += cx.nlanes) SW[i] = in.swing[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+  // entry `lane` of the reference state and of the next node's state, requested now and used (by the same lane) in the cost
+  // phase and in b~: no global round trip in the middle of the kernel
+  const double xref_l = in.xref[cx.lane < 22 ? cx.lane : 0], xnext_l = in.xnext[cx.lane < 22 ? cx.lane : 0];
+  auto xref_at = [xref_l](int) { return xref_l; };
+  auto xnext_at = [xnext_l](int) { return xnext_l; };
+#else
+  auto xref_at = [&in](int i) { return in.xref[i]; };
+  auto xnext_at = [&in](int i) { return in.xnext[i]; };
+#endif
   cx.sync();
   // ---- stage 1: leg value passes of BOTH evaluation points at once.  The legs are evaluated in the base frame and the
   // joint block of the flow map is the input itself, so the joint state of the second RK2 point (q + dt qd) is known
@@ -283,7 +295,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
             r1 = fvel.y;
             r2 = fvel.z + C.zv_gain * pz + C.zv_off;
           } else {      // normal velocity + xy soft reference (LeggedRobotPreComputation.cpp:96-117)
-            const double* sw = in.swing + 6 * i;
+            const double* sw = SW + 6 * i;
             const Dual1 px = Dual1(xs[6]) + fr.x, py = Dual1(xs[7]) + fr.y;
             r0 = fvel.z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
             r1 = C.xy_gain * px + fvel.x - (sw[3] + C.xy_gain * sw[0]);
@@ -615,7 +627,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       }
       if (role < 22) {
         const int i = role;
-        const double dxv = xs[i] - in.xref[i];
+        const double dxv = xs[i] - xref_at(i);  // i == lane
         double qd_ = C.Q_diag[i] + shift_sum, qg = C.Q_diag[i] * dxv;
         pc += 0.5 * C.Q_diag[i] * dxv * dxv;
         if (i >= 12) {
@@ -625,7 +637,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         }
         Qd[i] = qd_;
         qx[i] = qg;
-        const double dd = xplus[i] - in.xnext[i];
+        const double dd = xplus[i] - xnext_at(i);
         pd += dd * dd;
       } else if (role < 34) {
         const int m = role - 22, foot = m / 3, a = m % 3;
@@ -783,7 +795,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     }
   }
   for (int row = cx.lane; row < 22; row += cx.nlanes) {
-    double s = xplus[row] - in.xnext[row];
+    double s = xplus[row] - xnext_at(row);  // row == lane
     if (row < 12) {
       for (int k = 0; k < 10; ++k) s += ABt[(34 + k) * 12 + row] * Kx[k * 23 + 22];
       for (int i = 0; i < HB_NC; ++i)

@@ -767,37 +767,48 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   // A~ = A + B_j Kx   and the kernel columns of B~ = B_j Z.  Momentum / base rows (0..11) on the matrix cores; the joint
   // rows are the closed form  A~ = [0 I] + dt Kx,  B~ = dt Z  (no force columns),  b~ = defect + dt ke.
+  double* btmp = W + 80;  // 12: B_j ke, the dynamic part of b~ (column 22 of the A~ tile: Kx carries ke in its column 22)
   {
     WaveTile<1, 2> ta;
-    tile_init(cx, ta, 12, 22, [ABt](int row, int c) { return ABt[c * 12 + row]; });
-    tile_mma<12, 12, true, 23, false, 10>(cx, ta, ABt + 34 * 12, Kx, 12, 22);
-    tile_store(cx, ta, 12, 22, [rec](int row, int c, double v) { rec[rec_A(row, c)] = v; });
+    tile_init(cx, ta, 12, 23, [ABt](int row, int c) { return c < 22 ? ABt[c * 12 + row] : 0.0; });
+    tile_mma<12, 12, true, 23, false, 10>(cx, ta, ABt + 34 * 12, Kx, 12, 23);
+    tile_store(cx, ta, 12, 23, [rec, btmp](int row, int c, double v) {
+      if (c < 22) rec[rec_A(row, c)] = v;
+      else btmp[row] = v;
+    });
     WaveTile<1, 1> tb;
     tile_init(cx, tb, 12, 6, [](int, int) { return 0.0; });
     tile_mma<12, 12, true, 6, false, 10>(cx, tb, ABt + 34 * 12, Z, 12, 6);
     tile_store(cx, tb, 12, 6, [rec, n_f, nz](int row, int b, double v) { if (b < nz) rec[rec_B(row, n_f + b)] = v; });
   }
-  for (int idx = cx.lane; idx < 220; idx += cx.nlanes) {
-    const int j = idx / 22, c = idx - 22 * j;
-    rec[rec_A(12 + j, c)] = (c == 12 + j ? 1.0 : 0.0) + dt * Kx[j * 23 + c];
-  }
-  // B~ columns: contact forces (foot order) first, zero padding after the kernel directions
-  for (int idx = cx.lane; idx < 22 * NU_T; idx += cx.nlanes) {
-    const int row = idx / NU_T, col = idx % NU_T;
-    if (col < n_f) {
-      // map col -> force index of the (col/3)-th contact foot
-      const int foot = (flist >> (2 * (col / 3))) & 3;
-      rec[rec_B(row, col)] = row < 12 ? ABt[(22 + 3 * foot + col % 3) * 12 + row] : 0.0;
-    } else if (col >= ntil) {
-      rec[rec_B(row, col)] = 0.0;
-    } else if (row >= 12) {
-      rec[rec_B(row, col)] = dt * Z[(row - 12) * 6 + col - n_f];
+  // joint rows of A~ and the recovery copy of Kx: one row per (uniform) step, one column per lane
+  for (int c = cx.lane; c < 22; c += cx.nlanes) {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const double kx = Kx[j * 23 + c];
+      rec[rec_A(12 + j, c)] = (c == 12 + j ? 1.0 : 0.0) + dt * kx;
+      rec[REC_KX + j * 22 + c] = kx;
     }
   }
+  cx.sync();
+  if (C.debug_stop == 30) return;
+  // B~ columns: contact forces (foot order) first, zero padding after the kernel directions; one column per (uniform)
+  // step, one row per lane (the kernel columns of rows 0..11 came from the tile above)
   for (int row = cx.lane; row < 22; row += cx.nlanes) {
+#pragma unroll
+    for (int col = 0; col < NU_T; ++col) {
+      if (col < n_f) {
+        const int foot = (flist >> (2 * (col / 3))) & 3;  // force index of the (col/3)-th contact foot
+        rec[rec_B(row, col)] = row < 12 ? ABt[(22 + 3 * foot + col % 3) * 12 + row] : 0.0;
+      } else if (col >= ntil) {
+        rec[rec_B(row, col)] = 0.0;
+      } else if (row >= 12) {
+        rec[rec_B(row, col)] = dt * Z[(row - 12) * 6 + col - n_f];
+      }
+    }
     double s = xplus[row] - xnext_at(row);  // row == lane
     if (row < 12) {
-      for (int k = 0; k < 10; ++k) s += ABt[(34 + k) * 12 + row] * Kx[k * 23 + 22];
+      s += btmp[row];
       for (int i = 0; i < HB_NC; ++i)
         if (!cf[i])
           for (int a = 0; a < 3; ++a) s -= ABt[(22 + 3 * i + a) * 12 + row] * us[3 * i + a];
@@ -806,6 +817,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     }
     rec[rec_b(row)] = s;
   }
+  if (C.debug_stop == 31) return;
   // Q~ = Q + Kx' M + P_j' Kx ,  Q = diag(Qd) + w sum_soft c c'      (three accumulating GEMMs on the matrix cores)
   // Q~ is symmetric up to rounding: only its upper block triangle is formed — tiles (0,0), (0,1) and (1,1), 27 MFMAs
   // instead of 36 — and the off-diagonal tile is stored twice (k_ric_bwd mirrors the upper triangle anyway).
@@ -831,6 +843,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     });
     tile_store(cx, t1, 6, 6, [rec, dt](int a, int b, double v) { rec[REC_QT + (16 + a) * 22 + 16 + b] = dt * v; });
   }
+  if (C.debug_stop == 32) return;
   // q~ = q + Kx' r_j + M' ke
   for (int a = cx.lane; a < 22; a += cx.nlanes) {
     double s = qx[a];
@@ -846,10 +859,12 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     tile_mma<12, 6, true, 22, false, 10>(cx, tp, Z, Mm, 6, 22);
     tile_store(cx, tp, 6, 22, [rec, n_f, nz, dt](int b, int c, double v) { if (b < nz) rec[rec_P(n_f + b, c)] = dt * v; });
   }
-  for (int idx = cx.lane; idx < NU_T * 22; idx += cx.nlanes) {
-    const int col = idx / 22;
-    if (col < n_f || col >= ntil) rec[rec_P(col, idx - 22 * col)] = 0.0;
+  for (int c = cx.lane; c < 22; c += cx.nlanes) {
+#pragma unroll
+    for (int a = 0; a < NU_T; ++a)
+      if (a < n_f || a >= ntil) rec[rec_P(a, c)] = 0.0;
   }
+  if (C.debug_stop == 33) return;
   // R~ (12x12): contact-force blocks, Z' R_jj Z, identity on the padding
   for (int idx = cx.lane; idx < NU_T * NU_T; idx += cx.nlanes) {
     const int ca = idx / NU_T, cb = idx % NU_T;
@@ -880,8 +895,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     }
     rec[rec_r(col)] = dt * s;
   }
+  if (C.debug_stop == 34) return;
   // recovery data
-  for (int idx = cx.lane; idx < 220; idx += cx.nlanes) rec[REC_KX + idx] = Kx[(idx / 22) * 23 + idx % 22];
   for (int k = cx.lane; k < 10; k += cx.nlanes) rec[REC_KE + k] = Kx[k * 23 + 22];
   for (int idx = cx.lane; idx < 60; idx += cx.nlanes) rec[REC_Z + idx] = Z[idx];
   for (int i = cx.lane; i < 12; i += cx.nlanes) rec[REC_DF + i] = cf[i / 3] ? 0.0 : -us[i];

@@ -136,7 +136,13 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
     const d2* rec2_ = reinterpret_cast<const d2*>(b.recs + (size_t(inst) * b.Nmax + (kk)) * REC_SIZE) + NP + (l);  \
     _Pragma("unroll") for (int r = 0; r < NQ; ++r) bufq[r] = rec2_[64 * r];                                        \
   }
-  if (n > 0) HB_RIC_FETCH(n - 1, cx.lane);
+  double meta_nf = 0.0, meta_nz = 0.0;
+  if (n > 0) {
+    HB_RIC_FETCH(n - 1, cx.lane);
+    const double* meta = b.recs + (size_t(inst) * b.Nmax + n - 1) * REC_SIZE + REC_META;
+    meta_nf = meta[0];
+    meta_nz = meta[1];
+  }
   for (int k = n - 1; k >= 0; --k) {
     // Per-lane addresses are rebuilt every stage from an opaque copy of the lane id: as loop invariants the compiler
     // hoisted ~100 of them out of the loop and then spilled them to scratch around the Cholesky, and every scratch
@@ -157,16 +163,19 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
       }
     }
     cx.sync();
-    // number of projected inputs of this stage (uniform; back long before the factorisation needs it)
-    const double* meta = b.recs + (size_t(inst) * b.Nmax + k) * REC_SIZE + REC_META;
-    const double m_nf = meta[0], m_nz = meta[1];
     if (dbg == 20) { if (k > 0) HB_RIC_FETCH(k - 1, l); continue; }  // profiling ablation: staging only
-    ric_phase1(cxk, lds);
-    if (dbg != 21) ric_phase2(cxk, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE, int(m_nf) + int(m_nz), dbg);
+    // n_til: number of projected inputs of this stage (uniform; requested one stage ahead with the prefetch)
+    const int n_til = int(meta_nf) + int(meta_nz);
+    ric_phase12(cxk, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE, n_til, dbg);
     asm volatile("" : "+v"(l));
     cxk.lane = l;
     HB_RIC_FETCH_Q(k, l);
-    if (k > 0) HB_RIC_FETCH(k - 1, l);
+    if (k > 0) {
+      HB_RIC_FETCH(k - 1, l);
+      const double* meta = b.recs + (size_t(inst) * b.Nmax + k - 1) * REC_SIZE + REC_META;
+      meta_nf = meta[0];
+      meta_nz = meta[1];
+    }
     if (dbg == 21 || dbg == 22 || dbg == 23) continue;
     RicT3 t;
     ric_phase3_mma(cxk, lds, t);

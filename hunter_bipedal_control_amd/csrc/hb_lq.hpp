@@ -40,11 +40,11 @@ struct DevConfig {
 
 // ---- node record layout in HBM (doubles) ------------------------------------------------------------
 // The Riccati part of the record is the LDS image of the backward sweep (hb_riccati.hpp RicLds): rows of 36
-//   [x block (22) | vector (1) | unused (1) | u block (12)]
+//   [x block (22) | vector (1) | u block (12) | unused (1)]
 // so that k_ric_bwd stages it with straight 16-byte copies (lane * 16 + constant) and no index arithmetic.  The unused
 // column is never written (the allocation is zeroed once) and only ever feeds discarded outputs of the tile GEMMs.
 constexpr int NU_T = 12;                 // projected input width (padded)
-constexpr int REC_LD = 36, REC_CV = 22, REC_CU = 24;
+constexpr int REC_LD = 36, REC_CV = 22, REC_CU = 23;
 constexpr int REC_AB = 0;                // 22 rows: [A~ | b~ | . | B~]
 constexpr int REC_PR = 792;              // 12 rows: [P~ | r~ | . | R~]
 constexpr int REC_QT = 1224;             // 22x22

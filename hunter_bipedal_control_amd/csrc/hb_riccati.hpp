@@ -11,7 +11,8 @@ namespace hb {
 // Every matrix is kept in a padded layout chosen so that each MFMA operand of the three GEMM groups is "per-lane base +
 // compile-time offset" (one address register per operand, offsets in the ds_read immediates) and so that the K-padding
 // of the 16x16x4 tiles is zeros on both sides:
-//   wide rows  (stride 36): [x block (22) | vector (1) | zero (1) | u block (12)]      [A~ b~ . B~], M1, [P~ r~ . R~], Hu
+//   wide rows  (stride 36): [x block (22) | vector (1) | u block (12) | unused (1)]    [A~ b~ B~ .], M1, [P~ r~ R~ .], Hu
+//   (the u block starts at column 23 so that x block + vector + up to 9 projected inputs fit two 16-column tiles)
 //   narrow rows (stride 24): [x block (22) | vector (1) | zero (1)]                     S (cols 22,23 zero), T, [K~ k~ .]
 // ABb and M1 carry two extra all-zero rows (K = 22 -> 24).  Buffers with disjoint lifetimes share storage (the
 // workgroup is one wave: its LDS accesses complete in program order):
@@ -19,7 +20,7 @@ namespace hb {
 //   PH  [P~ r~ . R~] (staged .. accumulator init of GEMM 2)  ->  Hu
 // [Q~ q~] has no buffer of its own: it is dropped over the dead A~ block once GEMM 3 has read its operands.
 struct RicLds {
-  static constexpr int LDN = 24, LDW = 36, CV = 22, CU = 24;
+  static constexpr int LDN = 24, LDW = 36, CV = 22, CU = 23;
   static constexpr int X = 0;                    // 24 x 36
   static constexpr int S = X;                    // 22 x 24
   static constexpr int s = S + 22 * LDN;         // 24
@@ -39,15 +40,18 @@ static_assert(RicLds::total * 8 <= 20480, "k_ric_bwd: LDS per instance must allo
 // One backward step on the staged record.  Updates S, s in place; writes the gains.
 //   M1 = S [A~ b~ B~] (+ s),  Hu = B~' M1 + [P~ r~ R~],  K~ = -Huu^-1 [Hux hu],
 //   S <- sym(Q~ + A~' M1_A + Hux' K~),  s <- q~ + A~' M1_b + Hux' k~          
-template <class Ctx>
+// NTW = number of 16-column tiles of the wide operands that are formed: 3 in general, 2 when the stage has at most 9
+// projected inputs (columns 0..31 = x block, vector, inputs 0..8): GEMM 1 24 instead of 36 MFMAs, GEMM 2 12 instead of 18.
+template <int NTW, class Ctx>
 HB_HD void ric_phase1(const Ctx& cx, double* lds) {
   const double* sv = lds + RicLds::s;
   double* M1 = lds + RicLds::M1;
-  WaveTile<2, 3> t;
-  tile_init(cx, t, 22, RicLds::LDW, [sv](int i, int c) { return c == RicLds::CV ? sv[i] : 0.0; });
-  tile_mma<24, RicLds::LDN, false, RicLds::LDW>(cx, t, lds + RicLds::S, lds + RicLds::ABb, 22, RicLds::LDW);
+  constexpr int NC = NTW * 16 < RicLds::LDW ? NTW * 16 : RicLds::LDW;
+  WaveTile<2, NTW> t;
+  tile_init(cx, t, 22, NC, [sv](int i, int c) { return c == RicLds::CV ? sv[i] : 0.0; });
+  tile_mma<24, RicLds::LDN, false, RicLds::LDW>(cx, t, lds + RicLds::S, lds + RicLds::ABb, 22, NC);
   // M1 overwrites S | s: every operand read above precedes these stores in the wave's program order
-  tile_store(cx, t, 22, RicLds::LDW, [M1](int i, int c, double v) { M1[i * RicLds::LDW + c] = v; });
+  tile_store(cx, t, 22, NC, [M1](int i, int c, double v) { M1[i * RicLds::LDW + c] = v; });
   cx.sync();
 }
 // Cholesky of the leading NT x NT block of Huu and the 23 triangular solves.  Every lane factors the (uniform) block
@@ -129,20 +133,34 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
   cx.sync();
 }
 // `n_til` = number of projected inputs of the stage (contact-force + kernel coordinates, REC_META)
-template <class Ctx>
-HB_HD void ric_phase2(const Ctx& cx, double* lds, double* gains, int n_til, int dbg = 0) {
+template <int NTW, class Ctx>
+HB_HD void ric_phase2_gemm(const Ctx& cx, double* lds) {
   const double* PRr = lds + RicLds::PRr;
   double* Hu = lds + RicLds::Hu;
-  {
-    WaveTile<1, 3> t;
-    tile_init(cx, t, NU_T, RicLds::LDW, [PRr](int a, int c) { return PRr[a * RicLds::LDW + c]; });
-    tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t, lds + RicLds::ABb + RicLds::CU, lds + RicLds::M1, NU_T, RicLds::LDW);
-    tile_store(cx, t, NU_T, RicLds::LDW, [Hu](int a, int c, double v) { Hu[a * RicLds::LDW + c] = v; });  // over [P~ r~ R~]
-  }
+  constexpr int NC = NTW * 16 < RicLds::LDW ? NTW * 16 : RicLds::LDW;
+  WaveTile<1, NTW> t;
+  tile_init(cx, t, NU_T, NC, [PRr](int a, int c) { return PRr[a * RicLds::LDW + c]; });
+  tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t, lds + RicLds::ABb + RicLds::CU, lds + RicLds::M1, NU_T, NC);
+  tile_store(cx, t, NU_T, NC, [Hu](int a, int c, double v) { Hu[a * RicLds::LDW + c] = v; });  // over [P~ r~ R~]
   cx.sync();
-  if (dbg == 22) return;
-  if (n_til <= 9) ric_factor_solve<9>(cx, lds, gains);
-  else ric_factor_solve<NU_T>(cx, lds, gains);
+}
+// GEMM 1, GEMM 2 and the factorisation / solves of one stage
+template <class Ctx>
+HB_HD void ric_phase12(const Ctx& cx, double* lds, double* gains, int n_til, int dbg = 0) {
+  static_assert(RicLds::CU + 9 <= 32, "x block, vector and 9 inputs must fit two tiles");
+  if (n_til <= 9) {
+    ric_phase1<2>(cx, lds);
+    if (dbg == 21) return;
+    ric_phase2_gemm<2>(cx, lds);
+    if (dbg == 22) return;
+    ric_factor_solve<9>(cx, lds, gains);
+  } else {
+    ric_phase1<3>(cx, lds);
+    if (dbg == 21) return;
+    ric_phase2_gemm<3>(cx, lds);
+    if (dbg == 22) return;
+    ric_factor_solve<NU_T>(cx, lds, gains);
+  }
 }
 // GEMM 3 in two halves: `ric_phase3_mma` accumulates T - [Q~ q~] = A~' [M1_A M1_b] + Hux' [K~ k~]; the caller then drops
 // [Q~ (22 x 22 row-major) | q~ (22)] at RicLds::Qs — it has no buffer of its own and goes over the A~ block, dead once
@@ -194,10 +212,8 @@ HB_HD void ric_stage(const Ctx& cx, double* lds, const double* rec) {
 }
 template <class Ctx>
 HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, const double* rec, double* gains, int dbg = 0) {
-  ric_phase1(cx, lds);
-  if (dbg == 21) return;  // profiling ablation markers (hb_config.reserved)
-  ric_phase2(cx, lds, gains, int(rec[REC_META]) + int(rec[REC_META + 1]), dbg);
-  if (dbg == 22 || dbg == 23) return;
+  ric_phase12(cx, lds, gains, int(rec[REC_META]) + int(rec[REC_META + 1]), dbg);
+  if (dbg == 21 || dbg == 22 || dbg == 23) return;  // profiling ablation markers (hb_config.reserved)
   RicT3 t;
   ric_phase3_mma(cx, lds, t);
   double* Qs = lds + RicLds::Qs;

@@ -214,6 +214,23 @@ template <class T> HB_HD Sym3<T> point_inertia(T m, Vec3<T> c) {
   r.xy = -(m * (c.x * c.y)); r.xz = -(m * (c.x * c.z)); r.yz = -(m * (c.y * c.z));
   return r;
 }
+// variants with CONSTANT (double) factors / summands: a dual number built from a constant carries a literal zero tangent
+// that IEEE arithmetic does not let the compiler fold away (x * 0.0 is not 0 for NaN / inf), so the products and sums
+// with constants are spelled with the mixed double / T operators instead
+template <class T> HB_HD Sym3<T> point_inertia_c(double m, Vec3<T> c) {
+  Sym3<T> r;
+  const T xx = c.x * c.x, yy = c.y * c.y, zz = c.z * c.z;
+  r.xx = m * (yy + zz); r.yy = m * (xx + zz); r.zz = m * (xx + yy);
+  r.xy = -(m * (c.x * c.y)); r.xz = -(m * (c.x * c.z)); r.yz = -(m * (c.y * c.z));
+  return r;
+}
+template <class T> HB_HD Vec3<T> scale_c(double s, Vec3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <class T> HB_HD Vec3<T> add_c(Vec3<T> a, Vec3<double> c) { return {a.x + c.x, a.y + c.y, a.z + c.z}; }
+template <class T> HB_HD Sym3<T> add_c(Sym3<T> a, const Sym3<double>& c) {
+  Sym3<T> r;
+  r.xx = a.xx + c.xx; r.xy = a.xy + c.xy; r.xz = a.xz + c.xz; r.yy = a.yy + c.yy; r.yz = a.yz + c.yz; r.zz = a.zz + c.zz;
+  return r;
+}
 // R I R^T for a constant body inertia I (6 doubles) and rotation R
 template <class T> HB_HD Sym3<T> rotate_inertia(const Mat3<T>& R, const double* I) {
   // columns of R scaled: M = R * I  (I symmetric constant)

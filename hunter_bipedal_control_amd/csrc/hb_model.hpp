@@ -432,17 +432,18 @@ template <class T>
 HB_HD void centroidal_core(const DevModel& M, Vec3<T> mc_legs, Sym3<T> IO_legs, Vec3<T> lj, Vec3<T> Lj_O, const T* zyx,
                            const T* hn, CentroidalCore<T>& out, const double* sc = nullptr /* (sin, cos) values of zyx, if known */) {
   const double mb = M.mass[0], mt = M.total_mass;
-  const Vec3<T> cb(T(M.com[0][0]), T(M.com[0][1]), T(M.com[0][2]));
-  Sym3<T> Ib;
-  Ib.xx = T(M.inertia[0][0]); Ib.xy = T(M.inertia[0][1]); Ib.xz = T(M.inertia[0][2]);
-  Ib.yy = T(M.inertia[0][3]); Ib.yz = T(M.inertia[0][4]); Ib.zz = T(M.inertia[0][5]);
-  const Vec3<T> mc = T(mb) * cb + mc_legs;
-  const Sym3<T> IO = Ib + point_inertia<T>(T(mb), cb) + IO_legs;
+  // base body: constants of the model (plain doubles, see point_inertia_c)
+  const Vec3<double> cb(M.com[0][0], M.com[0][1], M.com[0][2]);
+  Sym3<double> Ib;
+  Ib.xx = M.inertia[0][0]; Ib.xy = M.inertia[0][1]; Ib.xz = M.inertia[0][2];
+  Ib.yy = M.inertia[0][3]; Ib.yz = M.inertia[0][4]; Ib.zz = M.inertia[0][5];
+  const Vec3<T> mc = add_c(mc_legs, mb * cb);
+  const Sym3<T> IO = add_c(IO_legs, Ib + point_inertia<double>(mb, cb));
   const double inv_m = rcp_t(mt);
-  const Vec3<T> P = T(inv_m) * mc;  // COM in the base frame
+  const Vec3<T> P = scale_c(inv_m, mc);  // COM in the base frame
   Sym3<T> Icom = IO;
   {
-    const Sym3<T> sh = point_inertia<T>(T(mt), P);
+    const Sym3<T> sh = point_inertia_c<T>(mt, P);
     Icom.xx = Icom.xx - sh.xx; Icom.xy = Icom.xy - sh.xy; Icom.xz = Icom.xz - sh.xz;
     Icom.yy = Icom.yy - sh.yy; Icom.yz = Icom.yz - sh.yz; Icom.zz = Icom.zz - sh.zz;
   }
@@ -467,7 +468,7 @@ HB_HD void centroidal_core(const DevModel& M, Vec3<T> mc_legs, Sym3<T> IO_legs, 
   out.euler_rate = euler_rates_from_omega<T>(sz, cz, sy, cy, out.omega);
   out.com_rel = R * P;
   const Vec3<T> hlin(hn[0], hn[1], hn[2]);
-  out.v_lin = hlin - cross(out.omega, out.com_rel) - T(inv_m) * (R * lj);
+  out.v_lin = hlin - cross(out.omega, out.com_rel) - scale_c(inv_m, R * lj);
 }
 template <class T>
 HB_HD void centroidal_foot(const CentroidalCore<T>& c, Vec3<T> foot_b, Vec3<T> vj_b, Vec3<T>& foot_rel, Vec3<T>& foot_vel) {

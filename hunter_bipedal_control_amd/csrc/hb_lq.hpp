@@ -77,7 +77,7 @@ struct RelaxedBarrierD {
   HB_HD double d2(double h) const { const double r = rcp_t(h > delta ? h : delta); return mu * r * r; }
 };
 
-// LDS carve (doubles).  2522 doubles = 20 176 B per node -> 8 single-wave workgroups per CU (two per SIMD).
+// LDS carve (doubles).  At most 2560 doubles = 20 480 B per node -> 8 single-wave workgroups per CU (two per SIMD).
 //   fixed:     CDt [32][12] (constraint-row derivatives; the 12 contact-force directions are identically zero and are not
 //              stored: direction d < 22 -> row d, joint-rate direction 34 + k -> row 22 + k), xplus, rowval
 //   phase 1:   LJ (4 leg blocks) | J1 | J2 | small values             (LJ is dead once stage 2 is done)

@@ -594,15 +594,17 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   cx.sync();
   // unconstrained minimiser x = J J' g
   for (int k = cx.lane; k < NW; k += cx.nlanes) {
-    double s = 0.0;
-    for (int i = 0; i < NW; ++i) s += Jm[i * NW + k] * d[i];
-    z[k] = s;
+    double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NW; ++i) sa[i & 3] += Jm[i * NW + k] * d[i];
+    z[k] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
   }
   cx.sync();
   for (int i = cx.lane; i < NW; i += cx.nlanes) {
-    double s = 0.0;
-    for (int k = 0; k < NW; ++k) s += Jm[i * NW + k] * z[k];
-    x[i] = s;
+    double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NW; ++k) sa[k & 3] += Jm[i * NW + k] * z[k];
+    x[i] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
   }
   for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Rm[idx] = 0.0;
   for (int i = cx.lane; i < 64; i += cx.nlanes) is_active[i] = 0;
@@ -677,10 +679,13 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
     while (!done_p) {
       if (++iter > C.wbc_max_iter) { status = HB_INST_MAXITER; break; }
       // sp = n'x - rhs ; d = J' n
+      // (four interleaved partial sums per dot product: a single f64 FMA chain leaves most issue slots empty on a wave
+      // that has its SIMD to itself)
       for (int k = cx.lane; k < NW; k += cx.nlanes) {
-        double s = 0.0;
-        for (int i = 0; i < NW; ++i) s += Jm[i * NW + k] * np[i];
-        d[k] = s;
+        double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < NW; ++i) sa[i & 3] += Jm[i * NW + k] * np[i];
+        d[k] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
       }
       cx.sync();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -693,10 +698,13 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       }
 #endif
       // z = J2 d2 ; r = R^-1 d1 (column-oriented back substitution on a copy)
+      // (fixed trip count with a uniform mask instead of a loop from q: the compiler unrolls it and batches the LDS
+      // reads; the rolled loop paid one LDS round trip per term on a wave that has its SIMD to itself)
       for (int i = cx.lane; i < NW; i += cx.nlanes) {
-        double s = 0.0;
-        for (int j = q; j < NW; ++j) s += Jm[i * NW + j] * d[j];
-        z[i] = s;
+        double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < NW; ++j) sa[j & 3] += Jm[i * NW + j] * (j >= q ? d[j] : 0.0);
+        z[i] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
         if (i < q) r[i] = d[i];
       }
       cx.sync();
@@ -767,12 +775,19 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
           const double vtv = nrm2 - dq * dq + v0 * v0;
           if (vtv > 0.0 && nrm2 > 0.0) {
             const double beta = 2.0 * rcp_t(vtv);
+            // reflector vector hv = (0, ..., 0, v0, d[q+1], ..., d[NW-1]); each lane holds its row of J in registers:
+            // two fixed-length passes (unrolled, batched LDS traffic) instead of two rolled loops from q + 1
             for (int k = cx.lane; k < NW; k += cx.nlanes) {
-              double sacc = Jm[k * NW + q] * v0;
-              for (int j = q + 1; j < NW; ++j) sacc += Jm[k * NW + j] * d[j];
-              sacc *= beta;
-              Jm[k * NW + q] -= sacc * v0;
-              for (int j = q + 1; j < NW; ++j) Jm[k * NW + j] -= sacc * d[j];
+              double row[NW];
+              double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int j = 0; j < NW; ++j) {
+                row[j] = Jm[k * NW + j];
+                sa[j & 3] += row[j] * (j < q ? 0.0 : (j == q ? v0 : d[j]));
+              }
+              const double sacc = ((sa[0] + sa[1]) + (sa[2] + sa[3])) * beta;
+#pragma unroll
+              for (int j = 0; j < NW; ++j) Jm[k * NW + j] = row[j] - sacc * (j < q ? 0.0 : (j == q ? v0 : d[j]));
             }
           }
           cx.sync();

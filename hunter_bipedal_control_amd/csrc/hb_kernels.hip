@@ -116,13 +116,13 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
   const int n = b.n_nodes[inst];
   // Staging of a stage record through registers, 16-byte loads, every load of a lane issued before the first is
   // consumed.  The Riccati part of the record is the LDS image (hb_lq.hpp REC_* layout), so staging is two straight copies:
-  //   buf[r]    pair l + 64 r of doubles [0, REC_QT): rows of [A~ b~ . B~] -> RicLds::ABb, rows of [P~ r~ . R~] -> RicLds::PRr
+  //   buf[r]    pair l + 64 r of doubles [0, REC_QT): rows of [A~ b~ B~ .] -> RicLds::ABb, rows of [P~ r~ R~ .] -> RicLds::PRr
   //   bufq[r]   pair l + 64 r of [Q~ | q~] (253 pairs), dropped over the dead A~ block at the end of the stage (RicLds::Qs)
   // Slots beyond a block read a few doubles further inside the same record and are never stored.
   // Software pipeline (WaveCtx::sync does not drain global loads): [Q~ q~] of stage k and the staged part of stage k-1
   // are requested between the factorisation and the last GEMM of stage k — requested earlier they would be live across
   // the register-resident Cholesky, the register peak of the kernel.
-  constexpr int NL = 10, NQ = 4, NP_AB = REC_PR / 2, NP = REC_QT / 2;  // 396 pairs of [A~ b~ . B~], 612 pairs staged
+  constexpr int NL = 10, NQ = 4, NP_AB = REC_PR / 2, NP = REC_QT / 2;  // 396 pairs of [A~ b~ B~ .], 612 pairs staged
   static_assert(NP <= 64 * NL && 64 * NL * 2 + 2 * 64 * NQ <= REC_SIZE && REC_QT % 2 == 0 && REC_PR % 2 == 0, "record layout");
   typedef double d2 __attribute__((ext_vector_type(2)));  // (HIP's double2 struct kept the buffers in scratch memory)
   d2 buf[NL], bufq[NQ];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
       d2* st = reinterpret_cast<d2*>(lds + RicLds::ABb) + l;
 #pragma unroll
       for (int r = 0; r < NL; ++r) {
-        const int p = l + 64 * r;  // rows of [P~ r~ . R~] start 2 x 36 doubles further (K-padding rows of the A~ block)
+        const int p = l + 64 * r;  // rows of [P~ r~ R~ .] start 2 x 36 doubles further (K-padding rows of the A~ block)
         const int shift = (RicLds::PRr - RicLds::ABb - REC_PR) / 2;
         if (64 * r + 63 < NP_AB) st[64 * r] = buf[r];
         else if (64 * r >= NP_AB) { if (p < NP) st[64 * r + shift] = buf[r]; }
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
   for (int i = cx.lane; i < FwdLds::small; i += cx.nlanes) lds[i] = 0.0;  // dx0 = 0: x[0] is the measured state
   cx.sync();
   const int n = b.n_nodes[inst];
-  // What a step reads — the [A~ b~ . B~] rows and the recovery part of the stage record, the gains — is staged into LDS
+  // What a step reads — the [A~ b~ B~ .] rows and the recovery part of the stage record, the gains — is staged into LDS
   // with coalesced 16-byte loads, one stage ahead (WaveCtx::sync does not drain the loads in flight): the matrix-vector
   // products then run out of LDS instead of waiting for scattered global loads on the dx -> dx+ dependency chain.
   constexpr int P_AB = REC_PR / 2, P_RX = (REC_META + 6 - REC_KX) / 2, P_G = GAIN_SIZE / 2;  // 396, 176, 144 pairs

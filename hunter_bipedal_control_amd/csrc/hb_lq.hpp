@@ -45,8 +45,8 @@ struct DevConfig {
 // column is never written (the allocation is zeroed once) and only ever feeds discarded outputs of the tile GEMMs.
 constexpr int NU_T = 12;                 // projected input width (padded)
 constexpr int REC_LD = 36, REC_CV = 22, REC_CU = 23;
-constexpr int REC_AB = 0;                // 22 rows: [A~ | b~ | . | B~]
-constexpr int REC_PR = 792;              // 12 rows: [P~ | r~ | . | R~]
+constexpr int REC_AB = 0;                // 22 rows: [A~ | b~ | B~ | .]
+constexpr int REC_PR = 792;              // 12 rows: [P~ | r~ | R~ | .]
 constexpr int REC_QT = 1224;             // 22x22
 constexpr int REC_qT = 1708;             // 22
 constexpr int REC_RICCATI_END = 1730;

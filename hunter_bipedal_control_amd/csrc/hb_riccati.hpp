@@ -17,14 +17,14 @@ namespace hb {
 // ABb and M1 carry two extra all-zero rows (K = 22 -> 24).  Buffers with disjoint lifetimes share storage (the
 // workgroup is one wave: its LDS accesses complete in program order):
 //   X   S | s (node start .. GEMM 1)  ->  M1 (GEMM 1 .. GEMM 3)  ->  T = new S | s (written by GEMM 3, symmetrised in place)
-//   PH  [P~ r~ . R~] (staged .. accumulator init of GEMM 2)  ->  Hu
+//   PH  [P~ r~ R~ .] (staged .. accumulator init of GEMM 2)  ->  Hu
 // [Q~ q~] has no buffer of its own: it is dropped over the dead A~ block once GEMM 3 has read its operands.
 struct RicLds {
   static constexpr int LDN = 24, LDW = 36, CV = 22, CU = 23;
   static constexpr int X = 0;                    // 24 x 36
   static constexpr int S = X;                    // 22 x 24
   static constexpr int s = S + 22 * LDN;         // 24
-  static constexpr int M1 = X;                   // 24 x 36 : S [A~ b~ . B~] (+ s on the vector column); rows 22, 23 stay zero
+  static constexpr int M1 = X;                   // 24 x 36 : S [A~ b~ B~ .] (+ s on the vector column); rows 22, 23 stay zero
   static constexpr int ABb = X + 24 * LDW;       // 24 x 36
   static constexpr int PRr = ABb + 24 * LDW;     // 12 x 36
   static constexpr int Hu = PRr;                 // 12 x 36 : [Hux | hu | . | Huu]
@@ -229,7 +229,7 @@ struct FwdLds {
   static constexpr int acc = 84;      // 4: armijo (filled by riccati_fwd_finish), merit, dyn, eq
   static constexpr int accp = 88;     // 22 (+2): per-entry partial sums of the Armijo directional derivative
   static constexpr int small = 112;
-  // staged copy of what one forward step reads (device kernel): [A~ b~ . B~] rows | recovery data | gains
+  // staged copy of what one forward step reads (device kernel): [A~ b~ B~ .] rows | recovery data | gains
   static constexpr int AB = small;                 // REC_PR doubles (22 rows of 36)
   static constexpr int RX = AB + REC_PR;           // record elements [REC_KX, REC_META + 6)
   static constexpr int G = RX + (REC_META + 6 - REC_KX);
@@ -237,7 +237,7 @@ struct FwdLds {
 };
 static_assert((REC_META + 6 - REC_KX) % 2 == 0 && REC_KX % 2 == 0 && FwdLds::AB % 2 == 0, "16-byte staging");
 
-// One forward step.  `ab` = rows [A~ b~ . B~] of the stage record (stride REC_LD), `rx` = its recovery part (element
+// One forward step.  `ab` = rows [A~ b~ B~ .] of the stage record (stride REC_LD), `rx` = its recovery part (element
 // REC_KX onwards), `gains` = [K~ | k~]: pointers into global memory (host emulation) or into the staged LDS copy (kernel).
 // Advances dx in LDS and writes the full state/input step of this node.
 template <class Ctx>

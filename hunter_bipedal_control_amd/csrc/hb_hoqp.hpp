@@ -55,7 +55,7 @@ HB_HD int householder_qr_pivot(const Ctx& cx, double* T, int n, int m, int ldt, 
     for (int i = cx.lane; i < n; i += cx.nlanes) v[i] = (i < j) ? 0.0 : (i == j ? x0 - alpha : T[i * ldt + j]);
     cx.sync();
     const double vtv = best - x0 * x0 + (x0 - alpha) * (x0 - alpha);
-    const double beta = 2.0 / vtv;
+    const double beta = 2.0 * rcp_t(vtv);
     for (int c = j + cx.lane; c < m; c += cx.nlanes) {
       double s = 0.0;
       for (int i = j; i < n; ++i) s += v[i] * T[i * ldt + c];
@@ -104,7 +104,7 @@ HB_HD int small_lsqp(int n, int mA, const double* A, const double* b, double eps
     for (int k = 0; k < n; ++k) {
       const double a = R[k * LD + k], bb = np[k];
       if (bb == 0.0) continue;
-      const double h = sqrt(a * a + bb * bb), cc = a / h, ss = bb / h;
+      const double rh = rsqrt_t(a * a + bb * bb), cc = a * rh, ss = bb * rh;
       for (int j = k; j < n; ++j) {
         const double t1 = R[k * LD + j], t2 = np[j];
         R[k * LD + j] = cc * t1 + ss * t2;
@@ -117,7 +117,7 @@ HB_HD int small_lsqp(int n, int mA, const double* A, const double* b, double eps
     for (int i = col; i >= 0; --i) {
       double s = (i == col) ? 1.0 : 0.0;
       for (int k = i + 1; k <= col; ++k) s -= R[i * LD + k] * J[k * LD + col];
-      J[i * LD + col] = s / R[i * LD + i];
+      J[i * LD + col] = s * rcp_t(R[i * LD + i]);
     }
   }
   for (int k = 0; k < n; ++k) {
@@ -162,12 +162,12 @@ HB_HD int small_lsqp(int n, int mA, const double* A, const double* b, double eps
       for (int i = q - 1; i >= 0; --i) {
         double s = d[i];
         for (int k = i + 1; k < q; ++k) s -= R[i * LD + k] * r[k];
-        r[i] = s / R[i * LD + i];
+        r[i] = s * rcp_t(R[i * LD + i]);
       }
       double zn = 0.0, nn2 = 0.0;
       sp = -f[p];
       for (int i = 0; i < n; ++i) { zn += z[i] * np[i]; nn2 += np[i] * np[i]; sp += np[i] * x[i]; }
-      const double t2 = (zn > 1e-14 * (1.0 + nn2)) ? sp / zn : inf;
+      const double t2 = (zn > 1e-14 * (1.0 + nn2)) ? sp * rcp_t(zn) : inf;
       double t1 = inf;
       int l = -1;
       for (int j = 0; j < q; ++j)
@@ -185,7 +185,7 @@ HB_HD int small_lsqp(int n, int mA, const double* A, const double* b, double eps
         for (int j = n - 1; j > q; --j) {
           const double a = d[j - 1], bb = d[j];
           if (bb == 0.0) continue;
-          const double h = sqrt(a * a + bb * bb), cc = a / h, ss = bb / h;
+          const double h2 = a * a + bb * bb, rh = rsqrt_t(h2), cc = a * rh, ss = bb * rh, h = h2 * rh;
           d[j - 1] = h;
           d[j] = 0.0;
           for (int k = 0; k < n; ++k) {
@@ -215,7 +215,7 @@ HB_HD int small_lsqp(int n, int mA, const double* A, const double* b, double eps
       for (int j = l; j < q; ++j) {
         const double a = R[j * LD + j], bb = R[(j + 1) * LD + j];
         if (bb == 0.0) continue;
-        const double h = sqrt(a * a + bb * bb), cc = a / h, ss = bb / h;
+        const double rh = rsqrt_t(a * a + bb * bb), cc = a * rh, ss = bb * rh;
         for (int k = j; k < q; ++k) {
           const double t1j = R[j * LD + k], t2j = R[(j + 1) * LD + k];
           R[j * LD + k] = cc * t1j + ss * t2j;
@@ -360,7 +360,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
         const double a = Rm[k * NW + k], b = np[k];
         cx.sync();
         if (b != 0.0) {
-          const double h = sqrt(a * a + b * b), cc = a / h, ss = b / h;
+          const double rh2 = rsqrt_t(a * a + b * b), cc = a * rh2, ss = b * rh2;
           for (int j = k + cx.lane; j < NW; j += cx.nlanes) {
             const double t1 = Rm[k * NW + j], t2 = np[j];
             Rm[k * NW + j] = cc * t1 + ss * t2;
@@ -375,7 +375,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
       for (int i = col; i >= 0; --i) {
         double s = (i == col) ? 1.0 : 0.0;
         for (int k = i + 1; k <= col; ++k) s -= Rm[i * NW + k] * Jm[k * NW + col];
-        Jm[i * NW + col] = s / Rm[i * NW + i];
+        Jm[i * NW + col] = s * rcp_t(Rm[i * NW + i]);
       }
     }
     cx.sync();

@@ -55,9 +55,10 @@ def test_rbd(params, oracle, solver_small):
     assert np.abs(dJv - do).max() < 1e-10
 
 
-def test_riccati(params, oracle, solver_small):
-    rng = np.random.default_rng(2)
-    n, N, nu = 3, 30, 9
+@pytest.mark.parametrize("nu", [9, 12, 6])  # 9: two-tile GEMMs + 9-wide factor; 12: three tiles + 12-wide; 6: padded
+def test_riccati(params, oracle, solver_small, nu):
+    rng = np.random.default_rng(2 + nu)
+    n, N = 3, 30
     A = np.eye(22) + 0.05 * rng.standard_normal((n, N, 22, 22))
     B = 0.1 * rng.standard_normal((n, N, 22, nu))
     b = 0.01 * rng.standard_normal((n, N, 22))

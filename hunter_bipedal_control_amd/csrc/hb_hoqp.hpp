@@ -76,10 +76,15 @@ HB_HD int householder_qr_pivot(const Ctx& cx, double* T, int n, int m, int ldt, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Serial (one lane) least-squares QP  min 1/2|A x - b|^2 + eps/2|x|^2  s.t. D x <= f,  n <= 12, by Goldfarb–Idnani.
-// A: mA x n (ld 12), D: mD x n (ld 12).  Workspace ws >= 2*144 + 12*6 + 40 doubles.  Returns 0 / 1 (iteration limit) / 2.
-HB_HD int small_lsqp(int n, int mA, const double* A, const double* b, double eps, int mD, const double* D, const double* f,
-                     int max_iter, double* x, double* ws) {
+// Lane-cooperative least-squares QP  min 1/2|A x - b|^2 + eps/2|x|^2  s.t. D x <= f,  n <= 12, by Goldfarb–Idnani
+// (the per-level QP of the cascade; it used to run serially on one lane and made up two thirds of k_hwbc).
+// A: mA x n (ld 12), D: mD x n (ld 12), mD <= 40.  Workspace ws >= 440 doubles (LDS).  Every lane returns the same code:
+// 0 solved / 1 iteration limit / 2 infeasible.  All control flow is decided on values every lane reads from LDS or on
+// wave reductions, so it is uniform; one constraint per lane in the violation scan, one row / column per lane in the
+// factor updates.
+template <class Ctx>
+HB_HD int small_lsqp(const Ctx& cx, int n, int mA, const double* A, const double* b, double eps, int mD, const double* D,
+                     const double* f, int max_iter, double* x, double* ws) {
   constexpr int LD = 12;
   double* J = ws;            // n x n
   double* R = ws + 144;      // n x n upper
@@ -91,28 +96,33 @@ HB_HD int small_lsqp(int n, int mA, const double* A, const double* b, double eps
   double* g = np + 12;
   int* act = reinterpret_cast<int*>(g + 12);  // 12 ints
   int* is_act = act + 12;                     // mD <= 40 ints
+  double* viol = g + 12 + 26;                 // 40: violation of the inactive constraints (host reduction only)
   // R~ by Givens row insertion into sqrt(eps) I (stored in R), then J = R~^-1
   const double se = sqrt(eps);
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) R[i * LD + j] = (i == j) ? se : 0.0;
-  for (int i = 0; i < n; ++i) g[i] = 0.0;
+  for (int idx = cx.lane; idx < n * LD; idx += cx.nlanes) R[idx] = (idx / LD == idx % LD) ? se : 0.0;
+  for (int i = cx.lane; i < n; i += cx.nlanes) g[i] = 0.0;
+  cx.sync();
   for (int rw = 0; rw < mA; ++rw) {
-    for (int j = 0; j < n; ++j) {
+    for (int j = cx.lane; j < n; j += cx.nlanes) {
       np[j] = A[rw * LD + j];
       g[j] += A[rw * LD + j] * b[rw];
     }
+    cx.sync();
     for (int k = 0; k < n; ++k) {
       const double a = R[k * LD + k], bb = np[k];
-      if (bb == 0.0) continue;
-      const double rh = rsqrt_t(a * a + bb * bb), cc = a * rh, ss = bb * rh;
-      for (int j = k; j < n; ++j) {
-        const double t1 = R[k * LD + j], t2 = np[j];
-        R[k * LD + j] = cc * t1 + ss * t2;
-        np[j] = -ss * t1 + cc * t2;
+      cx.sync();
+      if (bb != 0.0) {
+        const double rh = rsqrt_t(a * a + bb * bb), cc = a * rh, ss = bb * rh;
+        for (int j = k + cx.lane; j < n; j += cx.nlanes) {
+          const double t1 = R[k * LD + j], t2 = np[j];
+          R[k * LD + j] = cc * t1 + ss * t2;
+          np[j] = -ss * t1 + cc * t2;
+        }
       }
+      cx.sync();
     }
   }
-  for (int col = 0; col < n; ++col) {
+  for (int col = cx.lane; col < n; col += cx.nlanes) {
     for (int i = n - 1; i > col; --i) J[i * LD + col] = 0.0;
     for (int i = col; i >= 0; --i) {
       double s = (i == col) ? 1.0 : 0.0;
@@ -120,50 +130,74 @@ HB_HD int small_lsqp(int n, int mA, const double* A, const double* b, double eps
       J[i * LD + col] = s * rcp_t(R[i * LD + i]);
     }
   }
-  for (int k = 0; k < n; ++k) {
+  cx.sync();
+  for (int k = cx.lane; k < n; k += cx.nlanes) {
     double s = 0.0;
     for (int i = 0; i < n; ++i) s += J[i * LD + k] * g[i];
     z[k] = s;
   }
-  for (int i = 0; i < n; ++i) {
+  cx.sync();
+  for (int i = cx.lane; i < n; i += cx.nlanes) {
     double s = 0.0;
     for (int k = 0; k < n; ++k) s += J[i * LD + k] * z[k];
     x[i] = s;
   }
-  for (int i = 0; i < n * LD; ++i) R[i] = 0.0;
-  for (int c = 0; c < mD; ++c) is_act[c] = 0;
+  for (int idx = cx.lane; idx < n * LD; idx += cx.nlanes) R[idx] = 0.0;
+  for (int c = cx.lane; c < mD; c += cx.nlanes) is_act[c] = 0;
+  cx.sync();
   int q = 0, iter = 0;
   const double inf = 1e300;
   while (true) {
+    // most violated inactive constraint, one constraint per lane
     int p = -1;
     double sp = 0.0;
-    for (int c = 0; c < mD; ++c) {
-      if (is_act[c]) continue;
-      double s = -f[c], nn = 0.0;
-      for (int j = 0; j < n; ++j) { s += D[c * LD + j] * x[j]; nn += D[c * LD + j] * D[c * LD + j]; }
-      if (nn == 0.0) continue;
-      if (s > 1e-9 * fmax(1.0, fabs(f[c])) && (p < 0 || s > sp)) { p = c; sp = s; }
+    {
+      double mine = -1.0;
+      for (int c = cx.lane; c < mD; c += cx.nlanes) {
+        double v = -1.0;
+        if (!is_act[c]) {
+          double s = -f[c], nn = 0.0;
+          for (int j = 0; j < n; ++j) { s += D[c * LD + j] * x[j]; nn += D[c * LD + j] * D[c * LD + j]; }
+          if (nn != 0.0 && s > 1e-9 * fmax(1.0, fabs(f[c]))) v = s;
+        }
+        viol[c] = v;
+        mine = v;  // (device: mD <= 40 <= lanes, one pass)
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+      const double gb = wave_max_f64(mine);
+      if (gb > 0.0) p = __ffsll(__ballot(mine == gb)) - 1;  // lowest index on ties, like the serial scan
+      (void)viol;
+#else
+      (void)mine;
+      cx.sync();
+      for (int c = 0; c < mD; ++c)
+        if (viol[c] > 0.0 && (p < 0 || viol[c] > sp)) { p = c; sp = viol[c]; }
+#endif
     }
     if (p < 0) return 0;
-    for (int j = 0; j < n; ++j) np[j] = D[p * LD + j];
+    for (int j = cx.lane; j < n; j += cx.nlanes) np[j] = D[p * LD + j];
+    cx.sync();
     double lam_p = 0.0;
     while (true) {
       if (++iter > max_iter) return 1;
-      for (int k = 0; k < n; ++k) {
+      for (int k = cx.lane; k < n; k += cx.nlanes) {
         double s = 0.0;
         for (int i = 0; i < n; ++i) s += J[i * LD + k] * np[i];
         d[k] = s;
       }
-      for (int i = 0; i < n; ++i) {
+      cx.sync();
+      for (int i = cx.lane; i < n; i += cx.nlanes) {
         double s = 0.0;
         for (int j = q; j < n; ++j) s += J[i * LD + j] * d[j];
         z[i] = s;
       }
-      for (int i = q - 1; i >= 0; --i) {
-        double s = d[i];
-        for (int k = i + 1; k < q; ++k) s -= R[i * LD + k] * r[k];
-        r[i] = s * rcp_t(R[i * LD + i]);
-      }
+      if (cx.lane == 0)
+        for (int i = q - 1; i >= 0; --i) {
+          double s = d[i];
+          for (int k = i + 1; k < q; ++k) s -= R[i * LD + k] * r[k];
+          r[i] = s * rcp_t(R[i * LD + i]);
+        }
+      cx.sync();
       double zn = 0.0, nn2 = 0.0;
       sp = -f[p];
       for (int i = 0; i < n; ++i) { zn += z[i] * np[i]; nn2 += np[i] * np[i]; sp += np[i] * x[i]; }
@@ -177,56 +211,67 @@ HB_HD int small_lsqp(int n, int mA, const double* A, const double* b, double eps
         }
       const double t = fmin(t1, t2);
       if (t >= inf) return 2;
+      cx.sync();
       if (t2 < inf)
-        for (int k = 0; k < n; ++k) x[k] -= t * z[k];
-      for (int j = 0; j < q; ++j) lam[j] -= t * r[j];
+        for (int k = cx.lane; k < n; k += cx.nlanes) x[k] -= t * z[k];
+      for (int j = cx.lane; j < q; j += cx.nlanes) lam[j] -= t * r[j];
       lam_p += t;
+      cx.sync();
       if (t2 < inf && t == t2) {
+        // full step: rotate d[q+1..] into d[q] from the bottom, the same rotations on the columns of J (one row per lane)
         for (int j = n - 1; j > q; --j) {
           const double a = d[j - 1], bb = d[j];
-          if (bb == 0.0) continue;
-          const double h2 = a * a + bb * bb, rh = rsqrt_t(h2), cc = a * rh, ss = bb * rh, h = h2 * rh;
-          d[j - 1] = h;
-          d[j] = 0.0;
-          for (int k = 0; k < n; ++k) {
-            const double t1j = J[k * LD + j - 1], t2j = J[k * LD + j];
-            J[k * LD + j - 1] = cc * t1j + ss * t2j;
-            J[k * LD + j] = -ss * t1j + cc * t2j;
+          cx.sync();
+          if (bb != 0.0) {
+            const double h2 = a * a + bb * bb, rh = rsqrt_t(h2), cc = a * rh, ss = bb * rh;
+            if (cx.lane == 0) { d[j - 1] = h2 * rh; d[j] = 0.0; }
+            for (int k = cx.lane; k < n; k += cx.nlanes) {
+              const double t1j = J[k * LD + j - 1], t2j = J[k * LD + j];
+              J[k * LD + j - 1] = cc * t1j + ss * t2j;
+              J[k * LD + j] = -ss * t1j + cc * t2j;
+            }
           }
+          cx.sync();
         }
         if (q < n && fabs(d[q]) > 1e-13 * fmax(1.0, fabs(R[0]))) {
-          for (int i = 0; i <= q; ++i) R[i * LD + q] = d[i];
-          act[q] = p;
-          lam[q] = lam_p;
-          is_act[p] = 1;
+          cx.sync();
+          for (int i = cx.lane; i <= q; i += cx.nlanes) R[i * LD + q] = d[i];
+          if (cx.lane == 0) { act[q] = p; lam[q] = lam_p; is_act[p] = 1; }
           ++q;
         }
+        cx.sync();
         break;
       }
       // partial / dual-only step: drop active constraint l
-      is_act[act[l]] = 0;
+      if (cx.lane == 0) is_act[act[l]] = 0;
+      cx.sync();
       for (int j = l; j < q - 1; ++j) {
-        for (int i = 0; i <= j + 1; ++i) R[i * LD + j] = R[i * LD + j + 1];
-        act[j] = act[j + 1];
-        lam[j] = lam[j + 1];
+        for (int i = cx.lane; i <= j + 1; i += cx.nlanes) R[i * LD + j] = R[i * LD + j + 1];
+        if (cx.lane == 0) { act[j] = act[j + 1]; lam[j] = lam[j + 1]; }
+        cx.sync();
       }
-      for (int i = 0; i < q; ++i) R[i * LD + q - 1] = 0.0;
+      for (int i = cx.lane; i < q; i += cx.nlanes) R[i * LD + q - 1] = 0.0;
       --q;
+      cx.sync();
       for (int j = l; j < q; ++j) {
         const double a = R[j * LD + j], bb = R[(j + 1) * LD + j];
-        if (bb == 0.0) continue;
-        const double rh = rsqrt_t(a * a + bb * bb), cc = a * rh, ss = bb * rh;
-        for (int k = j; k < q; ++k) {
-          const double t1j = R[j * LD + k], t2j = R[(j + 1) * LD + k];
-          R[j * LD + k] = cc * t1j + ss * t2j;
-          R[(j + 1) * LD + k] = -ss * t1j + cc * t2j;
+        cx.sync();
+        if (bb != 0.0) {
+          const double rh = rsqrt_t(a * a + bb * bb), cc = a * rh, ss = bb * rh;
+          for (int k = cx.lane; k < n; k += cx.nlanes) {
+            if (k >= j && k < q) {
+              const double t1j = R[j * LD + k], t2j = R[(j + 1) * LD + k];
+              R[j * LD + k] = cc * t1j + ss * t2j;
+              R[(j + 1) * LD + k] = -ss * t1j + cc * t2j;
+            }
+            const double u1 = J[k * LD + j], u2 = J[k * LD + j + 1];
+            J[k * LD + j] = cc * u1 + ss * u2;
+            J[k * LD + j + 1] = -ss * u1 + cc * u2;
+          }
         }
-        R[(j + 1) * LD + j] = 0.0;
-        for (int k = 0; k < n; ++k) {
-          const double u1 = J[k * LD + j], u2 = J[k * LD + j + 1];
-          J[k * LD + j] = cc * u1 + ss * u2;
-          J[k * LD + j + 1] = -ss * u1 + cc * u2;
-        }
+        cx.sync();
+        if (cx.lane == 0) R[(j + 1) * LD + j] = 0.0;
+        cx.sync();
       }
     }
   }
@@ -256,8 +301,8 @@ struct HoLds {
   static constexpr int DZ = rhs + 24;             // 40x12
   static constexpr int ft = DZ + 480;             // 40
   static constexpr int zs = ft + 40;              // 12 small solution
-  static constexpr int qpw = zs + 12;             // small QP workspace 2*144 + 72 + 40
-  static constexpr int work = qpw + 400;          // 80 (householder)
+  static constexpr int qpw = zs + 12;             // small QP workspace 2*144 + 72 + 26 + 40
+  static constexpr int work = qpw + 440;          // 80 (householder)
   static constexpr int ints = work + 80;          // 64 ints: violated flags (40), misc
   static constexpr int total = ints + 32;
 };
@@ -449,11 +494,11 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
     if (j == 0) ft[c] = rh - dx + v0[c];
   }
   cx.sync();
-  if (cx.lane == 0) {
-    imisc[1] = small_lsqp(n1, 6, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw);
+  {
+    const int rc1 = small_lsqp(cx, n1, 6, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw);
+    cx.sync();
+    if (rc1 > status) status = rc1;
   }
-  cx.sync();
-  if (imisc[1] > status) status = imisc[1];
   for (int i = cx.lane; i < NW; i += cx.nlanes) {
     double s = x[i];
     for (int j = 0; j < n1; ++j) s += Z1[i * 12 + j] * zs[j];
@@ -505,9 +550,9 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
       if (j == 0) ft[c] = rh - dx + v0[c];
     }
     cx.sync();
-    if (cx.lane == 0) imisc[1] = small_lsqp(n2, m2, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw);
+    const int rc2 = small_lsqp(cx, n2, m2, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw);
     cx.sync();
-    if (imisc[1] > status) status = imisc[1];
+    if (rc2 > status) status = rc2;
     for (int i = cx.lane; i < NW; i += cx.nlanes) {
       double s = x[i];
       for (int j = 0; j < n2; ++j) s += Z2[i * 12 + j] * zs[j];
@@ -525,8 +570,9 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
 __global__ __launch_bounds__(64) void k_hwbc(WbcBatch w, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
   const int inst = blockIdx.x;
   extern __shared__ __attribute__((aligned(16))) double lds_h[];
+  // hb_config.reserved = 41 / 42 stops the cascade after level 0 / 1 (profiling ablation only)
   hwbc_solve(WbcDeviceCtx(), *M, *C, w.xdes + size_t(inst) * HB_NX, w.udes + size_t(inst) * HB_NU, w.rbd + size_t(inst) * HB_NRBD,
-             w.mode[inst], lds_h, w.sol + size_t(inst) * NW, w.status + inst);
+             w.mode[inst], lds_h, w.sol + size_t(inst) * NW, w.status + inst, C->debug_stop == 41 ? 1 : (C->debug_stop == 42 ? 2 : 3));
   if (threadIdx.x == 0) w.iters[inst] = 0;
 }
 #endif

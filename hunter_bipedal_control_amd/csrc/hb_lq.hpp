@@ -779,7 +779,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     WaveTile<1, 1> tb;
     tile_init(cx, tb, 12, 6, [](int, int) { return 0.0; });
     tile_mma<12, 12, true, 6, false, 10>(cx, tb, ABt + 34 * 12, Z, 12, 6);
-    tile_store(cx, tb, 12, 6, [rec, n_f, nz](int row, int b, double v) { if (b < nz) rec[rec_B(row, n_f + b)] = v; });
+    tile_store_rm<REC_LD>(cx, tb, 12, nz, rec + rec_B(0, n_f));
   }
   // joint rows of A~ and the recovery copy of Kx: one row per (uniform) step, one column per lane
   for (int c = cx.lane; c < 22; c += cx.nlanes) {
@@ -841,7 +841,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       rec[REC_QT + a * 22 + b] = dt * v;
       if (b >= 16) rec[REC_QT + b * 22 + a] = dt * v;
     });
-    tile_store(cx, t1, 6, 6, [rec, dt](int a, int b, double v) { rec[REC_QT + (16 + a) * 22 + 16 + b] = dt * v; });
+    tile_store_rm<22>(cx, t1, 6, 6, rec + REC_QT + 16 * 22 + 16, dt);
   }
   if (C.debug_stop == 32) return;
   // q~ = q + Kx' r_j + M' ke
@@ -857,7 +857,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     WaveTile<1, 2> tp;
     tile_init(cx, tp, 6, 22, [](int, int) { return 0.0; });
     tile_mma<12, 6, true, 22, false, 10>(cx, tp, Z, Mm, 6, 22);
-    tile_store(cx, tp, 6, 22, [rec, n_f, nz, dt](int b, int c, double v) { if (b < nz) rec[rec_P(n_f + b, c)] = dt * v; });
+    tile_store_rm<REC_LD>(cx, tp, nz, 22, rec + rec_P(n_f, 0), dt);
   }
   for (int c = cx.lane; c < 22; c += cx.nlanes) {
 #pragma unroll

@@ -117,4 +117,28 @@ HB_HD void tile_store(const Ctx& cx, const WaveTile<MT, NT>& t, int Mr, int Nr, 
 #endif
 }
 
+// Store into a plain row-major destination dst[row * LD + col] (times `scale`): the address of every element is one
+// per-lane base plus a compile-time offset, so the store carries an immediate instead of rebuilding a 64-bit address
+// per element as the generic lambda form does.
+template <int LD, int MT, int NT, class Ctx>
+HB_HD void tile_store_rm(const Ctx& cx, const WaveTile<MT, NT>& t, int Mr, int Nr, double* dst, double scale = 1.0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+  double* p0 = dst + lk * LD + li;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tm + lk + 4 * r, col = 16 * tn + li;
+        if (row < Mr && col < Nr) p0[(16 * tm + 4 * r) * LD + 16 * tn] = scale * t.acc[tm][tn][r];
+      }
+#else
+  (void)cx;
+  for (int i = 0; i < Mr; ++i)
+    for (int j = 0; j < Nr; ++j) dst[i * LD + j] = scale * t.c[i][j];
+#endif
+}
+
 }  // namespace hb

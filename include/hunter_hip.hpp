@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "hunter_hip.h"
+#include "hunter_lcm.h"
 
 namespace hunter_hip {
 
@@ -358,6 +359,45 @@ class KalmanFilterEstimate {
  private:
   Context ctx_;
   vector_t rbdState_, observationState_;
+};
+
+// ---- LCM bridge: legged::LeggedMujocoSim::read / write (legged_examples/legged_mujoco/src/LeggedMujocoSim.cpp:28-62) ----
+// read():  the LOWSTATE payloads of the batch (336 bytes each, as received from LCM) -> estimator -> rbdState;
+// write(): joint command law on the WBC result still on the device -> LOWCMD payloads (496 bytes each) to publish.
+// Packing / unpacking runs on the device (include/hunter_lcm.h); liblcm itself is only needed for the transport.
+class LcmBridge {
+ public:
+  LcmBridge(Context ctx, const hb_estimator_config& settings, const hb_joint_gains& gains, const vector_t* xHat0 = nullptr)
+      : ctx_(std::move(ctx)), gains_(gains) {
+    ctx_.check(hb_estimator_reset(ctx_.get(), &settings, xHat0 ? xHat0->data() : nullptr), "hb_estimator_reset");
+  }
+  const vector_t& read(scalar_t period, const std::vector<uint8_t>& lowState, const std::vector<int32_t>& contactFlag,
+                       bool toResident = false) {
+    const size_t B = size_t(ctx_.batch());
+    if (lowState.size() != B * HB_LCM_LOW_STATE_BYTES || contactFlag.size() != B * HB_NC)
+      throw std::invalid_argument("[hunter_hip] LcmBridge::read: wrong buffer size");
+    rbdState_.resize(B * HB_NRBD);
+    observationState_.resize(B * HB_NX);
+    stamps_.resize(B);
+    ctx_.check(hb_estimator_update_lcm(ctx_.get(), period, lowState.data(), contactFlag.data(), toResident ? 1 : 0, rbdState_.data(),
+                                       observationState_.data(), stamps_.data()),
+               "hb_estimator_update_lcm");
+    return rbdState_;
+  }
+  const std::vector<uint8_t>& write(scalar_t period, int64_t timestampNs) {
+    lowCmd_.resize(size_t(ctx_.batch()) * HB_LCM_LOW_CMD_BYTES);
+    ctx_.check(hb_joint_command_lcm(ctx_.get(), &gains_, period, timestampNs, lowCmd_.data()), "hb_joint_command_lcm");
+    return lowCmd_;
+  }
+  const vector_t& observationState() const { return observationState_; }
+  const std::vector<int64_t>& timestamps() const { return stamps_; }
+
+ private:
+  Context ctx_;
+  hb_joint_gains gains_;
+  vector_t rbdState_, observationState_;
+  std::vector<int64_t> stamps_;
+  std::vector<uint8_t> lowCmd_;
 };
 
 // ---- the hot part of LeggedController::update (LeggedController.cpp:151-185) --------------------------------------

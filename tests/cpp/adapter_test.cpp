@@ -38,6 +38,37 @@ int main(int argc, char** argv) {
     std::printf("a context was created: a GPU is visible\n");
     return 4;
   }
+  if (what == "lcm" && argc >= 4) {
+    // adapter_test <params.bin> lcm <vectors.bin>: host codec of include/hunter_lcm.h against byte vectors produced by
+    // the reference's generated message classes (written by tests/test_cpp_adapter.py from tests/golden/ref_lcm.json):
+    // per message int32 type, int32 n_fields, int32 n_bytes, int64 timestamp, fields[n_fields], bytes[n_bytes].  No GPU.
+    std::FILE* f = std::fopen(argv[3], "rb");
+    if (!f) return 2;
+    int32_t head[3];
+    int n_ok = 0;
+    while (std::fread(head, sizeof(int32_t), 3, f) == 3) {
+      int64_t ts;
+      if (std::fread(&ts, sizeof ts, 1, f) != 1) return 2;
+      vector_t fields;
+      std::vector<uint8_t> bytes;
+      readv(f, fields, size_t(head[1]));
+      readv(f, bytes, size_t(head[2]));
+      if (hb_lcm_encoded_size(head[0]) != head[2] || hb_lcm_field_count(head[0]) != head[1]) return 5;
+      std::vector<uint8_t> out(bytes.size());
+      if (hb_lcm_encode(head[0], 1, &ts, fields.data(), out.data()) != HB_OK || out != bytes) return 6;
+      int64_t ts2 = 0;
+      vector_t f2(fields.size());
+      if (hb_lcm_decode(head[0], 1, bytes.data(), &ts2, f2.data()) != HB_OK || ts2 != ts ||
+          std::memcmp(f2.data(), fields.data(), fields.size() * sizeof(double)) != 0)
+        return 7;
+      bytes[2] ^= 0x10;  // foreign fingerprint
+      if (hb_lcm_decode(head[0], 1, bytes.data(), &ts2, f2.data()) != HB_ERR_ARG) return 8;
+      ++n_ok;
+    }
+    std::fclose(f);
+    std::printf("ok: %d lcm messages\n", n_ok);
+    return n_ok > 0 ? 0 : 9;
+  }
   if (what == "gait") {
     // adapter_test <params.bin> gait <t_start> <lower> <upper> [<lower2> <upper2>]: trot template inserted at t_start,
     // then getModeSchedule windows; prints "n ev... | modes..." per window (compared with refgen.GaitSchedule)

@@ -165,3 +165,25 @@ def test_cpp_reference_manager_and_mpc_match_python_path(params, tmp_path):
     finally:
         s.close()
     assert np.array_equal(xs.reshape(xg.shape), xg) and np.array_equal(us.reshape(ug.shape), ug)
+
+
+def test_cpp_lcm_codec_matches_the_reference_bytes(tmp_path):
+    """include/hunter_lcm.h through the C++ adapter program (plain g++, no GPU): encode / decode are bit-exact against the
+    bytes of the reference's own generated classes (tests/golden/ref_lcm.json), a foreign fingerprint is refused."""
+    import json
+    import struct
+    exe = _build()
+    golden = json.loads((ROOT / "tests/golden/ref_lcm.json").read_text())
+    vec = tmp_path / "lcm_vectors.bin"
+    n = 0
+    with open(vec, "wb") as f:
+        for code, t in enumerate(golden["types"]):
+            for m in t["messages"]:
+                fields, wire = bytes.fromhex(m["fields_hex"]), bytes.fromhex(m["bytes_hex"])
+                f.write(struct.pack("<iiiq", code, t["n_fields"], len(wire), m["timestamp"]))
+                f.write(fields)
+                f.write(wire)
+                n += 1
+    r = subprocess.run([str(exe), str(PARAMS_BIN), "lcm", str(vec)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout + r.stderr)
+    assert f"ok: {n} lcm messages" in r.stdout

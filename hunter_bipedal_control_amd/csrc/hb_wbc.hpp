@@ -612,6 +612,13 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
 
   if (C.debug_stop == 12) return;
   // ------------------------------------------------------------------ phase C: Goldfarb–Idnani iterations
+#if defined(__HIP_DEVICE_COMPILE__)
+  // lane i keeps row i of J in registers for the whole active-set loop: z = J2 d2 and the reflector update work on it
+  // without LDS reads (the LDS copy stays current for the column accesses of d = J'n and is what a constraint drop works on)
+  double jrow[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) jrow[j] = cx.lane < NW ? Jm[cx.lane * NW + j] : 0.0;
+#endif
   int q = 0, iter = 0, status = 0;
   int next_eq = 0;
   int next_eq_active = 0;  // equalities in the active set (never dropped)
@@ -703,7 +710,14 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       for (int i = cx.lane; i < NW; i += cx.nlanes) {
         double sa[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < NW; ++j) sa[j & 3] += Jm[i * NW + j] * (j >= q ? d[j] : 0.0);
+        for (int j = 0; j < NW; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          const double jij = jrow[j];
+#else
+          const double jij = Jm[i * NW + j];
+#endif
+          sa[j & 3] += jij * (j >= q ? d[j] : 0.0);
+        }
         z[i] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
         if (i < q) r[i] = d[i];
       }
@@ -778,16 +792,22 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
             // reflector vector hv = (0, ..., 0, v0, d[q+1], ..., d[NW-1]); each lane holds its row of J in registers:
             // two fixed-length passes (unrolled, batched LDS traffic) instead of two rolled loops from q + 1
             for (int k = cx.lane; k < NW; k += cx.nlanes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+              double* row = jrow;  // k == lane
+#else
               double row[NW];
+#pragma unroll
+              for (int j = 0; j < NW; ++j) row[j] = Jm[k * NW + j];
+#endif
               double sa[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-              for (int j = 0; j < NW; ++j) {
-                row[j] = Jm[k * NW + j];
-                sa[j & 3] += row[j] * (j < q ? 0.0 : (j == q ? v0 : d[j]));
-              }
+              for (int j = 0; j < NW; ++j) sa[j & 3] += row[j] * (j < q ? 0.0 : (j == q ? v0 : d[j]));
               const double sacc = ((sa[0] + sa[1]) + (sa[2] + sa[3])) * beta;
 #pragma unroll
-              for (int j = 0; j < NW; ++j) Jm[k * NW + j] = row[j] - sacc * (j < q ? 0.0 : (j == q ? v0 : d[j]));
+              for (int j = 0; j < NW; ++j) {
+                row[j] = row[j] - sacc * (j < q ? 0.0 : (j == q ? v0 : d[j]));
+                Jm[k * NW + j] = row[j];
+              }
             }
           }
           cx.sync();
@@ -834,6 +854,10 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
           if (cx.lane == 0) Rm[(j + 1) * NW + j] = 0.0;
           cx.sync();
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) jrow[j] = cx.lane < NW ? Jm[cx.lane * NW + j] : 0.0;  // the rotations worked on the LDS copy
+#endif
       }
     }
     if (status != 0) break;

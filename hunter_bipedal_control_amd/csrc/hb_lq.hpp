@@ -69,9 +69,9 @@ HB_HD constexpr int rec_r(int a) { return REC_PR + a * REC_LD + REC_CV; }       
 struct RelaxedBarrierD {
   double mu, delta;
   HB_HD double value(double h) const {
-    if (h > delta) return -mu * log(h);
+    if (h > delta) return -mu * log_t(h);
     const double z = (h - 2.0 * delta) * rcp_t(delta);
-    return mu * (-log(delta) + 0.5 * z * z - 0.5);
+    return mu * (-log_t(delta) + 0.5 * z * z - 0.5);
   }
   HB_HD double d1(double h) const { const double r = rcp_t(h > delta ? h : delta); return h > delta ? -mu * r : mu * (h - 2.0 * delta) * r * r; }
   HB_HD double d2(double h) const { const double r = rcp_t(h > delta ? h : delta); return mu * r * r; }

@@ -87,6 +87,36 @@ HB_HD void sincos_t(Dual1 a, Dual1& s, Dual1& c) {
   s = {sv, cv * a.d};
   c = {cv, -sv * a.d};
 }
+// Natural logarithm of a positive, normal, finite argument (the relaxed barriers only ever pass such values): the
+// fdlibm / FreeBSD __ieee754_log scheme — x = 2^k m, m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f),
+// log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with a degree-14 even polynomial R — without the special-case handling of
+// the library routine (zero, negative, subnormal, inf, NaN), which cost k_lq 3 % of its time.  Error < 1 ulp (+ the
+// reciprocal's).  `log_fd` is compiled for the host as well so that tests/test_host_emu.py can check it against libm.
+HB_HD double log_fd(double x) {
+  int k;
+#if defined(__HIP_DEVICE_COMPILE__)
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  k = __builtin_amdgcn_frexp_exp(x);
+#else
+  double m = frexp(x, &k);
+#endif
+  if (m < 0.70710678118654752440) { m *= 2.0; k -= 1; }
+  const double f = m - 1.0;
+  const double s = f * rcp_t(2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                            6.666666666666735130e-01);
+  const double R = t2 + t1, hfsq = 0.5 * f * f, dk = double(k);
+  return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+HB_HD double log_t(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return log_fd(x);
+#else
+  return log(x);
+#endif
+}
 // sine / cosine of an angle whose VALUE pair (sv, cv) is already known: the dual version only adds the tangents
 HB_HD void sincos_known(double sv, double cv, double, double& s, double& c) { s = sv; c = cv; }
 HB_HD void sincos_known(double sv, double cv, Dual1 a, Dual1& s, Dual1& c) {

@@ -181,6 +181,13 @@ void emu_kf_update(const hb_model* m, const hb_estimator_config* k, double dt, d
 }
 }
 
+extern "C" {
+// the device's logarithm scheme (hb_math.hpp log_fd), host build
+void emu_log_fd(const double* x, int n, double* y) {
+  for (int i = 0; i < n; ++i) y[i] = log_fd(x[i]);
+}
+}
+
 #include "../../hunter_bipedal_control_amd/csrc/hb_refgen.hpp"
 extern "C" {
 // device reference generation of one instance on the host

@@ -217,3 +217,17 @@ def test_device_plant_step_matches_numpy_plant(params, oracle, emu):
                            C.c_double(0.002), C.c_int(4), _p(lam), _p(vdot))
         assert np.abs(q - pl.q[0]).max() < 1e-10 and np.abs(v - pl.v[0]).max() < 1e-8, tick
         assert np.abs(lam - pl.last_lambda[0]).max() < 1e-6 * max(1.0, np.abs(lam).max())
+
+
+def test_device_logarithm_scheme_matches_libm(emu):
+    """hb_math.hpp log_fd (what the relaxed barriers use on the device instead of the library log) vs numpy over the range
+    of barrier arguments and far beyond: < 2 ulp."""
+    lib = emu[0]
+    rng = np.random.default_rng(3)
+    x = np.concatenate([10.0 ** rng.uniform(-12, 12, 20000), rng.uniform(0.05, 400.0, 20000), 1.0 + rng.uniform(-1e-3, 1e-3, 2000),
+                        [1.0, 0.5, 2.0, np.sqrt(0.5), np.sqrt(2.0), np.nextafter(np.sqrt(0.5), 0), 0.1, 5.0, 350.0]])
+    y = np.zeros_like(x)
+    lib.emu_log_fd(x.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(len(x)), y.ctypes.data_as(C.POINTER(C.c_double)))
+    ref = np.log(x)
+    err = np.abs(y - ref) / np.maximum(np.spacing(np.abs(ref)), 5e-324)
+    assert err.max() <= 2.0, (err.max(), x[err.argmax()])

@@ -413,6 +413,7 @@ HB_HD void node_value(const DevModel& M, const DevConfig& C, const double* x, co
     }
     cost += bf.value(Fz - C.force_lim[0]) + bf.value(C.force_lim[1] - Fz);
   }
+#pragma unroll 1  // 40 barrier evaluations: rolled, or the inlined logarithms push the kernel beyond 512 registers
   for (int j = 0; j < HB_NJ; ++j) {
     cost += bp.value(x[12 + j] - M.q_lower[j]) + bp.value(M.q_upper[j] - x[12 + j]);
     cost += bv.value(u[12 + j] + M.qd_limit[j]) + bv.value(M.qd_limit[j] - u[12 + j]);

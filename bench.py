@@ -42,8 +42,9 @@ def make_batch(params, batch, n_intervals, first_inst):
     """Seeded synthetic batch; 16 distinct instances tiled to the batch size to keep host set-up short (the reference
     manager with per-knot IK runs on the host, ~0.4 s per instance)."""
     from hunter_bipedal_control_amd import workload
+    from oracle import workloads
     distinct = min(batch, 16)
-    refs1, x01, rbd1, tn1 = workload.trot_batch(params, distinct, n_intervals=n_intervals, first_inst=first_inst)
+    refs1, x01, rbd1, tn1 = workloads.trot_batch(params, distinct, n_intervals=n_intervals, first_inst=first_inst)
     reps = (batch + distinct - 1) // distinct
     refs = {k: np.concatenate([v] * reps)[:batch] for k, v in refs1.items()}
     cat = lambda a: np.concatenate([a] * reps)[:batch]  # noqa: E731
@@ -124,6 +125,7 @@ def main():
 
     import torch
     from hunter_bipedal_control_amd import ingest, sharding
+    from oracle import workloads
     from hunter_bipedal_control_amd.solver import HunterSolver
 
     rank = int(os.environ.get("RANK", "0"))

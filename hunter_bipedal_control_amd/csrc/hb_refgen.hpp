@@ -33,6 +33,13 @@ HB_HD int rg_bisect_left(const double* ev, int n, double t) {
   }
   return lo;
 }
+// phase record the swing getters read at time t: findIndexInTimeArray clamped to the number of events - 1
+// (SwingTrajectoryPlanner::getXpositionConstraint & co., SwingTrajectoryPlanner.cpp:91-159)
+HB_HD int rg_phase_index(const double* ev, int n_ev, double t) {
+  int idx = rg_bisect_left(ev, n_ev, t);
+  if (idx > n_ev - 1) idx = n_ev - 1;
+  return idx < 0 ? 0 : idx;
+}
 HB_HD Mat3<double> rg_rot_zyx(const double* zyx) {
   double sz, cz, sy, cy, sx, cx;
   sincos_t(zyx[0], sz, cz);
@@ -84,7 +91,7 @@ HB_HD void rg_phase_eval(const RefgenConfig& K, const double* ph, double t, doub
   rg_multi_cubic(4, tn, pn, vn, t, out6[2], out6[5]);
 }
 
-// 2-knot target of one instance (cmd_vel_targets, TargetTrajectoriesPublisher.h:101-131).  The two states live in
+// 2-knot target of one instance (TargetTrajectoriesPublisher.cpp:102-130).  The two states live in
 // caller-provided memory (the kernels keep them in the last two knot slots of the instance, in HBM): a thread-private
 // copy would be indexed dynamically and end up in scratch.
 struct RgTarget {
@@ -98,23 +105,34 @@ struct RgTarget {
     return (1 - a) * cur[i] + a * tgt[i];
   }
 };
+// cmdVelToTargetTrajectories + targetPoseToTargetTrajectories (legged_controllers/src/TargetTrajectoriesPublisher.cpp:40-59,
+// 102-130): the command [vx vy vz wz] rotated into the world by the observed ZYX angles, its x component zeroed inside the
+// 0.06 dead band ELSE its y component; first knot = observed position and yaw (pitch / roll zero) with the height moved towards
+// comHeight by at most changeLimit_[2] = 0.04 (TargetTrajectoriesPublisher.h:97); second knot = the pose reached after `horizon`
+// (TIME_TO_TARGET = mpc.timeHorizon) at comHeight.
+constexpr double RG_CMD_DEAD_BAND = 0.06, RG_HEIGHT_CHANGE_LIMIT = 0.04;
 HB_HD void rg_make_target(const RefgenConfig& K, double t0, double horizon, const double* x_now, const double* cmd_vel, double* cur,
                           double* tgt, RgTarget& T) {
   const Mat3<double> Rn = rg_rot_zyx(x_now + 9);
-  const Vec3<double> vw = Rn * Vec3<double>(cmd_vel[0], cmd_vel[1], 0.0);
+  Vec3<double> vw = Rn * Vec3<double>(cmd_vel[0], cmd_vel[1], cmd_vel[2]);
+  if (fabs(vw.x) < RG_CMD_DEAD_BAND) vw.x = 0.0;
+  else if (fabs(vw.y) < RG_CMD_DEAD_BAND) vw.y = 0.0;
   T.t0 = t0;
   T.tf = t0 + horizon;
   T.cur = cur;
   T.tgt = tgt;
-  for (int i = 0; i < HB_NX; ++i) cur[i] = 0.0;
+  for (int i = 0; i < HB_NX; ++i) { cur[i] = 0.0; tgt[i] = 0.0; }
   cur[0] = vw.x; cur[1] = vw.y; cur[2] = vw.z;
-  cur[6] = x_now[6]; cur[7] = x_now[7]; cur[8] = K.com_height;
+  tgt[0] = vw.x; tgt[1] = vw.y; tgt[2] = vw.z;
+  double dz = K.com_height - x_now[8];
+  dz = dz > 0.0 ? fmin(dz, RG_HEIGHT_CHANGE_LIMIT) : fmax(dz, -RG_HEIGHT_CHANGE_LIMIT);
+  cur[6] = x_now[6]; cur[7] = x_now[7]; cur[8] = x_now[8] + dz;
   cur[9] = x_now[9];
-  for (int j = 0; j < HB_NJ; ++j) cur[12 + j] = K.default_joints[j];
-  for (int i = 0; i < HB_NX; ++i) tgt[i] = cur[i];
-  tgt[6] = cur[6] + vw.x * horizon;
-  tgt[7] = cur[7] + vw.y * horizon;
-  tgt[9] = cur[9] + cmd_vel[3] * horizon;
+  tgt[6] = x_now[6] + vw.x * horizon;
+  tgt[7] = x_now[7] + vw.y * horizon;
+  tgt[8] = K.com_height;
+  tgt[9] = x_now[9] + cmd_vel[3] * horizon;
+  for (int j = 0; j < HB_NJ; ++j) { cur[12 + j] = K.default_joints[j]; tgt[12 + j] = K.default_joints[j]; }
 }
 
 // ---- joint reference by inverse kinematics (InverseKinematics.cpp:20-231 as restated in refgen.py) -----------------
@@ -440,8 +458,7 @@ HB_HD void refgen_ik_leg(const DevModel& M, const RefgenConfig& K, int n_ev, con
     }
     for (int c = 0; c < 6; ++c) qref[c] = T.at(ti, 6 + c);
     // planned position of contact f1 of this leg at the knot time (SwingTrajectoryPlanner getters)
-    int idx = rg_bisect_left(ev, n_ev, ti);
-    if (idx > n_ev) idx = n_ev;
+    int idx = rg_phase_index(ev, n_ev, ti);
     double sw[6];
     rg_phase_eval(K, phases + (size_t(leg) * (RG_MAX_EVENTS + 1) + idx) * RG_PHASE, ti, sw);
     rg_compute_ik(M, qref, leg, Vec3<double>(sw[0], sw[1], sw[2]), Rdes, W);  // warm start: previous knot's solution
@@ -467,8 +484,7 @@ HB_HD void refgen_node(const RefgenConfig& K, int n_ev, const double* ev, const 
       const double* x0 = knot_x + size_t(i0) * HB_NX;
       for (int i = 0; i < HB_NX; ++i) xr[i] = (1 - a) * x0[i] + a * x0[HB_NX + i];
     }
-    int idx = rg_bisect_left(ev, n_ev, tk + eps);
-    if (idx > n_ev) idx = n_ev;
+    const int idx = rg_phase_index(ev, n_ev, tk + eps);
     for (int f = 0; f < HB_NC; ++f)
       rg_phase_eval(K, phases + (size_t(f) * (RG_MAX_EVENTS + 1) + idx) * RG_PHASE, tk + eps, sw + HB_SWING_REF * f);
   } else {

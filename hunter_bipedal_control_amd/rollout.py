@@ -3,44 +3,43 @@ policy -> WBC -> joint command -> plant, the loop of LeggedController::update (l
 137-278) and its MPC thread (:396-412), for every instance of a HunterSolver.
 
 Everything between the plant's state and the joint torque runs on the device (reference generation, SQP, policy
-evaluation, WBC, joint command law); the plant stub (plant.py) integrates on the host with the device's rigid-body
+evaluation, WBC, joint command law); the plant stub integrates either on the device (ResidentLoop, hb_plant_step) or on the host (DeviceLoop, with a plant object the
+caller injects — the tests pass the numpy twin oracle/plant.py)  with the device's rigid-body
 terms.  The observation is the plant's true state (no estimator noise); `hb_estimator_update` can be put in its place.
 """
 from __future__ import annotations
 
 import numpy as np
 
-from . import abi, refgen
+from . import abi, gait
 from . import solver as _solver
-from .plant import Plant
+from .gait import schedule_window  # noqa: F401  (re-exported: the tests address it as rollout.schedule_window)
 
 
-def standing_configuration(params: dict, batch: int) -> np.ndarray:
-    """q[B][16]: initialState of task.info with the base lowered so that the mean contact-point height is zero."""
+def standing_configuration(params: dict, batch: int, solver) -> np.ndarray:
+    """q[B][16]: initialState of task.info with the base lowered so that the mean contact-point height is zero (contact
+    points from the device kinematics, hb_eval_foot_kinematics)."""
     x0 = np.array(params["config"]["initial_state"], dtype=float)
     q = np.zeros((batch, 16))
     q[:, 0:3], q[:, 3:6], q[:, 6:] = x0[6:9], x0[9:12], x0[12:]
-    q[:, 2] -= refgen.foot_positions(params["model"], x0)[:, 2].mean()
+    feet = solver.eval_foot_kinematics(x0[None, :], np.zeros((1, 22)))[0]
+    q[:, 2] -= np.asarray(feet).reshape(4, 3)[:, 2].mean()
     return q
-
-
-def schedule_window(ms: refgen.ModeSchedule, lower: float, upper: float) -> refgen.ModeSchedule:
-    """The part of a mode schedule with event times inside (lower, upper) and the modes around them."""
-    ev = np.asarray(ms.event_times, dtype=float)
-    i0 = int(np.searchsorted(ev, lower, side="right"))
-    i1 = int(np.searchsorted(ev, upper, side="left"))
-    return refgen.ModeSchedule(list(ev[i0:i1]), list(ms.modes[i0:i1 + 1]))
 
 
 class DeviceLoop:
     """One HunterSolver driven in closed loop.  `gait` per instance (names of gait.info), `cmd_vel` [B][4]."""
 
     def __init__(self, solver, params: dict, gaits, cmd_vel, n_intervals: int = 100, mpc_every: int = 8, dt: float = 0.002,
-                 t_gait_start: float = 0.3, joint_ik: bool = True, use_estimator: bool = False, use_lcm: bool = False):
+                 t_gait_start: float = 0.3, joint_ik: bool = True, use_estimator: bool = False, use_lcm: bool = False,
+                 plant_factory=None):
         """use_lcm (with use_estimator): sensors and commands cross the controller boundary as LCM wire images — the
         plant side encodes low_state_t / applies the PD + feed-forward law of a decoded low_cmd_t like the MuJoCo bridge
         (mujoco/src/main.cc), the controller side uses hb_estimator_update_lcm / hb_joint_command_lcm."""
         assert not (use_lcm and not use_estimator)
+        if plant_factory is None:
+            raise ValueError("DeviceLoop integrates the plant on the host: pass plant_factory(rbd_fn, foot_fn, q0) "
+                             "(tests: oracle.plant.Plant); ResidentLoop keeps the plant on the device")
         self.use_lcm = use_lcm
         self.tau_applied = np.zeros((solver.B, 10))
         self.s, self.params = solver, params
@@ -54,7 +53,7 @@ class DeviceLoop:
         solver.refgen_reset(abi.make_refgen_config(params, joint_ik=joint_ik))
         # GaitSchedule output per instance; each MPC call hands the device the window [t - 1, t + horizon + 1.5] of it
         # (the reference asks its gait schedule for [t - T, t + 2T], SwitchedModelReferenceManager.cpp:147)
-        self.schedules = [refgen.gait_schedule(params, g, t_gait_start, 1.0e3 if g == "stance" else 60.0) for g in gaits]
+        self.schedules = [gait.gait_schedule(params, g, t_gait_start, 1.0e3 if g == "stance" else 60.0) for g in gaits]
         zeros_u = np.zeros((1, 22))
 
         def foot_fn(q):
@@ -62,7 +61,7 @@ class DeviceLoop:
             x[:, 6:9], x[:, 9:12], x[:, 12:] = q[:, 0:3], q[:, 3:6], q[:, 6:]
             return solver.eval_foot_kinematics(x, np.repeat(zeros_u, q.shape[0], axis=0))[0]
 
-        self.plant = Plant(lambda rbd: solver.eval_rbd(rbd), foot_fn, standing_configuration(params, self.B))
+        self.plant = plant_factory(lambda rbd: solver.eval_rbd(rbd), foot_fn, standing_configuration(params, self.B, solver))
         self.started = False
         self.last = {}
         # use_estimator: the observation comes from hb_estimator_update fed with the plant's ideal IMU, joint encoders and
@@ -110,7 +109,7 @@ class DeviceLoop:
             self.tau_applied = cmd["torque"]
         else:
             cmd = s.joint_command(self.gains, self.dt)
-        contact = np.array([refgen.mode_to_contact_flags(int(m)) for m in out["mode"]])
+        contact = np.array([gait.mode_to_contact_flags(int(m)) for m in out["mode"]])
         self.plant.step(cmd["torque"], contact, self.dt)
         self.contact = contact.astype(np.int32)
         self.t += self.dt
@@ -134,8 +133,8 @@ class ResidentLoop:
         self.gains = abi.make_joint_gains()
         self.t, self.tick = 0.0, 0
         solver.refgen_reset(abi.make_refgen_config(params, joint_ik=joint_ik))
-        self.schedules = [refgen.gait_schedule(params, g, t_gait_start, 1.0e3 if g == "stance" else 60.0) for g in gaits]
-        q0 = standing_configuration(params, self.B)
+        self.schedules = [gait.gait_schedule(params, g, t_gait_start, 1.0e3 if g == "stance" else 60.0) for g in gaits]
+        q0 = standing_configuration(params, self.B, solver)
         solver.plant_reset(q0)
         # resident observation of the initial state
         rbd = np.zeros((self.B, 32))

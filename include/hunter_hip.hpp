@@ -279,7 +279,8 @@ class GaitSchedule {
     while (ev.back() < finalTime)
       for (size_t i = 0; i < tp.modeSequence.size(); ++i) {
         md.push_back(tp.modeSequence[i]);
-        ev.push_back(ev.back() + tp.switchingTimes[i + 1] - tp.switchingTimes[i]);
+        const scalar_t deltaTime = tp.switchingTimes[i + 1] - tp.switchingTimes[i];  // the difference first: the reference's rounding
+        ev.push_back(ev.back() + deltaTime);
       }
     md.push_back(kStance);
   }

@@ -1,5 +1,8 @@
-"""Host-side reference manager: gait schedule, OCS2-style time discretisation, swing-foot splines, target
-trajectories -> the per-node tables ``hb_mpc_set_references`` consumes.
+"""TEST INFRASTRUCTURE — CPU checker of the device reference generation (hb_refgen_*): gait schedule, OCS2-style time
+discretisation, swing-foot splines, target trajectories -> the per-node tables ``hb_mpc_set_references`` consumes.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it; the product path never does.
+Pinned to the reference's own compiled code (GaitSchedule.cpp, SwingTrajectoryPlanner.cpp, TargetTrajectoriesPublisher.cpp
+built in place into oracle/_ref/libref_refgen.so) by tests/golden/ref_refgen.json — tests/test_ref_refgen.py.
 
 Restates (host logic, runs once per MPC call per instance in the reference):
   * ModeSchedule::modeAtTime / GaitSchedule::{tileModeSequenceTemplate, insertModeSequenceTemplate, getModeSchedule}
@@ -72,7 +75,7 @@ class GaitSchedule:
         while ev[-1] < final:
             for i, m in enumerate(tp.modes):
                 md.append(m)
-                ev.append(ev[-1] + tp.switching_times[i + 1] - tp.switching_times[i])
+                ev.append(ev[-1] + (tp.switching_times[i + 1] - tp.switching_times[i]))
         md.append(STANCE)
 
     def insert_template(self, template: ModeTemplate, start: float, final: float):
@@ -178,21 +181,35 @@ class TargetTrajectories:
         return (1 - a) * np.asarray(self.x[i]) + a * np.asarray(self.x[i + 1])
 
 
+CMD_DEAD_BAND = 0.06       # TargetTrajectoriesPublisher.cpp:109-112
+HEIGHT_CHANGE_LIMIT = 0.04  # changeLimit_[2], TargetTrajectoriesPublisher.h:97
+
+
 def cmd_vel_targets(t0: float, x_now: np.ndarray, cmd_vel, horizon: float, com_height: float, default_joints):
-    """2-knot target from a velocity command (TargetTrajectoriesPublisher.h:101-131): the base pose is
-    extrapolated with the commanded velocity rotated into the world by the current yaw-pitch-roll."""
-    vx, vy, _, wz = cmd_vel
-    zyx = x_now[9:12]
-    v_world = zyx_to_rotation(zyx) @ np.array([vx, vy, 0.0])
+    """cmdVelToTargetTrajectories + targetPoseToTargetTrajectories (TargetTrajectoriesPublisher.cpp:40-59,102-130): the
+    (rate-limited) command [vx vy vz wz] is rotated into the world by the observed yaw-pitch-roll; its x component is zeroed
+    inside the 0.06 dead band, ELSE its y component is; the first knot keeps the observed position and yaw (pitch / roll
+    zero) with the height moved towards comHeight by at most 0.04; the second knot is the pose reached after
+    `horizon` (= TIME_TO_TARGET = mpc.timeHorizon) at that velocity, at comHeight."""
+    vx, vy, vz, wz = cmd_vel
+    v_world = zyx_to_rotation(x_now[9:12]) @ np.array([vx, vy, vz])
+    if abs(v_world[0]) < CMD_DEAD_BAND:
+        v_world[0] = 0.0
+    elif abs(v_world[1]) < CMD_DEAD_BAND:
+        v_world[1] = 0.0
     cur = np.zeros(22)
     cur[6:9] = x_now[6:9]
-    cur[8] = com_height
+    dz = com_height - x_now[8]
+    dz = min(dz, HEIGHT_CHANGE_LIMIT) if dz > 0 else max(dz, -HEIGHT_CHANGE_LIMIT)
+    cur[8] = x_now[8] + dz
     cur[9] = x_now[9]
     cur[12:] = default_joints
-    tgt = cur.copy()
-    tgt[6] += v_world[0] * horizon
-    tgt[7] += v_world[1] * horizon
-    tgt[9] += wz * horizon
+    tgt = np.zeros(22)
+    tgt[6] = x_now[6] + v_world[0] * horizon
+    tgt[7] = x_now[7] + v_world[1] * horizon
+    tgt[8] = com_height
+    tgt[9] = x_now[9] + wz * horizon
+    tgt[12:] = default_joints
     cur[0:3] = v_world
     tgt[0:3] = v_world
     return TargetTrajectories([t0, t0 + horizon], [cur, tgt])
@@ -326,7 +343,8 @@ class SwingTrajectoryPlanner:
                     self.traj[j].append((const(nxt[j][0]), const(nxt[j][1]), const(nxt[j][2])))
 
     def swing_ref(self, foot: int, t: float) -> np.ndarray:
-        idx = min(bisect.bisect_left(self.events, t), len(self.traj[foot]) - 1)
+        # getXpositionConstraint & co.: findIndexInTimeArray clamped to the number of events - 1 (SwingTrajectoryPlanner.cpp:91-159)
+        idx = max(min(bisect.bisect_left(self.events, t), len(self.events) - 1), 0)
         sx, sy, sz = self.traj[foot][idx]
         return np.array([sx.position(t), sy.position(t), sz.position(t), sx.velocity(t), sy.velocity(t), sz.velocity(t)])
 

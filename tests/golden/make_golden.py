@@ -19,7 +19,8 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
-from hunter_bipedal_control_amd import ingest, refgen, workload  # noqa: E402
+from hunter_bipedal_control_amd import ingest, workload  # noqa: E402
+from oracle import refgen, workloads
 
 OUT = Path(__file__).parent
 
@@ -65,7 +66,7 @@ def part2():
     u = rng.standard_normal((6, 22)) * np.r_[np.full(12, 20.0), np.full(10, 1.0)]
     f, A, B = o.flow_map(x, u, jac=True)
     pos, vel = o.foot_kinematics(x, u)
-    refs, xs0, rbd, t_now = workload.trot_batch(params, 2, n_intervals=30, cmd_vel=(0.3, 0.0, 0.0, 0.1))
+    refs, xs0, rbd, t_now = workloads.trot_batch(params, 2, n_intervals=30, cmd_vel=(0.3, 0.0, 0.0, 0.1))
     xt = np.zeros((2, 31, 22)); ut = np.zeros((2, 30, 22))
     for i in range(2):
         xt[i], ut[i] = o.cold_start(refs["mode"][i], xs0[i])

@@ -1,0 +1,229 @@
+"""Generates tests/golden/ref_refgen.json from the REFERENCE's own reference-generation code.
+
+Run in the build container only (needs /root/reference):  make -C oracle ref && python tests/golden/make_ref_refgen.py
+oracle/_ref/libref_refgen.so is GaitSchedule.cpp, SwingTrajectoryPlanner.cpp, CubicSpline.cpp, MultiCubicSpline.cpp and
+TargetTrajectoriesPublisher.cpp of the reference compiled in place (oracle/Makefile, oracle/ref_refgen_capi.cpp).  Every
+number stored under an "out" key below was computed by that library; the inputs are seeded random draws around the
+operating point of config 2-4.  Sections:
+  gait      GaitSchedule insert / get sequences at the MPC cadence, with gait switches at event times
+  modes     modeNumber2StanceLeg / stanceLeg2ModeNumber
+  targets   observation + /cmd_vel message streams through the reference's callback (rate limiter, dead band, height clamp)
+  swing     SwingTrajectoryPlanner::update sequences (persistent latestStanceposition_) + the six getters on a time grid
+"""
+import ctypes as C
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from hunter_bipedal_control_amd import ingest  # noqa: E402
+from oracle import refgen  # noqa: E402  (forward kinematics of the input states only)
+
+lib = C.CDLL(str(ROOT / "oracle/_ref/libref_refgen.so"))
+DP, IP = C.POINTER(C.c_double), C.POINTER(C.c_int)
+_d = lambda a: a.ctypes.data_as(DP)
+_i = lambda a: a.ctypes.data_as(IP)
+lib.ref_gait_new.restype = C.c_void_p
+lib.ref_gait_new.argtypes = [DP, C.c_int, IP, DP, C.c_int, IP, C.c_double]
+lib.ref_gait_free.argtypes = [C.c_void_p]
+lib.ref_gait_insert.argtypes = [C.c_void_p, DP, C.c_int, IP, C.c_double, C.c_double]
+lib.ref_gait_get.argtypes = [C.c_void_p, C.c_double, C.c_double, DP, IP, C.c_int]
+lib.ref_gait_peek.argtypes = [C.c_void_p, DP, IP, C.c_int]
+lib.ref_ttp_configure.argtypes = [C.c_double, DP, C.c_double, C.c_double, C.c_double]
+lib.ref_ttp_observation.argtypes = [C.c_double, DP]
+lib.ref_ttp_cmd_vel.argtypes = [C.c_double] * 3 + [DP, DP, DP]
+lib.ref_swing_new.restype = C.c_void_p
+lib.ref_swing_new.argtypes = [DP]
+lib.ref_swing_free.argtypes = [C.c_void_p]
+lib.ref_swing_set.argtypes = [C.c_void_p, DP, DP]
+lib.ref_swing_update.argtypes = [C.c_void_p, DP, C.c_int, IP, DP, DP, C.c_int, C.c_double]
+lib.ref_swing_eval.argtypes = [C.c_void_p, DP, C.c_int, DP]
+lib.ref_swing_start_stop.argtypes = [C.c_void_p, C.c_int, C.c_double, DP]
+
+CAP = 256
+
+
+class RefGait:
+    def __init__(self, ev, modes, tpl_t, tpl_m, pts):
+        ev, modes = np.asarray(ev, dtype=np.float64), np.asarray(modes, dtype=np.int32)
+        tpl_t, tpl_m = np.asarray(tpl_t, dtype=np.float64), np.asarray(tpl_m, dtype=np.int32)
+        self.h = C.c_void_p(lib.ref_gait_new(_d(ev), len(ev), _i(modes), _d(tpl_t), len(tpl_t), _i(tpl_m), pts))
+
+    def insert(self, tpl_t, tpl_m, start, final):
+        tpl_t, tpl_m = np.asarray(tpl_t, dtype=np.float64), np.asarray(tpl_m, dtype=np.int32)
+        return lib.ref_gait_insert(self.h, _d(tpl_t), len(tpl_t), _i(tpl_m), start, final)
+
+    def _out(self, n, ev, md):
+        return None if n < 0 else dict(ev=ev[:n].tolist(), modes=md[:n + 1].tolist())
+
+    def get(self, lower, upper):
+        ev, md = np.zeros(CAP), np.zeros(CAP + 1, dtype=np.int32)
+        n = lib.ref_gait_get(self.h, lower, upper, _d(ev), _i(md), CAP)
+        assert n != -2
+        return self._out(n, ev, md)
+
+    def peek(self):
+        ev, md = np.zeros(CAP), np.zeros(CAP + 1, dtype=np.int32)
+        return self._out(lib.ref_gait_peek(self.h, _d(ev), _i(md), CAP), ev, md)
+
+    def __del__(self):
+        lib.ref_gait_free(self.h)
+
+
+def gait_cases(params, rng):
+    c = params["config"]
+    gaits = c["gaits"]
+    names = ["stance", "trot", "standing_trot", "flying_trot"]
+    cases = []
+    for case in range(6):
+        pts = [c["phase_transition_stance_time"], 0.0, 0.25][case % 3]
+        tpl0 = c["default_mode_template"]
+        # the reference's own starting point (reference.info:21-32); an EMPTY initial schedule is undefined behaviour in
+        # GaitSchedule::getModeSchedule (erase(end - 1, end) on an empty vector, GaitSchedule.cpp:115)
+        ims = c["initial_mode_schedule"]
+        g = RefGait(ims["event_times"], ims["modes"], tpl0["switching_times"], tpl0["modes"], pts)
+        ops = []
+        horizon = [1.5, 0.8, 3.0][case % 3]
+        t = 0.0
+        for step in range(int(rng.integers(14, 22))):
+            t += float(rng.choice([0.016, 0.02, 0.11]))
+            out = g.get(t - horizon, t + 2 * horizon)
+            ops.append(dict(op="get", lower=t - horizon, upper=t + 2 * horizon, out=out))
+            if out is None:
+                break
+            if rng.uniform() < 0.3:
+                name = names[int(rng.integers(0, 4))]
+                tpl = gaits[name]
+                # the reference inserts at the first event >= initTime of the window it just got (walkGait), or at
+                # initTime + 0.2 (trotGait); a few arbitrary start times exercise the erase / exception branches
+                mode = int(rng.integers(0, 3))
+                ev = out["ev"]
+                later = [e for e in ev if e >= t]
+                start = later[0] if (mode == 0 and later) else (t + 0.2 if mode == 1 else float(rng.uniform(t - 0.3, t + 1.0)))
+                rc = g.insert(tpl["switching_times"], tpl["modes"], start, t + horizon)
+                ops.append(dict(op="insert", template=dict(switching_times=tpl["switching_times"], modes=tpl["modes"]),
+                                start=start, final=t + horizon, rc=rc, out=g.peek()))
+        cases.append(dict(phase_transition_stance_time=pts, init=dict(ev=ims["event_times"], modes=ims["modes"]),
+                          template=dict(switching_times=tpl0["switching_times"], modes=tpl0["modes"]), ops=ops))
+    return cases
+
+
+def mode_cases():
+    out = []
+    for m in range(4):
+        f = np.zeros(4, dtype=np.int32)
+        lib.ref_mode_flags(m, _i(f))
+        out.append(dict(mode=m, flags=f.tolist(), back=lib.ref_flags_to_mode(_i(f))))
+    return out
+
+
+def random_state(params, rng, big=False):
+    c, m = params["config"], params["model"]
+    x = np.array(c["initial_state"], dtype=float)
+    s = 3.0 if big else 1.0
+    x[0:6] += 0.05 * rng.standard_normal(6)
+    x[6:8] += rng.uniform(-2.0, 2.0, 2)
+    x[8] += s * 0.03 * rng.standard_normal()
+    x[9] += rng.uniform(-3.0, 3.0)
+    x[10:12] += s * 0.05 * rng.standard_normal(2)
+    x[12:] += 0.03 * rng.standard_normal(10)
+    x[12:] = np.clip(x[12:], np.array(m["q_lower"]) + 0.02, np.array(m["q_upper"]) - 0.02)
+    return x
+
+
+def target_cases(params, rng):
+    c = params["config"]
+    dj = np.array(c["default_joint_state"], dtype=float)
+    cases = []
+    for case in range(10):
+        T = [1.5, 0.8, 3.0][case % 3]
+        lib.ref_ttp_configure(c["com_height"], _d(dj), T, 1.0, 0.5)
+        lib.ref_ttp_new()
+        msgs = []
+        t = 0.0
+        want = np.array([rng.uniform(-0.35, 0.35), rng.uniform(-0.15, 0.15), rng.uniform(-0.5, 0.5)])
+        for k in range(12):
+            t += 0.02
+            x = random_state(params, rng, big=(case % 2 == 1))
+            if k % 4 == 3:  # a new operator request; small values sit inside the 0.06 dead band
+                want = np.array([rng.choice([0.0, 0.03, 0.055, 0.065, 0.3, -0.3]) + 0.0, rng.choice([0.0, 0.05, -0.058, 0.1]),
+                                 rng.uniform(-0.5, 0.5)])
+            lib.ref_ttp_observation(t, _d(x))
+            t2, x2, f4 = np.zeros(2), np.zeros(44), np.zeros(4)
+            pub = lib.ref_ttp_cmd_vel(float(want[0]), float(want[1]), float(want[2]), _d(t2), _d(x2), _d(f4))
+            msgs.append(dict(t=t, x=x.tolist(), cmd=want.tolist(),
+                             out=dict(published=pub, filtered=f4.tolist(), t2=t2.tolist(), x2=x2.reshape(2, 22).tolist())))
+        cases.append(dict(time_to_target=T, com_height=c["com_height"], default_joints=dj.tolist(), msgs=msgs))
+    return cases
+
+
+def swing_cases(params, rng):
+    c = params["config"]
+    sw = c["swing"]
+    cfg = np.array([0.0, 0.0, sw["swing_height"], sw["swing_time_scale"], sw["feet_bias_x1"], sw["feet_bias_x2"], sw["feet_bias_y"],
+                    sw["feet_bias_z"], sw["next_position_z"]], dtype=float)
+    dj = np.array(c["default_joint_state"], dtype=float)
+    tpl0 = c["default_mode_template"]
+    cases = []
+    for case in range(6):
+        gait, T = [("trot", 1.5), ("trot", 3.0), ("standing_trot", 1.5), ("flying_trot", 0.8), ("trot", 0.8), ("standing_trot", 0.8)][case]
+        ims = c["initial_mode_schedule"]
+        g = RefGait(ims["event_times"], ims["modes"], tpl0["switching_times"], tpl0["modes"], c["phase_transition_stance_time"])
+        g.insert(c["gaits"][gait]["switching_times"], c["gaits"][gait]["modes"], 0.1, 1.6 + 2 * T)  # keeps every window inside HB_MAX_EVENTS
+        lib.ref_ttp_configure(c["com_height"], _d(dj), T, 1.0, 0.5)
+        lib.ref_ttp_new()
+        h = C.c_void_p(lib.ref_swing_new(_d(cfg)))
+        x = random_state(params, rng)
+        cmd = np.array([rng.uniform(-0.35, 0.35), rng.uniform(-0.15, 0.15), rng.uniform(-0.5, 0.5)])
+        steps = []
+        t = float(rng.uniform(0.0, 0.3))
+        for k in range(4):
+            sched = g.get(t - T, t + 2 * T)
+            lib.ref_ttp_observation(max(t, 1e-9), _d(x))
+            t2, x2, f4 = np.zeros(2), np.zeros(44), np.zeros(4)
+            assert lib.ref_ttp_cmd_vel(float(cmd[0]), float(cmd[1]), float(cmd[2]), _d(t2), _d(x2), _d(f4)) == 1
+            feet = refgen.foot_positions(params["model"], x).reshape(12).copy()
+            body_cmd = np.array([f4[0], f4[1], f4[2], f4[3], 0.0, 0.0])  # cmd_vel callback layout, SwitchedModelReferenceManager.cpp:91-97
+            lib.ref_swing_set(h, _d(body_cmd), _d(feet))
+            ev, md = np.array(sched["ev"], dtype=float), np.array(sched["modes"], dtype=np.int32)
+            rc = lib.ref_swing_update(h, _d(ev), len(ev), _i(md), _d(t2), _d(x2), 2, t)
+            inside = ev[(ev >= t) & (ev <= t + T)]
+            times = np.unique(np.concatenate([np.linspace(t, t + T, 9), inside[:4], inside[:4] + 1e-9])).astype(float)
+            out = np.zeros((len(times), 4, 6))
+            ss = np.zeros((4, 2))
+            if rc == 0:
+                lib.ref_swing_eval(h, _d(times), len(times), _d(out))
+                for leg in range(4):
+                    lib.ref_swing_start_stop(h, leg, t + 0.25 * T, _d(ss[leg]))
+            steps.append(dict(t_init=t, x=x.tolist(), feet=feet.tolist(), body_vel_cmd=body_cmd.tolist(), schedule=sched,
+                              target_t=t2.tolist(), target_x=x2.reshape(2, 22).tolist(), times=times.tolist(),
+                              out=dict(rc=rc, refs=out.tolist(), start_stop_at_quarter=ss.tolist())))
+            # advance: the robot moves with the command, joints wobble; a later call sees the same planner object
+            dt = float(rng.choice([0.016, 0.11, 0.31]))
+            t += dt
+            x = x.copy()
+            x[6] += dt * f4[0]
+            x[7] += dt * f4[1]
+            x[9] += dt * f4[3]
+            x[12:] += 0.02 * rng.standard_normal(10)
+        lib.ref_swing_free(h)
+        cases.append(dict(horizon=T, gait=gait, swing_config=cfg.tolist(), steps=steps))
+    return cases
+
+
+def main():
+    params = ingest.load_packaged()
+    rng = np.random.default_rng(20260925)
+    doc = dict(source="oracle/_ref/libref_refgen.so = reference GaitSchedule.cpp, SwingTrajectoryPlanner.cpp, CubicSpline.cpp, "
+                      "MultiCubicSpline.cpp, TargetTrajectoriesPublisher.cpp compiled in place (oracle/Makefile)",
+               gait=gait_cases(params, rng), modes=mode_cases(), targets=target_cases(params, rng), swing=swing_cases(params, rng))
+    out = ROOT / "tests/golden/ref_refgen.json"
+    out.write_text(json.dumps(doc))
+    print(out, out.stat().st_size, "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,8 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
-from hunter_bipedal_control_amd import ingest, refgen  # noqa: E402
+from hunter_bipedal_control_amd import ingest  # noqa: E402
+from oracle import refgen
 
 lib = C.CDLL(str(ROOT / "oracle/_ref/libref_splines.so"))
 _p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))

@@ -202,6 +202,23 @@ int emu_refgen(const hb_model* m, const hb::RefgenConfig* k, int n_ev, const dou
 }
 
 extern "C" {
+// planner step of one instance + the swing getters at m query times (tests/test_ref_refgen.py): target [2][22], out [m][4][6];
+// latest_stance [4][3] persists between calls like SwingTrajectoryPlanner::latestStanceposition_
+int emu_refgen_query(const hb_model* m, const hb::RefgenConfig* k, int n_ev, const double* ev, const int* modes, double t0, double horizon,
+                     const double* x_now, const double* cmd_vel, double* latest_stance, const double* times, int nt, double* target,
+                     double* out) {
+  DevModel d = make_dev_model(*m);
+  std::vector<double> phases(size_t(4) * (RG_MAX_EVENTS + 1) * RG_PHASE, 0.0), t(1024), knot_t(RG_MAX_KNOTS), knot_x(RG_MAX_KNOTS * HB_NX);
+  int n_nodes = 0, nk = 0;
+  const int st = refgen_plan(d, *k, n_ev, ev, modes, t0, horizon, x_now, cmd_vel, latest_stance, phases.data(), 1000, &n_nodes, t.data(), &nk,
+                             knot_t.data(), knot_x.data());
+  for (int i = 0; i < 2 * HB_NX; ++i) target[i] = knot_x[size_t(RG_MAX_KNOTS - 2) * HB_NX + i];
+  for (int j = 0; j < nt; ++j)
+    for (int f = 0; f < HB_NC; ++f)
+      rg_phase_eval(*k, phases.data() + (size_t(f) * (RG_MAX_EVENTS + 1) + rg_phase_index(ev, n_ev, times[j])) * RG_PHASE, times[j],
+                    out + (size_t(j) * HB_NC + f) * 6);
+  return st;
+}
 // swing reference of one phase record {t0, t1, p0[3], p1[3]} at m query times -> out[m][6] = [pos xyz, vel xyz]
 void emu_phase_eval(const hb::RefgenConfig* k, const double* ph, const double* t, int m, double* out) {
   for (int j = 0; j < m; ++j) rg_phase_eval(*k, ph, t[j], out + 6 * j);

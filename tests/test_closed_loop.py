@@ -1,10 +1,11 @@
 """Closed-loop rollouts.  The controller is only right if the robot stays up: the standing and
 trotting rollouts below exercise reference generation, SQP, policy evaluation, WBC and the joint command law together
-against the contact-consistent plant stub of hunter_bipedal_control_amd/plant.py."""
+against the contact-consistent plant stub of oracle/plant.py."""
 import numpy as np
 import pytest
 
 from closed_loop_oracle import OracleLoop
+from oracle.plant import Plant as _Plant
 
 
 def test_oracle_closed_loop_stands(params, oracle):
@@ -29,7 +30,7 @@ def test_device_closed_loop_matches_oracle_loop_then_trots(params, oracle):
     gaits = ["trot"] * B
     s = HunterSolver(params, batch=B, max_nodes=108)
     try:
-        dev = DeviceLoop(s, params, gaits, cmds)
+        dev = DeviceLoop(s, params, gaits, cmds, plant_factory=_Plant)
         twin = OracleLoop(oracle, params, "trot", cmds[0])
         for k in range(200):                                   # 0.4 s: stance, then the first swing phase
             qd_, vd_ = dev.step()
@@ -62,7 +63,7 @@ def test_device_closed_loop_with_the_state_estimator_in_the_loop(params):
     cmds = np.array([[0.2, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0]])
     s = HunterSolver(params, batch=B, max_nodes=108)
     try:
-        dev = DeviceLoop(s, params, ["trot", "stance"], cmds, use_estimator=True)
+        dev = DeviceLoop(s, params, ["trot", "stance"], cmds, use_estimator=True, plant_factory=_Plant)
         err_p, err_v = 0.0, 0.0
         for k in range(750):                                   # 1.5 s
             q, v = dev.step()
@@ -92,7 +93,7 @@ def test_closed_loop_over_the_lcm_wire_format_equals_the_array_loop(params):
     for use_lcm in (False, True):
         s = HunterSolver(params, batch=B, max_nodes=108)
         try:
-            dev = DeviceLoop(s, params, ["trot", "stance"], cmds, use_estimator=True, use_lcm=use_lcm)
+            dev = DeviceLoop(s, params, ["trot", "stance"], cmds, use_estimator=True, use_lcm=use_lcm, plant_factory=_Plant)
             qs = []
             for k in range(200):                               # 0.4 s: stance, then the first swing phase
                 q, v = dev.step()
@@ -110,14 +111,14 @@ def test_closed_loop_over_the_lcm_wire_format_equals_the_array_loop(params):
 def test_device_plant_matches_numpy_plant_and_resident_loop_trots(params):
     """hb_plant_step vs plant.py on the same torque sequence; then the fully device-resident loop (plant included) against
     the loop with the host-side plant."""
-    from hunter_bipedal_control_amd.plant import Plant
+    from oracle.plant import Plant
     from hunter_bipedal_control_amd.rollout import DeviceLoop, ResidentLoop, standing_configuration
     from hunter_bipedal_control_amd.solver import HunterSolver
     B = 4
     rng = np.random.default_rng(3)
     s = HunterSolver(params, batch=B, max_nodes=108)
     try:
-        q0 = standing_configuration(params, B)
+        q0 = standing_configuration(params, B, s)
         q0[:, 3:6] = 0.03 * rng.standard_normal((B, 3))
         v0 = 0.05 * rng.standard_normal((B, 16))
         zeros_u = np.zeros((B, 22))

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from hunter_bipedal_control_amd import workload
+from oracle import workloads
 
 ROOT = Path(__file__).resolve().parents[1]
 PKG = ROOT / "hunter_bipedal_control_amd"
@@ -34,6 +35,7 @@ def test_params_blob_matches_packaged_json(params):
     import ctypes as C
     import struct
     from hunter_bipedal_control_amd import abi
+    from oracle import workloads
     raw = PARAMS_BIN.read_bytes()
     magic, sm, sc, _ = struct.unpack("<4I", raw[:16])
     assert magic == abi.PARAMS_BLOB_MAGIC and sm == C.sizeof(abi.HbModel) and sc == C.sizeof(abi.HbConfig)
@@ -69,7 +71,7 @@ def test_cpp_adapter_control_loop_matches_ctypes_path(params, tmp_path, wbc_type
     from hunter_bipedal_control_amd.solver import HunterSolver
     exe = _build()
     B, N = 6, 40
-    refs, x0, rbd, t_now = workload.trot_batch(params, B, n_intervals=N)
+    refs, x0, rbd, t_now = workloads.trot_batch(params, B, n_intervals=N)
     nmax = refs["mode"].shape[1]
     prob, res = tmp_path / "problem.bin", tmp_path / "result.bin"
     _write_problem(prob, refs, x0, rbd, t_now, nmax)
@@ -102,7 +104,7 @@ def test_cpp_adapter_control_loop_matches_ctypes_path(params, tmp_path, wbc_type
 
 def test_cpp_gait_schedule_matches_host_reference_manager(params):
     """hunter_hip::GaitSchedule (C++) vs refgen.GaitSchedule (the Python restatement of GaitSchedule.cpp:57-161)."""
-    from hunter_bipedal_control_amd import refgen
+    from oracle import refgen, workloads
     exe = _build()
     windows = [(-1.4, 3.1), (0.05, 4.6), (0.41, 4.9), (2.0, 6.5)]
     args = [str(v) for w in windows for v in w]
@@ -124,7 +126,8 @@ def test_cpp_gait_schedule_matches_host_reference_manager(params):
 @pytest.mark.gpu
 def test_cpp_reference_manager_and_mpc_match_python_path(params, tmp_path):
     """GaitSchedule + ReferenceManager::preSolverRun + advanceMpc in C++ == the same through Python (device refgen)."""
-    from hunter_bipedal_control_amd import abi, refgen
+    from hunter_bipedal_control_amd import abi
+    from oracle import refgen, workloads
     from hunter_bipedal_control_amd.solver import HunterSolver
     exe = _build()
     B, N = 4, 40

@@ -2,7 +2,8 @@
 import numpy as np
 import pytest
 
-from hunter_bipedal_control_amd import abi, refgen, workload
+from hunter_bipedal_control_amd import abi
+from oracle import refgen, workloads
 
 pytestmark = pytest.mark.gpu
 
@@ -70,7 +71,7 @@ def test_estimate_feeds_mpc_and_wbc_without_leaving_the_device(params, oracle):
     the same estimates through the host-pointer entry points."""
     from hunter_bipedal_control_amd.solver import HunterSolver
     B, N = 8, 30
-    refs, x0, rbd0, t_now = workload.trot_batch(params, B, n_intervals=N)
+    refs, x0, rbd0, t_now = workloads.trot_batch(params, B, n_intervals=N)
     nmax = refs["mode"].shape[1]
     ecfg = abi.make_estimator_config(params)
     rng = np.random.default_rng(2)

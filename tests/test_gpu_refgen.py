@@ -3,7 +3,8 @@ SwitchedModelReferenceManager::modifyReferences / SwingTrajectoryPlanner (joint 
 import numpy as np
 import pytest
 
-from hunter_bipedal_control_amd import abi, refgen, workload
+from hunter_bipedal_control_amd import abi, workload
+from oracle import refgen
 
 pytestmark = pytest.mark.gpu
 GAITS = ["trot", "standing_trot", "flying_trot", "stance"]

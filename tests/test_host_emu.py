@@ -8,7 +8,8 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from hunter_bipedal_control_amd import abi, refgen, workload
+from hunter_bipedal_control_amd import abi, workload
+from oracle import refgen, workloads
 
 HERE = Path(__file__).resolve().parent / "host_emu"
 
@@ -58,7 +59,7 @@ def test_rnea_crba_match_oracle(params, oracle, emu):
 def test_device_sqp_iteration_matches_oracle(params, oracle, emu):
     lib, mdl, cfg = emu
     nmax = 40
-    refs, x0, _, _ = workload.trot_batch(params, 1, n_intervals=40, cmd_vel=(0.3, 0.0, 0.0, 0.1), max_nodes=nmax)
+    refs, x0, _, _ = workloads.trot_batch(params, 1, n_intervals=40, cmd_vel=(0.3, 0.0, 0.0, 0.1), max_nodes=nmax)
     N = int(refs["n_nodes"][0])
     xo = np.zeros((1, nmax + 1, 22)); uo = np.zeros((1, nmax, 22))
     xo[0], uo[0] = oracle.cold_start(refs["mode"][0], x0[0])
@@ -120,6 +121,7 @@ def test_device_hierarchical_wbc_matches_oracle(params, oracle, emu):
 def test_device_estimator_matches_oracle(params, oracle, emu):
     """hb_estimator.hpp (structured filter algebra, Cholesky instead of LU, forward momentum map) vs oracle/estimator.hpp."""
     from hunter_bipedal_control_amd import abi as _abi
+    from oracle import workloads
     lib, mdl, cfg = emu
     ecfg = _abi.make_estimator_config(params)
     rng = np.random.default_rng(17)
@@ -161,6 +163,7 @@ def test_device_reference_generation_matches_host_reference_manager(params, emu)
     """csrc/hb_refgen.hpp (targets, event-clipped grid, footholds, swing splines) vs refgen.py, which restates
     SwitchedModelReferenceManager::modifyReferences / SwingTrajectoryPlanner (joint_ik=False semantics)."""
     from hunter_bipedal_control_amd import abi as _abi
+    from oracle import workloads
     lib, mdl, cfg = emu
     c = params["config"]
     cases = [("trot", (0.3, 0.0, 0.0, 0.0), 0.1, 100), ("trot", (0.25, -0.1, 0.0, 0.4), 0.37, 60), ("standing_trot", (0.0, 0.0, 0.0, 0.0), 0.1, 40),
@@ -188,8 +191,8 @@ def test_device_reference_generation_matches_host_reference_manager(params, emu)
 def test_device_plant_step_matches_numpy_plant(params, oracle, emu):
     """csrc/hb_plant.hpp vs plant.py (numpy, rigid-body terms from the oracle) over a short torque-driven sequence with
     a contact switch."""
-    from hunter_bipedal_control_amd.plant import Plant
-    from hunter_bipedal_control_amd.rollout import standing_configuration
+    from closed_loop_oracle import standing_configuration
+    from oracle.plant import Plant
     lib, mdl, cfg = emu
     rng = np.random.default_rng(12)
 

@@ -5,7 +5,8 @@ centroidal velocity map the MPC tests already pin."""
 import numpy as np
 import pytest
 
-from hunter_bipedal_control_amd import abi, refgen
+from hunter_bipedal_control_amd import abi
+from oracle import refgen
 
 
 def _quat_from_zyx(zyx):

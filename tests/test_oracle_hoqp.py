@@ -2,7 +2,8 @@
 restated as a seeded property test, plus HierarchicalWbc properties."""
 import numpy as np
 
-from hunter_bipedal_control_amd import refgen, workload
+from hunter_bipedal_control_amd import workload
+from oracle import refgen
 
 
 def test_hoqp_two_task_properties(oracle):

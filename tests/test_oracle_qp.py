@@ -2,7 +2,8 @@
 import numpy as np
 from scipy.optimize import nnls
 
-from hunter_bipedal_control_amd import refgen, workload
+from hunter_bipedal_control_amd import workload
+from oracle import refgen
 
 
 def _check_kkt(A, b, eps, E, e, D, f, x, tol=1e-7):

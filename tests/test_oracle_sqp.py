@@ -1,7 +1,7 @@
 """CPU: the oracle's SQP pieces against dense linear algebra and convergence invariants."""
 import numpy as np
 
-from hunter_bipedal_control_amd import refgen, workload
+from oracle import refgen, workloads
 
 
 def test_riccati_matches_dense_kkt_solve(oracle):
@@ -41,7 +41,7 @@ def test_riccati_matches_dense_kkt_solve(oracle):
 def test_node_projection_is_least_squares_and_rank_structure(params, oracle):
     """D has the structural rank deficiency of two contact points per rigid foot; the projection satisfies the
     normal equations D'(D du + C dx + e) = 0 for every dx and D Pu = 0 (DESIGN.md "constraint projection")."""
-    refs, x0, _, _ = workload.trot_batch(params, 1, n_intervals=40, cmd_vel=(0.3, 0, 0, 0.1))
+    refs, x0, _, _ = workloads.trot_batch(params, 1, n_intervals=40, cmd_vel=(0.3, 0, 0, 0.1))
     rng = np.random.default_rng(3)
     expected = {3: (12, 10), 2: (14, 13), 1: (14, 13), 0: (16, 16)}  # mode -> (rows, rank) = forces 3*n_sw + velocity rank
     seen = set()
@@ -62,7 +62,7 @@ def test_node_projection_is_least_squares_and_rank_structure(params, oracle):
 
 
 def test_sqp_converges_and_merit_decreases(params, oracle):
-    refs, x0, _, _ = workload.trot_batch(params, 2, n_intervals=40, cmd_vel=(0.3, 0.0, 0.0, 0.1))
+    refs, x0, _, _ = workloads.trot_batch(params, 2, n_intervals=40, cmd_vel=(0.3, 0.0, 0.0, 0.1))
     x = np.zeros((2, 41, 22)); u = np.zeros((2, 40, 22))
     for i in range(2):
         x[i], u[i] = oracle.cold_start(refs["mode"][i], x0[i])
@@ -82,7 +82,7 @@ def test_config1_stance_is_an_equilibrium(params, oracle):
     """BASELINE config 1: single instance, STANCE, N = 20, targets = initial state: the weight-compensating input is
     nearly stationary — the contact forces carry the weight and the base stays put (the zero-velocity constraint's
     3 (p_z - 0.02) term, LeggedInterface.cpp:436-444, lifts the feet by the 18 mm they start below its set-point)."""
-    refs, x0, _, _ = workload.stance_batch(params, 1, n_intervals=20)
+    refs, x0, _, _ = workloads.stance_batch(params, 1, n_intervals=20)
     assert (refs["mode"][0] == 3).all() and refs["n_nodes"][0] == 20
     x = np.zeros((1, 21, 22)); u = np.zeros((1, 20, 22))
     x[0], u[0] = oracle.cold_start(refs["mode"][0], x0[0])

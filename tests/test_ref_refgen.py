@@ -1,0 +1,201 @@
+"""CPU: gait schedule, cmd_vel -> target trajectories and the swing planner pinned to the REFERENCE's own compiled code.
+
+tests/golden/ref_refgen.json holds outputs of oracle/_ref/libref_refgen.so — the reference's GaitSchedule.cpp,
+SwingTrajectoryPlanner.cpp, CubicSpline.cpp, MultiCubicSpline.cpp and TargetTrajectoriesPublisher.cpp (with the cmd_vel
+callback of its header) compiled in place (oracle/Makefile; fixture written by tests/golden/make_ref_refgen.py).  Held to
+them here:
+  * the product's host gait logic (hunter_bipedal_control_amd/gait.py) and the checker's (oracle/refgen.py): bit-exact
+    event times (same additions in the same order) and mode sequences over insert / get sequences,
+  * hunter_hip::GaitSchedule of the C++ adapter (include/hunter_hip.hpp): bit-exact as well,
+  * the command filter, dead band and height clamp: gait.CmdVelFilter + refgen.cmd_vel_targets, and the DEVICE code of
+    hb_refgen.hpp (rg_make_target, planner, spline getters) run on the host emulator,
+  * the swing planner over sequences of updates with persistent stance memory: refgen.SwingTrajectoryPlanner and the device
+    planner at 1e-12 (same arithmetic, different association order in the rotations).
+tests/test_gpu_refgen.py repeats the device part through the C ABI on the GPU.
+"""
+import ctypes as C
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from hunter_bipedal_control_amd import abi, gait
+from oracle import refgen
+
+HERE = Path(__file__).resolve().parent
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return json.loads((HERE / "golden/ref_refgen.json").read_text())
+
+
+@pytest.mark.parametrize("impl", ["product", "checker"])
+def test_gait_schedule_insert_get_sequences_bit_exact(golden, impl):
+    mod = gait if impl == "product" else refgen
+    n_ops = 0
+    for case in golden["gait"]:
+        tpl = case["template"]
+        gs = mod.GaitSchedule(mod.ModeSchedule(list(case["init"]["ev"]), list(case["init"]["modes"])),
+                              mod.ModeTemplate(tpl["switching_times"], tpl["modes"]), case["phase_transition_stance_time"])
+        for op in case["ops"]:
+            if op["op"] == "get":
+                ms = gs.get_mode_schedule(op["lower"], op["upper"])
+                assert ms.event_times == op["out"]["ev"], (impl, op["lower"])
+                assert list(ms.modes) == op["out"]["modes"]
+            else:
+                t = op["template"]
+                gs.insert_template(mod.ModeTemplate(t["switching_times"], t["modes"]), op["start"], op["final"])
+                assert op["rc"] == 0
+                assert gs.s.event_times == op["out"]["ev"] and list(gs.s.modes) == op["out"]["modes"]
+            n_ops += 1
+    assert n_ops > 80
+
+
+def test_mode_number_maps(golden):
+    for row in golden["modes"]:
+        assert [int(f) for f in gait.mode_to_contact_flags(row["mode"])] == row["flags"]
+        assert [int(f) for f in refgen.mode_to_contact_flags(row["mode"])] == row["flags"]
+        assert gait.contact_flags_to_mode(row["flags"]) == row["back"] == row["mode"]
+
+
+def test_cpp_adapter_gait_schedule_bit_exact(golden, tmp_path):
+    """hunter_hip::GaitSchedule driven with the same op sequences through a tiny test-only C shim."""
+    src = tmp_path / "gait_capi.cpp"
+    src.write_text('''
+#include "hunter_hip.hpp"
+using namespace hunter_hip;
+extern "C" {
+void* g_new(const double* ev, int n, const int* md, const double* tt, int nt, const int* tm, double pts) {
+  ModeSchedule s; s.eventTimes.assign(ev, ev + n); s.modeSequence.assign(md, md + n + 1);
+  ModeSequenceTemplate t; t.switchingTimes.assign(tt, tt + nt); t.modeSequence.assign(tm, tm + nt - 1);
+  return new GaitSchedule(s, t, pts);
+}
+void g_free(void* h) { delete static_cast<GaitSchedule*>(h); }
+int g_insert(void* h, const double* tt, int nt, const int* tm, double a, double b) {
+  ModeSequenceTemplate t; t.switchingTimes.assign(tt, tt + nt); t.modeSequence.assign(tm, tm + nt - 1);
+  try { static_cast<GaitSchedule*>(h)->insertModeSequenceTemplate(t, a, b); } catch (const std::exception&) { return -1; }
+  return 0;
+}
+int g_get(void* h, double lo, double hi, double* ev, int* md) {
+  try {
+    const ModeSchedule s = static_cast<GaitSchedule*>(h)->getModeSchedule(lo, hi);
+    for (size_t i = 0; i < s.eventTimes.size(); ++i) ev[i] = s.eventTimes[i];
+    for (size_t i = 0; i < s.modeSequence.size(); ++i) md[i] = s.modeSequence[i];
+    return int(s.eventTimes.size());
+  } catch (const std::exception&) { return -1; }
+}
+}
+''')
+    so = tmp_path / "libgait_capi.so"
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-fPIC", "-shared", "-I", str(HERE.parent / "include"), "-o", str(so), str(src)])
+    lib = C.CDLL(str(so))
+    DP, IP = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    d = lambda a: a.ctypes.data_as(DP)
+    i = lambda a: a.ctypes.data_as(IP)
+    lib.g_new.restype = C.c_void_p
+    lib.g_new.argtypes = [DP, C.c_int, IP, DP, C.c_int, IP, C.c_double]
+    lib.g_free.argtypes = [C.c_void_p]
+    lib.g_insert.argtypes = [C.c_void_p, DP, C.c_int, IP, C.c_double, C.c_double]
+    lib.g_get.argtypes = [C.c_void_p, C.c_double, C.c_double, DP, IP]
+    f64 = lambda v: np.asarray(v, dtype=np.float64)
+    i32 = lambda v: np.asarray(v, dtype=np.int32)
+    for case in golden["gait"]:
+        tpl = case["template"]
+        a, b, c_, e = f64(case["init"]["ev"]), i32(case["init"]["modes"]), f64(tpl["switching_times"]), i32(tpl["modes"])
+        h = C.c_void_p(lib.g_new(d(a), len(a), i(b), d(c_), len(c_), i(e), case["phase_transition_stance_time"]))
+        for op in case["ops"]:
+            if op["op"] == "get":
+                ev, md = np.zeros(512), np.zeros(513, dtype=np.int32)
+                n = lib.g_get(h, op["lower"], op["upper"], d(ev), i(md))
+                assert n == len(op["out"]["ev"])
+                assert ev[:n].tolist() == op["out"]["ev"] and md[:n + 1].tolist() == op["out"]["modes"]
+            else:
+                t = op["template"]
+                tt, tm = f64(t["switching_times"]), i32(t["modes"])
+                assert lib.g_insert(h, d(tt), len(tt), i(tm), op["start"], op["final"]) == op["rc"]
+        lib.g_free(h)
+
+
+def test_cmd_vel_filter_dead_band_and_height_clamp(golden):
+    """The reference's /cmd_vel callback: rate limiter (lastVel_), then cmdVelToTargetTrajectories."""
+    hit_dead_band = hit_clamp = 0
+    for case in golden["targets"]:
+        flt = gait.CmdVelFilter(1)
+        for m in case["msgs"]:
+            out = m["out"]
+            assert out["published"] == 1
+            f = flt([[m["cmd"][0], m["cmd"][1], m["cmd"][2]]])[0]
+            assert f.tolist() == out["filtered"]                     # clamped differences: exact
+            x = np.array(m["x"])
+            tt = refgen.cmd_vel_targets(m["t"], x, f, case["time_to_target"], case["com_height"], case["default_joints"])
+            assert tt.t[0] == out["t2"][0] and abs(tt.t[1] - out["t2"][1]) < 1e-15
+            ref = np.array(out["x2"])
+            assert np.abs(np.array(tt.x) - ref).max() < TOL
+            assert np.abs(gait.first_target_state(x, f)[[0, 1, 2, 9]] - ref[0][[0, 1, 2, 9]]).max() < TOL
+            hit_dead_band += int(ref[0][0] == 0.0 or ref[0][1] == 0.0)
+            hit_clamp += int(abs(abs(ref[0][8] - x[8]) - 0.04) < 1e-15)
+    assert hit_dead_band > 10 and hit_clamp > 10                     # the fixture exercises both branches
+
+
+def _planner_inputs(step):
+    sched = refgen.ModeSchedule(list(step["schedule"]["ev"]), list(step["schedule"]["modes"]))
+    targets = refgen.TargetTrajectories(list(step["target_t"]), [np.array(x) for x in step["target_x"]])
+    return sched, targets
+
+
+def test_swing_planner_update_sequences(golden, params):
+    """refgen.SwingTrajectoryPlanner vs SwingTrajectoryPlanner::update + getters over sequences of calls on one object."""
+    worst = 0.0
+    for case in golden["swing"]:
+        cfgv = case["swing_config"]
+        pl = refgen.SwingTrajectoryPlanner(dict(params["config"]["swing"], swing_height=cfgv[2], swing_time_scale=cfgv[3]))
+        pl.latest_stance = [np.zeros(3) for _ in range(4)]           # latestStanceposition_{} of a fresh reference object
+        for step in case["steps"]:
+            assert step["out"]["rc"] == 0
+            sched, targets = _planner_inputs(step)
+            pl.body_vel_cmd = np.array(step["body_vel_cmd"])
+            pl.current_feet = [np.array(step["feet"][3 * i:3 * i + 3]) for i in range(4)]
+            pl.update(sched, targets, step["t_init"])
+            ref = np.array(step["out"]["refs"])
+            got = np.array([[pl.swing_ref(f, t) for f in range(4)] for t in step["times"]])
+            worst = max(worst, np.abs(got - ref).max())
+    assert worst < TOL, worst
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    so = HERE / "host_emu/libhostemu.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", str(so), str(HERE / "host_emu/hostemu.cpp")])
+    return C.CDLL(str(so))
+
+
+def test_device_planner_and_targets_on_the_host_emulator(golden, params, emu_lib):
+    """csrc/hb_refgen.hpp (rg_make_target, refgen_plan, rg_phase_eval) against the reference-compiled vectors: the 2-knot
+    target and, over sequences of planner updates with persistent stance memory, the swing references at the query times."""
+    _p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    _pi = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    mdl = abi.make_model(params)
+    worst_sw = worst_tg = 0.0
+    for case in golden["swing"]:
+        rcfg = abi.make_refgen_config(params, joint_ik=False)
+        rcfg.swing_height, rcfg.swing_time_scale = case["swing_config"][2], case["swing_config"][3]
+        ls = np.zeros(12)
+        for step in case["steps"]:
+            ev = np.array(step["schedule"]["ev"], dtype=np.float64)
+            md = np.array(step["schedule"]["modes"], dtype=np.int32)
+            assert len(ev) <= abi.HB_MAX_EVENTS
+            x = np.array(step["x"])
+            cmd = np.array(step["body_vel_cmd"][:4])
+            times = np.array(step["times"], dtype=np.float64)
+            tgt = np.zeros((2, 22))
+            out = np.zeros((len(times), 4, 6))
+            rc = emu_lib.emu_refgen_query(C.byref(mdl), C.byref(rcfg), C.c_int(len(ev)), _p(ev), _pi(md), C.c_double(step["t_init"]),
+                                          C.c_double(case["horizon"]), _p(x), _p(cmd), _p(ls), _p(times), C.c_int(len(times)), _p(tgt), _p(out))
+            assert rc == 0
+            worst_tg = max(worst_tg, np.abs(tgt - np.array(step["target_x"])).max())
+            worst_sw = max(worst_sw, np.abs(out - np.array(step["out"]["refs"])).max())
+    assert worst_tg < TOL and worst_sw < TOL, (worst_tg, worst_sw)

@@ -14,7 +14,8 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from hunter_bipedal_control_amd import abi, ingest, refgen
+from hunter_bipedal_control_amd import abi, ingest
+from oracle import refgen
 
 HERE = Path(__file__).resolve().parent
 TOL = 1e-13

@@ -3,7 +3,8 @@ import sys
 import time
 sys.path.insert(0, '.')
 import numpy as np
-from hunter_bipedal_control_amd import abi, ingest, refgen, workload
+from hunter_bipedal_control_amd import abi, ingest, workload
+from oracle import refgen
 from hunter_bipedal_control_amd.solver import HunterSolver
 
 P = ingest.load_packaged()

@@ -1,12 +1,13 @@
 import sys, time, json
 sys.path.insert(0, '.')
 import numpy as np
-from hunter_bipedal_control_amd import ingest, workload
+from hunter_bipedal_control_amd import ingest
+from oracle import workloads
 from hunter_bipedal_control_amd.solver import HunterSolver
 P = ingest.load_packaged()
 for B in (256, 4096):
     N = 100
-    refs1, x01, rbd1, tn1 = workload.trot_batch(P, 64, n_intervals=N)
+    refs1, x01, rbd1, tn1 = workloads.trot_batch(P, 64, n_intervals=N)
     reps = B // 64
     refs = {k: np.concatenate([v]*reps) for k, v in refs1.items()}
     x0, rbd, tn = np.concatenate([x01]*reps), np.concatenate([rbd1]*reps), np.concatenate([tn1]*reps)

@@ -278,6 +278,148 @@ HB_HD int small_lsqp(const Ctx& cx, int n, int mA, const double* A, const double
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Generic HoQp cascade on small dense tasks — HoQp.cpp:21-198 for tasks {A x = b (least squares), D x <= f (slacked)} given as
+// plain matrices: the same building blocks the WBC cascade above uses from level 1 on (small_lsqp, householder_qr_pivot),
+// without the structure of the whole-body problem.  It exists so that the reference's own unit test
+// (legged_wbc/test/HoQp_test.cpp:18-55, two random tasks on four variables) can be run against DEVICE code (hb_hoqp_solve).
+// Level k solves, over  x = x_{k-1} + Z_k z  and the slack v >= 0 of its own inequalities,
+//     min 1/2 |A_k x - b_k|^2 + 1/2 |v|^2    s.t.  D_k x - v <= f_k,   D_j x <= f_j + v_j*  (j < k)
+// (HoQp::buildHMatrix / buildCVector / buildDMatrix / buildFVector), then Z_{k+1} = Z_k kernel(A_k Z_k).
+constexpr int HQ_N = 8;    // variables
+constexpr int HQ_M = 8;    // rows per block (A_k, D_k)
+constexpr int HQ_L = 3;    // levels
+struct HqLds {
+  static constexpr int Z = 0;                    // n x nz   (ld 12)
+  static constexpr int Zn = Z + HQ_N * 12;       // next kernel basis
+  static constexpr int AZ = Zn + HQ_N * 12;      // (mA + nv) x nvar (ld 12)
+  static constexpr int rhs = AZ + 2 * HQ_M * 12;
+  static constexpr int DZ = rhs + 2 * HQ_M;      // <= 40 x nvar (ld 12)
+  static constexpr int ft = DZ + 40 * 12;
+  static constexpr int zs = ft + 40;             // 12
+  static constexpr int qpw = zs + 12;            // 440
+  static constexpr int Tm = qpw + 440;           // 8 x 8
+  static constexpr int Qm = Tm + 64;             // 8 x 8
+  static constexpr int work = Qm + 64;           // 80
+  static constexpr int x = work + 80;            // 8
+  static constexpr int v = x + HQ_N;             // L x 8
+  static constexpr int total = v + HQ_L * HQ_M;
+};
+// A, D: [L][HQ_M][HQ_N]; b, f: [L][HQ_M]; x_levels: [L][HQ_N] solution after each level; slack: [L][HQ_M].
+// Returns 0 solved / 1 iteration limit / 2 infeasible / 3 size limit.
+template <class Ctx>
+HB_HD int hoqp_generic(const Ctx& cx, int n, int n_levels, const int* mA, const int* mD, const double* A, const double* b, const double* D,
+                       const double* f, double eps, int max_iter, double* x_levels, double* slack, double* lds) {
+  double* Z = lds + HqLds::Z;
+  double* Zn = lds + HqLds::Zn;
+  double* AZ = lds + HqLds::AZ;
+  double* rhs = lds + HqLds::rhs;
+  double* DZ = lds + HqLds::DZ;
+  double* ft = lds + HqLds::ft;
+  double* zs = lds + HqLds::zs;
+  double* qpw = lds + HqLds::qpw;
+  double* Tm = lds + HqLds::Tm;
+  double* Qm = lds + HqLds::Qm;
+  double* work = lds + HqLds::work;
+  double* x = lds + HqLds::x;
+  double* v = lds + HqLds::v;
+  for (int idx = cx.lane; idx < HQ_N * 12; idx += cx.nlanes) Z[idx] = (idx / 12 == idx % 12 && idx / 12 < n) ? 1.0 : 0.0;
+  for (int i = cx.lane; i < HQ_N; i += cx.nlanes) x[i] = 0.0;
+  for (int i = cx.lane; i < HQ_L * HQ_M; i += cx.nlanes) v[i] = 0.0;
+  cx.sync();
+  int nz = n, status = 0;
+  for (int k = 0; k < n_levels; ++k) {
+    const double* Ak = A + size_t(k) * HQ_M * HQ_N;
+    const double* Dk = D + size_t(k) * HQ_M * HQ_N;
+    const int ma = mA[k], nv = mD[k], nvar = nz + nv;
+    int n_rows = 2 * nv;
+    for (int j = 0; j < k; ++j) n_rows += mD[j];
+    if (nvar > 12 || n_rows > 40 || nvar == 0) { status = 3; break; }
+    // least-squares rows: [A_k Z | 0], then [0 | I]
+    for (int idx = cx.lane; idx < (ma + nv) * 12; idx += cx.nlanes) {
+      const int i = idx / 12, j = idx % 12;
+      double s = 0.0;
+      if (i < ma) {
+        if (j < nz)
+          for (int c = 0; c < n; ++c) s += Ak[i * HQ_N + c] * Z[c * 12 + j];
+      } else if (j == nz + (i - ma)) {
+        s = 1.0;
+      }
+      AZ[idx] = s;
+    }
+    for (int i = cx.lane; i < ma + nv; i += cx.nlanes) {
+      double s = 0.0;
+      if (i < ma) {
+        s = b[k * HQ_M + i];
+        for (int c = 0; c < n; ++c) s -= Ak[i * HQ_N + c] * x[c];
+      }
+      rhs[i] = s;
+    }
+    // constraint rows: own inequalities with slack, slack sign, the earlier levels' inequalities with their slack frozen
+    for (int idx = cx.lane; idx < n_rows * 12; idx += cx.nlanes) {
+      const int r = idx / 12, j = idx % 12;
+      double s = 0.0;
+      if (r < nv) {
+        if (j < nz) { for (int c = 0; c < n; ++c) s += Dk[r * HQ_N + c] * Z[c * 12 + j]; }
+        else if (j == nz + r) s = -1.0;
+      } else if (r < 2 * nv) {
+        if (j == nz + (r - nv)) s = -1.0;
+      } else {
+        int rr = r - 2 * nv, lv = 0;
+        while (rr >= mD[lv]) { rr -= mD[lv]; ++lv; }
+        if (j < nz) { const double* Dj = D + size_t(lv) * HQ_M * HQ_N; for (int c = 0; c < n; ++c) s += Dj[rr * HQ_N + c] * Z[c * 12 + j]; }
+      }
+      DZ[idx] = s;
+    }
+    for (int r = cx.lane; r < n_rows; r += cx.nlanes) {
+      double s = 0.0;
+      if (r < nv) {
+        s = f[k * HQ_M + r];
+        for (int c = 0; c < n; ++c) s -= Dk[r * HQ_N + c] * x[c];
+      } else if (r >= 2 * nv) {
+        int rr = r - 2 * nv, lv = 0;
+        while (rr >= mD[lv]) { rr -= mD[lv]; ++lv; }
+        const double* Dj = D + size_t(lv) * HQ_M * HQ_N;
+        s = f[lv * HQ_M + rr] + v[lv * HQ_M + rr];
+        for (int c = 0; c < n; ++c) s -= Dj[rr * HQ_N + c] * x[c];
+      }
+      ft[r] = s;
+    }
+    cx.sync();
+    const int rc = small_lsqp(cx, nvar, ma + nv, AZ, rhs, eps, n_rows, DZ, ft, max_iter, zs, qpw);
+    cx.sync();
+    if (rc > status) status = rc;
+    for (int i = cx.lane; i < n; i += cx.nlanes) {
+      double s = x[i];
+      for (int j = 0; j < nz; ++j) s += Z[i * 12 + j] * zs[j];
+      work[i] = s;
+    }
+    cx.sync();
+    for (int i = cx.lane; i < n; i += cx.nlanes) { x[i] = work[i]; x_levels[k * HQ_N + i] = work[i]; }
+    for (int i = cx.lane; i < nv; i += cx.nlanes) { v[k * HQ_M + i] = zs[nz + i]; slack[k * HQ_M + i] = zs[nz + i]; }
+    cx.sync();
+    // kernel of A_k Z (ma x nz): QR of its transpose (nz x ma)
+    if (ma > 0 && nz > 0 && k + 1 < n_levels) {
+      for (int idx = cx.lane; idx < nz * ma; idx += cx.nlanes) Tm[idx] = AZ[(idx % ma) * 12 + idx / ma];
+      cx.sync();
+      const int r = householder_qr_pivot(cx, Tm, nz, ma, ma, Qm, work);
+      const int nzn = nz - r;
+      for (int idx = cx.lane; idx < HQ_N * 12; idx += cx.nlanes) {
+        const int i = idx / 12, j = idx % 12;
+        double s = 0.0;
+        if (j < nzn && i < n)
+          for (int c = 0; c < nz; ++c) s += Z[i * 12 + c] * Qm[c * nz + r + j];
+        Zn[idx] = s;
+      }
+      cx.sync();
+      for (int idx = cx.lane; idx < HQ_N * 12; idx += cx.nlanes) Z[idx] = Zn[idx];
+      cx.sync();
+      nz = nzn;
+    }
+  }
+  return status;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 struct HoLds {
   static constexpr int J = 0;                     // 38x38
   static constexpr int R = J + NW * NW;           // 38x38
@@ -567,6 +709,22 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
 }
 
 #if defined(__HIPCC__)
+// generic cascade: one wave per problem (unit-level entry point hb_hoqp_solve)
+__global__ __launch_bounds__(64) void k_hoqp_generic(int n, int n_levels, const int* mA, const int* mD, const double* A, const double* b,
+                                                     const double* D, const double* f, double eps, int max_iter, double* x_levels,
+                                                     double* slack, int* status) {
+  __shared__ double lds[HqLds::total];
+  const int p = blockIdx.x;
+  struct Cx {
+    int lane;
+    static constexpr int nlanes = 64;
+    __device__ void sync() const { __syncthreads(); }
+  } cx{int(threadIdx.x)};
+  const size_t o = size_t(p) * HQ_L;
+  const int rc = hoqp_generic(cx, n, n_levels, mA, mD, A + o * HQ_M * HQ_N, b + o * HQ_M, D + o * HQ_M * HQ_N, f + o * HQ_M, eps, max_iter,
+                              x_levels + o * HQ_N, slack + o * HQ_M, lds);
+  if (cx.lane == 0) status[p] = rc;
+}
 __global__ __launch_bounds__(64) void k_hwbc(WbcBatch w, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
   const int inst = blockIdx.x;
   extern __shared__ __attribute__((aligned(16))) double lds_h[];

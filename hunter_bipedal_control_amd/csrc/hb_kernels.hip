@@ -1593,6 +1593,47 @@ int32_t hb_eval_rbd(hb_ctx* ctx, int32_t n, const double* rbd, double* Mo, doubl
   return HB_OK;
 }
 
+int32_t hb_hoqp_solve(hb_ctx* ctx, int32_t n_problems, int32_t n_vars, int32_t n_levels, const int32_t* m_eq, const int32_t* m_in,
+                      const double* A, const double* b, const double* D, const double* f, double* x, double* slack, int32_t* status) {
+  if (!ctx || n_problems <= 0 || n_vars <= 0 || n_vars > HQ_N || n_levels <= 0 || n_levels > HQ_L || !m_eq || !m_in || !A || !b || !D || !f ||
+      !x || !slack || !status)
+    return HB_ERR_ARG;
+  for (int l = 0; l < n_levels; ++l)
+    if (m_eq[l] < 0 || m_eq[l] > HQ_M || m_in[l] < 0 || m_in[l] > HQ_M) {
+      ctx->err = "hb_hoqp_solve: at most 8 equality-type and 8 inequality rows per level";
+      return HB_ERR_ARG;
+    }
+  HB_HIP(hipSetDevice(ctx->device));
+  const size_t P = size_t(n_problems), nm = P * HQ_L * HQ_M * HQ_N, nv = P * HQ_L * HQ_M, nx = P * HQ_L * HQ_N;
+  double *dA = nullptr, *dD = nullptr, *db = nullptr, *df = nullptr, *dx = nullptr, *ds = nullptr;
+  int *dma = nullptr, *dmd = nullptr, *dst = nullptr;
+  hipError_t e = hipSuccess;
+  auto al = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+  al(reinterpret_cast<void**>(&dA), nm * 8); al(reinterpret_cast<void**>(&dD), nm * 8); al(reinterpret_cast<void**>(&db), nv * 8);
+  al(reinterpret_cast<void**>(&df), nv * 8); al(reinterpret_cast<void**>(&dx), nx * 8); al(reinterpret_cast<void**>(&ds), nv * 8);
+  al(reinterpret_cast<void**>(&dma), HQ_L * sizeof(int)); al(reinterpret_cast<void**>(&dmd), HQ_L * sizeof(int));
+  al(reinterpret_cast<void**>(&dst), P * sizeof(int));
+  auto cp = [&](void* d, const void* h, size_t bytes) { if (e == hipSuccess) e = hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); };
+  cp(dA, A, nm * 8); cp(dD, D, nm * 8); cp(db, b, nv * 8); cp(df, f, nv * 8);
+  cp(dma, m_eq, size_t(n_levels) * sizeof(int)); cp(dmd, m_in, size_t(n_levels) * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(dx, 0, nx * 8);
+  if (e == hipSuccess) e = hipMemset(ds, 0, nv * 8);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_hoqp_generic, dim3(n_problems), dim3(64), 0, ctx->s_wbc, n_vars, n_levels, dma, dmd, dA, db, dD, df, ctx->hconfig.wbc_eps,
+                       4 * ctx->hconfig.wbc_max_iter, dx, ds, dst);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->s_wbc);
+  if (e == hipSuccess) e = hipMemcpy(x, dx, nx * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(slack, ds, nv * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(status, dst, P * sizeof(int), hipMemcpyDeviceToHost);
+  for (void* p : {static_cast<void*>(dA), static_cast<void*>(dD), static_cast<void*>(db), static_cast<void*>(df), static_cast<void*>(dx),
+                  static_cast<void*>(ds), static_cast<void*>(dma), static_cast<void*>(dmd), static_cast<void*>(dst)})
+    if (p) (void)hipFree(p);
+  if (e != hipSuccess) { ctx->err = std::string("hb_hoqp_solve: ") + hipGetErrorString(e); return HB_ERR_DEVICE; }
+  return HB_OK;
+}
+
 int32_t hb_centroidal_state_from_rbd(hb_ctx* ctx, int32_t n, const double* rbd, double* x) {
   if (!ctx || !rbd || !x || n <= 0) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "hb_sync", "hb_get_stats", "hb_get_input_cost", "hb_version", "hb_eval_flow_map", "hb_eval_foot_kinematics",
     "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
     "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd", "hb_plant_reset", "hb_plant_step",
-    "hb_plant_get_state",
+    "hb_plant_get_state", "hb_hoqp_solve",
 ]
 # include/hunter_lcm.h
 LCM_SYMBOLS = ["hb_lcm_fingerprint", "hb_lcm_encoded_size", "hb_lcm_field_count", "hb_lcm_encode", "hb_lcm_decode", "hb_lcm_frame",
@@ -357,6 +357,25 @@ class HunterSolver:
         x = np.zeros((rbd.shape[0], 22))
         self._check(self.lib.hb_centroidal_state_from_rbd(self.ctx, C.c_int32(rbd.shape[0]), _p(rbd), _p(x)), "hb_centroidal_state_from_rbd")
         return x
+
+    def hoqp_solve(self, tasks_batch):
+        """Generic hierarchical QP cascade (hb_hoqp_solve).  tasks_batch: list of problems, each a list (highest priority
+        first) of dicts A, b, D, f with the same row counts per level across the batch.  -> x [P][L][n], slack list per
+        level [P][m_in[l]], status [P]."""
+        P, L = len(tasks_batch), len(tasks_batch[0])
+        n = tasks_batch[0][0]["A"].shape[1]
+        m_eq = np.array([tasks_batch[0][l]["A"].shape[0] for l in range(L)], dtype=np.int32)
+        m_in = np.array([tasks_batch[0][l]["D"].shape[0] for l in range(L)], dtype=np.int32)
+        A, D = np.zeros((P, 3, 8, 8)), np.zeros((P, 3, 8, 8))
+        b, f = np.zeros((P, 3, 8)), np.zeros((P, 3, 8))
+        for p, tasks in enumerate(tasks_batch):
+            for l, t in enumerate(tasks):
+                A[p, l, :m_eq[l], :n], b[p, l, :m_eq[l]] = t["A"], t["b"]
+                D[p, l, :m_in[l], :n], f[p, l, :m_in[l]] = t["D"], t["f"]
+        x, slack, status = np.zeros((P, 3, 8)), np.zeros((P, 3, 8)), np.zeros(P, dtype=np.int32)
+        self._check(self.lib.hb_hoqp_solve(self.ctx, C.c_int32(P), C.c_int32(n), C.c_int32(L), _p(m_eq), _p(m_in), _p(A), _p(b), _p(D), _p(f),
+                                           _p(x), _p(slack), _p(status)), "hb_hoqp_solve")
+        return x[:, :L, :n], [slack[:, l, :m_in[l]] for l in range(L)], status
 
     def riccati_solve(self, A, Bm, b, Q, R, P, q, r, dx0):
         A, Bm, b, Q, R, P, q, r, dx0 = map(_f64, (A, Bm, b, Q, R, P, q, r, dx0))

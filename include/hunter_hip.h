@@ -313,6 +313,15 @@ int32_t hb_centroidal_state_from_rbd(hb_ctx* ctx, int32_t n, const double* rbd /
 int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, int32_t nu, const double* A, const double* B,
                          const double* b, const double* Q, const double* R, const double* P, const double* q,
                          const double* r, const double* dx0, double* dx /*[n][N+1][22]*/, double* du /*[n][N][nu]*/);
+/* Generic hierarchical QP cascade on small dense tasks (HoQp.cpp:21-198; HoQp.h:24-89): n_problems independent stacks of
+ * n_levels <= 3 tasks {A x = b in the least-squares sense, D x <= f with slack} on n_vars <= 8 variables, m_eq[l] / m_in[l]
+ * <= 8 rows per level (the same shape for every problem).  Blocks are padded: A, D [n_problems][3][8][8] row-major, b, f
+ * [n_problems][3][8].  Outputs: x [n_problems][3][8] = solution after each level (HoQp::getSolutions of that level),
+ * slack [n_problems][3][8] = the level's own slack (HoQp::getStackedSlackSolutions tail), status [n_problems] = hb_inst_status.
+ * The device counterpart of the reference's unit test legged_wbc/test/HoQp_test.cpp:18-55; runs the building blocks of the
+ * HierarchicalWbc kernel (hb_config.wbc_type = 1) on plain matrices. */
+int32_t hb_hoqp_solve(hb_ctx* ctx, int32_t n_problems, int32_t n_vars, int32_t n_levels, const int32_t* m_eq, const int32_t* m_in,
+                      const double* A, const double* b, const double* D, const double* f, double* x, double* slack, int32_t* status);
 /* QP step of the last SQP iteration (before the line search scaled it): dx[batch][max_nodes+1][22],
  * du[batch][max_nodes][22]; either may be NULL. */
 int32_t hb_mpc_get_step(hb_ctx* ctx, double* dx, double* du);

@@ -198,7 +198,16 @@ def swing_cases(params, rng):
                 lib.ref_swing_eval(h, _d(times), len(times), _d(out))
                 for leg in range(4):
                     lib.ref_swing_start_stop(h, leg, t + 0.25 * T, _d(ss[leg]))
-            steps.append(dict(t_init=t, x=x.tolist(), feet=feet.tolist(), body_vel_cmd=body_cmd.tolist(), schedule=sched,
+            # the shooting grid of this call (checker's event-clipped discretisation) and the reference's getters on every 5th node
+            # (+1e-9, the offset the node tables are built with): what tests/test_gpu_refgen.py holds hb_refgen_update's tables to
+            node_t = refgen.time_discretization(t, t + T, c["dt"], list(ev))
+            node_idx = np.arange(0, len(node_t) - 1, 5)
+            node_q = (node_t[node_idx] + 1e-9).astype(float)
+            node_refs = np.zeros((len(node_q), 4, 6))
+            if rc == 0 and k < 2:
+                lib.ref_swing_eval(h, _d(node_q), len(node_q), _d(node_refs))
+            steps.append(dict(t_init=t, x=x.tolist(), node_idx=node_idx.tolist() if k < 2 else [], n_nodes=len(node_t) - 1,
+                              node_refs=node_refs.tolist() if k < 2 else [], feet=feet.tolist(), body_vel_cmd=body_cmd.tolist(), schedule=sched,
                               target_t=t2.tolist(), target_x=x2.reshape(2, 22).tolist(), times=times.tolist(),
                               out=dict(rc=rc, refs=out.tolist(), start_stop_at_quarter=ss.tolist())))
             # advance: the robot moves with the command, joints wobble; a later call sees the same planner object

@@ -545,3 +545,27 @@ def test_wbc_desired_orientation_equal_to_measured(params, oracle):
     assert status.max() == 0 and np.isfinite(sol).all() and np.array_equal(status, sto)
     scale = np.maximum(1.0, np.abs(so).max(axis=1, keepdims=True))
     assert (np.abs(sol - so) / scale).max() < 1e-6
+
+
+def test_hoqp_two_task_properties_on_device(params, oracle):
+    """The reference's own unit test, legged_wbc/test/HoQp_test.cpp:18-55 (TEST(HoQP, twoTask)), against DEVICE code: generic
+    random two-task problems (2 equality-type + 2 inequality rows per task, 4 variables; every third one with the test's
+    all-ones second task) through hb_hoqp_solve — the cascade built from the blocks of the HierarchicalWbc kernel.  Checked:
+    the reference test's assertions (1e-6), and agreement with the oracle cascade."""
+    from test_oracle_hoqp import _two_task_problem, check_two_task_properties
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    rng = np.random.default_rng(0)
+    problems = [_two_task_problem(rng, ones_variant=(k % 3 == 0)) for k in range(96)]
+    s = HunterSolver(params, batch=1, max_nodes=4)
+    try:
+        x, slack, status = s.hoqp_solve(problems)
+    finally:
+        s.close()
+    assert status.max() == 0
+    worst = 0.0
+    for p, tasks in enumerate(problems):
+        check_two_task_properties(tasks, x[p, 0], x[p, 1], slack[0][p], slack[1][p])
+        xo1, _, st = oracle.hoqp(tasks)
+        assert st == 0
+        worst = max(worst, np.abs(x[p, 1] - xo1).max())
+    assert worst < 1e-6, worst

@@ -57,6 +57,45 @@ def test_device_reference_generation_matches_host_over_two_calls(params):
         s.close()
 
 
+def test_device_tables_against_reference_compiled_vectors(params):
+    """hb_refgen_update through the C ABI vs tests/golden/ref_refgen.json (outputs of the reference's own
+    TargetTrajectoriesPublisher.cpp / SwingTrajectoryPlanner.cpp compiled in place): first node's target state = the
+    dead-banded, height-clamped knot, and the swing references of every 5th node, over the first two planner updates of
+    every case (the second one starts from the stance memory the first one left on the device)."""
+    import json
+    from pathlib import Path
+    from hunter_bipedal_control_amd import gait
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    golden = json.loads((Path(__file__).resolve().parent / "golden/ref_refgen.json").read_text())
+    cases = golden["swing"]
+    B = len(cases)
+    nmax = max(st["n_nodes"] for c in cases for st in c["steps"][:2]) + 4
+    c0 = params["config"]
+    worst_sw = worst_x = 0.0
+    # one solver per horizon value is not needed: the horizon is a call argument, but it is one scalar per call -> group by it
+    for T in sorted({c["horizon"] for c in cases}):
+        idx = [i for i, c in enumerate(cases) if c["horizon"] == T]
+        s = HunterSolver(params, batch=len(idx), max_nodes=nmax)
+        try:
+            rcfg = abi.make_refgen_config(params, joint_ik=False)
+            s.refgen_reset(rcfg, latest_stance=np.zeros((len(idx), 4, 3)))     # latestStanceposition_{} of a fresh reference object
+            for k in range(2):
+                steps = [cases[i]["steps"][k] for i in idx]
+                s.refgen_set_schedule([gait.ModeSchedule(st["schedule"]["ev"], st["schedule"]["modes"]) for st in steps])
+                status = s.refgen_update(np.array([st["t_init"] for st in steps]), T, np.array([st["x"] for st in steps]),
+                                         np.array([st["body_vel_cmd"][:4] for st in steps]))
+                assert status.max() == 0
+                got = s.get_references()
+                for j, st in enumerate(steps):
+                    assert got["n_nodes"][j] == st["n_nodes"]
+                    worst_x = max(worst_x, np.abs(got["x_ref"][j][0][:12] - np.array(st["target_x"][0])[:12]).max())
+                    worst_sw = max(worst_sw, np.abs(got["swing"][j][st["node_idx"]] - np.array(st["node_refs"])).max())
+        finally:
+            s.close()
+    assert worst_x < 1e-12 and worst_sw < 1e-12, (worst_x, worst_sw)
+    assert abs(c0["dt"] - 0.015) < 1e-15
+
+
 def test_mpc_on_device_generated_references_equals_uploaded_references(params):
     """estimate/observe -> references -> MPC without the tables ever crossing PCIe."""
     from hunter_bipedal_control_amd.solver import HunterSolver

@@ -84,3 +84,57 @@ def test_hoqp_level1_against_scipy(params, oracle):
         assert r.success or r.fun < 1e-10
         assert abs(0.5 * np.sum((A1 @ x2 - b1) ** 2) - r.fun) < 1e-7 * max(1.0, r.fun)
         assert np.abs(t[0]["A"] @ (x2 - x1)).max() < 1e-9          # stays in the kernel of the higher task
+
+
+def _two_task_problem(rng, ones_variant):
+    """HoQp_test.cpp:18-55: task0 random A (2x4), b = 1, random D (2x4), f = 1; task1 = task0 with A = ones (ones_variant) —
+    or, for the seeded sweep, fully random second task."""
+    t0 = dict(A=rng.uniform(-1, 1, (2, 4)), b=np.ones(2), D=rng.uniform(-1, 1, (2, 4)), f=np.ones(2))
+    if ones_variant:
+        t1 = dict(A=np.ones((2, 4)), b=t0["b"].copy(), D=t0["D"].copy(), f=t0["f"].copy())
+    else:
+        t1 = dict(A=rng.uniform(-1, 1, (2, 4)), b=rng.uniform(-1, 1, 2), D=rng.uniform(-1, 1, (2, 4)), f=rng.uniform(0, 1, 2))
+    return [t0, t1]
+
+
+def check_two_task_properties(tasks, x0, x1, slack0, slack1, prec=1e-6):
+    """The assertions of TEST(HoQP, twoTask): equality satisfaction under strict priority when the slack vanishes, and
+    D x <= f + slack on both levels."""
+    t0, t1 = tasks
+    if np.abs(slack0).max() < prec:
+        assert np.abs(t0["A"] @ x0 - t0["b"]).max() < prec * max(1.0, np.abs(t0["b"]).max())
+    if np.abs(slack1).max() < prec and np.abs(slack0).max() < prec:
+        assert np.abs(t0["A"] @ x1 - t0["b"]).max() < prec * max(1.0, np.abs(t0["b"]).max())
+    assert (t0["D"] @ x0 <= t0["f"] + slack0 + prec).all()
+    assert (t1["D"] @ x1 <= t1["f"] + slack1 + prec).all()
+    assert (t0["D"] @ x1 <= t0["f"] + slack0 + prec).all()       # the higher level's inequalities stay hard below it
+    assert (slack0 >= -prec).all() and (slack1 >= -prec).all()
+
+
+def test_device_generic_cascade_on_host_emulator_matches_oracle(oracle):
+    """csrc/hb_hoqp.hpp::hoqp_generic (the device code, run on the host emulator) vs the oracle cascade on the reference's
+    two-task shape: same solutions and slacks, and the reference test's properties."""
+    import ctypes as C
+    import subprocess
+    from pathlib import Path
+    here = Path(__file__).resolve().parent
+    so = here / "host_emu/libhostemu.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", str(so), str(here / "host_emu/hostemu.cpp")])
+    lib = C.CDLL(str(so))
+    _p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(0)
+    for trial in range(30):
+        tasks = _two_task_problem(rng, ones_variant=(trial % 3 == 0))
+        A, D, b, f = np.zeros((3, 8, 8)), np.zeros((3, 8, 8)), np.zeros((3, 8)), np.zeros((3, 8))
+        for l, t in enumerate(tasks):
+            A[l, :2, :4], b[l, :2], D[l, :2, :4], f[l, :2] = t["A"], t["b"], t["D"], t["f"]
+        mA, mD = np.array([2, 2, 0], dtype=np.int32), np.array([2, 2, 0], dtype=np.int32)
+        x, slack = np.zeros((3, 8)), np.zeros((3, 8))
+        rc = lib.emu_hoqp_generic(4, 2, _p(mA), _p(mD), _p(A), _p(b), _p(D), _p(f), C.c_double(1e-8), C.c_int(500), _p(x), _p(slack))
+        assert rc == 0
+        xo0, so0, st0 = oracle.hoqp(tasks[:1])
+        xo1, so1, st1 = oracle.hoqp(tasks)
+        assert st0 == 0 and st1 == 0
+        assert np.abs(x[0, :4] - xo0).max() < 1e-6 and np.abs(x[1, :4] - xo1).max() < 1e-6
+        assert np.abs(slack[0, :2] - so0[:2]).max() < 1e-6
+        check_two_task_properties(tasks, x[0, :4], x[1, :4], slack[0, :2], slack[1, :2])

@@ -122,7 +122,10 @@ def make_config(params: dict, **overrides) -> HbConfig:
     out.wbc_max_iter = 120
     _fill(out.default_joint_state, c["default_joint_state"])
     for k, v in overrides.items():
-        setattr(out, k, v)
+        if isinstance(v, (list, tuple)):
+            _fill(getattr(out, k), v)
+        else:
+            setattr(out, k, v)
     return out
 
 
@@ -141,12 +144,13 @@ def make_estimator_config(params: dict, **overrides) -> HbEstimatorConfig:
 
 class HbJointGains(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("kp_big_stance", "kp_big_swing", "kd_big", "kp_small_stance", "kp_small_swing", "kd_small",
-                                          "kd_feet")]
+                                          "kd_feet", "kp_position", "kd_position")]
 
 
 def make_joint_gains(**overrides) -> HbJointGains:
     """Defaults of legged_controllers/cfg/Tutorials.cfg:6-16 (dynamic_reconfigure)."""
-    d = dict(kp_big_stance=40.0, kp_big_swing=30.0, kd_big=2.0, kp_small_stance=30.0, kp_small_swing=20.0, kd_small=2.0, kd_feet=0.01)
+    d = dict(kp_big_stance=40.0, kp_big_swing=30.0, kd_big=2.0, kp_small_stance=30.0, kp_small_swing=20.0, kd_small=2.0, kd_feet=0.01,
+             kp_position=10.0, kd_position=3.0)
     d.update(overrides)
     out = HbJointGains()
     for k, v in d.items():
@@ -155,6 +159,9 @@ def make_joint_gains(**overrides) -> HbJointGains:
 
 
 HB_MAX_EVENTS = 64
+# hb_status / per-instance status words (include/hunter_hip.h)
+HB_OK, HB_ERR_ARG, HB_ERR_DEVICE, HB_ERR_STATE, HB_ERR_NO_GPU = 0, -1, -2, -3, -4
+HB_INST_OK, HB_INST_MAXITER, HB_INST_INFEASIBLE, HB_INST_NAN = 0, 1, 2, 3
 
 
 class RefgenConfig(C.Structure):

@@ -715,11 +715,7 @@ __global__ __launch_bounds__(64) void k_hoqp_generic(int n, int n_levels, const 
                                                      double* slack, int* status) {
   __shared__ double lds[HqLds::total];
   const int p = blockIdx.x;
-  struct Cx {
-    int lane;
-    static constexpr int nlanes = 64;
-    __device__ void sync() const { __syncthreads(); }
-  } cx{int(threadIdx.x)};
+  const WbcDeviceCtx cx;
   const size_t o = size_t(p) * HQ_L;
   const int rc = hoqp_generic(cx, n, n_levels, mA, mD, A + o * HQ_M * HQ_N, b + o * HQ_M, D + o * HQ_M * HQ_N, f + o * HQ_M, eps, max_iter,
                               x_levels + o * HQ_N, slack + o * HQ_M, lds);

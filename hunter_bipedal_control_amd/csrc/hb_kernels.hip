@@ -7,6 +7,7 @@
 #include <cstring>
 #include <string>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "hb_host.hpp"
@@ -63,6 +64,14 @@ struct Batch {
   int* accepted;    // [B]
   double* perf;     // [B][4] merit dyn eq step
   int* ric_fail;    // [B]
+  int* mpc_status;  // [B] hb_inst_status of the last MPC call
+  // iterate of the previous MPC call on ITS time grid (warm start across calls, k_warm_shift); x / u and xp / up swap roles
+  double* xp;       // [B][Nmax+1][22]
+  double* up;       // [B][Nmax][22]
+  double* tp;       // [B][Nmax+1]
+  int* modep;       // [B][Nmax]
+  int* np_nodes;    // [B]
+  int* grid_dirty;  // [B] the node tables changed since the iterate was last brought onto them
 };
 
 __global__ void k_set_x0(Batch b) {
@@ -73,9 +82,11 @@ __global__ void k_set_x0(Batch b) {
 }
 
 // cold start: x_k = x0, u_k = weight compensation of mode_k (LeggedRobotInitializer.cpp:67-77)
-__global__ void k_cold_start(Batch b, const DevModel* __restrict__ M) {
+__global__ void k_cold_start(Batch b, const DevModel* __restrict__ M, const unsigned char* mask) {
   const int k = blockIdx.x, inst = blockIdx.y;
   const int lane = threadIdx.x;
+  if (mask && !mask[inst]) return;
+  if (k == 0 && lane == 0) { b.grid_dirty[inst] = 0; b.mpc_status[inst] = HB_INST_OK; }
   if (k > b.n_nodes[inst]) return;
   double* xk = b.x + (size_t(inst) * (b.Nmax + 1) + k) * HB_NX;
   if (lane < HB_NX) xk[lane] = b.x0[inst * HB_NX + lane];
@@ -88,6 +99,82 @@ __global__ void k_cold_start(Batch b, const DevModel* __restrict__ M) {
     if (lane < 12 && lane % 3 == 2 && cf[lane / 3]) v = M->total_mass * M->gravity / nc;
     b.u[(size_t(inst) * b.Nmax + k) * HB_NU + lane] = v;
   }
+}
+
+// Warm start across MPC calls: the previous call's iterate (xp, up on the grid tp / modep / np_nodes) is brought onto the new node
+// tables — OCS2 SqpSolver::initializeStateInputTrajectories [OCS2-knowledge]: inside the previous horizon the state at every
+// new node time and the input at the start of every new interval are interpolated linearly from the previous solution; beyond
+// it the initializer takes over (LeggedRobotInitializer.cpp:67-77: the state is carried on, the input is the weight
+// compensation of the interval's mode).  Defined here: an input is HELD instead of interpolated across a mode
+// switch of the previous solution (the neighbouring node belongs to another contact configuration), and the last previous
+// interval holds its input.  One thread per (instance, node); instances whose tables did not change are left alone.
+__global__ void k_warm_shift(Batch b, const DevModel* __restrict__ M) {
+  const int k = blockIdx.x, inst = blockIdx.y, lane = threadIdx.x;
+  if (!b.grid_dirty[inst]) return;
+  const int n = b.n_nodes[inst], np = b.np_nodes[inst];
+  if (k > n) return;
+  const size_t N = b.Nmax;
+  const double* tp = b.tp + size_t(inst) * (N + 1);
+  const double* xp = b.xp + size_t(inst) * (N + 1) * HB_NX;
+  const double* up = b.up + size_t(inst) * N * HB_NU;
+  const int* mp = b.modep + size_t(inst) * N;
+  const double t = b.t[size_t(inst) * (N + 1) + k];
+  double* xk = b.x + (size_t(inst) * (N + 1) + k) * HB_NX;
+  // old interval that contains t: tp[i] <= t < tp[i+1] (clamped)
+  int i = 0;
+  while (i + 1 < np && tp[i + 1] <= t) ++i;
+  if (lane < HB_NX) {
+    double v;
+    if (np <= 0 || t >= tp[np]) v = xp[(np > 0 ? np : 0) * HB_NX + lane];
+    else if (t <= tp[0]) v = xp[lane];
+    else {
+      const double a = (t - tp[i]) / (tp[i + 1] - tp[i]);
+      v = (1.0 - a) * xp[i * HB_NX + lane] + a * xp[(i + 1) * HB_NX + lane];
+    }
+    xk[lane] = v;
+  }
+  if (k < n && lane < HB_NU) {
+    double v;
+    if (np <= 0 || t >= tp[np]) {  // beyond the previous horizon: weight compensation of this interval's mode
+      bool cf[HB_NC];
+      mode_flags(b.mode[size_t(inst) * N + k], cf);
+      int nc = 0;
+      for (int c = 0; c < HB_NC; ++c) nc += cf[c];
+      v = (lane < 12 && lane % 3 == 2 && cf[lane / 3]) ? M->total_mass * M->gravity / nc : 0.0;
+    } else if (t <= tp[0]) {
+      v = up[lane];
+    } else if (i + 1 >= np || mp[i + 1] != mp[i]) {
+      v = up[i * HB_NU + lane];
+    } else {
+      const double a = (t - tp[i]) / (tp[i + 1] - tp[i]);
+      v = (1.0 - a) * up[i * HB_NU + lane] + a * up[(i + 1) * HB_NU + lane];
+    }
+    b.u[(size_t(inst) * N + k) * HB_NU + lane] = v;
+  }
+}
+// instances whose tables did NOT change keep their iterate: copy it over from the previous buffers (the host swapped them)
+__global__ void k_warm_keep(Batch b) {
+  const int k = blockIdx.x, inst = blockIdx.y, lane = threadIdx.x;
+  if (b.grid_dirty[inst] || k > b.Nmax) return;
+  const size_t N = b.Nmax;
+  if (lane < HB_NX) b.x[(size_t(inst) * (N + 1) + k) * HB_NX + lane] = b.xp[(size_t(inst) * (N + 1) + k) * HB_NX + lane];
+  if (k < b.Nmax && lane < HB_NU) b.u[(size_t(inst) * N + k) * HB_NU + lane] = b.up[(size_t(inst) * N + k) * HB_NU + lane];
+}
+__global__ void k_grid_clean(Batch b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < b.B) b.grid_dirty[i] = 0;
+}
+// per-instance status word of an MPC call: a failed Riccati pivot or a non-finite performance index is HB_INST_NAN (the
+// step was not taken), a line search that rejected every step size is HB_INST_MAXITER (iterate unchanged)
+__global__ void k_mpc_status(Batch b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.B) return;
+  const double* p = b.perf + size_t(i) * 4;
+  const bool finite = isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]) && isfinite(b.acc[i * 4 + 0]) && isfinite(b.acc[i * 4 + 1]);
+  int st = HB_INST_OK;
+  if (b.ric_fail[i] || !finite) st = HB_INST_NAN;
+  else if (!b.accepted[i]) st = HB_INST_MAXITER;
+  b.mpc_status[i] = st;
 }
 
 __global__ __launch_bounds__(64, 2) void k_lq(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
@@ -462,30 +549,51 @@ __global__ void k_plant_reset(PlantBatch p, const DevModel* __restrict__ M) {
   for (int c = 0; c < HB_NC; ++c) p.pinned[4 * i + c] = 0;
 }
 
-// ---- joint command law: one thread per (instance, joint) ---------------------------------------------------------
-__global__ void k_joint_command(WbcBatch w, hb_joint_gains g, double dt, double* out /*[6][B][10]: posDes velDes kp kd ff torque*/) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= w.B * HB_NJ) return;
-  const int i = gid / HB_NJ, j = gid - HB_NJ * i;
-  const double qdd = w.sol[size_t(i) * HB_NWBC + 6 + j], ff = w.sol[size_t(i) * HB_NWBC + 28 + j];
-  const double pos = w.xdes[size_t(i) * HB_NX + 12 + j] + 0.5 * qdd * dt * dt;
-  const double vel = w.udes[size_t(i) * HB_NU + 12 + j] + qdd * dt;
+// ---- joint command law: one thread per instance, joints in the reference's order -----------------------------------
+// LeggedController.cpp:186-256 incl. the limit protection (:196-208: a joint more than 0.02 rad outside its urdf limits
+// latches emergencyStopFlag_ — only while the controller is loaded — and from THAT joint on, and on every later tick, the
+// command is setCommand(0, 0, 0, 1, 0), :245-248) and the unloaded-controller branch (:209-221: MPC joint targets with the
+// position gains, no feed-forward).  estop / loaded are per-instance device state (hb_joint_set_flags).
+__global__ void k_joint_command(WbcBatch w, const DevModel* __restrict__ M, hb_joint_gains g, double dt, int* estop, const int* loaded,
+                                double* out /*[6][B][10]: posDes velDes kp kd ff torque*/) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w.B) return;
   bool cf[HB_NC];
   mode_flags(w.mode[i], cf);
-  const bool contact = j < 5 ? cf[0] : cf[1];  // cmdContactFlag[int(j / 5)]
-  const int k = j < 5 ? j : j - 5;
-  double kp, kd;
-  if (k == 0 || k == 1) { kp = contact ? g.kp_small_stance : g.kp_small_swing; kd = g.kd_small; }
-  else if (k == 4) { kp = contact ? g.kp_small_stance : g.kp_small_swing; kd = g.kd_feet; }
-  else { kp = contact ? g.kp_big_stance : g.kp_big_swing; kd = g.kd_big; }
-  const double q = w.rbd[size_t(i) * HB_NRBD + 6 + j], qd = w.rbd[size_t(i) * HB_NRBD + 6 + HB_NV + j];
+  bool stop = estop[i] != 0;
+  const bool is_loaded = loaded[i] != 0;
   const size_t n = size_t(w.B) * HB_NJ;
-  out[gid] = pos;
-  out[n + gid] = vel;
-  out[2 * n + gid] = kp;
-  out[3 * n + gid] = kd;
-  out[4 * n + gid] = ff;
-  out[5 * n + gid] = ff + kp * (pos - q) + kd * (vel - qd);
+  for (int j = 0; j < HB_NJ; ++j) {
+    const double q = w.rbd[size_t(i) * HB_NRBD + 6 + j], qd = w.rbd[size_t(i) * HB_NRBD + 6 + HB_NV + j];
+    if (!stop && is_loaded && (q > M->q_upper[j] + 0.02 || q < M->q_lower[j] - 0.02)) stop = true;
+    const int k = j < 5 ? j : j - 5;
+    double pos, vel, kp, kd, ff;
+    if (!is_loaded) {
+      pos = w.xdes[size_t(i) * HB_NX + 12 + j];
+      vel = w.udes[size_t(i) * HB_NU + 12 + j];
+      kp = g.kp_position;
+      kd = k == 4 ? g.kd_feet : g.kd_position;
+      ff = 0.0;
+    } else {
+      const double qdd = w.sol[size_t(i) * HB_NWBC + 6 + j];
+      ff = w.sol[size_t(i) * HB_NWBC + 28 + j];
+      pos = w.xdes[size_t(i) * HB_NX + 12 + j] + 0.5 * qdd * dt * dt;
+      vel = w.udes[size_t(i) * HB_NU + 12 + j] + qdd * dt;
+      const bool contact = j < 5 ? cf[0] : cf[1];  // cmdContactFlag[int(j / 5)]
+      if (k == 0 || k == 1) { kp = contact ? g.kp_small_stance : g.kp_small_swing; kd = g.kd_small; }
+      else if (k == 4) { kp = contact ? g.kp_small_stance : g.kp_small_swing; kd = g.kd_feet; }
+      else { kp = contact ? g.kp_big_stance : g.kp_big_swing; kd = g.kd_big; }
+    }
+    if (stop) { pos = 0.0; vel = 0.0; kp = 0.0; kd = 1.0; ff = 0.0; }
+    const size_t gid = size_t(i) * HB_NJ + j;
+    out[gid] = pos;
+    out[n + gid] = vel;
+    out[2 * n + gid] = kp;
+    out[3 * n + gid] = kd;
+    out[4 * n + gid] = ff;
+    out[5 * n + gid] = ff + kp * (pos - q) + kd * (vel - qd);
+  }
+  estop[i] = stop ? 1 : 0;
 }
 
 // ---- reference generation: one thread per instance -------------------------------------------------------------
@@ -561,7 +669,7 @@ struct EstBatch {
   const double *quat, *w_local, *a_local, *qj, *qdj;  // inputs [B][4|3|3|10|10]
   const int* contact;                                 // [B][4]
   double *rbd, *x;                                    // outputs [B][32], [B][22]
-  double *res_rbd, *res_x0;                           // resident inputs of hb_step_resident (or null)
+  double *res_rbd, *res_x0, *res_t;                   // resident inputs of hb_step_resident (or null)
 };
 
 __global__ __launch_bounds__(64) void k_estimator(EstBatch e, const DevModel* __restrict__ M, hb_estimator_config K, double dt) {
@@ -574,6 +682,7 @@ __global__ __launch_bounds__(64) void k_estimator(EstBatch e, const DevModel* __
     __syncthreads();  // lane 0 wrote the outputs
     for (int c = cx.lane; c < HB_NRBD; c += 64) e.res_rbd[HB_NRBD * i + c] = e.rbd[HB_NRBD * i + c];
     for (int c = cx.lane; c < HB_NX; c += 64) e.res_x0[HB_NX * i + c] = e.x[HB_NX * i + c];
+    if (cx.lane == 0) e.res_t[i] += dt;  // the resident time follows the observation, as in hb_plant_step
   }
 }
 __global__ void k_estimator_reset(int B, double* xhat, double* P, double* yaw_last, const double* xhat0) {
@@ -590,8 +699,20 @@ __global__ void k_estimator_reset(int B, double* xhat, double* P, double* yaw_la
 // ===========================================================================================================
 // host side
 // ===========================================================================================================
+// Error text of the last failed call, per calling thread (errno-like): the reference drives one solver from two threads
+// (control thread / MPC thread, LeggedController.cpp:396-421) and each reads back only its own failures.
+struct ErrSlot {
+  static std::string& tl() { static thread_local std::string s; return s; }
+  ErrSlot& operator=(const std::string& m) { tl() = m; return *this; }
+  ErrSlot& operator=(const char* m) { tl() = m; return *this; }
+  const char* c_str() const { return tl().c_str(); }
+};
+
 struct hb_ctx {
   int device = 0, B = 0, Nmax = 0;
+  // Guards the host-side state both threads touch while ENQUEUEING work (policy hand-over flags, counters); never held across
+  // a device synchronisation.
+  std::mutex mtx;
   hb_model model;
   hb_config config;
   DevModel hmodel;
@@ -601,10 +722,14 @@ struct hb_ctx {
   Batch b{};
   hipStream_t s_mpc = nullptr, s_wbc = nullptr;
   hipEvent_t ev[9]{};  // 0..4 MPC phases, 5/6 WBC begin/end, 7 publish, 8 policy buffers consumed by the last policy evaluation
+  // cross-stream ordering points that are NOT timing events: 0 / 1 resident-input writers (plant, estimator) wait for the MPC
+  // stream / the MPC stream waits for them; 2 / 3 fork of the chunk streams from the MPC / WBC streams; 4.. join of chunk c
+  hipEvent_t ev_sync[4 + 8]{};
+  bool grid_saved = false;  // tp / modep / np_nodes hold the grid the iterate lives on; the tables have changed since
   bool policy_read_pending = false;
   bool refs_set = false, traj_set = false, timed = false;
   std::vector<void*> allocs;
-  std::string err;
+  ErrSlot err;
   WbcBatch w{};
   hb_stats stats{};
   double* x0_seq = nullptr;  // optional device-resident sequence of measured states for hb_step_resident
@@ -613,7 +738,10 @@ struct hb_ctx {
   // per-instance sweeps of one chunk overlap the per-node kernels of another)
   int n_chunks = 1;
   hipStream_t s_chunk[8]{};
+  unsigned char* reset_mask = nullptr;  // [B] staging of hb_mpc_reset_masked
   double* jc_out = nullptr;  // joint command outputs [6][B][10]
+  int* jc_estop = nullptr;   // [B] latched emergencyStopFlag_ per instance
+  int* jc_loaded = nullptr;  // [B] loadControllerFlag_ per instance (default: loaded)
   uint64_t* lcm_cmd = nullptr;    // [B][62] low_cmd_t wire images
   uint64_t* lcm_state = nullptr;  // [B][42] low_state_t wire images
   long long* lcm_ts = nullptr;    // [B]
@@ -693,6 +821,8 @@ int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch,
   if ((e = hipStreamCreateWithFlags(&ctx->s_wbc, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
   for (auto& ev : ctx->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return fail("event", e);
+  for (auto& ev : ctx->ev_sync)
+    if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail("event", e);
   for (auto& sc : ctx->s_chunk)
     if ((e = hipStreamCreateWithFlags(&sc, hipStreamNonBlocking)) != hipSuccess) return fail("chunk stream", e);
   const size_t B = batch, N = max_nodes;
@@ -719,6 +849,13 @@ int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch,
   A(b.accepted, B);
   A(b.perf, B * 4);
   A(b.ric_fail, B);
+  A(b.mpc_status, B);
+  A(b.xp, B * (N + 1) * HB_NX);
+  A(b.up, B * N * HB_NU);
+  A(b.tp, B * (N + 1));
+  A(b.modep, B * N);
+  A(b.np_nodes, B);
+  A(b.grid_dirty, B);
   WbcBatch& w = ctx->w;
   w.B = batch;
   A(w.t_now, B);
@@ -755,10 +892,44 @@ void hb_destroy(hb_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (void* p : ctx->allocs) (void)hipFree(p);
   for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
+  for (auto& ev : ctx->ev_sync) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(ctx->s_mpc);
   (void)hipStreamDestroy(ctx->s_wbc);
   for (auto& sc : ctx->s_chunk) (void)hipStreamDestroy(sc);
   delete ctx;
+}
+
+// joint command outputs and the per-instance controller flags (allocated on first use; loaded = 1, no emergency stop)
+static int32_t joint_state_alloc(hb_ctx* ctx) {
+  if (ctx->jc_out) return HB_OK;
+  const size_t n = size_t(ctx->B) * HB_NJ;
+  HB_HIP(dalloc(ctx, &ctx->jc_out, 6 * n));
+  HB_HIP(dalloc(ctx, &ctx->jc_estop, size_t(ctx->B)));
+  HB_HIP(dalloc(ctx, &ctx->jc_loaded, size_t(ctx->B)));
+  std::vector<int> ones(size_t(ctx->B), 1);
+  HB_HIP(hipMemcpy(ctx->jc_loaded, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice));
+  return HB_OK;
+}
+
+int32_t hb_joint_set_flags(hb_ctx* ctx, const int32_t* controller_loaded, const int32_t* emergency_stop) {
+  if (!ctx) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  int32_t rc = joint_state_alloc(ctx);
+  if (rc != HB_OK) return rc;
+  HB_HIP(hipStreamSynchronize(ctx->s_wbc));
+  if (controller_loaded) HB_HIP(hipMemcpy(ctx->jc_loaded, controller_loaded, size_t(ctx->B) * sizeof(int), hipMemcpyHostToDevice));
+  if (emergency_stop) HB_HIP(hipMemcpy(ctx->jc_estop, emergency_stop, size_t(ctx->B) * sizeof(int), hipMemcpyHostToDevice));
+  return HB_OK;
+}
+
+int32_t hb_joint_get_emergency_stop(hb_ctx* ctx, int32_t* emergency_stop) {
+  if (!ctx || !emergency_stop) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  int32_t rc = joint_state_alloc(ctx);
+  if (rc != HB_OK) return rc;
+  HB_HIP(hipStreamSynchronize(ctx->s_wbc));
+  HB_HIP(hipMemcpy(emergency_stop, ctx->jc_estop, size_t(ctx->B) * sizeof(int), hipMemcpyDeviceToHost));
+  return HB_OK;
 }
 
 int32_t hb_joint_command(hb_ctx* ctx, const hb_joint_gains* gains, double dt, double* pos_des, double* vel_des, double* kp, double* kd,
@@ -770,9 +941,11 @@ int32_t hb_joint_command(hb_ctx* ctx, const hb_joint_gains* gains, double dt, do
   }
   HB_HIP(hipSetDevice(ctx->device));
   const size_t n = size_t(ctx->B) * HB_NJ;
-  if (!ctx->jc_out) HB_HIP(dalloc(ctx, &ctx->jc_out, 6 * n));
+  int32_t rc_ = joint_state_alloc(ctx);
+  if (rc_ != HB_OK) return rc_;
   hipStream_t s = ctx->s_wbc;
-  hipLaunchKernelGGL(k_joint_command, dim3((unsigned(n) + 255) / 256), dim3(256), 0, s, ctx->w, *gains, dt, ctx->jc_out);
+  hipLaunchKernelGGL(k_joint_command, dim3((ctx->B + 63) / 64), dim3(64), 0, s, ctx->w, ctx->dmodel, *gains, dt, ctx->jc_estop, ctx->jc_loaded,
+                     ctx->jc_out);
   HB_HIP(hipGetLastError());
   double* outs[6] = {pos_des, vel_des, kp, kd, tau_ff, torque};
   for (int a = 0; a < 6; ++a)
@@ -829,15 +1002,15 @@ int32_t hb_plant_step(hb_ctx* ctx, const double* tau, const int32_t* contact, do
   const double* dtau = tau ? p.tau : ctx->jc_out + 5 * B * HB_NJ;
   if (to_resident) {
     // the resident observation feeds the next hb_mpc_solve(NULL) / hb_refgen_update(NULL) on the MPC stream
-    HB_HIP(hipEventRecord(ctx->ev[7], ctx->s_mpc));
-    HB_HIP(hipStreamWaitEvent(s, ctx->ev[7], 0));
+    HB_HIP(hipEventRecord(ctx->ev_sync[0], ctx->s_mpc));
+    HB_HIP(hipStreamWaitEvent(s, ctx->ev_sync[0], 0));
   }
   hipLaunchKernelGGL(k_plant, dim3(ctx->B), dim3(64), 0, s, p, ctx->dmodel, dtau, contact ? p.contact : nullptr, ctx->w.mode, dt, substeps,
                      to_resident ? ctx->w.rbd : nullptr, to_resident ? ctx->b.x0 : nullptr, to_resident ? ctx->w.t_now : nullptr);
   HB_HIP(hipGetLastError());
   if (to_resident) {
-    HB_HIP(hipEventRecord(ctx->ev[6], s));
-    HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev[6], 0));
+    HB_HIP(hipEventRecord(ctx->ev_sync[1], s));
+    HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev_sync[1], 0));
   }
   return HB_OK;
 }
@@ -916,6 +1089,23 @@ int32_t hb_refgen_set_schedule(hb_ctx* ctx, int32_t i0, int32_t cnt, const int32
   return HB_OK;
 }
 
+// Called (on the MPC stream) before node tables are overwritten while an iterate exists: keeps the grid that iterate lives on,
+// so that the next solve can bring it onto the new tables (k_warm_shift).  Instances [i0, i0 + cnt) are marked dirty.
+static int32_t save_grid_before_table_update(hb_ctx* ctx, int i0, int cnt) {
+  if (!ctx->traj_set) return HB_OK;
+  Batch& b = ctx->b;
+  const size_t B = ctx->B, N = ctx->Nmax;
+  hipStream_t s = ctx->s_mpc;
+  if (!ctx->grid_saved) {
+    HB_HIP(hipMemcpyAsync(b.tp, b.t, B * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemcpyAsync(b.modep, b.mode, B * N * sizeof(int), hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemcpyAsync(b.np_nodes, b.n_nodes, B * sizeof(int), hipMemcpyDeviceToDevice, s));
+    ctx->grid_saved = true;
+  }
+  HB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.grid_dirty + i0), 1, size_t(cnt), s));
+  return HB_OK;
+}
+
 int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const double* x_now, const double* cmd_vel, int32_t* status) {
   if (!ctx || !t0 || !cmd_vel || !(horizon > 0.0)) return HB_ERR_ARG;
   if (!ctx->rg_ready) {
@@ -931,6 +1121,10 @@ int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const do
   const size_t B = ctx->B;
   RefgenBatch& r = ctx->rg;
   hipStream_t s = ctx->s_mpc;  // the tables belong to the MPC side
+  {
+    int32_t rc = save_grid_before_table_update(ctx, 0, ctx->B);
+    if (rc != HB_OK) return rc;
+  }
   HB_HIP(hipMemcpyAsync(r.t0, t0, B * 8, hipMemcpyHostToDevice, s));
   HB_HIP(hipMemcpyAsync(r.cmd, cmd_vel, B * 4 * 8, hipMemcpyHostToDevice, s));
   if (x_now) HB_HIP(hipMemcpyAsync(ctx->b.x0, x_now, B * HB_NX * 8, hipMemcpyHostToDevice, s));
@@ -1009,8 +1203,17 @@ static int32_t estimator_run(hb_ctx* ctx, double dt, int32_t to_resident, double
   hipStream_t s = ctx->s_wbc;
   e.res_rbd = to_resident ? ctx->w.rbd : nullptr;
   e.res_x0 = to_resident ? ctx->b.x0 : nullptr;
+  e.res_t = to_resident ? ctx->w.t_now : nullptr;
+  if (to_resident) {  // the resident observation feeds the MPC stream: write it between two ordering points (as hb_plant_step does)
+    HB_HIP(hipEventRecord(ctx->ev_sync[0], ctx->s_mpc));
+    HB_HIP(hipStreamWaitEvent(s, ctx->ev_sync[0], 0));
+  }
   hipLaunchKernelGGL(k_estimator, dim3(ctx->B), dim3(64), 0, s, e, ctx->dmodel, ctx->est_cfg, dt);
   HB_HIP(hipGetLastError());
+  if (to_resident) {
+    HB_HIP(hipEventRecord(ctx->ev_sync[1], s));
+    HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev_sync[1], 0));
+  }
   if (rbd) HB_HIP(hipMemcpyAsync(rbd, e.rbd, B * HB_NRBD * 8, hipMemcpyDeviceToHost, s));
   if (x_state) HB_HIP(hipMemcpyAsync(x_state, e.x, B * HB_NX * 8, hipMemcpyDeviceToHost, s));
   HB_HIP(hipStreamSynchronize(s));
@@ -1182,6 +1385,10 @@ int32_t hb_mpc_set_references(hb_ctx* ctx, int32_t i0, int32_t cnt, const int32_
   const size_t N = ctx->Nmax;
   Batch& b = ctx->b;
   HB_HIP(hipSetDevice(ctx->device));
+  {
+    int32_t rc = save_grid_before_table_update(ctx, i0, cnt);
+    if (rc != HB_OK) return rc;
+  }
   HB_HIP(hipMemcpyAsync(b.n_nodes + i0, n_nodes, cnt * sizeof(int), hipMemcpyHostToDevice, ctx->s_mpc));
   HB_HIP(hipMemcpyAsync(b.t + i0 * (N + 1), t, cnt * (N + 1) * 8, hipMemcpyHostToDevice, ctx->s_mpc));
   HB_HIP(hipMemcpyAsync(b.mode + i0 * N, mode, cnt * N * sizeof(int), hipMemcpyHostToDevice, ctx->s_mpc));
@@ -1192,18 +1399,54 @@ int32_t hb_mpc_set_references(hb_ctx* ctx, int32_t i0, int32_t cnt, const int32_
   return HB_OK;
 }
 
-int32_t hb_mpc_reset(hb_ctx* ctx, const double* x0) {
-  if (!ctx) return HB_ERR_ARG;
+static int32_t mpc_cold_start(hb_ctx* ctx, const double* x0, const uint8_t* mask) {
   if (!ctx->refs_set) {
     ctx->err = "hb_mpc_reset: references not set";
     return HB_ERR_STATE;
   }
   HB_HIP(hipSetDevice(ctx->device));
-  if (x0) HB_HIP(hipMemcpyAsync(ctx->b.x0, x0, size_t(ctx->B) * HB_NX * 8, hipMemcpyHostToDevice, ctx->s_mpc));
-  hipLaunchKernelGGL(k_cold_start, dim3(ctx->Nmax + 1, ctx->B), dim3(64), 0, ctx->s_mpc, ctx->b, ctx->dmodel);
+  const size_t B = ctx->B;
+  unsigned char* dmask = nullptr;
+  if (mask) {
+    if (!ctx->traj_set) {
+      ctx->err = "hb_mpc_reset_masked: no iterate yet (hb_mpc_reset first)";
+      return HB_ERR_STATE;
+    }
+    if (!ctx->reset_mask) HB_HIP(dalloc(ctx, &ctx->reset_mask, B));
+    dmask = ctx->reset_mask;
+    HB_HIP(hipMemcpyAsync(dmask, mask, B, hipMemcpyHostToDevice, ctx->s_mpc));
+  }
+  if (x0) {
+    if (!mask) {
+      HB_HIP(hipMemcpyAsync(ctx->b.x0, x0, B * HB_NX * 8, hipMemcpyHostToDevice, ctx->s_mpc));
+    } else {  // only the masked rows of the observation are replaced
+      for (size_t i = 0; i < B; ++i)
+        if (mask[i]) HB_HIP(hipMemcpyAsync(ctx->b.x0 + i * HB_NX, x0 + i * HB_NX, HB_NX * 8, hipMemcpyHostToDevice, ctx->s_mpc));
+    }
+  }
+  hipLaunchKernelGGL(k_cold_start, dim3(ctx->Nmax + 1, ctx->B), dim3(64), 0, ctx->s_mpc, ctx->b, ctx->dmodel, dmask);
   HB_HIP(hipGetLastError());
   HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  if (!mask) ctx->grid_saved = false;  // every instance sits on the current tables
   ctx->traj_set = true;
+  return HB_OK;
+}
+
+int32_t hb_mpc_reset(hb_ctx* ctx, const double* x0) {
+  if (!ctx) return HB_ERR_ARG;
+  return mpc_cold_start(ctx, x0, nullptr);
+}
+
+int32_t hb_mpc_reset_masked(hb_ctx* ctx, const uint8_t* mask, const double* x0) {
+  if (!ctx || !mask) return HB_ERR_ARG;
+  return mpc_cold_start(ctx, x0, mask);
+}
+
+int32_t hb_mpc_get_status(hb_ctx* ctx, int32_t* status) {
+  if (!ctx || !status) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipMemcpyAsync(status, ctx->b.mpc_status, size_t(ctx->B) * sizeof(int), hipMemcpyDeviceToHost, ctx->s_mpc));
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
   return HB_OK;
 }
 
@@ -1213,7 +1456,9 @@ int32_t hb_mpc_set_trajectory(hb_ctx* ctx, const double* x, const double* u) {
   HB_HIP(hipSetDevice(ctx->device));
   HB_HIP(hipMemcpyAsync(ctx->b.x, x, B * (N + 1) * HB_NX * 8, hipMemcpyHostToDevice, ctx->s_mpc));
   HB_HIP(hipMemcpyAsync(ctx->b.u, u, B * N * HB_NU * 8, hipMemcpyHostToDevice, ctx->s_mpc));
+  hipLaunchKernelGGL(k_grid_clean, dim3((ctx->B + 255) / 256), dim3(256), 0, ctx->s_mpc, ctx->b);  // given on the current tables
   HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  ctx->grid_saved = false;
   ctx->traj_set = true;
   return HB_OK;
 }
@@ -1226,7 +1471,8 @@ static Batch batch_view(const Batch& b, int i0, int cnt) {
   v.n_nodes += o; v.t += o * (N + 1); v.mode += o * N; v.xref += o * N * HB_NX; v.swing += o * N * 24;
   v.x += o * (N + 1) * HB_NX; v.u += o * N * HB_NU; v.x0 += o * HB_NX; v.recs += o * N * REC_SIZE; v.gains += o * N * GAIN_SIZE;
   v.dx += o * (N + 1) * HB_NX; v.du += o * N * HB_NU; v.acc += o * 4; v.partial += o * N * 3; v.accepted += o; v.perf += o * 4;
-  v.ric_fail += o;
+  v.ric_fail += o; v.mpc_status += o; v.xp += o * (N + 1) * HB_NX; v.up += o * N * HB_NU; v.tp += o * (N + 1); v.modep += o * N;
+  v.np_nodes += o; v.grid_dirty += o;
   return v;
 }
 static WbcBatch wbc_view(const WbcBatch& w, int Nmax, int i0, int cnt) {
@@ -1239,8 +1485,26 @@ static WbcBatch wbc_view(const WbcBatch& w, int Nmax, int i0, int cnt) {
   return v;
 }
 
+// Brings the iterate onto the current node tables if they changed since it was computed (see k_warm_shift); MPC stream.
+static int32_t warm_start_onto_new_tables(hb_ctx* ctx) {
+  if (!ctx->grid_saved) return HB_OK;
+  Batch& b = ctx->b;
+  std::swap(b.x, b.xp);
+  std::swap(b.u, b.up);
+  hipLaunchKernelGGL(k_warm_shift, dim3(ctx->Nmax + 1, ctx->B), dim3(64), 0, ctx->s_mpc, b, ctx->dmodel);
+  hipLaunchKernelGGL(k_warm_keep, dim3(ctx->Nmax + 1, ctx->B), dim3(64), 0, ctx->s_mpc, b);
+  hipLaunchKernelGGL(k_grid_clean, dim3((ctx->B + 255) / 256), dim3(256), 0, ctx->s_mpc, b);
+  HB_HIP(hipGetLastError());
+  ctx->grid_saved = false;
+  return HB_OK;
+}
+
 static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t stream = nullptr) {
   const bool whole = cnt < 0;
+  if (whole) {
+    int32_t rc = warm_start_onto_new_tables(ctx);
+    if (rc != HB_OK) return rc;
+  }
   const Batch b = whole ? ctx->b : batch_view(ctx->b, i0, cnt);
   hipStream_t s = whole ? ctx->s_mpc : stream;
   const int B = b.B, N = ctx->Nmax;
@@ -1262,9 +1526,13 @@ static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t
                          ctx->config.alpha_decay, ctx->config.alpha_min);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[4], s));
   }
+  hipLaunchKernelGGL(k_mpc_status, dim3((B + 255) / 256), dim3(256), 0, s, b);
   HB_HIP(hipGetLastError());
-  if (whole) ctx->timed = true;
-  ctx->stats.n_mpc_solves += B;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    if (whole) ctx->timed = true;
+    ctx->stats.n_mpc_solves += B;
+  }
   return HB_OK;
 }
 
@@ -1316,6 +1584,7 @@ int32_t hb_mpc_publish(hb_ctx* ctx) {
   HB_HIP(hipSetDevice(ctx->device));
   // device-to-device copy of the solution into the policy buffers read by the WBC stream
   hipStream_t s = ctx->s_mpc;
+  std::lock_guard<std::mutex> lk(ctx->mtx);  // enqueue only: the control thread may be inside hb_wbc_update right now
   // only the copies below touch the policy buffers: they wait for the last policy evaluation on the WBC stream, the SQP
   // kernels of the next solve do not (so a WBC solve overlaps the next LQ approximation)
   if (ctx->policy_read_pending) {
@@ -1337,6 +1606,7 @@ static int32_t wbc_launch(hb_ctx* ctx, bool from_policy, double dt) {
   (void)dt;
   WbcBatch& w = ctx->w;
   hipStream_t s = ctx->s_wbc;
+  std::lock_guard<std::mutex> lk(ctx->mtx);  // enqueue only (pairs with hb_mpc_publish on the MPC thread)
   HB_HIP(hipEventRecord(ctx->ev[5], s));
   if (from_policy) {
     hipLaunchKernelGGL(k_policy_eval, dim3((ctx->B + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
@@ -1454,17 +1724,26 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
     HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev[6], 0));
     return HB_OK;
   }
-  // pipelined: every chunk of instances is a linear sequence MPC -> publish -> policy evaluation -> WBC on its own stream
-  if (ctx->n_seq > 0) {
-    HB_HIP(hipEventRecord(ctx->ev[7], ctx->s_mpc));
-    for (int c = 0; c < ctx->n_chunks; ++c) HB_HIP(hipStreamWaitEvent(ctx->s_chunk[c], ctx->ev[7], 0));
+  // pipelined: every chunk of instances is a linear sequence MPC -> publish -> policy evaluation -> WBC on its own stream.
+  // Fork: the chunk streams start after everything queued so far on the MPC stream (x0 sequence copy, table updates, warm
+  // start, resident-input writers ordered into it) and on the WBC stream (resident rbd / time writers, the last reader of the
+  // policy buffers).  Join: both library streams wait for every chunk, so that the getters, the joint command, the plant and
+  // the next table update — which only know the two library streams — see a finished step.
+  {
+    int32_t rc = warm_start_onto_new_tables(ctx);
+    if (rc != HB_OK) return rc;
   }
+  HB_HIP(hipEventRecord(ctx->ev_sync[2], ctx->s_mpc));
+  HB_HIP(hipEventRecord(ctx->ev_sync[3], ctx->s_wbc));
   const int per = (ctx->B + ctx->n_chunks - 1) / ctx->n_chunks;
   const size_t N = ctx->Nmax;
+  int used = 0;
   for (int c = 0; c < ctx->n_chunks; ++c) {
     const int i0 = c * per, cnt = std::min(per, ctx->B - i0);
     if (cnt <= 0) break;
     hipStream_t s = ctx->s_chunk[c];
+    HB_HIP(hipStreamWaitEvent(s, ctx->ev_sync[2], 0));
+    HB_HIP(hipStreamWaitEvent(s, ctx->ev_sync[3], 0));
     int32_t rc = mpc_iterations(ctx, i0, cnt, s);
     if (rc != HB_OK) return rc;
     const Batch b = batch_view(ctx->b, i0, cnt);
@@ -1480,9 +1759,19 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
     else
       hipLaunchKernelGGL(k_wbc, dim3(cnt), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
     HB_HIP(hipGetLastError());
+    HB_HIP(hipEventRecord(ctx->ev_sync[4 + c], s));
+    used = c + 1;
   }
-  ctx->w.policy_valid = true;
-  ctx->stats.n_wbc_solves += ctx->B;
+  for (int c = 0; c < used; ++c) {
+    HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev_sync[4 + c], 0));
+    HB_HIP(hipStreamWaitEvent(ctx->s_wbc, ctx->ev_sync[4 + c], 0));
+  }
+  {
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    ctx->w.policy_valid = true;
+    ctx->policy_read_pending = false;  // the join above already orders the next policy write after this step's readers
+    ctx->stats.n_wbc_solves += ctx->B;
+  }
   return HB_OK;
 }
 

@@ -26,7 +26,8 @@ ABI_SYMBOLS = [
     "hb_sync", "hb_get_stats", "hb_get_input_cost", "hb_version", "hb_eval_flow_map", "hb_eval_foot_kinematics",
     "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
     "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd", "hb_plant_reset", "hb_plant_step",
-    "hb_plant_get_state", "hb_hoqp_solve",
+    "hb_plant_get_state", "hb_hoqp_solve", "hb_mpc_reset_masked", "hb_mpc_get_status", "hb_joint_set_flags",
+    "hb_joint_get_emergency_stop",
 ]
 # include/hunter_lcm.h
 LCM_SYMBOLS = ["hb_lcm_fingerprint", "hb_lcm_encoded_size", "hb_lcm_field_count", "hb_lcm_encode", "hb_lcm_decode", "hb_lcm_frame",
@@ -201,6 +202,27 @@ class HunterSolver:
 
     def joint_command_resident(self, gains: "abi.HbJointGains", dt=0.002):
         self._check(self.lib.hb_joint_command(self.ctx, C.byref(gains), C.c_double(dt), None, None, None, None, None, None), "hb_joint_command")
+
+    def reset_masked(self, mask, x0=None):
+        """Cold start of the instances with mask[i] != 0 (hb_mpc_reset_masked)."""
+        m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8).reshape(self.B)
+        x = None if x0 is None else _f64(x0, (self.B, 22))
+        self._check(self.lib.hb_mpc_reset_masked(self.ctx, _p(m), _p(x)), "hb_mpc_reset_masked")
+
+    def mpc_status(self):
+        st = np.zeros(self.B, dtype=np.int32)
+        self._check(self.lib.hb_mpc_get_status(self.ctx, _p(st)), "hb_mpc_get_status")
+        return st
+
+    def joint_set_flags(self, controller_loaded=None, emergency_stop=None):
+        a = None if controller_loaded is None else _i32(controller_loaded, (self.B,))
+        b = None if emergency_stop is None else _i32(emergency_stop, (self.B,))
+        self._check(self.lib.hb_joint_set_flags(self.ctx, _p(a), _p(b)), "hb_joint_set_flags")
+
+    def joint_emergency_stop(self):
+        st = np.zeros(self.B, dtype=np.int32)
+        self._check(self.lib.hb_joint_get_emergency_stop(self.ctx, _p(st)), "hb_joint_get_emergency_stop")
+        return st
 
     def reset_resident(self):
         """Cold start of the MPC iterate from the device-resident observation (hb_mpc_reset with x0 = NULL)."""

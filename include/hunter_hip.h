@@ -120,6 +120,9 @@ typedef struct hb_stats {
 int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch, int32_t max_nodes,
                   int32_t device, hb_ctx** out);
 void hb_destroy(hb_ctx* ctx);
+/* Message of the last call that FAILED ON THE CALLING THREAD (errno-like, thread-local): the reference drives one solver from
+ * two threads (control thread: hb_wbc_update / hb_joint_command / estimator; MPC thread: hb_refgen_update / hb_mpc_solve /
+ * hb_mpc_publish — LeggedController.cpp:396-421), which this library supports for exactly that split. */
 const char* hb_last_error(const hb_ctx* ctx); /* ctx may be NULL: message of the failed hb_create */
 
 /* ---- references ------------------------------------------------------------------------------
@@ -138,7 +141,18 @@ int32_t hb_mpc_set_references(hb_ctx* ctx, int32_t inst_begin, int32_t inst_coun
 
 /* Cold start: x_k = x0, u_k = weight compensation of mode_k (LeggedRobotInitializer.cpp:67-77). */
 int32_t hb_mpc_reset(hb_ctx* ctx, const double* x0 /*[batch][22], or NULL: the device-resident observation*/);
-/* Warm start from caller-provided trajectories (x [batch][max_nodes+1][22], u [batch][max_nodes][22]). */
+/* Cold start of the instances with mask[i] != 0 only — the per-instance form of LeggedController::resetMPC / resetMpcNode
+ * (LeggedController.cpp:460-465), e.g. after hb_mpc_get_status reported HB_INST_NAN for them.  x0 may be NULL (the
+ * device-resident observation); otherwise only the masked rows of x0 [batch][22] are read. */
+int32_t hb_mpc_reset_masked(hb_ctx* ctx, const uint8_t* mask /*[batch]*/, const double* x0);
+/* Per-instance status word of the last MPC call (hb_inst_status): HB_INST_NAN = non-positive Riccati pivot or a non-finite
+ * value (the step was not taken, the iterate is the previous one: the batch counterpart of the exception path of the MPC
+ * thread, LeggedController.cpp:413-418), HB_INST_MAXITER = the filter line search rejected every step size. */
+int32_t hb_mpc_get_status(hb_ctx* ctx, int32_t* status /*[batch]*/);
+/* Warm start from caller-provided trajectories (x [batch][max_nodes+1][22], u [batch][max_nodes][22]) on the CURRENT tables.
+ * Between MPC calls the library warm-starts by itself: when the node tables changed (hb_mpc_set_references /
+ * hb_refgen_update) the next hb_mpc_solve first interpolates the previous iterate onto the new node times and falls back to
+ * the initializer beyond the previous horizon (OCS2 SqpSolver::initializeStateInputTrajectories). */
 int32_t hb_mpc_set_trajectory(hb_ctx* ctx, const double* x, const double* u);
 
 /* ---- MPC -------------------------------------------------------------------------------------
@@ -182,11 +196,20 @@ int32_t hb_wbc_update_direct(hb_ctx* ctx, const double* x_des, const double* u_d
  *   (kp, kd) by joint: hip roll / yaw (0,1,5,6) small gains, ankle (4,9) small kp with kd_feet, others big gains;
  *   stance or swing kp by the planned contact flag of the leg (:223-245);  feed-forward = WBC torque
  *   torque = ff + kp (posDes - q) + kd (velDes - qd)                                                       (:252-256)
- * Limit protection / emergency stop (:196-208,247-250) need the hardware handles and stay with the caller.
+ * Limit protection (:196-208): a measured joint position (rbd) more than 0.02 rad outside the urdf limits latches the
+ * instance's emergency stop — only while its controller is loaded — and from that joint on, and on every later call, the
+ * command is setCommand(0, 0, 0, 1, 0) (:245-248).  Unloaded controller (:209-221): MPC joint targets with kp_position /
+ * kd_position (kd_feet on the ankle joints 4, 9), no feed-forward.
  * Outputs (any may be NULL) are [batch][10]. Gains default to legged_controllers/cfg/Tutorials.cfg:6-16. */
 typedef struct hb_joint_gains {
   double kp_big_stance, kp_big_swing, kd_big, kp_small_stance, kp_small_swing, kd_small, kd_feet;
+  double kp_position, kd_position;   /* unloaded-controller branch (Tutorials.cfg:6-7) */
 } hb_joint_gains;
+/* Per-instance controller flags of the joint command law, device-resident: loadControllerFlag_ (default 1 = loaded; the
+ * reference starts at 0 until /load_controller, LeggedController.cpp:489-493) and the emergency-stop latch
+ * (emergencyStopFlag_, also set by the /emergency_stop topic, :477-481).  Either array may be NULL (left as is). */
+int32_t hb_joint_set_flags(hb_ctx* ctx, const int32_t* controller_loaded /*[batch]*/, const int32_t* emergency_stop /*[batch]*/);
+int32_t hb_joint_get_emergency_stop(hb_ctx* ctx, int32_t* emergency_stop /*[batch]*/);
 int32_t hb_joint_command(hb_ctx* ctx, const hb_joint_gains* gains, double dt, double* pos_des, double* vel_des,
                          double* kp, double* kd, double* tau_ff, double* torque);
 

@@ -16,6 +16,45 @@ def standing_configuration(params, batch):
     return q
 
 
+def warm_shift(params, prev_refs, xs, us, refs):
+    """The previous call's iterate brought onto the new node tables (device: k_warm_shift; OCS2
+    SqpSolver::initializeStateInputTrajectories): states interpolated linearly in time, inputs interpolated at the interval
+    start but HELD across a mode switch of the previous solution and on its last interval; beyond the previous horizon the
+    state is carried on and the input is the weight compensation of the interval's mode."""
+    n, npv = int(refs["n_nodes"][0]), int(prev_refs["n_nodes"][0])
+    t, tp, mp = refs["t"][0], prev_refs["t"][0], prev_refs["mode"][0]
+    m = sum(params["model"]["mass"])
+    xn, un = np.zeros_like(xs), np.zeros_like(us)
+    for k in range(n + 1):
+        tk = t[k]
+        i = 0
+        while i + 1 < npv and tp[i + 1] <= tk:
+            i += 1
+        if tk >= tp[npv]:
+            xn[0, k] = xs[0, npv]
+        elif tk <= tp[0]:
+            xn[0, k] = xs[0, 0]
+        else:
+            a = (tk - tp[i]) / (tp[i + 1] - tp[i])
+            xn[0, k] = (1.0 - a) * xs[0, i] + a * xs[0, i + 1]
+        if k < n:
+            if tk >= tp[npv]:
+                cf = refgen.mode_to_contact_flags(int(refs["mode"][0, k]))
+                u = np.zeros(22)
+                for c in range(4):
+                    if cf[c]:
+                        u[3 * c + 2] = m * 9.81 / sum(cf)
+                un[0, k] = u
+            elif tk <= tp[0]:
+                un[0, k] = us[0, 0]
+            elif i + 1 >= npv or mp[i + 1] != mp[i]:
+                un[0, k] = us[0, i]
+            else:
+                a = (tk - tp[i]) / (tp[i + 1] - tp[i])
+                un[0, k] = (1.0 - a) * us[0, i] + a * us[0, i + 1]
+    return xn, un
+
+
 class OracleLoop:
     def __init__(self, oracle, params, gait, cmd_vel, n_intervals=100, mpc_every=8, dt=0.002, t_gait_start=0.3):
         self.o, self.params, self.gait, self.cmd = oracle, params, gait, tuple(cmd_vel)
@@ -64,6 +103,8 @@ class OracleLoop:
                 self.xs, self.us = np.zeros((1, nmax + 1, 22)), np.zeros((1, nmax, 22))
                 n = refs["n_nodes"][0]
                 self.xs[0, :n + 1], self.us[0, :n] = o.cold_start(refs["mode"][0, :n], x_obs[0])
+            else:
+                self.xs, self.us = warm_shift(self.params, self.pol[0], self.xs, self.us, refs)
             o.mpc_solve(refs, x_obs, self.xs, self.us, iters=1)
             self.pol = (refs, self.xs.copy(), self.us.copy())
         refs, px, pu = self.pol

@@ -6,12 +6,19 @@ Riccati backward/forward + filter line search + policy write) **plus** 1 WBC sol
 dynamics + task assembly + QP)  (SURVEY.md §8d).  A *step* = one such update for every instance of the batch, with all
 inputs already resident in HBM (hb_step_resident); nothing crosses PCIe inside the timed region.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+The batch is BASELINE.json configs[2]: 4096 DISTINCT instances (state seed 1234 + instance id, trot from t = 0.1, cmd_vel
+(0.3, 0, 0, 0)); their node tables (targets, event-clipped grids, footholds, swing splines, per-knot IK joint references)
+are generated ON THE DEVICE by hb_refgen_update before the timed region.  `--random-cmd` switches to configs[3]'s
+per-instance commands (seed 4321 + id, gait per instance from walkGait).
 
-Multi-GPU: independent instances are sharded across ranks (weak scaling: 4096 instances per GPU, no data-path
-collective; RCCL only for the barrier / max-over-ranks of the timing).
+    python bench.py --gpus 1 --steps 200 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W [--total-batch 4096 [--gather]]
+
+Multi-GPU: independent instances are sharded across ranks, no data-path collective (RCCL only for the barrier / the
+max-over-ranks of the timing / the status histogram).  Default = weak scaling, 4096 instances per GPU.  `--total-batch T`
+= strong scaling (configs[3]: 4096 split 512/GPU over 8 GPUs); `--gather` additionally times an RCCL all-gather of the
+status words and the solution trajectories after the timed region and reports the throughput with it included.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -29,26 +36,13 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# Algorithmic bytes per shooting node, f64 (restated per kernel in DESIGN.md §Roofline):
+# Algorithmic bytes per shooting node, f64 (restated per kernel in DESIGN.md §3):
 BYTES_PER_NODE = {
     "k_lq": 2486 * 8 + 88 * 8,              # LQ tensors written once + trajectory read
     "k_ric_bwd": 2486 * 8 + 506 * 8,        # LQ tensors read once + gains written
     "k_ric_fwd": 506 * 8 + 88 * 8,          # gains read + trajectory step written
 }
 BYTES_PER_UPDATE = lambda N: 48576 * N + 352 + 912  # noqa: E731  whole update
-
-
-def make_batch(params, batch, n_intervals, first_inst):
-    """Seeded synthetic batch; 16 distinct instances tiled to the batch size to keep host set-up short (the reference
-    manager with per-knot IK runs on the host, ~0.4 s per instance)."""
-    from hunter_bipedal_control_amd import workload
-    from oracle import workloads
-    distinct = min(batch, 16)
-    refs1, x01, rbd1, tn1 = workloads.trot_batch(params, distinct, n_intervals=n_intervals, first_inst=first_inst)
-    reps = (batch + distinct - 1) // distinct
-    refs = {k: np.concatenate([v] * reps)[:batch] for k, v in refs1.items()}
-    cat = lambda a: np.concatenate([a] * reps)[:batch]  # noqa: E731
-    return refs, cat(x01), cat(rbd1), cat(tn1)
 
 
 def x0_sequence(x0, seed, n_seq=8, sigma=0.01):
@@ -75,13 +69,16 @@ def usable_cores() -> int:
 
 
 def cpu_baseline(params, n_intervals, seconds_budget=20.0):
-    """Times the CPU oracle ("port": a restatement of OCS2 + qpOASES semantics, not the upstream binaries) on the
-    host cores for a bounded sample of the same workload."""
+    """Times the CPU oracle ("port": the builder's restatement of the OCS2 SQP + qpOASES WBC semantics — NOT the upstream
+    binaries, which cannot be built here; it carries 44-wide dual numbers through a sum-over-bodies model and is a soft
+    target) on the host cores for a bounded sample of the same workload.  The reference's own design budget for comparison:
+    one MPC iteration within 10 ms on 4 threads at N ~ 54 (task.info:144,150), one WBC within 2 ms (hunter.yaml:2)."""
+    from oracle import workloads
     from oracle.pyoracle import Oracle
     cores = usable_cores()
     o = Oracle(params)
     n = cores  # one instance per core and repetition
-    refs, x0, rbd, t_now = make_batch(params, n, n_intervals, first_inst=0)
+    refs, x0, rbd, t_now = workloads.trot_batch(params, n, n_intervals=n_intervals, first_inst=0)
     nmax = refs["mode"].shape[1]
     x = np.zeros((n, nmax + 1, 22))
     u = np.zeros((n, nmax, 22))
@@ -108,24 +105,111 @@ def cpu_baseline(params, n_intervals, seconds_budget=20.0):
     return {
         "value": done / total, "unit": "updates/s", "cores": cores, "kind": "port",
         "sample": f"{done} updates ({n} instances x {done // n} repetitions, N={n_intervals}, warm-started) on {cores} threads; "
-                  f"MPC {1e3 * t_mpc / done * cores:.1f} ms and WBC {1e3 * t_wbc / done * cores:.3f} ms per instance per core",
+                  f"MPC {1e3 * t_mpc / done * cores:.1f} ms and WBC {1e3 * t_wbc / done * cores:.3f} ms per instance per core; "
+                  "oracle port of the OCS2 + qpOASES semantics, not the upstream binaries",
     }
+
+
+def config1_latency(params, device, n_list=(54, 100), reps=40):
+    """The reference's own operating point: ONE robot, timeHorizon 0.8 s (task.info:144 -> N = 54) and the benchmark's N = 100.
+    Wall latency of one MPC call (hb_mpc_solve with a host observation + sync) and of one control tick (hb_wbc_update with host
+    pointers in and out) against the reference's 100 Hz / 500 Hz budgets (task.info:150, hunter.yaml:2)."""
+    from hunter_bipedal_control_amd import workload
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    out = {"mpc_budget_ms": 10.0, "wbc_budget_ms": 2.0}
+    for N in n_list:
+        s = HunterSolver(params, batch=1, max_nodes=N + 4, device=device)
+        try:
+            w = workload.device_trot_batch(s, params, n_intervals=N)
+            x0, rbd, t_now = w["x0"], w["rbd"], w["t_now"]
+            seq = x0_sequence(x0, 5)
+            for k in range(5):
+                s.mpc_solve(seq[k % len(seq)])
+                s.sync()
+            s.publish()
+            t_mpc, t_wbc = [], []
+            for k in range(reps):
+                t0 = time.perf_counter()
+                s.mpc_solve(seq[k % len(seq)])
+                s.sync()
+                t1 = time.perf_counter()
+                s.publish()
+                t2 = time.perf_counter()
+                out_w = s.wbc_update(t_now, rbd, dt=0.002)
+                t3 = time.perf_counter()
+                assert out_w["status"][0] == 0
+                t_mpc.append(1e3 * (t1 - t0))
+                t_wbc.append(1e3 * (t3 - t2))
+            out[f"N{N}"] = {"mpc_ms_median": float(np.median(t_mpc)), "mpc_ms_max": float(np.max(t_mpc)),
+                            "wbc_tick_ms_median": float(np.median(t_wbc)), "wbc_tick_ms_max": float(np.max(t_wbc))}
+        finally:
+            s.close()
+    return out
+
+
+def full_tick_figure(params, s, w, steps, dt_mpc=0.010):
+    """Second figure: the whole per-MPC-call path of the reference in the timed region — state estimation (sensor arrays from
+    the host: PCIe inclusive), reference generation at the advancing time (tables refreshed every call, as
+    SwitchedModelReferenceManager::modifyReferences is), one SQP iteration, publish, policy evaluation + WBC."""
+    from hunter_bipedal_control_amd import abi
+    B = s.B
+    rbd = w["rbd"]
+    zyx = rbd[:, 0:3]
+    cz, sz, cy, sy, cx, sx = (np.cos(zyx[:, 0] / 2), np.sin(zyx[:, 0] / 2), np.cos(zyx[:, 1] / 2), np.sin(zyx[:, 1] / 2),
+                              np.cos(zyx[:, 2] / 2), np.sin(zyx[:, 2] / 2))
+    quat = np.stack([sx * cy * cz - cx * sy * sz, cx * sy * cz + sx * cy * sz, cx * cy * sz - sx * sy * cz,
+                     cx * cy * cz + sx * sy * sz], axis=1)          # (x, y, z, w) of the ZYX rotation
+    w_loc = np.zeros((B, 3))
+    a_loc = np.tile([0.0, 0.0, 9.81], (B, 1))
+    contact = np.ones((B, 4), dtype=np.int32)
+    xh0 = np.zeros((B, 18))
+    xh0[:, 0:3] = rbd[:, 3:6]
+    feet = s.eval_foot_kinematics(w["x0"], np.zeros((B, 22)))[0]
+    xh0[:, 6:18] = np.asarray(feet).reshape(B, 12)
+    s.set_resident_x0_sequence(None)
+    s.estimator_reset(abi.make_estimator_config(params), xh0)
+    t = w["t_now"].copy()
+
+    def tick(k):
+        s.estimator_update(0.002, quat, w_loc, a_loc, rbd[:, 6:16], rbd[:, 22:32], contact, to_resident=True)
+        status = s.refgen_update(t + dt_mpc * k, w["horizon"], None, w["cmd"])
+        s.step_resident()
+        return status
+
+    for k in range(3):
+        tick(k)
+    s.sync()
+    t0 = time.perf_counter()
+    bad = 0
+    for k in range(steps):
+        bad = max(bad, int(tick(3 + k).max()))
+    s.sync()
+    el = time.perf_counter() - t0
+    sol, status = s.get_wbc_solution()
+    return {"updates_per_s": B * steps / el, "ms_per_step": 1e3 * el / steps, "steps": steps,
+            "refgen_status_max": bad, "wbc_status_histogram": [int((status == i).sum()) for i in range(4)],
+            "mpc_status_histogram": [int((s.mpc_status() == i).sum()) for i in range(4)],
+            "what": "estimator (host sensor arrays, PCIe inclusive) + device reference generation at the advancing time + "
+                    "1 SQP iteration + publish + policy evaluation + WBC per step"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU (weak scaling)")
+    ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: this many instances split over the ranks")
     ap.add_argument("--nodes", type=int, default=100, help="shooting intervals N")
     ap.add_argument("--chunks", type=int, default=1, help="instance ranges pipelined on separate HIP streams")
+    ap.add_argument("--random-cmd", action="store_true", help="configs[3]: per-instance cmd_vel, gait from walkGait")
+    ap.add_argument("--gather", action="store_true", help="time an RCCL all-gather of status + trajectories (multi-GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the full-tick figure and the config-1 latency block")
     args = ap.parse_args()
 
     import torch
-    from hunter_bipedal_control_amd import ingest, sharding
-    from oracle import workloads
+    from hunter_bipedal_control_amd import ingest, sharding, workload
     from hunter_bipedal_control_amd.solver import HunterSolver
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,14 +224,23 @@ def main():
         dist.init_process_group(backend="nccl")  # RCCL
 
     params = ingest.load_packaged()
-    B, N = args.batch, args.nodes
-    refs, x0, rbd, t_now = make_batch(params, B, N, first_inst=rank * B)
+    N = args.nodes
+    strong = args.total_batch > 0
+    if strong:
+        lo, hi = sharding.shard_range(args.total_batch, world, rank)
+        B, first = hi - lo, lo
+        total_instances = args.total_batch
+    else:
+        B, first = args.batch, rank * args.batch
+        total_instances = args.batch * world
     s = HunterSolver(params, batch=B, max_nodes=N, device=local_rank)
-    s.set_references(refs)
-    s.reset(x0)
-    s.set_resident_inputs(x0, t_now, rbd)
-    s.set_resident_x0_sequence(x0_sequence(x0, rank))
+    t_setup = time.perf_counter()
+    w = workload.device_trot_batch(s, params, n_intervals=N, first_inst=first, cmd_vel_random=args.random_cmd)
+    s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+    s.set_resident_x0_sequence(x0_sequence(w["x0"], rank))
     s.set_chunks(args.chunks)
+    s.sync()
+    t_setup = time.perf_counter() - t_setup
 
     def barrier():
         s.sync()
@@ -166,13 +259,13 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, dist, device="cuda")
     ms_per_step = 1e3 * elapsed / args.steps
-    value = sharding.aggregate_throughput(B, world, args.steps, elapsed)
+    value = total_instances * args.steps / elapsed
 
     # per-kernel device time: HIP events recorded on the library's own MPC / WBC streams (hb_get_stats), averaged
     # over extra un-timed steps with a sync after each so the events are complete.
     s.set_chunks(1)  # phase times are recorded on one stream
-    phases = {"k_lq": 0.0, "k_ric_bwd": 0.0, "k_ric_fwd": 0.0, "linesearch": 0.0, "k_wbc": 0.0}
-    n_prof = 5
+    phases = {"k_lq": 0.0, "k_ric_bwd": 0.0, "k_ric_fwd": 0.0, "linesearch": 0.0, "k_wbc": 0.0, "mpc_total": 0.0}
+    n_prof = 10
     for _ in range(n_prof):
         s.step_resident()
         st = s.stats()
@@ -181,38 +274,99 @@ def main():
         phases["k_ric_fwd"] += st["ms_riccati_fwd"] / n_prof
         phases["linesearch"] += st["ms_linesearch"] / n_prof
         phases["k_wbc"] += st["ms_wbc"] / n_prof
+        phases["mpc_total"] += st["ms_mpc_total"] / n_prof
     perf = s.get_performance()
     sol, status = s.get_wbc_solution()
-    s.close()
+    mpc_status = s.mpc_status()
+    n_nodes = s.get_references()["n_nodes"]
     hist = sharding.sum_over_ranks([int((status == k).sum()) for k in range(4)], dist, device="cuda")
+    mpc_hist = sharding.sum_over_ranks([int((mpc_status == k).sum()) for k in range(4)], dist, device="cuda")
+    step_hist = sharding.sum_over_ranks([int((perf[:, 3] == 1.0).sum()), int(((perf[:, 3] < 1.0) & (perf[:, 3] > 0.0)).sum()),
+                                         int((perf[:, 3] == 0.0).sum())], dist, device="cuda")
+
+    # optional: what a gather of the per-instance outputs over xGMI would add
+    gather = None
+    if args.gather and dist is not None:
+        xs, us = s.get_solution()
+        payload = torch.from_numpy(np.concatenate([xs.ravel(), us.ravel()])).cuda()
+        st_t = torch.from_numpy(status.astype(np.int32)).cuda()
+        out_p = torch.empty(world * payload.numel(), dtype=payload.dtype, device="cuda")
+        out_s = torch.empty(world * st_t.numel(), dtype=st_t.dtype, device="cuda")
+        for _ in range(2):
+            dist.all_gather_into_tensor(out_s, st_t)
+            dist.all_gather_into_tensor(out_p, payload)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            dist.all_gather_into_tensor(out_s, st_t)
+            dist.all_gather_into_tensor(out_p, payload)
+        torch.cuda.synchronize()
+        g_ms = sharding.max_over_ranks(1e3 * (time.perf_counter() - tg) / reps, dist, device="cuda")
+        gather = {"ms_per_step": g_ms, "bytes_per_rank": int(payload.numel() * 8 + st_t.numel() * 4),
+                  "value_with_gather": total_instances / ((ms_per_step + g_ms) * 1e-3),
+                  "what": "all-gather (RCCL) of the status words and the x / u solution trajectories of every instance"}
+
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            extras["with_refgen_and_estimator"] = full_tick_figure(params, s, w, steps=max(10, min(50, args.steps // 4)))
+        except Exception as e:  # noqa: BLE001  (a secondary figure must not take the headline line down)
+            extras["with_refgen_and_estimator"] = {"error": repr(e)}
+    s.close()
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            extras["config1_latency_ms"] = config1_latency(params, local_rank)
+        except Exception as e:  # noqa: BLE001
+            extras["config1_latency_ms"] = {"error": repr(e)}
 
     if rank == 0:
         dom = max(("k_lq", "k_ric_bwd", "k_ric_fwd"), key=lambda k: phases[k])
-        alg_bytes = BYTES_PER_NODE[dom] * N * B
+        alg_bytes = BYTES_PER_NODE[dom] * int(n_nodes.sum())
         achieved = alg_bytes / (phases[dom] * 1e-3) / 1e9
         traffic = None
         pmc = ROOT / "profiles" / "pmc_latest.json"
-        if pmc.exists():
+        if pmc.exists() and B == 4096 and N == 100:
             try:
                 traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        per_kernel = {k: {"ms": phases[k], "algorithmic_GBs": BYTES_PER_NODE[k] * int(n_nodes.sum()) / (phases[k] * 1e-3) / 1e9,
+                          "frac_of_hbm_peak": BYTES_PER_NODE[k] * int(n_nodes.sum()) / (phases[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                      for k in ("k_lq", "k_ric_bwd", "k_ric_fwd")}
         out = {
             "metric": "MPC+WBC updates/sec (batch=4096, N=100, 12-DoF)",
             "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"batch={B}/GPU hunter instances, trot gait, N={N} shooting intervals (dt 0.015 s), "
-                                   "1 SQP iteration + WeightedWbc per update, inputs resident in HBM (BASELINE.json configs[2])",
-                       "batch_per_gpu": B, "horizon_nodes": N, "parallelism": f"instances sharded x{world}, no data-path collective; {args.chunks} pipelined instance ranges per GPU"},
+            "config": {"workload": f"{total_instances} distinct hunter instances ({B}/GPU, state seed 1234 + id), "
+                                   + ("per-instance cmd_vel (seed 4321 + id), gait per instance from walkGait"
+                                      if args.random_cmd else "trot gait from t = 0.1, cmd_vel (0.3, 0, 0, 0)")
+                                   + f", N={N} shooting intervals (dt 0.015 s), node tables generated on the device "
+                                     "(hb_refgen_update, per-knot IK joint references), 1 SQP iteration + WeightedWbc per update, "
+                                     "inputs resident in HBM (BASELINE.json configs[" + ("3" if args.random_cmd or strong else "2") + "])",
+                       "batch_per_gpu": B, "total_instances": total_instances, "horizon_nodes": N, "setup_s": t_setup,
+                       "parallelism": (f"strong scaling: {total_instances} instances split over {world} rank(s)" if strong else
+                                       f"weak scaling: {B} instances per rank x {world}") +
+                                      f", no data-path collective; {args.chunks} pipelined instance range(s) per GPU"
+                                      + ("; all-gather of outputs timed separately" if gather else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": phases[dom],
-                         "whole_update_frac_of_hbm_roofline": (BYTES_PER_UPDATE(N) * value / world) / (HBM_PEAK_GBS * 1e9)},
+                         "whole_update_frac_of_hbm_roofline": (BYTES_PER_UPDATE(N) * value / world) / (HBM_PEAK_GBS * 1e9),
+                         "per_kernel": per_kernel},
             "phase_ms": phases,
+            "halves": {"mpc_solves_per_s_per_gpu": B / (phases["mpc_total"] * 1e-3), "wbc_solves_per_s_per_gpu": B / (phases["k_wbc"] * 1e-3),
+                       "note": "device time of each half alone (HIP events); the reference runs them 1:5 (100 Hz MPC, 500 Hz WBC)"},
             "solver_state": {"max_dyn_sse": float(perf[:, 1].max()), "max_eq_sse": float(perf[:, 2].max()),
-                             "wbc_status_histogram_all_ranks": hist},
+                             "wbc_status_histogram_all_ranks": hist, "mpc_status_histogram_all_ranks": mpc_hist,
+                             "line_search_step_histogram_all_ranks": {"full": step_hist[0], "backtracked": step_hist[1], "rejected": step_hist[2]},
+                             "nodes_per_instance_min_max": [int(n_nodes.min()), int(n_nodes.max())]},
         }
+        if gather:
+            out["gather"] = gather
+        out.update(extras)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(params, N)
         print(json.dumps(out))

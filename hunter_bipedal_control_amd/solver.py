@@ -253,6 +253,9 @@ class HunterSolver:
                                                     _p(_f64(rbd, (self.B, 32))), _p(walk)), "hb_set_resident_inputs")
 
     def set_resident_x0_sequence(self, x0_seq):
+        if x0_seq is None:  # back to the single device-resident observation
+            self._check(self.lib.hb_set_resident_x0_sequence(self.ctx, C.c_int32(0), None), "hb_set_resident_x0_sequence")
+            return
         x0_seq = _f64(x0_seq)
         assert x0_seq.ndim == 3 and x0_seq.shape[1:] == (self.B, 22)
         self._check(self.lib.hb_set_resident_x0_sequence(self.ctx, C.c_int32(x0_seq.shape[0]), _p(x0_seq)), "hb_set_resident_x0_sequence")
@@ -287,7 +290,7 @@ class HunterSolver:
         self._check(self.lib.hb_refgen_reset(self.ctx, C.byref(rg_cfg), _p(ls)), "hb_refgen_reset")
 
     def refgen_set_schedule(self, schedules, inst_begin: int = 0):
-        """schedules: list of refgen.ModeSchedule, one per instance."""
+        """schedules: list of gait.ModeSchedule (event_times, modes), one per instance."""
         cnt = len(schedules)
         n_ev = np.array([len(s.event_times) for s in schedules], dtype=np.int32)
         if n_ev.max(initial=0) > abi.HB_MAX_EVENTS:

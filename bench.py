@@ -147,13 +147,26 @@ def config1_latency(params, device, n_list=(54, 100), reps=40):
     return out
 
 
-def full_tick_figure(params, s, w, steps, dt_mpc=0.010):
+def full_tick_figure(params, device, B, N, first, random_cmd, steps, dt_mpc=0.010):
     """Second figure: the whole per-MPC-call path of the reference in the timed region — state estimation (sensor arrays from
     the host: PCIe inclusive), reference generation at the advancing time (tables refreshed every call, as
     SwitchedModelReferenceManager::modifyReferences is), one SQP iteration, publish, policy evaluation + WBC."""
+    from hunter_bipedal_control_amd import abi, workload
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    # its own context: off the grid-aligned start time the event-clipped grid needs a few more than N intervals
+    s = HunterSolver(params, batch=B, max_nodes=N + 8, device=device)
+    try:
+        return _full_tick(params, s, workload.device_trot_batch(s, params, n_intervals=N, first_inst=first, cmd_vel_random=random_cmd),
+                          steps, dt_mpc)
+    finally:
+        s.close()
+
+
+def _full_tick(params, s, w, steps, dt_mpc):
     from hunter_bipedal_control_amd import abi
     B = s.B
     rbd = w["rbd"]
+    s.set_resident_inputs(w["x0"], w["t_now"], rbd)
     zyx = rbd[:, 0:3]
     cz, sz, cy, sy, cx, sx = (np.cos(zyx[:, 0] / 2), np.sin(zyx[:, 0] / 2), np.cos(zyx[:, 1] / 2), np.sin(zyx[:, 1] / 2),
                               np.cos(zyx[:, 2] / 2), np.sin(zyx[:, 2] / 2))
@@ -166,11 +179,11 @@ def full_tick_figure(params, s, w, steps, dt_mpc=0.010):
     xh0[:, 0:3] = rbd[:, 3:6]
     feet = s.eval_foot_kinematics(w["x0"], np.zeros((B, 22)))[0]
     xh0[:, 6:18] = np.asarray(feet).reshape(B, 12)
-    s.set_resident_x0_sequence(None)
     s.estimator_reset(abi.make_estimator_config(params), xh0)
     t = w["t_now"].copy()
 
     def tick(k):
+        s.set_resident_time(t + dt_mpc * k)
         s.estimator_update(0.002, quat, w_loc, a_loc, rbd[:, 6:16], rbd[:, 22:32], contact, to_resident=True)
         status = s.refgen_update(t + dt_mpc * k, w["horizon"], None, w["cmd"])
         s.step_resident()
@@ -309,13 +322,13 @@ def main():
                   "what": "all-gather (RCCL) of the status words and the x / u solution trajectories of every instance"}
 
     extras = {}
-    if rank == 0 and world == 1 and not args.no_extras:
-        try:
-            extras["with_refgen_and_estimator"] = full_tick_figure(params, s, w, steps=max(10, min(50, args.steps // 4)))
-        except Exception as e:  # noqa: BLE001  (a secondary figure must not take the headline line down)
-            extras["with_refgen_and_estimator"] = {"error": repr(e)}
     s.close()
     if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            extras["with_refgen_and_estimator"] = full_tick_figure(params, local_rank, B, N, first, args.random_cmd,
+                                                                   steps=max(10, min(50, args.steps // 4)))
+        except Exception as e:  # noqa: BLE001  (a secondary figure must not take the headline line down)
+            extras["with_refgen_and_estimator"] = {"error": repr(e)}
         try:
             extras["config1_latency_ms"] = config1_latency(params, local_rank)
         except Exception as e:  # noqa: BLE001

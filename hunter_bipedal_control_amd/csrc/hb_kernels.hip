@@ -669,7 +669,7 @@ struct EstBatch {
   const double *quat, *w_local, *a_local, *qj, *qdj;  // inputs [B][4|3|3|10|10]
   const int* contact;                                 // [B][4]
   double *rbd, *x;                                    // outputs [B][32], [B][22]
-  double *res_rbd, *res_x0, *res_t;                   // resident inputs of hb_step_resident (or null)
+  double *res_rbd, *res_x0;                           // resident inputs of hb_step_resident (or null)
 };
 
 __global__ __launch_bounds__(64) void k_estimator(EstBatch e, const DevModel* __restrict__ M, hb_estimator_config K, double dt) {
@@ -682,7 +682,6 @@ __global__ __launch_bounds__(64) void k_estimator(EstBatch e, const DevModel* __
     __syncthreads();  // lane 0 wrote the outputs
     for (int c = cx.lane; c < HB_NRBD; c += 64) e.res_rbd[HB_NRBD * i + c] = e.rbd[HB_NRBD * i + c];
     for (int c = cx.lane; c < HB_NX; c += 64) e.res_x0[HB_NX * i + c] = e.x[HB_NX * i + c];
-    if (cx.lane == 0) e.res_t[i] += dt;  // the resident time follows the observation, as in hb_plant_step
   }
 }
 __global__ void k_estimator_reset(int B, double* xhat, double* P, double* yaw_last, const double* xhat0) {
@@ -1203,7 +1202,6 @@ static int32_t estimator_run(hb_ctx* ctx, double dt, int32_t to_resident, double
   hipStream_t s = ctx->s_wbc;
   e.res_rbd = to_resident ? ctx->w.rbd : nullptr;
   e.res_x0 = to_resident ? ctx->b.x0 : nullptr;
-  e.res_t = to_resident ? ctx->w.t_now : nullptr;
   if (to_resident) {  // the resident observation feeds the MPC stream: write it between two ordering points (as hb_plant_step does)
     HB_HIP(hipEventRecord(ctx->ev_sync[0], ctx->s_mpc));
     HB_HIP(hipStreamWaitEvent(s, ctx->ev_sync[0], 0));
@@ -1679,6 +1677,14 @@ int32_t hb_set_resident_inputs(hb_ctx* ctx, const double* x0, const double* t_no
   HB_HIP(hipMemcpy(ctx->w.t_now, t_now, B * 8, hipMemcpyHostToDevice));
   HB_HIP(hipMemcpy(ctx->w.rbd, rbd, B * HB_NRBD * 8, hipMemcpyHostToDevice));
   if (walk_flag) HB_HIP(hipMemcpy(ctx->w.walk, walk_flag, B * sizeof(int), hipMemcpyHostToDevice));
+  return HB_OK;
+}
+
+int32_t hb_set_resident_time(hb_ctx* ctx, const double* t_now) {
+  if (!ctx || !t_now) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipMemcpyAsync(ctx->w.t_now, t_now, size_t(ctx->B) * 8, hipMemcpyHostToDevice, ctx->s_wbc));
+  HB_HIP(hipStreamSynchronize(ctx->s_wbc));  // host buffer is caller-owned
   return HB_OK;
 }
 

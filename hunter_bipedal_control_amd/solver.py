@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
     "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd", "hb_plant_reset", "hb_plant_step",
     "hb_plant_get_state", "hb_hoqp_solve", "hb_mpc_reset_masked", "hb_mpc_get_status", "hb_joint_set_flags",
-    "hb_joint_get_emergency_stop",
+    "hb_joint_get_emergency_stop", "hb_set_resident_time",
 ]
 # include/hunter_lcm.h
 LCM_SYMBOLS = ["hb_lcm_fingerprint", "hb_lcm_encoded_size", "hb_lcm_field_count", "hb_lcm_encode", "hb_lcm_decode", "hb_lcm_frame",
@@ -251,6 +251,9 @@ class HunterSolver:
         walk = None if walk_flag is None else _i32(walk_flag, (self.B,))
         self._check(self.lib.hb_set_resident_inputs(self.ctx, _p(_f64(x0, (self.B, 22))), _p(_f64(t_now, (self.B,))),
                                                     _p(_f64(rbd, (self.B, 32))), _p(walk)), "hb_set_resident_inputs")
+
+    def set_resident_time(self, t_now):
+        self._check(self.lib.hb_set_resident_time(self.ctx, _p(_f64(t_now, (self.B,)))), "hb_set_resident_time")
 
     def set_resident_x0_sequence(self, x0_seq):
         if x0_seq is None:  # back to the single device-resident observation

@@ -74,7 +74,10 @@ def device_trot_batch(solver, params: dict, n_intervals: int = 100, first_inst: 
     gaits = gait_names(params, x0, cmd, t0) if cmd_vel_random else ["trot"] * B
     cache = {}
     for g in set(gaits):
-        cache[g] = gait.schedule_window(gait.gait_schedule(params, g, t_gait_start, t0 + 2 * horizon + 1.0), t0 - horizon, t0 + 2 * horizon)
+        # like GaitSchedule::getModeSchedule(t0 - T, t0 + 2 T), the schedule must reach PAST t0 + 2 T: the planner looks one stance
+        # phase beyond every swing phase it places (SwingTrajectoryPlanner.cpp:226-236); + 1 s lets the tables be refreshed at
+        # later times without a new schedule (bench.py full-tick figure)
+        cache[g] = gait.schedule_window(gait.gait_schedule(params, g, t_gait_start, t0 + 2 * horizon + 2.0), t0 - horizon - 1.0, 1e9)
     schedules = [cache[g] for g in gaits]
     solver.refgen_reset(abi.make_refgen_config(params, joint_ik=joint_ik))
     solver.refgen_set_schedule(schedules)

@@ -237,6 +237,9 @@ int32_t hb_plant_get_state(hb_ctx* ctx, double* q, double* v, double* rbd, doubl
  * were uploaded once with hb_set_resident_inputs; nothing crosses PCIe. */
 int32_t hb_set_resident_inputs(hb_ctx* ctx, const double* x0, const double* t_now, const double* rbd,
                                const int32_t* walk_flag);
+/* The device-resident controller time alone ([batch], host).  hb_plant_step(to_resident) advances it by itself; an estimator
+ * with to_resident (which replaces the resident observation and rbd state but knows no clock) leaves it to the caller. */
+int32_t hb_set_resident_time(hb_ctx* ctx, const double* t_now);
 int32_t hb_step_resident(hb_ctx* ctx, double dt);
 /* Optional: a device-resident cyclic sequence of measured states x0_seq[n_seq][batch][22]; step k of
  * hb_step_resident starts its MPC solve from x0_seq[k % n_seq] (emulates the estimator feeding a new state each

@@ -146,7 +146,7 @@ def test_device_plant_matches_numpy_plant_and_resident_loop_trots(params):
     for resident in (True, False):
         s = HunterSolver(params, batch=B, max_nodes=108)
         try:
-            loop = (ResidentLoop if resident else DeviceLoop)(s, params, gaits, cmds)
+            loop = ResidentLoop(s, params, gaits, cmds) if resident else DeviceLoop(s, params, gaits, cmds, plant_factory=_Plant)
             for k in range(600):                               # 1.2 s
                 loop.step()
             finals.append(s.plant_state()["q"] if resident else loop.plant.q.copy())

@@ -48,7 +48,7 @@ def _solve_shard(params, lo, hi):
     mass = sum(params["model"]["mass"])
     rows = []
     for i in range(hi - lo):
-        sched = gait.schedule_window(gait.gait_schedule(params, gaits[i], t0, t0 + 2 * horizon + 1.0), t0 - horizon, t0 + 2 * horizon)
+        sched = gait.gait_schedule(params, gaits[i], t0, t0 + 2 * horizon + 1.0)
         ev, md = np.array(sched.event_times, dtype=np.float64), np.array(sched.modes, dtype=np.int32)
         n = C.c_int()
         t, mode = np.zeros(nmax + 1), np.zeros(nmax, dtype=np.int32)

@@ -5,7 +5,7 @@ tag=${1:-r02}; shift
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 python -c "import torch; print(torch.cuda.get_device_name(0))" > $out/device.txt 2>&1
-(time timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 -x --deselect tests/test_closed_loop.py 2>&1 | tail -40) > $out/pytest.log 2>&1
+(time timeout 1500 python -m pytest tests -m gpu -q --maxfail=30 --deselect tests/test_closed_loop.py 2>&1 | tail -40) > $out/pytest.log 2>&1
 for extra in "$@"; do
   case $extra in
     closed) (time timeout 900 python -m pytest tests/test_closed_loop.py -m gpu -q 2>&1 | tail -30) > $out/pytest_closed.log 2>&1 ;;

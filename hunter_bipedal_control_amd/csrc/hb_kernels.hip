@@ -775,6 +775,9 @@ static hipError_t dalloc(hb_ctx* ctx, T** p, size_t n) {
   if (e == hipSuccess) {
     ctx->allocs.push_back(*p);
     e = hipMemset(*p, 0, n * sizeof(T));
+    // the library's streams are non-blocking: without this, work queued on them right after a late allocation (reset mask,
+    // joint-command state, LCM staging) could run BEFORE the zero fill on the null stream
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   }
   return e;
 }

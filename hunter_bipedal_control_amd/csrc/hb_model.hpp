@@ -242,6 +242,23 @@ template <class Ctx, class LEG, class QF, class QDF, class XA = NoExtraAngles>
 HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LEG leg_of, QF qj, QDF qdj, double* blk_all, double* val_all,
                                int n_extra = 0, XA extra = XA(), double* extra_sc = nullptr) {
   const int ntask = 5 * ngroups;
+  // Model constants of this lane's (group, joint) task, requested ONCE up front (device: one task per lane): read where they
+  // are used, every stage paid a global-memory round trip on the model struct — five of them inside the serial frame chain.
+  // The joint origin goes to the chain through LDS (slots 15..17 of the joint block, free until stage B).
+  struct JC { double ax[3], org[3], com[3], in[6], m; };
+  auto load_jc = [&M](int j, JC& c) {
+    const int b = j + 1;
+    for (int e = 0; e < 3; ++e) { c.ax[e] = M.axis[j][e]; c.org[e] = M.origin[j][e]; c.com[e] = M.com[b][e]; }
+    for (int e = 0; e < 6; ++e) c.in[e] = M.inertia[b][e];
+    c.m = M.mass[b];
+  };
+#if defined(__HIP_DEVICE_COMPILE__)
+  JC jc_lane;
+  {
+    const int r = cx.lane < ntask ? cx.lane : 0;
+    load_jc(5 * leg_of(r / 5) + (r - 5 * (r / 5)), jc_lane);
+  }
+#endif
   // A: local joint rotations
   for (int r = cx.lane; r < ntask + n_extra; r += cx.nlanes) {
     const bool ex = r >= ntask;
@@ -252,9 +269,16 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
       extra_sc[2 * (r - ntask)] = sv;
       extra_sc[2 * (r - ntask) + 1] = cv;
     } else {
-      const Mat3<double> E = axis_rot_sc<double>(M.axis[j], sv, cv);
+#if defined(__HIP_DEVICE_COMPILE__)
+      const JC& jc = jc_lane;
+#else
+      JC jc;
+      load_jc(j, jc);
+#endif
+      const Mat3<double> E = axis_rot_sc<double>(jc.ax, sv, cv);
       double* B = blk_all + g * LEGJ_SIZE + k * LEGJ_STRIDE;
       for (int e = 0; e < 9; ++e) B[21 + e] = E.m[e];
+      for (int e = 0; e < 3; ++e) B[15 + e] = jc.org[e];
     }
   }
   cx.sync();
@@ -277,7 +301,7 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
       Rn[e] = r0 * B[21 + col] + r1 * B[21 + 3 + col] + r2 * B[21 + 6 + col];
       if (col == 0) {  // origin of joint k, component `row`
         const double prev = (k > 0) ? B[LEGJ_O - LEGJ_STRIDE + row] : 0.0;
-        B[LEGJ_O + row] = prev + r0 * M.origin[j][0] + r1 * M.origin[j][1] + r2 * M.origin[j][2];
+        B[LEGJ_O + row] = prev + r0 * B[15] + r1 * B[16] + r2 * B[17];
       }
     }
     cx.sync();
@@ -291,17 +315,23 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
   cx.sync();
   // B: per joint, axis and the body behind it (first moment, inertia about the base origin)
   for (int r = cx.lane; r < ntask; r += cx.nlanes) {
-    const int g = r / 5, k = r - 5 * g, j = 5 * leg_of(g) + k, b = j + 1;
+    const int g = r / 5, k = r - 5 * g;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const JC& jc = jc_lane;
+#else
+    JC jc;
+    load_jc(5 * leg_of(g) + k, jc);
+#endif
     double* B = blk_all + g * LEGJ_SIZE + k * LEGJ_STRIDE;
     Mat3<double> Rm, E;
     for (int e = 0; e < 9; ++e) { Rm.m[e] = B[6 + e]; E.m[e] = B[21 + e]; }
     const Vec3<double> o = ld3(B + LEGJ_O);
-    st3(B + LEGJ_A, Rm * Vec3<double>(M.axis[j][0], M.axis[j][1], M.axis[j][2]));
+    st3(B + LEGJ_A, Rm * Vec3<double>(jc.ax[0], jc.ax[1], jc.ax[2]));
     const Mat3<double> R = Rm * E;
-    const double mb = M.mass[b];
-    const Vec3<double> c = o + R * Vec3<double>(M.com[b][0], M.com[b][1], M.com[b][2]);
+    const double mb = jc.m;
+    const Vec3<double> c = o + R * Vec3<double>(jc.com[0], jc.com[1], jc.com[2]);
     st3(B + LEGJ_MCK, mb * c);
-    st6(B + LEGJ_IOK, rotate_inertia<double>(R, M.inertia[b]) + point_inertia<double>(mb, c));
+    st6(B + LEGJ_IOK, rotate_inertia<double>(R, jc.in) + point_inertia<double>(mb, c));
     B[LEGJ_MS] = mb;
   }
   cx.sync();

@@ -80,11 +80,11 @@ def test_udp_short_message_framing(lib):
 
 @pytest.mark.gpu
 def test_device_packers_match_the_host_codec_and_the_array_entry_points(params, golden, lib):
-    import bench
+    from oracle import workloads
     from hunter_bipedal_control_amd import abi
     from hunter_bipedal_control_amd.solver import HunterSolver
     B, N = 64, 20
-    refs, x0, rbd, tn = bench.make_batch(params, B, N, 0)
+    refs, x0, rbd, tn = workloads.trot_batch(params, B, n_intervals=N)
     s = HunterSolver(params, batch=B, max_nodes=N)
     s.set_references(refs); s.reset(x0); s.set_resident_inputs(x0, tn, rbd)
     s.step_resident()

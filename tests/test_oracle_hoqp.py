@@ -101,10 +101,14 @@ def check_two_task_properties(tasks, x0, x1, slack0, slack1, prec=1e-6):
     """The assertions of TEST(HoQP, twoTask): equality satisfaction under strict priority when the slack vanishes, and
     D x <= f + slack on both levels."""
     t0, t1 = tasks
+
+    def is_approx(a, b):  # Eigen::DenseBase::isApprox: |a - b| <= prec * min(|a|, |b|)  (Euclidean norms)
+        return np.linalg.norm(a - b) <= prec * min(np.linalg.norm(a), np.linalg.norm(b))
+
     if np.abs(slack0).max() < prec:
-        assert np.abs(t0["A"] @ x0 - t0["b"]).max() < prec * max(1.0, np.abs(t0["b"]).max())
+        assert is_approx(t0["A"] @ x0, t0["b"])
     if np.abs(slack1).max() < prec and np.abs(slack0).max() < prec:
-        assert np.abs(t0["A"] @ x1 - t0["b"]).max() < prec * max(1.0, np.abs(t0["b"]).max())
+        assert is_approx(t0["A"] @ x1, t0["b"])
     assert (t0["D"] @ x0 <= t0["f"] + slack0 + prec).all()
     assert (t1["D"] @ x1 <= t1["f"] + slack1 + prec).all()
     assert (t0["D"] @ x1 <= t0["f"] + slack0 + prec).all()       # the higher level's inequalities stay hard below it

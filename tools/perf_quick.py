@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Quick device timing of the update (B = 4096, N = 100, device-generated config-3 workload) for kernel work:
+    python tools/perf_quick.py [--lib path/to/variant.so] [--ablate-lq] [--ablate-ric] [--steps K]
+Prints one JSON line per run: phase times from HIP events (hb_get_stats) and the step rate."""
+import argparse, json, os, sys, time
+sys.path.insert(0, ".")
+import numpy as np
+ap = argparse.ArgumentParser()
+ap.add_argument("--lib", default=None)
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--ablate-lq", action="store_true")
+ap.add_argument("--ablate-ric", action="store_true")
+ap.add_argument("--batch", type=int, default=4096)
+args = ap.parse_args()
+from pathlib import Path
+from hunter_bipedal_control_amd import ingest, workload, solver as _solver_mod
+if args.lib:  # a variant build (tools only; the product loader has no override)
+    _solver_mod._LIB_PATH = Path(args.lib).resolve()
+from hunter_bipedal_control_amd.solver import HunterSolver
+import bench
+P = ingest.load_packaged()
+B, N = args.batch, 100
+
+
+def run(reserved=0, steps=args.steps):
+    s = HunterSolver(P, batch=B, max_nodes=N, reserved=reserved)
+    w = workload.device_trot_batch(s, P, n_intervals=N)
+    s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+    s.set_resident_x0_sequence(bench.x0_sequence(w["x0"], 0))
+    for _ in range(3):
+        s.step_resident()
+    s.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.step_resident()
+    s.sync()
+    el = time.perf_counter() - t0
+    acc = {}
+    for _ in range(5):
+        s.step_resident()
+        st = s.stats()
+        for k in ("ms_lq", "ms_riccati_bwd", "ms_riccati_fwd", "ms_linesearch", "ms_wbc", "ms_mpc_total"):
+            acc[k] = acc.get(k, 0.0) + st[k] / 5
+    perf = s.get_performance()
+    ok = bool(np.isfinite(perf).all()) and float(perf[:, 3].min()) > 0
+    s.close()
+    return dict(reserved=reserved, updates_per_s=round(B * steps / el), ms_per_step=round(1e3 * el / steps, 3), sane=ok,
+                **{k: round(v, 3) for k, v in acc.items()})
+
+
+print(json.dumps(dict(lib=args.lib or "default", **run())))
+if args.ablate_lq:
+    for stop in (10, 6, 7, 9, 1, 2, 3, 4, 5, 30, 31, 32, 33, 34):
+        r = run(stop, steps=5)
+        print(json.dumps(dict(stop=stop, ms_lq=r["ms_lq"])))
+if args.ablate_ric:
+    for stop in (20, 21, 22, 23):
+        r = run(stop, steps=5)
+        print(json.dumps(dict(stop=stop, ms_ric_bwd=r["ms_riccati_bwd"])))

@@ -37,6 +37,7 @@ struct WaveCtx {
   int lane;
   static constexpr int nlanes = 64;
   __device__ WaveCtx() : lane(threadIdx.x) {}
+  __device__ explicit WaveCtx(int l) : lane(l) {}
   __device__ void sync() const {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -811,6 +812,7 @@ int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch,
   ctx->config = *config;
   ctx->hmodel = make_dev_model(*model);
   ctx->hconfig = make_dev_config(*config, ctx->hmodel);
+
   auto fail = [&](const char* what, hipError_t e) {
     g_create_error = std::string("hb_create: ") + what + ": " + hipGetErrorString(e);
     for (void* p : ctx->allocs) (void)hipFree(p);

@@ -124,8 +124,172 @@ struct NodeIn {
   int mode;
 };
 
-template <class Ctx>
-HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const NodeIn& in, double* lds, double* rec) {
+// Pointers into the phase-1 view of one node's LDS region (LqLds).
+struct LqP1 {
+  double *xs, *us, *xe, *fv, *FR, *LV_all, *SC, *SW, *J1, *J2, *CDt, *rowval, *LJ_all;
+};
+HB_HD LqP1 lq_p1(double* lds) {
+  LqP1 p;
+  p.xs = lds + LqLds::p1;   // 22 values of x
+  p.us = p.xs + 22;         // 22 values of u
+  p.xe = p.us + 22;         // 22 state values of the second RK2 point
+  p.fv = p.xe + 22;         // 2 x 12 flow-map values (rows 0..11) of the two points
+  p.FR = p.fv + 24;         // 2 x 12: (contact point - COM) at the two points
+  p.LV_all = p.FR + 24;     // 2 points x 2 legs x 27 leg values
+  p.SC = p.LV_all + 108;    // 2 x 6: sin / cos of the ZYX angles at the two RK2 points
+  p.SW = p.SC + 12;         // 4 x 6 swing references of the node
+  p.J1 = lds + LqLds::J1;   // 44 x 12: d f(rows 0..11) / d direction at point 1
+  p.J2 = lds + LqLds::J2;   // same at point 2
+  p.CDt = lds + LqLds::CDt;
+  p.rowval = lds + LqLds::rowval;
+  p.LJ_all = lds + LqLds::LJ;  // 4 x LEGJ_SIZE; its head is overwritten by ABt in the final compose
+  return p;
+}
+
+// Whole-body combine of ONE (node, RK2 point, nonlinear direction) task: directions h, zyx, joints, joint rates run on duals
+// assembled from the stage-1 leg tangents (29 of the 44 directions; ti = 0..28).  Writes column `dir` of the point's Jacobian,
+// for the first point the constraint-row derivatives / values, and — on the lane of direction 0 — the point's values:
+// always for the second point; for the first point only with `first_point_values` (the node-pair kernel has no separate
+// value pre-pass: its first-point pass delivers f(x, u) itself).
+HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int mode, int pt, int ti, bool first_point_values) {
+  const LqP1 P = lq_p1(lds);
+  double* xs = P.xs; double* us = P.us; double* xe = P.xe; double* fv = P.fv; double* FR = P.FR; double* LV_all = P.LV_all;
+  double* SC = P.SC; double* SW = P.SW; double* J1 = P.J1; double* J2 = P.J2; double* CDt = P.CDt; double* rowval = P.rowval;
+  double* LJ_all = P.LJ_all;
+  bool cf[HB_NC];
+  mode_flags(mode, cf);
+  const int dir = ti < 6 ? ti : (ti < 19 ? ti + 3 : ti + 15);
+  double* Jp = pt == 0 ? J1 : J2;
+  const double* LJ = LJ_all + pt * 2 * LEGJ_SIZE;
+  const double* LV = LV_all + pt * 54;
+  const double* xb = pt == 0 ? xs : xe;
+  {
+    // which leg tangent (if any) feeds this direction
+    int tl = -1, ts = 0;
+    if (dir >= 12 && dir < 22) { tl = (dir - 12) / 5; ts = (dir - 12) % 5; }
+    if (dir >= 34) { tl = (dir - 34) / 5; ts = 5 + (dir - 34) % 5; }
+    // leg sums (value of both legs, tangent of the one leg this direction seeds — closed form, in registers)
+    double t[27];
+    if (tl >= 0) {
+      leg_tangent(LJ + tl * LEGJ_SIZE, ts % 5, ts >= 5, t);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 27; ++e) t[e] = 0.0;
+    }
+    auto S = [LV, &t](int e) { return Dual1(LV[e] + LV[27 + e], t[e]); };
+    CentroidalCore<Dual1> core;
+    {
+      Dual1 zyx[3], hn[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) hn[i] = Dual1(xb[i], dir == i ? 1.0 : 0.0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) zyx[i] = Dual1(xb[9 + i], dir == 9 + i ? 1.0 : 0.0);
+      Sym3<Dual1> IOs;
+      IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
+      centroidal_core<Dual1>(M, Vec3<Dual1>(S(0), S(1), S(2)), IOs, Vec3<Dual1>(S(9), S(10), S(11)),
+                             Vec3<Dual1>(S(12), S(13), S(14)), zyx, hn, core, SC + 6 * pt);
+    }
+    // contact points one at a time (rolled loop keeps the register footprint small)
+    Vec3<Dual1> ms;
+#pragma unroll 1
+    for (int i = 0; i < HB_NC; ++i) {
+      const int leg = i & 1, f = i >> 1;
+      const double* v = LV + leg * 27 + 15 + 3 * f;
+      // tangent of contact point f of the seeded leg: selected with conditional moves — indexing t[] with the
+      // (rolled) loop counter would force the whole array into scratch memory
+      const double wl = (tl == leg) ? 1.0 : 0.0;
+      const double tp0 = f ? t[18] : t[15], tp1 = f ? t[19] : t[16], tp2 = f ? t[20] : t[17];
+      const double tv0 = f ? t[24] : t[21], tv1 = f ? t[25] : t[22], tv2 = f ? t[26] : t[23];
+      const Vec3<Dual1> fb{Dual1(v[0], wl * tp0), Dual1(v[1], wl * tp1), Dual1(v[2], wl * tp2)};
+      const Vec3<Dual1> vb{Dual1(v[6], wl * tv0), Dual1(v[7], wl * tv1), Dual1(v[8], wl * tv2)};
+      Vec3<Dual1> fr, fvel;
+      centroidal_foot<Dual1>(core, fb, vb, fr, fvel);
+      const Vec3<Dual1> rr = fr - core.com_rel;
+      const Vec3<Dual1> F{Dual1(us[3 * i]), Dual1(us[3 * i + 1]), Dual1(us[3 * i + 2])};
+      ms = ms + cross(rr, F);
+      if (dir == 0) { FR[12 * pt + 3 * i] = rr.x.v; FR[12 * pt + 3 * i + 1] = rr.y.v; FR[12 * pt + 3 * i + 2] = rr.z.v; }
+      if (pt == 0) {
+        // constraint rows: slot 3i+a  (base position enters only through the closed-form lanes below)
+        const Dual1 pz = Dual1(xs[8]) + fr.z;
+        Dual1 r0, r1, r2;
+        if (cf[i]) {  // zero velocity (LeggedInterface.cpp:436-444)
+          r0 = fvel.x;
+          r1 = fvel.y;
+          r2 = fvel.z + C.zv_gain * pz + C.zv_off;
+        } else {      // normal velocity + xy soft reference (LeggedRobotPreComputation.cpp:96-117)
+          const double* sw = SW + 6 * i;
+          const Dual1 px = Dual1(xs[6]) + fr.x, py = Dual1(xs[7]) + fr.y;
+          r0 = fvel.z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
+          r1 = C.xy_gain * px + fvel.x - (sw[3] + C.xy_gain * sw[0]);
+          r2 = C.xy_gain * py + fvel.y - (sw[4] + C.xy_gain * sw[1]);
+        }
+        const int cdr = cd_row(dir);
+        CDt[cdr * 12 + 3 * i + 0] = r0.d;
+        CDt[cdr * 12 + 3 * i + 1] = r1.d;
+        CDt[cdr * 12 + 3 * i + 2] = r2.d;
+        if (dir == 0) {
+          rowval[3 * i + 0] = r0.v;
+          rowval[3 * i + 1] = r1.v;
+          rowval[3 * i + 2] = r2.v;
+        }
+      }
+    }
+    const double inv_m = rcp_t(M.total_mass);
+    const Dual1 f[12] = {Dual1(0.0), Dual1(0.0), Dual1(0.0), inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
+                         core.v_lin.x, core.v_lin.y, core.v_lin.z, core.euler_rate.x, core.euler_rate.y, core.euler_rate.z};
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = f[i].d;
+    if (dir == 0 && (pt == 1 || first_point_values)) {  // values of this point (single-node form: the first point's come from the pre-pass)
+      double fsx = 0, fsy = 0, fsz = 0;
+      for (int i = 0; i < HB_NC; ++i) { fsx += us[3 * i]; fsy += us[3 * i + 1]; fsz += us[3 * i + 2]; }
+      fv[12 * pt] = inv_m * fsx; fv[12 * pt + 1] = inv_m * fsy; fv[12 * pt + 2] = inv_m * fsz - M.gravity;
+#pragma unroll
+      for (int i = 3; i < 12; ++i) fv[12 * pt + i] = f[i].v;
+    }
+  }
+}
+
+// Closed-form directions of one (node, point): base position (6..8) and contact forces (22..33); ti = 0..14.
+HB_HD void lq_closed_task(const DevModel& M, const DevConfig& C, double* lds, int mode, int pt, int ti) {
+  const LqP1 P = lq_p1(lds);
+  double* FR = P.FR; double* J1 = P.J1; double* J2 = P.J2; double* CDt = P.CDt;
+  bool cf[HB_NC];
+  mode_flags(mode, cf);
+  const int dir = ti < 3 ? 6 + ti : 19 + ti;
+  double* Jp = pt == 0 ? J1 : J2;
+  const bool is_pos = dir < 9, is_f = !is_pos;
+  double col[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) col[i] = 0.0;
+  if (is_f) {
+    const int i = (dir - 22) / 3, a = (dir - 22) % 3;
+    const double inv_m = rcp_t(M.total_mass);
+    col[a] = inv_m;
+    // (r x e_a) / m
+    const double rx = FR[12 * pt + 3 * i], ry = FR[12 * pt + 3 * i + 1], rz = FR[12 * pt + 3 * i + 2];
+    if (a == 0) { col[4] = rz * inv_m; col[5] = -ry * inv_m; }
+    if (a == 1) { col[3] = -rz * inv_m; col[5] = rx * inv_m; }
+    if (a == 2) { col[3] = ry * inv_m; col[4] = -rx * inv_m; }
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = col[i];
+  if (pt == 0 && is_pos) {  // the constraint rows do not depend on the contact forces: those directions are not stored
+    for (int i = 0; i < HB_NC; ++i) {
+      double r0 = 0, r1 = 0, r2 = 0;
+      if (cf[i]) { if (dir == 8) r2 = C.zv_gain; }
+      else { if (dir == 8) r0 = C.kp_normal; if (dir == 6) r1 = C.xy_gain; if (dir == 7) r2 = C.xy_gain; }
+      CDt[dir * 12 + 3 * i + 0] = r0;
+      CDt[dir * 12 + 3 * i + 1] = r1;
+      CDt[dir * 12 + 3 * i + 2] = r2;
+    }
+  }
+}
+
+// Everything after the model phase of one node, executed by the node's own wavefront: RK2 compose, constraint projection,
+// cost / soft-constraint quadratisation, change of variables, stage record.  `xref_at(i)` / `xnext_at(i)` deliver entry i of
+// the reference state and of the next node's state (device: requested at kernel start, one entry per lane).
+template <class Ctx, class XR, class XN>
+HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const NodeIn& in, double* lds, double* rec, XR xref_at, XN xnext_at) {
   double* ABt = lds + LqLds::ABt;
   double* CDt = lds + LqLds::CDt;
   double* xplus = lds + LqLds::xplus;
@@ -150,217 +314,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   const double dt = in.dt;
   bool cf[HB_NC];
   mode_flags(in.mode, cf);
-
-  // -------------------------------------------------------------- phase 1: sensitivities of the RK2 step
-  // The only nonlinear dependence of f and of the foot kinematics is on (zyx, joints); per evaluation point:
-  //   stage 1  one value pass per leg, then 20 lanes = (leg, seed) evaluate closed-form tangents of the leg outputs
-  //   stage 2  lane = direction (44): directions h, zyx, joints, rates run the whole-body combine on duals built
-  //            from the stage-1 tangents; base-position and contact-force directions are closed form
-  // then [A_k | B_k] is composed from the two points' Jacobians (OCS2 RK2 sensitivity, SURVEY.md B.4).
-  double* xs = lds + LqLds::p1;        // 22 values of x
-  double* us = xs + 22;                // 22 values of u
-  double* xe = us + 22;                // 22 state values of the current evaluation point
-  double* fv = xe + 22;                // 2 x 12 flow-map values (rows 0..11) of the two points
-  double* FR = fv + 24;                // 2 x 12: (contact point - COM) at the two points
-  double* LV_all = FR + 24;            // 2 points x 2 legs x 27 leg values
-  double* SC = LV_all + 108;           // 2 x 6: sin / cos of the ZYX angles at the two RK2 points
-  double* SW = SC + 12;                // 4 x 6 swing references of the node
-  double* J1 = lds + LqLds::J1;        // 44 x 12: d f(rows 0..11) / d direction at point 1
-  double* J2 = lds + LqLds::J2;        // same at point 2
-  // (xs, us stay valid to the end of the kernel — no later buffer reaches them — and every later phase reads x and u from
-  // these LDS copies instead of going back to global memory)
-  for (int i = cx.lane; i < 22; i += cx.nlanes) {
-    xs[i] = in.x[i];
-    us[i] = in.u[i];
-    xe[i] = in.x[i];
-  }
-  for (int i = cx.lane; i < 24; i += cx.nlanes) SW[i] = in.swing[i];
-#if defined(__HIP_DEVICE_COMPILE__)
-  // entry `lane` of the reference state and of the next node's state, requested now and used (by the same lane) in the cost
-  // phase and in b~: no global round trip in the middle of the kernel
-  const double xref_l = in.xref[cx.lane < 22 ? cx.lane : 0], xnext_l = in.xnext[cx.lane < 22 ? cx.lane : 0];
-  auto xref_at = [xref_l](int) { return xref_l; };
-  auto xnext_at = [xnext_l](int) { return xnext_l; };
-#else
-  auto xref_at = [&in](int i) { return in.xref[i]; };
-  auto xnext_at = [&in](int i) { return in.xnext[i]; };
-#endif
-  cx.sync();
-  // ---- stage 1: leg value passes of BOTH evaluation points at once.  The legs are evaluated in the base frame and the
-  // joint block of the flow map is the input itself, so the joint state of the second RK2 point (q + dt qd) is known
-  // up front: the four (point, leg) value passes run together, one (evaluation, joint) pair per lane (base-frame suffix
-  // composites per joint, staged in LDS); the direction lanes of stage 2 then
-  // evaluate the closed-form tangents of the 27 leg outputs (rigid rotation of the outboard composite about the seeded
-  // joint axis).
-  if (C.debug_stop == 10) return;
-  double* LJ_all = lds + LqLds::LJ;  // 4 x LEGJ_SIZE; its head is overwritten by ABt in the final compose
-  leg_value_pass_coop(cx, M, 4, [](int g) { return g & 1; },
-                      [xs, us, dt](int g, int j) { return xs[12 + j] + ((g >> 1) ? dt : 0.0) * us[12 + j]; },
-                      [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all, 3, [xs](int i) { return xs[9 + i]; }, SC);
-  if (C.debug_stop == 6) return;
-  // ---- value of the flow map at the first RK2 point (one lane, plain doubles): the second point x + dt f(x, u) must be
-  // known before its directional pass can start, and a value-only evaluation costs well under half a dual pass.
-  for (int l = cx.lane; l < 1; l += cx.nlanes) {
-    const double* LV = LV_all;
-    auto S = [LV](int e) { return LV[e] + LV[27 + e]; };
-    CentroidalCore<double> core;
-    Sym3<double> IOs;
-    IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
-    centroidal_core<double>(M, Vec3<double>(S(0), S(1), S(2)), IOs, Vec3<double>(S(9), S(10), S(11)),
-                            Vec3<double>(S(12), S(13), S(14)), xs + 9, xs, core, SC);
-    Vec3<double> msum;
-    double fsx = 0, fsy = 0, fsz = 0;
-#pragma unroll 1
-    for (int i = 0; i < HB_NC; ++i) {
-      const double* v = LV + (i & 1) * 27 + 15 + 3 * (i >> 1);
-      Vec3<double> fr, fvel;
-      centroidal_foot<double>(core, ld3(v), ld3(v + 6), fr, fvel);
-      const Vec3<double> F(us[3 * i], us[3 * i + 1], us[3 * i + 2]);
-      msum = msum + cross(fr - core.com_rel, F);
-      fsx += F.x; fsy += F.y; fsz += F.z;
-    }
-    const double inv_m = rcp_t(M.total_mass);
-    fv[0] = inv_m * fsx; fv[1] = inv_m * fsy; fv[2] = inv_m * fsz - M.gravity;
-    fv[3] = inv_m * msum.x; fv[4] = inv_m * msum.y; fv[5] = inv_m * msum.z;
-    fv[6] = core.v_lin.x; fv[7] = core.v_lin.y; fv[8] = core.v_lin.z;
-    fv[9] = core.euler_rate.x; fv[10] = core.euler_rate.y; fv[11] = core.euler_rate.z;
-    // second evaluation point of Heun's method: x + dt f(x,u), same input
-    for (int i = 0; i < 22; ++i) xe[i] = xs[i] + dt * (i < 12 ? fv[i] : us[i]);
-  }
-  cx.sync();
-  // sine / cosine of the ZYX angles at the second point, one angle per lane: the 58 lanes of stage 2 then only add tangents
-  for (int i = cx.lane; i < 3; i += cx.nlanes) sincos_t(xe[9 + i], SC[6 + 2 * i], SC[6 + 2 * i + 1]);
-  cx.sync();
-  if (C.debug_stop == 7) return;
-  // ---- stage 2: whole-body combine per (point, direction).  Only 29 of the 44 directions are nonlinear (momentum 0..5,
-  // zyx 9..11, joints 12..21, joint rates 34..43), so both RK2 points fit ONE pass of the wave: task = 29 pt + index.
-  for (int task = cx.lane; task < 58; task += cx.nlanes) {
-    const int pt = task >= 29 ? 1 : 0, ti = task - 29 * pt;
-    const int dir = ti < 6 ? ti : (ti < 19 ? ti + 3 : ti + 15);
-    double* Jp = pt == 0 ? J1 : J2;
-    const double* LJ = LJ_all + pt * 2 * LEGJ_SIZE;
-    const double* LV = LV_all + pt * 54;
-    const double* xb = pt == 0 ? xs : xe;
-    {
-      // which leg tangent (if any) feeds this direction
-      int tl = -1, ts = 0;
-      if (dir >= 12 && dir < 22) { tl = (dir - 12) / 5; ts = (dir - 12) % 5; }
-      if (dir >= 34) { tl = (dir - 34) / 5; ts = 5 + (dir - 34) % 5; }
-      // leg sums (value of both legs, tangent of the one leg this direction seeds — closed form, in registers)
-      double t[27];
-      if (tl >= 0) {
-        leg_tangent(LJ + tl * LEGJ_SIZE, ts % 5, ts >= 5, t);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 27; ++e) t[e] = 0.0;
-      }
-      auto S = [LV, &t](int e) { return Dual1(LV[e] + LV[27 + e], t[e]); };
-      CentroidalCore<Dual1> core;
-      {
-        Dual1 zyx[3], hn[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) hn[i] = Dual1(xb[i], dir == i ? 1.0 : 0.0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) zyx[i] = Dual1(xb[9 + i], dir == 9 + i ? 1.0 : 0.0);
-        Sym3<Dual1> IOs;
-        IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
-        centroidal_core<Dual1>(M, Vec3<Dual1>(S(0), S(1), S(2)), IOs, Vec3<Dual1>(S(9), S(10), S(11)),
-                               Vec3<Dual1>(S(12), S(13), S(14)), zyx, hn, core, SC + 6 * pt);
-      }
-      // contact points one at a time (rolled loop keeps the register footprint small)
-      Vec3<Dual1> ms;
-#pragma unroll 1
-      for (int i = 0; i < HB_NC; ++i) {
-        const int leg = i & 1, f = i >> 1;
-        const double* v = LV + leg * 27 + 15 + 3 * f;
-        // tangent of contact point f of the seeded leg: selected with conditional moves — indexing t[] with the
-        // (rolled) loop counter would force the whole array into scratch memory
-        const double wl = (tl == leg) ? 1.0 : 0.0;
-        const double tp0 = f ? t[18] : t[15], tp1 = f ? t[19] : t[16], tp2 = f ? t[20] : t[17];
-        const double tv0 = f ? t[24] : t[21], tv1 = f ? t[25] : t[22], tv2 = f ? t[26] : t[23];
-        const Vec3<Dual1> fb{Dual1(v[0], wl * tp0), Dual1(v[1], wl * tp1), Dual1(v[2], wl * tp2)};
-        const Vec3<Dual1> vb{Dual1(v[6], wl * tv0), Dual1(v[7], wl * tv1), Dual1(v[8], wl * tv2)};
-        Vec3<Dual1> fr, fvel;
-        centroidal_foot<Dual1>(core, fb, vb, fr, fvel);
-        const Vec3<Dual1> rr = fr - core.com_rel;
-        const Vec3<Dual1> F{Dual1(us[3 * i]), Dual1(us[3 * i + 1]), Dual1(us[3 * i + 2])};
-        ms = ms + cross(rr, F);
-        if (dir == 0) { FR[12 * pt + 3 * i] = rr.x.v; FR[12 * pt + 3 * i + 1] = rr.y.v; FR[12 * pt + 3 * i + 2] = rr.z.v; }
-        if (pt == 0) {
-          // constraint rows: slot 3i+a  (base position enters only through the closed-form lanes below)
-          const Dual1 pz = Dual1(xs[8]) + fr.z;
-          Dual1 r0, r1, r2;
-          if (cf[i]) {  // zero velocity (LeggedInterface.cpp:436-444)
-            r0 = fvel.x;
-            r1 = fvel.y;
-            r2 = fvel.z + C.zv_gain * pz + C.zv_off;
-          } else {      // normal velocity + xy soft reference (LeggedRobotPreComputation.cpp:96-117)
-            const double* sw = SW + 6 * i;
-            const Dual1 px = Dual1(xs[6]) + fr.x, py = Dual1(xs[7]) + fr.y;
-            r0 = fvel.z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
-            r1 = C.xy_gain * px + fvel.x - (sw[3] + C.xy_gain * sw[0]);
-            r2 = C.xy_gain * py + fvel.y - (sw[4] + C.xy_gain * sw[1]);
-          }
-          const int cdr = cd_row(dir);
-          CDt[cdr * 12 + 3 * i + 0] = r0.d;
-          CDt[cdr * 12 + 3 * i + 1] = r1.d;
-          CDt[cdr * 12 + 3 * i + 2] = r2.d;
-          if (dir == 0) {
-            rowval[3 * i + 0] = r0.v;
-            rowval[3 * i + 1] = r1.v;
-            rowval[3 * i + 2] = r2.v;
-          }
-        }
-      }
-      const double inv_m = rcp_t(M.total_mass);
-      const Dual1 f[12] = {Dual1(0.0), Dual1(0.0), Dual1(0.0), inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
-                           core.v_lin.x, core.v_lin.y, core.v_lin.z, core.euler_rate.x, core.euler_rate.y, core.euler_rate.z};
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = f[i].d;
-      if (dir == 0 && pt == 1) {  // values of the second point (the first point's come from the value pass above)
-        double fsx = 0, fsy = 0, fsz = 0;
-        for (int i = 0; i < HB_NC; ++i) { fsx += us[3 * i]; fsy += us[3 * i + 1]; fsz += us[3 * i + 2]; }
-        fv[12] = inv_m * fsx; fv[13] = inv_m * fsy; fv[14] = inv_m * fsz - M.gravity;
-#pragma unroll
-        for (int i = 3; i < 12; ++i) fv[12 + i] = f[i].v;
-      }
-    }
-  }
-  cx.sync();
-  if (C.debug_stop == 9) return;
-  // closed-form directions of both points: base position (6..8) and contact forces (22..33); task = 15 pt + index
-  for (int task = cx.lane; task < 30; task += cx.nlanes) {
-    const int pt = task >= 15 ? 1 : 0, ti = task - 15 * pt;
-    const int dir = ti < 3 ? 6 + ti : 19 + ti;
-    double* Jp = pt == 0 ? J1 : J2;
-    const bool is_pos = dir < 9, is_f = !is_pos;
-    double col[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) col[i] = 0.0;
-    if (is_f) {
-      const int i = (dir - 22) / 3, a = (dir - 22) % 3;
-      const double inv_m = rcp_t(M.total_mass);
-      col[a] = inv_m;
-      // (r x e_a) / m
-      const double rx = FR[12 * pt + 3 * i], ry = FR[12 * pt + 3 * i + 1], rz = FR[12 * pt + 3 * i + 2];
-      if (a == 0) { col[4] = rz * inv_m; col[5] = -ry * inv_m; }
-      if (a == 1) { col[3] = -rz * inv_m; col[5] = rx * inv_m; }
-      if (a == 2) { col[3] = ry * inv_m; col[4] = -rx * inv_m; }
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = col[i];
-    if (pt == 0 && is_pos) {  // the constraint rows do not depend on the contact forces: those directions are not stored
-      for (int i = 0; i < HB_NC; ++i) {
-        double r0 = 0, r1 = 0, r2 = 0;
-        if (cf[i]) { if (dir == 8) r2 = C.zv_gain; }
-        else { if (dir == 8) r0 = C.kp_normal; if (dir == 6) r1 = C.xy_gain; if (dir == 7) r2 = C.xy_gain; }
-        CDt[dir * 12 + 3 * i + 0] = r0;
-        CDt[dir * 12 + 3 * i + 1] = r1;
-        CDt[dir * 12 + 3 * i + 2] = r2;
-      }
-    }
-  }
-  cx.sync();
+  const LqP1 P1 = lq_p1(lds);
+  double* xs = P1.xs; double* us = P1.us; double* fv = P1.fv; double* J1 = P1.J1; double* J2 = P1.J2;
   // ---- compose  x+ = x + dt/2 (f1 + f2(x + dt f1)) :
   //   d x+_i / d dir = [dir==i] + dt/2 (J1 + J2)[dir][i] + dt^2/2 ( sum_{c<12} J2[c][i] J1[dir][c] + sum_j J2[12+j][i] [dir==34+j] )
   // rows 0..11 of x+ : the 44 x 12 x 12 contraction runs on the matrix cores (9 MFMAs)
@@ -908,6 +863,125 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     rec[REC_META + 4] = dt * scal[1];
     rec[REC_META + 5] = dt * scal[2];
   }
+}
+
+template <class Ctx>
+HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const NodeIn& in, double* lds, double* rec) {
+  double* ABt = lds + LqLds::ABt;
+  double* CDt = lds + LqLds::CDt;
+  double* xplus = lds + LqLds::xplus;
+  double* rowval = lds + LqLds::rowval;
+  double* GtG = lds + LqLds::GtG;
+  double* W = lds + LqLds::W;
+  double* Kx = lds + LqLds::Kx;
+  double* Z = lds + LqLds::Z;
+  double* Pj = lds + LqLds::Pj;
+  double* Rjj = lds + LqLds::Rjj;
+  double* Mm = lds + LqLds::Mm;
+  double* RFF = lds + LqLds::RFF;
+  double* qx = lds + LqLds::qx;
+  double* ru = lds + LqLds::ru;
+  double* Qd = lds + LqLds::Qd;
+  double* scal = lds + LqLds::scal;
+  int* ints = reinterpret_cast<int*>(lds + LqLds::ints);
+  int* perm = ints;          // [10]
+  int* eqs = ints + 12;      // [12] eq slot list
+  int* softs = ints + 24;    // [8] soft slot list
+
+  const double dt = in.dt;
+  bool cf[HB_NC];
+  mode_flags(in.mode, cf);
+
+  // -------------------------------------------------------------- phase 1: sensitivities of the RK2 step
+  // The only nonlinear dependence of f and of the foot kinematics is on (zyx, joints); per evaluation point:
+  //   stage 1  one value pass per leg, then 20 lanes = (leg, seed) evaluate closed-form tangents of the leg outputs
+  //   stage 2  lane = direction (44): directions h, zyx, joints, rates run the whole-body combine on duals built
+  //            from the stage-1 tangents; base-position and contact-force directions are closed form
+  // then [A_k | B_k] is composed from the two points' Jacobians (OCS2 RK2 sensitivity, SURVEY.md B.4).
+  double* xs = lds + LqLds::p1;        // 22 values of x
+  double* us = xs + 22;                // 22 values of u
+  double* xe = us + 22;                // 22 state values of the current evaluation point
+  double* fv = xe + 22;                // 2 x 12 flow-map values (rows 0..11) of the two points
+  double* FR = fv + 24;                // 2 x 12: (contact point - COM) at the two points
+  double* LV_all = FR + 24;            // 2 points x 2 legs x 27 leg values
+  double* SC = LV_all + 108;           // 2 x 6: sin / cos of the ZYX angles at the two RK2 points
+  double* SW = SC + 12;                // 4 x 6 swing references of the node
+  double* J1 = lds + LqLds::J1;        // 44 x 12: d f(rows 0..11) / d direction at point 1
+  double* J2 = lds + LqLds::J2;        // same at point 2
+  // (xs, us stay valid to the end of the kernel — no later buffer reaches them — and every later phase reads x and u from
+  // these LDS copies instead of going back to global memory)
+  for (int i = cx.lane; i < 22; i += cx.nlanes) {
+    xs[i] = in.x[i];
+    us[i] = in.u[i];
+    xe[i] = in.x[i];
+  }
+  for (int i = cx.lane; i < 24; i += cx.nlanes) SW[i] = in.swing[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+  // entry `lane` of the reference state and of the next node's state, requested now and used (by the same lane) in the cost
+  // phase and in b~: no global round trip in the middle of the kernel
+  const double xref_l = in.xref[cx.lane < 22 ? cx.lane : 0], xnext_l = in.xnext[cx.lane < 22 ? cx.lane : 0];
+  auto xref_at = [xref_l](int) { return xref_l; };
+  auto xnext_at = [xnext_l](int) { return xnext_l; };
+#else
+  auto xref_at = [&in](int i) { return in.xref[i]; };
+  auto xnext_at = [&in](int i) { return in.xnext[i]; };
+#endif
+  cx.sync();
+  // ---- stage 1: leg value passes of BOTH evaluation points at once.  The legs are evaluated in the base frame and the
+  // joint block of the flow map is the input itself, so the joint state of the second RK2 point (q + dt qd) is known
+  // up front: the four (point, leg) value passes run together, one (evaluation, joint) pair per lane (base-frame suffix
+  // composites per joint, staged in LDS); the direction lanes of stage 2 then
+  // evaluate the closed-form tangents of the 27 leg outputs (rigid rotation of the outboard composite about the seeded
+  // joint axis).
+  if (C.debug_stop == 10) return;
+  double* LJ_all = lds + LqLds::LJ;  // 4 x LEGJ_SIZE; its head is overwritten by ABt in the final compose
+  leg_value_pass_coop(cx, M, 4, [](int g) { return g & 1; },
+                      [xs, us, dt](int g, int j) { return xs[12 + j] + ((g >> 1) ? dt : 0.0) * us[12 + j]; },
+                      [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all, 3, [xs](int i) { return xs[9 + i]; }, SC);
+  if (C.debug_stop == 6) return;
+  // ---- value of the flow map at the first RK2 point (one lane, plain doubles): the second point x + dt f(x, u) must be
+  // known before its directional pass can start, and a value-only evaluation costs well under half a dual pass.
+  for (int l = cx.lane; l < 1; l += cx.nlanes) {
+    const double* LV = LV_all;
+    auto S = [LV](int e) { return LV[e] + LV[27 + e]; };
+    CentroidalCore<double> core;
+    Sym3<double> IOs;
+    IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
+    centroidal_core<double>(M, Vec3<double>(S(0), S(1), S(2)), IOs, Vec3<double>(S(9), S(10), S(11)),
+                            Vec3<double>(S(12), S(13), S(14)), xs + 9, xs, core, SC);
+    Vec3<double> msum;
+    double fsx = 0, fsy = 0, fsz = 0;
+#pragma unroll 1
+    for (int i = 0; i < HB_NC; ++i) {
+      const double* v = LV + (i & 1) * 27 + 15 + 3 * (i >> 1);
+      Vec3<double> fr, fvel;
+      centroidal_foot<double>(core, ld3(v), ld3(v + 6), fr, fvel);
+      const Vec3<double> F(us[3 * i], us[3 * i + 1], us[3 * i + 2]);
+      msum = msum + cross(fr - core.com_rel, F);
+      fsx += F.x; fsy += F.y; fsz += F.z;
+    }
+    const double inv_m = rcp_t(M.total_mass);
+    fv[0] = inv_m * fsx; fv[1] = inv_m * fsy; fv[2] = inv_m * fsz - M.gravity;
+    fv[3] = inv_m * msum.x; fv[4] = inv_m * msum.y; fv[5] = inv_m * msum.z;
+    fv[6] = core.v_lin.x; fv[7] = core.v_lin.y; fv[8] = core.v_lin.z;
+    fv[9] = core.euler_rate.x; fv[10] = core.euler_rate.y; fv[11] = core.euler_rate.z;
+    // second evaluation point of Heun's method: x + dt f(x,u), same input
+    for (int i = 0; i < 22; ++i) xe[i] = xs[i] + dt * (i < 12 ? fv[i] : us[i]);
+  }
+  cx.sync();
+  // sine / cosine of the ZYX angles at the second point, one angle per lane: the 58 lanes of stage 2 then only add tangents
+  for (int i = cx.lane; i < 3; i += cx.nlanes) sincos_t(xe[9 + i], SC[6 + 2 * i], SC[6 + 2 * i + 1]);
+  cx.sync();
+  if (C.debug_stop == 7) return;
+  // ---- stage 2: whole-body combine per (point, direction).  Only 29 of the 44 directions are nonlinear (momentum 0..5,
+  // zyx 9..11, joints 12..21, joint rates 34..43), so both RK2 points fit ONE pass of the wave: task = 29 pt + index.
+  for (int task = cx.lane; task < 58; task += cx.nlanes) lq_dual_task(M, C, lds, in.mode, task >= 29 ? 1 : 0, task >= 29 ? task - 29 : task, false);
+  cx.sync();
+  if (C.debug_stop == 9) return;
+  // closed-form directions of both points: base position (6..8) and contact forces (22..33); task = 15 pt + index
+  for (int task = cx.lane; task < 30; task += cx.nlanes) lq_closed_task(M, C, lds, in.mode, task >= 15 ? 1 : 0, task >= 15 ? task - 15 : task);
+  cx.sync();
+  lq_tail(cx, M, C, in, lds, rec, xref_at, xnext_at);
 }
 
 }  // namespace hb

@@ -238,9 +238,17 @@ HB_HD void leg_value_pass(const DevModel& M, int leg, QF qj, QDF qdj, double* bl
 // `extra(i)`, i < n_extra: further angles whose (sin, cos) pairs are wanted (written to extra_sc[2 i], [2 i + 1]); they
 // ride along in the sine / cosine evaluation of stage A on otherwise idle lanes.
 struct NoExtraAngles { HB_HD double operator()(int) const { return 0.0; } };
+// Where group g keeps its data when the groups of one call belong to several nodes (k_lq works on node pairs): groups
+// [n gpb, (n + 1) gpb) live `hi` doubles behind those of node n - 1; `xpn` extra angles per node, their (sin, cos) pairs likewise.
+struct LegLayout {
+  int gpb = 1 << 20, hi = 0, xpn = 1 << 20;
+  HB_HD int blk(int g) const { return (g / gpb) * hi + (g % gpb) * LEGJ_SIZE; }
+  HB_HD int val(int g) const { return (g / gpb) * hi + (g % gpb) * 27; }
+  HB_HD int xsc(int i) const { return (i / xpn) * hi + 2 * (i % xpn); }
+};
 template <class Ctx, class LEG, class QF, class QDF, class XA = NoExtraAngles>
 HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LEG leg_of, QF qj, QDF qdj, double* blk_all, double* val_all,
-                               int n_extra = 0, XA extra = XA(), double* extra_sc = nullptr) {
+                               int n_extra = 0, XA extra = XA(), double* extra_sc = nullptr, LegLayout lay = LegLayout()) {
   const int ntask = 5 * ngroups;
   // Model constants of this lane's (group, joint) task, requested ONCE up front (device: one task per lane): read where they
   // are used, every stage paid a global-memory round trip on the model struct — five of them inside the serial frame chain.
@@ -266,8 +274,8 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
     double sv, cv;
     sincos_t(ex ? extra(r - ntask) : qj(g, j), sv, cv);
     if (ex) {
-      extra_sc[2 * (r - ntask)] = sv;
-      extra_sc[2 * (r - ntask) + 1] = cv;
+      extra_sc[lay.xsc(r - ntask)] = sv;
+      extra_sc[lay.xsc(r - ntask) + 1] = cv;
     } else {
 #if defined(__HIP_DEVICE_COMPILE__)
       const JC& jc = jc_lane;
@@ -276,7 +284,7 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
       load_jc(j, jc);
 #endif
       const Mat3<double> E = axis_rot_sc<double>(jc.ax, sv, cv);
-      double* B = blk_all + g * LEGJ_SIZE + k * LEGJ_STRIDE;
+      double* B = blk_all + lay.blk(g) + k * LEGJ_STRIDE;
       for (int e = 0; e < 9; ++e) B[21 + e] = E.m[e];
       for (int e = 0; e < 3; ++e) B[15 + e] = jc.org[e];
     }
@@ -288,14 +296,14 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
   // free until stage C) and o_k: one ordering point per joint instead of a serial 5-joint chain on one lane per group.
   for (int r = cx.lane; r < 9 * ngroups; r += cx.nlanes) {
     const int g = r / 9, e = r - 9 * g;
-    blk_all[g * LEGJ_SIZE + 6 + e] = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
+    blk_all[lay.blk(g) + 6 + e] = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
   }
   cx.sync();
 #pragma unroll 1
   for (int k = 0; k < 5; ++k) {
     for (int r = cx.lane; r < 9 * ngroups; r += cx.nlanes) {
       const int g = r / 9, e = r - 9 * g, row = e / 3, col = e - 3 * row, j = 5 * leg_of(g) + k;
-      double* B = blk_all + g * LEGJ_SIZE + k * LEGJ_STRIDE;
+      double* B = blk_all + lay.blk(g) + k * LEGJ_STRIDE;
       const double r0 = B[6 + 3 * row], r1 = B[6 + 3 * row + 1], r2 = B[6 + 3 * row + 2];
       double* Rn = (k < 4) ? B + LEGJ_STRIDE + 6 : B + 30;
       Rn[e] = r0 * B[21 + col] + r1 * B[21 + 3 + col] + r2 * B[21 + 6 + col];
@@ -308,8 +316,8 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
   }
   for (int r = cx.lane; r < 6 * ngroups; r += cx.nlanes) {  // contact points behind the last joint: lane (g, f, axis)
     const int g = r / 6, fa = r - 6 * g, f = fa / 3, a = fa - 3 * f, ci = leg_of(g) + 2 * f;
-    const double* B4 = blk_all + g * LEGJ_SIZE + 4 * LEGJ_STRIDE;
-    blk_all[g * LEGJ_SIZE + LEGJ_FEET + fa] = B4[LEGJ_O + a] + B4[30 + 3 * a] * M.contact_offset[ci][0] +
+    const double* B4 = blk_all + lay.blk(g) + 4 * LEGJ_STRIDE;
+    blk_all[lay.blk(g) + LEGJ_FEET + fa] = B4[LEGJ_O + a] + B4[30 + 3 * a] * M.contact_offset[ci][0] +
                                               B4[30 + 3 * a + 1] * M.contact_offset[ci][1] + B4[30 + 3 * a + 2] * M.contact_offset[ci][2];
   }
   cx.sync();
@@ -322,7 +330,7 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
     JC jc;
     load_jc(5 * leg_of(g) + k, jc);
 #endif
-    double* B = blk_all + g * LEGJ_SIZE + k * LEGJ_STRIDE;
+    double* B = blk_all + lay.blk(g) + k * LEGJ_STRIDE;
     Mat3<double> Rm, E;
     for (int e = 0; e < 9; ++e) { Rm.m[e] = B[6 + e]; E.m[e] = B[21 + e]; }
     const Vec3<double> o = ld3(B + LEGJ_O);
@@ -340,7 +348,7 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
   // leaves a divergent loop together; a serial host walks the joints in increasing order, which only needs m >= k).
   for (int r = cx.lane; r < ntask; r += cx.nlanes) {
     const int g = r / 5, k = r - 5 * g, j0 = 5 * leg_of(g);
-    double* blk = blk_all + g * LEGJ_SIZE;
+    double* blk = blk_all + lay.blk(g);
     double* B = blk + k * LEGJ_STRIDE;
     Vec3<double> om, w;
     for (int m = 0; m < k; ++m) {
@@ -372,7 +380,7 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
   // E: suffix sums of the joint-rate momenta and of the joint-induced contact-point velocities
   for (int r = cx.lane; r < ntask; r += cx.nlanes) {
     const int g = r / 5, k = r - 5 * g, j0 = 5 * leg_of(g);
-    double* blk = blk_all + g * LEGJ_SIZE;
+    double* blk = blk_all + lay.blk(g);
     double* B = blk + k * LEGJ_STRIDE;
     const Vec3<double> p0 = ld3(blk + LEGJ_FEET), p1 = ld3(blk + LEGJ_FEET + 3);
     Vec3<double> lin, ang, v0, v1;
@@ -390,7 +398,7 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
     st3(B + LEGJ_VJ, v0);
     st3(B + LEGJ_VJ + 3, v1);
     if (k == 0) {
-      double* val = val_all + 27 * g;
+      double* val = val_all + lay.val(g);
       st3(val + 0, ld3(B + LEGJ_MC)); st6(val + 3, ld6(B + LEGJ_IO)); st3(val + 9, lin); st3(val + 12, ang);
       st3(val + 15, p0); st3(val + 18, p1); st3(val + 21, v0); st3(val + 24, v1);
     }

@@ -1,0 +1,79 @@
+// legged/HipLeggedController — the ros_control plugin surface of the reference (legged::LeggedController,
+// legged_controllers/include/legged_controllers/LeggedController.h:41-62) over the MI355X-native solver.
+// Same base class, same init / starting / update / stopping contract, same topics; the hot path is behind hunter_hip.hpp.
+#pragma once
+
+#include <atomic>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <controller_interface/multi_interface_controller.h>
+#include <geometry_msgs/Twist.h>
+#include <hardware_interface/imu_sensor_interface.h>
+#include <legged_common/hardware_interface/ContactSensorInterface.h>
+#include <legged_common/hardware_interface/HybridJointInterface.h>
+#include <ros/ros.h>
+#include <std_msgs/Float32.h>
+
+#include <hunter_hip.hpp>
+
+namespace legged {
+
+class HipLeggedController
+    : public controller_interface::MultiInterfaceController<HybridJointInterface, hardware_interface::ImuSensorInterface,
+                                                            ContactSensorInterface> {
+ public:
+  HipLeggedController() = default;
+  ~HipLeggedController() override;
+  bool init(hardware_interface::RobotHW* robot_hw, ros::NodeHandle& controller_nh) override;
+  void update(const ros::Time& time, const ros::Duration& period) override;
+  void starting(const ros::Time& time) override;
+  void stopping(const ros::Time& /*time*/) override { mpcRunning_ = false; }
+
+ protected:
+  // the reference's own extension points (LeggedController.h:57-62), kept virtual for the same reason
+  virtual void updateStateEstimation(const ros::Time& time, const ros::Duration& period);
+  virtual void setupMpc();
+  virtual void setupMrt();
+
+  void cmdVelCallback(const geometry_msgs::Twist::ConstPtr& msg);
+  void setWalkCallback(const std_msgs::Float32::ConstPtr& msg);
+  void loadControllerCallback(const std_msgs::Float32::ConstPtr& msg);
+  void emergencyStopCallback(const std_msgs::Float32::ConstPtr& msg);
+
+  // hardware (LeggedController.h:76-80)
+  std::vector<HybridJointHandle> hybridJointHandles_;
+  std::vector<ContactSensorHandle> contactHandles_;
+  hardware_interface::ImuSensorHandle imuSensorHandle_;
+
+  // solver: one context, batch 1
+  hb_model model_{};
+  hb_config config_{};
+  std::unique_ptr<hunter_hip::Context> ctx_;
+  std::unique_ptr<hunter_hip::MpcMrtInterface> mpcMrtInterface_;
+  std::unique_ptr<hunter_hip::ReferenceManager> referenceManager_;
+  std::unique_ptr<hunter_hip::KalmanFilterEstimate> stateEstimate_;
+  hunter_hip::CmdVelFilter cmdVelFilter_;
+
+  hunter_hip::SystemObservation currentObservation_;
+  hunter_hip::vector_t measuredRbdState_;
+  hunter_hip::ControlOutput control_;
+  hb_joint_gains gains_{};
+
+  ros::Subscriber subCmdVel_, subSetWalk_, subLoadController_, subEmergencyStop_;
+  ros::Duration startingTime_;
+
+ private:
+  std::thread mpcThread_;
+  std::atomic_bool controllerRunning_{false}, mpcRunning_{false}, firstStartMpc_{false};
+  std::atomic_bool loadControllerFlag_{false}, setWalkFlag_{false}, emergencyStopFlag_{false};
+  std::mutex cmdMutex_;
+  double cmdVel_[4] = {0.0, 0.0, 0.0, 0.0};   // filtered command [vx vy vz yawRate]
+  double timeHorizon_ = 0.8, mpcDesiredFrequency_ = 100.0;
+  int plannedMode_ = 3;
+};
+
+}  // namespace legged

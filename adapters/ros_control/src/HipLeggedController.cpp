@@ -1,0 +1,193 @@
+// legged/HipLeggedController: LeggedController::{init, starting, update, MPC thread} (legged_controllers/src/LeggedController.cpp:
+// 41-135,137-278,376-431) re-expressed over hunter_hip.hpp.  What runs where:
+//   control thread (update, 500 Hz)   sensors -> hb_estimator_update -> hb_mpc_publish + hb_wbc_update (policy evaluation + WBC)
+//                                     -> hb_joint_command (PD law, limit protection, e-stop) -> HybridJointHandle::setCommand
+//   MPC thread (mpcDesiredFrequency)  GaitSchedule (host) -> hb_refgen_update (targets, footholds, swing splines, IK) -> hb_mpc_solve
+#include "hunter_hip_controllers/HipLeggedController.h"
+
+#include <chrono>
+#include <cmath>
+
+#include <pluginlib/class_list_macros.hpp>
+
+namespace legged {
+
+using hunter_hip::vector_t;
+
+bool HipLeggedController::init(hardware_interface::RobotHW* robot_hw, ros::NodeHandle& controller_nh) {
+  // ---- parameters: the flattened URDF + task.info + reference.info (tools/make_hunter_params.py) — LeggedController.cpp:44-71
+  std::string paramsFile;
+  if (!controller_nh.getParam("/hunter_hip/params_file", paramsFile)) {
+    ROS_ERROR("[HipLeggedController] /hunter_hip/params_file is not set");
+    return false;
+  }
+  int device = 0;
+  controller_nh.getParam("/hunter_hip/device", device);
+  controller_nh.getParam("/hunter_hip/time_horizon", timeHorizon_);
+  controller_nh.getParam("/hunter_hip/mpc_frequency", mpcDesiredFrequency_);
+  try {
+    hunter_hip::loadPackagedParameters(paramsFile, model_, config_);
+    const int maxNodes = int(std::ceil(timeHorizon_ / config_.dt)) + 8;   // event-clipped grid: a few nodes more than T / dt
+    ctx_.reset(new hunter_hip::Context(model_, config_, /*batch*/ 1, maxNodes, device));
+    setupMpc();
+    setupMrt();
+  } catch (const std::exception& e) {   // init() returns false where the reference's constructors throw (LeggedInterface.cpp:62,73,84)
+    ROS_ERROR("[HipLeggedController] %s", e.what());
+    return false;
+  }
+
+  // ---- hardware handles — LeggedController.cpp:90-111
+  auto* hybridJointInterface = robot_hw->get<HybridJointInterface>();
+  const std::vector<std::string> jointNames{"leg_l1_joint", "leg_l2_joint", "leg_l3_joint", "leg_l4_joint", "leg_l5_joint",
+                                            "leg_r1_joint", "leg_r2_joint", "leg_r3_joint", "leg_r4_joint", "leg_r5_joint"};
+  for (const auto& name : jointNames) hybridJointHandles_.push_back(hybridJointInterface->getHandle(name));
+  auto* contactInterface = robot_hw->get<ContactSensorInterface>();
+  for (const auto& name : std::vector<std::string>{"leg_l_f1", "leg_r_f1", "leg_l_f2", "leg_r_f2"})
+    contactHandles_.push_back(contactInterface->getHandle(name));
+  imuSensorHandle_ = robot_hw->get<hardware_interface::ImuSensorInterface>()->getHandle("imu_link");
+
+  // ---- state estimate — setupStateEstimate, LeggedController.cpp:75-83 (settings: task.info kalmanFilter block)
+  hb_estimator_config est{};
+  est.foot_radius = 0.02;
+  est.imu_process_noise_position = 0.02;
+  est.imu_process_noise_velocity = 0.02;
+  est.foot_process_noise_position = 0.002;
+  est.foot_sensor_noise_position = 0.005;
+  est.foot_sensor_noise_velocity = 0.1;
+  est.foot_height_sensor_noise = 0.01;
+  controller_nh.getParam("/hunter_hip/kalman/foot_radius", est.foot_radius);
+  stateEstimate_.reset(new hunter_hip::KalmanFilterEstimate(*ctx_, est));
+
+  // gains: dynamic_reconfigure defaults of legged_controllers/cfg/Tutorials.cfg:6-16
+  gains_.kp_big_stance = 40.0; gains_.kp_big_swing = 30.0; gains_.kd_big = 2.0;
+  gains_.kp_small_stance = 30.0; gains_.kp_small_swing = 20.0; gains_.kd_small = 2.0; gains_.kd_feet = 0.01;
+  gains_.kp_position = 10.0; gains_.kd_position = 3.0;
+
+  // ---- topics — LeggedController.cpp:113-121 and the target publisher's /cmd_vel
+  ros::NodeHandle nh;
+  subCmdVel_ = nh.subscribe<geometry_msgs::Twist>("/cmd_vel", 1, &HipLeggedController::cmdVelCallback, this);
+  subSetWalk_ = nh.subscribe<std_msgs::Float32>("/set_walk", 1, &HipLeggedController::setWalkCallback, this);
+  subLoadController_ = nh.subscribe<std_msgs::Float32>("/load_controller", 1, &HipLeggedController::loadControllerCallback, this);
+  subEmergencyStop_ = nh.subscribe<std_msgs::Float32>("/emergency_stop", 1, &HipLeggedController::emergencyStopCallback, this);
+  return true;
+}
+
+void HipLeggedController::setupMpc() {   // ≙ LeggedController::setupMpc (:376-388): the solver and its reference manager
+  mpcMrtInterface_.reset(new hunter_hip::MpcMrtInterface(*ctx_));
+  hb_refgen_config rg{};
+  rg.dt = config_.dt;
+  rg.com_height = 0.63;              // reference.info:5
+  rg.next_position_z = 0.02;         // task.info swing_trajectory_config
+  rg.swing_height = 0.06;
+  rg.swing_time_scale = 0.15;
+  const double bias[4][3] = {{0.034, 0.11, -0.63}, {0.034, -0.11, -0.63}, {-0.056, 0.11, -0.63}, {-0.056, -0.11, -0.63}};   // task.info:28-31
+  for (int i = 0; i < 4; ++i)
+    for (int a = 0; a < 3; ++a) rg.feet_bias[i][a] = bias[i][a];
+  for (int j = 0; j < HB_NJ; ++j) rg.default_joints[j] = config_.default_joint_state[j];
+  rg.joint_ik = 1;
+  // initialModeSchedule / defaultModeSequenceTemplate of reference.info:21-46
+  hunter_hip::GaitSchedule gait(hunter_hip::ModeSchedule{{0.5}, {3, 3}}, hunter_hip::ModeSequenceTemplate{{0.0, 1.0}, {3}},
+                                /*phaseTransitionStanceTime*/ 0.1);
+  referenceManager_.reset(new hunter_hip::ReferenceManager(*ctx_, rg, std::vector<hunter_hip::GaitSchedule>{gait}));
+  referenceManager_->setWalkGaitSelection(true);   // gaitType_ 0: stance / trot from the averaged command speed (walkGait)
+}
+
+void HipLeggedController::setupMrt() {   // ≙ LeggedController::setupMrt (:390-431): the MPC thread
+  controllerRunning_ = true;
+  mpcThread_ = std::thread([this]() {
+    bool coldStarted = false;
+    while (controllerRunning_) {
+      if (!mpcRunning_) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; }
+      const auto t0 = std::chrono::steady_clock::now();
+      try {
+        hunter_hip::SystemObservation obs;
+        double cmd[4];
+        { std::lock_guard<std::mutex> lk(cmdMutex_); obs = currentObservation_; std::copy(cmdVel_, cmdVel_ + 4, cmd); }
+        const vector_t initTime{obs.time}, cmdVel(cmd, cmd + 4);
+        referenceManager_->preSolverRun(initTime, timeHorizon_, cmdVel, &obs.state);     // modifyReferences
+        if (!coldStarted) { mpcMrtInterface_->resetMpcNode(obs.state); coldStarted = true; }
+        mpcMrtInterface_->setCurrentObservation(obs);
+        mpcMrtInterface_->advanceMpc();                                                  // :406
+        std::vector<int32_t> status(1);
+        ctx_->check(hb_mpc_get_status(ctx_->get(), status.data()), "hb_mpc_get_status");
+        if (status[0] == HB_INST_NAN) throw std::runtime_error("SQP iteration failed (non-finite value / Riccati pivot)");
+        firstStartMpc_ = true;
+      } catch (const std::exception& e) {   // :413-418
+        controllerRunning_ = false;
+        ROS_ERROR("[HipLeggedController MPC thread] Error : %s", e.what());
+        stopRequest(ros::Time());
+      }
+      std::this_thread::sleep_until(t0 + std::chrono::duration<double>(1.0 / mpcDesiredFrequency_));
+    }
+  });
+}
+
+void HipLeggedController::starting(const ros::Time& time) {   // ≙ :112-135
+  startingTime_.fromSec(time.toSec() - 0.0001);
+  updateStateEstimation(time - startingTime_, ros::Duration(0.002));
+  mpcRunning_ = true;
+}
+
+void HipLeggedController::updateStateEstimation(const ros::Time& time, const ros::Duration& period) {   // ≙ :280-349
+  vector_t jointPos(10), jointVel(10), quat(4), angularVel(3), linearAccel(3);
+  for (size_t i = 0; i < hybridJointHandles_.size(); ++i) {
+    jointPos[i] = hybridJointHandles_[i].getPosition();
+    jointVel[i] = hybridJointHandles_[i].getVelocity();
+  }
+  for (size_t i = 0; i < 4; ++i) quat[i] = imuSensorHandle_.getOrientation()[i];
+  for (size_t i = 0; i < 3; ++i) {
+    angularVel[i] = imuSensorHandle_.getAngularVelocity()[i];
+    linearAccel[i] = imuSensorHandle_.getLinearAcceleration()[i];
+  }
+  // commanded contact flags of the planned mode; all closed before the first policy (:298-307)
+  std::vector<int32_t> contact(4, 1);
+  if (firstStartMpc_) {
+    const bool L = plannedMode_ == 2 || plannedMode_ == 3, R = plannedMode_ == 1 || plannedMode_ == 3;
+    contact = {L, R, L, R};
+  }
+  measuredRbdState_ = stateEstimate_->update(period.toSec(), quat, angularVel, linearAccel, jointPos, jointVel, contact);
+  std::lock_guard<std::mutex> lk(cmdMutex_);
+  currentObservation_.time = time.toSec();
+  currentObservation_.state = stateEstimate_->observationState();   // incl. the yaw unwrapping of :331-334
+  currentObservation_.mode = size_t(plannedMode_);
+}
+
+void HipLeggedController::update(const ros::Time& time, const ros::Duration& period) {   // ≙ :137-278
+  const ros::Time shifted = time - startingTime_;
+  updateStateEstimation(shifted, period);
+  if (!firstStartMpc_) return;   // no policy yet: the handles keep their last command
+  const vector_t tNow{currentObservation_.time};
+  const std::vector<int32_t> walk{setWalkFlag_ ? 1 : 0};
+  hunter_hip::controllerUpdate(*mpcMrtInterface_, tNow, measuredRbdState_, &walk, period.toSec(), control_);   // :151-185
+  plannedMode_ = control_.plannedMode[0];
+  currentObservation_.input = control_.optimizedInput;
+  // joint command law with limit protection / e-stop latch / unloaded-controller branch on the device (:186-257)
+  const int32_t loaded = loadControllerFlag_ ? 1 : 0, estop = emergencyStopFlag_ ? 1 : 0;
+  ctx_->check(hb_joint_set_flags(ctx_->get(), &loaded, emergencyStopFlag_ ? &estop : nullptr), "hb_joint_set_flags");
+  double posDes[10], velDes[10], kp[10], kd[10], ff[10];
+  ctx_->check(hb_joint_command(ctx_->get(), &gains_, period.toSec(), posDes, velDes, kp, kd, ff, nullptr), "hb_joint_command");
+  int32_t latched = 0;
+  ctx_->check(hb_joint_get_emergency_stop(ctx_->get(), &latched), "hb_joint_get_emergency_stop");
+  if (latched) emergencyStopFlag_ = true;
+  for (size_t j = 0; j < hybridJointHandles_.size(); ++j) hybridJointHandles_[j].setCommand(posDes[j], velDes[j], kp[j], kd[j], ff[j]);
+}
+
+void HipLeggedController::cmdVelCallback(const geometry_msgs::Twist::ConstPtr& msg) {
+  // the rate limiter of the target publisher's callback (TargetTrajectoriesPublisher.h:101-131); dead band / height clamp
+  // are applied on the device when the targets are built
+  std::lock_guard<std::mutex> lk(cmdMutex_);
+  const double* f = cmdVelFilter_(msg->linear.x, msg->linear.y, msg->angular.z);
+  std::copy(f, f + 4, cmdVel_);
+}
+void HipLeggedController::setWalkCallback(const std_msgs::Float32::ConstPtr&) { setWalkFlag_ = true; }                  // :483-487
+void HipLeggedController::loadControllerCallback(const std_msgs::Float32::ConstPtr&) { loadControllerFlag_ = true; }    // :489-493
+void HipLeggedController::emergencyStopCallback(const std_msgs::Float32::ConstPtr&) { emergencyStopFlag_ = true; }      // :477-481
+
+HipLeggedController::~HipLeggedController() {   // ≙ :351-374
+  controllerRunning_ = false;
+  if (mpcThread_.joinable()) mpcThread_.join();
+}
+
+}  // namespace legged
+
+PLUGINLIB_EXPORT_CLASS(legged::HipLeggedController, controller_interface::ControllerBase)

@@ -18,8 +18,11 @@
 // One Context = one GPU = `batch` independent robot instances.  batch == 1 reproduces the reference's shapes.
 #pragma once
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <numeric>
 #include <iostream>
 #include <memory>
 #include <stdexcept>
@@ -289,16 +292,100 @@ class GaitSchedule {
   scalar_t phaseTransitionStanceTime_;
 };
 
+// The per-callback rate limiter of the /cmd_vel subscriber (lastVel_ / changeLimit_,
+// legged_controllers/include/legged_controllers/TargetTrajectoriesPublisher.h:97-119): every message moves the filtered
+// command by at most (0.1, 0.05, -, 0.3) towards the request; linear z is forced to zero.  One filter per instance.
+class CmdVelFilter {
+ public:
+  // request (vx, vy, yaw rate) -> filtered [vx, vy, 0, yaw rate] (what cmdVelToTargetTrajectories and the device take)
+  const scalar_t* operator()(scalar_t vx, scalar_t vy, scalar_t yawRate) {
+    step(0, vx, 0.1);
+    step(1, vy, 0.05);
+    last_[2] = 0.0;
+    step(3, yawRate, 0.3);
+    return last_;
+  }
+  const scalar_t* last() const { return last_; }
+
+ private:
+  void step(int k, scalar_t want, scalar_t limit) {
+    scalar_t d = want - last_[k];
+    d = d > 0 ? std::fmin(d, limit) : std::fmax(d, -limit);
+    last_[k] += d;
+  }
+  scalar_t last_[4] = {0.0, 0.0, 0.0, 0.0};
+};
+
+// The two templates hard-coded next to the reference manager (SwitchedModelReferenceManager.cpp:55-61).
+inline ModeSequenceTemplate stanceTemplate() { return ModeSequenceTemplate{{0.0, 0.5}, {3}}; }
+inline ModeSequenceTemplate trotTemplate() { return ModeSequenceTemplate{{0.0, 0.3, 0.6}, {2, 1}}; }
+
+// gaitLevel_ / velAbsHistory_ of one instance: SwitchedModelReferenceManager::{calculateVelAbs, walkGait,
+// findInsertModeSequenceTemplateTimer} (SwitchedModelReferenceManager.cpp:173-249).  `update` is what modifyReferences does
+// between getModeSchedule and the swing-planner update; a template it inserts takes effect from the NEXT getModeSchedule.
+class GaitSelector {
+ public:
+  int level() const { return level_; }
+  scalar_t velAvg() const { return velAvg_; }
+  // cmdVel [vx vy vz yawRate] (filtered), observation state x[22], the schedule window this MPC call got, initTime / finalTime
+  void update(const scalar_t* cmdVel, const scalar_t* x, const ModeSchedule& window, scalar_t initTime, scalar_t finalTime,
+              GaitSchedule& gaitSchedule) {
+    // stateTrajectory[0] of cmdVelToTargetTrajectories (TargetTrajectoriesPublisher.cpp:102-130): the command rotated by the
+    // observed ZYX angles with the 0.06 dead band (x, ELSE y); its pose knot keeps the yaw and zeroes pitch / roll
+    scalar_t R[9];
+    rotZyx(x[9], x[10], x[11], R);
+    scalar_t v[3] = {R[0] * cmdVel[0] + R[1] * cmdVel[1] + R[2] * cmdVel[2], R[3] * cmdVel[0] + R[4] * cmdVel[1] + R[5] * cmdVel[2],
+                     R[6] * cmdVel[0] + R[7] * cmdVel[1] + R[8] * cmdVel[2]};
+    if (std::fabs(v[0]) < 0.06) v[0] = 0.0;
+    else if (std::fabs(v[1]) < 0.06) v[1] = 0.0;
+    // calculateVelAbs (:229-249): command rotated by the first target's angles (yaw, 0, 0), z zeroed, yaw rate / 3, averaged
+    // with the first target's momentum entries [v, 0] treated the same way; 50-sample history
+    rotZyx(x[9], 0.0, 0.0, R);
+    const scalar_t c0 = R[0] * cmdVel[0] + R[1] * cmdVel[1] + R[2] * cmdVel[2], c1 = R[3] * cmdVel[0] + R[4] * cmdVel[1] + R[5] * cmdVel[2];
+    const scalar_t m[4] = {0.5 * c0 + 0.5 * v[0], 0.5 * c1 + 0.5 * v[1], 0.0, 0.5 * (cmdVel[3] / 3.0) + 0.5 * (0.0 / 3.0)};
+    history_.push_front(std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2] + m[3] * m[3]));
+    while (history_.size() > 50) history_.pop_back();
+    velAvg_ = std::accumulate(history_.begin(), history_.end(), 0.0) / scalar_t(history_.size());
+    // walkGait (:185-217)
+    int want = level_;
+    if (velAvg_ <= 0.02) want = 0;
+    else if (velAvg_ > 0.03 && velAvg_ < 0.4) want = 1;
+    else if (velAvg_ >= 0.4) want = 3;
+    if (want == level_) return;
+    level_ = want;
+    if (want == 3) return;  // "flying trot": the reference only prints (:206-214)
+    size_t id = 0;           // findInsertModeSequenceTemplateTimer: first event of the window >= initTime
+    while (id < window.eventTimes.size() && window.eventTimes[id] < initTime) ++id;
+    if (id >= window.eventTimes.size()) return;  // (the reference reads past the end here)
+    gaitSchedule.insertModeSequenceTemplate(want == 0 ? stanceTemplate() : trotTemplate(), window.eventTimes[id], finalTime);
+  }
+
+ private:
+  static void rotZyx(scalar_t z, scalar_t y, scalar_t xr, scalar_t* R) {
+    const scalar_t cz = std::cos(z), sz = std::sin(z), cy = std::cos(y), sy = std::sin(y), cx = std::cos(xr), sx = std::sin(xr);
+    R[0] = cz * cy; R[1] = cz * sy * sx - sz * cx; R[2] = cz * sy * cx + sz * sx;
+    R[3] = sz * cy; R[4] = sz * sy * sx + cz * cx; R[5] = sz * sy * cx - cz * sx;
+    R[6] = -sy;     R[7] = cy * sx;                R[8] = cy * cx;
+  }
+  int level_ = 0;
+  scalar_t velAvg_ = 0.0;
+  std::deque<scalar_t> history_;
+};
+
 // SwitchedModelReferenceManager::modifyReferences (SwitchedModelReferenceManager.cpp:136-171) for the whole batch: the
-// pre-solver hook the MPC thread runs before every advanceMpc().  One GaitSchedule per instance.
+// pre-solver hook the MPC thread runs before every advanceMpc().  One GaitSchedule (+ gait selector) per instance.
 class ReferenceManager {
  public:
   ReferenceManager(Context ctx, const hb_refgen_config& settings, std::vector<GaitSchedule> gaitSchedules)
-      : ctx_(std::move(ctx)), gaits_(std::move(gaitSchedules)) {
+      : ctx_(std::move(ctx)), gaits_(std::move(gaitSchedules)), selectors_(gaits_.size()) {
     if (int(gaits_.size()) != ctx_.batch()) throw std::invalid_argument("[hunter_hip] one GaitSchedule per instance expected");
     ctx_.check(hb_refgen_reset(ctx_.get(), &settings, nullptr), "hb_refgen_reset");
   }
   GaitSchedule& gaitSchedule(int instance) { return gaits_.at(size_t(instance)); }
+  GaitSelector& gaitSelector(int instance) { return selectors_.at(size_t(instance)); }
+  // gaitType_ == 0 of the reference (the default, /gait_type topic): the gait of every instance follows its averaged command
+  // speed (walkGait).  It needs the observation on the host, i.e. preSolverRun must be given `observation`.
+  void setWalkGaitSelection(bool on) { walkGait_ = on; }
   // initTime [batch], cmdVel [batch][4] = (vx, vy, vz, yaw rate); observation [batch][22] or nullptr = the resident one
   void preSolverRun(const vector_t& initTime, scalar_t timeHorizon, const vector_t& cmdVel, const vector_t* observation = nullptr) {
     const size_t B = size_t(ctx_.batch());
@@ -310,6 +397,10 @@ class ReferenceManager {
       // the reference asks for [t - T, t + 2T] (SwitchedModelReferenceManager.cpp:147)
       const ModeSchedule ms = gaits_[i].getModeSchedule(initTime[i] - timeHorizon, initTime[i] + 2.0 * timeHorizon);
       if (ms.eventTimes.size() > size_t(HB_MAX_EVENTS)) throw std::invalid_argument("[hunter_hip] mode schedule longer than HB_MAX_EVENTS");
+      if (walkGait_) {
+        if (!observation) throw std::invalid_argument("[hunter_hip] walk-gait selection needs the observation on the host");
+        selectors_[i].update(cmdVel.data() + 4 * i, observation->data() + HB_NX * i, ms, initTime[i], initTime[i] + timeHorizon, gaits_[i]);
+      }
       nEvents[i] = int32_t(ms.eventTimes.size());
       for (size_t e = 0; e < ms.eventTimes.size(); ++e) events[i * HB_MAX_EVENTS + e] = ms.eventTimes[e];
       for (size_t e = 0; e < ms.modeSequence.size(); ++e) modes[i * (HB_MAX_EVENTS + 1) + e] = ms.modeSequence[e];
@@ -326,6 +417,8 @@ class ReferenceManager {
  private:
   Context ctx_;
   std::vector<GaitSchedule> gaits_;
+  std::vector<GaitSelector> selectors_;
+  bool walkGait_ = false;
   std::vector<int32_t> status_;
 };
 

@@ -1,7 +1,7 @@
 /* hunter_lcm.h — wire format of the reference's low-level LCM messages.
  *
  * The reference talks to the MuJoCo simulator / the robot bridge over LCM with three message types defined in
- * lcm_msg/include/{lowcmd_lcmt,lowstate_lcmt,fullstate_lcmt}.lcm (generated classes lcm_msg/include/lcm_msg/*.hpp):
+ * lcm_msg/include/{lowcmd_lcmt,lowstate_lcmt,fullstate_lcmt}.lcm (generated classes lcm_msg/include/lcm_msg/ *.hpp):
  *   channel "LOWCMD"        low_cmd_t    controller -> plant   (legged_examples/legged_mujoco/src/mujoco_lcm/MujocoLcm.cpp:41-45)
  *   channel "LOWSTATE"      low_state_t  plant -> controller   (mujoco/src/lcm_interface/LcmInterface.cpp:104-109)
  *   channel "LOWSTATEFULL"  full_state_t plant -> tools

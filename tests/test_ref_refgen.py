@@ -199,3 +199,73 @@ def test_device_planner_and_targets_on_the_host_emulator(golden, params, emu_lib
             worst_tg = max(worst_tg, np.abs(tgt - np.array(step["target_x"])).max())
             worst_sw = max(worst_sw, np.abs(out - np.array(step["out"]["refs"])).max())
     assert worst_tg < TOL and worst_sw < TOL, (worst_tg, worst_sw)
+
+
+def test_cpp_adapter_cmd_vel_filter_and_gait_selector(golden, params, tmp_path):
+    """hunter_hip::CmdVelFilter against the reference's own callback (golden 'filtered'); hunter_hip::GaitSelector (walkGait /
+    calculateVelAbs with the 50-sample history) against the Python mirror over a command stream that crosses every threshold,
+    including the template insertions it makes into the gait schedule."""
+    src = tmp_path / "sel_capi.cpp"
+    src.write_text('''
+#include "hunter_hip.hpp"
+using namespace hunter_hip;
+extern "C" {
+void* f_new() { return new CmdVelFilter(); }
+void f_step(void* h, double vx, double vy, double wz, double* out4) { const double* l = (*static_cast<CmdVelFilter*>(h))(vx, vy, wz); for (int i = 0; i < 4; ++i) out4[i] = l[i]; }
+struct Sel { GaitSelector sel; GaitSchedule gs; Sel(double pts) : gs(ModeSchedule{{0.5}, {3, 3}}, ModeSequenceTemplate{{0.0, 1.0}, {3}}, pts) {} };
+void* s_new(double pts) { return new Sel(pts); }
+int s_step(void* h, const double* cmd4, const double* x22, double t, double T, double* vel_avg, double* ev, int* md) {
+  Sel* s = static_cast<Sel*>(h);
+  const ModeSchedule w = s->gs.getModeSchedule(t - T, t + 2 * T);
+  s->sel.update(cmd4, x22, w, t, t + T, s->gs);
+  *vel_avg = s->sel.velAvg();
+  for (size_t i = 0; i < w.eventTimes.size(); ++i) ev[i] = w.eventTimes[i];
+  for (size_t i = 0; i < w.modeSequence.size(); ++i) md[i] = w.modeSequence[i];
+  return int(w.eventTimes.size()) * 10 + s->sel.level();
+}
+}
+''')
+    so = tmp_path / "libsel_capi.so"
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-fPIC", "-shared", "-I", str(HERE.parent / "include"), "-o", str(so), str(src)])
+    lib = C.CDLL(str(so))
+    DP, IP = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    lib.f_new.restype = C.c_void_p
+    lib.f_step.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, DP]
+    lib.s_new.restype = C.c_void_p
+    lib.s_new.argtypes = [C.c_double]
+    lib.s_step.argtypes = [C.c_void_p, DP, DP, C.c_double, C.c_double, DP, DP, IP]
+    for case in golden["targets"]:
+        f = C.c_void_p(lib.f_new())
+        for m in case["msgs"]:
+            out = np.zeros(4)
+            lib.f_step(f, m["cmd"][0], m["cmd"][1], m["cmd"][2], out.ctypes.data_as(DP))
+            assert out.tolist() == m["out"]["filtered"]
+    # gait selection: ramp the command up through the trot thresholds, hold, drop to zero, go beyond 0.4
+    c = params["config"]
+    rng = np.random.default_rng(8)
+    T, pts = 1.5, c["phase_transition_stance_time"]
+    sel_c = C.c_void_p(lib.s_new(pts))
+    sel_p = gait.GaitSelector()
+    gs_p = gait.GaitSchedule(gait.ModeSchedule([0.5], [3, 3]), gait.ModeTemplate([0.0, 1.0], [3]), pts)
+    flt = gait.CmdVelFilter(1)
+    x = np.array(c["initial_state"], dtype=float)
+    levels = set()
+    t = 0.0
+    for k in range(400):
+        t += 0.016
+        want = [0.0, 0.0, 0.0] if k < 20 else [0.3, 0.05, 0.2] if k < 150 else [0.0, 0.0, 0.0] if k < 280 else [0.9, 0.3, 1.5]
+        if k % 3 == 0:
+            cmd = flt([want])[0]
+        x[9:12] = [0.3 * np.sin(0.01 * k), 0.02 * rng.standard_normal(), 0.02 * rng.standard_normal()]
+        ev, md, va = np.zeros(256), np.zeros(257, dtype=np.int32), C.c_double()
+        code = lib.s_step(sel_c, cmd.ctypes.data_as(DP), x.ctypes.data_as(DP), t, T, C.byref(va), ev.ctypes.data_as(DP), md.ctypes.data_as(IP))
+        win = gs_p.get_mode_schedule(t - T, t + 2 * T)
+        level, tpl, t_ins = sel_p.update(cmd, gait.first_target_state(x, cmd), win, t)
+        if tpl is not None and t_ins is not None:
+            gs_p.insert_template(tpl, t_ins, t + T)
+        n_ev = code // 10
+        assert code % 10 == level and n_ev == len(win.event_times)
+        assert ev[:n_ev].tolist() == win.event_times and md[:n_ev + 1].tolist() == list(win.modes)
+        assert abs(va.value - sel_p.vel_avg) < 1e-15
+        levels.add(level)
+    assert levels == {0, 1, 3}

@@ -1,6 +1,27 @@
 #!/bin/bash
 # Builds libhunter_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+# The build FAILS if one of the hot kernels of the update spills to scratch memory: every scratch reload is followed by
+# s_waitcnt vmcnt(0), which drains the software-pipelined record prefetch of the sweeps.
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o ../libhunter_hip.so hb_kernels.hip "$@"
+LOG=$(mktemp)
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Rpass-analysis=kernel-resource-usage -o ../libhunter_hip.so hb_kernels.hip "$@" 2> "$LOG" || { cat "$LOG" >&2; rm -f "$LOG"; exit 1; }
+grep -E "error|warning:" "$LOG" | grep -v "Wcomment" >&2 || true
+python3 - "$LOG" <<'PY'
+import re, sys
+hot = ["k_lqE", "k_ric_bwdE", "k_ric_fwdE", "5k_wbcE", "k_ls_evalE", "k_policy_evalE"]
+txt = open(sys.argv[1]).read()
+rows, bad = [], []
+for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?LDS Size \[bytes/block\]: (\d+)", txt, re.S):
+    name, vg, ag, scr, occ, lds = m.group(1), *map(int, m.groups()[1:])
+    if any(h in name for h in hot):
+        rows.append(f"  {name[:48]:48s} vgpr {vg:3d} agpr {ag:3d} scratch {scr:3d} B  waves/SIMD {occ}  lds {lds} B")
+        if scr:
+            bad.append(name)
+print("hot-kernel resources (gfx950):")
+print("\n".join(rows))
+if bad:
+    sys.exit("build.sh: scratch memory in hot kernel(s): " + ", ".join(bad))
+PY
+rm -f "$LOG"

@@ -58,6 +58,43 @@ HB_HD void ric_phase1(const Ctx& cx, double* lds) {
 // redundantly in registers, lane c < 23 then solves its own right-hand side.  NT = 9 serves every stage with at most
 // 9 projected inputs (single support: 6 contact-force + 3 kernel coordinates; flight: 6) — the padding rows of the
 // record are R~ = I, B~ = 0, P~ = 0, r~ = 0, so their gains are exactly zero and the factor work drops by ~(9/12)^3.
+// Cholesky factor of the leading NB x NB block of Huu, redundantly per lane in registers; lane 0 writes it back over the
+// (dead) lower triangle of Huu with the RECIPROCALS of the diagonal.  Returns true when a pivot was not positive.
+template <int NB, class Ctx>
+HB_HD bool ric_chol_block(const Ctx& cx, double* Hu) {
+  double L[NB * (NB + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = Hu[i * RicLds::LDW + RicLds::CU + j];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double d = L[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+    if (!(d > 0.0)) { bad = true; d = 1.0; }
+    const double inv = rsqrt_t(d);
+    L[j * (j + 1) / 2 + j] = inv;  // store the reciprocal of the diagonal
+#pragma unroll
+    for (int i = j + 1; i < NB; ++i) {
+      double sacc = L[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) sacc -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+      L[i * (i + 1) / 2 + j] = sacc * inv;
+    }
+  }
+  // The factor (lane-uniform) goes back to LDS over the lower triangle of Huu, which is dead from here on: the solves
+  // then read it through broadcast loads and the registers are free again (explicit "spill" to LDS; a register
+  // file that still held L here pushed the kernel's loop invariants into scratch memory).
+  if (cx.lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) Hu[i * RicLds::LDW + RicLds::CU + j] = L[i * (i + 1) / 2 + j];
+  }
+  return bad;
+}
 template <int NT, class Ctx>
 HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
   double* Hu = lds + RicLds::Hu;
@@ -66,39 +103,67 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
   // keep the loads of this width's triangle inside its branch: hoisted above the 9 / 12 dispatch they were spilled
   asm volatile("" ::: "memory");
 #endif
-  {
-    double L[NT * (NT + 1) / 2];
+  if constexpr (NT <= 9) {
+    const bool bad = ric_chol_block<NT>(cx, Hu);
+    if (bad && cx.lane == 0) lds[RicLds::flag] = 1.0;
+  } else {
+    // 12 projected inputs (double support: 12 contact forces): blocked — the 9 x 9 leading block in registers as above, then
+    // rows 9..11 one per lane against the factor in LDS, then the 3 x 3 Schur complement.  A 78-element register triangle
+    // (156 VGPRs) next to the record prefetch was what put 100 B/lane of this kernel into scratch memory.
+    static_assert(NT == 12, "blocked factorisation: 9 + 3");
+    bool bad = ric_chol_block<9>(cx, Hu);
+    cx.sync();
+    const double* Lm = Hu + RicLds::CU;   // L(i, j) = Lm[i * LDW + j]
+    for (int r = 9 + cx.lane; r < 12; r += cx.nlanes) {   // L21 row r: forward substitution with L11 (diagonal = reciprocals)
+      double l[9];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+      for (int j = 0; j < 9; ++j) {
+        double sacc = Lm[r * RicLds::LDW + j];
 #pragma unroll
-      for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = Hu[i * RicLds::LDW + RicLds::CU + j];
-    bool bad = false;
+        for (int k = 0; k < j; ++k) sacc -= l[k] * Lm[j * RicLds::LDW + k];
+        l[j] = sacc * Lm[j * RicLds::LDW + j];
+      }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      double d = L[j * (j + 1) / 2 + j];
+      for (int j = 0; j < 9; ++j) Hu[r * RicLds::LDW + RicLds::CU + j] = l[j];
+    }
+    cx.sync();
+    {
+      // Schur complement of the trailing 3 x 3 block and its factor, redundantly per lane (6 elements)
+      double S[6];
 #pragma unroll
-      for (int k = 0; k < j; ++k) d -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
-      if (!(d > 0.0)) { bad = true; d = 1.0; }
-      const double inv = rsqrt_t(d);
-      L[j * (j + 1) / 2 + j] = inv;  // store the reciprocal of the diagonal
+      for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int i = j + 1; i < NT; ++i) {
-        double sacc = L[i * (i + 1) / 2 + j];
+        for (int j = 0; j <= i; ++j) {
+          double sacc = Lm[(9 + i) * RicLds::LDW + 9 + j];
 #pragma unroll
-        for (int k = 0; k < j; ++k) sacc -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
-        L[i * (i + 1) / 2 + j] = sacc * inv;
+          for (int k = 0; k < 9; ++k) sacc -= Lm[(9 + i) * RicLds::LDW + k] * Lm[(9 + j) * RicLds::LDW + k];
+          S[i * (i + 1) / 2 + j] = sacc;
+        }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double d = S[j * (j + 1) / 2 + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= S[j * (j + 1) / 2 + k] * S[j * (j + 1) / 2 + k];
+        if (!(d > 0.0)) { bad = true; d = 1.0; }
+        const double inv = rsqrt_t(d);
+        S[j * (j + 1) / 2 + j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < 3; ++i) {
+          double sacc = S[i * (i + 1) / 2 + j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) sacc -= S[i * (i + 1) / 2 + k] * S[j * (j + 1) / 2 + k];
+          S[i * (i + 1) / 2 + j] = sacc * inv;
+        }
+      }
+      cx.sync();   // every lane has read the trailing block before lane 0 overwrites it
+      if (cx.lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) Hu[(9 + i) * RicLds::LDW + RicLds::CU + 9 + j] = S[i * (i + 1) / 2 + j];
       }
     }
     if (bad && cx.lane == 0) lds[RicLds::flag] = 1.0;
-    // The factor (lane-uniform) goes back to LDS over the lower triangle of Huu, which is dead from here on: the solves
-    // then read it through broadcast loads and the registers are free again (explicit "spill" to LDS; a register
-    // file that still held L here pushed the kernel's loop invariants into scratch memory).
-    if (cx.lane == 0) {
-#pragma unroll
-      for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) Hu[i * RicLds::LDW + RicLds::CU + j] = L[i * (i + 1) / 2 + j];
-    }
   }
   cx.sync();
   {
@@ -111,6 +176,10 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
 #pragma unroll
         for (int k = 0; k < a; ++k) sacc -= Lm[a * RicLds::LDW + k] * y[k];
         y[a] = sacc * Lm[a * RicLds::LDW + a];
+#if defined(__HIP_DEVICE_COMPILE__)
+        // 12-wide: keep the factor loads row by row — hoisted all at once (132 of them) they took the register file
+        if (NT > 9) asm volatile("" ::: "memory");
+#endif
       }
 #pragma unroll
       for (int a = NT - 1; a >= 0; --a) {
@@ -118,6 +187,9 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
 #pragma unroll
         for (int k = a + 1; k < NT; ++k) sacc -= Lm[k * RicLds::LDW + a] * y[k];
         y[a] = sacc * Lm[a * RicLds::LDW + a];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (NT > 9) asm volatile("" ::: "memory");
+#endif
       }
 #pragma unroll
       for (int a = NT; a < NU_T; ++a) y[a] = 0.0;

@@ -258,8 +258,8 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
     asm volatile("" : "+v"(l));
     cxk.lane = l;
     HB_RIC_FETCH_Q(k, l);
-    if (k > 0) {
-      HB_RIC_FETCH(k - 1, l);
+    if (k > 0) {  // (requested a whole stage earlier — right after the staging stores, 254 VGPRs, no scratch — the sweep
+      HB_RIC_FETCH(k - 1, l);  //  takes the same 2.06 ms: it does not wait for HBM, it is bound by its own dependent work)
       const double* meta = b.recs + (size_t(inst) * b.Nmax + k - 1) * REC_SIZE + REC_META;
       meta_nf = meta[0];
       meta_nz = meta[1];

@@ -46,8 +46,24 @@ def main():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             v["hbm_bytes_per_launch_raw"] = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
             v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "SQ_BUSY_CYCLES" in v and v["SQ_BUSY_CYCLES"] > 0:
-            v["mfma_busy_frac_of_sq_busy"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / v["SQ_BUSY_CYCLES"]
+        # Matrix-pipe busy fraction, normalised.  SQ_VALU_MFMA_BUSY_CYCLES is reported as (pipe-busy cycles summed over all SIMDs) / 32
+        # on this stack: k_ric_bwd issues 63 v_mfma_f64_16x16x4_f64 per stage, 64 pipe cycles each, and the counter reads
+        # 409 600 stages x 126 = 63 x 64 / 32 per stage (profiles/r01m_pmc.txt).  Hence
+        #     mfma_pipe_busy_frac = 32 * SQ_VALU_MFMA_BUSY_CYCLES / (N_SIMD * GRBM_GUI_ACTIVE),   N_SIMD = 256 CUs x 4
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("GRBM_GUI_ACTIVE", 0) > 0:
+            v["mfma_pipe_busy_frac"] = 32.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * v["GRBM_GUI_ACTIVE"])
+        if "hbm_bytes_per_launch" in v and v.get("avg_us_under_profiling", 0) > 0:
+            v["hbm_GBs_under_profiling"] = v["hbm_bytes_per_launch"] / (v["avg_us_under_profiling"] * 1e-6) / 1e9
+        # wave-cycle breakdown (MI355X_MICROARCH.md §rocprofv3 PMC slots): parked at s_waitcnt / barrier, issue-stalled, issuing
+        if v.get("SQ_WAVE_CYCLES", 0) > 0:
+            for src, dst in (("SQ_WAIT_ANY", "wave_frac_parked_waitcnt"), ("SQ_WAIT_INST_ANY", "wave_frac_issue_stalled"),
+                             ("SQ_ACTIVE_INST_ANY", "wave_frac_issuing")):
+                if src in v:
+                    v[dst] = v[src] / v["SQ_WAVE_CYCLES"]
+        if v.get("SQ_WAVES", 0) > 0:
+            for src in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_MFMA"):
+                if src in v:
+                    v[src.lower() + "_per_wave"] = v[src] / v["SQ_WAVES"]
     json.dump(merged, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
     lines = [f"# rocprofv3 --pmc per-kernel means ({tag}); bytes corrected per MI355X_MICROARCH.md §HBM (FETCH x2 for wide reads)"]
     for k, v in sorted(merged.items(), key=lambda kv: -kv[1].get("avg_us_under_profiling", 0)):

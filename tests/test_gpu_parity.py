@@ -569,3 +569,42 @@ def test_hoqp_two_task_properties_on_device(params, oracle):
         assert st == 0
         worst = max(worst, np.abs(x[p, 1] - xo1).max())
     assert worst < 1e-6, worst
+
+
+def test_headline_workload_parity_64_distinct_instances_n100(params, oracle):
+    """The benchmark's own workload shape at its exact size per instance: N = 100, 64 DISTINCT instances (state seeds 1234 + id)
+    with node tables generated on the device as bench.py does; one SQP iteration + WBC against the oracle on the same tables."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B, N = 64, 100
+    s = HunterSolver(params, batch=B, max_nodes=N)
+    try:
+        w = workload.device_trot_batch(s, params, n_intervals=N)
+        refs = s.get_references()
+        assert (refs["n_nodes"] == N).all() and len({tuple(np.round(x, 12)) for x in w["x0"]}) == B
+        s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+        s.step_resident()
+        x, u = s.get_solution()
+        sol, status = s.get_wbc_solution()
+        perf = s.get_performance()
+        st = s.mpc_status()
+    finally:
+        s.close()
+    assert st.max() == 0 and status.max() == 0
+    xo, uo = np.zeros_like(x), np.zeros_like(u)
+    for i in range(B):
+        xo[i], uo[i] = oracle.cold_start(refs["mode"][i], w["x0"][i])
+    po = oracle.mpc_solve(refs, w["x0"], xo, uo, iters=1, threads=8)
+    assert np.abs(x - xo).max() < 1e-7 and np.abs(u - uo).max() < 1e-6
+    assert np.array_equal(perf[:, 3], po[:, 3])                       # identical accepted step sizes
+    # WBC on the published policy at t_now: desired state / input by the oracle's interpolation, then the oracle's QP
+    tt = refs["t"]
+    xd, ud, md = np.zeros((B, 22)), np.zeros((B, 22)), np.zeros(B, dtype=np.int32)
+    for i in range(B):
+        k = int(np.searchsorted(tt[i, :N + 1], w["t_now"][i], side="right") - 1)
+        a = (w["t_now"][i] - tt[i, k]) / (tt[i, k + 1] - tt[i, k])
+        xd[i] = (1 - a) * xo[i, k] + a * xo[i, k + 1]
+        ud[i] = (1 - a) * uo[i, k] + a * uo[i, min(k + 1, N - 1)]
+        md[i] = refs["mode"][i, k]
+    so, sto, _ = oracle.wbc_update(xd, ud, w["rbd"], md, stance_flag=np.zeros(B, dtype=np.int32), threads=8)
+    assert np.array_equal(status, sto)
+    assert np.abs(sol[:, :28] - so[:, :28]).max() < 1e-5 * max(1.0, np.abs(so[:, :28]).max()) and np.abs(sol[:, 28:] - so[:, 28:]).max() < 1e-4

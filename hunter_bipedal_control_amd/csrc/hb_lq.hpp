@@ -168,13 +168,16 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
     int tl = -1, ts = 0;
     if (dir >= 12 && dir < 22) { tl = (dir - 12) / 5; ts = (dir - 12) % 5; }
     if (dir >= 34) { tl = (dir - 34) / 5; ts = 5 + (dir - 34) % 5; }
-    // leg sums (value of both legs, tangent of the one leg this direction seeds — closed form, in registers)
-    double t[27];
+    // leg sums (value of both legs, tangent of the one leg this direction seeds — closed form, in registers).  Only the 15
+    // tangents of the leg composite are formed here; those of a contact point are formed when the point is processed (all 27
+    // up front kept 24 more registers live through the whole-body combine: the kernel's register peak)
+    double t[15];
+    const double* LJs = LJ + (tl >= 0 ? tl : 0) * LEGJ_SIZE;
     if (tl >= 0) {
-      leg_tangent(LJ + tl * LEGJ_SIZE, ts % 5, ts >= 5, t);
+      leg_tangent_body(LJs, ts % 5, ts >= 5, t);
     } else {
 #pragma unroll
-      for (int e = 0; e < 27; ++e) t[e] = 0.0;
+      for (int e = 0; e < 15; ++e) t[e] = 0.0;
     }
     auto S = [LV, &t](int e) { return Dual1(LV[e] + LV[27 + e], t[e]); };
     CentroidalCore<Dual1> core;
@@ -189,19 +192,20 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
       centroidal_core<Dual1>(M, Vec3<Dual1>(S(0), S(1), S(2)), IOs, Vec3<Dual1>(S(9), S(10), S(11)),
                              Vec3<Dual1>(S(12), S(13), S(14)), zyx, hn, core, SC + 6 * pt);
     }
+    // the base-velocity rows of this direction are final: out of the registers before the contact loop
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Jp[dir * 12 + 9 + i] = comp(core.euler_rate, i).d;
+    const Vec3<double> euler_rate_v(core.euler_rate.x.v, core.euler_rate.y.v, core.euler_rate.z.v);
     // contact points one at a time (rolled loop keeps the register footprint small)
     Vec3<Dual1> ms;
 #pragma unroll 1
     for (int i = 0; i < HB_NC; ++i) {
       const int leg = i & 1, f = i >> 1;
       const double* v = LV + leg * 27 + 15 + 3 * f;
-      // tangent of contact point f of the seeded leg: selected with conditional moves — indexing t[] with the
-      // (rolled) loop counter would force the whole array into scratch memory
-      const double wl = (tl == leg) ? 1.0 : 0.0;
-      const double tp0 = f ? t[18] : t[15], tp1 = f ? t[19] : t[16], tp2 = f ? t[20] : t[17];
-      const double tv0 = f ? t[24] : t[21], tv1 = f ? t[25] : t[22], tv2 = f ? t[26] : t[23];
-      const Vec3<Dual1> fb{Dual1(v[0], wl * tp0), Dual1(v[1], wl * tp1), Dual1(v[2], wl * tp2)};
-      const Vec3<Dual1> vb{Dual1(v[6], wl * tv0), Dual1(v[7], wl * tv1), Dual1(v[8], wl * tv2)};
+      Vec3<double> tp, tv;
+      if (tl == leg) leg_tangent_foot(LJs, ts % 5, ts >= 5, f, tp, tv);
+      const Vec3<Dual1> fb{Dual1(v[0], tp.x), Dual1(v[1], tp.y), Dual1(v[2], tp.z)};
+      const Vec3<Dual1> vb{Dual1(v[6], tv.x), Dual1(v[7], tv.y), Dual1(v[8], tv.z)};
       Vec3<Dual1> fr, fvel;
       centroidal_foot<Dual1>(core, fb, vb, fr, fvel);
       const Vec3<Dual1> rr = fr - core.com_rel;
@@ -236,9 +240,9 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
     }
     const double inv_m = rcp_t(M.total_mass);
     const Dual1 f[12] = {Dual1(0.0), Dual1(0.0), Dual1(0.0), inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
-                         core.v_lin.x, core.v_lin.y, core.v_lin.z, core.euler_rate.x, core.euler_rate.y, core.euler_rate.z};
+                         core.v_lin.x, core.v_lin.y, core.v_lin.z, Dual1(euler_rate_v.x), Dual1(euler_rate_v.y), Dual1(euler_rate_v.z)};
 #pragma unroll
-    for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = f[i].d;
+    for (int i = 0; i < 9; ++i) Jp[dir * 12 + i] = f[i].d;
     if (dir == 0 && (pt == 1 || first_point_values)) {  // values of this point (single-node form: the first point's come from the pre-pass)
       double fsx = 0, fsy = 0, fsz = 0;
       for (int i = 0; i < HB_NC; ++i) { fsx += us[3 * i]; fsy += us[3 * i + 1]; fsz += us[3 * i + 2]; }

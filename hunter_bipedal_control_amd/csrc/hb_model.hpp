@@ -447,6 +447,51 @@ HB_HD void leg_tangent(const double* blk, int s, bool rate, double* t) {
   st3(t + 24, cross(a, ld3(B + LEGJ_VJ + 3)) + cross(omp, ap1));
 }
 
+// The same tangents in two parts, for callers with a tight register budget: the 15 tangents of the leg's composite
+// (mc, IO, l, L) first, the 12 of one contact point's position / joint-induced velocity when that point is processed.
+HB_HD void leg_tangent_body(const double* blk, int s, bool rate, double* t /*[15]*/) {
+  const double* B = blk + s * LEGJ_STRIDE;
+  const Vec3<double> a = ld3(B + LEGJ_A), o = ld3(B + LEGJ_O), ls = ld3(B + LEGJ_l), Ls = ld3(B + LEGJ_L);
+  if (rate) {
+    for (int e = 0; e < 9; ++e) t[e] = 0.0;
+    st3(t + 9, ls);
+    st3(t + 12, Ls);
+    return;
+  }
+  const Vec3<double> mcs = ld3(B + LEGJ_MC), lin = ld3(B + LEGJ_LIN), ang = ld3(B + LEGJ_ANG);
+  const Vec3<double> omp = ld3(B + LEGJ_OMP), wp = ld3(B + LEGJ_WP);
+  const Sym3<double> IOs = ld6(B + LEGJ_IO);
+  const Vec3<double> y0 = cross(a, Vec3<double>(IOs.xx, IOs.xy, IOs.xz));
+  const Vec3<double> y1 = cross(a, Vec3<double>(IOs.xy, IOs.yy, IOs.yz));
+  const Vec3<double> y2 = cross(a, Vec3<double>(IOs.xz, IOs.yz, IOs.zz));
+  const Vec3<double> tt = cross(o, a);
+  const double tr = 2.0 * dot(mcs, tt);
+  Sym3<double> dIO;
+  dIO.xx = y0.x + y0.x + tr - 2.0 * tt.x * mcs.x;
+  dIO.yy = y1.y + y1.y + tr - 2.0 * tt.y * mcs.y;
+  dIO.zz = y2.z + y2.z + tr - 2.0 * tt.z * mcs.z;
+  dIO.xy = y1.x + y0.y - (tt.x * mcs.y + mcs.x * tt.y);
+  dIO.xz = y2.x + y0.z - (tt.x * mcs.z + mcs.x * tt.z);
+  dIO.yz = y2.y + y1.z - (tt.y * mcs.z + mcs.y * tt.z);
+  st3(t + 0, ls);
+  st6(t + 3, dIO);
+  st3(t + 9, cross(a, lin) + cross(omp, ls));
+  st3(t + 12, cross(a, ang - cross(o, lin)) + cross(o, cross(a, lin)) + dIO * omp - cross(ls, wp));
+}
+// contact point f (0 / 1) of the leg: tangent of its position and of its joint-induced velocity
+HB_HD void leg_tangent_foot(const double* blk, int s, bool rate, int f, Vec3<double>& tp, Vec3<double>& tv) {
+  const double* B = blk + s * LEGJ_STRIDE;
+  const Vec3<double> a = ld3(B + LEGJ_A), o = ld3(B + LEGJ_O);
+  const Vec3<double> ap = cross(a, ld3(blk + LEGJ_FEET + 3 * f) - o);
+  if (rate) {
+    tp = Vec3<double>();
+    tv = ap;
+  } else {
+    tp = ap;
+    tv = cross(a, ld3(B + LEGJ_VJ + 3 * f)) + cross(ld3(B + LEGJ_OMP), ap);
+  }
+}
+
 // ZYX euler rates from the world angular velocity (inverse of omega = E(zyx) * rates).
 template <class T>
 HB_HD Vec3<T> euler_rates_from_omega(T sz, T cz, T sy, T cy, Vec3<T> w) {

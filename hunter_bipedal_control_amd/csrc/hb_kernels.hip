@@ -178,10 +178,14 @@ __global__ void k_mpc_status(Batch b) {
   b.mpc_status[i] = st;
 }
 
-__global__ __launch_bounds__(64, 2) void k_lq(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
+// HB_LQ_LDS_PAD: occupancy experiments only (tools/occupancy_variants.sh) — extra (or, negative, missing) doubles of LDS per node
+#ifndef HB_LQ_LDS_PAD
+#define HB_LQ_LDS_PAD 0
+#endif
+__global__ __launch_bounds__(64, 3) void k_lq(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
   const int k = blockIdx.x, inst = blockIdx.y;
   if (k >= b.n_nodes[inst]) return;
-  __shared__ double lds[LqLds::total];
+  __shared__ double lds[LqLds::total + HB_LQ_LDS_PAD];
   const size_t nd = size_t(inst) * b.Nmax + k;
   const double* tt = b.t + size_t(inst) * (b.Nmax + 1);
   NodeIn in;

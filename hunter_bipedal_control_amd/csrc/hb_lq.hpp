@@ -77,42 +77,60 @@ struct RelaxedBarrierD {
   HB_HD double d2(double h) const { const double r = rcp_t(h > delta ? h : delta); return mu * r * r; }
 };
 
-// LDS carve (doubles).  At most 2560 doubles = 20 480 B per node -> 8 single-wave workgroups per CU (two per SIMD).
+// LDS carve (doubles).  At most 2240 doubles = 17 920 B per node -> 9 single-wave workgroups per CU (k_lq is bound by the
+// number of resident wavefronts, DESIGN.md 3.1, so every double here is throughput).
 //   fixed:     CDt [32][12] (constraint-row derivatives; the 12 contact-force directions are identically zero and are not
-//              stored: direction d < 22 -> row d, joint-rate direction 34 + k -> row 22 + k), xplus, rowval
+//              stored: direction d < 22 -> row d, joint-rate direction 34 + k -> row 22 + k), rowval, xs, us, fv, and xe:
+//              the state of the second RK2 point during phase 1, x+ afterwards
 //   phase 1:   LJ (4 leg blocks) | J1 | J2 | small values             (LJ is dead once stage 2 is done)
+//              J1 / J2 hold rows 3..11 of d f / d direction only (9 columns): rows 0..2 (d (sum F / m - g)) are the constants
+//              [dir == 22 + 3 j + i] / m.  J1 has no rows for the base-position directions 6..8 (identically zero, and
+//              never a right operand); J2 keeps them as zeros because rows 3..11 are the right operand of the compose
 //   compose:   ABt [44][12] over the head of LJ.  Only rows 0..11 of x+ are stored; the joint rows q+ = q + dt qd are
 //              the closed form  d q+_j / d dir = [dir == 12 + j] + dt [dir == 34 + j]  and are expanded where used
-//   phase 2+:  every later buffer aliases the rest of the phase-1 region (dead after the compose)
+//   phase 2+:  every later buffer aliases the rest of the phase-1 region (dead after the compose); P_j and R_jj (written
+//              after the projection) lie over G'G and G'[C e] (dead after the projection)
 struct LqLds {
   static constexpr int CDt = 0;              // [32][12]
-  static constexpr int xplus = CDt + 384;    // 22
-  static constexpr int rowval = xplus + 22;  // 12
-  static constexpr int ABt = rowval + 12;    // [44][12]
-  static constexpr int GtG = ABt + 528;      // 10x10 (becomes L)
-  static constexpr int W = GtG + 100;        // 10x23 (G'C | G'e), then reused
-  static constexpr int Kx = W + 230;         // 10x23 (Kx | ke)
+  static constexpr int rowval = CDt + 384;   // 12
+  static constexpr int xs = rowval + 12;     // 22 values of x
+  static constexpr int us = xs + 22;         // 22 values of u
+  static constexpr int fv = us + 22;         // 2 x 12 flow-map values (rows 0..11) at the two RK2 points
+  static constexpr int xe = fv + 24;         // 22
+  static constexpr int xplus = xe;
+  static constexpr int ABt = xe + 22;        // [44][12]
+  static constexpr int GtG = ABt + 528;      // 10x10
+  static constexpr int W = GtG + 100;        // 10x23 (G'C | G'e)
+  static constexpr int Pj = GtG;             // 10x22   } over G'G | W
+  static constexpr int Rjj = Pj + 220;       // 10x10   }
+  static constexpr int Wl = W + 230;         // 92: r_j + R_jj ke (10), R_jj Z at 16 (60), B_j ke at 80 (12)
+  static constexpr int Kx = Wl + 92;         // 10x23 (Kx | ke)
   static constexpr int Z = Kx + 230;         // 10x6
-  static constexpr int Pj = Z + 60;          // 10x22
-  static constexpr int Rjj = Pj + 220;       // 10x10
-  static constexpr int Mm = Rjj + 100;       // 10x22
+  static constexpr int Mm = Z + 60;          // 10x22
   static constexpr int RFF = Mm + 220;       // 4 blocks 3x3
   static constexpr int qx = RFF + 36;        // 22 (continuous-time gradient wrt x)
   static constexpr int ru = qx + 22;         // 22 (wrt u)
   static constexpr int Qd = ru + 22;         // 22 diagonal of Q incl. barriers/shift
   static constexpr int scal = Qd + 22;       // 16 scalars (cost, sums, ...)
   static constexpr int ints = scal + 16;     // 32 ints packed in 16 doubles: perm[10], rank, eq slots...
+  static constexpr int tail_end = ints + 16;
   // phase-1 view of the aliased region
   static constexpr int LJ = ABt;             // 4 x LEGJ_SIZE (824)
-  static constexpr int J1 = LJ + 4 * LEGJ_SIZE;  // [44][12]
-  static constexpr int J2 = J1 + 528;        // [44][12]
-  static constexpr int p1 = J2 + 528;        // xs us xe fv FR LV = 222 doubles, (sin, cos) of zyx at both RK2 points = 12, swing refs 24
-  static constexpr int total = (p1 + 258 > ints + 16) ? p1 + 258 : ints + 16;
+  static constexpr int J1 = LJ + 4 * LEGJ_SIZE;  // [41][9]
+  static constexpr int J2 = J1 + 41 * 9;     // [44][9]
+  static constexpr int FR = J2 + 44 * 9;     // 2 x 12: (contact point - COM) at the two points
+  static constexpr int LV = FR + 24;         // 2 points x 2 legs x 27 leg values
+  static constexpr int SC = LV + 108;        // 2 x 6: sin / cos of the ZYX angles at the two RK2 points
+  static constexpr int p1_end = SC + 12;
+  static constexpr int total = p1_end > tail_end ? p1_end : tail_end;
 };
-static_assert(LqLds::GtG >= LqLds::ABt + 528 && LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are still being read");
-static_assert(LqLds::total * 8 <= 20480, "k_lq: LDS per node must allow 8 workgroups per CU");
+static_assert(LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are still being read");
+static_assert(LqLds::Rjj + 100 <= LqLds::Wl, "P_j | R_jj must fit over G'G | W");
+static_assert(LqLds::total * 8 <= 17920, "k_lq: LDS per node must allow 9 workgroups per CU");
 // row of CDt that holds direction d (d < 22 or d >= 34)
 HB_HD int cd_row(int dir) { return dir < 22 ? dir : dir - 12; }
+// row of J1 / J2 (RK2 point pt) that holds direction d; the first point has no rows for the base-position directions
+HB_HD int j_row(int pt, int dir) { return (pt == 0 && dir >= 6) ? dir - 3 : dir; }
 
 struct NodeIn {
   const double* x;      // 22
@@ -126,19 +144,18 @@ struct NodeIn {
 
 // Pointers into the phase-1 view of one node's LDS region (LqLds).
 struct LqP1 {
-  double *xs, *us, *xe, *fv, *FR, *LV_all, *SC, *SW, *J1, *J2, *CDt, *rowval, *LJ_all;
+  double *xs, *us, *xe, *fv, *FR, *LV_all, *SC, *J1, *J2, *CDt, *rowval, *LJ_all;
 };
 HB_HD LqP1 lq_p1(double* lds) {
   LqP1 p;
-  p.xs = lds + LqLds::p1;   // 22 values of x
-  p.us = p.xs + 22;         // 22 values of u
-  p.xe = p.us + 22;         // 22 state values of the second RK2 point
-  p.fv = p.xe + 22;         // 2 x 12 flow-map values (rows 0..11) of the two points
-  p.FR = p.fv + 24;         // 2 x 12: (contact point - COM) at the two points
-  p.LV_all = p.FR + 24;     // 2 points x 2 legs x 27 leg values
-  p.SC = p.LV_all + 108;    // 2 x 6: sin / cos of the ZYX angles at the two RK2 points
-  p.SW = p.SC + 12;         // 4 x 6 swing references of the node
-  p.J1 = lds + LqLds::J1;   // 44 x 12: d f(rows 0..11) / d direction at point 1
+  p.xs = lds + LqLds::xs;
+  p.us = lds + LqLds::us;
+  p.xe = lds + LqLds::xe;
+  p.fv = lds + LqLds::fv;
+  p.FR = lds + LqLds::FR;
+  p.LV_all = lds + LqLds::LV;
+  p.SC = lds + LqLds::SC;
+  p.J1 = lds + LqLds::J1;   // rows 3..11 of d f / d direction at point 1 (see LqLds)
   p.J2 = lds + LqLds::J2;   // same at point 2
   p.CDt = lds + LqLds::CDt;
   p.rowval = lds + LqLds::rowval;
@@ -151,15 +168,15 @@ HB_HD LqP1 lq_p1(double* lds) {
 // for the first point the constraint-row derivatives / values, and — on the lane of direction 0 — the point's values:
 // always for the second point; for the first point only with `first_point_values` (the node-pair kernel has no separate
 // value pre-pass: its first-point pass delivers f(x, u) itself).
-HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int mode, int pt, int ti, bool first_point_values) {
+HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int mode, const double* swing, int pt, int ti, bool first_point_values) {
   const LqP1 P = lq_p1(lds);
   double* xs = P.xs; double* us = P.us; double* xe = P.xe; double* fv = P.fv; double* FR = P.FR; double* LV_all = P.LV_all;
-  double* SC = P.SC; double* SW = P.SW; double* J1 = P.J1; double* J2 = P.J2; double* CDt = P.CDt; double* rowval = P.rowval;
+  double* SC = P.SC; double* CDt = P.CDt; double* rowval = P.rowval;
   double* LJ_all = P.LJ_all;
   bool cf[HB_NC];
   mode_flags(mode, cf);
   const int dir = ti < 6 ? ti : (ti < 19 ? ti + 3 : ti + 15);
-  double* Jp = pt == 0 ? J1 : J2;
+  double* Jp = (pt == 0 ? P.J1 : P.J2) + j_row(pt, dir) * 9;  // this direction's row: d f(rows 3..11)
   const double* LJ = LJ_all + pt * 2 * LEGJ_SIZE;
   const double* LV = LV_all + pt * 54;
   const double* xb = pt == 0 ? xs : xe;
@@ -194,7 +211,7 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
     }
     // the base-velocity rows of this direction are final: out of the registers before the contact loop
 #pragma unroll
-    for (int i = 0; i < 3; ++i) Jp[dir * 12 + 9 + i] = comp(core.euler_rate, i).d;
+    for (int i = 0; i < 3; ++i) Jp[6 + i] = comp(core.euler_rate, i).d;
     const Vec3<double> euler_rate_v(core.euler_rate.x.v, core.euler_rate.y.v, core.euler_rate.z.v);
     // contact points one at a time (rolled loop keeps the register footprint small)
     Vec3<Dual1> ms;
@@ -221,7 +238,7 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
           r1 = fvel.y;
           r2 = fvel.z + C.zv_gain * pz + C.zv_off;
         } else {      // normal velocity + xy soft reference (LeggedRobotPreComputation.cpp:96-117)
-          const double* sw = SW + 6 * i;
+          const double* sw = swing + 6 * i;  // (uniform address: scalar loads)
           const Dual1 px = Dual1(xs[6]) + fr.x, py = Dual1(xs[7]) + fr.y;
           r0 = fvel.z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
           r1 = C.xy_gain * px + fvel.x - (sw[3] + C.xy_gain * sw[0]);
@@ -242,7 +259,7 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
     const Dual1 f[12] = {Dual1(0.0), Dual1(0.0), Dual1(0.0), inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
                          core.v_lin.x, core.v_lin.y, core.v_lin.z, Dual1(euler_rate_v.x), Dual1(euler_rate_v.y), Dual1(euler_rate_v.z)};
 #pragma unroll
-    for (int i = 0; i < 9; ++i) Jp[dir * 12 + i] = f[i].d;
+    for (int i = 3; i < 9; ++i) Jp[i - 3] = f[i].d;
     if (dir == 0 && (pt == 1 || first_point_values)) {  // values of this point (single-node form: the first point's come from the pre-pass)
       double fsx = 0, fsy = 0, fsz = 0;
       for (int i = 0; i < HB_NC; ++i) { fsx += us[3 * i]; fsy += us[3 * i + 1]; fsz += us[3 * i + 2]; }
@@ -256,27 +273,28 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
 // Closed-form directions of one (node, point): base position (6..8) and contact forces (22..33); ti = 0..14.
 HB_HD void lq_closed_task(const DevModel& M, const DevConfig& C, double* lds, int mode, int pt, int ti) {
   const LqP1 P = lq_p1(lds);
-  double* FR = P.FR; double* J1 = P.J1; double* J2 = P.J2; double* CDt = P.CDt;
+  double* FR = P.FR; double* CDt = P.CDt;
   bool cf[HB_NC];
   mode_flags(mode, cf);
   const int dir = ti < 3 ? 6 + ti : 19 + ti;
-  double* Jp = pt == 0 ? J1 : J2;
   const bool is_pos = dir < 9, is_f = !is_pos;
-  double col[12];
+  double col[9];  // rows 3..11 of d f / d direction
 #pragma unroll
-  for (int i = 0; i < 12; ++i) col[i] = 0.0;
+  for (int i = 0; i < 9; ++i) col[i] = 0.0;
   if (is_f) {
     const int i = (dir - 22) / 3, a = (dir - 22) % 3;
     const double inv_m = rcp_t(M.total_mass);
-    col[a] = inv_m;
     // (r x e_a) / m
     const double rx = FR[12 * pt + 3 * i], ry = FR[12 * pt + 3 * i + 1], rz = FR[12 * pt + 3 * i + 2];
-    if (a == 0) { col[4] = rz * inv_m; col[5] = -ry * inv_m; }
-    if (a == 1) { col[3] = -rz * inv_m; col[5] = rx * inv_m; }
-    if (a == 2) { col[3] = ry * inv_m; col[4] = -rx * inv_m; }
+    if (a == 0) { col[1] = rz * inv_m; col[2] = -ry * inv_m; }
+    if (a == 1) { col[0] = -rz * inv_m; col[2] = rx * inv_m; }
+    if (a == 2) { col[0] = ry * inv_m; col[1] = -rx * inv_m; }
   }
+  if (is_f || pt == 1) {
+    double* Jp = (pt == 0 ? P.J1 : P.J2) + j_row(pt, dir) * 9;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) Jp[dir * 12 + i] = col[i];
+    for (int i = 0; i < 9; ++i) Jp[i] = col[i];
+  }
   if (pt == 0 && is_pos) {  // the constraint rows do not depend on the contact forces: those directions are not stored
     for (int i = 0; i < HB_NC; ++i) {
       double r0 = 0, r1 = 0, r2 = 0;
@@ -300,6 +318,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* rowval = lds + LqLds::rowval;
   double* GtG = lds + LqLds::GtG;
   double* W = lds + LqLds::W;
+  double* Wl = lds + LqLds::Wl;
   double* Kx = lds + LqLds::Kx;
   double* Z = lds + LqLds::Z;
   double* Pj = lds + LqLds::Pj;
@@ -322,14 +341,29 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* xs = P1.xs; double* us = P1.us; double* fv = P1.fv; double* J1 = P1.J1; double* J2 = P1.J2;
   // ---- compose  x+ = x + dt/2 (f1 + f2(x + dt f1)) :
   //   d x+_i / d dir = [dir==i] + dt/2 (J1 + J2)[dir][i] + dt^2/2 ( sum_{c<12} J2[c][i] J1[dir][c] + sum_j J2[12+j][i] [dir==34+j] )
-  // rows 0..11 of x+ : the 44 x 12 x 12 contraction runs on the matrix cores (9 MFMAs)
+  // rows 3..11 of x+ : the 41 x 9 x 9 contraction (directions with a J1 row x flow-map rows 3..11) runs on the matrix cores;
+  // rows 0..2 (sum F / m - g at both points) and the base-position directions are constants
   {
+    const double inv_m = rcp_t(M.total_mass);
     WaveTile<3, 1> tl;
-    tile_init(cx, tl, 44, 12, [J2](int dir, int i) { return dir >= 34 ? J2[(dir - 22) * 12 + i] : 0.0; });
-    tile_mma<12, 12, false, 12>(cx, tl, J1, J2, 44, 12);
-    tile_store(cx, tl, 44, 12, [ABt, J1, J2, dt](int dir, int i, double acc) {
-      ABt[dir * 12 + i] = (dir == i ? 1.0 : 0.0) + 0.5 * dt * (J1[dir * 12 + i] + J2[dir * 12 + i]) + 0.5 * dt * dt * acc;
+    tile_init(cx, tl, 41, 9, [J2](int r, int i) { return r >= 31 ? J2[(r - 19) * 9 + i] : 0.0; });  // r = dir - 3
+    tile_mma<12, 9, false, 9, false, 9>(cx, tl, J1, J2 + 27, 41, 9);
+    tile_store(cx, tl, 41, 9, [ABt, J1, J2, dt, inv_m](int r, int i, double acc) {
+      const int dir = r < 6 ? r : r + 3;
+      // the momentum directions 0..2 of the contraction: d f_c / d F_(j,a) = [c == a] / m at the first point
+      if (dir >= 22 && dir < 34) acc += inv_m * J2[((dir - 22) % 3) * 9 + i];
+      ABt[dir * 12 + 3 + i] = (dir == 3 + i ? 1.0 : 0.0) + 0.5 * dt * (J1[r * 9 + i] + J2[dir * 9 + i]) + 0.5 * dt * dt * acc;
     });
+    for (int idx = cx.lane; idx < 44 * 3 + 27; idx += cx.nlanes) {
+      if (idx < 132) {
+        const int dir = idx / 3, i = idx - 3 * dir;
+        const bool force_i = dir >= 22 && dir < 34 && (dir - 22) % 3 == i;
+        ABt[dir * 12 + i] = (dir == i ? 1.0 : 0.0) + (force_i ? dt * inv_m : 0.0);
+      } else {
+        const int e = idx - 132, dir = 6 + e / 9, i = 3 + e % 9;
+        ABt[dir * 12 + i] = dir == i ? 1.0 : 0.0;
+      }
+    }
   }
   // joint rows q+ = q + dt qd: closed form, never stored (see LqLds)
   for (int i = cx.lane; i < 22; i += cx.nlanes)
@@ -696,17 +730,17 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     });
   }
   cx.sync();
-  // M = P_j + R_jj Kx  (10x22),  and the vector R_jj ke + r_j -> W column reuse (10)
+  // M = P_j + R_jj Kx  (10x22),  and the vector R_jj ke + r_j (10)
   {
     WaveTile<1, 2> tm;
     tile_init(cx, tm, 10, 23, [Pj, ru](int k, int c) { return c < 22 ? Pj[k * 22 + c] : ru[12 + k]; });
     tile_mma<12, 10, false, 23, false, 10>(cx, tm, Rjj, Kx, 10, 23);
-    tile_store(cx, tm, 10, 23, [Mm, W](int k, int c, double v) {
+    tile_store(cx, tm, 10, 23, [Mm, Wl](int k, int c, double v) {
       if (c < 22) Mm[k * 22 + c] = v;
-      else W[k] = v;  // r_j + R_jj ke
+      else Wl[k] = v;  // r_j + R_jj ke
     });
   }
-  double* RZ = W + 16;  // R_jj Z (10x6), for R~ = Z' R_jj Z
+  double* RZ = Wl + 16;  // R_jj Z (10x6), for R~ = Z' R_jj Z
   for (int idx = cx.lane; idx < 60; idx += cx.nlanes) {
     const int k = idx / 6, b = idx - 6 * k;
     double s = 0;
@@ -726,7 +760,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   // A~ = A + B_j Kx   and the kernel columns of B~ = B_j Z.  Momentum / base rows (0..11) on the matrix cores; the joint
   // rows are the closed form  A~ = [0 I] + dt Kx,  B~ = dt Z  (no force columns),  b~ = defect + dt ke.
-  double* btmp = W + 80;  // 12: B_j ke, the dynamic part of b~ (column 22 of the A~ tile: Kx carries ke in its column 22)
+  double* btmp = Wl + 80;  // 12: B_j ke, the dynamic part of b~ (column 22 of the A~ tile: Kx carries ke in its column 22)
   {
     WaveTile<1, 2> ta;
     tile_init(cx, ta, 12, 23, [ABt](int row, int c) { return c < 22 ? ABt[c * 12 + row] : 0.0; });
@@ -850,7 +884,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       s = ru[3 * foot + col % 3];
     } else if (col < ntil) {
       const int b = col - n_f;
-      for (int k = 0; k < 10; ++k) s += Z[k * 6 + b] * W[k];
+      for (int k = 0; k < 10; ++k) s += Z[k * 6 + b] * Wl[k];
     }
     rec[rec_r(col)] = dt * s;
   }
@@ -871,27 +905,6 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
 
 template <class Ctx>
 HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const NodeIn& in, double* lds, double* rec) {
-  double* ABt = lds + LqLds::ABt;
-  double* CDt = lds + LqLds::CDt;
-  double* xplus = lds + LqLds::xplus;
-  double* rowval = lds + LqLds::rowval;
-  double* GtG = lds + LqLds::GtG;
-  double* W = lds + LqLds::W;
-  double* Kx = lds + LqLds::Kx;
-  double* Z = lds + LqLds::Z;
-  double* Pj = lds + LqLds::Pj;
-  double* Rjj = lds + LqLds::Rjj;
-  double* Mm = lds + LqLds::Mm;
-  double* RFF = lds + LqLds::RFF;
-  double* qx = lds + LqLds::qx;
-  double* ru = lds + LqLds::ru;
-  double* Qd = lds + LqLds::Qd;
-  double* scal = lds + LqLds::scal;
-  int* ints = reinterpret_cast<int*>(lds + LqLds::ints);
-  int* perm = ints;          // [10]
-  int* eqs = ints + 12;      // [12] eq slot list
-  int* softs = ints + 24;    // [8] soft slot list
-
   const double dt = in.dt;
   bool cf[HB_NC];
   mode_flags(in.mode, cf);
@@ -902,16 +915,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   //   stage 2  lane = direction (44): directions h, zyx, joints, rates run the whole-body combine on duals built
   //            from the stage-1 tangents; base-position and contact-force directions are closed form
   // then [A_k | B_k] is composed from the two points' Jacobians (OCS2 RK2 sensitivity).
-  double* xs = lds + LqLds::p1;        // 22 values of x
-  double* us = xs + 22;                // 22 values of u
-  double* xe = us + 22;                // 22 state values of the current evaluation point
-  double* fv = xe + 22;                // 2 x 12 flow-map values (rows 0..11) of the two points
-  double* FR = fv + 24;                // 2 x 12: (contact point - COM) at the two points
-  double* LV_all = FR + 24;            // 2 points x 2 legs x 27 leg values
-  double* SC = LV_all + 108;           // 2 x 6: sin / cos of the ZYX angles at the two RK2 points
-  double* SW = SC + 12;                // 4 x 6 swing references of the node
-  double* J1 = lds + LqLds::J1;        // 44 x 12: d f(rows 0..11) / d direction at point 1
-  double* J2 = lds + LqLds::J2;        // same at point 2
+  const LqP1 P1 = lq_p1(lds);
+  double* xs = P1.xs; double* us = P1.us; double* xe = P1.xe; double* fv = P1.fv; double* LV_all = P1.LV_all; double* SC = P1.SC;
   // (xs, us stay valid to the end of the kernel — no later buffer reaches them — and every later phase reads x and u from
   // these LDS copies instead of going back to global memory)
   for (int i = cx.lane; i < 22; i += cx.nlanes) {
@@ -919,7 +924,6 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     us[i] = in.u[i];
     xe[i] = in.x[i];
   }
-  for (int i = cx.lane; i < 24; i += cx.nlanes) SW[i] = in.swing[i];
 #if defined(__HIP_DEVICE_COMPILE__)
   // entry `lane` of the reference state and of the next node's state, requested now and used (by the same lane) in the cost
   // phase and in b~: no global round trip in the middle of the kernel
@@ -953,6 +957,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
     centroidal_core<double>(M, Vec3<double>(S(0), S(1), S(2)), IOs, Vec3<double>(S(9), S(10), S(11)),
                             Vec3<double>(S(12), S(13), S(14)), xs + 9, xs, core, SC);
+    // (keeps the compiler from clustering the LDS reads of the whole value pass up front: that alone cost 20 registers)
+    asm volatile("" ::: "memory");
     Vec3<double> msum;
     double fsx = 0, fsy = 0, fsz = 0;
 #pragma unroll 1
@@ -979,7 +985,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   if (C.debug_stop == 7) return;
   // ---- stage 2: whole-body combine per (point, direction).  Only 29 of the 44 directions are nonlinear (momentum 0..5,
   // zyx 9..11, joints 12..21, joint rates 34..43), so both RK2 points fit ONE pass of the wave: task = 29 pt + index.
-  for (int task = cx.lane; task < 58; task += cx.nlanes) lq_dual_task(M, C, lds, in.mode, task >= 29 ? 1 : 0, task >= 29 ? task - 29 : task, false);
+  for (int task = cx.lane; task < 58; task += cx.nlanes) lq_dual_task(M, C, lds, in.mode, in.swing, task >= 29 ? 1 : 0, task >= 29 ? task - 29 : task, false);
   cx.sync();
   if (C.debug_stop == 9) return;
   // closed-form directions of both points: base position (6..8) and contact forces (22..33); task = 15 pt + index

@@ -77,15 +77,19 @@ struct RelaxedBarrierD {
   HB_HD double d2(double h) const { const double r = rcp_t(h > delta ? h : delta); return mu * r * r; }
 };
 
-// LDS carve (doubles).  At most 2240 doubles = 17 920 B per node -> 9 single-wave workgroups per CU (k_lq is bound by the
-// number of resident wavefronts, DESIGN.md 3.1, so every double here is throughput).
+// LDS carve (doubles).  At most 2048 doubles = 16 384 B per node -> 10 single-wave workgroups per CU (k_lq runs faster
+// with every additional resident wavefront, DESIGN.md 3.1, so every double here is throughput).
 //   fixed:     CDt [32][12] (constraint-row derivatives; the 12 contact-force directions are identically zero and are not
-//              stored: direction d < 22 -> row d, joint-rate direction 34 + k -> row 22 + k), rowval, xs, us, fv, and xe:
-//              the state of the second RK2 point during phase 1, x+ afterwards
+//              stored: direction d < 22 -> row d, joint-rate direction 34 + k -> row 22 + k), rowval, xs, us, fv (later the
+//              scalars of the cost phase), and xe: the state of the second RK2 point during phase 1, x+ afterwards
 //   phase 1:   LJ (4 leg blocks) | J1 | J2 | small values             (LJ is dead once stage 2 is done)
-//              J1 / J2 hold rows 3..11 of d f / d direction only (9 columns): rows 0..2 (d (sum F / m - g)) are the constants
-//              [dir == 22 + 3 j + i] / m.  J1 has no rows for the base-position directions 6..8 (identically zero, and
-//              never a right operand); J2 keeps them as zeros because rows 3..11 are the right operand of the compose
+//              J1 / J2 hold d f / d direction at the two RK2 points for the 29 directions that need the whole-body combine
+//              (row j_row(dir): momentum, zyx, joints, joint rates) and for rows 3..11 of f only, in the column order
+//              j_col: [angular momentum rate | euler rate | linear velocity].  Everything else is closed form: rows 0..2
+//              of f (sum F / m - g) have the constant derivatives [dir == 22 + 3 j + i] / m, the base-position directions
+//              have none, the contact-force directions have (r_j x e_a) / m in the angular-momentum rows (from FR).  With
+//              this order the right operand of the compose (rows of J2 for the state directions that f depends on:
+//              angular momentum 3..5 and zyx 9..11) is rows 3..8 of J2 and the contraction depth is 6
 //   compose:   ABt [44][12] over the head of LJ.  Only rows 0..11 of x+ are stored; the joint rows q+ = q + dt qd are
 //              the closed form  d q+_j / d dir = [dir == 12 + j] + dt [dir == 34 + j]  and are expanded where used
 //   phase 2+:  every later buffer aliases the rest of the phase-1 region (dead after the compose); P_j and R_jj (written
@@ -96,6 +100,7 @@ struct LqLds {
   static constexpr int xs = rowval + 12;     // 22 values of x
   static constexpr int us = xs + 22;         // 22 values of u
   static constexpr int fv = us + 22;         // 2 x 12 flow-map values (rows 0..11) at the two RK2 points
+  static constexpr int scal = fv;            // 16 scalars (cost, sums, ...) once fv is dead (after x+)
   static constexpr int xe = fv + 24;         // 22
   static constexpr int xplus = xe;
   static constexpr int ABt = xe + 22;        // [44][12]
@@ -103,34 +108,40 @@ struct LqLds {
   static constexpr int W = GtG + 100;        // 10x23 (G'C | G'e)
   static constexpr int Pj = GtG;             // 10x22   } over G'G | W
   static constexpr int Rjj = Pj + 220;       // 10x10   }
-  static constexpr int Wl = W + 230;         // 92: r_j + R_jj ke (10), R_jj Z at 16 (60), B_j ke at 80 (12)
-  static constexpr int Kx = Wl + 92;         // 10x23 (Kx | ke)
+  static constexpr int rjk = Rjj + 100;      // 10: r_j + R_jj ke (the last ten doubles of W)
+  static constexpr int RZ = W + 230;         // 10x6: R_jj Z
+  static constexpr int btmp = RZ + 60;       // 12: B_j ke
+  static constexpr int Kx = btmp + 12;       // 10x23 (Kx | ke)
   static constexpr int Z = Kx + 230;         // 10x6
   static constexpr int Mm = Z + 60;          // 10x22
   static constexpr int RFF = Mm + 220;       // 4 blocks 3x3
   static constexpr int qx = RFF + 36;        // 22 (continuous-time gradient wrt x)
   static constexpr int ru = qx + 22;         // 22 (wrt u)
   static constexpr int Qd = ru + 22;         // 22 diagonal of Q incl. barriers/shift
-  static constexpr int scal = Qd + 22;       // 16 scalars (cost, sums, ...)
-  static constexpr int ints = scal + 16;     // 32 ints packed in 16 doubles: perm[10], rank, eq slots...
+  static constexpr int ints = Qd + 22;       // 32 ints packed in 16 doubles: perm[10], rank, eq slots...
   static constexpr int tail_end = ints + 16;
   // phase-1 view of the aliased region
   static constexpr int LJ = ABt;             // 4 x LEGJ_SIZE (824)
-  static constexpr int J1 = LJ + 4 * LEGJ_SIZE;  // [41][9]
-  static constexpr int J2 = J1 + 41 * 9;     // [44][9]
-  static constexpr int FR = J2 + 44 * 9;     // 2 x 12: (contact point - COM) at the two points
+  static constexpr int J1 = LJ + 4 * LEGJ_SIZE;  // [29][9]
+  static constexpr int J2 = J1 + 29 * 9;     // [29][9]
+  static constexpr int FR = J2 + 29 * 9;     // 2 x 12: (contact point - COM) at the two points
   static constexpr int LV = FR + 24;         // 2 points x 2 legs x 27 leg values
   static constexpr int SC = LV + 108;        // 2 x 6: sin / cos of the ZYX angles at the two RK2 points
   static constexpr int p1_end = SC + 12;
   static constexpr int total = p1_end > tail_end ? p1_end : tail_end;
 };
 static_assert(LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are still being read");
-static_assert(LqLds::Rjj + 100 <= LqLds::Wl, "P_j | R_jj must fit over G'G | W");
-static_assert(LqLds::total * 8 <= 17920, "k_lq: LDS per node must allow 9 workgroups per CU");
+static_assert(LqLds::Qd >= LqLds::p1_end, "the reference state is parked in Qd during phase 1");
+static_assert(LqLds::rjk + 10 <= LqLds::RZ, "P_j | R_jj | r_j must fit over G'G | W");
+static_assert(LqLds::total * 8 <= 16384, "k_lq: LDS per node must allow 10 workgroups per CU");
 // row of CDt that holds direction d (d < 22 or d >= 34)
 HB_HD int cd_row(int dir) { return dir < 22 ? dir : dir - 12; }
-// row of J1 / J2 (RK2 point pt) that holds direction d; the first point has no rows for the base-position directions
-HB_HD int j_row(int pt, int dir) { return (pt == 0 && dir >= 6) ? dir - 3 : dir; }
+// row of J1 / J2 that holds direction d (momentum 0..5, zyx 9..11, joints 12..21, joint rates 34..43) and its inverse
+HB_HD int j_row(int dir) { return dir < 6 ? dir : (dir < 22 ? dir - 3 : dir - 15); }
+HB_HD int j_dir(int row) { return row < 6 ? row : (row < 19 ? row + 3 : row + 15); }
+// column of J1 / J2 that holds row i (3..11) of f: [3 4 5 | 9 10 11 | 6 7 8], and its inverse
+HB_HD int j_col(int frow) { return frow < 6 ? frow - 3 : (frow < 9 ? frow : frow - 6); }
+HB_HD int j_frow(int col) { return col < 3 ? col + 3 : (col < 6 ? col + 6 : col); }
 
 struct NodeIn {
   const double* x;      // 22
@@ -176,7 +187,7 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
   bool cf[HB_NC];
   mode_flags(mode, cf);
   const int dir = ti < 6 ? ti : (ti < 19 ? ti + 3 : ti + 15);
-  double* Jp = (pt == 0 ? P.J1 : P.J2) + j_row(pt, dir) * 9;  // this direction's row: d f(rows 3..11)
+  double* Jp = (pt == 0 ? P.J1 : P.J2) + j_row(dir) * 9;  // this direction's row: d f(rows 3..11), columns j_col
   const double* LJ = LJ_all + pt * 2 * LEGJ_SIZE;
   const double* LV = LV_all + pt * 54;
   const double* xb = pt == 0 ? xs : xe;
@@ -211,7 +222,7 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
     }
     // the base-velocity rows of this direction are final: out of the registers before the contact loop
 #pragma unroll
-    for (int i = 0; i < 3; ++i) Jp[6 + i] = comp(core.euler_rate, i).d;
+    for (int i = 0; i < 3; ++i) Jp[3 + i] = comp(core.euler_rate, i).d;
     const Vec3<double> euler_rate_v(core.euler_rate.x.v, core.euler_rate.y.v, core.euler_rate.z.v);
     // contact points one at a time (rolled loop keeps the register footprint small)
     Vec3<Dual1> ms;
@@ -259,7 +270,7 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
     const Dual1 f[12] = {Dual1(0.0), Dual1(0.0), Dual1(0.0), inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
                          core.v_lin.x, core.v_lin.y, core.v_lin.z, Dual1(euler_rate_v.x), Dual1(euler_rate_v.y), Dual1(euler_rate_v.z)};
 #pragma unroll
-    for (int i = 3; i < 9; ++i) Jp[i - 3] = f[i].d;
+    for (int i = 0; i < 3; ++i) { Jp[i] = f[3 + i].d; Jp[6 + i] = f[6 + i].d; }
     if (dir == 0 && (pt == 1 || first_point_values)) {  // values of this point (single-node form: the first point's come from the pre-pass)
       double fsx = 0, fsy = 0, fsz = 0;
       for (int i = 0; i < HB_NC; ++i) { fsx += us[3 * i]; fsy += us[3 * i + 1]; fsz += us[3 * i + 2]; }
@@ -270,40 +281,19 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
   }
 }
 
-// Closed-form directions of one (node, point): base position (6..8) and contact forces (22..33); ti = 0..14.
-HB_HD void lq_closed_task(const DevModel& M, const DevConfig& C, double* lds, int mode, int pt, int ti) {
-  const LqP1 P = lq_p1(lds);
-  double* FR = P.FR; double* CDt = P.CDt;
+// Constraint-row derivatives of the base-position directions (6..8; first RK2 point): closed form.  ti = 0..2.
+HB_HD void lq_closed_task(const DevConfig& C, double* lds, int mode, int ti) {
+  double* CDt = lds + LqLds::CDt;
   bool cf[HB_NC];
   mode_flags(mode, cf);
-  const int dir = ti < 3 ? 6 + ti : 19 + ti;
-  const bool is_pos = dir < 9, is_f = !is_pos;
-  double col[9];  // rows 3..11 of d f / d direction
-#pragma unroll
-  for (int i = 0; i < 9; ++i) col[i] = 0.0;
-  if (is_f) {
-    const int i = (dir - 22) / 3, a = (dir - 22) % 3;
-    const double inv_m = rcp_t(M.total_mass);
-    // (r x e_a) / m
-    const double rx = FR[12 * pt + 3 * i], ry = FR[12 * pt + 3 * i + 1], rz = FR[12 * pt + 3 * i + 2];
-    if (a == 0) { col[1] = rz * inv_m; col[2] = -ry * inv_m; }
-    if (a == 1) { col[0] = -rz * inv_m; col[2] = rx * inv_m; }
-    if (a == 2) { col[0] = ry * inv_m; col[1] = -rx * inv_m; }
-  }
-  if (is_f || pt == 1) {
-    double* Jp = (pt == 0 ? P.J1 : P.J2) + j_row(pt, dir) * 9;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Jp[i] = col[i];
-  }
-  if (pt == 0 && is_pos) {  // the constraint rows do not depend on the contact forces: those directions are not stored
-    for (int i = 0; i < HB_NC; ++i) {
-      double r0 = 0, r1 = 0, r2 = 0;
-      if (cf[i]) { if (dir == 8) r2 = C.zv_gain; }
-      else { if (dir == 8) r0 = C.kp_normal; if (dir == 6) r1 = C.xy_gain; if (dir == 7) r2 = C.xy_gain; }
-      CDt[dir * 12 + 3 * i + 0] = r0;
-      CDt[dir * 12 + 3 * i + 1] = r1;
-      CDt[dir * 12 + 3 * i + 2] = r2;
-    }
+  const int dir = 6 + ti;
+  for (int i = 0; i < HB_NC; ++i) {
+    double r0 = 0, r1 = 0, r2 = 0;
+    if (cf[i]) { if (dir == 8) r2 = C.zv_gain; }
+    else { if (dir == 8) r0 = C.kp_normal; if (dir == 6) r1 = C.xy_gain; if (dir == 7) r2 = C.xy_gain; }
+    CDt[dir * 12 + 3 * i + 0] = r0;
+    CDt[dir * 12 + 3 * i + 1] = r1;
+    CDt[dir * 12 + 3 * i + 2] = r2;
   }
 }
 
@@ -318,7 +308,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* rowval = lds + LqLds::rowval;
   double* GtG = lds + LqLds::GtG;
   double* W = lds + LqLds::W;
-  double* Wl = lds + LqLds::Wl;
+  double* rjk = lds + LqLds::rjk;
   double* Kx = lds + LqLds::Kx;
   double* Z = lds + LqLds::Z;
   double* Pj = lds + LqLds::Pj;
@@ -341,26 +331,43 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* xs = P1.xs; double* us = P1.us; double* fv = P1.fv; double* J1 = P1.J1; double* J2 = P1.J2;
   // ---- compose  x+ = x + dt/2 (f1 + f2(x + dt f1)) :
   //   d x+_i / d dir = [dir==i] + dt/2 (J1 + J2)[dir][i] + dt^2/2 ( sum_{c<12} J2[c][i] J1[dir][c] + sum_j J2[12+j][i] [dir==34+j] )
-  // rows 3..11 of x+ : the 41 x 9 x 9 contraction (directions with a J1 row x flow-map rows 3..11) runs on the matrix cores;
-  // rows 0..2 (sum F / m - g at both points) and the base-position directions are constants
+  // rows 3..11 of x+ for the 29 stored directions: the 29 x 6 x 9 contraction (f depends on the state directions angular
+  // momentum and zyx only, besides the joints) runs on the matrix cores; the contact-force directions, rows 0..2
+  // (sum F / m - g at both points) and the base-position directions are closed form
   {
     const double inv_m = rcp_t(M.total_mass);
-    WaveTile<3, 1> tl;
-    tile_init(cx, tl, 41, 9, [J2](int r, int i) { return r >= 31 ? J2[(r - 19) * 9 + i] : 0.0; });  // r = dir - 3
-    tile_mma<12, 9, false, 9, false, 9>(cx, tl, J1, J2 + 27, 41, 9);
-    tile_store(cx, tl, 41, 9, [ABt, J1, J2, dt, inv_m](int r, int i, double acc) {
-      const int dir = r < 6 ? r : r + 3;
-      // the momentum directions 0..2 of the contraction: d f_c / d F_(j,a) = [c == a] / m at the first point
-      if (dir >= 22 && dir < 34) acc += inv_m * J2[((dir - 22) % 3) * 9 + i];
-      ABt[dir * 12 + 3 + i] = (dir == 3 + i ? 1.0 : 0.0) + 0.5 * dt * (J1[r * 9 + i] + J2[dir * 9 + i]) + 0.5 * dt * dt * acc;
+    const double* FR = P1.FR;
+    WaveTile<2, 1> tl;
+    tile_init(cx, tl, 29, 9, [J2](int r, int c) { return r >= 19 ? J2[(r - 10) * 9 + c] : 0.0; });  // joint-rate direction 34 + j: row of joint 12 + j
+    tile_mma<8, 9, false, 9, false, 6>(cx, tl, J1, J2 + 27, 29, 9);
+    tile_store(cx, tl, 29, 9, [ABt, J1, J2, dt](int r, int c, double acc) {
+      const int dir = j_dir(r), i = j_frow(c);
+      ABt[dir * 12 + i] = (dir == i ? 1.0 : 0.0) + 0.5 * dt * (J1[r * 9 + c] + J2[r * 9 + c]) + 0.5 * dt * dt * acc;
     });
-    for (int idx = cx.lane; idx < 44 * 3 + 27; idx += cx.nlanes) {
-      if (idx < 132) {
-        const int dir = idx / 3, i = idx - 3 * dir;
+    for (int idx = cx.lane; idx < 108 + 132 + 27; idx += cx.nlanes) {
+      if (idx < 108) {
+        // contact-force direction (j, a), row j_frow(c):  d f / d F_(j,a) = e_a / m (rows 0..2), (r_j x e_a) / m (rows 3..5)
+        const int fd = idx / 9, c = idx - 9 * fd, j = fd / 3, a = fd - 3 * j;
+        double g1[3], g2[3];  // (r x e_a) / m at the two points
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          const double rx = FR[12 * pt + 3 * j], ry = FR[12 * pt + 3 * j + 1], rz = FR[12 * pt + 3 * j + 2];
+          double* g = pt == 0 ? g1 : g2;
+          g[0] = (a == 1 ? -rz : (a == 2 ? ry : 0.0)) * inv_m;
+          g[1] = (a == 0 ? rz : (a == 2 ? -rx : 0.0)) * inv_m;
+          g[2] = (a == 0 ? -ry : (a == 1 ? rx : 0.0)) * inv_m;
+        }
+        double acc = inv_m * J2[a * 9 + c];  // through the linear momentum, direction a
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc += J2[(3 + k) * 9 + c] * g1[k];  // through the angular momentum
+        const double lin = c < 3 ? g1[c] + g2[c] : 0.0;
+        ABt[(22 + fd) * 12 + j_frow(c)] = 0.5 * dt * lin + 0.5 * dt * dt * acc;
+      } else if (idx < 240) {
+        const int e = idx - 108, dir = e / 3, i = e - 3 * dir;
         const bool force_i = dir >= 22 && dir < 34 && (dir - 22) % 3 == i;
         ABt[dir * 12 + i] = (dir == i ? 1.0 : 0.0) + (force_i ? dt * inv_m : 0.0);
       } else {
-        const int e = idx - 132, dir = 6 + e / 9, i = 3 + e % 9;
+        const int e = idx - 240, dir = 6 + e / 9, i = 3 + e % 9;
         ABt[dir * 12 + i] = dir == i ? 1.0 : 0.0;
       }
     }
@@ -735,12 +742,12 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     WaveTile<1, 2> tm;
     tile_init(cx, tm, 10, 23, [Pj, ru](int k, int c) { return c < 22 ? Pj[k * 22 + c] : ru[12 + k]; });
     tile_mma<12, 10, false, 23, false, 10>(cx, tm, Rjj, Kx, 10, 23);
-    tile_store(cx, tm, 10, 23, [Mm, Wl](int k, int c, double v) {
+    tile_store(cx, tm, 10, 23, [Mm, rjk](int k, int c, double v) {
       if (c < 22) Mm[k * 22 + c] = v;
-      else Wl[k] = v;  // r_j + R_jj ke
+      else rjk[k] = v;  // r_j + R_jj ke
     });
   }
-  double* RZ = Wl + 16;  // R_jj Z (10x6), for R~ = Z' R_jj Z
+  double* RZ = lds + LqLds::RZ;  // R_jj Z (10x6), for R~ = Z' R_jj Z
   for (int idx = cx.lane; idx < 60; idx += cx.nlanes) {
     const int k = idx / 6, b = idx - 6 * k;
     double s = 0;
@@ -760,7 +767,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   // A~ = A + B_j Kx   and the kernel columns of B~ = B_j Z.  Momentum / base rows (0..11) on the matrix cores; the joint
   // rows are the closed form  A~ = [0 I] + dt Kx,  B~ = dt Z  (no force columns),  b~ = defect + dt ke.
-  double* btmp = Wl + 80;  // 12: B_j ke, the dynamic part of b~ (column 22 of the A~ tile: Kx carries ke in its column 22)
+  double* btmp = lds + LqLds::btmp;  // 12: B_j ke, the dynamic part of b~ (column 22 of the A~ tile: Kx carries ke in its column 22)
   {
     WaveTile<1, 2> ta;
     tile_init(cx, ta, 12, 23, [ABt](int row, int c) { return c < 22 ? ABt[c * 12 + row] : 0.0; });
@@ -884,7 +891,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       s = ru[3 * foot + col % 3];
     } else if (col < ntil) {
       const int b = col - n_f;
-      for (int k = 0; k < 10; ++k) s += Z[k * 6 + b] * Wl[k];
+      for (int k = 0; k < 10; ++k) s += Z[k * 6 + b] * rjk[k];
     }
     rec[rec_r(col)] = dt * s;
   }
@@ -925,10 +932,13 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     xe[i] = in.x[i];
   }
 #if defined(__HIP_DEVICE_COMPILE__)
-  // entry `lane` of the reference state and of the next node's state, requested now and used (by the same lane) in the cost
-  // phase and in b~: no global round trip in the middle of the kernel
-  const double xref_l = in.xref[cx.lane < 22 ? cx.lane : 0], xnext_l = in.xnext[cx.lane < 22 ? cx.lane : 0];
-  auto xref_at = [xref_l](int) { return xref_l; };
+  // entry `lane` of the next node's state, requested now and used (by the same lane) in the cost phase and in b~
+  const double xnext_l = in.xnext[cx.lane < 22 ? cx.lane : 0];
+  // the reference state waits in the Q-diagonal buffer, which nothing touches before the cost phase (there lane i reads
+  // entry i, then overwrites it): two registers less across the projection
+  double* xref_lds = lds + LqLds::Qd;
+  if (cx.lane < 22) xref_lds[cx.lane] = in.xref[cx.lane];
+  auto xref_at = [xref_lds](int i) { return xref_lds[i]; };
   auto xnext_at = [xnext_l](int) { return xnext_l; };
 #else
   auto xref_at = [&in](int i) { return in.xref[i]; };
@@ -947,9 +957,12 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
                       [xs, us, dt](int g, int j) { return xs[12 + j] + ((g >> 1) ? dt : 0.0) * us[12 + j]; },
                       [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all, 3, [xs](int i) { return xs[9 + i]; }, SC);
   if (C.debug_stop == 6) return;
-  // ---- value of the flow map at the first RK2 point (one lane, plain doubles): the second point x + dt f(x, u) must be
-  // known before its directional pass can start, and a value-only evaluation costs well under half a dual pass.
-  for (int l = cx.lane; l < 1; l += cx.nlanes) {
+  // ---- value of the flow map at the first RK2 point (plain doubles): the second point x + dt f(x, u) must be known before
+  // its directional pass can start, and a value-only evaluation costs well under half a dual pass.  Device: four lanes run
+  // the (identical) whole-body part and take one contact point each — the moment sum is a DPP add inside the quad — and
+  // the sine / cosine of the second point's ZYX angles come straight from the registers of lanes 0..2.
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (cx.lane < 4) {
     const double* LV = LV_all;
     auto S = [LV](int e) { return LV[e] + LV[27 + e]; };
     CentroidalCore<double> core;
@@ -959,9 +972,38 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
                             Vec3<double>(S(12), S(13), S(14)), xs + 9, xs, core, SC);
     // (keeps the compiler from clustering the LDS reads of the whole value pass up front: that alone cost 20 registers)
     asm volatile("" ::: "memory");
+    const int i = cx.lane;
+    const double* v = LV + (i & 1) * 27 + 15 + 3 * (i >> 1);
+    Vec3<double> fr, fvel;
+    centroidal_foot<double>(core, ld3(v), ld3(v + 6), fr, fvel);
+    const Vec3<double> F(us[3 * i], us[3 * i + 1], us[3 * i + 2]);
+    const Vec3<double> mi = cross(fr - core.com_rel, F);
+    const double msx = quad_sum_f64(mi.x), msy = quad_sum_f64(mi.y), msz = quad_sum_f64(mi.z);
+    const double fsx = quad_sum_f64(F.x), fsy = quad_sum_f64(F.y), fsz = quad_sum_f64(F.z);
+    const double inv_m = rcp_t(M.total_mass);
+    if (i == 0) {
+      fv[0] = inv_m * fsx; fv[1] = inv_m * fsy; fv[2] = inv_m * fsz - M.gravity;
+      fv[3] = inv_m * msx; fv[4] = inv_m * msy; fv[5] = inv_m * msz;
+      fv[6] = core.v_lin.x; fv[7] = core.v_lin.y; fv[8] = core.v_lin.z;
+      fv[9] = core.euler_rate.x; fv[10] = core.euler_rate.y; fv[11] = core.euler_rate.z;
+    }
+    if (i < 3) sincos_t(xs[9 + i] + dt * comp(core.euler_rate, i), SC[6 + 2 * i], SC[6 + 2 * i + 1]);
+  }
+  cx.sync();
+  // second evaluation point of Heun's method: x + dt f(x,u), same input
+  if (cx.lane < 22) xe[cx.lane] = xs[cx.lane] + dt * (cx.lane < 12 ? fv[cx.lane] : us[cx.lane]);
+  cx.sync();
+#else
+  for (int l = cx.lane; l < 1; l += cx.nlanes) {
+    const double* LV = LV_all;
+    auto S = [LV](int e) { return LV[e] + LV[27 + e]; };
+    CentroidalCore<double> core;
+    Sym3<double> IOs;
+    IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
+    centroidal_core<double>(M, Vec3<double>(S(0), S(1), S(2)), IOs, Vec3<double>(S(9), S(10), S(11)),
+                            Vec3<double>(S(12), S(13), S(14)), xs + 9, xs, core, SC);
     Vec3<double> msum;
     double fsx = 0, fsy = 0, fsz = 0;
-#pragma unroll 1
     for (int i = 0; i < HB_NC; ++i) {
       const double* v = LV + (i & 1) * 27 + 15 + 3 * (i >> 1);
       Vec3<double> fr, fvel;
@@ -975,21 +1017,20 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     fv[3] = inv_m * msum.x; fv[4] = inv_m * msum.y; fv[5] = inv_m * msum.z;
     fv[6] = core.v_lin.x; fv[7] = core.v_lin.y; fv[8] = core.v_lin.z;
     fv[9] = core.euler_rate.x; fv[10] = core.euler_rate.y; fv[11] = core.euler_rate.z;
-    // second evaluation point of Heun's method: x + dt f(x,u), same input
     for (int i = 0; i < 22; ++i) xe[i] = xs[i] + dt * (i < 12 ? fv[i] : us[i]);
   }
   cx.sync();
-  // sine / cosine of the ZYX angles at the second point, one angle per lane: the 58 lanes of stage 2 then only add tangents
   for (int i = cx.lane; i < 3; i += cx.nlanes) sincos_t(xe[9 + i], SC[6 + 2 * i], SC[6 + 2 * i + 1]);
   cx.sync();
+#endif
   if (C.debug_stop == 7) return;
   // ---- stage 2: whole-body combine per (point, direction).  Only 29 of the 44 directions are nonlinear (momentum 0..5,
   // zyx 9..11, joints 12..21, joint rates 34..43), so both RK2 points fit ONE pass of the wave: task = 29 pt + index.
   for (int task = cx.lane; task < 58; task += cx.nlanes) lq_dual_task(M, C, lds, in.mode, in.swing, task >= 29 ? 1 : 0, task >= 29 ? task - 29 : task, false);
   cx.sync();
   if (C.debug_stop == 9) return;
-  // closed-form directions of both points: base position (6..8) and contact forces (22..33); task = 15 pt + index
-  for (int task = cx.lane; task < 30; task += cx.nlanes) lq_closed_task(M, C, lds, in.mode, task >= 15 ? 1 : 0, task >= 15 ? task - 15 : task);
+  // constraint rows of the base-position directions (closed form)
+  for (int task = cx.lane; task < 3; task += cx.nlanes) lq_closed_task(C, lds, in.mode, task);
   cx.sync();
   lq_tail(cx, M, C, in, lds, rec, xref_at, xnext_at);
 }

@@ -160,6 +160,19 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 #undef HB_DPP_ADD
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+// Sum over each aligned group of four lanes (all four must be active), returned to all of them: two quad_perm adds.
+__device__ __forceinline__ double quad_sum_f64(double v) {
+#define HB_DPP_QADD(ctrl)                                                                    \
+  {                                                                                          \
+    const int lo2_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false); \
+    const int hi2_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false); \
+    v += __hiloint2double(hi2_, lo2_);                                                       \
+  }
+  HB_DPP_QADD(0xB1)  // quad_perm:[1,0,3,2]
+  HB_DPP_QADD(0x4E)  // quad_perm:[2,3,0,1]
+#undef HB_DPP_QADD
+  return v;
+}
 #endif
 HB_HD double rsqrt_t(double a) {
 #if defined(__HIP_DEVICE_COMPILE__)

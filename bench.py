@@ -294,6 +294,10 @@ def main():
     n_nodes = s.get_references()["n_nodes"]
     hist = sharding.sum_over_ranks([int((status == k).sum()) for k in range(4)], dist, device="cuda")
     mpc_hist = sharding.sum_over_ranks([int((mpc_status == k).sum()) for k in range(4)], dist, device="cuda")
+    wbc_iters = s.get_wbc_iterations()            # active-set iterations of the last WBC solve (nWSR of the reference)
+    it_edges = [0, 16, 20, 24, 28, 32, 40, 64, 1 << 30]
+    it_hist = sharding.sum_over_ranks([int(((wbc_iters >= lo) & (wbc_iters < hi)).sum()) for lo, hi in zip(it_edges, it_edges[1:])],
+                                      dist, device="cuda")
     step_hist = sharding.sum_over_ranks([int((perf[:, 3] == 1.0).sum()), int(((perf[:, 3] < 1.0) & (perf[:, 3] > 0.0)).sum()),
                                          int((perf[:, 3] == 0.0).sum())], dist, device="cuda")
 
@@ -374,6 +378,9 @@ def main():
                        "note": "device time of each half alone (HIP events); the reference runs them 1:5 (100 Hz MPC, 500 Hz WBC)"},
             "solver_state": {"max_dyn_sse": float(perf[:, 1].max()), "max_eq_sse": float(perf[:, 2].max()),
                              "wbc_status_histogram_all_ranks": hist, "mpc_status_histogram_all_ranks": mpc_hist,
+                             "wbc_active_set_iterations_histogram_all_ranks": {f"{lo}..{hi - 1}" if hi < (1 << 30) else f">={lo}": n
+                                                                               for lo, hi, n in zip(it_edges, it_edges[1:], it_hist)},
+                             "wbc_active_set_iterations_min_max_rank0": [int(wbc_iters.min()), int(wbc_iters.max())],
                              "line_search_step_histogram_all_ranks": {"full": step_hist[0], "backtracked": step_hist[1], "rejected": step_hist[2]},
                              "nodes_per_instance_min_max": [int(n_nodes.min()), int(n_nodes.max())]},
         }

@@ -1808,6 +1808,14 @@ int32_t hb_get_wbc_solution(hb_ctx* ctx, double* sol, int32_t* status) {
   return HB_OK;
 }
 
+int32_t hb_get_wbc_iterations(hb_ctx* ctx, int32_t* iters) {
+  if (!ctx || !iters) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipStreamSynchronize(ctx->s_wbc));
+  HB_HIP(hipMemcpy(iters, ctx->w.iters, size_t(ctx->B) * sizeof(int), hipMemcpyDeviceToHost));
+  return HB_OK;
+}
+
 int32_t hb_get_stats(hb_ctx* ctx, hb_stats* out) {
   if (!ctx || !out) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));

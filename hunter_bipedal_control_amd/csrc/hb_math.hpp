@@ -160,6 +160,10 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 #undef HB_DPP_ADD
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+// Value of lane `src` (uniform) in every lane
+__device__ __forceinline__ double wave_bcast_f64(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
 // Sum over each aligned group of four lanes (all four must be active), returned to all of them: two quad_perm adds.
 __device__ __forceinline__ double quad_sum_f64(double v) {
 #define HB_DPP_QADD(ctrl)                                                                    \

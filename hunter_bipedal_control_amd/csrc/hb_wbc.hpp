@@ -619,17 +619,132 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
 #pragma unroll
   for (int j = 0; j < NW; ++j) jrow[j] = cx.lane < NW ? Jm[cx.lane * NW + j] : 0.0;
 #endif
+  // One Householder reflector H maps d2 = d[q:] onto (alpha, 0, ...); the trailing columns of J are updated as J2 <- J2 H,
+  // each lane owning a row of J (one barrier instead of one per rotation).  Leaves d = (d1, alpha, 0, ...).
+  auto reflect = [&](int q) {
+    double nrm2 = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+      const double dj = (cx.lane >= q && cx.lane < NW) ? d[cx.lane] : 0.0;
+      nrm2 = wave_sum_f64(dj * dj);
+    }
+#else
+    for (int j = q; j < NW; ++j) nrm2 += d[j] * d[j];
+#endif
+    const double dq = d[q];
+    const double alpha = dq > 0.0 ? -sqrt(nrm2) : sqrt(nrm2);
+    const double v0 = dq - alpha;
+    const double vtv = nrm2 - dq * dq + v0 * v0;
+    if (vtv > 0.0 && nrm2 > 0.0) {
+      const double beta = 2.0 * rcp_t(vtv);
+      // reflector vector hv = (0, ..., 0, v0, d[q+1], ..., d[NW-1]); each lane holds its row of J in registers:
+      // two fixed-length passes (unrolled, batched LDS traffic) instead of two rolled loops from q + 1
+      for (int k = cx.lane; k < NW; k += cx.nlanes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        double* row = jrow;  // k == lane
+#else
+        double row[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) row[j] = Jm[k * NW + j];
+#endif
+        double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < NW; ++j) sa[j & 3] += row[j] * (j < q ? 0.0 : (j == q ? v0 : d[j]));
+        const double sacc = ((sa[0] + sa[1]) + (sa[2] + sa[3])) * beta;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          row[j] = row[j] - sacc * (j < q ? 0.0 : (j == q ? v0 : d[j]));
+          Jm[k * NW + j] = row[j];
+        }
+      }
+    }
+    cx.sync();
+    for (int j = q + cx.lane; j < NW; j += cx.nlanes) d[j] = (j == q) ? alpha : 0.0;
+    cx.sync();
+  };
   int q = 0, iter = 0, status = 0;
-  int next_eq = 0;
-  int next_eq_active = 0;  // equalities in the active set (never dropped)
+  // ---- the equalities (16 equation-of-motion rows + 3 zero-force rows per swing foot) enter the active set as a block:
+  // they are never dropped and no inequality is active yet, so the dual method's step-length logic is idle for them —
+  // each addition is the full primal step.  Per row only d = J'n, the reflector and the new column of R are formed; the
+  // primal point after the block is  x - J1 R^-T (N'x - b)  in one go (forward substitution through lane registers).
+  if (wc.n_eq > C.wbc_max_iter) status = HB_INST_MAXITER;  // every addition counts as one iteration (nWSR)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int p = 0; p < 16 + 3 * HB_NC; ++p) {  // (fixed trip count: unrolled on the device, q = p is then a constant in `reflect`)
+    if (p >= wc.n_eq || status != 0) break;
+    if (p < 16) {
+      for (int k = cx.lane; k < NW; k += cx.nlanes) {
+        double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < NW; ++i) sa[i & 3] += Jm[i * NW + k] * Ee[p * NW + i];
+        d[k] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+      }
+    } else {
+      const int sidx = 16 + 3 * wc.swing_feet[(p - 16) / 3] + (p - 16) % 3;  // unit normal: a row of J
+      for (int k = cx.lane; k < NW; k += cx.nlanes) d[k] = Jm[sidx * NW + k];
+    }
+    cx.sync();
+    reflect(q);
+    if (!(fabs(d[q]) > 1e-13 * fmax(1.0, fabs(Rm[0])))) { status = HB_INST_INFEASIBLE; break; }  // dependent equality rows
+    for (int i = cx.lane; i <= q; i += cx.nlanes) Rm[i * NW + q] = d[i];
+    if (cx.lane == 0) { act[q] = p; lam[q] = 0.0; is_active[p] = 1; }
+    ++q;
+    ++iter;
+    cx.sync();
+  }
+  if (status == 0 && q > 0) {
+    // residuals s_p = n_p'x - b_p (lane p), then R'y = s by substitution, then x -= J1 y
+    for (int pp = cx.lane; pp < NW; pp += cx.nlanes) {
+      double sres = 0.0;
+      if (pp < q) {
+        if (pp < 16) {
+          double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int i = 0; i < NW; ++i) sa[i & 3] += Ee[pp * NW + i] * x[i];
+          sres = (sa[0] + sa[1]) + (sa[2] + sa[3]) - beom[pp];
+        } else {
+          sres = x[16 + 3 * wc.swing_feet[(pp - 16) / 3] + (pp - 16) % 3];
+        }
+      }
+      r[pp] = sres;
+    }
+    cx.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+      double sres = cx.lane < NW ? r[cx.lane] : 0.0;
+      const double rdiag = rcp_t(cx.lane < q ? Rm[cx.lane * NW + cx.lane] : 1.0);
+      double xacc = 0.0;
+      for (int i = 0; i < q; ++i) {  // y_i = s_i / R_ii (uniform), s_p -= R_ip y_i on the lanes p > i, x -= J(:, i) y_i
+        const double yi = wave_bcast_f64(sres * rdiag, i);
+        if (cx.lane > i && cx.lane < q) sres -= Rm[i * NW + cx.lane] * yi;
+        xacc += (cx.lane < NW ? Jm[cx.lane * NW + i] : 0.0) * yi;
+      }
+      if (cx.lane < NW) x[cx.lane] -= xacc;
+    }
+#else
+    for (int l0 = cx.lane; l0 < 1; l0 += cx.nlanes) {
+      for (int i = 0; i < q; ++i) {
+        const double yi = r[i] / Rm[i * NW + i];
+        for (int pp = i + 1; pp < q; ++pp) r[pp] -= Rm[i * NW + pp] * yi;
+        r[i] = yi;
+      }
+      for (int k = 0; k < NW; ++k) {
+        double acc = 0.0;
+        for (int i = 0; i < q; ++i) acc += Jm[k * NW + i] * r[i];
+        x[k] -= acc;
+      }
+    }
+#endif
+    cx.sync();
+  }
+  const int next_eq_active = q;  // equalities in the active set (never dropped)
   const int n_cons = wc.n_eq + wc.n_in;
   const double inf = 1e300;
-  while (true) {
+  while (status == 0) {
     int p = -1;
     double sp = 0.0;
-    if (next_eq < wc.n_eq) {
-      p = next_eq++;
-    } else {
+    {
       // most violated inequality (lane-parallel scan + reduction through LDS)
       double best = 0.0;
       int bi = -1;
@@ -663,13 +778,9 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       cx.sync();
 #endif
     }
-    const bool p_is_eq = p < wc.n_eq;
-    // dense normal of p into np, rhs in prhs
+    // dense normal of p (an inequality: the equalities are all in) into np, rhs in prhs
     double prhs;
-    if (p < 16) {
-      for (int i = cx.lane; i < NW; i += cx.nlanes) np[i] = Ee[p * NW + i];
-      prhs = beom[p];
-    } else {
+    {
       int idx[3];
       double cfv[3];
       const int nn = sparse_row(wc, C, p, idx, cfv, &prhs);
@@ -744,7 +855,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       for (int i = 0; i < NW; ++i) { zn += z[i] * np[i]; nn2 += np[i] * np[i]; }
 #endif
       const double t2 = (zn > 1e-14 * (1.0 + nn2)) ? sp * rcp_t(zn) : inf;
-      const double dir = (p_is_eq && sp < 0.0) ? -1.0 : 1.0;
+      const double dir = 1.0;
       double t1 = inf;
       int l = -1;
       for (int j = 0; j < q && need_r; ++j) {
@@ -771,54 +882,12 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       }
       cx.sync();
       if (t2 < inf && t == t2abs) {
-        // full step: add constraint p.  One Householder reflector H maps d2 = d[q:] onto (alpha, 0, ...); the trailing
-        // columns of J are updated as J2 <- J2 H, each lane owning rows of J (one barrier instead of one per rotation).
-        {
-          double nrm2 = 0.0;
-#if defined(__HIP_DEVICE_COMPILE__)
-          {
-            const double dj = (cx.lane >= q && cx.lane < NW) ? d[cx.lane] : 0.0;
-            nrm2 = wave_sum_f64(dj * dj);
-          }
-#else
-          for (int j = q; j < NW; ++j) nrm2 += d[j] * d[j];
-#endif
-          const double dq = d[q];
-          const double alpha = dq > 0.0 ? -sqrt(nrm2) : sqrt(nrm2);
-          const double v0 = dq - alpha;
-          const double vtv = nrm2 - dq * dq + v0 * v0;
-          if (vtv > 0.0 && nrm2 > 0.0) {
-            const double beta = 2.0 * rcp_t(vtv);
-            // reflector vector hv = (0, ..., 0, v0, d[q+1], ..., d[NW-1]); each lane holds its row of J in registers:
-            // two fixed-length passes (unrolled, batched LDS traffic) instead of two rolled loops from q + 1
-            for (int k = cx.lane; k < NW; k += cx.nlanes) {
-#if defined(__HIP_DEVICE_COMPILE__)
-              double* row = jrow;  // k == lane
-#else
-              double row[NW];
-#pragma unroll
-              for (int j = 0; j < NW; ++j) row[j] = Jm[k * NW + j];
-#endif
-              double sa[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-              for (int j = 0; j < NW; ++j) sa[j & 3] += row[j] * (j < q ? 0.0 : (j == q ? v0 : d[j]));
-              const double sacc = ((sa[0] + sa[1]) + (sa[2] + sa[3])) * beta;
-#pragma unroll
-              for (int j = 0; j < NW; ++j) {
-                row[j] = row[j] - sacc * (j < q ? 0.0 : (j == q ? v0 : d[j]));
-                Jm[k * NW + j] = row[j];
-              }
-            }
-          }
-          cx.sync();
-          for (int j = q + cx.lane; j < NW; j += cx.nlanes) d[j] = (j == q) ? alpha : 0.0;
-          cx.sync();
-        }
+        // full step: add constraint p
+        reflect(q);
         if (fabs(d[q]) > 1e-13 * fmax(1.0, fabs(Rm[0]))) {
           for (int i = cx.lane; i <= q; i += cx.nlanes) Rm[i * NW + q] = d[i];
           if (cx.lane == 0) { act[q] = p; lam[q] = lam_p; is_active[p] = 1; }
           ++q;
-          if (p_is_eq) ++next_eq_active;
         }
         cx.sync();
         done_p = true;

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
     "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd", "hb_plant_reset", "hb_plant_step",
     "hb_plant_get_state", "hb_hoqp_solve", "hb_mpc_reset_masked", "hb_mpc_get_status", "hb_joint_set_flags",
-    "hb_joint_get_emergency_stop", "hb_set_resident_time",
+    "hb_joint_get_emergency_stop", "hb_set_resident_time", "hb_get_wbc_iterations",
 ]
 # include/hunter_lcm.h
 LCM_SYMBOLS = ["hb_lcm_fingerprint", "hb_lcm_encoded_size", "hb_lcm_field_count", "hb_lcm_encode", "hb_lcm_decode", "hb_lcm_frame",
@@ -273,6 +273,12 @@ class HunterSolver:
         sol, status = np.zeros((self.B, 38)), np.zeros(self.B, dtype=np.int32)
         self._check(self.lib.hb_get_wbc_solution(self.ctx, _p(sol), _p(status)), "hb_get_wbc_solution")
         return sol, status
+
+    def get_wbc_iterations(self):
+        """Active-set iterations of the last WBC solve per instance."""
+        it = np.zeros(self.B, dtype=np.int32)
+        self._check(self.lib.hb_get_wbc_iterations(self.ctx, _p(it)), "hb_get_wbc_iterations")
+        return it
 
     def sync(self):
         self._check(self.lib.hb_sync(self.ctx), "hb_sync")

@@ -246,6 +246,9 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt);
  * MPC call, LeggedController.cpp:141-144).  n_seq = 0 disables it. */
 int32_t hb_set_resident_x0_sequence(hb_ctx* ctx, int32_t n_seq, const double* x0_seq);
 int32_t hb_get_wbc_solution(hb_ctx* ctx, double* sol /*[batch][38]*/, int32_t* status /*[batch]*/);
+/* Active-set iterations of the last WBC solve of every instance (constraint additions + drops of the dual active-set
+ * method; the role of nWSR at WeightedWbc.cpp:51-55).  iters: [batch]. */
+int32_t hb_get_wbc_iterations(hb_ctx* ctx, int32_t* iters /*[batch]*/);
 /* Pipelining of hb_step_resident: the batch is cut into n_chunks (1..8) instance ranges, each a linear
  * MPC -> publish -> WBC sequence on its own HIP stream so that the per-instance sweeps of one range overlap the
  * per-node kernels of another.  Results are identical for every n_chunks; hb_get_stats phase times are only

@@ -294,8 +294,8 @@ __global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
   // What a step reads — the [A~ b~ B~ .] rows and the recovery part of the stage record, the gains — is staged into LDS
   // with coalesced 16-byte loads, one stage ahead (WaveCtx::sync does not drain the loads in flight): the matrix-vector
   // products then run out of LDS instead of waiting for scattered global loads on the dx -> dx+ dependency chain.
-  constexpr int P_AB = REC_PR / 2, P_RX = (REC_META + 6 - REC_KX) / 2, P_G = GAIN_SIZE / 2;  // 396, 176, 144 pairs
-  constexpr int N_AB = (P_AB + 63) / 64, N_RX = (P_RX + 63) / 64, N_G = (P_G + 63) / 64;     // 7, 3, 3 loads per lane
+  constexpr int P_AB = 12 * REC_LD / 2, P_RX = (REC_RX_END - REC_KX) / 2, P_G = GAIN_SIZE / 2;  // 216, 182, 144 pairs
+  constexpr int N_AB = (P_AB + 63) / 64, N_RX = (P_RX + 63) / 64, N_G = (P_G + 63) / 64;        // 4, 3, 3 loads per lane
   typedef double d2 __attribute__((ext_vector_type(2)));
   d2 bab[N_AB], brx[N_RX], bg[N_G];
   const int l = cx.lane;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
     const d2* pab_ = reinterpret_cast<const d2*>(b.recs + nd_ * REC_SIZE + REC_AB) + l;                   \
     const d2* prx_ = reinterpret_cast<const d2*>(b.recs + nd_ * REC_SIZE + REC_KX) + l;                   \
     const d2* pg_ = reinterpret_cast<const d2*>(b.gains + nd_ * GAIN_SIZE) + l;                           \
-    _Pragma("unroll") for (int r = 0; r < N_AB; ++r) bab[r] = pab_[64 * r]; /* slots past 396 stay inside the record */ \
+    _Pragma("unroll") for (int r = 0; r < N_AB; ++r) bab[r] = pab_[64 * r]; /* slots past 216 stay inside the record */ \
     _Pragma("unroll") for (int r = 0; r < N_RX; ++r) brx[r] = (64 * r + 63 < P_RX || l + 64 * r < P_RX) ? prx_[64 * r] : d2{0.0, 0.0}; \
     _Pragma("unroll") for (int r = 0; r < N_G; ++r) bg[r] = (64 * r + 63 < P_G || l + 64 * r < P_G) ? pg_[64 * r] : d2{0.0, 0.0}; \
   }

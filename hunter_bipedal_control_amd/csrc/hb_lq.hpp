@@ -57,6 +57,9 @@ constexpr int REC_DF = 2020;             // 12: constant part of dF (= -F on swi
 constexpr int REC_QF = 2032;             // 22 unprojected cost gradient wrt x (x dt)
 constexpr int REC_RF = 2054;             // 22 unprojected cost gradient wrt u (x dt)
 constexpr int REC_META = 2076;           // nf, nz, mode, cost*dt, dyn_sse*dt, eq_sse*dt
+constexpr int REC_DT = REC_META + 6;     // interval length (the forward sweep forms the joint rows q+ = q + dt qd itself)
+constexpr int REC_DQ = REC_META + 8;     // 10: defect of the joint rows, (q + dt qd) - q_next
+constexpr int REC_RX_END = REC_DQ + 10;  // end of what the forward sweep reads behind REC_KX
 constexpr int REC_SIZE = 2112;           // 16.5 KiB, a multiple of 512 B
 constexpr int GAIN_SIZE = 288;           // K~ 12x22 (264) + k~ 12 + pad
 HB_HD constexpr int rec_A(int i, int c) { return REC_AB + i * REC_LD + c; }            // A~(i, c)
@@ -807,6 +810,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       }
     }
     double s = xplus[row] - xnext_at(row);  // row == lane
+    if (row >= 12) rec[REC_DQ + row - 12] = s;
     if (row < 12) {
       s += btmp[row];
       for (int i = 0; i < HB_NC; ++i)
@@ -907,6 +911,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     rec[REC_META + 3] = dt * scal[0];
     rec[REC_META + 4] = dt * scal[1];
     rec[REC_META + 5] = dt * scal[2];
+    rec[REC_DT] = dt;
   }
 }
 

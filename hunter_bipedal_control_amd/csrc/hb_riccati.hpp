@@ -302,14 +302,15 @@ struct FwdLds {
   static constexpr int accp = 88;     // 22 (+2): per-entry partial sums of the Armijo directional derivative
   static constexpr int small = 112;
   // staged copy of what one forward step reads (device kernel): [A~ b~ B~ .] rows | recovery data | gains
-  static constexpr int AB = small;                 // REC_PR doubles (22 rows of 36)
-  static constexpr int RX = AB + REC_PR;           // record elements [REC_KX, REC_META + 6)
-  static constexpr int G = RX + (REC_META + 6 - REC_KX);
+  static constexpr int AB = small;                 // rows 0..11 of [A~ b~ B~ .] (12 rows of 36)
+  static constexpr int RX = AB + 12 * REC_LD;      // record elements [REC_KX, REC_RX_END)
+  static constexpr int G = RX + (REC_RX_END - REC_KX);
   static constexpr int total = G + GAIN_SIZE;
 };
-static_assert((REC_META + 6 - REC_KX) % 2 == 0 && REC_KX % 2 == 0 && FwdLds::AB % 2 == 0, "16-byte staging");
+static_assert((REC_RX_END - REC_KX) % 2 == 0 && (12 * REC_LD) % 2 == 0 && REC_KX % 2 == 0 && FwdLds::AB % 2 == 0, "16-byte staging");
 
-// One forward step.  `ab` = rows [A~ b~ B~ .] of the stage record (stride REC_LD), `rx` = its recovery part (element
+// One forward step.  `ab` = rows 0..11 of [A~ b~ B~ .] of the stage record (stride REC_LD; the joint rows are the closed
+// form q+ = q + dt qd and are formed from the recovered joint rates), `rx` = its recovery part (element
 // REC_KX onwards), `gains` = [K~ | k~]: pointers into global memory (host emulation) or into the staged LDS copy (kernel).
 // Advances dx in LDS and writes the full state/input step of this node.
 template <class Ctx>
@@ -328,6 +329,8 @@ HB_HD void riccati_fwd_node(const Ctx& cx, double* lds, const double* ab, const 
   const double* QF = rx + (REC_QF - REC_KX);
   const double* RF = rx + (REC_RF - REC_KX);
   const double* META = rx + (REC_META - REC_KX);
+  const double* DQ = rx + (REC_DQ - REC_KX);
+  const double dt = rx[REC_DT - REC_KX];
   const int n_f = int(META[0]), nz = int(META[1]), mode = int(META[2]);
   bool cf[HB_NC];
   mode_flags(mode, cf);
@@ -338,13 +341,13 @@ HB_HD void riccati_fwd_node(const Ctx& cx, double* lds, const double* ab, const 
   }
   cx.sync();
   for (int i = cx.lane; i < 22 + 22; i += cx.nlanes) {
-    if (i < 22) {
+    if (i < 12) {
       const double* row = ab + i * REC_LD;
       double s = row[REC_CV];
       for (int c = 0; c < 22; ++c) s += row[c] * dx[c];
       for (int a = 0; a < NU_T; ++a) s += row[REC_CU + a] * ut[a];
       dxn[i] = s;
-    } else {
+    } else if (i >= 22) {
       const int m = i - 22;
       double s;
       if (m < 12) {
@@ -361,6 +364,7 @@ HB_HD void riccati_fwd_node(const Ctx& cx, double* lds, const double* ab, const 
         s = KE[k];
         for (int c = 0; c < 22; ++c) s += KX[k * 22 + c] * dx[c];
         for (int b = 0; b < nz; ++b) s += Zk[k * 6 + b] * ut[n_f + b];
+        dxn[12 + k] = DQ[k] + dx[12 + k] + dt * s;  // joint row of the step: (q + dt qd)+ - q_next
       }
       du[m] = s;
     }

@@ -60,6 +60,15 @@ def main():
                              ("SQ_ACTIVE_INST_ANY", "wave_frac_issuing")):
                 if src in v:
                     v[dst] = v[src] / v["SQ_WAVE_CYCLES"]
+        # lanes doing work in the average VALU instruction; LDS cycles lost to bank conflicts
+        if v.get("SQ_ACTIVE_INST_VALU", 0) > 0 and "SQ_THREAD_CYCLES_VALU" in v:
+            v["valu_lane_utilisation"] = v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"])
+        if v.get("SQ_LDS_IDX_ACTIVE", 0) > 0 and "SQ_LDS_BANK_CONFLICT" in v:
+            v["lds_bank_conflict_frac"] = v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"]
+        # Average resident wavefronts per CU.  SQ_WAVE_CYCLES is reported in units of 4 cycles and sampled 1 / 32 on this stack
+        # (checked on k_lq at 8 workgroups per CU, profiles/r02a_pmc.txt: 272.8 M x 128 / 17.3 M cycles = 2 018 = 7.9 x 256)
+        if v.get("GRBM_GUI_ACTIVE", 0) > 0 and "SQ_WAVE_CYCLES" in v:
+            v["avg_resident_waves_per_cu"] = 128.0 * v["SQ_WAVE_CYCLES"] / v["GRBM_GUI_ACTIVE"] / 256.0
         if v.get("SQ_WAVES", 0) > 0:
             for src in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_MFMA"):
                 if src in v:

@@ -3,13 +3,13 @@ import sys, time, os; sys.path.insert(0,'.')
 import numpy as np
 from hunter_bipedal_control_amd import ingest
 from oracle.pyoracle import Oracle
-import bench
+from oracle import workloads
 P = ingest.load_packaged(); o = Oracle(P)
 print("cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
 try: print("cpu.max", open("/sys/fs/cgroup/cpu.max").read().strip())
 except Exception as e: print("no cgroup cpu.max", e)
 n = 32
-refs, x0, rbd, tn = bench.make_batch(P, n, 100, 0)
+refs, x0, rbd, tn = workloads.trot_batch(P, n, n_intervals=100)
 x = np.zeros((n,101,22)); u = np.zeros((n,100,22))
 for i in range(n): x[i], u[i] = o.cold_start(refs["mode"][i], x0[i])
 for th in (1, 4, 8, 16, 32):

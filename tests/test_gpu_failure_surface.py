@@ -15,7 +15,7 @@ import threading
 import numpy as np
 import pytest
 
-from hunter_bipedal_control_amd import abi, workload
+from hunter_bipedal_control_amd import abi, gait, workload
 from oracle import refgen, workloads
 
 pytestmark = pytest.mark.gpu
@@ -101,6 +101,33 @@ def test_wbc_iteration_limit_reuses_previous_solution(params, oracle):
         assert (st2 == abi.HB_INST_MAXITER).all() and np.array_equal(sol2, sol1)
         stats = s.stats()
         assert stats["n_status"][abi.HB_INST_MAXITER] == B
+    finally:
+        s.close()
+
+
+def test_wbc_iteration_counts_cover_the_equality_rows(params):
+    """hb_get_wbc_iterations (the nWSR of WeightedWbc.cpp:51-55): every equality row is one working-set change — 16 equation-of-
+    motion rows + 3 zero-force rows per swing foot — plus whatever the inequalities needed; well inside the default limit."""
+    B = 8
+    rng = np.random.default_rng(5)
+    x0 = np.array(params["config"]["initial_state"])
+    mass = sum(params["model"]["mass"])
+    xd = x0 + 0.02 * rng.standard_normal((B, 22))
+    ud = np.zeros((B, 22))
+    ud[:, 2:12:3] = mass * 9.81 / 4
+    rbd = np.stack([workload.rbd_from_state(x0 + 0.02 * rng.standard_normal(22), i) for i in range(B)])
+    mode = np.array([3, 3, 1, 1, 2, 2, 0, 0], dtype=np.int32)          # stance, single support (two contact points off), flight
+    n_swing = np.array([0, 0, 2, 2, 2, 2, 4, 4])
+    for i, m in enumerate(mode):                                        # desired forces only on the contact feet of each mode
+        for f, on in enumerate(gait.mode_to_contact_flags(int(m))):
+            if not on:
+                ud[i, 3 * f:3 * f + 3] = 0.0
+    s = _solver(params, B, 4)
+    try:
+        sol, st = s.wbc_update_direct(xd, ud, rbd, mode)
+        it = s.get_wbc_iterations()
+        assert (st == abi.HB_INST_OK).all()
+        assert (it >= 16 + 3 * n_swing).all() and (it <= 16 + 3 * n_swing + 40).all(), it
     finally:
         s.close()
 

@@ -527,6 +527,111 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   int status = 0;
   const double se = sqrt(C.wbc_eps);
   for (int it = 0; it < 12; ++it) {
+    if (it == 0) {
+      // First pass (no violated inequality rows yet — in normal operation the only pass): the triangular factor of
+      // [sqrt(eps) I ; A0] by 38 structured Householder reflectors instead of 28 x 38 Givens rotations.  Reflector k has
+      // its support on row k of the identity block and on the 28 rows of A0, so row k of the factor is final after step k
+      // and the identity block never has to be stored.  x = R^-1 R^-T A0'b0 by two substitutions (no inverse).
+#if defined(__HIP_DEVICE_COMPILE__)
+      {
+        // lane j owns column j of A0 (28 registers); column k reaches the other lanes as wave-uniform values (v_readlane)
+        constexpr int MA = 28;
+        const int j = cx.lane;
+        double acol[MA];
+        double gj = 0.0;
+#pragma unroll
+        for (int r = 0; r < MA; ++r) {
+          acol[r] = j < NW ? a0_row(r, j) : 0.0;
+          gj += acol[r] * a0_rhs(r);
+        }
+        double rinv = 0.0;  // 1 / R_jj once step j is done
+#pragma unroll 1
+        for (int k = 0; k < NW; ++k) {
+          double dot = 0.0;
+          double ck[MA];
+#pragma unroll
+          for (int r = 0; r < MA; ++r) {
+            ck[r] = wave_bcast_f64(acol[r], k);
+            dot += ck[r] * acol[r];
+          }
+          const double sig2 = se * se + wave_bcast_f64(dot, k);
+          const double alpha = -sqrt(sig2);
+          const double v0 = se - alpha;
+          const double beta = 2.0 * rcp_t(sig2 - se * se + v0 * v0);
+          const double w = beta * (dot + (j == k ? v0 * se : 0.0));
+          const bool live = j > k && j < NW;
+#pragma unroll
+          for (int r = 0; r < MA; ++r) acol[r] = live ? acol[r] - w * ck[r] : (j == k ? 0.0 : acol[r]);
+          if (j < NW) Rm[k * NW + j] = j < k ? 0.0 : (j == k ? alpha : -w * v0);
+          if (j == k) rinv = rcp_t(alpha);
+        }
+        cx.sync();
+        // R'y = g (lane j carries g_j, then y_j), R x = y
+#pragma unroll 1
+        for (int k = 0; k < NW; ++k) {
+          const double yk = wave_bcast_f64(gj * rinv, k);
+          if (j == k) gj = yk;
+          if (j > k && j < NW) gj -= Rm[k * NW + j] * yk;
+        }
+#pragma unroll 1
+        for (int k = NW - 1; k >= 0; --k) {
+          const double xk = wave_bcast_f64(gj * rinv, k);
+          if (j == k) gj = xk;
+          if (j < k) gj -= Rm[j * NW + k] * xk;
+        }
+        if (j < NW) x[j] = gj;
+        cx.sync();
+      }
+#else
+      {
+        // same algorithm, A0 in the (not yet used) T buffer, one column per loop trip
+        constexpr int MA = 28;
+        for (int idx = cx.lane; idx < MA * NW; idx += cx.nlanes) Tm[idx] = a0_row(idx / NW, idx % NW);
+        cx.sync();
+        for (int jj = cx.lane; jj < NW; jj += cx.nlanes) {
+          double sacc = 0.0;
+          for (int r = 0; r < MA; ++r) sacc += Tm[r * NW + jj] * a0_rhs(r);
+          g[jj] = sacc;
+        }
+        cx.sync();
+        for (int k = 0; k < NW; ++k) {
+          for (int jj = cx.lane; jj < NW; jj += cx.nlanes) {
+            double dot = 0.0;
+            for (int r = 0; r < MA; ++r) dot += Tm[r * NW + k] * Tm[r * NW + jj];
+            np[jj] = dot;
+          }
+          cx.sync();
+          const double sig2 = se * se + np[k];
+          const double alpha = -sqrt(sig2);
+          const double v0 = se - alpha;
+          const double beta = 2.0 * rcp_t(sig2 - se * se + v0 * v0);
+          for (int jj = cx.lane; jj < NW; jj += cx.nlanes) {
+            const double w = beta * (np[jj] + (jj == k ? v0 * se : 0.0));
+            if (jj > k)
+              for (int r = 0; r < MA; ++r) Tm[r * NW + jj] -= w * Tm[r * NW + k];
+            Rm[k * NW + jj] = jj < k ? 0.0 : (jj == k ? alpha : -w * v0);
+          }
+          cx.sync();
+          for (int r = cx.lane; r < MA; r += cx.nlanes) Tm[r * NW + k] = 0.0;
+          cx.sync();
+        }
+        for (int l0 = cx.lane; l0 < 1; l0 += cx.nlanes) {
+          for (int k = 0; k < NW; ++k) {
+            const double yk = g[k] / Rm[k * NW + k];
+            g[k] = yk;
+            for (int jj = k + 1; jj < NW; ++jj) g[jj] -= Rm[k * NW + jj] * yk;
+          }
+          for (int k = NW - 1; k >= 0; --k) {
+            const double xk = g[k] / Rm[k * NW + k];
+            g[k] = xk;
+            for (int jj = 0; jj < k; ++jj) g[jj] -= Rm[jj * NW + k] * xk;
+          }
+          for (int k = 0; k < NW; ++k) x[k] = g[k];
+        }
+        cx.sync();
+      }
+#endif
+    } else {
     for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Rm[idx] = (idx / NW == idx % NW) ? se : 0.0;
     for (int i = cx.lane; i < NW; i += cx.nlanes) g[i] = 0.0;
     cx.sync();
@@ -578,6 +683,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
       x[i] = s;
     }
     cx.sync();
+    }
     // violated set of the new point
     if (cx.lane == 0) imisc[0] = 0;
     cx.sync();
@@ -611,6 +717,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
     Z1[idx] = j < n1 ? Qm[i * NW + r0 + j] : 0.0;
   }
   cx.sync();
+  if (C.debug_stop == 43) return;  // profiling ablation: level 0 + kernel basis
   // ------------------------------------------------------------------ level 1: base acceleration
   const double* A1 = Aw + 3 * wc.n_sw * 16;
   const double* b1 = bw + 3 * wc.n_sw;
@@ -648,6 +755,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   }
   cx.sync();
   for (int i = cx.lane; i < NW; i += cx.nlanes) x[i] = g[i];
+  if (C.debug_stop == 44) return;  // profiling ablation: ... + level-1 QP
   // kernel of A1 Z1 (6 x n1): QR of its transpose (n1 x 6)
   for (int idx = cx.lane; idx < n1 * 6; idx += cx.nlanes) Tm[idx] = AZ[(idx % 6) * 12 + idx / 6];
   cx.sync();

@@ -708,6 +708,73 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
     return;
   }
   // ------------------------------------------------------------------ kernel of the level-0 task: Z1
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Column-pivoted Householder QR of A0' with lane c owning column c of it (= row c of A0, 38 registers): the column norms
+  // are per-lane sums, the pivot is a wave maximum, the reflector reaches the other lanes through LDS (where it also waits
+  // for the back-application) and every lane updates its own column — no orthogonal factor is accumulated.  The kernel
+  // basis is H_0 ... H_(r-1) applied to the unit vectors e_r ..: lane b carries column b of it.
+  int r0 = 0;
+  {
+    constexpr int MT = 28;
+    const int c = cx.lane;
+    double t[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t[i] = c < MT ? a0_row(c, i) : 0.0;
+    bool done = c >= MT;
+    double* Vs = Qm;        // reflector j: Vs[j * NW + i]
+    double* betas = work;   // [28]
+    double r00 = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < MT; ++j) {  // (rolled: every access to t[] below has a compile-time index; rows above j are masked / zero)
+      double nr = 0.0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) nr += i >= j ? t[i] * t[i] : 0.0;
+      const double best = wave_max_f64(done ? -1.0 : nr);
+      const double rjj = sqrt(best);
+      if (j == 0) r00 = rjj;
+      if (!(rjj > 1e-9 * r00) || rjj == 0.0) break;
+      const int pv = __ffsll(__ballot(!done && nr == best)) - 1;
+      if (c == pv) {
+        double x0 = 0.0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) x0 = i == j ? t[i] : x0;
+        const double alpha = x0 > 0.0 ? -rjj : rjj;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) Vs[j * NW + i] = i < j ? 0.0 : (i == j ? x0 - alpha : t[i]);
+        betas[j] = 2.0 * rcp_t(best - x0 * x0 + (x0 - alpha) * (x0 - alpha));
+        done = true;
+      }
+      cx.sync();
+      if (!done) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) sacc += Vs[j * NW + i] * t[i];
+        sacc *= betas[j];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) t[i] -= sacc * Vs[j * NW + i];
+      }
+      r0 = j + 1;
+    }
+    const int nk = NW - r0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t[i] = (i == r0 + c) ? 1.0 : 0.0;
+#pragma unroll 1
+    for (int j = r0 - 1; j >= 0; --j) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) sacc += Vs[j * NW + i] * t[i];
+      sacc *= betas[j];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) t[i] -= sacc * Vs[j * NW + i];
+    }
+    if (c < 12) {
+#pragma unroll
+      for (int i = 0; i < NW; ++i) Z1[i * 12 + c] = c < nk ? t[i] : 0.0;
+    }
+  }
+  const int n1 = NW - r0;  // 10..12
+  cx.sync();
+#else
   for (int idx = cx.lane; idx < NW * 28; idx += cx.nlanes) Tm[idx] = a0_row(idx % 28, idx / 28);
   cx.sync();
   const int r0 = householder_qr_pivot(cx, Tm, NW, mA0, 28, Qm, work);
@@ -717,6 +784,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
     Z1[idx] = j < n1 ? Qm[i * NW + r0 + j] : 0.0;
   }
   cx.sync();
+#endif
   if (C.debug_stop == 43) return;  // profiling ablation: level 0 + kernel basis
   // ------------------------------------------------------------------ level 1: base acceleration
   const double* A1 = Aw + 3 * wc.n_sw * 16;

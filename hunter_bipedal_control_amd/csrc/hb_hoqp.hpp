@@ -485,8 +485,8 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   wc.n_sw = 0;
   wc.n_c = 0;
   for (int i = 0; i < HB_NC; ++i) {
-    if (cf[i]) wc.contact_feet[wc.n_c++] = i;
-    else wc.swing_feet[wc.n_sw++] = i;
+    if (cf[i]) wc.add_contact(i);
+    else wc.add_swing(i);
   }
   wc.n_eq = 16 + 3 * wc.n_sw;
   wc.n_in = 20 + 5 * wc.n_c;
@@ -500,17 +500,17 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
     if (r < 16) return Ee[r * NW + col];
     if (r < 16 + 3 * wc.n_sw) {
       const int s = r - 16;
-      return (col == 16 + 3 * wc.swing_feet[s / 3] + s % 3) ? 1.0 : 0.0;
+      return (col == 16 + 3 * wc.swing_foot(s / 3) + s % 3) ? 1.0 : 0.0;
     }
     const int s = r - 16 - 3 * wc.n_sw;
-    const int foot = wc.contact_feet[s / 3];
+    const int foot = wc.contact_foot(s / 3);
     return col < 16 ? Jc[(3 * foot + s % 3) * 16 + col] : 0.0;
   };
   auto a0_rhs = [&](int r) -> double {
     if (r < 16) return beom[r];
     if (r < 16 + 3 * wc.n_sw) return 0.0;
     const int s = r - 16 - 3 * wc.n_sw;
-    return -dJv[3 * wc.contact_feet[s / 3] + s % 3];
+    return -dJv[3 * wc.contact_foot(s / 3) + s % 3];
   };
   auto ineq_row = [&](int c, int col, double* rhs_out) -> double {
     int idx[3];

@@ -305,15 +305,20 @@ struct WbcLds {
 //   torque limits 20 rows (+tau_j <= lim, -tau_j <= lim), friction pyramid 5 rows per contact foot.
 struct WbcCons {
   int n_eq, n_in;
-  int swing_feet[HB_NC], n_sw;
-  int contact_feet[HB_NC], n_c;
+  // the swing / contact feet in foot order, two bits each (as arrays they were indexed dynamically and lived in scratch memory)
+  int sw_pack = 0, n_sw = 0;
+  int c_pack = 0, n_c = 0;
+  HB_HD int swing_foot(int k) const { return (sw_pack >> (2 * k)) & 3; }
+  HB_HD int contact_foot(int k) const { return (c_pack >> (2 * k)) & 3; }
+  HB_HD void add_swing(int i) { sw_pack |= i << (2 * n_sw); ++n_sw; }
+  HB_HD void add_contact(int i) { c_pack |= i << (2 * n_c); ++n_c; }
 };
 
 // sparse inequality / selector rows: returns up to 3 (index, coeff) pairs and the right-hand side
 HB_HD int sparse_row(const WbcCons& wc, const DevConfig& C, int cid, int* idx, double* cf, double* rhs) {
   if (cid < 16 + 3 * wc.n_sw) {  // zero-force selector (equality)
     const int s = cid - 16;
-    idx[0] = 16 + 3 * wc.swing_feet[s / 3] + s % 3;
+    idx[0] = 16 + 3 * wc.swing_foot(s / 3) + s % 3;
     cf[0] = 1.0;
     *rhs = 0.0;
     return 1;
@@ -326,7 +331,7 @@ HB_HD int sparse_row(const WbcCons& wc, const DevConfig& C, int cid, int* idx, d
     *rhs = C.torque_limits[j % 5];
     return 1;
   }
-  const int p = c - 20, foot = wc.contact_feet[p / 5], r = p % 5;
+  const int p = c - 20, foot = wc.contact_foot(p / 5), r = p % 5;
   const int base = 16 + 3 * foot;
   *rhs = 0.0;
   if (r == 0) { idx[0] = base + 2; cf[0] = -1.0; return 1; }
@@ -467,7 +472,7 @@ HB_HD void wbc_phase_a(const Ctx& cx, const DevModel& M, const DevConfig& C, con
     // swing leg rows (WbcBase.cpp:297-323), weight w_swing: row 3 s + a, one (row, column) entry per lane
     for (int idx = cx.lane; idx < 3 * wc.n_sw * 17; idx += cx.nlanes) {
       const int row = idx / 17, col = idx - 17 * row, sidx = row / 3, a = row - 3 * sidx;
-      const int i = wc.swing_feet[sidx];
+      const int i = wc.swing_foot(sidx);
       if (col < 16) {
         Aw[row * 16 + col] = w_swing * comp(contact_jac(P, i, col), a);
       } else {
@@ -524,8 +529,8 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   wc.n_sw = 0;
   wc.n_c = 0;
   for (int i = 0; i < HB_NC; ++i) {
-    if (cf[i]) wc.contact_feet[wc.n_c++] = i;
-    else wc.swing_feet[wc.n_sw++] = i;
+    if (cf[i]) wc.add_contact(i);
+    else wc.add_swing(i);
   }
   wc.n_eq = 16 + 3 * wc.n_sw;
   wc.n_in = 20 + 5 * wc.n_c;
@@ -681,7 +686,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
         d[k] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
       }
     } else {
-      const int sidx = 16 + 3 * wc.swing_feet[(p - 16) / 3] + (p - 16) % 3;  // unit normal: a row of J
+      const int sidx = 16 + 3 * wc.swing_foot((p - 16) / 3) + (p - 16) % 3;  // unit normal: a row of J
       for (int k = cx.lane; k < NW; k += cx.nlanes) d[k] = Jm[sidx * NW + k];
     }
     cx.sync();
@@ -704,7 +709,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
           for (int i = 0; i < NW; ++i) sa[i & 3] += Ee[pp * NW + i] * x[i];
           sres = (sa[0] + sa[1]) + (sa[2] + sa[3]) - beom[pp];
         } else {
-          sres = x[16 + 3 * wc.swing_feet[(pp - 16) / 3] + (pp - 16) % 3];
+          sres = x[16 + 3 * wc.swing_foot((pp - 16) / 3) + (pp - 16) % 3];
         }
       }
       r[pp] = sres;

@@ -420,10 +420,16 @@ HB_HD int hoqp_generic(const Ctx& cx, int n, int n_levels, const int* mA, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// LDS layout of the cascade (doubles).  `HoLds` is the straightforward one (every buffer its own storage; the host emulation
+// uses it: its generic QR needs the full 38 x 38 orthogonal factor and the 38 x 28 work matrix).  `HoLdsDev` is what the kernel
+// runs on: the level-0 buffers (J, R: the iterated fallback path and the phase-A workspace) are dead once level 0 has its point,
+// and everything the later levels use — reflectors, kernel bases, projected tasks, the small QP's workspace — lies over them:
+// 75.8 KB -> 34.6 KB per instance, 2 -> 4 instances per CU (the kernel holds one wavefront per SIMD).
 struct HoLds {
   static constexpr int J = 0;                     // 38x38
   static constexpr int R = J + NW * NW;           // 38x38
   static constexpr int Q = R + NW * NW;           // 38x38 orthogonal factor / kernel bases
+  static constexpr int Q2 = Q;                    // orthogonal factor of the second (small) QR
   static constexpr int T = Q + NW * NW;           // 38x28 (A0') then scratch
   static constexpr int Ee = T + NW * 28;          // 16x38
   static constexpr int Jc = Ee + 16 * NW;         // 12x16
@@ -448,35 +454,77 @@ struct HoLds {
   static constexpr int ints = work + 80;          // 64 ints: violated flags (40), misc
   static constexpr int total = ints + 32;
 };
+struct HoLdsDev {
+  // persistent
+  static constexpr int Ee = 0;                    // 16x38
+  static constexpr int Jc = Ee + 16 * NW;         // 12x16
+  static constexpr int dJv = Jc + 192;            // 12
+  static constexpr int Aw = dJv + 12;             // 18x16
+  static constexpr int bw = Aw + 288;             // 18
+  static constexpr int beom = bw + 18;            // 16
+  static constexpr int x = beom + 16;             // 38
+  static constexpr int g = x + NW;                // 38
+  static constexpr int z = g + NW;                // 38
+  static constexpr int np = z + NW;               // 38
+  static constexpr int v0 = np + NW;              // 40 slack of level 0
+  static constexpr int work = v0 + 40;            // 80 (reflector scalars, householder)
+  static constexpr int ints = work + 80;          // 64 ints
+  static constexpr int shared = ints + 32;
+  // level 0 (and phase A's workspace)
+  static constexpr int J = shared;                // 38x38
+  static constexpr int R = J + NW * NW;           // 38x38
+  // after level 0, over J | R
+  static constexpr int Z1 = shared;               // 38x12  } the 28 reflectors (28 x 38) lie over Z1 | Z2 | AZ: they are dead
+  static constexpr int Z2 = Z1 + NW * 12;         // 38x6   } before the first of these is written
+  static constexpr int AZ = Z2 + NW * 12;         // 24x12
+  static constexpr int Q = Z1;                    // reflectors of the kernel QR (28 x 38)
+  static constexpr int rhs = AZ + 288;            // 24
+  static constexpr int DZ = rhs + 24;             // 40x12
+  static constexpr int ft = DZ + 480;             // 40
+  static constexpr int zs = ft + 40;              // 12
+  static constexpr int qpw = zs + 12;             // 440
+  static constexpr int T = qpw + 440;             // small work matrix of the second QR (<= 12 x 6)
+  static constexpr int Q2 = T + 72;               // its orthogonal factor (<= 12 x 12)
+  static constexpr int late_end = Q2 + 144;
+  static constexpr int total = (R + NW * NW > late_end) ? R + NW * NW : late_end;
+};
+static_assert(HoLdsDev::Q + 28 * NW <= HoLdsDev::rhs, "the reflectors must not reach buffers that are written while they are live");
+static_assert(HoLdsDev::total * 8 <= 40960, "k_hwbc: 4 instances per CU");
 
 template <class Ctx>
 HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const double* xdes, const double* udes,
                       const double* rbd, int mode, double* lds, double* sol, int* status_out, int max_level = 3) {
-  double* Jm = lds + HoLds::J;
-  double* Rm = lds + HoLds::R;
-  double* Qm = lds + HoLds::Q;
-  double* Tm = lds + HoLds::T;
-  double* Ee = lds + HoLds::Ee;
-  double* Jc = lds + HoLds::Jc;
-  double* dJv = lds + HoLds::dJv;
-  double* Aw = lds + HoLds::Aw;
-  double* bw = lds + HoLds::bw;
-  double* beom = lds + HoLds::beom;
-  double* x = lds + HoLds::x;
-  double* g = lds + HoLds::g;
-  double* z = lds + HoLds::z;
-  double* np = lds + HoLds::np;
-  double* v0 = lds + HoLds::v0;
-  double* Z1 = lds + HoLds::Z1;
-  double* Z2 = lds + HoLds::Z2;
-  double* AZ = lds + HoLds::AZ;
-  double* rhs = lds + HoLds::rhs;
-  double* DZ = lds + HoLds::DZ;
-  double* ft = lds + HoLds::ft;
-  double* zs = lds + HoLds::zs;
-  double* qpw = lds + HoLds::qpw;
-  double* work = lds + HoLds::work;
-  int* viol = reinterpret_cast<int*>(lds + HoLds::ints);  // [40] current violated set, [40..] misc
+#if defined(__HIP_DEVICE_COMPILE__)
+  using L = HoLdsDev;
+#else
+  using L = HoLds;
+#endif
+  double* Jm = lds + L::J;
+  double* Rm = lds + L::R;
+  double* Qm = lds + L::Q;
+  double* Tm = lds + L::T;
+  double* Q2 = lds + L::Q2;
+  double* Ee = lds + L::Ee;
+  double* Jc = lds + L::Jc;
+  double* dJv = lds + L::dJv;
+  double* Aw = lds + L::Aw;
+  double* bw = lds + L::bw;
+  double* beom = lds + L::beom;
+  double* x = lds + L::x;
+  double* g = lds + L::g;
+  double* z = lds + L::z;
+  double* np = lds + L::np;
+  double* v0 = lds + L::v0;
+  double* Z1 = lds + L::Z1;
+  double* Z2 = lds + L::Z2;
+  double* AZ = lds + L::AZ;
+  double* rhs = lds + L::rhs;
+  double* DZ = lds + L::DZ;
+  double* ft = lds + L::ft;
+  double* zs = lds + L::zs;
+  double* qpw = lds + L::qpw;
+  double* work = lds + L::work;
+  int* viol = reinterpret_cast<int*>(lds + L::ints);  // [40] current violated set, [40..] misc
   int* imisc = viol + 48;
 
   bool cf[HB_NC];
@@ -827,13 +875,13 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   // kernel of A1 Z1 (6 x n1): QR of its transpose (n1 x 6)
   for (int idx = cx.lane; idx < n1 * 6; idx += cx.nlanes) Tm[idx] = AZ[(idx % 6) * 12 + idx / 6];
   cx.sync();
-  const int r1 = householder_qr_pivot(cx, Tm, n1, 6, 6, Qm, work);
+  const int r1 = householder_qr_pivot(cx, Tm, n1, 6, 6, Q2, work);
   const int n2 = n1 - r1;
   for (int idx = cx.lane; idx < NW * 12; idx += cx.nlanes) {
     const int i = idx / 12, j = idx % 12;
     double s = 0.0;
     if (j < n2)
-      for (int k = 0; k < n1; ++k) s += Z1[i * 12 + k] * Qm[k * n1 + r1 + j];
+      for (int k = 0; k < n1; ++k) s += Z1[i * 12 + k] * Q2[k * n1 + r1 + j];
     Z2[idx] = s;
   }
   cx.sync();

@@ -883,7 +883,7 @@ int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch,
   A(w.pn, B);
 #undef A
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hwbc), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               int(HoLds::total * sizeof(double)))) != hipSuccess)
+                               int(HoLdsDev::total * sizeof(double)))) != hipSuccess)
     return fail("k_hwbc LDS size", e);
   if ((e = hipMemcpy(ctx->dmodel, &ctx->hmodel, sizeof(DevModel), hipMemcpyHostToDevice)) != hipSuccess) return fail("model", e);
   if ((e = hipMemcpy(ctx->dconfig, &ctx->hconfig, sizeof(DevConfig), hipMemcpyHostToDevice)) != hipSuccess) return fail("config", e);
@@ -1621,7 +1621,7 @@ static int32_t wbc_launch(hb_ctx* ctx, bool from_policy, double dt) {
     ctx->policy_read_pending = true;
   }
   if (ctx->config.wbc_type == 1)
-    hipLaunchKernelGGL(k_hwbc, dim3(ctx->B), dim3(64), HoLds::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
+    hipLaunchKernelGGL(k_hwbc, dim3(ctx->B), dim3(64), HoLdsDev::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
   else
     hipLaunchKernelGGL(k_wbc, dim3(ctx->B), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
   HB_HIP(hipEventRecord(ctx->ev[6], s));
@@ -1771,7 +1771,7 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
     HB_HIP(hipMemcpyAsync(w.pn, b.n_nodes, size_t(cnt) * sizeof(int), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_policy_eval, dim3((cnt + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
     if (ctx->config.wbc_type == 1)
-      hipLaunchKernelGGL(k_hwbc, dim3(cnt), dim3(64), HoLds::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
+      hipLaunchKernelGGL(k_hwbc, dim3(cnt), dim3(64), HoLdsDev::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
     else
       hipLaunchKernelGGL(k_wbc, dim3(cnt), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
     HB_HIP(hipGetLastError());

@@ -562,6 +562,38 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       s = C.w_force * C.w_force * udes[i - 16];
     d[i] = s;
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Device: the 16 x 16 triangle of [sqrt(eps) I ; A_w] by 16 structured Householder reflectors (support: row k of the identity
+  // block + the dense cost rows), lane j owning column j of A_w in registers and column k reaching the other lanes as
+  // wave-uniform values — no LDS traffic and no ordering point inside the factorisation (see k_hwbc level 0, hb_hoqp.hpp).
+  {
+    constexpr int MA = 18;
+    const int j = cx.lane;
+    double acol[MA];
+#pragma unroll
+    for (int r = 0; r < MA; ++r) acol[r] = (j < 16 && r < n_aw) ? Aw[r * 16 + j] : 0.0;
+#pragma unroll 1
+    for (int k = 0; k < 16; ++k) {
+      double dot = 0.0;
+      double ck[MA];
+#pragma unroll
+      for (int r = 0; r < MA; ++r) {
+        ck[r] = wave_bcast_f64(acol[r], k);
+        dot += ck[r] * acol[r];
+      }
+      const double sig2 = se * se + wave_bcast_f64(dot, k);
+      const double alpha = -sqrt(sig2);
+      const double v0 = se - alpha;
+      const double beta = 2.0 * rcp_t(sig2 - se * se + v0 * v0);
+      const double w = beta * (dot + (j == k ? v0 * se : 0.0));
+      const bool live = j > k && j < 16;
+#pragma unroll
+      for (int r = 0; r < MA; ++r) acol[r] = live ? acol[r] - w * ck[r] : (j == k ? 0.0 : acol[r]);
+      if (j < 16) Rm[k * NW + j] = j < k ? 0.0 : (j == k ? alpha : -w * v0);
+    }
+    cx.sync();
+  }
+#else
   for (int rw = 0; rw < n_aw; ++rw) {
     for (int i = cx.lane; i < NW; i += cx.nlanes) np[i] = (i < 16) ? Aw[rw * 16 + i] : 0.0;
     cx.sync();
@@ -581,6 +613,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       cx.sync();
     }
   }
+#endif
   // J = R~^-1 (upper triangular inverse), one column per lane.  R~ is a dense 16 x 16 triangle (the cost rows only
   // involve the accelerations) followed by a diagonal: columns >= 16 of the inverse are the reciprocal diagonal.
   for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Jm[idx] = 0.0;

@@ -6,7 +6,7 @@ WBC solution 1e-5 (regularised-minimiser rule) with EoM residual 1e-8
 import numpy as np
 import pytest
 
-from hunter_bipedal_control_amd import workload
+from hunter_bipedal_control_amd import abi, workload
 from oracle import refgen, workloads
 
 pytestmark = pytest.mark.gpu
@@ -209,6 +209,48 @@ def test_full_size_properties(params, oracle):
     assert status.max() == 0
     tl = np.tile(np.array(params["config"]["torque_limits"]), 2)
     assert (np.abs(sol[:, 28:]) <= tl + 1e-8).all()
+
+
+def test_headline_size_properties_4096_by_100(params):
+    """BASELINE.json configs[2] at its full size — 4096 distinct instances x N = 100, node tables generated on the device exactly
+    as bench.py does — through size-independent properties: every instance accepts its steps, shooting defects and equality
+    constraints close over six SQP iterations, the WBC is feasible within the torque limits, and a second context fed the same inputs reproduces the
+    iterate and the WBC solution bit for bit (no cross-instance coupling, no atomics, deterministic kernels)."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B, N = 4096, 100
+
+    def run():
+        s = HunterSolver(params, batch=B, max_nodes=N)
+        try:
+            w = workload.device_trot_batch(s, params, n_intervals=N)
+            s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+            perfs = []
+            for it in range(6):
+                s.step_resident()
+                perfs.append(s.get_performance())
+            sol, status = s.get_wbc_solution()
+            x, u = s.get_solution()
+            return perfs, sol, status, x, u, s.mpc_status(), s.get_references()["n_nodes"]
+        finally:
+            s.close()
+
+    perfs, sol, status, x, u, mpc_status, n_nodes = run()
+    perf = perfs[-1]
+    assert (n_nodes == N).all()
+    assert np.isfinite(x).all() and np.isfinite(u).all() and np.isfinite(sol).all()
+    # (an instance that has converged may have its last step refused by the filter line search: HB_INST_MAXITER, never NaN)
+    assert np.isin(mpc_status, (abi.HB_INST_OK, abi.HB_INST_MAXITER)).all() and (status == 0).all()
+    for it in range(5):   # (near convergence the filter line search may refuse a step: only the first five are required to move)
+        assert (perfs[it][:, 3] > 0).all(), f"SQP iteration {it}: the line search must accept a step for every instance"
+    # dt-weighted SSE of the shooting defects / equality constraints: 2.5e-3 / 3.9 after the first iteration of this workload
+    assert perf[:, 1].max() < 1e-6 and perf[:, 2].max() < 1e-3, perf[:, 1:3].max(axis=0)
+    assert perf[:, 1].max() < 1e-3 * perfs[0][:, 1].max() and perf[:, 2].max() < 1e-3 * perfs[0][:, 2].max()
+    tl = np.tile(np.array(params["config"]["torque_limits"]), 2)
+    assert (np.abs(sol[:, 28:]) <= tl + 1e-8).all()
+    # the instances are distinct (seed 1234 + id): no two iterates coincide
+    assert len({x[i, 50].tobytes() for i in range(0, B, 64)}) == B // 64
+    perfs2, sol2, status2, x2, u2, _, _ = run()
+    assert np.array_equal(x, x2) and np.array_equal(u, u2) and np.array_equal(sol, sol2) and np.array_equal(perf, perfs2[-1])
 
 
 def _oracle_cold(oracle, refs, x0, nmax):

@@ -216,6 +216,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=100, help="shooting intervals N")
     ap.add_argument("--chunks", type=int, default=1, help="instance ranges pipelined on separate HIP streams")
     ap.add_argument("--random-cmd", action="store_true", help="configs[3]: per-instance cmd_vel, gait from walkGait")
+    ap.add_argument("--hierarchical", action="store_true", help="configs[4]: HierarchicalWbc (3-priority HoQp cascade) instead of WeightedWbc")
     ap.add_argument("--gather", action="store_true", help="time an RCCL all-gather of status + trajectories (multi-GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the full-tick figure and the config-1 latency block")
@@ -246,7 +247,7 @@ def main():
     else:
         B, first = args.batch, rank * args.batch
         total_instances = args.batch * world
-    s = HunterSolver(params, batch=B, max_nodes=N, device=local_rank)
+    s = HunterSolver(params, batch=B, max_nodes=N, device=local_rank, wbc_type=1 if args.hierarchical else 0)
     t_setup = time.perf_counter()
     w = workload.device_trot_batch(s, params, n_intervals=N, first_inst=first, cmd_vel_random=args.random_cmd)
     s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
@@ -361,8 +362,9 @@ def main():
                                    + ("per-instance cmd_vel (seed 4321 + id), gait per instance from walkGait"
                                       if args.random_cmd else "trot gait from t = 0.1, cmd_vel (0.3, 0, 0, 0)")
                                    + f", N={N} shooting intervals (dt 0.015 s), node tables generated on the device "
-                                     "(hb_refgen_update, per-knot IK joint references), 1 SQP iteration + WeightedWbc per update, "
-                                     "inputs resident in HBM (BASELINE.json configs[" + ("3" if args.random_cmd or strong else "2") + "])",
+                                     "(hb_refgen_update, per-knot IK joint references), 1 SQP iteration + "
+                                     + ("HierarchicalWbc" if args.hierarchical else "WeightedWbc") + " per update, "
+                                     "inputs resident in HBM (BASELINE.json configs[" + ("4" if args.hierarchical else "3" if args.random_cmd or strong else "2") + "])",
                        "batch_per_gpu": B, "total_instances": total_instances, "horizon_nodes": N, "setup_s": t_setup,
                        "parallelism": (f"strong scaling: {total_instances} instances split over {world} rank(s)" if strong else
                                        f"weak scaling: {B} instances per rank x {world}") +

@@ -31,4 +31,16 @@ if full and "updates_per_s" in rows[0]:
     pred = {"predicted_8gpu_strong_scaling_updates_per_s": 8 * rows[0]["updates_per_s"],
             "predicted_efficiency_vs_8x_weak": rows[0]["updates_per_s"] / full,
             "note": "configs[3]: 4096 instances split 512/GPU; each GPU then runs at its B = 512 rate (instances are independent, no collective)"}
-print(json.dumps({"sweep": rows, "prediction": pred}, indent=1))
+# one GPU's share of BASELINE configs[4]: 8192 instances x N = 200 over 8 GPUs = 1024 per GPU, HierarchicalWbc
+c4 = None
+r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--batch", "1024", "--nodes", "200", "--hierarchical", "--steps", "60", "--warmup", "5",
+                    "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True)
+line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+if r.returncode == 0 and line:
+    j = json.loads(line[-1])
+    c4 = {"batch_per_gpu": 1024, "horizon_nodes": 200, "wbc": "HierarchicalWbc", "updates_per_s_one_gpu": j["value"], "ms_per_step": j["ms_per_step"],
+          "phase_ms": j["phase_ms"], "predicted_8gpu_updates_per_s": 8 * j["value"],
+          "note": "configs[4] (batch 8192, N = 200, 3-priority stack) sharded 1024 per GPU, no collective"}
+else:
+    c4 = {"error": (r.stderr or r.stdout)[-400:]}
+print(json.dumps({"sweep": rows, "prediction": pred, "configs4_one_gpu_share": c4}, indent=1))

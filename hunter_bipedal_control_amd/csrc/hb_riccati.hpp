@@ -60,9 +60,8 @@ HB_HD void ric_phase1(const Ctx& cx, double* lds) {
 // record are R~ = I, B~ = 0, P~ = 0, r~ = 0, so their gains are exactly zero and the factor work drops by ~(9/12)^3.
 // Cholesky factor of the leading NB x NB block of Huu, redundantly per lane in registers; lane 0 writes it back over the
 // (dead) lower triangle of Huu with the RECIPROCALS of the diagonal.  Returns true when a pivot was not positive.
-template <int NB, class Ctx>
-HB_HD bool ric_chol_block(const Ctx& cx, double* Hu) {
-  double L[NB * (NB + 1) / 2];
+template <int NB, bool KEEP = false, class Ctx>
+HB_HD bool ric_chol_block(const Ctx& cx, double* Hu, double (&L)[NB * (NB + 1) / 2]) {
 #pragma unroll
   for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -87,6 +86,7 @@ HB_HD bool ric_chol_block(const Ctx& cx, double* Hu) {
   // The factor (lane-uniform) goes back to LDS over the lower triangle of Huu, which is dead from here on: the solves
   // then read it through broadcast loads and the registers are free again (explicit "spill" to LDS; a register
   // file that still held L here pushed the kernel's loop invariants into scratch memory).
+  if (KEEP) return bad;  // the caller keeps the factor in registers (device, NB <= 9: no LDS round trip before the solves)
   if (cx.lane == 0) {
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -103,15 +103,22 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
   // keep the loads of this width's triangle inside its branch: hoisted above the 9 / 12 dispatch they were spilled
   asm volatile("" ::: "memory");
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr bool reg_factor = NT <= 9;
+#else
+  constexpr bool reg_factor = false;
+#endif
+  constexpr int NB1 = NT <= 9 ? NT : 9;
+  double Lr[NB1 * (NB1 + 1) / 2];
   if constexpr (NT <= 9) {
-    const bool bad = ric_chol_block<NT>(cx, Hu);
+    const bool bad = ric_chol_block<NT, reg_factor>(cx, Hu, Lr);
     if (bad && cx.lane == 0) lds[RicLds::flag] = 1.0;
   } else {
     // 12 projected inputs (double support: 12 contact forces): blocked — the 9 x 9 leading block in registers as above, then
     // rows 9..11 one per lane against the factor in LDS, then the 3 x 3 Schur complement.  A 78-element register triangle
     // (156 VGPRs) next to the record prefetch was what put 100 B/lane of this kernel into scratch memory.
     static_assert(NT == 12, "blocked factorisation: 9 + 3");
-    bool bad = ric_chol_block<9>(cx, Hu);
+    bool bad = ric_chol_block<9>(cx, Hu, Lr);
     cx.sync();
     const double* Lm = Hu + RicLds::CU;   // L(i, j) = Lm[i * LDW + j]
     for (int r = 9 + cx.lane; r < 12; r += cx.nlanes) {   // L21 row r: forward substitution with L11 (diagonal = reciprocals)
@@ -165,17 +172,21 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
     }
     if (bad && cx.lane == 0) lds[RicLds::flag] = 1.0;
   }
-  cx.sync();
+  if (!reg_factor) cx.sync();
   {
     const double* Lm = Hu + RicLds::CU;  // L(i, j) = Lm[i * LDW + j], j <= i; diagonal holds the reciprocals
+    auto Lf = [&Lr, Lm](int i, int j) {
+      if constexpr (reg_factor) return Lr[i * (i + 1) / 2 + j];
+      else return Lm[i * RicLds::LDW + j];
+    };
     for (int c = cx.lane; c < 23; c += cx.nlanes) {  // columns 0..21 = Hux, 22 = hu
       double y[NU_T];
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
         double sacc = -Hu[a * RicLds::LDW + c];
 #pragma unroll
-        for (int k = 0; k < a; ++k) sacc -= Lm[a * RicLds::LDW + k] * y[k];
-        y[a] = sacc * Lm[a * RicLds::LDW + a];
+        for (int k = 0; k < a; ++k) sacc -= Lf(a, k) * y[k];
+        y[a] = sacc * Lf(a, a);
 #if defined(__HIP_DEVICE_COMPILE__)
         // 12-wide: keep the factor loads row by row — hoisted all at once (132 of them) they took the register file
         if (NT > 9) asm volatile("" ::: "memory");
@@ -185,8 +196,8 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
       for (int a = NT - 1; a >= 0; --a) {
         double sacc = y[a];
 #pragma unroll
-        for (int k = a + 1; k < NT; ++k) sacc -= Lm[k * RicLds::LDW + a] * y[k];
-        y[a] = sacc * Lm[a * RicLds::LDW + a];
+        for (int k = a + 1; k < NT; ++k) sacc -= Lf(k, a) * y[k];
+        y[a] = sacc * Lf(a, a);
 #if defined(__HIP_DEVICE_COMPILE__)
         if (NT > 9) asm volatile("" ::: "memory");
 #endif

@@ -8,7 +8,7 @@ from hunter_bipedal_control_amd import ingest, workload
 from hunter_bipedal_control_amd.solver import HunterSolver
 P = ingest.load_packaged()
 B, N = 4096, 100
-for wt, stop in ((0, 0), (0, 11), (0, 12), (1, 41), (1, 43), (1, 44), (1, 42), (1, 0)):
+for wt, stop in ((0, 0), (0, 13), (0, 14), (0, 15), (0, 11), (0, 12), (1, 41), (1, 43), (1, 44), (1, 42), (1, 0)):
     s = HunterSolver(P, batch=B, max_nodes=N, wbc_type=wt, reserved=stop)
     w = workload.device_trot_batch(s, P, n_intervals=N)
     s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])

@@ -452,7 +452,8 @@ struct HoLds {
   static constexpr int qpw = zs + 12;             // small QP workspace 2*144 + 72 + 26 + 40
   static constexpr int work = qpw + 440;          // 80 (householder)
   static constexpr int ints = work + 80;          // 64 ints: violated flags (40), misc
-  static constexpr int total = ints + 32;
+  static constexpr int xprev = ints + 32;         // 38: previous level-0 point (damped passes)
+  static constexpr int total = xprev + NW;
 };
 struct HoLdsDev {
   // persistent
@@ -469,7 +470,8 @@ struct HoLdsDev {
   static constexpr int v0 = np + NW;              // 40 slack of level 0
   static constexpr int work = v0 + 40;            // 80 (reflector scalars, householder)
   static constexpr int ints = work + 80;          // 64 ints
-  static constexpr int shared = ints + 32;
+  static constexpr int xprev = ints + 32;         // 38: previous level-0 point (damped passes)
+  static constexpr int shared = xprev + NW;
   // level 0 (and phase A's workspace)
   static constexpr int J = shared;                // 38x38
   static constexpr int R = J + NW * NW;           // 38x38
@@ -574,7 +576,37 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   // ------------------------------------------------------------------ level 0
   int status = 0;
   const double se = sqrt(C.wbc_eps);
-  for (int it = 0; it < 12; ++it) {
+  // phi(p) = 1/2 |A0 p - b0|^2 + 1/2 |(D p - f)_+|^2 + eps/2 |p|^2 : the convex piecewise quadratic that level 0 minimises.
+  // One term per lane (28 task rows, <= 40 inequality rows: 64 lanes hold at most 68 -> two trips), summed through `work`.
+  auto phi = [&](const double* pnt) -> double {
+    double part = 0.0;
+    for (int rw = cx.lane; rw < mA0 + wc.n_in; rw += cx.nlanes) {
+      double sres;
+      if (rw < mA0) {
+        sres = -a0_rhs(rw);
+        for (int i = 0; i < NW; ++i) sres += a0_row(rw, i) * pnt[i];
+      } else {
+        int idx[3];
+        double cfv[3], rh;
+        const int nn = sparse_row(wc, C, wc.n_eq + rw - mA0, idx, cfv, &rh);
+        sres = -rh;
+        for (int t = 0; t < nn; ++t) sres += cfv[t] * pnt[idx[t]];
+        sres = sres > 0.0 ? sres : 0.0;
+      }
+      part += 0.5 * sres * sres;
+    }
+    for (int i = cx.lane; i < NW; i += cx.nlanes) part += 0.5 * C.wbc_eps * pnt[i] * pnt[i];
+    work[cx.lane] = part;
+    cx.sync();
+    double tot = 0.0;
+    for (int l = 0; l < cx.nlanes; ++l) tot += work[l];
+    cx.sync();
+    return tot;
+  };
+  double* xprev = lds + L::xprev;
+  constexpr int kMaxPass = 30, kDampFrom = 6;
+  for (int it = 0; it < kMaxPass; ++it) {
+    bool full_step = true;
     if (it == 0) {
       // First pass (no violated inequality rows yet — in normal operation the only pass): the triangular factor of
       // [sqrt(eps) I ; A0] by 38 structured Householder reflectors instead of 28 x 38 Givens rotations.  Reflector k has
@@ -680,6 +712,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
       }
 #endif
     } else {
+    for (int i = cx.lane; i < NW; i += cx.nlanes) xprev[i] = x[i];
     for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Rm[idx] = (idx / NW == idx % NW) ? se : 0.0;
     for (int i = cx.lane; i < NW; i += cx.nlanes) g[i] = 0.0;
     cx.sync();
@@ -731,6 +764,19 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
       x[i] = s;
     }
     cx.sync();
+    // x is the minimiser of the quadratic piece of the previous point's violated set: a descent direction of phi from
+    // xprev, but the full step may overshoot into other pieces and the pass can cycle (seen with joint rates of several
+    // rad/s).  Plain passes settle within a handful in every case met so far; from pass kDampFrom on the step backtracks
+    // on phi (convex, C1), which makes the sequence converge.
+    if (it >= kDampFrom) {
+      const double phi_prev = phi(xprev);
+      for (int bt = 0; bt < 10; ++bt) {
+        if (phi(x) <= phi_prev) break;
+        full_step = false;  // (the point is then not the minimiser of its piece: another pass follows whatever the set does)
+        for (int i = cx.lane; i < NW; i += cx.nlanes) x[i] = xprev[i] + 0.5 * (x[i] - xprev[i]);
+        cx.sync();
+      }
+    }
     }
     // violated set of the new point
     if (cx.lane == 0) imisc[0] = 0;
@@ -747,8 +793,8 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
       if (nv != viol[c]) { viol[c] = nv; imisc[0] = 1; }
     }
     cx.sync();
-    if (!imisc[0]) break;
-    if (it == 11) status = HB_INST_MAXITER;
+    if (!imisc[0] && full_step) break;
+    if (it == kMaxPass - 1) status = HB_INST_MAXITER;
   }
   if (max_level <= 1) {
     for (int i = cx.lane; i < NW; i += cx.nlanes) sol[i] = x[i];

@@ -118,6 +118,19 @@ def test_device_hierarchical_wbc_matches_oracle(params, oracle, emu):
         assert np.abs(se - so[0]).max() < 1e-6 * max(1.0, np.abs(so[0]).max())
 
 
+def test_device_hierarchical_wbc_violated_level0_rows(params, oracle, emu):
+    """Fast joint motion: the level-0 pass iterates over violated torque-limit / friction rows (and cycles without damping)."""
+    from test_gpu_parity import _fast_moving_wbc_inputs
+    lib, mdl, cfg = emu
+    xd, ud, rbd, mode = _fast_moving_wbc_inputs(params, 12, seed=5)
+    for i in (4, 6, 7, 8, 11):
+        so, st = oracle.hwbc_update(xd[i], ud[i], rbd[i], int(mode[i]))
+        se, ste = np.zeros(38), C.c_int()
+        lib.emu_hwbc(C.byref(mdl), C.byref(cfg), _p(xd[i]), _p(ud[i]), _p(rbd[i]), C.c_int(int(mode[i])), _p(se), C.byref(ste), C.c_int(3))
+        assert ste.value == st[0] == 0
+        assert np.abs(se - so[0]).max() < 1e-6 * max(1.0, np.abs(so[0]).max())
+
+
 def test_device_estimator_matches_oracle(params, oracle, emu):
     """hb_estimator.hpp (structured filter algebra, Cholesky instead of LU, forward momentum map) vs oracle/estimator.hpp."""
     from hunter_bipedal_control_amd import abi as _abi

@@ -874,14 +874,15 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
         if (i < q) r[i] = d[i];
       }
       cx.sync();
-      // the dual step direction r = R^-1 d1 only matters for active INEQUALITIES (their multipliers must stay >= 0);
-      // while only equalities are active (the whole first phase) it is skipped
+      // the dual step direction r = R^-1 d1 only matters for active INEQUALITIES (their multipliers must stay >= 0).  The
+      // equalities hold positions 0 .. next_eq_active - 1 of the active set for good and R is upper triangular, so the back
+      // substitution stops there: q - n_eq steps (0 .. 3 typically) instead of q (22 +), two ordering points each
       const bool need_r = q > next_eq_active;
       if (need_r)
-        for (int i = q - 1; i >= 0; --i) {
+        for (int i = q - 1; i >= next_eq_active; --i) {
           const double ri = r[i] / Rm[i * NW + i];
           cx.sync();
-          for (int k = cx.lane; k < i; k += cx.nlanes) r[k] -= Rm[k * NW + i] * ri;
+          for (int k = next_eq_active + cx.lane; k < i; k += cx.nlanes) r[k] -= Rm[k * NW + i] * ri;
           if (cx.lane == 0) r[i] = ri;
           cx.sync();
         }
@@ -899,8 +900,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       const double dir = 1.0;
       double t1 = inf;
       int l = -1;
-      for (int j = 0; j < q && need_r; ++j) {
-        if (act[j] < wc.n_eq) continue;
+      for (int j = next_eq_active; j < q && need_r; ++j) {
         const double rj = dir * r[j];
         if (rj > 0.0) {
           const double tj = lam[j] / rj;
@@ -913,12 +913,12 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       cx.sync();
       if (t2 >= inf) {
         if (need_r)
-          for (int j = cx.lane; j < q; j += cx.nlanes) lam[j] -= t * dir * r[j];
+          for (int j = next_eq_active + cx.lane; j < q; j += cx.nlanes) lam[j] -= t * dir * r[j];
         lam_p += t;
       } else {
         for (int k = cx.lane; k < NW; k += cx.nlanes) x[k] -= dir * t * z[k];
         if (need_r)
-          for (int j = cx.lane; j < q; j += cx.nlanes) lam[j] -= t * dir * r[j];
+          for (int j = next_eq_active + cx.lane; j < q; j += cx.nlanes) lam[j] -= t * dir * r[j];
         lam_p += t;
       }
       cx.sync();

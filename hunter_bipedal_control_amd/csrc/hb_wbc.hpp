@@ -819,20 +819,14 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       cx.sync();
 #endif
     }
-    // dense normal of p (an inequality: the equalities are all in) into np, rhs in prhs
+    // normal of p — an inequality (the equalities are all in): at most two non-zeros, kept as (index, coefficient) pairs;
+    // every product with it (n'x, J'n, z'n, n'n) is one or two terms instead of a 38-term sum or a wave reduction
     double prhs;
-    {
-      int idx[3];
-      double cfv[3];
-      const int nn = sparse_row(wc, C, p, idx, cfv, &prhs);
-      for (int i = cx.lane; i < NW; i += cx.nlanes) {
-        double vv = 0.0;
-        for (int t = 0; t < nn; ++t)
-          if (idx[t] == i) vv = cfv[t];
-        np[i] = vv;
-      }
-    }
-    cx.sync();
+    int pidx[3] = {0, 0, 0};
+    double pcf[3] = {0.0, 0.0, 0.0};
+    const int pnn = sparse_row(wc, C, p, pidx, pcf, &prhs);
+    const int pi0 = pidx[0], pi1 = pnn > 1 ? pidx[1] : pidx[0];
+    const double pc0 = pcf[0], pc1 = pnn > 1 ? pcf[1] : 0.0;
     double lam_p = 0.0;
     bool done_p = false;
     while (!done_p) {
@@ -840,22 +834,9 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       // sp = n'x - rhs ; d = J' n
       // (four interleaved partial sums per dot product: a single f64 FMA chain leaves most issue slots empty on a wave
       // that has its SIMD to itself)
-      for (int k = cx.lane; k < NW; k += cx.nlanes) {
-        double sa[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int i = 0; i < NW; ++i) sa[i & 3] += Jm[i * NW + k] * np[i];
-        d[k] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
-      }
+      for (int k = cx.lane; k < NW; k += cx.nlanes) d[k] = pc0 * Jm[pi0 * NW + k] + pc1 * Jm[pi1 * NW + k];
       cx.sync();
-#if defined(__HIP_DEVICE_COMPILE__)
-      sp = wave_sum_f64(cx.lane < NW ? np[cx.lane] * x[cx.lane] : 0.0) - prhs;  // one product per lane, DPP sum
-#else
-      {
-        double s = -prhs;
-        for (int i = 0; i < NW; ++i) s += np[i] * x[i];
-        sp = s;
-      }
-#endif
+      sp = pc0 * x[pi0] + pc1 * x[pi1] - prhs;
       // z = J2 d2 ; r = R^-1 d1 (column-oriented back substitution on a copy)
       // (fixed trip count with a uniform mask instead of a loop from q: the compiler unrolls it and batches the LDS
       // reads; the rolled loop paid one LDS round trip per term on a wave that has its SIMD to itself)
@@ -886,16 +867,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
           if (cx.lane == 0) r[i] = ri;
           cx.sync();
         }
-      double zn = 0.0, nn2 = 0.0;
-#if defined(__HIP_DEVICE_COMPILE__)
-      {
-        const double npi = cx.lane < NW ? np[cx.lane] : 0.0, zi = cx.lane < NW ? z[cx.lane] : 0.0;
-        zn = wave_sum_f64(zi * npi);
-        nn2 = wave_sum_f64(npi * npi);
-      }
-#else
-      for (int i = 0; i < NW; ++i) { zn += z[i] * np[i]; nn2 += np[i] * np[i]; }
-#endif
+      const double zn = pc0 * z[pi0] + pc1 * z[pi1], nn2 = pc0 * pc0 + pc1 * pc1;
       const double t2 = (zn > 1e-14 * (1.0 + nn2)) ? sp * rcp_t(zn) : inf;
       const double dir = 1.0;
       double t1 = inf;

@@ -709,3 +709,36 @@ def test_headline_workload_parity_64_distinct_instances_n100(params, oracle):
     so, sto, _ = oracle.wbc_update(xd, ud, w["rbd"], md, stance_flag=np.zeros(B, dtype=np.int32), threads=8)
     assert np.array_equal(status, sto)
     assert np.abs(sol[:, :28] - so[:, :28]).max() < 1e-5 * max(1.0, np.abs(so[:, :28]).max()) and np.abs(sol[:, 28:] - so[:, 28:]).max() < 1e-4
+
+
+def test_randomised_command_workload_parity_two_iterations(params, oracle):
+    """BASELINE configs[3]'s workload shape — per-instance cmd_vel (seed 4321 + id), gait per instance from walkGait —
+    with the node tables generated on the device; TWO SQP iterations (the second starts from the first's
+    iterate) against the oracle on the same tables."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B, N = 32, 60
+    s = HunterSolver(params, batch=B, max_nodes=N)
+    try:
+        w = workload.device_trot_batch(s, params, n_intervals=N, cmd_vel_random=True)
+        refs = s.get_references()
+        s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+        perfs = []
+        for it in range(2):
+            s.mpc_solve(w["x0"])
+            perfs.append(s.get_performance())
+        x, u = s.get_solution()
+        st = s.mpc_status()
+    finally:
+        s.close()
+    assert st.max() == 0
+    assert len({tuple(np.round(r, 9)) for r in refs["x_ref"][:, N // 2]}) == B, "every instance follows its own command"
+    xo, uo = np.zeros_like(x), np.zeros_like(u)
+    for i in range(B):
+        n = int(refs["n_nodes"][i])
+        xo[i, :n + 1], uo[i, :n] = oracle.cold_start(refs["mode"][i, :n], w["x0"][i])
+    for it in range(2):
+        po = oracle.mpc_solve(refs, w["x0"], xo, uo, iters=1, threads=8)
+        assert np.array_equal(perfs[it][:, 3], po[:, 3]), it               # identical accepted step sizes
+        assert np.allclose(perfs[it][:, :3], po[:, :3], rtol=1e-6, atol=1e-9)
+    assert np.abs(x - xo).max() < 1e-6 and np.abs(u - uo).max() < 1e-5
+

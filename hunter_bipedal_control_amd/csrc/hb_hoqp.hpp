@@ -99,10 +99,48 @@ HB_HD int small_lsqp(const Ctx& cx, int n, int mA, const double* A, const double
   double* viol = g + 12 + 26;                 // 40: violation of the inactive constraints (host reduction only)
   // R~ by Givens row insertion into sqrt(eps) I (stored in R), then J = R~^-1
   const double se = sqrt(eps);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Device: n structured Householder reflectors on lane-owned columns (registers, wave-uniform broadcasts) instead of mA x n
+  // Givens rotations with two ordering points each — see the level-0 factorisation in hwbc_solve.
+  {
+    constexpr int MA = 24;  // level 1: 6 rows, level 2: 12 + 3 n_sw <= 24
+    const int j = cx.lane;
+    double acol[MA];
+    double gj = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < MA; ++rr) {
+      acol[rr] = (j < n && rr < mA) ? A[rr * LD + j] : 0.0;
+      gj += acol[rr] * (rr < mA ? b[rr] : 0.0);
+    }
+    if (j < n) g[j] = gj;
+#pragma unroll 1
+    for (int k = 0; k < n; ++k) {
+      double dot = 0.0;
+      double ck[MA];
+#pragma unroll
+      for (int rr = 0; rr < MA; ++rr) {
+        ck[rr] = wave_bcast_f64(acol[rr], k);
+        dot += ck[rr] * acol[rr];
+      }
+      const double sig2 = se * se + wave_bcast_f64(dot, k);
+      const double alpha = -sqrt(sig2);
+      const double v0 = se - alpha;
+      const double beta = 2.0 * rcp_t(sig2 - se * se + v0 * v0);
+      const double w = beta * (dot + (j == k ? v0 * se : 0.0));
+      const bool live = j > k && j < n;
+#pragma unroll
+      for (int rr = 0; rr < MA; ++rr) acol[rr] = live ? acol[rr] - w * ck[rr] : (j == k ? 0.0 : acol[rr]);
+      if (j < LD) R[k * LD + j] = (j < k || j >= n) ? 0.0 : (j == k ? alpha : -w * v0);
+    }
+    cx.sync();
+  }
+  for (int rw = 0; rw < 0; ++rw) {
+#else
   for (int idx = cx.lane; idx < n * LD; idx += cx.nlanes) R[idx] = (idx / LD == idx % LD) ? se : 0.0;
   for (int i = cx.lane; i < n; i += cx.nlanes) g[i] = 0.0;
   cx.sync();
   for (int rw = 0; rw < mA; ++rw) {
+#endif
     for (int j = cx.lane; j < n; j += cx.nlanes) {
       np[j] = A[rw * LD + j];
       g[j] += A[rw * LD + j] * b[rw];

@@ -117,6 +117,42 @@ void orc_rbd_qv(void* h, const double* q, const double* v, double* M, double* nl
   std::memcpy(dJv, r.dJv.data(), 12 * sizeof(double));
 }
 
+// Everything WbcBase::updateMeasured (legged_wbc/src/WbcBase.cpp:68-120) takes out of pinocchio, as full matrices, for the
+// generator of the reference-compiled WBC golden vectors (tests/golden/make_ref_wbc.py feeds them to oracle/_ref/libref_wbc.so):
+// M 16x16, nle 16, J / dJ 12x16 (contact frames, linear rows), Jb / dJb 6x16 (base_link, [linear; angular]), contact
+// positions / velocities 4x3.  The time variations are the dual parts along q + eps v.
+void orc_rbd_full(void* h, const double* q, const double* v, double* M, double* nle, double* J, double* dJ, double* Jb, double* dJb,
+                  double* ee_pos, double* ee_vel) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  RbdQuantities rq;
+  rbd_measured(pb.mdl, q, v, rq);
+  copy_mat(rq.M, M);
+  std::memcpy(nle, rq.nle.data(), 8 * HB_NV);
+  copy_mat(rq.J, J);
+  Kin<double> k;
+  k.compute(pb.mdl, q);
+  D1 qd[HB_NV];
+  for (int i = 0; i < HB_NV; ++i) { qd[i] = D1(q[i]); qd[i].d[0] = v[i]; }
+  Kin<D1> kd;
+  kd.compute(pb.mdl, qd);
+  for (int i = 0; i < HB_NC; ++i) {
+    const V3<D1> pd = kd.contact_point(pb.mdl, i);
+    for (int j = 0; j < HB_NV; ++j) {
+      const V3<D1> col = kd.lin_jac(pb.mdl.contact_body[i], pd, j);
+      for (int r = 0; r < 3; ++r) dJ[(3 * i + r) * HB_NV + j] = col[r].d[0];
+    }
+    for (int r = 0; r < 3; ++r) { ee_pos[3 * i + r] = rq.foot_pos[i][r]; ee_vel[3 * i + r] = rq.foot_vel[i][r]; }
+  }
+  for (int j = 0; j < HB_NV; ++j) {
+    const V3<double> l = k.lin_jac(0, k.p[0], j), a = k.ang_jac(0, j);
+    const V3<D1> ld = kd.lin_jac(0, kd.p[0], j), ad = kd.ang_jac(0, j);
+    for (int r = 0; r < 3; ++r) {
+      Jb[r * HB_NV + j] = l[r]; Jb[(3 + r) * HB_NV + j] = a[r];
+      dJb[r * HB_NV + j] = ld[r].d[0]; dJb[(3 + r) * HB_NV + j] = ad[r].d[0];
+    }
+  }
+}
+
 void orc_desired_kinematics(void* h, const double* x, const double* u, double* base_pose, double* base_vel,
                             double* base_acc, double* foot_pos, double* foot_vel) {
   const Problem& pb = *static_cast<Problem*>(h);

@@ -92,6 +92,15 @@ class Oracle:
         self.lib.orc_rbd_qv(self.h, _opt(q), _opt(v), _opt(M), _opt(nle), _opt(J), _opt(dJv))
         return M, nle, J, dJv
 
+    def rbd_full(self, q, v):
+        """Everything WbcBase::updateMeasured takes out of pinocchio (full matrices; oracle_capi.cpp orc_rbd_full)."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        o = dict(M=np.zeros((16, 16)), nle=np.zeros(16), J=np.zeros((12, 16)), dJ=np.zeros((12, 16)), Jb=np.zeros((6, 16)),
+                 dJb=np.zeros((6, 16)), ee_pos=np.zeros((4, 3)), ee_vel=np.zeros((4, 3)))
+        self.lib.orc_rbd_full(self.h, _opt(q), _opt(v), *[_opt(o[k]) for k in ("M", "nle", "J", "dJ", "Jb", "dJb", "ee_pos", "ee_vel")])
+        return o
+
     def desired_kinematics(self, x, u):
         x = np.ascontiguousarray(x, dtype=np.float64)
         u = np.ascontiguousarray(u, dtype=np.float64)

@@ -1,0 +1,233 @@
+"""The whole-body controller held to the REFERENCE's own compiled code.
+
+tests/golden/ref_wbc.npz was written by tests/golden/make_ref_wbc.py from oracle/_ref/libref_wbc.so = the reference's
+legged_wbc/src/{WbcBase, WeightedWbc, HierarchicalWbc, HoQp}.cpp + include/legged_wbc/Task.h compiled in place (rigid-body
+quantities fed from the oracle, QP engine = the oracle's solver behind a qpOASES::QProblem stand-in).  What
+these vectors pin is everything the reference's own files compute: the rows of the ten task builders (WbcBase.cpp:138-338),
+their gains read from the reference's task.info, stacking / weighting (Task.h, WeightedWbc.cpp:68-81), the order of the three
+HierarchicalWbc levels (HierarchicalWbc.cpp:23-27) and the HoQp cascade (HoQp.cpp:21-198: slack formulation, frozen higher-
+priority inequalities, null-space projection through FullPivLU::kernel()).
+
+CPU tests hold the ORACLE to the vectors; the -m gpu tests hold the DEVICE (through the C-ABI) to the same vectors.
+
+Tolerances.  Task rows: 1e-12 (same arithmetic on the same inputs).  WeightedWbc solution: 1e-6 relative, torques 1e-6 N m.
+HierarchicalWbc / HoQp solutions: the cascade regularises each level in the coordinates of its null-space basis (the
+reference: LU kernel basis, not orthonormal; oracle / device: orthonormal bases), so where a level is ill-conditioned — single
+support asks for six base accelerations through a line contact and gets the sixth from swing-leg reaction, with joint
+accelerations of 1e2..1e4 rad/s^2 — the minimisers differ at the level of the regularisation: they are compared at 1e-3
+relative to |x|_inf, torques at 2e-3 N m, and through basis-independent quantities: every level's residual VECTOR at
+1e-4 relative.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+GOLD = Path(__file__).parent / "golden" / "ref_wbc.npz"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _task(g, i, name):
+    return tuple(g[f"wbc_{i}_out_{name}_{k}"] for k in "AbDf")
+
+
+def _levels(g, i):
+    """The three HierarchicalWbc levels from the reference-built tasks (HierarchicalWbc.cpp:23-27)."""
+    eom, tl, fc, nc = (_task(g, i, n) for n in ("eom", "torque_limits", "friction_cone", "no_contact_motion"))
+    ba, cf, sw = (_task(g, i, n) for n in ("base_accel", "contact_force", "swing_leg"))
+    l0 = dict(A=np.vstack([eom[0], fc[0], nc[0]]), b=np.concatenate([eom[1], fc[1], nc[1]]), D=np.vstack([tl[2], fc[2]]), f=np.concatenate([tl[3], fc[3]]))
+    l1 = dict(A=ba[0], b=ba[1], D=np.zeros((0, 38)), f=np.zeros(0))
+    l2 = dict(A=np.vstack([0.1 * cf[0], sw[0]]), b=np.concatenate([0.1 * cf[1], sw[1]]), D=np.zeros((0, 38)), f=np.zeros(0))
+    return [l0, l1, l2]
+
+
+def _inputs(g):
+    return g["wbc_x_des"], g["wbc_u_des"], g["wbc_rbd"], g["wbc_mode"]
+
+
+def test_reference_task_settings_are_the_packaged_ones(gold, params):
+    """loadTasksSetting read the reference's task.info; the packaged parameters must carry the same numbers: the torque-limit
+    rows, friction pyramid, and a stance weighted task = weight.baseAccel * [I6 0] are visible in the reference-built tasks."""
+    c = params["config"]
+    f = gold["wbc_0_out_torque_limits_f"]
+    assert np.array_equal(f, np.tile(np.array(c["torque_limits"]), 4))
+    D = gold["wbc_0_out_friction_cone_D"]
+    assert D[1, 16 + 2] == -c["wbc_friction_mu"] and D[0, 16 + 2] == -1.0
+    A = gold["wbc_0_out_weighted_tasks_stance_A"]
+    assert A.shape == (6, 38) and np.array_equal(A[:, :6], c["weight_base_accel"] * np.eye(6)) and not A[:, 6:].any()
+
+
+def test_oracle_task_rows_match_reference_built_tasks(gold, oracle):
+    xd, ud, rbd, mode = _inputs(gold)
+    worst = 0.0
+    for i in range(int(gold["wbc_n"])):
+        pr = oracle.wbc_problem(xd[i], ud[i], rbd[i], int(mode[i]), False)
+        A, b, D, f = _task(gold, i, "weighted_constraints")
+        Aw, bw, _, _ = _task(gold, i, "weighted_tasks")
+        for mine, ref in ((pr["Aeq"], A), (pr["beq"], b), (pr["D"], D), (pr["f"], f), (pr["Aw"], Aw), (pr["bw"], bw)):
+            assert mine.shape == ref.shape
+            worst = max(worst, np.abs(mine - ref).max() / max(1.0, np.abs(ref).max()))
+        prs = oracle.wbc_problem(xd[i], ud[i], rbd[i], int(mode[i]), True)
+        Aws, bws, _, _ = _task(gold, i, "weighted_tasks_stance")
+        assert np.array_equal(prs["Aw"], Aws) and np.array_equal(prs["bw"], bws)
+        lv = _levels(gold, i)
+        for l in range(3):
+            t = oracle.hwbc_tasks(xd[i], ud[i], rbd[i], int(mode[i]), l)
+            for k in "AbDf":
+                assert t[k].shape == lv[l][k].shape, (i, l, k)
+                if t[k].size:
+                    worst = max(worst, np.abs(t[k] - lv[l][k]).max() / max(1.0, np.abs(lv[l][k]).max()))
+    assert worst < 1e-12, worst
+
+
+def test_reference_row_counts(gold):
+    """WBC problem sizes of SURVEY.md 8c (6): constraints 16 + 3 n_swing equalities, 20 + 5 n_c + 3 n_swing inequalities."""
+    mode = gold["wbc_mode"]
+    for i in range(int(gold["wbc_n"])):
+        nc = {0: 0, 1: 2, 2: 2, 3: 4}[int(mode[i])]
+        A, _, D, _ = _task(gold, i, "weighted_constraints")
+        assert A.shape[0] == 16 + 3 * (4 - nc) and D.shape[0] == 20 + 5 * nc + 3 * (4 - nc)
+        assert _task(gold, i, "no_contact_motion")[0].shape[0] == 3 * nc
+        assert _task(gold, i, "swing_leg")[0].shape[0] == 3 * (4 - nc)
+
+
+def _check_weighted(sol, gold, i, tag="weighted_sol"):
+    ref = gold[f"wbc_{i}_out_{tag}"]
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(sol - ref).max() / scale < 1e-6, (i, np.abs(sol - ref).max())
+    assert np.abs(sol[28:] - ref[28:]).max() < 1e-6
+
+
+def _check_hier(sol, gold, i):
+    ref = gold[f"wbc_{i}_out_hier_sol"]
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(sol - ref).max() / scale < 1e-3, (i, np.abs(sol - ref).max(), scale)
+    assert np.abs(sol[28:] - ref[28:]).max() < 2e-3
+    for l, lv in enumerate(_levels(gold, i)):
+        r_mine, r_ref = lv["A"] @ sol - lv["b"], lv["A"] @ ref - lv["b"]
+        assert np.abs(r_mine - r_ref).max() < 1e-4 * max(1.0, np.abs(lv["b"]).max(), np.abs(r_ref).max()), (i, l)
+        if lv["D"].shape[0]:
+            assert (lv["D"] @ sol - lv["f"]).max() < 1e-6
+
+
+def test_oracle_weighted_wbc_matches_reference_update(gold, oracle):
+    xd, ud, rbd, mode = _inputs(gold)
+    for i in range(int(gold["wbc_n"])):
+        so, st, _ = oracle.wbc_update(xd[i], ud[i], rbd[i], mode[i:i + 1])
+        assert st[0] == 0
+        _check_weighted(so[0], gold, i)
+        if mode[i] == 3:
+            so, st, _ = oracle.wbc_update(xd[i], ud[i], rbd[i], mode[i:i + 1], stance_flag=np.ones(1, dtype=np.int32))
+            assert st[0] == 0
+            _check_weighted(so[0], gold, i, "weighted_sol_stance")
+
+
+def test_oracle_hierarchical_wbc_matches_reference_update(gold, oracle):
+    xd, ud, rbd, mode = _inputs(gold)
+    for i in range(int(gold["wbc_n"])):
+        so, st = oracle.hwbc_update(xd[i], ud[i], rbd[i], mode[i:i + 1])
+        assert st[0] == 0
+        _check_hier(so[0], gold, i)
+
+
+def _hoqp_case(g, c):
+    mA, mD = g[f"hoqp_{c}_mA"], g[f"hoqp_{c}_mD"]
+    A, b, D, f = (g[f"hoqp_{c}_{k}"] for k in "AbDf")
+    n = A.shape[1]
+    tasks, oa, od = [], 0, 0
+    for l in range(len(mA)):
+        tasks.append(dict(A=A[oa:oa + mA[l]], b=b[oa:oa + mA[l]], D=D[od:od + mD[l]].reshape(-1, n), f=f[od:od + mD[l]]))
+        oa += mA[l]
+        od += mD[l]
+    return tasks, g[f"hoqp_{c}_out_x"]
+
+
+def _check_hoqp(x, tasks, xref):
+    """Level residual vectors agree (basis independent); the solution itself where the stacked task matrix has full column rank."""
+    for l, t in enumerate(tasks):
+        r_mine, r_ref = t["A"] @ x - t["b"], t["A"] @ xref - t["b"]
+        assert np.abs(r_mine - r_ref).max() < 2e-5 * max(1.0, np.abs(t["b"]).max()), l
+    stacked = np.vstack([t["A"] for t in tasks])
+    sv = np.linalg.svd(stacked, compute_uv=False)
+    if len(sv) >= stacked.shape[1] and sv[-1] > 1e-2 * sv[0]:
+        assert np.abs(x - xref).max() < 2e-5 * max(1.0, np.abs(xref).max())
+
+
+def test_oracle_hoqp_matches_reference_hoqp(gold, oracle):
+    checked = 0
+    for c in range(int(gold["hoqp_n"])):
+        tasks, xref = _hoqp_case(gold, c)
+        x, _, st = oracle.hoqp(tasks)
+        if st != 0:
+            continue  # infeasible stacks of hard higher-priority inequalities (random draws): nothing to compare
+        _check_hoqp(x, tasks, xref)
+        checked += 1
+    assert checked >= 20
+
+
+def test_reference_kernel_basis_annihilates_the_stacked_tasks(gold):
+    """HoQp::buildZMatrix (FullPivLU::kernel through the stand-in): A_l Z = 0 for every level of the stack."""
+    for c in range(int(gold["hoqp_n"])):
+        tasks, _ = _hoqp_case(gold, c)
+        Z = gold[f"hoqp_{c}_out_Z"]
+        if not np.abs(Z).max() > 0:
+            continue  # full-rank stack: Eigen's kernel() returns one zero column
+        for t in tasks:
+            assert np.abs(t["A"] @ Z).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------------- device
+@pytest.mark.gpu
+def test_device_weighted_wbc_matches_reference_update(gold, params):
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    xd, ud, rbd, mode = _inputs(gold)
+    n = int(gold["wbc_n"])
+    s = HunterSolver(params, batch=n, max_nodes=4)
+    try:
+        sol, status = s.wbc_update_direct(xd, ud, rbd, mode, np.zeros(n, dtype=np.int32))
+        sol_st, status_st = s.wbc_update_direct(xd, ud, rbd, mode, (mode == 3).astype(np.int32))
+    finally:
+        s.close()
+    assert status.max() == 0 and status_st.max() == 0
+    for i in range(n):
+        _check_weighted(sol[i], gold, i)
+        if mode[i] == 3:
+            _check_weighted(sol_st[i], gold, i, "weighted_sol_stance")
+
+
+@pytest.mark.gpu
+def test_device_hierarchical_wbc_matches_reference_update(gold, params):
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    xd, ud, rbd, mode = _inputs(gold)
+    n = int(gold["wbc_n"])
+    s = HunterSolver(params, batch=n, max_nodes=4, wbc_type=1)
+    try:
+        sol, status = s.wbc_update_direct(xd, ud, rbd, mode)
+    finally:
+        s.close()
+    assert status.max() == 0
+    for i in range(n):
+        _check_hier(sol[i], gold, i)
+
+
+@pytest.mark.gpu
+def test_device_hoqp_matches_reference_hoqp(gold, params, oracle):
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    s = HunterSolver(params, batch=1, max_nodes=4)
+    checked = 0
+    try:
+        for c in range(int(gold["hoqp_n"])):
+            tasks, xref = _hoqp_case(gold, c)
+            if oracle.hoqp(tasks)[2] != 0:
+                continue
+            x, _, status = s.hoqp_solve([tasks])
+            assert status[0] == 0, c
+            _check_hoqp(x[0, len(tasks) - 1], tasks, xref)
+            checked += 1
+    finally:
+        s.close()
+    assert checked >= 20

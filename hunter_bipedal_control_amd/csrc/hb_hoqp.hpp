@@ -371,7 +371,13 @@ HB_HD int hoqp_generic(const Ctx& cx, int n, int n_levels, const int* mA, const 
     const int ma = mA[k], nv = mD[k], nvar = nz + nv;
     int n_rows = 2 * nv;
     for (int j = 0; j < k; ++j) n_rows += mD[j];
-    if (nvar > 12 || n_rows > 40 || nvar == 0) { status = 3; break; }
+    if (nvar > 12 || n_rows > 40) { status = 3; break; }
+    if (nvar == 0) {
+      // the earlier levels used up every direction and this level brings no slack: nothing can move.  The reference gets here
+      // through FullPivLU::kernel() of a full-rank stack, a single zero column (HoQp.cpp:155-158): x stays x of the level above
+      for (int i = cx.lane; i < n; i += cx.nlanes) x_levels[k * HQ_N + i] = x[i];
+      continue;
+    }
     // least-squares rows: [A_k Z | 0], then [0 | I]
     for (int idx = cx.lane; idx < (ma + nv) * 12; idx += cx.nlanes) {
       const int i = idx / 12, j = idx % 12;

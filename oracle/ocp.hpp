@@ -137,6 +137,20 @@ struct FootKin {
   V3<T> pos[HB_NC], vel[HB_NC];
 };
 
+// Friction cone of one contact (FrictionConeConstraint.cpp:164-233, surface normal = world z, t_R_w = I):
+//   h = mu (Fz + gripper) - sqrt(Fx^2 + Fy^2 + regularization),  its gradient and Hessian with respect to (Fx, Fy, Fz).
+// (pinned to the reference's compiled file: tests/test_ref_constraints.py)
+struct ConeTerms { double h, g[3], H[3][3]; };
+inline ConeTerms friction_cone_terms(const hb_config& c, double Fx, double Fy, double Fz) {
+  const double t2 = Fx * Fx + Fy * Fy + c.friction_reg, tn = std::sqrt(t2), t32 = tn * t2;
+  ConeTerms o{};
+  o.h = c.friction_mu * (Fz + c.friction_gripper) - tn;
+  o.g[0] = -Fx / tn; o.g[1] = -Fy / tn; o.g[2] = c.friction_mu;
+  o.H[0][0] = -(Fy * Fy + c.friction_reg) / t32; o.H[0][1] = Fx * Fy / t32;
+  o.H[1][0] = Fx * Fy / t32; o.H[1][1] = -(Fx * Fx + c.friction_reg) / t32;
+  return o;
+}
+
 inline void stage_terms(const Problem& pb, const NodeRef& ref, const double* x, const double* u, NodeValue& val,
                         NodeLQ* lq) {
   const hb_config& c = pb.cfg;
@@ -178,11 +192,10 @@ inline void stage_terms(const Problem& pb, const NodeRef& ref, const double* x, 
   const RelaxedBarrier fb{c.friction_barrier_mu, c.friction_barrier_delta};
   for (int i = 0; i < HB_NC; ++i) {
     if (!cf[i]) continue;
-    const double Fx = u[3 * i], Fy = u[3 * i + 1], Fz = u[3 * i + 2];
-    const double t2 = Fx * Fx + Fy * Fy + c.friction_reg, tn = std::sqrt(t2), t32 = tn * t2;
-    const double h = c.friction_mu * (Fz + c.friction_gripper) - tn;
-    const double g[3] = {-Fx / tn, -Fy / tn, c.friction_mu};
-    double H[3][3] = {{-(Fy * Fy + c.friction_reg) / t32, Fx * Fy / t32, 0}, {Fx * Fy / t32, -(Fx * Fx + c.friction_reg) / t32, 0}, {0, 0, 0}};
+    const ConeTerms ct = friction_cone_terms(c, u[3 * i], u[3 * i + 1], u[3 * i + 2]);
+    const double h = ct.h;
+    const double* g = ct.g;
+    const auto& H = ct.H;
     const double p1 = fb.d1(h), p2 = fb.d2(h);
     cost += fb.value(h);
     for (int a = 0; a < 3; ++a) {

@@ -56,6 +56,18 @@ double orc_relaxed_barrier(double mu, double delta, double hval, int order) {
   return order == 0 ? b.value(hval) : (order == 1 ? b.d1(hval) : b.d2(hval));
 }
 
+// Friction cone of one contact: out = [h, g(3), H(9), hessianDiagonalShift]  (ocp.hpp friction_cone_terms)
+void orc_friction_cone(void* h, const double* F, double* out) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  const ConeTerms ct = friction_cone_terms(pb.cfg, F[0], F[1], F[2]);
+  out[0] = ct.h;
+  for (int a = 0; a < 3; ++a) {
+    out[1 + a] = ct.g[a];
+    for (int b = 0; b < 3; ++b) out[4 + 3 * a + b] = ct.H[a][b];
+  }
+  out[13] = pb.cfg.friction_hess_shift;
+}
+
 void orc_flow_map(void* h, int n, const double* x, const double* u, double* f, double* dfdx, double* dfdu) {
   const Problem& pb = *static_cast<Problem*>(h);
   for (int i = 0; i < n; ++i) {

@@ -54,6 +54,13 @@ class Oracle:
     def relaxed_barrier(self, mu, delta, h, order=0):
         return self.lib.orc_relaxed_barrier(mu, delta, h, order)
 
+    def friction_cone(self, F):
+        """h, grad (3), Hessian (3x3) of the friction cone at contact force F, and the configured hessianDiagonalShift."""
+        F = np.ascontiguousarray(F, dtype=np.float64)
+        out = np.zeros(14)
+        self.lib.orc_friction_cone(self.h, _opt(F), _opt(out))
+        return out[0], out[1:4].copy(), out[4:13].reshape(3, 3).copy(), out[13]
+
     def flow_map(self, x, u, jac=False):
         x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
         u = np.ascontiguousarray(np.atleast_2d(u), dtype=np.float64)

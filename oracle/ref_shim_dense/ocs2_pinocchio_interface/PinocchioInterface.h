@@ -15,6 +15,7 @@ class PinocchioInterface {
   PinocchioInterface(PinocchioInterface&& o) noexcept : model_(o.model_), data_(o.data_) {}
   PinocchioInterface& operator=(const PinocchioInterface&) = delete;
   const pinocchio::Model& getModel() const { return *model_; }
+  pinocchio::Model& mutableModel() { return *model_; }
   pinocchio::Data& getData() { return *data_; }
   const pinocchio::Data& getData() const { return *data_; }
   void setRole(int r) { data_->role = r; }

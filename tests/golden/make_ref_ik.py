@@ -1,0 +1,70 @@
+"""Generates tests/golden/ref_ik.json from the REFERENCE's own inverse kinematics.
+
+Run in the build container only (needs /root/reference):  make -C oracle ref && python tests/golden/make_ref_ik.py
+oracle/_ref/libref_ik.so is legged_interface/src/foot_planner/InverseKinematics.cpp of the reference compiled in place
+(oracle/Makefile, oracle/ref_ik_capi.cpp; the pinocchio kinematics it calls are evaluated with the oracle's forward kinematics).
+Cases: seeded joint states around the default stance, foot targets from millimetres to decimetres away (every stopping rule of
+the iteration is hit: small error at start, stagnation, error increase, tolerance reached, iteration limit), targets beyond the
+joint limits, base orientations up to 0.3 rad, desired foot rotations = base rotation (what calculateJointRef asks for) and
+perturbed ones.  Every "out" was computed by reference code.
+"""
+import ctypes as C
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from hunter_bipedal_control_amd import abi, ingest  # noqa: E402
+from oracle import refgen  # noqa: E402
+
+lib = C.CDLL(str(ROOT / "oracle/_ref/libref_ik.so"))
+DP = C.POINTER(C.c_double)
+_d = lambda a: a.ctypes.data_as(DP)
+lib.refik_create.restype = C.c_void_p
+lib.refik_create.argtypes = [C.c_void_p]
+lib.refik_destroy.argtypes = [C.c_void_p]
+lib.refik_compute.argtypes = [C.c_void_p, C.c_int, DP, C.c_int, DP, DP, DP]
+lib.refik_foot_pos.argtypes = [C.c_void_p, DP, DP]
+
+
+def main():
+    params = ingest.load_packaged()
+    mdl = abi.make_model(params)
+    h = C.c_void_p(lib.refik_create(C.byref(mdl)))
+    rng = np.random.default_rng(31)
+    qj0 = np.array(params["config"]["default_joint_state"])
+    x0 = np.array(params["config"]["initial_state"])
+    cases = []
+    scales = [0.002, 0.008, 0.02, 0.05, 0.1, 0.25]
+    for k in range(72):
+        q = np.zeros(16)
+        q[0:3] = [0.3 * rng.standard_normal(), 0.3 * rng.standard_normal(), 0.63 + 0.02 * rng.standard_normal()]
+        q[3:6] = [rng.uniform(-3, 3), 0.1 * rng.standard_normal(), 0.1 * rng.standard_normal()] if k % 3 else [0.0, 0.0, 0.0]
+        q[6:] = qj0 + (0.15 if k % 2 else 0.03) * rng.standard_normal(10)
+        leg = k % 2
+        state = np.concatenate([np.zeros(6), q])
+        feet = np.zeros(12)
+        lib.refik_foot_pos(h, _d(state), _d(feet))
+        des = feet[3 * leg:3 * leg + 3] + scales[k % 6] * rng.standard_normal(3)
+        if k % 12 == 11:
+            des[2] -= 0.4   # out of reach: the knee hits its limit
+        R_base = refgen.zyx_to_rotation(q[3:6])
+        R_des = R_base if k % 4 else R_base @ refgen.zyx_to_rotation(0.2 * rng.standard_normal(3))
+        R_des = np.ascontiguousarray(R_des)
+        o = {}
+        for which, name in ((0, "translation"), (1, "rotation"), (2, "ik")):
+            out = np.zeros(5)
+            lib.refik_compute(h, which, _d(q), leg, _d(np.ascontiguousarray(des)), _d(R_des), _d(out))
+            o[name] = out.tolist()
+        cases.append(dict(q=q.tolist(), leg=leg, des_pos=des.tolist(), R_des=R_des.tolist(), feet=feet.tolist(), out=o))
+    lib.refik_destroy(h)
+    dst = ROOT / "tests/golden/ref_ik.json"
+    dst.write_text(json.dumps(dict(cases=cases), indent=0))
+    print(f"wrote {dst} ({dst.stat().st_size / 1024:.0f} KiB, {len(cases)} cases)")
+
+
+if __name__ == "__main__":
+    main()

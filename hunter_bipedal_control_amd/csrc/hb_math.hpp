@@ -164,6 +164,37 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __device__ __forceinline__ double wave_bcast_f64(double v, int src) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
+// Scans over groups of eight lanes whose lanes 5..7 hold zeros (group = one leg evaluation, lane k < 5 = joint k).  Row shifts
+// stay inside a DPP row of 16 = two groups; the bank mask (banks = lanes 0-3, 4-7, 8-11, 12-15 of the row) keeps a shift from
+// writing lanes it must not: a suffix sum never needs to update lanes 4..7 of a group (lane 4 would only add the zeros above
+// it), a prefix sum's last step (distance 4) only updates lane 4.  Disabled / out-of-row lanes add 0.
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_shift_f64(double v) {
+  const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, BANK, false);
+  const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, BANK, false);
+  return __hiloint2double(hi_, lo_);
+}
+// the same shift with the value disabled / out-of-row lanes see given explicitly (the neutral element of a product scan is 1)
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_shift_f64_old(double v, double neutral) {
+  const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(neutral), __double2loint(v), CTRL, 0xf, BANK, false);
+  const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(neutral), __double2hiint(v), CTRL, 0xf, BANK, false);
+  return __hiloint2double(hi_, lo_);
+}
+// lane k of a group <- sum over lanes k .. 4 of the group
+__device__ __forceinline__ double seg8_suffix_sum(double v) {
+  v += dpp_shift_f64<0x101, 0x5>(v);  // row_shl:1
+  v += dpp_shift_f64<0x102, 0x5>(v);  // row_shl:2
+  v += dpp_shift_f64<0x104, 0x5>(v);  // row_shl:4
+  return v;
+}
+// lane k of a group <- sum over lanes 0 .. k of the group (lanes 5..7 end up with garbage: nobody reads them)
+__device__ __forceinline__ double seg8_prefix_sum(double v) {
+  v += dpp_shift_f64<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_shift_f64<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_shift_f64<0x114, 0xa>(v);  // row_shr:4, lanes 4..7 of each group only
+  return v;
+}
 // Sum over each aligned group of four lanes (all four must be active), returned to all of them: two quad_perm adds.
 __device__ __forceinline__ double quad_sum_f64(double v) {
 #define HB_DPP_QADD(ctrl)                                                                    \
@@ -325,5 +356,17 @@ template <class T> HB_HD Mat3<T> axis_rot_sc(const double* ax, T s, T c) {
   r.m[6] -= ax[1] * s; r.m[7] += ax[0] * s;
   return r;
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// One step of an inclusive prefix PRODUCT of 3x3 matrices over groups of eight lanes (see seg8_prefix_sum): P <- S P with S the
+// matrix of the lane CTRL shifts in, the identity for lanes the shift leaves alone.
+template <int CTRL, int BANK>
+__device__ __forceinline__ void seg8_prefix_mat3(Mat3<double>& P) {
+  Mat3<double> S;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) S.m[e] = dpp_shift_f64_old<CTRL, BANK>(P.m[e], (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0);
+  P = S * P;
+}
+#endif
 
 }  // namespace hb

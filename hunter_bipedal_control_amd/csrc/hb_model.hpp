@@ -261,12 +261,104 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
     c.m = M.mass[b];
   };
 #if defined(__HIP_DEVICE_COMPILE__)
-  JC jc_lane;
+  // Device: the whole pass is register resident, one (group, joint) pair per lane, group g on lanes 8 g .. 8 g + 4 (at most four
+  // groups).  A group never straddles a DPP row of 16 and its lanes 5..7 carry neutral elements, so everything that runs along
+  // the five joints is a scan by row shifts (hb_math.hpp): the frames before each joint are a prefix PRODUCT of the joint
+  // rotations (three steps instead of a five-step chain through LDS with an ordering point per joint), the joint origins a
+  // prefix sum, the composites / momenta / contact-point velocities suffix sums.  LDS is touched twice: the two contact points
+  // (lane 4 of a group -> its other lanes) and the final store of the joint blocks.
+  static_assert(Ctx::nlanes == 64, "leg_value_pass_coop: one wavefront");
   {
-    const int r = cx.lane < ntask ? cx.lane : 0;
-    load_jc(5 * leg_of(r / 5) + (r - 5 * (r / 5)), jc_lane);
+    const int dg = cx.lane >> 3, dk = cx.lane & 7;
+    const bool dvalid = dk < 5 && dg < ngroups;
+    const int g = dvalid ? dg : 0, k = dvalid ? dk : 0;
+    const double on = dvalid ? 1.0 : 0.0;   // padding lanes contribute zeros to the sums
+    JC jc;
+    load_jc(5 * leg_of(g) + k, jc);
+    double* blk = blk_all + lay.blk(g);
+    double* B = blk + k * LEGJ_STRIDE;
+    // A: local joint rotations (extra angles ride on lanes 32 ..)
+    const bool ex = cx.lane >= 32 && cx.lane - 32 < n_extra;
+    double sv = 0.0, cv = 1.0;
+    if (dvalid || ex) sincos_t(ex ? extra(cx.lane - 32) : qj(g, 5 * leg_of(g) + k), sv, cv);
+    if (ex) {
+      extra_sc[lay.xsc(cx.lane - 32)] = sv;
+      extra_sc[lay.xsc(cx.lane - 32) + 1] = cv;
+    }
+    Mat3<double> E = axis_rot_sc<double>(jc.ax, sv, cv);
+    if (!dvalid) E = Mat3<double>::identity();
+    // frames: inclusive prefix product P_k = E_0 ... E_k, then R_k^- = P_{k-1} (identity in front of the first joint)
+    Mat3<double> P = E;
+    seg8_prefix_mat3<0x111, 0xf>(P);   // row_shr:1
+    seg8_prefix_mat3<0x112, 0xf>(P);   // row_shr:2
+    seg8_prefix_mat3<0x114, 0xa>(P);   // row_shr:4: only lane 4 of a group has a partner
+    Mat3<double> Rm;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      const double sh = dpp_shift_f64_old<0x111, 0xf>(P.m[e], (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0);
+      Rm.m[e] = (dk == 0) ? ((e == 0 || e == 4 || e == 8) ? 1.0 : 0.0) : sh;
+    }
+    // joint origins: o_k = sum_{m <= k} R_m^- origin_m
+    const Vec3<double> ot = on * (Rm * Vec3<double>(jc.org[0], jc.org[1], jc.org[2]));
+    const Vec3<double> o(seg8_prefix_sum(ot.x), seg8_prefix_sum(ot.y), seg8_prefix_sum(ot.z));
+    // contact points behind the last joint (frame P_4): lane 4 of the group publishes them
+    if (dvalid && dk == 4) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int ci = leg_of(g) + 2 * f;
+        st3(blk + LEGJ_FEET + 3 * f, o + P * Vec3<double>(M.contact_offset[ci][0], M.contact_offset[ci][1], M.contact_offset[ci][2]));
+      }
+    }
+    cx.sync();
+    const Vec3<double> p0 = ld3(blk + LEGJ_FEET), p1 = ld3(blk + LEGJ_FEET + 3);
+    // B: axis and the body behind the joint
+    const double qd = on * qdj(g, 5 * leg_of(g) + k);
+    const Vec3<double> a = Rm * Vec3<double>(jc.ax[0], jc.ax[1], jc.ax[2]);
+    const double mb = on * jc.m;
+    const Vec3<double> c = o + P * Vec3<double>(jc.com[0], jc.com[1], jc.com[2]);
+    // C + D: suffix sums (joints k .. 4) of mass, first moment, inertia about the base origin; prefix sums of the joint-rate twist
+    const double ms = seg8_suffix_sum(mb);
+    const Vec3<double> mck = mb * c;
+    const Vec3<double> mc(seg8_suffix_sum(mck.x), seg8_suffix_sum(mck.y), seg8_suffix_sum(mck.z));
+    const Sym3<double> IOk = rotate_inertia<double>(P, jc.in) + point_inertia<double>(mb, c);
+    Sym3<double> IO;
+    IO.xx = seg8_suffix_sum(on * IOk.xx); IO.xy = seg8_suffix_sum(on * IOk.xy); IO.xz = seg8_suffix_sum(on * IOk.xz);
+    IO.yy = seg8_suffix_sum(on * IOk.yy); IO.yz = seg8_suffix_sum(on * IOk.yz); IO.zz = seg8_suffix_sum(on * IOk.zz);
+    const Vec3<double> tw = qd * a, tww = qd * cross(a, o);
+    const Vec3<double> om(seg8_prefix_sum(tw.x) - tw.x, seg8_prefix_sum(tw.y) - tw.y, seg8_prefix_sum(tw.z) - tw.z);
+    const Vec3<double> w(seg8_prefix_sum(tww.x) - tww.x, seg8_prefix_sum(tww.y) - tww.y, seg8_prefix_sum(tww.z) - tww.z);
+    const Vec3<double> l = cross(a, mc - ms * o);
+    const Vec3<double> L = IO * a - cross(mc, cross(a, o));
+    // E: suffix sums of the joint-rate momenta and of the joint-induced contact-point velocities
+    const Vec3<double> ql = qd * l, qL = qd * L, q0 = qd * cross(a, p0 - o), q1 = qd * cross(a, p1 - o);
+    const Vec3<double> lin(seg8_suffix_sum(ql.x), seg8_suffix_sum(ql.y), seg8_suffix_sum(ql.z));
+    const Vec3<double> ang(seg8_suffix_sum(qL.x), seg8_suffix_sum(qL.y), seg8_suffix_sum(qL.z));
+    const Vec3<double> v0(seg8_suffix_sum(q0.x), seg8_suffix_sum(q0.y), seg8_suffix_sum(q0.z));
+    const Vec3<double> v1(seg8_suffix_sum(q1.x), seg8_suffix_sum(q1.y), seg8_suffix_sum(q1.z));
+    if (dvalid) {
+      st3(B + LEGJ_A, a);
+      st3(B + LEGJ_O, o);
+      st3(B + LEGJ_OMP, om);
+      st3(B + LEGJ_WP, w);
+      st3(B + LEGJ_l, l);
+      st3(B + LEGJ_L, L);
+      st3(B + LEGJ_MC, mc);
+      st6(B + LEGJ_IO, IO);
+      B[LEGJ_MS] = ms;
+      st3(B + LEGJ_LIN, lin);
+      st3(B + LEGJ_ANG, ang);
+      st3(B + LEGJ_VJ, v0);
+      st3(B + LEGJ_VJ + 3, v1);
+      if (dk == 0) {
+        double* val = val_all + lay.val(g);
+        st3(val + 0, mc); st6(val + 3, IO); st3(val + 9, lin); st3(val + 12, ang);
+        st3(val + 15, p0); st3(val + 18, p1); st3(val + 21, v0); st3(val + 24, v1);
+      }
+    }
+    cx.sync();
+    return;
   }
-#endif
+#else
   // A: local joint rotations
   for (int r = cx.lane; r < ntask + n_extra; r += cx.nlanes) {
     const bool ex = r >= ntask;
@@ -277,12 +369,8 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
       extra_sc[lay.xsc(r - ntask)] = sv;
       extra_sc[lay.xsc(r - ntask) + 1] = cv;
     } else {
-#if defined(__HIP_DEVICE_COMPILE__)
-      const JC& jc = jc_lane;
-#else
       JC jc;
       load_jc(j, jc);
-#endif
       const Mat3<double> E = axis_rot_sc<double>(jc.ax, sv, cv);
       double* B = blk_all + lay.blk(g) + k * LEGJ_STRIDE;
       for (int e = 0; e < 9; ++e) B[21 + e] = E.m[e];
@@ -290,6 +378,7 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
     }
   }
   cx.sync();
+#endif
   // chain: frames before each joint and joint origins; contact points behind the last joint
   // nine lanes per group: lane (g, e) owns entry e = 3 row + col of the frame.  Step k reads only what step k-1 wrote
   // (R_k^-, E_k, o_{k-1}) and writes R_{k+1}^- (the frame behind the last joint goes to slots 30..38 of the last block,
@@ -324,12 +413,8 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
   // B: per joint, axis and the body behind it (first moment, inertia about the base origin)
   for (int r = cx.lane; r < ntask; r += cx.nlanes) {
     const int g = r / 5, k = r - 5 * g;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const JC& jc = jc_lane;
-#else
     JC jc;
     load_jc(5 * leg_of(g) + k, jc);
-#endif
     double* B = blk_all + lay.blk(g) + k * LEGJ_STRIDE;
     Mat3<double> Rm, E;
     for (int e = 0; e < 9; ++e) { Rm.m[e] = B[6 + e]; E.m[e] = B[21 + e]; }
@@ -404,6 +489,7 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
     }
   }
   cx.sync();
+
 }
 
 // 27 tangents of the leg outputs with respect to joint angle s (rate == false) or joint rate s (rate == true).

@@ -640,19 +640,33 @@ __global__ __launch_bounds__(64) void k_refgen(Batch b, RefgenBatch r, const Dev
                             b.t + size_t(i) * (N + 1), r.n_knots + i, r.knot_t + size_t(i) * RG_MAX_KNOTS,
                             r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX);
 }
-// joint-reference IK: one thread per (instance, leg)
-constexpr int RG_IK_BLOCK = 32;  // threads per block: one LDS work area each (60 KB per block)
-__global__ __launch_bounds__(RG_IK_BLOCK) void k_refgen_ik(Batch b, RefgenBatch r, const DevModel* __restrict__ M, hb_refgen_config K,
-                                                             double horizon) {
-  static_assert(sizeof(RgIkWork) % 8 == 0, "work area is a whole number of doubles");
-  __shared__ double work_raw[RG_IK_BLOCK * (sizeof(RgIkWork) / 8)];
-  RgIkWork* work = reinterpret_cast<RgIkWork*>(work_raw);
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = gid >> 1, leg = gid & 1;
-  if (i >= b.B) return;
-  refgen_ik_leg(*M, K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.t0[i], horizon, b.x0 + size_t(i) * HB_NX,
-                r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, r.n_knots[i], r.knot_t + size_t(i) * RG_MAX_KNOTS,
-                r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX, leg, work[threadIdx.x]);
+// joint-reference IK: eight lanes per (instance, leg), eight pairs per wavefront (hb_refgen.hpp refgen_ik_group)
+__global__ __launch_bounds__(64) void k_refgen_ik(Batch b, RefgenBatch r, const DevModel* __restrict__ M, hb_refgen_config K, double horizon) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the routine is built from cross-lane instructions: device pass only)
+  const int gid = blockIdx.x * 8 + (threadIdx.x >> 3);
+  const bool valid = gid < 2 * b.B;
+  const int i = valid ? gid >> 1 : 0, leg = gid & 1;
+  refgen_ik_group(*M, K, valid, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.t0[i], horizon, b.x0 + size_t(i) * HB_NX,
+                  r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, r.n_knots[i], r.knot_t + size_t(i) * RG_MAX_KNOTS,
+                  r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX, leg);
+#endif
+}
+// test hook (hb_ik_solve): n independent InverseKinematics::computeIK problems, eight lanes each
+__global__ __launch_bounds__(64) void k_ik_solve(int n, const DevModel* __restrict__ M, const double* __restrict__ q16, const int* __restrict__ leg,
+                                                 const double* __restrict__ des, const double* __restrict__ Rdes, double* __restrict__ out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int gid = blockIdx.x * 8 + (threadIdx.x >> 3);
+  const int p = gid < n ? gid : 0;
+  IkLane L;
+  ik_lane_setup(*M, leg[p], L);
+  const double* q = q16 + size_t(p) * HB_NV;
+  const Mat3<double> R0 = rg_rot_zyx(q + 3);
+  Mat3<double> Rd;
+  for (int e = 0; e < 9; ++e) Rd.m[e] = Rdes[size_t(p) * 9 + e];
+  double qk = q[6 + 5 * leg[p] + (L.joint ? L.k : 0)];
+  ik_solve(L, R0, Vec3<double>(q[0], q[1], q[2]), Vec3<double>(des[3 * p], des[3 * p + 1], des[3 * p + 2]), Rd, qk);
+  if (gid < n && L.joint) out[size_t(p) * 5 + L.k] = qk;
+#endif
 }
 // node tables: one thread per (instance, node), consecutive lanes = consecutive nodes of one instance
 __global__ __launch_bounds__(64) void k_refgen_nodes(Batch b, RefgenBatch r, hb_refgen_config K) {
@@ -1138,8 +1152,7 @@ int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const do
   if (x_now) HB_HIP(hipMemcpyAsync(ctx->b.x0, x_now, B * HB_NX * 8, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_refgen, dim3((ctx->B + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
   if (ctx->rg_cfg.joint_ik)
-    hipLaunchKernelGGL(k_refgen_ik, dim3((2 * ctx->B + RG_IK_BLOCK - 1) / RG_IK_BLOCK), dim3(RG_IK_BLOCK), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg,
-                       horizon);
+    hipLaunchKernelGGL(k_refgen_ik, dim3((2 * ctx->B + 7) / 8), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
   hipLaunchKernelGGL(k_refgen_nodes, dim3((ctx->B * ctx->Nmax + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->rg_cfg);
   HB_HIP(hipGetLastError());
   r.init_stance = 0;
@@ -1903,6 +1916,28 @@ int32_t hb_eval_rbd(hb_ctx* ctx, int32_t n, const double* rbd, double* Mo, doubl
   if (J) HB_HIP(hipMemcpy(J, dJ, size_t(n) * 192 * 8, hipMemcpyDeviceToHost));
   if (dJv) HB_HIP(hipMemcpy(dJv, dd, size_t(n) * 12 * 8, hipMemcpyDeviceToHost));
   (void)hipFree(dr); (void)hipFree(dM); (void)hipFree(dn); (void)hipFree(dJ); (void)hipFree(dd);
+  return HB_OK;
+}
+
+int32_t hb_ik_solve(hb_ctx* ctx, int32_t n, const double* q16, const int32_t* leg, const double* des_pos, const double* R_des, double* out5) {
+  if (!ctx || n <= 0 || !q16 || !leg || !des_pos || !R_des || !out5) return HB_ERR_ARG;
+  HB_HIP(hipSetDevice(ctx->device));
+  double *dq = nullptr, *dd = nullptr, *dR = nullptr, *dout = nullptr;
+  int* dl = nullptr;
+  HB_HIP(hipMalloc(&dq, size_t(n) * HB_NV * 8));
+  HB_HIP(hipMalloc(&dd, size_t(n) * 3 * 8));
+  HB_HIP(hipMalloc(&dR, size_t(n) * 9 * 8));
+  HB_HIP(hipMalloc(&dout, size_t(n) * 5 * 8));
+  HB_HIP(hipMalloc(&dl, size_t(n) * sizeof(int)));
+  HB_HIP(hipMemcpy(dq, q16, size_t(n) * HB_NV * 8, hipMemcpyHostToDevice));
+  HB_HIP(hipMemcpy(dd, des_pos, size_t(n) * 3 * 8, hipMemcpyHostToDevice));
+  HB_HIP(hipMemcpy(dR, R_des, size_t(n) * 9 * 8, hipMemcpyHostToDevice));
+  HB_HIP(hipMemcpy(dl, leg, size_t(n) * sizeof(int), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_ik_solve, dim3((n + 7) / 8), dim3(64), 0, ctx->s_mpc, n, ctx->dmodel, dq, dl, dd, dR, dout);
+  HB_HIP(hipGetLastError());
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
+  HB_HIP(hipMemcpy(out5, dout, size_t(n) * 5 * 8, hipMemcpyDeviceToHost));
+  hipFree(dq); hipFree(dd); hipFree(dR); hipFree(dout); hipFree(dl);
   return HB_OK;
 }
 

@@ -358,6 +358,23 @@ template <class T> HB_HD Mat3<T> axis_rot_sc(const double* ax, T s, T c) {
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// All-reduce over each aligned group of eight lanes: two quad permutes and the half-row mirror (lane i <-> 7 - i).
+__device__ __forceinline__ double seg8_allsum(double v) {
+  v += dpp_shift_f64<0xB1, 0xf>(v);   // quad_perm:[1,0,3,2]
+  v += dpp_shift_f64<0x4E, 0xf>(v);   // quad_perm:[2,3,0,1]
+  v += dpp_shift_f64<0x141, 0xf>(v);  // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ double seg8_allmax(double v) {
+  v = fmax(v, dpp_shift_f64<0xB1, 0xf>(v));
+  v = fmax(v, dpp_shift_f64<0x4E, 0xf>(v));
+  v = fmax(v, dpp_shift_f64<0x141, 0xf>(v));
+  return v;
+}
+// value of lane `k` (0..7, may differ per group) of the caller's group of eight
+__device__ __forceinline__ double seg8_get(double v, int k) { return __shfl(v, (int(threadIdx.x) & 56) | k, 64); }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
 // One step of an inclusive prefix PRODUCT of 3x3 matrices over groups of eight lanes (see seg8_prefix_sum): P <- S P with S the
 // matrix of the lane CTRL shifts in, the identity for lanes the shift leaves alone.
 template <int CTRL, int BANK>

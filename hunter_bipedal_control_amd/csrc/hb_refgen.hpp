@@ -317,6 +317,295 @@ HB_HD void rg_compute_ik(const DevModel& M, double* q16, int leg, const Vec3<dou
   }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ------------------------------------------------------------------------------------------------------------------------------
+// Lane-cooperative form of rg_compute_ik (device): eight lanes per (instance, leg), lane k < 5 = joint k of the leg, so one
+// wavefront works on eight inverse-kinematics problems at once and nothing is indexed dynamically (the thread-per-leg form kept
+// its 5 x 5 work arrays in LDS and walked them serially: 1.2 ms per 4096-batch on 128 half-empty wavefronts).  Same algorithm,
+// same pivot / rank / stopping rules as rg_compute_ik; sums over the five joints are all-reduces inside the group of eight
+// (hb_math.hpp seg8_*), the frames along the chain a prefix product of the joint rotations.  Every lane of the wavefront must
+// call these functions together (cross-lane operations); decisions that differ between groups are predicates, not branches.
+struct IkLane {
+  double ax[3], org[3];   // axis and origin of this lane's joint (parent frame)
+  double lo, hi;          // joint limits
+  double off[3];          // contact point f1 of the leg in the last link's frame
+  bool joint;             // lane k < 5
+  int k;                  // lane index inside the group
+};
+struct IkKin {
+  Vec3<double> foot;      // contact point, world (uniform in the group)
+  Mat3<double> Rf;        // foot rotation (uniform in the group)
+  Vec3<double> jl, ja;    // this joint's column of the linear (world-aligned) / angular (LOCAL) Jacobian
+};
+__device__ __forceinline__ void ik_kin(const IkLane& L, const Mat3<double>& R0, const Vec3<double>& p0, double q, IkKin& o) {
+  double sv = 0.0, cv = 1.0;
+  if (L.joint) sincos_t(q, sv, cv);
+  Mat3<double> E = axis_rot_sc<double>(L.ax, sv, cv);
+  if (!L.joint) E = Mat3<double>::identity();
+  Mat3<double> P = E;
+  seg8_prefix_mat3<0x111, 0xf>(P);
+  seg8_prefix_mat3<0x112, 0xf>(P);
+  seg8_prefix_mat3<0x114, 0xa>(P);
+  Mat3<double> Pex;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const double idv = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
+    const double sh = dpp_shift_f64_old<0x111, 0xf>(P.m[e], idv);
+    Pex.m[e] = (L.k == 0) ? idv : sh;
+  }
+  const Mat3<double> Rm = R0 * Pex;           // frame in front of this joint
+  const double on = L.joint ? 1.0 : 0.0;
+  const Vec3<double> ot = on * (Rm * Vec3<double>(L.org[0], L.org[1], L.org[2]));
+  const Vec3<double> org(p0.x + seg8_prefix_sum(ot.x), p0.y + seg8_prefix_sum(ot.y), p0.z + seg8_prefix_sum(ot.z));
+  const Vec3<double> axw = Rm * Vec3<double>(L.ax[0], L.ax[1], L.ax[2]);
+  const Mat3<double> Rl = R0 * P;             // on lane 4: the frame behind the last joint
+  const Vec3<double> fl = org + Rl * Vec3<double>(L.off[0], L.off[1], L.off[2]);
+  o.foot = Vec3<double>(seg8_get(fl.x, 4), seg8_get(fl.y, 4), seg8_get(fl.z, 4));
+#pragma unroll
+  for (int e = 0; e < 9; ++e) o.Rf.m[e] = seg8_get(Rl.m[e], 4);
+  o.jl = cross(axw, o.foot - org);
+  o.ja = tmul(o.Rf, axw);
+}
+// Eigen::ColPivHouseholderQR::solve (threshold thr) of a 3 x n system whose columns are owned by the lanes with `col` set
+// (n <= 5): this lane's entry of the basic solution (free variables zero).  b is uniform in the group.
+__device__ __forceinline__ double ik_colpiv_solve(double a0, double a1, double a2, bool col, double b0, double b1, double b2, double thr) {
+  double a[3] = {a0, a1, a2}, b[3] = {b0, b1, b2}, diag[3] = {0.0, 0.0, 0.0};
+  int ord = -1;                       // pivot position of this lane's column
+  int pvl[3] = {0, 0, 0};             // lane (inside the group) of the column at each pivot position
+  const int n_col = __popc((unsigned)((__ballot(col) >> (threadIdx.x & 56)) & 0xff));
+  const int shift = threadIdx.x & 56;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const bool stepon = j < n_col;    // steps = min(3, n)
+    double nn = 0.0;
+#pragma unroll
+    for (int r = j; r < 3; ++r) nn += a[r] * a[r];
+    const bool cand = col && ord < 0;
+    const double best = seg8_allmax(cand ? nn : -1.0);
+    const unsigned hit = (unsigned)((__ballot(cand && nn == best) >> shift) & 0xff);
+    const int pv = hit ? __ffs(hit) - 1 : 0;
+    const bool live = stepon && hit != 0;
+    if (live && (threadIdx.x & 7) == pv) ord = j;
+    if (live) pvl[j] = pv;
+    const double nrm = sqrt(fmax(best, 0.0));
+    double av[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) av[r] = seg8_get(a[r], pv);
+    const bool refl = live && nrm > 0.0;
+    const double alpha = av[j] > 0.0 ? -nrm : nrm;
+    double v[3] = {0.0, 0.0, 0.0}, vv = 0.0;
+#pragma unroll
+    for (int r = j; r < 3; ++r) { v[r] = av[r] - (r == j ? alpha : 0.0); vv += v[r] * v[r]; }
+    const bool doit = refl && vv > 0.0;
+    const double beta = doit ? 2.0 / vv : 0.0;
+    // columns at positions >= j: the pivot column and everything not chosen yet
+    if (col && (ord < 0 || ord == j)) {
+      double d = 0.0;
+#pragma unroll
+      for (int r = j; r < 3; ++r) d += v[r] * a[r];
+      d *= beta;
+#pragma unroll
+      for (int r = j; r < 3; ++r) a[r] -= d * v[r];
+    }
+    {
+      double d = 0.0;
+#pragma unroll
+      for (int r = j; r < 3; ++r) d += v[r] * b[r];
+      d *= beta;
+#pragma unroll
+      for (int r = j; r < 3; ++r) b[r] -= d * v[r];
+    }
+    diag[j] = live ? seg8_get(a[j], pv) : 0.0;   // a[j][j] after the reflection (alpha; the raw entry if the step was skipped)
+  }
+  int rank = 0;
+  const double d0 = fabs(diag[0]);
+  const int steps = n_col < 3 ? n_col : 3;
+  if (d0 > 0.0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < steps && fabs(diag[i]) > thr * d0) ++rank;
+  }
+  // upper triangle R[i][p], i < p, from the lanes that own the pivot columns
+  const double r01 = seg8_get(a[0], pvl[1]), r02 = seg8_get(a[0], pvl[2]), r12 = seg8_get(a[1], pvl[2]);
+  double z[3] = {0.0, 0.0, 0.0};
+  if (rank > 2) z[2] = b[2] / diag[2];
+  if (rank > 1) z[1] = (b[1] - (rank > 2 ? r12 * z[2] : 0.0)) / diag[1];
+  if (rank > 0) z[0] = (b[0] - (rank > 1 ? r01 * z[1] : 0.0) - (rank > 2 ? r02 * z[2] : 0.0)) / diag[0];
+  double y = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (ord == i && i < rank) y = z[i];
+  return y;
+}
+// One step direction of the rotation stage: v = -N y with N an orthonormal basis of null(Jl) (trailing rows of Q' from the
+// column-pivoted QR of Jl', rank threshold 1e-12) and y the basic solution of (Ja N) y = err.  jl / ja: this lane's columns.
+__device__ __forceinline__ double ik_rotation_step(const IkLane& L, const Vec3<double>& jl, const Vec3<double>& ja, const Vec3<double>& err) {
+  // At = Jl' (5 x 3): row k on lane k; the three columns are registers, pivoted by swapping registers
+  double a[3] = {L.joint ? jl.x : 0.0, L.joint ? jl.y : 0.0, L.joint ? jl.z : 0.0};
+  double qt[5];   // column `lane` of Q' (Q'[r][lane], r < 5); Q' starts as the identity
+#pragma unroll
+  for (int r = 0; r < 5; ++r) qt[r] = (L.joint && L.k == r) ? 1.0 : 0.0;
+  double diag[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const bool rowon = L.joint && L.k >= j;
+    double nn[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = j; c < 3; ++c) nn[c] = seg8_allsum(rowon ? a[c] * a[c] : 0.0);
+    int pv = j;
+    double best = nn[j];
+#pragma unroll
+    for (int c = j + 1; c < 3; ++c)
+      if (nn[c] > best) { best = nn[c]; pv = c; }
+#pragma unroll
+    for (int c = j + 1; c < 3; ++c)
+      if (pv == c) { const double t = a[j]; a[j] = a[c]; a[c] = t; }
+    const double nrm = sqrt(best);
+    const double ajj = seg8_get(a[j], j);
+    const double alpha = ajj > 0.0 ? -nrm : nrm;
+    const double vk = rowon ? a[j] - (L.k == j ? alpha : 0.0) : 0.0;   // reflector entry of this lane's row
+    const double vv = seg8_allsum(vk * vk);
+    const bool doit = nrm > 0.0 && vv > 0.0;
+    const double beta = doit ? 2.0 / vv : 0.0;
+#pragma unroll
+    for (int c = j; c < 3; ++c) {
+      const double d = beta * seg8_allsum(vk * a[c]);
+      a[c] -= d * vk;
+    }
+    // Q' <- H Q': every lane needs the whole reflector to update its own column
+    double vr[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) vr[r] = seg8_get(vk, r);
+    double d = 0.0;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) d += vr[r] * qt[r];
+    d *= beta;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) qt[r] -= d * vr[r];
+    diag[j] = seg8_get(a[j], j);
+  }
+  int rank = 0;
+  const double d0 = fabs(diag[0]);
+  if (d0 > 0.0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (fabs(diag[i]) > 1e-12 * d0) ++rank;
+  }
+  const int nd = 5 - rank;
+  // w[r'] = Ja * (row r' of Q')' (uniform): lane c < nd then owns column c of A = Ja N, N = rows rank .. 4 of Q'
+  Vec3<double> mine;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const double qv = L.joint ? qt[r] : 0.0;
+    const Vec3<double> w(seg8_allsum(ja.x * qv), seg8_allsum(ja.y * qv), seg8_allsum(ja.z * qv));
+    if (L.k + rank == r) mine = w;
+  }
+  const bool col = L.k < nd && L.k < 5;
+  const double y = ik_colpiv_solve(mine.x, mine.y, mine.z, col, err.x, err.y, err.z, 0.01);
+  double v = 0.0;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int c = r - rank;
+    const double yc = seg8_get(y, c < 0 ? 0 : c);
+    if (c >= 0) v -= qt[r] * yc;
+  }
+  return v;
+}
+// InverseKinematics::computeIK for the group's leg: q (this lane's joint angle) is updated in place.
+__device__ __forceinline__ void ik_solve(const IkLane& L, const Mat3<double>& R0, const Vec3<double>& p0, const Vec3<double>& des,
+                                         const Mat3<double>& Rdes, double& q) {
+#pragma unroll 1
+  for (int stage = 0; stage < 2; ++stage) {
+    IkKin kin;
+    ik_kin(L, R0, p0, q, kin);
+    auto error = [&](const IkKin& kk) {
+      if (stage == 0) return kk.foot - des;
+      Mat3<double> Rt;  // Rdes' R
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Rt.m[3 * r + c] = Rdes.m[r] * kk.Rf.m[c] + Rdes.m[3 + r] * kk.Rf.m[3 + c] + Rdes.m[6 + r] * kk.Rf.m[6 + c];
+      return rg_log3(Rt);
+    };
+    Vec3<double> err = error(kin);
+    double last = sqrt(dot(err, err));
+    bool done = last < 0.01;
+#pragma unroll 1
+    for (int it = 0; it < 5; ++it) {
+      if (__ballot(!done) == 0) break;
+      double v;
+      if (stage == 0) v = -ik_colpiv_solve(kin.jl.x, kin.jl.y, kin.jl.z, L.joint, err.x, err.y, err.z, 0.01);
+      else v = ik_rotation_step(L, kin.jl, kin.ja, err);
+      const double qn = fmin(L.hi, fmax(L.lo, q + 0.7 * v));
+      IkKin kn;
+      ik_kin(L, R0, p0, done ? q : qn, kn);
+      const Vec3<double> en = error(kn);
+      const double nn = sqrt(dot(en, en));
+      const bool stop_keep_old = nn > last || fabs(nn - last) < 1e-3;
+      if (!done) {
+        if (stop_keep_old) {
+          done = true;
+        } else {
+          last = nn; q = qn; kin = kn; err = en;
+          if (nn < 0.01) done = true;
+        }
+      }
+    }
+  }
+}
+__device__ __forceinline__ void ik_lane_setup(const DevModel& M, int leg, IkLane& L) {
+  L.k = threadIdx.x & 7;
+  L.joint = L.k < 5;
+  const int j = 5 * leg + (L.joint ? L.k : 0);
+  for (int e = 0; e < 3; ++e) { L.ax[e] = M.axis[j][e]; L.org[e] = M.origin[j][e]; L.off[e] = M.contact_offset[leg][e]; }
+  L.lo = M.q_lower[j];
+  L.hi = M.q_upper[j];
+}
+// refgen_ik_leg, one group of eight lanes per (instance, leg); `valid` = the group has an instance
+__device__ __forceinline__ void refgen_ik_group(const DevModel& M, const RefgenConfig& K, bool valid, int n_ev, const double* ev, double t0,
+                                                double horizon, const double* x_now, const double* phases, int nk, double* knot_t,
+                                                double* knot_x, int leg) {
+  IkLane L;
+  ik_lane_setup(M, leg, L);
+  RgTarget T;
+  T.t0 = t0;
+  T.tf = t0 + horizon;
+  T.cur = knot_x + size_t(RG_MAX_KNOTS - 2) * HB_NX;
+  T.tgt = knot_x + size_t(RG_MAX_KNOTS - 1) * HB_NX;
+  const Mat3<double> Rdes = rg_rot_zyx(x_now + 9);
+  double q = K.default_joints[5 * leg + (L.joint ? L.k : 0)];
+  const double step = (T.tf - t0) / (nk - 1);
+  const bool run = valid && nk > 2;
+  int nk_max = run ? nk : 0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) nk_max = max(nk_max, __shfl_xor(nk_max, m, 64));
+#pragma unroll 1
+  for (int i = 0; i < nk_max; ++i) {
+    const bool on = run && i < nk;
+    const int ii = on ? i : 0;
+    const double ti = ii == nk - 1 ? T.tf : t0 + ii * step;  // numpy.linspace
+    double zyx[3];
+    for (int c = 0; c < 3; ++c) zyx[c] = T.at(ti, 9 + c);
+    const Vec3<double> p0(T.at(ti, 6), T.at(ti, 7), T.at(ti, 8));
+    const Mat3<double> R0 = rg_rot_zyx(zyx);
+    const int idx = rg_phase_index(ev, n_ev, ti);
+    double sw[6];
+    rg_phase_eval(K, phases + (size_t(leg) * (RG_MAX_EVENTS + 1) + idx) * RG_PHASE, ti, sw);
+    double qs = q;
+    ik_solve(L, R0, p0, Vec3<double>(sw[0], sw[1], sw[2]), Rdes, qs);  // warm start: previous knot's solution
+    if (on) {
+      q = qs;
+      double* xk = knot_x + size_t(i) * HB_NX;
+      if (L.joint) xk[12 + 5 * leg + L.k] = q;
+      if (leg == 0) {
+        if (L.k == 7) knot_t[i] = ti;
+        for (int c = L.k; c < 12; c += 8) xk[c] = T.at(ti, c);
+      }
+    }
+  }
+}
+#endif
+
 // Planner step of one instance: swing phases of the four feet and the shooting grid.  `phases` is
 // [4][RG_MAX_EVENTS + 1][RG_PHASE]; `latest_stance` [4][3] persists between calls
 // (SwingTrajectoryPlanner::latestStanceposition_).  Returns 0, or 1 if a swing phase has no take-off / touch-down time

@@ -351,6 +351,12 @@ int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, int32_t nu, const do
  * HierarchicalWbc kernel (hb_config.wbc_type = 1) on plain matrices. */
 int32_t hb_hoqp_solve(hb_ctx* ctx, int32_t n_problems, int32_t n_vars, int32_t n_levels, const int32_t* m_eq, const int32_t* m_in,
                       const double* A, const double* b, const double* D, const double* f, double* x, double* slack, int32_t* status);
+/* n independent inverse-kinematics problems of the joint-reference generator (InverseKinematics::computeIK(init_q, leg, pos, R_des),
+ * legged_interface/src/foot_planner/InverseKinematics.cpp:36-231): q16[n][16] = [base pos, zyx, joints] start configurations,
+ * leg[n] in {0 left, 1 right}, des_pos[n][3] target of contact f1 of the leg, R_des[n][9] row-major desired foot rotation;
+ * out5[n][5] = the leg's joint angles.  Runs the lane-cooperative device routine that hb_refgen_update uses per knot; it is
+ * the entry the reference-compiled golden vectors (tests/golden/ref_ik.json) are checked through. */
+int32_t hb_ik_solve(hb_ctx* ctx, int32_t n, const double* q16, const int32_t* leg, const double* des_pos, const double* R_des, double* out5);
 /* QP step of the last SQP iteration (before the line search scaled it): dx[batch][max_nodes+1][22],
  * du[batch][max_nodes][22]; either may be NULL. */
 int32_t hb_mpc_get_step(hb_ctx* ctx, double* dx, double* du);

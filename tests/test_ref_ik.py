@@ -72,3 +72,26 @@ def test_reference_ik_respects_joint_limits_and_improves_the_foot_position(param
         q[6 + 5 * leg:11 + 5 * leg] = out
         e1 = np.linalg.norm(refgen._leg_kinematics(model, q, leg)[0] - np.array(c["des_pos"]))
         assert e1 <= e0 + 1e-15
+
+
+@pytest.mark.gpu
+def test_device_ik_matches_reference_ik(params):
+    """hb_ik_solve = the lane-cooperative routine hb_refgen_update runs per knot (eight lanes per leg), against the reference-
+    compiled vectors; threshold-marginal cases excluded as above."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    model = params["model"]
+    s = HunterSolver(params, batch=1, max_nodes=4)
+    try:
+        out = s.ik_solve([c["q"] for c in CASES], [c["leg"] for c in CASES], [c["des_pos"] for c in CASES], [c["R_des"] for c in CASES])
+    finally:
+        s.close()
+    checked = 0
+    for c, o in zip(CASES, out):
+        q, leg = np.array(c["q"]), c["leg"]
+        q2 = q.copy()
+        q2[6 + 5 * leg:11 + 5 * leg] = c["out"]["translation"]
+        if _rank_marginal(model, q2, leg) or _rank_marginal(model, q, leg):
+            continue
+        assert np.abs(o - np.array(c["out"]["ik"])).max() < 1e-8, (CASES.index(c), o, c["out"]["ik"])
+        checked += 1
+    assert checked >= 60

@@ -110,7 +110,7 @@ def cpu_baseline(params, n_intervals, seconds_budget=20.0):
     }
 
 
-def config1_latency(params, device, n_list=(54, 100), reps=40):
+def config1_latency(params, device, n_list=(54, 100), reps=250):
     """The reference's own operating point: ONE robot, timeHorizon 0.8 s (task.info:144 -> N = 54) and the benchmark's N = 100.
     Wall latency of one MPC call (hb_mpc_solve with a host observation + sync) and of one control tick (hb_wbc_update with host
     pointers in and out) against the reference's 100 Hz / 500 Hz budgets (task.info:150, hunter.yaml:2)."""
@@ -127,6 +127,8 @@ def config1_latency(params, device, n_list=(54, 100), reps=40):
                 s.mpc_solve(seq[k % len(seq)])
                 s.sync()
             s.publish()
+            for _ in range(10):  # warm-up of the control tick as well: the first hb_wbc_update pays the lazy load of its kernels
+                s.wbc_update(t_now, rbd, dt=0.002)   # (36 ms in the round-2 line, against a 2 ms budget)
             t_mpc, t_wbc = [], []
             for k in range(reps):
                 t0 = time.perf_counter()
@@ -140,8 +142,10 @@ def config1_latency(params, device, n_list=(54, 100), reps=40):
                 assert out_w["status"][0] == 0
                 t_mpc.append(1e3 * (t1 - t0))
                 t_wbc.append(1e3 * (t3 - t2))
-            out[f"N{N}"] = {"mpc_ms_median": float(np.median(t_mpc)), "mpc_ms_max": float(np.max(t_mpc)),
-                            "wbc_tick_ms_median": float(np.median(t_wbc)), "wbc_tick_ms_max": float(np.max(t_wbc))}
+            out[f"N{N}"] = {"ticks": reps,
+                            "mpc_ms_median": float(np.median(t_mpc)), "mpc_ms_p99": float(np.percentile(t_mpc, 99)), "mpc_ms_max": float(np.max(t_mpc)),
+                            "wbc_tick_ms_median": float(np.median(t_wbc)), "wbc_tick_ms_p99": float(np.percentile(t_wbc, 99)),
+                            "wbc_tick_ms_max": float(np.max(t_wbc))}
         finally:
             s.close()
     return out
@@ -181,11 +185,22 @@ def _full_tick(params, s, w, steps, dt_mpc):
     xh0[:, 6:18] = np.asarray(feet).reshape(B, 12)
     s.estimator_reset(abi.make_estimator_config(params), xh0)
     t = w["t_now"].copy()
+    # sensor arrays in pinned host memory, as a driver that feeds a batch every tick would hold them (pageable memory halves the
+    # PCIe rate of the 1 MB per tick)
+    def pin(a):
+        a = np.ascontiguousarray(a)
+        try:
+            import torch
+            return torch.from_numpy(a).pin_memory().numpy()
+        except Exception:  # noqa: BLE001  (no torch HIP runtime in this process: pageable memory then)
+            return a
+    quat, w_loc, a_loc, contact = pin(quat), pin(w_loc), pin(a_loc), pin(contact)
+    qj_s, qdj_s, cmd_s = pin(rbd[:, 6:16]), pin(rbd[:, 22:32]), pin(w["cmd"])
 
     def tick(k):
         s.set_resident_time(t + dt_mpc * k)
-        s.estimator_update(0.002, quat, w_loc, a_loc, rbd[:, 6:16], rbd[:, 22:32], contact, to_resident=True)
-        status = s.refgen_update(t + dt_mpc * k, w["horizon"], None, w["cmd"])
+        s.estimator_update(0.002, quat, w_loc, a_loc, qj_s, qdj_s, contact, to_resident=True)
+        status = s.refgen_update(t + dt_mpc * k, w["horizon"], None, cmd_s)
         s.step_resident()
         return status
 
@@ -206,6 +221,38 @@ def _full_tick(params, s, w, steps, dt_mpc):
                     "1 SQP iteration + publish + policy evaluation + WBC per step"}
 
 
+def backtracking_figure(params, device, B, N, first, random_cmd, steps):
+    """Third figure: the same batch WITHOUT the measurement noise on x0 — every call re-solves an almost converged problem, the
+    full Newton step no longer passes the filter and the line search walks down its step sizes (k_ls_tail), the case the
+    headline's timed region never sees."""
+    from hunter_bipedal_control_amd import workload
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    s = HunterSolver(params, batch=B, max_nodes=N, device=device)
+    try:
+        w = workload.device_trot_batch(s, params, n_intervals=N, first_inst=first, cmd_vel_random=random_cmd)
+        s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+        for _ in range(6):
+            s.step_resident()
+        s.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s.step_resident()
+        s.sync()
+        el = time.perf_counter() - t0
+        ls = 0.0
+        for _ in range(5):
+            s.step_resident()
+            ls += s.stats()["ms_linesearch"] / 5
+        perf = s.get_performance()
+        return {"updates_per_s": B * steps / el, "ms_per_step": 1e3 * el / steps, "steps": steps, "linesearch_ms": ls,
+                "line_search_step_histogram": {"full": int((perf[:, 3] == 1.0).sum()), "backtracked": int(((perf[:, 3] < 1.0) & (perf[:, 3] > 0.0)).sum()),
+                                               "rejected": int((perf[:, 3] == 0.0).sum())},
+                "mpc_status_histogram": [int((s.mpc_status() == i).sum()) for i in range(4)],
+                "what": "fixed x0 (no measurement noise): repeated SQP iterations on a converging iterate; the filter line search backtracks"}
+    finally:
+        s.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,7 +261,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU (weak scaling)")
     ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: this many instances split over the ranks")
     ap.add_argument("--nodes", type=int, default=100, help="shooting intervals N")
-    ap.add_argument("--chunks", type=int, default=1, help="instance ranges pipelined on separate HIP streams")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="instance ranges free-running on separate HIP streams, their steps replayed as hipGraphs (0 = auto: 4 from 1024 "
+                         "instances per GPU, 2 below; 1 = one stream, no graphs)")
     ap.add_argument("--random-cmd", action="store_true", help="configs[3]: per-instance cmd_vel, gait from walkGait")
     ap.add_argument("--hierarchical", action="store_true", help="configs[4]: HierarchicalWbc (3-priority HoQp cascade) instead of WeightedWbc")
     ap.add_argument("--gather", action="store_true", help="time an RCCL all-gather of status + trajectories (multi-GPU)")
@@ -252,7 +301,13 @@ def main():
     w = workload.device_trot_batch(s, params, n_intervals=N, first_inst=first, cmd_vel_random=args.random_cmd)
     s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
     s.set_resident_x0_sequence(x0_sequence(w["x0"], rank))
-    s.set_chunks(args.chunks)
+    n_chunks = args.chunks if args.chunks > 0 else (4 if B >= 1024 else 2)
+    s.set_chunks(n_chunks)
+    if n_chunks > 1:
+        # priming (setup, untimed): the library captures one hipGraph per (chunk, x0-sequence slot) once the chunk streams are in
+        # steady state; the capture passes must not fall into the timed region whatever --warmup is
+        for _ in range(12):
+            s.step_resident()
     s.sync()
     t_setup = time.perf_counter() - t_setup
 
@@ -335,6 +390,11 @@ def main():
         except Exception as e:  # noqa: BLE001  (a secondary figure must not take the headline line down)
             extras["with_refgen_and_estimator"] = {"error": repr(e)}
         try:
+            extras["with_backtracking_line_search"] = backtracking_figure(params, local_rank, B, N, first, args.random_cmd,
+                                                                          steps=max(10, min(40, args.steps // 5)))
+        except Exception as e:  # noqa: BLE001
+            extras["with_backtracking_line_search"] = {"error": repr(e)}
+        try:
             extras["config1_latency_ms"] = config1_latency(params, local_rank)
         except Exception as e:  # noqa: BLE001
             extras["config1_latency_ms"] = {"error": repr(e)}
@@ -343,11 +403,15 @@ def main():
         dom = max(("k_lq", "k_ric_bwd", "k_ric_fwd"), key=lambda k: phases[k])
         alg_bytes = BYTES_PER_NODE[dom] * int(n_nodes.sum())
         achieved = alg_bytes / (phases[dom] * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = ROOT / "profiles" / "pmc_latest.json"
         if pmc.exists() and B == 4096 and N == 100:
             try:
-                traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+                pj = json.loads(pmc.read_text())
+                traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/pmc_latest.json" + (f" ({pj['tag']})" if "tag" in pj else "") +
+                                  ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload, collected in a separate run "
+                                  "(counters cannot be read inside the timed process), NOT measured in this run")
             except Exception:
                 traffic = None
         per_kernel = {k: {"ms": phases[k], "algorithmic_GBs": BYTES_PER_NODE[k] * int(n_nodes.sum()) / (phases[k] * 1e-3) / 1e9,
@@ -364,18 +428,23 @@ def main():
                                    + f", N={N} shooting intervals (dt 0.015 s), node tables generated on the device "
                                      "(hb_refgen_update, per-knot IK joint references), 1 SQP iteration + "
                                      + ("HierarchicalWbc" if args.hierarchical else "WeightedWbc") + " per update, "
+                                     "x0 of every call perturbed by measurement noise (sigma 0.01) so that no call re-solves a converged problem: "
+                                     "every line search accepts the full step, NO backtracking inside the timed region "
+                                     "(the backtracking case is the separate figure with_backtracking_line_search), "
                                      "inputs resident in HBM (BASELINE.json configs[" + ("4" if args.hierarchical else "3" if args.random_cmd or strong else "2") + "])",
                        "batch_per_gpu": B, "total_instances": total_instances, "horizon_nodes": N, "setup_s": t_setup,
                        "parallelism": (f"strong scaling: {total_instances} instances split over {world} rank(s)" if strong else
                                        f"weak scaling: {B} instances per rank x {world}") +
-                                      f", no data-path collective; {args.chunks} pipelined instance range(s) per GPU"
+                                      f", no data-path collective; {n_chunks} instance range(s) per GPU, each free-running on its own HIP stream (steps replayed as hipGraphs)"
                                       + ("; all-gather of outputs timed separately" if gather else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": phases[dom],
                          "whole_update_frac_of_hbm_roofline": (BYTES_PER_UPDATE(N) * value / world) / (HBM_PEAK_GBS * 1e9),
                          "per_kernel": per_kernel},
             "phase_ms": phases,
+            "phase_ms_note": "HIP-event times of the kernels with the whole batch on ONE stream (no chunk overlap), taken after the timed region; "
+                             "the headline runs the same kernels per instance range on " + str(n_chunks) + " concurrent stream(s)",
             "halves": {"mpc_solves_per_s_per_gpu": B / (phases["mpc_total"] * 1e-3), "wbc_solves_per_s_per_gpu": B / (phases["k_wbc"] * 1e-3),
                        "note": "device time of each half alone (HIP events); the reference runs them 1:5 (100 Hz MPC, 500 Hz WBC)"},
             "solver_state": {"max_dyn_sse": float(perf[:, 1].max()), "max_eq_sse": float(perf[:, 2].max()),

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Builds libhunter_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+# (k_ls_tail is exempt on purpose: it is the backtracking tail of the line search, entered only by instances whose full step was
+# rejected — none in the steady-state timed region — and carries 452 B/lane of scratch next to its 256 + 256 registers.)
 # The build FAILS if one of the hot kernels of the update (either WBC flavour included) spills to scratch memory: every scratch reload is followed by
 # s_waitcnt vmcnt(0), which drains the software-pipelined record prefetch of the sweeps.
 set -e

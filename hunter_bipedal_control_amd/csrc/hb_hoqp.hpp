@@ -1036,6 +1036,7 @@ __global__ __launch_bounds__(64) void k_hoqp_generic(int n, int n_levels, const 
   if (cx.lane == 0) status[p] = rc;
 }
 __global__ __launch_bounds__(64) void k_hwbc(WbcBatch w, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
+  __builtin_amdgcn_s_setprio(3);  // per-instance serial solve: latency critical next to another chunk's LQ kernel (see k_ric_bwd)
   const int inst = blockIdx.x;
   extern __shared__ __attribute__((aligned(16))) double lds_h[];
   // hb_config.reserved = 41 / 42 stops the cascade after level 0 / 1 (profiling ablation only)

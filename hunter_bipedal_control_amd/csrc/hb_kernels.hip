@@ -109,57 +109,62 @@ __global__ void k_cold_start(Batch b, const DevModel* __restrict__ M, const unsi
 // compensation of the interval's mode).  Defined here: an input is HELD instead of interpolated across a mode
 // switch of the previous solution (the neighbouring node belongs to another contact configuration), and the last previous
 // interval holds its input.  One thread per (instance, node); instances whose tables did not change are left alone.
-__global__ void k_warm_shift(Batch b, const DevModel* __restrict__ M) {
+__global__ __launch_bounds__(64) void k_warm_shift(Batch b, const DevModel* __restrict__ M) {
+  // block = (node, instance); lanes 0..21 one state entry each, lanes 22..43 one input entry each.  Instances whose tables did
+  // not change keep their iterate (plain copy from the previous buffers: the host swapped them); the others are interpolated
+  // from the previous solution on ITS time grid.  The old interval that contains the node time is found by bisection (a
+  // linear scan was a chain of up to N dependent loads per block: 0.51 ms per 4096 x 100 launch, 0.06 ms of it memory traffic).
   const int k = blockIdx.x, inst = blockIdx.y, lane = threadIdx.x;
-  if (!b.grid_dirty[inst]) return;
-  const int n = b.n_nodes[inst], np = b.np_nodes[inst];
-  if (k > n) return;
   const size_t N = b.Nmax;
-  const double* tp = b.tp + size_t(inst) * (N + 1);
+  const bool is_x = lane < HB_NX, is_u = lane >= HB_NX && lane < HB_NX + HB_NU;
+  const int e = is_x ? lane : lane - HB_NX;
   const double* xp = b.xp + size_t(inst) * (N + 1) * HB_NX;
   const double* up = b.up + size_t(inst) * N * HB_NU;
+  double* xk = b.x + (size_t(inst) * (N + 1) + k) * HB_NX;
+  double* uk = b.u + (size_t(inst) * N + k) * HB_NU;
+  if (!b.grid_dirty[inst]) {
+    if (is_x) xk[e] = xp[size_t(k) * HB_NX + e];
+    if (is_u && k < int(N)) uk[e] = up[size_t(k) * HB_NU + e];
+    return;
+  }
+  const int n = b.n_nodes[inst], np = b.np_nodes[inst];
+  if (k > n) return;
+  const double* tp = b.tp + size_t(inst) * (N + 1);
   const int* mp = b.modep + size_t(inst) * N;
   const double t = b.t[size_t(inst) * (N + 1) + k];
-  double* xk = b.x + (size_t(inst) * (N + 1) + k) * HB_NX;
-  // old interval that contains t: tp[i] <= t < tp[i+1] (clamped)
-  int i = 0;
-  while (i + 1 < np && tp[i + 1] <= t) ++i;
-  if (lane < HB_NX) {
-    double v;
-    if (np <= 0 || t >= tp[np]) v = xp[(np > 0 ? np : 0) * HB_NX + lane];
-    else if (t <= tp[0]) v = xp[lane];
-    else {
-      const double a = (t - tp[i]) / (tp[i + 1] - tp[i]);
-      v = (1.0 - a) * xp[i * HB_NX + lane] + a * xp[(i + 1) * HB_NX + lane];
-    }
-    xk[lane] = v;
+  // old interval that contains t: the largest i in [0, np - 1] with tp[i] <= t (0 if there is none)
+  int lo = 0, hi = np > 0 ? np - 1 : 0;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tp[mid] <= t) lo = mid; else hi = mid - 1;
   }
-  if (k < n && lane < HB_NU) {
+  const int i = lo;
+  const bool beyond = np <= 0 || t >= tp[np], before = !beyond && t <= tp[0];
+  const double a = (beyond || before) ? 0.0 : (t - tp[i]) / (tp[i + 1] - tp[i]);
+  if (is_x) {
     double v;
-    if (np <= 0 || t >= tp[np]) {  // beyond the previous horizon: weight compensation of this interval's mode
+    if (beyond) v = xp[size_t(np > 0 ? np : 0) * HB_NX + e];
+    else if (before) v = xp[e];
+    else v = (1.0 - a) * xp[size_t(i) * HB_NX + e] + a * xp[size_t(i + 1) * HB_NX + e];
+    xk[e] = v;
+  }
+  if (is_u && k < n) {
+    double v;
+    if (beyond) {  // beyond the previous horizon: weight compensation of this interval's mode
       bool cf[HB_NC];
       mode_flags(b.mode[size_t(inst) * N + k], cf);
       int nc = 0;
       for (int c = 0; c < HB_NC; ++c) nc += cf[c];
-      v = (lane < 12 && lane % 3 == 2 && cf[lane / 3]) ? M->total_mass * M->gravity / nc : 0.0;
-    } else if (t <= tp[0]) {
-      v = up[lane];
+      v = (e < 12 && e % 3 == 2 && cf[e / 3]) ? M->total_mass * M->gravity / nc : 0.0;
+    } else if (before) {
+      v = up[e];
     } else if (i + 1 >= np || mp[i + 1] != mp[i]) {
-      v = up[i * HB_NU + lane];
+      v = up[size_t(i) * HB_NU + e];
     } else {
-      const double a = (t - tp[i]) / (tp[i + 1] - tp[i]);
-      v = (1.0 - a) * up[i * HB_NU + lane] + a * up[(i + 1) * HB_NU + lane];
+      v = (1.0 - a) * up[size_t(i) * HB_NU + e] + a * up[size_t(i + 1) * HB_NU + e];
     }
-    b.u[(size_t(inst) * N + k) * HB_NU + lane] = v;
+    uk[e] = v;
   }
-}
-// instances whose tables did NOT change keep their iterate: copy it over from the previous buffers (the host swapped them)
-__global__ void k_warm_keep(Batch b) {
-  const int k = blockIdx.x, inst = blockIdx.y, lane = threadIdx.x;
-  if (b.grid_dirty[inst] || k > b.Nmax) return;
-  const size_t N = b.Nmax;
-  if (lane < HB_NX) b.x[(size_t(inst) * (N + 1) + k) * HB_NX + lane] = b.xp[(size_t(inst) * (N + 1) + k) * HB_NX + lane];
-  if (k < b.Nmax && lane < HB_NU) b.u[(size_t(inst) * N + k) * HB_NU + lane] = b.up[(size_t(inst) * N + k) * HB_NU + lane];
 }
 __global__ void k_grid_clean(Batch b) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,15 +172,18 @@ __global__ void k_grid_clean(Batch b) {
 }
 // per-instance status word of an MPC call: a failed Riccati pivot or a non-finite performance index is HB_INST_NAN (the
 // step was not taken), a line search that rejected every step size is HB_INST_MAXITER (iterate unchanged)
-__global__ void k_mpc_status(Batch b) {
+__global__ void k_mpc_status(Batch b, int first_iteration) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.B) return;
   const double* p = b.perf + size_t(i) * 4;
-  const bool finite = isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]) && isfinite(b.acc[i * 4 + 0]) && isfinite(b.acc[i * 4 + 1]);
+  // (perf is only rewritten when a step is accepted; acc is the baseline of THIS iteration, rewritten by every forward sweep)
+  const bool finite = isfinite(b.acc[i * 4 + 0]) && isfinite(b.acc[i * 4 + 1]) && isfinite(b.acc[i * 4 + 2]) && isfinite(b.acc[i * 4 + 3]) &&
+                      (!b.accepted[i] || (isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2])));
   int st = HB_INST_OK;
   if (b.ric_fail[i] || !finite) st = HB_INST_NAN;
   else if (!b.accepted[i]) st = HB_INST_MAXITER;
-  b.mpc_status[i] = st;
+  // sticky over the SQP iterations of one call: the worst word any iteration produced (NAN > INFEASIBLE > MAXITER > OK)
+  b.mpc_status[i] = first_iteration ? st : max(b.mpc_status[i], st);
 }
 
 // HB_LQ_LDS_PAD: occupancy experiments only (tools/occupancy_variants.sh) — extra (or, negative, missing) doubles of LDS per node
@@ -200,6 +208,9 @@ __global__ __launch_bounds__(64, 3) void k_lq(Batch b, const DevModel* __restric
 }
 
 __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
+  // per-instance serial chain: when this kernel shares SIMDs with the node-parallel LQ kernel of another chunk stream (chunked
+  // hb_step_resident), it is the latency-critical one — ask the arbiter to issue it first
+  __builtin_amdgcn_s_setprio(3);
   const int inst = blockIdx.x;
   __shared__ double lds[RicLds::total];
   const WaveCtx cx;
@@ -285,6 +296,7 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
 }
 
 __global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
+  __builtin_amdgcn_s_setprio(3);  // see k_ric_bwd
   const int inst = blockIdx.x;
   __shared__ double lds[FwdLds::total];
   const WaveCtx cx;
@@ -756,8 +768,21 @@ struct hb_ctx {
   // per-instance sweeps of one chunk overlap the per-node kernels of another)
   int n_chunks = 1;
   hipStream_t s_chunk[8]{};
+  // hipGraphs of one chunk's whole step (x0 -> SQP iteration -> publish -> policy -> WBC), one per (chunk, x0-sequence slot): at
+  // small batch sizes the step is launch bound — ~25 enqueues per chunk and step against kernels of 100..900 us — and the
+  // chunk streams only overlap if the host keeps them fed.  Graphs captured in epoch e are stale once a device pointer they
+  // hold changes (the iterate / previous-iterate swap of the warm start, a new x0 sequence, a new chunk count).
+  static constexpr int GRAPH_SLOTS = 16;
+  hipGraphExec_t chunk_graph[8][GRAPH_SLOTS]{};
+  uint64_t chunk_graph_epoch[8][GRAPH_SLOTS]{};
+  uint64_t graph_epoch = 1;
+  int64_t dbg_graph_launches = 0, dbg_direct = 0, dbg_forks = 0, dbg_captures = 0;
+  int steady_chunked_steps = 0;   // chunked steps since the last fork: graphs are only captured in steady state
+  int chunks_pending = 0;    // chunk streams of the last chunked hb_step_resident not yet joined into the library streams
+  bool fork_needed = true;   // something may have been queued on the library streams since the last chunked step
   unsigned char* reset_mask = nullptr;  // [B] staging of hb_mpc_reset_masked
   double* jc_out = nullptr;  // joint command outputs [6][B][10]
+  bool jc_computed = false;  // hb_joint_command has run (jc_out alone is also allocated by hb_joint_set_flags / get_emergency_stop)
   int* jc_estop = nullptr;   // [B] latched emergencyStopFlag_ per instance
   int* jc_loaded = nullptr;  // [B] loadControllerFlag_ per instance (default: loaded)
   uint64_t* lcm_cmd = nullptr;    // [B][62] low_cmd_t wire images
@@ -917,8 +942,25 @@ void hb_destroy(hb_ctx* ctx) {
   for (auto& ev : ctx->ev_sync) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(ctx->s_mpc);
   (void)hipStreamDestroy(ctx->s_wbc);
+  for (auto& row : ctx->chunk_graph)
+    for (auto& g : row)
+      if (g) (void)hipGraphExecDestroy(g);
   for (auto& sc : ctx->s_chunk) (void)hipStreamDestroy(sc);
   delete ctx;
+}
+
+// Chunked hb_step_resident calls free-run: every chunk of instances is its own stream that goes from one step straight into the
+// next (instances are independent), without a per-step join.  The join into the two library streams happens here, lazily, at
+// the start of every OTHER entry point — the getters, the table updates, the joint command, hb_sync ... only know s_mpc / s_wbc —
+// and the next chunked step then forks again from them.
+static void lazy_join(hb_ctx* ctx) {
+  if (ctx->chunks_pending == 0 && ctx->fork_needed) return;  // nothing in flight (always, without chunks): no state is touched
+  for (int c = 0; c < ctx->chunks_pending; ++c) {
+    (void)hipStreamWaitEvent(ctx->s_mpc, ctx->ev_sync[4 + c], 0);
+    (void)hipStreamWaitEvent(ctx->s_wbc, ctx->ev_sync[4 + c], 0);
+  }
+  ctx->chunks_pending = 0;
+  ctx->fork_needed = true;
 }
 
 // joint command outputs and the per-instance controller flags (allocated on first use; loaded = 1, no emergency stop)
@@ -934,6 +976,7 @@ static int32_t joint_state_alloc(hb_ctx* ctx) {
 }
 
 int32_t hb_joint_set_flags(hb_ctx* ctx, const int32_t* controller_loaded, const int32_t* emergency_stop) {
+  if (ctx) lazy_join(ctx);
   if (!ctx) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   int32_t rc = joint_state_alloc(ctx);
@@ -945,6 +988,7 @@ int32_t hb_joint_set_flags(hb_ctx* ctx, const int32_t* controller_loaded, const 
 }
 
 int32_t hb_joint_get_emergency_stop(hb_ctx* ctx, int32_t* emergency_stop) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !emergency_stop) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   int32_t rc = joint_state_alloc(ctx);
@@ -956,6 +1000,7 @@ int32_t hb_joint_get_emergency_stop(hb_ctx* ctx, int32_t* emergency_stop) {
 
 int32_t hb_joint_command(hb_ctx* ctx, const hb_joint_gains* gains, double dt, double* pos_des, double* vel_des, double* kp, double* kd,
                          double* tau_ff, double* torque) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !gains) return HB_ERR_ARG;
   if (ctx->stats.n_wbc_solves == 0) {
     ctx->err = "hb_joint_command: no WBC solution yet";
@@ -969,6 +1014,7 @@ int32_t hb_joint_command(hb_ctx* ctx, const hb_joint_gains* gains, double dt, do
   hipLaunchKernelGGL(k_joint_command, dim3((ctx->B + 63) / 64), dim3(64), 0, s, ctx->w, ctx->dmodel, *gains, dt, ctx->jc_estop, ctx->jc_loaded,
                      ctx->jc_out);
   HB_HIP(hipGetLastError());
+  ctx->jc_computed = true;
   double* outs[6] = {pos_des, vel_des, kp, kd, tau_ff, torque};
   for (int a = 0; a < 6; ++a)
     if (outs[a]) HB_HIP(hipMemcpyAsync(outs[a], ctx->jc_out + a * n, n * 8, hipMemcpyDeviceToHost, s));
@@ -977,6 +1023,7 @@ int32_t hb_joint_command(hb_ctx* ctx, const hb_joint_gains* gains, double dt, do
 }
 
 int32_t hb_plant_reset(hb_ctx* ctx, const double* q0, const double* v0, double baumgarte, double eps) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !q0 || !(baumgarte >= 0.0) || !(eps >= 0.0)) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   const size_t B = ctx->B;
@@ -1006,12 +1053,13 @@ int32_t hb_plant_reset(hb_ctx* ctx, const double* q0, const double* v0, double b
 }
 
 int32_t hb_plant_step(hb_ctx* ctx, const double* tau, const int32_t* contact, double dt, int32_t substeps, int32_t to_resident) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !(dt > 0.0) || substeps < 1) return HB_ERR_ARG;
   if (!ctx->plant_ready) {
     ctx->err = "hb_plant_step: call hb_plant_reset first";
     return HB_ERR_STATE;
   }
-  if ((!tau && !ctx->jc_out) || (!contact && ctx->stats.n_wbc_solves == 0)) {
+  if ((!tau && !ctx->jc_computed) || (!contact && ctx->stats.n_wbc_solves == 0)) {
     ctx->err = "hb_plant_step: no device-resident torque / contact flags yet (hb_joint_command after a WBC call)";
     return HB_ERR_STATE;
   }
@@ -1038,6 +1086,7 @@ int32_t hb_plant_step(hb_ctx* ctx, const double* tau, const int32_t* contact, do
 }
 
 int32_t hb_plant_get_state(hb_ctx* ctx, double* q, double* v, double* rbd, double* lambda, double* vdot) {
+  if (ctx) lazy_join(ctx);
   if (!ctx) return HB_ERR_ARG;
   if (!ctx->plant_ready) {
     ctx->err = "hb_plant_get_state: call hb_plant_reset first";
@@ -1056,6 +1105,7 @@ int32_t hb_plant_get_state(hb_ctx* ctx, double* q, double* v, double* rbd, doubl
 }
 
 int32_t hb_refgen_reset(hb_ctx* ctx, const hb_refgen_config* cfg, const double* latest_stance) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !cfg || !(cfg->dt > 0.0)) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   const size_t B = ctx->B;
@@ -1084,6 +1134,7 @@ int32_t hb_refgen_reset(hb_ctx* ctx, const hb_refgen_config* cfg, const double* 
 
 int32_t hb_refgen_set_schedule(hb_ctx* ctx, int32_t i0, int32_t cnt, const int32_t* n_events, const double* event_times,
                                const int32_t* modes) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !n_events || !event_times || !modes || i0 < 0 || cnt <= 0 || i0 + cnt > ctx->B) return HB_ERR_ARG;
   if (!ctx->rg_ready) {
     ctx->err = "hb_refgen_set_schedule: call hb_refgen_reset first";
@@ -1129,6 +1180,7 @@ static int32_t save_grid_before_table_update(hb_ctx* ctx, int i0, int cnt) {
 }
 
 int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const double* x_now, const double* cmd_vel, int32_t* status) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !t0 || !cmd_vel || !(horizon > 0.0)) return HB_ERR_ARG;
   if (!ctx->rg_ready) {
     ctx->err = "hb_refgen_update: call hb_refgen_reset first";
@@ -1164,6 +1216,7 @@ int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const do
 
 int32_t hb_mpc_get_references(hb_ctx* ctx, int32_t i0, int32_t cnt, int32_t* n_nodes, double* t, int32_t* mode, double* x_ref,
                               double* swing_ref) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || i0 < 0 || cnt <= 0 || i0 + cnt > ctx->B) return HB_ERR_ARG;
   if (!ctx->refs_set) {
     ctx->err = "hb_mpc_get_references: references not set";
@@ -1182,6 +1235,7 @@ int32_t hb_mpc_get_references(hb_ctx* ctx, int32_t i0, int32_t cnt, int32_t* n_n
 }
 
 int32_t hb_estimator_reset(hb_ctx* ctx, const hb_estimator_config* cfg, const double* x_hat0) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !cfg) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   const size_t B = ctx->B;
@@ -1243,6 +1297,7 @@ static int32_t estimator_run(hb_ctx* ctx, double dt, int32_t to_resident, double
 int32_t hb_estimator_update(hb_ctx* ctx, double dt, const double* quat, const double* ang_vel_local, const double* lin_acc_local,
                             const double* joint_pos, const double* joint_vel, const int32_t* contact_flag, int32_t to_resident,
                             double* rbd, double* x_state) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !quat || !ang_vel_local || !lin_acc_local || !joint_pos || !joint_vel || !contact_flag || !(dt > 0.0)) return HB_ERR_ARG;
   if (!ctx->est_ready) {
     ctx->err = "hb_estimator_update: call hb_estimator_reset first";
@@ -1313,6 +1368,7 @@ int32_t hb_lcm_frame(const char* channel, uint32_t seq, const uint8_t* payload, 
 }
 
 int32_t hb_joint_command_lcm(hb_ctx* ctx, const hb_joint_gains* gains, double dt, int64_t timestamp_ns, uint8_t* low_cmd) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !gains || !low_cmd) return HB_ERR_ARG;
   int32_t rc = hb_joint_command(ctx, gains, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   if (rc != HB_OK) return rc;
@@ -1329,6 +1385,7 @@ int32_t hb_joint_command_lcm(hb_ctx* ctx, const hb_joint_gains* gains, double dt
 
 int32_t hb_estimator_update_lcm(hb_ctx* ctx, double dt, const uint8_t* low_state, const int32_t* contact_flag, int32_t to_resident,
                                 double* rbd, double* x_state, int64_t* timestamp) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !low_state || !contact_flag || !(dt > 0.0)) return HB_ERR_ARG;
   if (!ctx->est_ready) {
     ctx->err = "hb_estimator_update_lcm: call hb_estimator_reset first";
@@ -1362,6 +1419,7 @@ int32_t hb_estimator_update_lcm(hb_ctx* ctx, double dt, const uint8_t* low_state
 }
 
 int32_t hb_estimator_get_filter(hb_ctx* ctx, double* x_hat, double* P) {
+  if (ctx) lazy_join(ctx);
   if (!ctx) return HB_ERR_ARG;
   if (!ctx->est_ready) {
     ctx->err = "hb_estimator_get_filter: call hb_estimator_reset first";
@@ -1375,6 +1433,7 @@ int32_t hb_estimator_get_filter(hb_ctx* ctx, double* x_hat, double* P) {
 }
 
 int32_t hb_sync(hb_ctx* ctx) {
+  if (ctx) lazy_join(ctx);
   if (!ctx) return HB_ERR_ARG;
   HB_HIP(hipStreamSynchronize(ctx->s_mpc));
   HB_HIP(hipStreamSynchronize(ctx->s_wbc));
@@ -1393,6 +1452,7 @@ int32_t hb_get_input_cost(const hb_ctx* ctx, double* R) {
 
 int32_t hb_mpc_set_references(hb_ctx* ctx, int32_t i0, int32_t cnt, const int32_t* n_nodes, const double* t,
                               const int32_t* mode, const double* x_ref, const double* swing_ref) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !n_nodes || !t || !mode || !x_ref || !swing_ref || i0 < 0 || cnt <= 0 || i0 + cnt > ctx->B) {
     if (ctx) ctx->err = "hb_mpc_set_references: bad argument";
     return HB_ERR_ARG;
@@ -1453,16 +1513,19 @@ static int32_t mpc_cold_start(hb_ctx* ctx, const double* x0, const uint8_t* mask
 }
 
 int32_t hb_mpc_reset(hb_ctx* ctx, const double* x0) {
+  if (ctx) lazy_join(ctx);
   if (!ctx) return HB_ERR_ARG;
   return mpc_cold_start(ctx, x0, nullptr);
 }
 
 int32_t hb_mpc_reset_masked(hb_ctx* ctx, const uint8_t* mask, const double* x0) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !mask) return HB_ERR_ARG;
   return mpc_cold_start(ctx, x0, mask);
 }
 
 int32_t hb_mpc_get_status(hb_ctx* ctx, int32_t* status) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !status) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   HB_HIP(hipMemcpyAsync(status, ctx->b.mpc_status, size_t(ctx->B) * sizeof(int), hipMemcpyDeviceToHost, ctx->s_mpc));
@@ -1471,6 +1534,7 @@ int32_t hb_mpc_get_status(hb_ctx* ctx, int32_t* status) {
 }
 
 int32_t hb_mpc_set_trajectory(hb_ctx* ctx, const double* x, const double* u) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !x || !u) return HB_ERR_ARG;
   const size_t B = ctx->B, N = ctx->Nmax;
   HB_HIP(hipSetDevice(ctx->device));
@@ -1511,8 +1575,8 @@ static int32_t warm_start_onto_new_tables(hb_ctx* ctx) {
   Batch& b = ctx->b;
   std::swap(b.x, b.xp);
   std::swap(b.u, b.up);
+  ++ctx->graph_epoch;  // captured chunk graphs hold the old pointers
   hipLaunchKernelGGL(k_warm_shift, dim3(ctx->Nmax + 1, ctx->B), dim3(64), 0, ctx->s_mpc, b, ctx->dmodel);
-  hipLaunchKernelGGL(k_warm_keep, dim3(ctx->Nmax + 1, ctx->B), dim3(64), 0, ctx->s_mpc, b);
   hipLaunchKernelGGL(k_grid_clean, dim3((ctx->B + 255) / 256), dim3(256), 0, ctx->s_mpc, b);
   HB_HIP(hipGetLastError());
   ctx->grid_saved = false;
@@ -1545,8 +1609,9 @@ static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t
       hipLaunchKernelGGL(k_ls_tail, dim3(B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, ctx->config.alpha_decay,
                          ctx->config.alpha_decay, ctx->config.alpha_min);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[4], s));
+    // evaluated per iteration: ric_fail / accepted are overwritten by the next one
+    hipLaunchKernelGGL(k_mpc_status, dim3((B + 255) / 256), dim3(256), 0, s, b, it == 0 ? 1 : 0);
   }
-  hipLaunchKernelGGL(k_mpc_status, dim3((B + 255) / 256), dim3(256), 0, s, b);
   HB_HIP(hipGetLastError());
   {
     std::lock_guard<std::mutex> lk(ctx->mtx);
@@ -1557,6 +1622,7 @@ static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t
 }
 
 int32_t hb_mpc_solve(hb_ctx* ctx, const double* x0) {
+  if (ctx) lazy_join(ctx);
   if (!ctx) return HB_ERR_ARG;
   if (!ctx->refs_set || !ctx->traj_set) {
     ctx->err = "hb_mpc_solve: call hb_mpc_set_references and hb_mpc_reset/hb_mpc_set_trajectory first";
@@ -1571,6 +1637,7 @@ int32_t hb_mpc_solve(hb_ctx* ctx, const double* x0) {
 }
 
 int32_t hb_mpc_get_solution(hb_ctx* ctx, int32_t i0, int32_t cnt, double* x, double* u) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || i0 < 0 || cnt <= 0 || i0 + cnt > ctx->B) return HB_ERR_ARG;
   const size_t N = ctx->Nmax;
   HB_HIP(hipSetDevice(ctx->device));
@@ -1581,6 +1648,7 @@ int32_t hb_mpc_get_solution(hb_ctx* ctx, int32_t i0, int32_t cnt, double* x, dou
 }
 
 int32_t hb_mpc_get_step(hb_ctx* ctx, double* dx, double* du) {
+  if (ctx) lazy_join(ctx);
   if (!ctx) return HB_ERR_ARG;
   const size_t B = ctx->B, N = ctx->Nmax;
   HB_HIP(hipSetDevice(ctx->device));
@@ -1591,6 +1659,7 @@ int32_t hb_mpc_get_step(hb_ctx* ctx, double* dx, double* du) {
 }
 
 int32_t hb_mpc_get_performance(hb_ctx* ctx, double* perf) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !perf) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   HB_HIP(hipMemcpyAsync(perf, ctx->b.perf, size_t(ctx->B) * 4 * 8, hipMemcpyDeviceToHost, ctx->s_mpc));
@@ -1599,6 +1668,7 @@ int32_t hb_mpc_get_performance(hb_ctx* ctx, double* perf) {
 }
 
 int32_t hb_mpc_publish(hb_ctx* ctx) {
+  if (ctx) lazy_join(ctx);
   if (!ctx) return HB_ERR_ARG;
   const size_t B = ctx->B, N = ctx->Nmax;
   HB_HIP(hipSetDevice(ctx->device));
@@ -1645,6 +1715,7 @@ static int32_t wbc_launch(hb_ctx* ctx, bool from_policy, double dt) {
 
 int32_t hb_wbc_update(hb_ctx* ctx, const double* t_now, const double* rbd, const int32_t* walk_flag, double dt,
                       double* sol, double* x_des, double* u_des, int32_t* planned_mode, int32_t* status) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || ((t_now == nullptr) != (rbd == nullptr))) return HB_ERR_ARG;
   if (!ctx->w.policy_valid) {
     ctx->err = "hb_wbc_update: no published policy (hb_mpc_publish)";
@@ -1672,6 +1743,7 @@ int32_t hb_wbc_update(hb_ctx* ctx, const double* t_now, const double* rbd, const
 
 int32_t hb_wbc_update_direct(hb_ctx* ctx, const double* x_des, const double* u_des, const double* rbd, const int32_t* mode,
                              const int32_t* stance_flag, double dt, double* sol, int32_t* status) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !x_des || !u_des || !rbd || !mode) return HB_ERR_ARG;
   const size_t B = ctx->B;
   WbcBatch& w = ctx->w;
@@ -1692,6 +1764,7 @@ int32_t hb_wbc_update_direct(hb_ctx* ctx, const double* x_des, const double* u_d
 }
 
 int32_t hb_set_resident_inputs(hb_ctx* ctx, const double* x0, const double* t_now, const double* rbd, const int32_t* walk_flag) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !x0 || !t_now || !rbd) return HB_ERR_ARG;
   const size_t B = ctx->B;
   HB_HIP(hipSetDevice(ctx->device));
@@ -1703,6 +1776,7 @@ int32_t hb_set_resident_inputs(hb_ctx* ctx, const double* x0, const double* t_no
 }
 
 int32_t hb_set_resident_time(hb_ctx* ctx, const double* t_now) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !t_now) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   HB_HIP(hipMemcpyAsync(ctx->w.t_now, t_now, size_t(ctx->B) * 8, hipMemcpyHostToDevice, ctx->s_wbc));
@@ -1711,10 +1785,12 @@ int32_t hb_set_resident_time(hb_ctx* ctx, const double* t_now) {
 }
 
 int32_t hb_set_resident_x0_sequence(hb_ctx* ctx, int32_t n_seq, const double* x0_seq) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || n_seq < 0 || (n_seq > 0 && !x0_seq)) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   ctx->n_seq = 0;
   ctx->seq_idx = 0;
+  ++ctx->graph_epoch;
   if (n_seq == 0) return HB_OK;
   const size_t bytes = size_t(n_seq) * ctx->B * HB_NX * 8;
   if (hipMalloc(reinterpret_cast<void**>(&ctx->x0_seq), bytes) != hipSuccess) {
@@ -1734,12 +1810,15 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
     return HB_ERR_STATE;
   }
   HB_HIP(hipSetDevice(ctx->device));
+  const double* x0_next = nullptr;
+  const int seq_slot = ctx->seq_idx;
   if (ctx->n_seq > 0) {
-    HB_HIP(hipMemcpyAsync(ctx->b.x0, ctx->x0_seq + size_t(ctx->seq_idx) * ctx->B * HB_NX, size_t(ctx->B) * HB_NX * 8,
-                          hipMemcpyDeviceToDevice, ctx->s_mpc));
+    x0_next = ctx->x0_seq + size_t(ctx->seq_idx) * ctx->B * HB_NX;
     ctx->seq_idx = (ctx->seq_idx + 1) % ctx->n_seq;
   }
   if (ctx->n_chunks <= 1) {
+    lazy_join(ctx);
+    if (x0_next) HB_HIP(hipMemcpyAsync(ctx->b.x0, x0_next, size_t(ctx->B) * HB_NX * 8, hipMemcpyDeviceToDevice, ctx->s_mpc));
     int32_t rc = mpc_iterations(ctx);
     if (rc != HB_OK) return rc;
     rc = hb_mpc_publish(ctx);
@@ -1753,17 +1832,22 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
     HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev[6], 0));
     return HB_OK;
   }
-  // pipelined: every chunk of instances is a linear sequence MPC -> publish -> policy evaluation -> WBC on its own stream.
-  // Fork: the chunk streams start after everything queued so far on the MPC stream (x0 sequence copy, table updates, warm
-  // start, resident-input writers ordered into it) and on the WBC stream (resident rbd / time writers, the last reader of the
-  // policy buffers).  Join: both library streams wait for every chunk, so that the getters, the joint command, the plant and
-  // the next table update — which only know the two library streams — see a finished step.
-  {
+  // pipelined: every chunk of instances is a linear sequence x0 -> MPC -> publish -> policy evaluation -> WBC on its own stream,
+  // and consecutive steps of one chunk follow each other on that stream without waiting for the other chunks (lazy_join): the
+  // per-instance sweeps of one chunk (k_ric_bwd: a serial chain over the horizon that leaves most SIMDs idle at small batch
+  // sizes) overlap the LQ kernel of the others, across step boundaries.
+  // Fork (only when another entry point ran since the last chunked step, or the tables changed): the chunk streams start after
+  // everything queued so far on the MPC stream (table updates, warm start, resident-input writers ordered into it) and on the
+  // WBC stream (resident rbd / time writers, the last reader of the policy buffers).
+  const bool fork = ctx->fork_needed || ctx->grid_saved || ctx->chunks_pending != ctx->n_chunks;
+  if (fork) {
+    ++ctx->dbg_forks;
+    lazy_join(ctx);
     int32_t rc = warm_start_onto_new_tables(ctx);
     if (rc != HB_OK) return rc;
+    HB_HIP(hipEventRecord(ctx->ev_sync[2], ctx->s_mpc));
+    HB_HIP(hipEventRecord(ctx->ev_sync[3], ctx->s_wbc));
   }
-  HB_HIP(hipEventRecord(ctx->ev_sync[2], ctx->s_mpc));
-  HB_HIP(hipEventRecord(ctx->ev_sync[3], ctx->s_wbc));
   const int per = (ctx->B + ctx->n_chunks - 1) / ctx->n_chunks;
   const size_t N = ctx->Nmax;
   int used = 0;
@@ -1771,48 +1855,99 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
     const int i0 = c * per, cnt = std::min(per, ctx->B - i0);
     if (cnt <= 0) break;
     hipStream_t s = ctx->s_chunk[c];
-    HB_HIP(hipStreamWaitEvent(s, ctx->ev_sync[2], 0));
-    HB_HIP(hipStreamWaitEvent(s, ctx->ev_sync[3], 0));
-    int32_t rc = mpc_iterations(ctx, i0, cnt, s);
-    if (rc != HB_OK) return rc;
-    const Batch b = batch_view(ctx->b, i0, cnt);
-    const WbcBatch w = wbc_view(ctx->w, ctx->Nmax, i0, cnt);
-    HB_HIP(hipMemcpyAsync(w.px, b.x, size_t(cnt) * (N + 1) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
-    HB_HIP(hipMemcpyAsync(w.pu, b.u, size_t(cnt) * N * HB_NU * 8, hipMemcpyDeviceToDevice, s));
-    HB_HIP(hipMemcpyAsync(w.pt, b.t, size_t(cnt) * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
-    HB_HIP(hipMemcpyAsync(w.pmode, b.mode, size_t(cnt) * N * sizeof(int), hipMemcpyDeviceToDevice, s));
-    HB_HIP(hipMemcpyAsync(w.pn, b.n_nodes, size_t(cnt) * sizeof(int), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_policy_eval, dim3((cnt + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
-    if (ctx->config.wbc_type == 1)
-      hipLaunchKernelGGL(k_hwbc, dim3(cnt), dim3(64), HoLdsDev::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
-    else
-      hipLaunchKernelGGL(k_wbc, dim3(cnt), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
+    if (fork) {
+      HB_HIP(hipStreamWaitEvent(s, ctx->ev_sync[2], 0));
+      HB_HIP(hipStreamWaitEvent(s, ctx->ev_sync[3], 0));
+    }
+    auto enqueue = [&]() -> int32_t {
+      if (x0_next)
+        HB_HIP(hipMemcpyAsync(ctx->b.x0 + size_t(i0) * HB_NX, x0_next + size_t(i0) * HB_NX, size_t(cnt) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
+      int32_t rc = mpc_iterations(ctx, i0, cnt, s);
+      if (rc != HB_OK) return rc;
+      const Batch b = batch_view(ctx->b, i0, cnt);
+      const WbcBatch w = wbc_view(ctx->w, ctx->Nmax, i0, cnt);
+      HB_HIP(hipMemcpyAsync(w.px, b.x, size_t(cnt) * (N + 1) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
+      HB_HIP(hipMemcpyAsync(w.pu, b.u, size_t(cnt) * N * HB_NU * 8, hipMemcpyDeviceToDevice, s));
+      HB_HIP(hipMemcpyAsync(w.pt, b.t, size_t(cnt) * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
+      HB_HIP(hipMemcpyAsync(w.pmode, b.mode, size_t(cnt) * N * sizeof(int), hipMemcpyDeviceToDevice, s));
+      HB_HIP(hipMemcpyAsync(w.pn, b.n_nodes, size_t(cnt) * sizeof(int), hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(k_policy_eval, dim3((cnt + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
+      if (ctx->config.wbc_type == 1)
+        hipLaunchKernelGGL(k_hwbc, dim3(cnt), dim3(64), HoLdsDev::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
+      else
+        hipLaunchKernelGGL(k_wbc, dim3(cnt), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
+      return HB_OK;
+    };
+    // steady state (no fork for a few steps, the x0 slot fits): replay the step as one graph launch
+    const int slot = ctx->n_seq > 0 ? seq_slot : 0;
+    const bool graphable = !fork && ctx->steady_chunked_steps >= 2 && slot < hb_ctx::GRAPH_SLOTS && ctx->n_seq <= hb_ctx::GRAPH_SLOTS;
+    bool launched = false;
+    if (graphable) {
+      hipGraphExec_t& ge = ctx->chunk_graph[c][slot];
+      if (ge && ctx->chunk_graph_epoch[c][slot] != ctx->graph_epoch) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
+      if (!ge) {
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          const int32_t rc = enqueue();
+          const hipError_t ce = hipStreamEndCapture(s, &g);
+          ++ctx->dbg_captures;
+          if (rc == HB_OK && ce == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
+            ctx->chunk_graph_epoch[c][slot] = ctx->graph_epoch;
+            std::lock_guard<std::mutex> lk(ctx->mtx);
+            ctx->stats.n_mpc_solves -= cnt;  // (counted by the capture pass; the launch below counts the real one)
+          } else {
+            ge = nullptr;
+          }
+          if (g) (void)hipGraphDestroy(g);
+          (void)hipGetLastError();
+        }
+      }
+      if (ge && hipGraphLaunch(ge, s) == hipSuccess) {
+        launched = true;
+        ++ctx->dbg_graph_launches;
+        std::lock_guard<std::mutex> lk(ctx->mtx);
+        ctx->stats.n_mpc_solves += cnt;
+      }
+    }
+    if (!launched) {
+      ++ctx->dbg_direct;
+      const int32_t rc = enqueue();
+      if (rc != HB_OK) return rc;
+    }
     HB_HIP(hipGetLastError());
     HB_HIP(hipEventRecord(ctx->ev_sync[4 + c], s));
     used = c + 1;
   }
-  for (int c = 0; c < used; ++c) {
-    HB_HIP(hipStreamWaitEvent(ctx->s_mpc, ctx->ev_sync[4 + c], 0));
-    HB_HIP(hipStreamWaitEvent(ctx->s_wbc, ctx->ev_sync[4 + c], 0));
-  }
+  ctx->chunks_pending = used;
+  ctx->fork_needed = false;
+  ctx->steady_chunked_steps = fork ? 0 : ctx->steady_chunked_steps + 1;
   {
     std::lock_guard<std::mutex> lk(ctx->mtx);
     ctx->w.policy_valid = true;
-    ctx->policy_read_pending = false;  // the join above already orders the next policy write after this step's readers
+    ctx->policy_read_pending = false;  // the lazy join orders the next policy write (by another entry point) after these readers
     ctx->stats.n_wbc_solves += ctx->B;
   }
   return HB_OK;
 }
 
+int32_t hb_debug_chunk_counters(hb_ctx* ctx, int64_t* out4) {
+  if (!ctx || !out4) return HB_ERR_ARG;
+  out4[0] = ctx->dbg_graph_launches; out4[1] = ctx->dbg_direct; out4[2] = ctx->dbg_forks; out4[3] = ctx->dbg_captures;
+  return HB_OK;
+}
+
 int32_t hb_set_chunks(hb_ctx* ctx, int32_t n_chunks) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || n_chunks < 1 || n_chunks > 8) return HB_ERR_ARG;
   int32_t rc = hb_sync(ctx);
   if (rc != HB_OK) return rc;
   ctx->n_chunks = n_chunks;
+  ++ctx->graph_epoch;
   return HB_OK;
 }
 
 int32_t hb_get_wbc_solution(hb_ctx* ctx, double* sol, int32_t* status) {
+  if (ctx) lazy_join(ctx);
   if (!ctx) return HB_ERR_ARG;
   const size_t B = ctx->B;
   HB_HIP(hipSetDevice(ctx->device));
@@ -1823,6 +1958,7 @@ int32_t hb_get_wbc_solution(hb_ctx* ctx, double* sol, int32_t* status) {
 }
 
 int32_t hb_get_wbc_iterations(hb_ctx* ctx, int32_t* iters) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !iters) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   HB_HIP(hipStreamSynchronize(ctx->s_wbc));
@@ -1831,6 +1967,7 @@ int32_t hb_get_wbc_iterations(hb_ctx* ctx, int32_t* iters) {
 }
 
 int32_t hb_get_stats(hb_ctx* ctx, hb_stats* out) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !out) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   HB_HIP(hipStreamSynchronize(ctx->s_mpc));
@@ -1857,6 +1994,7 @@ int32_t hb_get_stats(hb_ctx* ctx, hb_stats* out) {
 
 // ---- unit-level entry points ---------------------------------------------------------------------------
 int32_t hb_eval_flow_map(hb_ctx* ctx, int32_t n, const double* x, const double* u, double* f, double* dfdx, double* dfdu) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || n <= 0 || !x || !u || !f) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   double *dx_, *du_, *df_, *dA = nullptr, *dB = nullptr;
@@ -1882,6 +2020,7 @@ int32_t hb_eval_flow_map(hb_ctx* ctx, int32_t n, const double* x, const double* 
 }
 
 int32_t hb_eval_foot_kinematics(hb_ctx* ctx, int32_t n, const double* x, const double* u, double* pos, double* vel) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || n <= 0 || !x || !u || !pos || !vel) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   double *dx_, *du_, *dp, *dv;
@@ -1900,6 +2039,7 @@ int32_t hb_eval_foot_kinematics(hb_ctx* ctx, int32_t n, const double* x, const d
 }
 
 int32_t hb_eval_rbd(hb_ctx* ctx, int32_t n, const double* rbd, double* Mo, double* nle, double* J, double* dJv) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || n <= 0 || !rbd) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   double *dr, *dM, *dn, *dJ, *dd;
@@ -1920,6 +2060,7 @@ int32_t hb_eval_rbd(hb_ctx* ctx, int32_t n, const double* rbd, double* Mo, doubl
 }
 
 int32_t hb_ik_solve(hb_ctx* ctx, int32_t n, const double* q16, const int32_t* leg, const double* des_pos, const double* R_des, double* out5) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || n <= 0 || !q16 || !leg || !des_pos || !R_des || !out5) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   double *dq = nullptr, *dd = nullptr, *dR = nullptr, *dout = nullptr;
@@ -1943,6 +2084,7 @@ int32_t hb_ik_solve(hb_ctx* ctx, int32_t n, const double* q16, const int32_t* le
 
 int32_t hb_hoqp_solve(hb_ctx* ctx, int32_t n_problems, int32_t n_vars, int32_t n_levels, const int32_t* m_eq, const int32_t* m_in,
                       const double* A, const double* b, const double* D, const double* f, double* x, double* slack, int32_t* status) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || n_problems <= 0 || n_vars <= 0 || n_vars > HQ_N || n_levels <= 0 || n_levels > HQ_L || !m_eq || !m_in || !A || !b || !D || !f ||
       !x || !slack || !status)
     return HB_ERR_ARG;
@@ -1983,6 +2125,7 @@ int32_t hb_hoqp_solve(hb_ctx* ctx, int32_t n_problems, int32_t n_vars, int32_t n
 }
 
 int32_t hb_centroidal_state_from_rbd(hb_ctx* ctx, int32_t n, const double* rbd, double* x) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || !rbd || !x || n <= 0) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
   double *drbd = nullptr, *dx = nullptr;
@@ -2004,6 +2147,7 @@ int32_t hb_centroidal_state_from_rbd(hb_ctx* ctx, int32_t n, const double* rbd, 
 int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, int32_t nu, const double* A, const double* Bm, const double* bv,
                          const double* Q, const double* R, const double* P, const double* q, const double* r,
                          const double* dx0, double* dx, double* du) {
+  if (ctx) lazy_join(ctx);
   if (!ctx || n <= 0 || N <= 0 || nu <= 0 || nu > NU_T || n > ctx->B || N > ctx->Nmax) return HB_ERR_ARG;
   // pack stage data into node records on the host, run the same kernels the MPC uses
   const size_t Nm = ctx->Nmax;

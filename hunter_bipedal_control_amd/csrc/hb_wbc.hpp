@@ -1001,6 +1001,7 @@ struct WbcDeviceCtx {
 };
 
 __global__ __launch_bounds__(64) void k_wbc(WbcBatch w, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
+  __builtin_amdgcn_s_setprio(3);  // per-instance serial solve: latency critical next to another chunk's LQ kernel (see k_ric_bwd)
   const int inst = blockIdx.x;
   __shared__ double lds[WbcLds::total];
   wbc_solve(WbcDeviceCtx(), *M, *C, w.xdes + size_t(inst) * HB_NX, w.udes + size_t(inst) * HB_NU, w.rbd + size_t(inst) * HB_NRBD,

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
     "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd", "hb_plant_reset", "hb_plant_step",
     "hb_plant_get_state", "hb_hoqp_solve", "hb_mpc_reset_masked", "hb_mpc_get_status", "hb_joint_set_flags",
-    "hb_joint_get_emergency_stop", "hb_set_resident_time", "hb_get_wbc_iterations", "hb_ik_solve",
+    "hb_joint_get_emergency_stop", "hb_set_resident_time", "hb_get_wbc_iterations", "hb_ik_solve", "hb_debug_chunk_counters",
 ]
 # include/hunter_lcm.h
 LCM_SYMBOLS = ["hb_lcm_fingerprint", "hb_lcm_encoded_size", "hb_lcm_field_count", "hb_lcm_encode", "hb_lcm_decode", "hb_lcm_frame",
@@ -410,6 +410,11 @@ class HunterSolver:
         self._check(self.lib.hb_hoqp_solve(self.ctx, C.c_int32(P), C.c_int32(n), C.c_int32(L), _p(m_eq), _p(m_in), _p(A), _p(b), _p(D), _p(f),
                                            _p(x), _p(slack), _p(status)), "hb_hoqp_solve")
         return x[:, :L, :n], [slack[:, l, :m_in[l]] for l in range(L)], status
+
+    def chunk_counters(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._check(self.lib.hb_debug_chunk_counters(self.ctx, _p(out)), "hb_debug_chunk_counters")
+        return dict(graph_launches=int(out[0]), direct=int(out[1]), forks=int(out[2]), captures=int(out[3]))
 
     def ik_solve(self, q16, leg, des_pos, R_des):
         """n independent InverseKinematics::computeIK problems on the device (hb_ik_solve) -> joint angles [n][5]."""

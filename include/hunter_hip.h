@@ -351,6 +351,9 @@ int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, int32_t nu, const do
  * HierarchicalWbc kernel (hb_config.wbc_type = 1) on plain matrices. */
 int32_t hb_hoqp_solve(hb_ctx* ctx, int32_t n_problems, int32_t n_vars, int32_t n_levels, const int32_t* m_eq, const int32_t* m_in,
                       const double* A, const double* b, const double* D, const double* f, double* x, double* slack, int32_t* status);
+/* Diagnostics of the chunked hb_step_resident: out4 = [graph launches, directly enqueued chunk steps, forks from the library streams,
+ * graph captures] since hb_create. */
+int32_t hb_debug_chunk_counters(hb_ctx* ctx, int64_t* out4);
 /* n independent inverse-kinematics problems of the joint-reference generator (InverseKinematics::computeIK(init_q, leg, pos, R_des),
  * legged_interface/src/foot_planner/InverseKinematics.cpp:36-231): q16[n][16] = [base pos, zyx, joints] start configurations,
  * leg[n] in {0 left, 1 right}, des_pos[n][3] target of contact f1 of the leg, R_des[n][9] row-major desired foot rotation;

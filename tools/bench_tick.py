@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Full control/MPC tick (estimator -> reference generation -> SQP iteration -> publish -> policy + WBC) broken down by call:
+host wall time of every entry point with a sync after each (attribution run), then the un-instrumented tick rate.
+    python tools/bench_tick.py [--steps K] [--batch B]      (rocprofv3 --kernel-trace --stats -- python tools/bench_tick.py for kernels)"""
+import argparse, json, sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np
+import bench
+from hunter_bipedal_control_amd import abi, ingest, workload
+from hunter_bipedal_control_amd.solver import HunterSolver
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--batch", type=int, default=4096)
+args = ap.parse_args()
+P = ingest.load_packaged()
+B, N = args.batch, 100
+s = HunterSolver(P, batch=B, max_nodes=N + 8)
+w = workload.device_trot_batch(s, P, n_intervals=N)
+r = bench._full_tick(P, s, w, args.steps, 0.010)
+print(json.dumps({"full_tick": {k: r[k] for k in ("updates_per_s", "ms_per_step")}}))
+# attribution: same calls, a sync after each
+rbd = w["rbd"]
+quat = np.tile([0.0, 0.0, 0.0, 1.0], (B, 1))
+zero3, acc = np.zeros((B, 3)), np.tile([0.0, 0.0, 9.81], (B, 1))
+contact = np.ones((B, 4), dtype=np.int32)
+t = w["t_now"].copy()
+acc_t = {}
+def timed(name, fn):
+    t0 = time.perf_counter(); fn(); s.sync(); acc_t[name] = acc_t.get(name, 0.0) + time.perf_counter() - t0
+for k in range(args.steps):
+    tk = t + 0.010 * (100 + k)
+    timed("set_resident_time", lambda: s.set_resident_time(tk))
+    timed("estimator_update", lambda: s.estimator_update(0.002, quat, zero3, acc, rbd[:, 6:16], rbd[:, 22:32], contact, to_resident=True))
+    timed("refgen_update", lambda: s.refgen_update(tk, w["horizon"], None, w["cmd"]))
+    timed("step_resident", lambda: s.step_resident())
+print(json.dumps({"per_call_ms": {k: round(1e3 * v / args.steps, 3) for k, v in acc_t.items()}, "stats": s.stats()}))
+s.close()

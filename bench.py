@@ -262,8 +262,8 @@ def main():
     ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: this many instances split over the ranks")
     ap.add_argument("--nodes", type=int, default=100, help="shooting intervals N")
     ap.add_argument("--chunks", type=int, default=0,
-                    help="instance ranges free-running on separate HIP streams, their steps replayed as hipGraphs (0 = auto: 4 from 1024 "
-                         "instances per GPU, 2 below; 1 = one stream, no graphs)")
+                    help="instance ranges free-running on separate HIP streams, their steps replayed as hipGraphs (0 = auto: 4, the number of "
+                         "hardware queues the runtime gives a process; 1 = one stream, no graphs)")
     ap.add_argument("--random-cmd", action="store_true", help="configs[3]: per-instance cmd_vel, gait from walkGait")
     ap.add_argument("--hierarchical", action="store_true", help="configs[4]: HierarchicalWbc (3-priority HoQp cascade) instead of WeightedWbc")
     ap.add_argument("--gather", action="store_true", help="time an RCCL all-gather of status + trajectories (multi-GPU)")
@@ -296,12 +296,18 @@ def main():
     else:
         B, first = args.batch, rank * args.batch
         total_instances = args.batch * world
+    # Runtime warm-up (setup, untimed): a context of the same size is created and destroyed first.  Measured on this stack
+    # (gpurun_out r03: tools/chunk_debug.py): the FIRST context a process creates overlaps its chunk streams
+    # worse than any later one (4096 x 100, 4 chunks: 370 k vs 405 k updates/s; one stream: 389 k either way) — a first-use
+    # effect of the ROCm runtime's queue / memory set-up that no ordering of our own stream creation or allocations reproduces.
+    if (args.chunks if args.chunks > 0 else 4) > 1:
+        HunterSolver(params, batch=B, max_nodes=N, device=local_rank).close()
     s = HunterSolver(params, batch=B, max_nodes=N, device=local_rank, wbc_type=1 if args.hierarchical else 0)
     t_setup = time.perf_counter()
     w = workload.device_trot_batch(s, params, n_intervals=N, first_inst=first, cmd_vel_random=args.random_cmd)
     s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
     s.set_resident_x0_sequence(x0_sequence(w["x0"], rank))
-    n_chunks = args.chunks if args.chunks > 0 else (4 if B >= 1024 else 2)
+    n_chunks = args.chunks if args.chunks > 0 else (4 if B >= 64 else 1)
     s.set_chunks(n_chunks)
     if n_chunks > 1:
         # priming (setup, untimed): the library captures one hipGraph per (chunk, x0-sequence slot) once the chunk streams are in
@@ -326,6 +332,7 @@ def main():
     s.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    chunk_counters = s.chunk_counters()
     elapsed = sharding.max_over_ranks(elapsed, dist, device="cuda")
     ms_per_step = 1e3 * elapsed / args.steps
     value = total_instances * args.steps / elapsed
@@ -453,7 +460,8 @@ def main():
                                                                                for lo, hi, n in zip(it_edges, it_edges[1:], it_hist)},
                              "wbc_active_set_iterations_min_max_rank0": [int(wbc_iters.min()), int(wbc_iters.max())],
                              "line_search_step_histogram_all_ranks": {"full": step_hist[0], "backtracked": step_hist[1], "rejected": step_hist[2]},
-                             "nodes_per_instance_min_max": [int(n_nodes.min()), int(n_nodes.max())]},
+                             "nodes_per_instance_min_max": [int(n_nodes.min()), int(n_nodes.max())],
+                             "chunk_step_counters_rank0": chunk_counters},
         }
         if gather:
             out["gather"] = gather

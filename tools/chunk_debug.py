@@ -7,7 +7,7 @@ P = ingest.load_packaged()
 N = 100
 import itertools
 import os
-for B, chunks in itertools.product((512, 1024, 4096), tuple(int(c) for c in os.environ.get('CHUNKS', '4,6,8').split(','))):
+for B, chunks in itertools.product(tuple(int(c) for c in os.environ.get('BATCHES', '512,1024,4096').split(',')), tuple(int(c) for c in os.environ.get('CHUNKS', '4,6,8').split(','))):
     s = HunterSolver(P, batch=B, max_nodes=N)
     w = workload.device_trot_batch(s, P, n_intervals=N)
     s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])

@@ -32,12 +32,14 @@ class HipLeggedController
   void update(const ros::Time& time, const ros::Duration& period) override;
   void starting(const ros::Time& time) override;
   void stopping(const ros::Time& /*time*/) override { mpcRunning_ = false; }
+  int plannedMode() const { return plannedMode_; }   // mode of the policy at the last control tick (the reference publishes it on a topic)
 
  protected:
   // the reference's own extension points (LeggedController.h:57-62), kept virtual for the same reason
   virtual void updateStateEstimation(const ros::Time& time, const ros::Duration& period);
   virtual void setupMpc();
   virtual void setupMrt();
+  void mpcPass();
 
   void cmdVelCallback(const geometry_msgs::Twist::ConstPtr& msg);
   void setWalkCallback(const std_msgs::Float32::ConstPtr& msg);
@@ -50,6 +52,7 @@ class HipLeggedController
   hardware_interface::ImuSensorHandle imuSensorHandle_;
 
   // solver: one context, batch 1
+  hunter_hip::Parameters params_;
   hb_model model_{};
   hb_config config_{};
   std::unique_ptr<hunter_hip::Context> ctx_;
@@ -73,7 +76,10 @@ class HipLeggedController
   std::mutex cmdMutex_;
   double cmdVel_[4] = {0.0, 0.0, 0.0, 0.0};   // filtered command [vx vy vz yawRate]
   double timeHorizon_ = 0.8, mpcDesiredFrequency_ = 100.0;
-  int plannedMode_ = 3;
+  std::atomic_int plannedMode_{3};
+  int mpcEveryNTicks_ = 0;   // 0: own MPC thread at mpcDesiredFrequency; n > 0: lock-step, one MPC pass every n control ticks
+  long tick_ = 0;
+  bool coldStarted_ = false;
 };
 
 }  // namespace legged

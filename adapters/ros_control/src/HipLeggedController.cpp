@@ -1,8 +1,11 @@
 // legged/HipLeggedController: LeggedController::{init, starting, update, MPC thread} (legged_controllers/src/LeggedController.cpp:
 // 41-135,137-278,376-431) re-expressed over hunter_hip.hpp.  What runs where:
-//   control thread (update, 500 Hz)   sensors -> hb_estimator_update -> hb_mpc_publish + hb_wbc_update (policy evaluation + WBC)
+//   control thread (update, 500 Hz)   sensors -> hb_estimator_update -> hb_wbc_update (policy evaluation + WBC)
 //                                     -> hb_joint_command (PD law, limit protection, e-stop) -> HybridJointHandle::setCommand
 //   MPC thread (mpcDesiredFrequency)  GaitSchedule (host) -> hb_refgen_update (targets, footholds, swing splines, IK) -> hb_mpc_solve
+//                                     -> hb_mpc_publish (the policy hand-over is an MPC-thread call)
+// Settings come from the reference's own files (task.info / hunter.urdf / reference.info, as LeggedController::init reads them)
+// or from the packaged image of the same values (data/hunter_params.bin); nothing is hard-coded here.
 #include "hunter_hip_controllers/HipLeggedController.h"
 
 #include <chrono>
@@ -15,18 +18,27 @@ namespace legged {
 using hunter_hip::vector_t;
 
 bool HipLeggedController::init(hardware_interface::RobotHW* robot_hw, ros::NodeHandle& controller_nh) {
-  // ---- parameters: the flattened URDF + task.info + reference.info (tools/make_hunter_params.py) — LeggedController.cpp:44-71
-  std::string paramsFile;
-  if (!controller_nh.getParam("/hunter_hip/params_file", paramsFile)) {
-    ROS_ERROR("[HipLeggedController] /hunter_hip/params_file is not set");
+  // ---- parameters — LeggedController.cpp:44-71 reads /taskFile, /urdfFile, /referenceFile; so does this plugin (C++ ingest,
+  // hunter_ingest.hpp).  Alternatively /hunter_hip/params_file names the packaged image of the same values.
+  std::string taskFile, urdfFile, referenceFile, gaitFile, paramsFile;
+  const bool haveFiles = controller_nh.getParam("/taskFile", taskFile) && controller_nh.getParam("/urdfFile", urdfFile) &&
+                         controller_nh.getParam("/referenceFile", referenceFile);
+  controller_nh.getParam("/gaitCommandFile", gaitFile);
+  if (!haveFiles && !controller_nh.getParam("/hunter_hip/params_file", paramsFile)) {
+    ROS_ERROR("[HipLeggedController] neither /taskFile + /urdfFile + /referenceFile nor /hunter_hip/params_file is set");
     return false;
   }
   int device = 0;
   controller_nh.getParam("/hunter_hip/device", device);
-  controller_nh.getParam("/hunter_hip/time_horizon", timeHorizon_);
-  controller_nh.getParam("/hunter_hip/mpc_frequency", mpcDesiredFrequency_);
   try {
-    hunter_hip::loadPackagedParameters(paramsFile, model_, config_);
+    params_ = haveFiles ? hunter_hip::loadParameters(taskFile, urdfFile, referenceFile, gaitFile) : hunter_hip::loadParametersBlob(paramsFile);
+    model_ = params_.model;
+    config_ = params_.config;
+    timeHorizon_ = params_.timeHorizon;               // task.info mpc.timeHorizon
+    mpcDesiredFrequency_ = params_.mpcFrequency;      // task.info mpc.mpcDesiredFrequency
+    controller_nh.getParam("/hunter_hip/time_horizon", timeHorizon_);
+    controller_nh.getParam("/hunter_hip/mpc_frequency", mpcDesiredFrequency_);
+    controller_nh.getParam("/hunter_hip/mpc_every_n_ticks", mpcEveryNTicks_);   // > 0: lock-step MPC inside update() (simulation)
     const int maxNodes = int(std::ceil(timeHorizon_ / config_.dt)) + 8;   // event-clipped grid: a few nodes more than T / dt
     ctx_.reset(new hunter_hip::Context(model_, config_, /*batch*/ 1, maxNodes, device));
     setupMpc();
@@ -46,22 +58,12 @@ bool HipLeggedController::init(hardware_interface::RobotHW* robot_hw, ros::NodeH
     contactHandles_.push_back(contactInterface->getHandle(name));
   imuSensorHandle_ = robot_hw->get<hardware_interface::ImuSensorInterface>()->getHandle("imu_link");
 
-  // ---- state estimate — setupStateEstimate, LeggedController.cpp:75-83 (settings: task.info kalmanFilter block)
-  hb_estimator_config est{};
-  est.foot_radius = 0.02;
-  est.imu_process_noise_position = 0.02;
-  est.imu_process_noise_velocity = 0.02;
-  est.foot_process_noise_position = 0.002;
-  est.foot_sensor_noise_position = 0.005;
-  est.foot_sensor_noise_velocity = 0.1;
-  est.foot_height_sensor_noise = 0.01;
-  controller_nh.getParam("/hunter_hip/kalman/foot_radius", est.foot_radius);
-  stateEstimate_.reset(new hunter_hip::KalmanFilterEstimate(*ctx_, est));
+  // ---- state estimate — setupStateEstimate, LeggedController.cpp:75-83; noise settings = the kalmanFilter block of task.info
+  // (KalmanFilterEstimate::loadSettings, LinearKalmanFilter.cpp:317-335)
+  stateEstimate_.reset(new hunter_hip::KalmanFilterEstimate(*ctx_, params_.estimator));
 
-  // gains: dynamic_reconfigure defaults of legged_controllers/cfg/Tutorials.cfg:6-16
-  gains_.kp_big_stance = 40.0; gains_.kp_big_swing = 30.0; gains_.kd_big = 2.0;
-  gains_.kp_small_stance = 30.0; gains_.kp_small_swing = 20.0; gains_.kd_small = 2.0; gains_.kd_feet = 0.01;
-  gains_.kp_position = 10.0; gains_.kd_position = 3.0;
+  // gains: dynamic_reconfigure defaults of legged_controllers/cfg/Tutorials.cfg:6-16 (hunter_ingest.hpp)
+  gains_ = params_.gains;
 
   // ---- topics — LeggedController.cpp:113-121 and the target publisher's /cmd_vel
   ros::NodeHandle nh;
@@ -74,44 +76,40 @@ bool HipLeggedController::init(hardware_interface::RobotHW* robot_hw, ros::NodeH
 
 void HipLeggedController::setupMpc() {   // ≙ LeggedController::setupMpc (:376-388): the solver and its reference manager
   mpcMrtInterface_.reset(new hunter_hip::MpcMrtInterface(*ctx_));
-  hb_refgen_config rg{};
-  rg.dt = config_.dt;
-  rg.com_height = 0.63;              // reference.info:5
-  rg.next_position_z = 0.02;         // task.info swing_trajectory_config
-  rg.swing_height = 0.06;
-  rg.swing_time_scale = 0.15;
-  const double bias[4][3] = {{0.034, 0.11, -0.63}, {0.034, -0.11, -0.63}, {-0.056, 0.11, -0.63}, {-0.056, -0.11, -0.63}};   // task.info:28-31
-  for (int i = 0; i < 4; ++i)
-    for (int a = 0; a < 3; ++a) rg.feet_bias[i][a] = bias[i][a];
-  for (int j = 0; j < HB_NJ; ++j) rg.default_joints[j] = config_.default_joint_state[j];
-  rg.joint_ik = 1;
-  // initialModeSchedule / defaultModeSequenceTemplate of reference.info:21-46
-  hunter_hip::GaitSchedule gait(hunter_hip::ModeSchedule{{0.5}, {3, 3}}, hunter_hip::ModeSequenceTemplate{{0.0, 1.0}, {3}},
-                                /*phaseTransitionStanceTime*/ 0.1);
+  const hb_refgen_config rg = params_.refgen;   // comHeight / defaultJointState (reference.info), swing_trajectory_config (task.info)
+  // initialModeSchedule / defaultModeSequenceTemplate of reference.info:21-46, phaseTransitionStanceTime of task.info:11
+  hunter_hip::GaitSchedule gait(hunter_hip::ModeSchedule{params_.initialEventTimes, params_.initialModes},
+                                hunter_hip::ModeSequenceTemplate{params_.defaultTemplate.switchingTimes, params_.defaultTemplate.modes},
+                                params_.phaseTransitionStanceTime);
   referenceManager_.reset(new hunter_hip::ReferenceManager(*ctx_, rg, std::vector<hunter_hip::GaitSchedule>{gait}));
   referenceManager_->setWalkGaitSelection(true);   // gaitType_ 0: stance / trot from the averaged command speed (walkGait)
 }
 
+// one pass of the MPC thread body (LeggedController.cpp:396-412): references, one SQP call, policy hand-over
+void HipLeggedController::mpcPass() {
+  hunter_hip::SystemObservation obs;
+  double cmd[4];
+  { std::lock_guard<std::mutex> lk(cmdMutex_); obs = currentObservation_; std::copy(cmdVel_, cmdVel_ + 4, cmd); }
+  const vector_t initTime{obs.time}, cmdVel(cmd, cmd + 4);
+  referenceManager_->preSolverRun(initTime, timeHorizon_, cmdVel, &obs.state);     // modifyReferences
+  if (!coldStarted_) { mpcMrtInterface_->resetMpcNode(obs.state); coldStarted_ = true; }
+  mpcMrtInterface_->setCurrentObservation(obs);
+  mpcMrtInterface_->advanceMpc();                                                  // :406 (solve + publish, both on this thread)
+  std::vector<int32_t> status(1);
+  ctx_->check(hb_mpc_get_status(ctx_->get(), status.data()), "hb_mpc_get_status");
+  if (status[0] == HB_INST_NAN) throw std::runtime_error("SQP iteration failed (non-finite value / Riccati pivot)");
+  firstStartMpc_ = true;
+}
+
 void HipLeggedController::setupMrt() {   // ≙ LeggedController::setupMrt (:390-431): the MPC thread
   controllerRunning_ = true;
+  if (mpcEveryNTicks_ > 0) return;       // lock-step mode: update() runs mpcPass() itself every n-th tick
   mpcThread_ = std::thread([this]() {
-    bool coldStarted = false;
     while (controllerRunning_) {
       if (!mpcRunning_) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; }
       const auto t0 = std::chrono::steady_clock::now();
       try {
-        hunter_hip::SystemObservation obs;
-        double cmd[4];
-        { std::lock_guard<std::mutex> lk(cmdMutex_); obs = currentObservation_; std::copy(cmdVel_, cmdVel_ + 4, cmd); }
-        const vector_t initTime{obs.time}, cmdVel(cmd, cmd + 4);
-        referenceManager_->preSolverRun(initTime, timeHorizon_, cmdVel, &obs.state);     // modifyReferences
-        if (!coldStarted) { mpcMrtInterface_->resetMpcNode(obs.state); coldStarted = true; }
-        mpcMrtInterface_->setCurrentObservation(obs);
-        mpcMrtInterface_->advanceMpc();                                                  // :406
-        std::vector<int32_t> status(1);
-        ctx_->check(hb_mpc_get_status(ctx_->get(), status.data()), "hb_mpc_get_status");
-        if (status[0] == HB_INST_NAN) throw std::runtime_error("SQP iteration failed (non-finite value / Riccati pivot)");
-        firstStartMpc_ = true;
+        mpcPass();
       } catch (const std::exception& e) {   // :413-418
         controllerRunning_ = false;
         ROS_ERROR("[HipLeggedController MPC thread] Error : %s", e.what());
@@ -155,12 +153,21 @@ void HipLeggedController::updateStateEstimation(const ros::Time& time, const ros
 void HipLeggedController::update(const ros::Time& time, const ros::Duration& period) {   // ≙ :137-278
   const ros::Time shifted = time - startingTime_;
   updateStateEstimation(shifted, period);
+  if (mpcEveryNTicks_ > 0 && mpcRunning_ && (tick_++ % mpcEveryNTicks_) == 0) {   // lock-step MPC (simulation): same body, this thread
+    try {
+      mpcPass();
+    } catch (const std::exception& e) {
+      ROS_ERROR("[HipLeggedController] MPC error : %s", e.what());
+      stopRequest(time);
+      return;
+    }
+  }
   if (!firstStartMpc_) return;   // no policy yet: the handles keep their last command
-  const vector_t tNow{currentObservation_.time};
+  const vector_t tNow{shifted.toSec()};
   const std::vector<int32_t> walk{setWalkFlag_ ? 1 : 0};
   hunter_hip::controllerUpdate(*mpcMrtInterface_, tNow, measuredRbdState_, &walk, period.toSec(), control_);   // :151-185
   plannedMode_ = control_.plannedMode[0];
-  currentObservation_.input = control_.optimizedInput;
+  { std::lock_guard<std::mutex> lk(cmdMutex_); currentObservation_.input = control_.optimizedInput; }   // the MPC thread copies the observation
   // joint command law with limit protection / e-stop latch / unloaded-controller branch on the device (:186-257)
   const int32_t loaded = loadControllerFlag_ ? 1 : 0, estop = emergencyStopFlag_ ? 1 : 0;
   ctx_->check(hb_joint_set_flags(ctx_->get(), &loaded, emergencyStopFlag_ ? &estop : nullptr), "hb_joint_set_flags");

@@ -1,6 +1,10 @@
-// TEST STAND-IN (tests/test_ros_adapter_syntax.py only): the sliver of roscpp HipLeggedController touches, declarations only.
+// MOCK ros_control layer (tests only): the part of roscpp legged/HipLeggedController touches, functional enough to RUN the
+// plugin without ROS — a parameter map behind NodeHandle::getParam, a topic registry that delivers messages to the subscribed
+// callbacks, Time / Duration arithmetic.  tests/cpp/plugin_test.cpp drives the controller through it.
 #pragma once
 #include <cstdio>
+#include <functional>
+#include <map>
 #include <memory>
 #include <string>
 namespace ros {
@@ -13,15 +17,48 @@ struct Duration {
 };
 struct Time {
   Time() {}
+  explicit Time(double s) : sec_(s) {}
   double toSec() const { return sec_; }
-  Time operator-(const Duration& d) const { Time t; t.sec_ = sec_ - d.sec_; return t; }
+  Time operator-(const Duration& d) const { return Time(sec_ - d.sec_); }
+  Time operator+(const Duration& d) const { return Time(sec_ + d.sec_); }
   double sec_ = 0.0;
 };
 struct Subscriber {};
+namespace mock {
+struct Param { bool is_string = false; std::string s; double d = 0.0; };
+inline std::map<std::string, Param>& params() { static std::map<std::string, Param> p; return p; }
+inline void setParam(const std::string& k, const std::string& v) { Param p; p.is_string = true; p.s = v; params()[k] = p; }
+inline void setParam(const std::string& k, double v) { Param p; p.d = v; params()[k] = p; }
+inline std::map<std::string, std::function<void(const std::shared_ptr<const void>&)>>& topics() {
+  static std::map<std::string, std::function<void(const std::shared_ptr<const void>&)>> t;
+  return t;
+}
+template <class M>
+bool publish(const std::string& topic, const M& msg) {
+  auto it = topics().find(topic);
+  if (it == topics().end()) return false;
+  it->second(std::static_pointer_cast<const void>(std::make_shared<const M>(msg)));
+  return true;
+}
+}  // namespace mock
 class NodeHandle {
  public:
-  template <class T> bool getParam(const std::string&, T&) const { return false; }
-  template <class M, class C> Subscriber subscribe(const std::string&, int, void (C::*)(const typename M::ConstPtr&), C*) { return Subscriber(); }
+  bool getParam(const std::string& k, std::string& v) const {
+    auto it = mock::params().find(k);
+    if (it == mock::params().end() || !it->second.is_string) return false;
+    v = it->second.s;
+    return true;
+  }
+  template <class T> bool getParam(const std::string& k, T& v) const {
+    auto it = mock::params().find(k);
+    if (it == mock::params().end() || it->second.is_string) return false;
+    v = T(it->second.d);
+    return true;
+  }
+  template <class M, class C> Subscriber subscribe(const std::string& topic, int, void (C::*cb)(const typename M::ConstPtr&), C* obj) {
+    mock::topics()[topic] = [cb, obj](const std::shared_ptr<const void>& p) { (obj->*cb)(std::static_pointer_cast<const M>(p)); };
+    return Subscriber();
+  }
 };
 }  // namespace ros
-#define ROS_ERROR(...) std::fprintf(stderr, __VA_ARGS__)
+#define ROS_ERROR(...) (std::fprintf(stderr, __VA_ARGS__), std::fprintf(stderr, "\n"))

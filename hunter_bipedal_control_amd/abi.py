@@ -185,15 +185,29 @@ def make_refgen_config(params: dict, joint_ik: bool = True) -> RefgenConfig:
     return out
 
 
-PARAMS_BLOB_MAGIC = 0x48423031  # "HB01"
+PARAMS_BLOB_MAGIC = 0x48423032  # "HB02"
 
 
 def write_params_blob(params: dict, path) -> None:
-    """Binary image {magic, sizeof(hb_model), sizeof(hb_config), 0, hb_model, hb_config} for C++ hosts
-    (include/hunter_hip.hpp loadPackagedParameters); defaults of make_config (WeightedWbc)."""
+    """Binary image of everything a C++ host needs at LeggedController::init, version 2 (include/hunter_ingest.hpp
+    loadParametersBlob / writeParametersBlob write and read the same bytes): header {magic, sizeof of the five structs, number of
+    initial event times, number of template switching times}, hb_model, hb_config (defaults of make_config: WeightedWbc),
+    hb_estimator_config, hb_refgen_config, hb_joint_gains, {timeHorizon, mpcDesiredFrequency, phaseTransitionStanceTime}, the
+    initial mode schedule and the default mode-sequence template of reference.info."""
     import struct
+    c = params["config"]
     model, config = make_model(params), make_config(params)
+    est, rg, gains = make_estimator_config(params), make_refgen_config(params), make_joint_gains()
+    ev, modes = c["initial_mode_schedule"]["event_times"], c["initial_mode_schedule"]["modes"]
+    tt, tm = c["default_mode_template"]["switching_times"], c["default_mode_template"]["modes"]
+    assert len(modes) == len(ev) + 1 and len(tm) == len(tt) - 1
     with open(path, "wb") as f:
-        f.write(struct.pack("<4I", PARAMS_BLOB_MAGIC, C.sizeof(HbModel), C.sizeof(HbConfig), 0))
-        f.write(bytes(model))
-        f.write(bytes(config))
+        f.write(struct.pack("<8I", PARAMS_BLOB_MAGIC, C.sizeof(HbModel), C.sizeof(HbConfig), C.sizeof(HbEstimatorConfig), C.sizeof(RefgenConfig),
+                            C.sizeof(HbJointGains), len(ev), len(tt)))
+        for st in (model, config, est, rg, gains):
+            f.write(bytes(st))
+        f.write(struct.pack("<3d", c["time_horizon"], c["mpc_frequency"], c["phase_transition_stance_time"]))
+        f.write(struct.pack(f"<{len(ev)}d", *ev))
+        f.write(struct.pack(f"<{len(modes)}i", *modes))
+        f.write(struct.pack(f"<{len(tt)}d", *tt))
+        f.write(struct.pack(f"<{len(tm)}i", *tm))

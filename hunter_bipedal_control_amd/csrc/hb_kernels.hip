@@ -1367,6 +1367,20 @@ int32_t hb_lcm_frame(const char* channel, uint32_t seq, const uint8_t* payload, 
   return int32_t(total);
 }
 
+int32_t hb_lcm_unframe(const uint8_t* frame, int32_t frame_len, char* channel, int32_t channel_cap, uint32_t* seq, int32_t* payload_offset) {
+  if (!frame || frame_len < 10 || !channel || channel_cap < 2 || !payload_offset) return HB_ERR_ARG;
+  uint32_t magic = 0, sq = 0;
+  for (int b = 0; b < 4; ++b) { magic = (magic << 8) | frame[b]; sq = (sq << 8) | frame[4 + b]; }
+  if (magic != 0x4c433032u) return HB_ERR_ARG;   // not a short LCM message ("LC03" fragments are not produced by this path)
+  int32_t i = 8;
+  while (i < frame_len && frame[i] != 0) ++i;
+  if (i >= frame_len || i - 8 >= channel_cap || i - 8 > 63) return HB_ERR_ARG;
+  std::memcpy(channel, frame + 8, size_t(i - 8) + 1);
+  if (seq) *seq = sq;
+  *payload_offset = i + 1;
+  return frame_len - (i + 1);
+}
+
 int32_t hb_joint_command_lcm(hb_ctx* ctx, const hb_joint_gains* gains, double dt, int64_t timestamp_ns, uint8_t* low_cmd) {
   if (ctx) lazy_join(ctx);
   if (!ctx || !gains || !low_cmd) return HB_ERR_ARG;

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "hb_joint_get_emergency_stop", "hb_set_resident_time", "hb_get_wbc_iterations", "hb_ik_solve", "hb_debug_chunk_counters",
 ]
 # include/hunter_lcm.h
-LCM_SYMBOLS = ["hb_lcm_fingerprint", "hb_lcm_encoded_size", "hb_lcm_field_count", "hb_lcm_encode", "hb_lcm_decode", "hb_lcm_frame",
+LCM_SYMBOLS = ["hb_lcm_fingerprint", "hb_lcm_encoded_size", "hb_lcm_field_count", "hb_lcm_encode", "hb_lcm_decode", "hb_lcm_frame", "hb_lcm_unframe",
                "hb_joint_command_lcm", "hb_estimator_update_lcm"]
 
 

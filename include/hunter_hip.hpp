@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "hunter_hip.h"
+#include "hunter_ingest.hpp"
 #include "hunter_lcm.h"
 
 namespace hunter_hip {
@@ -64,17 +65,13 @@ struct ReferenceTables {
   vector_t swingRef;            // [batch][maxNodes][4][6]
 };
 
-// Binary image of {hb_model, hb_config} written by tools/make_hunter_params.py (data/hunter_params.bin): the
-// flattened URDF + task.info / reference.info the reference reads at LeggedController::init.
+// The packaged parameter image (data/hunter_params.bin, written by tools/make_hunter_params.py; format HB02, hunter_ingest.hpp):
+// the flattened URDF + task.info / reference.info the reference reads at LeggedController::init.  hunter_ingest.hpp also reads
+// the reference's files themselves (loadParameters).
 inline void loadPackagedParameters(const std::string& path, hb_model& model, hb_config& config) {
-  std::FILE* f = std::fopen(path.c_str(), "rb");
-  if (!f) throw std::invalid_argument("[hunter_hip] parameter file not found: " + path);
-  uint32_t head[4] = {0, 0, 0, 0};
-  const bool ok = std::fread(head, sizeof(head), 1, f) == 1 && head[0] == 0x48423031u /* "HB01" */ &&
-                  head[1] == sizeof(hb_model) && head[2] == sizeof(hb_config) &&
-                  std::fread(&model, sizeof(hb_model), 1, f) == 1 && std::fread(&config, sizeof(hb_config), 1, f) == 1;
-  std::fclose(f);
-  if (!ok) throw std::invalid_argument("[hunter_hip] parameter file does not match this ABI: " + path);
+  const Parameters p = loadParametersBlob(path);
+  model = p.model;
+  config = p.config;
 }
 
 class Context {
@@ -135,10 +132,17 @@ class MpcMrtInterface {
   }
   void setCurrentObservation(const SystemObservation& obs) { setCurrentObservation(std::vector<SystemObservation>{obs}); }
   // MPC_MRT_Interface::advanceMpc (LeggedController.cpp:406): one SQP solve from the current observation (asynchronous
-  // on the library's MPC stream, like the reference's MPC thread)
-  void advanceMpc() { ctx_.check(hb_mpc_solve(ctx_.get(), x0_.data()), "hb_mpc_solve"); }
-  // MPC_MRT_Interface::updatePolicy (LeggedController.cpp:154)
-  void updatePolicy() { ctx_.check(hb_mpc_publish(ctx_.get()), "hb_mpc_publish"); }
+  // on the library's MPC stream, like the reference's MPC thread), then the hand-over of the new policy.  hb_mpc_publish is an
+  // MPC-THREAD call (include/hunter_hip.h): it must be ordered with the table updates and the warm start that precede the
+  // solve on this thread — published from the control thread it could pair the previous iterate with the next call's time /
+  // mode tables.  The policy evaluation of the control thread (hb_wbc_update) picks the new buffers up through stream events.
+  void advanceMpc() {
+    ctx_.check(hb_mpc_solve(ctx_.get(), x0_.data()), "hb_mpc_solve");
+    ctx_.check(hb_mpc_publish(ctx_.get()), "hb_mpc_publish");
+  }
+  // MPC_MRT_Interface::updatePolicy (LeggedController.cpp:154): kept for call-site parity; the hand-over already happened in
+  // advanceMpc on the MPC thread, nothing is left to do on the control thread
+  void updatePolicy() {}
   // PrimalSolution of the last solve (LeggedController.cpp:269, visualisation)
   void getSolution(vector_t& stateTrajectory, vector_t& inputTrajectory) const {
     const size_t B = size_t(ctx_.batch()), N = size_t(ctx_.maxNodes());

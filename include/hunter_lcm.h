@@ -46,6 +46,11 @@ int32_t hb_lcm_decode(int32_t type, int32_t n, const uint8_t* in, int64_t* times
  * not fit `maxlen`.  Published LCM format; the reference holds no vector for it (it links liblcm). */
 int32_t hb_lcm_frame(const char* channel, uint32_t seq, const uint8_t* payload, int32_t payload_len, uint8_t* out, int32_t maxlen);
 
+/* Inverse of hb_lcm_frame for a received datagram: channel name (NUL-terminated, at most channel_cap - 1 characters), sequence
+ * number and the offset of the payload inside `frame`.  Returns the payload length, or HB_ERR_ARG for anything that is not a
+ * well-formed short LCM message. */
+int32_t hb_lcm_unframe(const uint8_t* frame, int32_t frame_len, char* channel, int32_t channel_cap, uint32_t* seq, int32_t* payload_offset);
+
 /* ---- device-side packers: the batch never leaves the GPU in anything but wire format ----------------------------------
  * hb_joint_command_lcm = hb_joint_command followed by the packing of LeggedMujocoSim::write
  * (legged_examples/legged_mujoco/src/LeggedMujocoSim.cpp:56-62): joint_pos = posDes, joint_vel = velDes, kp, kd,

@@ -30,18 +30,6 @@ def _build():
     return exe
 
 
-def test_params_blob_matches_packaged_json(params):
-    """data/hunter_params.bin is the byte image of the structs abi.make_model / make_config build from the JSON."""
-    import ctypes as C
-    import struct
-    from hunter_bipedal_control_amd import abi
-    from oracle import workloads
-    raw = PARAMS_BIN.read_bytes()
-    magic, sm, sc, _ = struct.unpack("<4I", raw[:16])
-    assert magic == abi.PARAMS_BLOB_MAGIC and sm == C.sizeof(abi.HbModel) and sc == C.sizeof(abi.HbConfig)
-    assert raw[16:16 + sm] == bytes(abi.make_model(params)) and raw[16 + sm:] == bytes(abi.make_config(params))
-
-
 def test_adapter_builds_and_fails_loudly_without_gpu():
     import torch
     exe = _build()

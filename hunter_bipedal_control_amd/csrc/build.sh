@@ -7,8 +7,11 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+OUT=../libhunter_hip.so
+# --ablate: the profiling variant with the phase-by-phase exits compiled in (tools/perf_quick.py --lib variants/libhunter_hip_ablate.so --ablate-lq)
+if [ "$1" = "--ablate" ]; then shift; mkdir -p ../../variants; OUT=../../variants/libhunter_hip_ablate.so; set -- -DHB_ABLATE "$@"; fi
 LOG=$(mktemp)
-$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Rpass-analysis=kernel-resource-usage -o ../libhunter_hip.so hb_kernels.hip "$@" 2> "$LOG" || { cat "$LOG" >&2; rm -f "$LOG"; exit 1; }
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Rpass-analysis=kernel-resource-usage -o $OUT hb_kernels.hip "$@" 2> "$LOG" || { cat "$LOG" >&2; rm -f "$LOG"; exit 1; }
 grep -E "error|warning:" "$LOG" | grep -v "Wcomment" >&2 || true
 python3 - "$LOG" <<'PY'
 import re, sys

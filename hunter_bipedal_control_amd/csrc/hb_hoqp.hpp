@@ -923,7 +923,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   }
   cx.sync();
 #endif
-  if (C.debug_stop == 43) return;  // profiling ablation: level 0 + kernel basis
+  HB_ABLATE_STOP(C.debug_stop == 43);  // profiling ablation: level 0 + kernel basis
   // ------------------------------------------------------------------ level 1: base acceleration
   const double* A1 = Aw + 3 * wc.n_sw * 16;
   const double* b1 = bw + 3 * wc.n_sw;
@@ -961,7 +961,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   }
   cx.sync();
   for (int i = cx.lane; i < NW; i += cx.nlanes) x[i] = g[i];
-  if (C.debug_stop == 44) return;  // profiling ablation: ... + level-1 QP
+  HB_ABLATE_STOP(C.debug_stop == 44);  // profiling ablation: ... + level-1 QP
   // kernel of A1 Z1 (6 x n1): QR of its transpose (n1 x 6)
   for (int idx = cx.lane; idx < n1 * 6; idx += cx.nlanes) Tm[idx] = AZ[(idx % 6) * 12 + idx / 6];
   cx.sync();
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(64) void k_hwbc(WbcBatch w, const DevModel* __restr
   extern __shared__ __attribute__((aligned(16))) double lds_h[];
   // hb_config.reserved = 41 / 42 stops the cascade after level 0 / 1 (profiling ablation only)
   hwbc_solve(WbcDeviceCtx(), *M, *C, w.xdes + size_t(inst) * HB_NX, w.udes + size_t(inst) * HB_NU, w.rbd + size_t(inst) * HB_NRBD,
-             w.mode[inst], lds_h, w.sol + size_t(inst) * NW, w.status + inst, C->debug_stop == 41 ? 1 : (C->debug_stop == 42 ? 2 : 3));
+             w.mode[inst], lds_h, w.sol + size_t(inst) * NW, w.status + inst, (HB_ABLATE_ON && C->debug_stop == 41) ? 1 : ((HB_ABLATE_ON && C->debug_stop == 42) ? 2 : 3));
   if (threadIdx.x == 0) w.iters[inst] = 0;
 }
 #endif

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
       }
     }
     cx.sync();
-    if (dbg == 20) { if (k > 0) HB_RIC_FETCH(k - 1, l); continue; }  // profiling ablation: staging only
+    if (HB_ABLATE_ON && dbg == 20) { if (k > 0) HB_RIC_FETCH(k - 1, l); continue; }  // profiling ablation: staging only
     // n_til: number of projected inputs of this stage (uniform; requested one stage ahead with the prefetch)
     const int n_til = int(meta_nf) + int(meta_nz);
     ric_phase12(cxk, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE, n_til, dbg);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
       meta_nf = meta[0];
       meta_nz = meta[1];
     }
-    if (dbg == 21 || dbg == 22 || dbg == 23) continue;
+    if (HB_ABLATE_ON && (dbg == 21 || dbg == 22 || dbg == 23)) continue;
     RicT3 t;
     ric_phase3_mma(cxk, lds, t);
     {

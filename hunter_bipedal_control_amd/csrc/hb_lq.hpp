@@ -134,7 +134,7 @@ struct LqLds {
   static constexpr int total = p1_end > tail_end ? p1_end : tail_end;
 };
 static_assert(LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are still being read");
-static_assert(LqLds::Qd >= LqLds::p1_end, "the reference state is parked in Qd during phase 1");
+static_assert(LqLds::Qd >= LqLds::p1_end && LqLds::ru >= LqLds::p1_end, "the reference / next state are parked in Qd / ru during phase 1");
 static_assert(LqLds::rjk + 10 <= LqLds::RZ, "P_j | R_jj | r_j must fit over G'G | W");
 static_assert(LqLds::total * 8 <= 16384, "k_lq: LDS per node must allow 10 workgroups per CU");
 // row of CDt that holds direction d (d < 22 or d >= 34)
@@ -379,7 +379,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   for (int i = cx.lane; i < 22; i += cx.nlanes)
     xplus[i] = (i < 12) ? xs[i] + 0.5 * dt * (fv[i] + fv[12 + i]) : xs[i] + dt * us[i];
   cx.sync();
-  if (C.debug_stop == 1) return;
+  HB_ABLATE_STOP(C.debug_stop == 1);
   // slot classification (uniform)
   int n_eq = 0, n_soft = 0, n_f = 0;
   for (int i = 0; i < HB_NC; ++i) {
@@ -506,7 +506,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       if (!((donemask >> i) & 1)) perm[w++] = i;
   }
   cx.sync();
-  if (C.debug_stop == 2) return;
+  HB_ABLATE_STOP(C.debug_stop == 2);
   const int rank = rank_l;
   const int nz = 10 - rank;
   // Solve A11 Y = -W1 (23 right-hand sides) and, in the same instruction stream, the kernel basis
@@ -561,7 +561,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     }
   }
 
-  if (C.debug_stop == 3) return;
+  HB_ABLATE_STOP(C.debug_stop == 3);
   // -------------------------------------------------------------- phase 4a: cost pieces, one "role" per lane
   // roles 0..21 state entries, 22..43 input entries, 44..55 constraint slots, 56..59 friction barrier values.
   // Partial sums (cost, defect^2, equality^2) are reduced through LDS (scratch aliases Mm, not live yet).
@@ -600,6 +600,8 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       if (cf[i]) shift_sum += -coneb[12 * i + 8] * C.friction_shift;
     for (int role = cx.lane; role < 64; role += cx.nlanes) {
       double pc = 0, pd = 0, pe = 0;
+      // (device: x_next is parked in the ru buffer, which the input roles below overwrite — read it before any role writes)
+      const double xnext_i = role < 22 ? xnext_at(role) : 0.0;
       // two-sided relaxed barrier of this role, evaluated once on a common path (joint position limits, F_z limits,
       // joint velocity limits): value, first and second derivative sums
       double bval = 0.0, bd1 = 0.0, bd2 = 0.0;
@@ -640,8 +642,9 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         }
         Qd[i] = qd_;
         qx[i] = qg;
-        const double dd = xplus[i] - xnext_at(i);
+        const double dd = xplus[i] - xnext_i;
         pd += dd * dd;
+        xplus[i] = dd;  // from here on the slot holds the shooting defect x+ - x_next (b~ below is its only other reader)
       } else if (role < 34) {
         const int m = role - 22, foot = m / 3, a = m % 3;
         const double du = us[m] - ((a == 2 && cf[foot]) ? fz_nom : 0.0);
@@ -713,7 +716,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   cx.sync();
 #endif
-  if (C.debug_stop == 4) return;
+  HB_ABLATE_STOP(C.debug_stop == 4);
   // soft rows: gradients and the dense pieces P_j, R_jj
   for (int c = cx.lane; c < 22; c += cx.nlanes) {
     double s = 0;
@@ -759,7 +762,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   cx.sync();
 
-  if (C.debug_stop == 5) return;
+  HB_ABLATE_STOP(C.debug_stop == 5);
   // -------------------------------------------------------------- phase 3+4b: write the projected record
   const int ntil = n_f + nz;
   int flist = 0;  // contact feet in foot order, two bits each: projected force column block j belongs to foot (flist >> 2j) & 3
@@ -794,7 +797,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     }
   }
   cx.sync();
-  if (C.debug_stop == 30) return;
+  HB_ABLATE_STOP(C.debug_stop == 30);
   // B~ columns: contact forces (foot order) first, zero padding after the kernel directions; one column per (uniform)
   // step, one row per lane (the kernel columns of rows 0..11 came from the tile above)
   for (int row = cx.lane; row < 22; row += cx.nlanes) {
@@ -809,7 +812,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         rec[rec_B(row, col)] = dt * Z[(row - 12) * 6 + col - n_f];
       }
     }
-    double s = xplus[row] - xnext_at(row);  // row == lane
+    double s = xplus[row];  // the shooting defect of this row (stored by the cost phase)
     if (row >= 12) rec[REC_DQ + row - 12] = s;
     if (row < 12) {
       s += btmp[row];
@@ -821,7 +824,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     }
     rec[rec_b(row)] = s;
   }
-  if (C.debug_stop == 31) return;
+  HB_ABLATE_STOP(C.debug_stop == 31);
   // Q~ = Q + Kx' M + P_j' Kx ,  Q = diag(Qd) + w sum_soft c c'      (three accumulating GEMMs on the matrix cores)
   // Q~ is symmetric up to rounding: only its upper block triangle is formed — tiles (0,0), (0,1) and (1,1), 27 MFMAs
   // instead of 36 — and the off-diagonal tile is stored twice (k_ric_bwd mirrors the upper triangle anyway).
@@ -847,7 +850,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     });
     tile_store_rm<22>(cx, t1, 6, 6, rec + REC_QT + 16 * 22 + 16, dt);
   }
-  if (C.debug_stop == 32) return;
+  HB_ABLATE_STOP(C.debug_stop == 32);
   // q~ = q + Kx' r_j + M' ke
   for (int a = cx.lane; a < 22; a += cx.nlanes) {
     double s = qx[a];
@@ -868,7 +871,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     for (int a = 0; a < NU_T; ++a)
       if (a < n_f || a >= ntil) rec[rec_P(a, c)] = 0.0;
   }
-  if (C.debug_stop == 33) return;
+  HB_ABLATE_STOP(C.debug_stop == 33);
   // R~ (12x12): contact-force blocks, Z' R_jj Z, identity on the padding
   for (int idx = cx.lane; idx < NU_T * NU_T; idx += cx.nlanes) {
     const int ca = idx / NU_T, cb = idx % NU_T;
@@ -899,7 +902,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     }
     rec[rec_r(col)] = dt * s;
   }
-  if (C.debug_stop == 34) return;
+  HB_ABLATE_STOP(C.debug_stop == 34);
   // recovery data
   for (int k = cx.lane; k < 10; k += cx.nlanes) rec[REC_KE + k] = Kx[k * 23 + 22];
   for (int idx = cx.lane; idx < 60; idx += cx.nlanes) rec[REC_Z + idx] = Z[idx];
@@ -937,14 +940,14 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     xe[i] = in.x[i];
   }
 #if defined(__HIP_DEVICE_COMPILE__)
-  // entry `lane` of the next node's state, requested now and used (by the same lane) in the cost phase and in b~
-  const double xnext_l = in.xnext[cx.lane < 22 ? cx.lane : 0];
-  // the reference state waits in the Q-diagonal buffer, which nothing touches before the cost phase (there lane i reads
-  // entry i, then overwrites it): two registers less across the projection
+  // the reference state and the next node's state wait in the Q-diagonal / input-gradient buffers, which nothing touches before
+  // the cost phase (there lane i reads entry i of both, then overwrites them; the defect x+ - x_next it forms stays in the x+
+  // slot for b~): no register is held across the model phase and the projection for them
   double* xref_lds = lds + LqLds::Qd;
-  if (cx.lane < 22) xref_lds[cx.lane] = in.xref[cx.lane];
+  double* xnext_lds = lds + LqLds::ru;
+  if (cx.lane < 22) { xref_lds[cx.lane] = in.xref[cx.lane]; xnext_lds[cx.lane] = in.xnext[cx.lane]; }
   auto xref_at = [xref_lds](int i) { return xref_lds[i]; };
-  auto xnext_at = [xnext_l](int) { return xnext_l; };
+  auto xnext_at = [xnext_lds](int i) { return xnext_lds[i]; };
 #else
   auto xref_at = [&in](int i) { return in.xref[i]; };
   auto xnext_at = [&in](int i) { return in.xnext[i]; };
@@ -956,12 +959,12 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   // composites per joint, staged in LDS); the direction lanes of stage 2 then
   // evaluate the closed-form tangents of the 27 leg outputs (rigid rotation of the outboard composite about the seeded
   // joint axis).
-  if (C.debug_stop == 10) return;
+  HB_ABLATE_STOP(C.debug_stop == 10);
   double* LJ_all = lds + LqLds::LJ;  // 4 x LEGJ_SIZE; its head is overwritten by ABt in the final compose
   leg_value_pass_coop(cx, M, 4, [](int g) { return g & 1; },
                       [xs, us, dt](int g, int j) { return xs[12 + j] + ((g >> 1) ? dt : 0.0) * us[12 + j]; },
                       [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all, 3, [xs](int i) { return xs[9 + i]; }, SC);
-  if (C.debug_stop == 6) return;
+  HB_ABLATE_STOP(C.debug_stop == 6);
   // ---- value of the flow map at the first RK2 point (plain doubles): the second point x + dt f(x, u) must be known before
   // its directional pass can start, and a value-only evaluation costs well under half a dual pass.  Device: four lanes run
   // the (identical) whole-body part and take one contact point each — the moment sum is a DPP add inside the quad — and
@@ -1028,12 +1031,12 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   for (int i = cx.lane; i < 3; i += cx.nlanes) sincos_t(xe[9 + i], SC[6 + 2 * i], SC[6 + 2 * i + 1]);
   cx.sync();
 #endif
-  if (C.debug_stop == 7) return;
+  HB_ABLATE_STOP(C.debug_stop == 7);
   // ---- stage 2: whole-body combine per (point, direction).  Only 29 of the 44 directions are nonlinear (momentum 0..5,
   // zyx 9..11, joints 12..21, joint rates 34..43), so both RK2 points fit ONE pass of the wave: task = 29 pt + index.
   for (int task = cx.lane; task < 58; task += cx.nlanes) lq_dual_task(M, C, lds, in.mode, in.swing, task >= 29 ? 1 : 0, task >= 29 ? task - 29 : task, false);
   cx.sync();
-  if (C.debug_stop == 9) return;
+  HB_ABLATE_STOP(C.debug_stop == 9);
   // constraint rows of the base-position directions (closed form)
   for (int task = cx.lane; task < 3; task += cx.nlanes) lq_closed_task(C, lds, in.mode, task);
   cx.sync();

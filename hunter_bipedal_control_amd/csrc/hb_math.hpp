@@ -11,6 +11,22 @@
 #define HB_HD inline
 #endif
 
+// Profiling ablation exits (tools/perf_quick.py --ablate-*): compiled in only with -DHB_ABLATE (csrc/build.sh --ablate builds the
+// variant library variants/libhunter_hip_ablate.so); the release kernels carry none of them.
+#if defined(HB_ABLATE)
+#define HB_ABLATE_STOP(cond) do { if (cond) return; } while (0)
+#define HB_ABLATE_ON 1
+#else
+// (the exits also bounded the compiler's code motion across phases: without any ordering point at these places k_lq hoists loads
+// over whole phases and spills 12 B/lane; a compiler-only ordering point keeps the schedule of the variant they were tuned on)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HB_ABLATE_STOP(cond) asm volatile("" ::: "memory")
+#else
+#define HB_ABLATE_STOP(cond) do { } while (0)
+#endif
+#define HB_ABLATE_ON 0
+#endif
+
 namespace hb {
 
 // value + one tangent: lane l of the LQ kernel carries d/d(direction l)

@@ -233,15 +233,15 @@ HB_HD void ric_phase12(const Ctx& cx, double* lds, double* gains, int n_til, int
   static_assert(RicLds::CU + 9 <= 32, "x block, vector and 9 inputs must fit two tiles");
   if (n_til <= 9) {
     ric_phase1<2>(cx, lds);
-    if (dbg == 21) return;
+    HB_ABLATE_STOP(dbg == 21);
     ric_phase2_gemm<2>(cx, lds);
-    if (dbg == 22) return;
+    HB_ABLATE_STOP(dbg == 22);
     ric_factor_solve<9>(cx, lds, gains);
   } else {
     ric_phase1<3>(cx, lds);
-    if (dbg == 21) return;
+    HB_ABLATE_STOP(dbg == 21);
     ric_phase2_gemm<3>(cx, lds);
-    if (dbg == 22) return;
+    HB_ABLATE_STOP(dbg == 22);
     ric_factor_solve<NU_T>(cx, lds, gains);
   }
 }
@@ -296,7 +296,7 @@ HB_HD void ric_stage(const Ctx& cx, double* lds, const double* rec) {
 template <class Ctx>
 HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, const double* rec, double* gains, int dbg = 0) {
   ric_phase12(cx, lds, gains, int(rec[REC_META]) + int(rec[REC_META + 1]), dbg);
-  if (dbg == 21 || dbg == 22 || dbg == 23) return;  // profiling ablation markers (hb_config.reserved)
+  HB_ABLATE_STOP(dbg == 21 || dbg == 22 || dbg == 23);  // profiling ablation markers (hb_config.reserved)
   RicT3 t;
   ric_phase3_mma(cx, lds, t);
   double* Qs = lds + RicLds::Qs;

@@ -405,14 +405,14 @@ HB_HD void wbc_phase_a(const Ctx& cx, const DevModel& M, const DevConfig& C, con
     }
   }
   cx.sync();
-  if (C.debug_stop == 13) return;  // profiling ablation markers 13..16 (hb_config.reserved): phase A step by step
+  HB_ABLATE_STOP(C.debug_stop == 13);  // profiling ablation markers 13..16 (hb_config.reserved): phase A step by step
   for (int task = cx.lane; task < 4; task += cx.nlanes) {
     const int pass = task >> 1, leg = task & 1;
     if (pass == 0) body_pass_leg(M, q, v, P, K.W[task], leg, K.LA[task]);
     else if (!stance_mode) body_pass_leg(M, K.qd, K.vd, D, K.W[task], leg, K.LA[task]);
   }
   cx.sync();
-  if (C.debug_stop == 14) return;
+  HB_ABLATE_STOP(C.debug_stop == 14);
   for (int task = cx.lane; task < 2; task += cx.nlanes) {
     if (task == 0) {
       body_pass_finish(P, K.BA[0], K.LA[0], K.LA[1]);
@@ -441,7 +441,7 @@ HB_HD void wbc_phase_a(const Ctx& cx, const DevModel& M, const DevConfig& C, con
     }
   }
   cx.sync();
-  if (C.debug_stop == 15) return;
+  HB_ABLATE_STOP(C.debug_stop == 15);
   // ---- step 2: fills shared by the wave.  EoM rows: [M, -J', -S'] x = -nle   (WbcBase.cpp:138-149)
   for (int idx = cx.lane; idx < 16 * NW; idx += cx.nlanes) {
     const int i = idx / NW, j = idx - NW * i;
@@ -546,7 +546,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   if (cx.lane == 0) misc[0] = 0.0;  // status
   cx.sync();
 
-  if (C.debug_stop == 11 || (C.debug_stop >= 13 && C.debug_stop <= 15)) return;
+  HB_ABLATE_STOP(C.debug_stop == 11 || (C.debug_stop >= 13 && C.debug_stop <= 15));
   // ------------------------------------------------------------------ phase B: R~ by Givens row insertion
   const double se = sqrt(C.wbc_eps);
   for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Rm[idx] = (idx / NW == idx % NW) ? se : 0.0;
@@ -651,7 +651,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   for (int i = cx.lane; i < 64; i += cx.nlanes) is_active[i] = 0;
   cx.sync();
 
-  if (C.debug_stop == 12) return;
+  HB_ABLATE_STOP(C.debug_stop == 12);
   // ------------------------------------------------------------------ phase C: Goldfarb–Idnani iterations
 #if defined(__HIP_DEVICE_COMPILE__)
   // lane i keeps row i of J in registers for the whole active-set loop: z = J2 d2 and the reflector update work on it

@@ -3,7 +3,8 @@
 Prints host-side (PCIe-inclusive: 34 doubles in, 54 out per instance) ms per tick; the kernel time is in the profile."""
 import sys
 import time
-sys.path.insert(0, '.')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 from hunter_bipedal_control_amd import abi, ingest
 from hunter_bipedal_control_amd.solver import HunterSolver

@@ -1,7 +1,8 @@
 """Throughput of hb_refgen_update at the bench batch size (run on the GPU box, optionally under rocprofv3)."""
 import sys
 import time
-sys.path.insert(0, '.')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 from hunter_bipedal_control_amd import abi, ingest, workload
 from oracle import refgen

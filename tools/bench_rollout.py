@@ -2,7 +2,8 @@
 WBC, joint command, plant stub) on the device.  Run on the GPU box:  python tools/bench_rollout.py [ticks]"""
 import sys
 import time
-sys.path.insert(0, '.')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 from hunter_bipedal_control_amd import ingest
 from hunter_bipedal_control_amd.rollout import ResidentLoop

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 cd /tmp
 run() {  # name, counters...
   name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" -d $out/pmc_$name -o p -- python $OLDPWD/bench.py --steps 8 --warmup 2 --no-extras --no-cpu-baseline > $out/pmc_$name.log 2>&1
+  timeout 600 rocprofv3 --pmc "$@" -d $out/pmc_$name -o p -- python $OLDPWD/bench.py --steps 8 --warmup 2 --chunks 1 --no-extras --no-cpu-baseline > $out/pmc_$name.log 2>&1
 }
 passes=${2:-"fetch write sq wait mix lds cyc"}
 for p in $passes; do

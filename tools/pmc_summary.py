@@ -73,7 +73,7 @@ def main():
             for src in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_MFMA"):
                 if src in v:
                     v[src.lower() + "_per_wave"] = v[src] / v["SQ_WAVES"]
-    json.dump(merged, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+    json.dump(dict(merged, tag=tag), open(f"profiles/{tag}_pmc.json", "w"), indent=1)
     lines = [f"# rocprofv3 --pmc per-kernel means ({tag}); bytes corrected per MI355X_MICROARCH.md §HBM (FETCH x2 for wide reads)"]
     for k, v in sorted(merged.items(), key=lambda kv: -kv[1].get("avg_us_under_profiling", 0)):
         lines.append(k)

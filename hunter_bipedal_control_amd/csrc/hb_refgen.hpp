@@ -15,6 +15,7 @@
 namespace hb {
 
 constexpr int RG_MAX_EVENTS = 64;
+#define HB_NAN (__builtin_nan(""))
 constexpr int RG_PHASE = 8;  // per (foot, phase): ts, tf, p0[3], p1[3]; a stance (constant) phase is stored with ts > tf
 
 using RefgenConfig = hb_refgen_config;  // include/hunter_hip.h
@@ -71,8 +72,8 @@ HB_HD void rg_phase_eval(const RefgenConfig& K, const double* ph, double t, doub
   const double t0 = ph[0], t1 = ph[1];
   const double* p0 = ph + 2;
   const double* p1 = ph + 5;
-  if (t0 > t1) {  // stance phase: two identical nodes with zero velocity
-    for (int a = 0; a < 3; ++a) { out6[a] = p1[a]; out6[3 + a] = 0.0; }
+  if (t0 > t1) {  // stance phase: two identical nodes with zero velocity (NaN positions: a spline of zero length, see refgen_plan)
+    for (int a = 0; a < 3; ++a) { out6[a] = p1[a]; out6[3 + a] = 0.0 * p1[a]; /* NaN stays NaN */ }
     return;
   }
   const double a1 = 0.417, l1 = 0.650, k1 = 1.770;
@@ -234,6 +235,54 @@ HB_HD void rg_colpiv_solve(int m, int n, double a[5][5], const double* b, double
   }
   for (int i = 0; i < rank; ++i) y[perm[i]] = z[i];
 }
+// Eigen::FullPivLU<3 x 5>::kernel() of the position Jacobian ([Eigen-knowledge] Eigen/src/LU/FullPivLU.h computeInPlace +
+// kernel_retval::evalTo; the reference calls it at InverseKinematics.cpp:171): complete pivoting — the biggest |entry| of the
+// remaining corner, the first one in column-major order on ties —, rank = number of pivots above epsilon * 3 * |max pivot|,
+// kernel = Q [-U11^-1 U12; I].  NOT an orthonormal basis: every kernel vector carries a 1 on one non-pivot joint, and since the
+// reference applies its 0.01 rank threshold to Ja N, the basis decides which directions survive — so it is reproduced, not
+// replaced by a better-conditioned one.  lu: 3 x 5 (destroyed); N[k][c], c < nd, on return.  (Negligible pivots are taken to come
+// last, as complete pivoting leaves them; Eigen's re-permutation for an interleaved negligible pivot is not reproduced.)
+HB_HD int rg_fullpiv_kernel(double lu[5][5], double N[5][5], int* q) {
+  const int rows = 3, cols = 5;
+  for (int j = 0; j < cols; ++j) q[j] = j;
+  int nonzero = rows;
+  double maxpivot = 0.0;
+  for (int k = 0; k < rows; ++k) {
+    int bi = k, bj = k;
+    double best = -1.0;
+    for (int j = k; j < cols; ++j)
+      for (int i = k; i < rows; ++i)
+        if (fabs(lu[i][j]) > best) { best = fabs(lu[i][j]); bi = i; bj = j; }
+    if (best == 0.0) { nonzero = k; break; }
+    maxpivot = fmax(maxpivot, best);
+    if (bi != k) for (int j = 0; j < cols; ++j) { const double t = lu[k][j]; lu[k][j] = lu[bi][j]; lu[bi][j] = t; }
+    if (bj != k) {
+      for (int i = 0; i < rows; ++i) { const double t = lu[i][k]; lu[i][k] = lu[i][bj]; lu[i][bj] = t; }
+      const int t = q[k]; q[k] = q[bj]; q[bj] = t;
+    }
+    for (int i = k + 1; i < rows; ++i) {
+      lu[i][k] /= lu[k][k];
+      for (int j = k + 1; j < cols; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+    }
+  }
+  const double pt = maxpivot * (3.0 * 2.220446049250313e-16);
+  int rk = 0;
+  for (int i = 0; i < nonzero; ++i) rk += fabs(lu[i][i]) > pt ? 1 : 0;
+  const int nd = cols - rk;
+  for (int k = 0; k < cols; ++k)
+    for (int c = 0; c < cols; ++c) N[k][c] = 0.0;
+  for (int c = 0; c < nd; ++c) {
+    double x[3] = {0.0, 0.0, 0.0};
+    for (int i = rk - 1; i >= 0; --i) {
+      double sacc = lu[i][rk + c];
+      for (int k = i + 1; k < rk; ++k) sacc -= lu[i][k] * x[k];
+      x[i] = sacc / lu[i][i];
+    }
+    for (int i = 0; i < rk; ++i) N[q[i]][c] = -x[i];
+    N[q[rk + c]][c] = 1.0;
+  }
+  return nd;
+}
 HB_HD Vec3<double> rg_log3(const Mat3<double>& R) {
   double c = 0.5 * (R.m[0] + R.m[4] + R.m[8] - 1.0);
   c = fmin(1.0, fmax(-1.0, c));
@@ -272,31 +321,22 @@ HB_HD void rg_compute_ik(const DevModel& M, double* q16, int leg, const Vec3<dou
         rg_colpiv_solve(3, 5, a, eb, 0.01, y, W);
         for (int c = 0; c < 5; ++c) v[c] = -y[c];
       } else {
-        // orthonormal basis of null(Jl): trailing columns of Q from the pivoted QR of Jl' (5 x 3)
+        // N = FullPivLU(Jl).kernel();  v = -N * ColPivQR(Ja N).solve(err)   (InverseKinematics.cpp:171-175)
         double (*at)[5] = W.at;
-        double (*Qt)[5] = W.Qt;
-        int* perm = W.perm2;
-        for (int r = 0; r < 5; ++r) {
-          for (int c = 0; c < 3; ++c) at[r][c] = Jl[c][r];
-          for (int c = 0; c < 5; ++c) Qt[r][c] = r == c ? 1.0 : 0.0;
-        }
-        rg_qrcp(5, 3, at, perm, 5, Qt, W.hv);  // Qt = Q'
-        int rank = 0;
-        const double d0 = fabs(at[0][0]);
-        if (d0 > 0.0)
-          for (int i = 0; i < 3; ++i)
-            if (fabs(at[i][i]) > 1e-12 * d0) ++rank;
-        const int nd = 5 - rank;  // null-space dimension; basis vectors are rows rank .. 4 of Q'
+        double (*Nk)[5] = W.Qt;
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 5; ++c) at[r][c] = Jl[r][c];
+        const int nd = rg_fullpiv_kernel(at, Nk, W.perm2);
         for (int r = 0; r < 3; ++r)
           for (int c = 0; c < nd; ++c) {
             double sacc = 0.0;
-            for (int k = 0; k < 5; ++k) sacc += Ja[r][k] * Qt[rank + c][k];
+            for (int k = 0; k < 5; ++k) sacc += Ja[r][k] * Nk[k][c];
             a[r][c] = sacc;
           }
         rg_colpiv_solve(3, nd, a, eb, 0.01, y, W);
         for (int k = 0; k < 5; ++k) {
           double sacc = 0.0;
-          for (int c = 0; c < nd; ++c) sacc += Qt[rank + c][k] * y[c];
+          for (int c = 0; c < nd; ++c) sacc += Nk[k][c] * y[c];
           v[k] = -sacc;
         }
       }
@@ -437,77 +477,97 @@ __device__ __forceinline__ double ik_colpiv_solve(double a0, double a1, double a
     if (ord == i && i < rank) y = z[i];
   return y;
 }
-// One step direction of the rotation stage: v = -N y with N an orthonormal basis of null(Jl) (trailing rows of Q' from the
-// column-pivoted QR of Jl', rank threshold 1e-12) and y the basic solution of (Ja N) y = err.  jl / ja: this lane's columns.
+// One step direction of the rotation stage: v = -N y, N = Eigen::FullPivLU(Jl).kernel() (see rg_fullpiv_kernel: complete
+// pivoting, kernel vectors with a 1 on the non-pivot joints), y the basic solution of (Ja N) y = err.  jl / ja: this lane's
+// columns.  The elimination runs on the lanes' registers: a column never moves, its lane tracks the POSITION it holds in Eigen's
+// permuted matrix (ties in the pivot search go to the smallest position, as Eigen's column-major scan does).
 __device__ __forceinline__ double ik_rotation_step(const IkLane& L, const Vec3<double>& jl, const Vec3<double>& ja, const Vec3<double>& err) {
-  // At = Jl' (5 x 3): row k on lane k; the three columns are registers, pivoted by swapping registers
   double a[3] = {L.joint ? jl.x : 0.0, L.joint ? jl.y : 0.0, L.joint ? jl.z : 0.0};
-  double qt[5];   // column `lane` of Q' (Q'[r][lane], r < 5); Q' starts as the identity
+  const int grp = int(threadIdx.x) & 56;
+  int pos = L.joint ? L.k : 7;
+  double dg[3] = {0.0, 0.0, 0.0}, maxpivot = 0.0;
+  int nonzero = 3;
+  bool stopped = false;
 #pragma unroll
-  for (int r = 0; r < 5; ++r) qt[r] = (L.joint && L.k == r) ? 1.0 : 0.0;
-  double diag[3] = {0.0, 0.0, 0.0};
+  for (int k = 0; k < 3; ++k) {
+    double bv = -1.0;
+    int br = k;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const bool rowon = L.joint && L.k >= j;
-    double nn[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = j; c < 3; ++c) nn[c] = seg8_allsum(rowon ? a[c] * a[c] : 0.0);
-    int pv = j;
-    double best = nn[j];
-#pragma unroll
-    for (int c = j + 1; c < 3; ++c)
-      if (nn[c] > best) { best = nn[c]; pv = c; }
-#pragma unroll
-    for (int c = j + 1; c < 3; ++c)
-      if (pv == c) { const double t = a[j]; a[j] = a[c]; a[c] = t; }
-    const double nrm = sqrt(best);
-    const double ajj = seg8_get(a[j], j);
-    const double alpha = ajj > 0.0 ? -nrm : nrm;
-    const double vk = rowon ? a[j] - (L.k == j ? alpha : 0.0) : 0.0;   // reflector entry of this lane's row
-    const double vv = seg8_allsum(vk * vk);
-    const bool doit = nrm > 0.0 && vv > 0.0;
-    const double beta = doit ? 2.0 / vv : 0.0;
-#pragma unroll
-    for (int c = j; c < 3; ++c) {
-      const double d = beta * seg8_allsum(vk * a[c]);
-      a[c] -= d * vk;
+    for (int r = k; r < 3; ++r) {
+      const double m = fabs(a[r]);
+      if (m > bv) { bv = m; br = r; }
     }
-    // Q' <- H Q': every lane needs the whole reflector to update its own column
-    double vr[5];
+    const bool cand = L.joint && pos >= k;
+    const double best = seg8_allmax(cand ? bv : -1.0);
+    const double pmin = -seg8_allmax((cand && bv == best) ? -double(pos) : -8.0);
+    const bool piv = cand && bv == best && double(pos) == pmin;
+    const unsigned hit = (unsigned)((__ballot(piv) >> grp) & 0xff);
+    const int pl = hit ? __ffs(hit) - 1 : 0;
+    if (!stopped && !(best > 0.0)) { stopped = true; nonzero = k; }
+    const bool live = !stopped;
+    const int bi = __shfl(br, grp | pl, 64);
+    if (live) {
+      maxpivot = fmax(maxpivot, best);
+      // rows k <-> bi, on every column
+      const double t = a[k];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) vr[r] = seg8_get(vk, r);
-    double d = 0.0;
+      for (int r = k + 1; r < 3; ++r)
+        if (bi == r) { a[k] = a[r]; a[r] = t; }
+      // columns k <-> position of the pivot
+      if (pos == k) pos = int(pmin);
+      else if (piv) pos = k;
+    }
+    const double pk = seg8_get(a[k], pl);
+    if (live) dg[k] = pk;
 #pragma unroll
-    for (int r = 0; r < 5; ++r) d += vr[r] * qt[r];
-    d *= beta;
-#pragma unroll
-    for (int r = 0; r < 5; ++r) qt[r] -= d * vr[r];
-    diag[j] = seg8_get(a[j], j);
+    for (int r = k + 1; r < 3; ++r) {
+      const double lr = seg8_get(a[r], pl) / pk;
+      if (live && L.joint && pos > k) a[r] -= lr * a[k];
+    }
   }
-  int rank = 0;
-  const double d0 = fabs(diag[0]);
-  if (d0 > 0.0) {
+  const double pt = maxpivot * (3.0 * 2.220446049250313e-16);
+  int rk = 0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      if (fabs(diag[i]) > 1e-12 * d0) ++rank;
+  for (int i = 0; i < 3; ++i)
+    if (i < nonzero && fabs(dg[i]) > pt) ++rk;
+  // by position (uniform in the group): the strict upper triangle of U11 ...
+  const double u01 = seg8_allsum((L.joint && pos == 1) ? a[0] : 0.0);
+  const double u02 = seg8_allsum((L.joint && pos == 2) ? a[0] : 0.0);
+  const double u12 = seg8_allsum((L.joint && pos == 2) ? a[1] : 0.0);
+  const int nd = 5 - rk;
+  // ... and, position by position, x = U11^-1 U[:, c] for every c that is a kernel column (c >= rk; c = 0 only for the zero
+  // matrix): kernel column c - rk is -x on the pivot joints and 1 on the joint at position c.  n[kk]: this lane's row of N.
+  double n[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const bool here = L.joint && pos == c;
+    const double b0 = c > 0 ? (c == 1 ? u01 : (c == 2 ? u02 : seg8_allsum(here ? a[0] : 0.0))) : 0.0;
+    const double b1 = c > 1 ? (c == 2 ? u12 : seg8_allsum(here ? a[1] : 0.0)) : 0.0;
+    const double b2 = c > 2 ? seg8_allsum(here ? a[2] : 0.0) : 0.0;
+    const double x2 = (rk > 2 && c > 2) ? b2 / dg[2] : 0.0;
+    const double x1 = (rk > 1 && c > 1) ? (b1 - (rk > 2 ? u12 * x2 : 0.0)) / dg[1] : 0.0;
+    const double x0 = (rk > 0 && c > 0) ? (b0 - (rk > 1 ? u01 * x1 : 0.0) - (rk > 2 ? u02 * x2 : 0.0)) / dg[0] : 0.0;
+    const double xp = pos == 0 ? x0 : (pos == 1 ? x1 : x2);
+    const double e = pos < rk ? -xp : (here ? 1.0 : 0.0);
+    const int kk = c - rk;
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+      if (L.joint && kk == m) n[m] = e;
   }
-  const int nd = 5 - rank;
-  // w[r'] = Ja * (row r' of Q')' (uniform): lane c < nd then owns column c of A = Ja N, N = rows rank .. 4 of Q'
+  // lane c < nd owns column c of A = Ja N
   Vec3<double> mine;
 #pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const double qv = L.joint ? qt[r] : 0.0;
-    const Vec3<double> w(seg8_allsum(ja.x * qv), seg8_allsum(ja.y * qv), seg8_allsum(ja.z * qv));
-    if (L.k + rank == r) mine = w;
+  for (int c = 0; c < 5; ++c) {
+    const Vec3<double> w(seg8_allsum(ja.x * n[c]), seg8_allsum(ja.y * n[c]), seg8_allsum(ja.z * n[c]));
+    if (L.k == c) mine = w;
   }
   const bool col = L.k < nd && L.k < 5;
   const double y = ik_colpiv_solve(mine.x, mine.y, mine.z, col, err.x, err.y, err.z, 0.01);
   double v = 0.0;
 #pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int c = r - rank;
-    const double yc = seg8_get(y, c < 0 ? 0 : c);
-    if (c >= 0) v -= qt[r] * yc;
+  for (int c = 0; c < 5; ++c) {
+    const double yc = seg8_get(y, c);
+    if (c < nd) v -= n[c] * yc;
   }
   return v;
 }
@@ -683,7 +743,13 @@ HB_HD int refgen_plan(const DevModel& M, const RefgenConfig& K, int n_ev, const 
         for (int a = 0; a < 3; ++a) { ph[2 + a] = last[a]; ph[5 + a] = nxt[a]; }
       } else {
         ph[0] = 1.0; ph[1] = 0.0;  // ts > tf marks a constant phase
-        for (int a = 0; a < 3; ++a) { ph[2 + a] = nxt[a]; ph[5 + a] = nxt[a]; }
+        // The reference builds the stance spline between eventTimes[s_idx] and eventTimes[f_idx] (SwingTrajectoryPlanner.cpp:253-276).
+        // findIndex leaves s_idx = 0 for the window's first phase, so a foot that lifts off at the first event gets a spline of
+        // ZERO length, and CubicSpline evaluates that to 0 * inf = NaN at every time (CubicSpline.cpp:46-84): position and
+        // velocity getters return NaN until the first event has passed.  Kept: calculateJointRef feeds it to the IK (whose
+        // iterates then land on the lower joint limits), and the MPC never reads the reference of a foot in contact.
+        const bool zero_len = n_ev > 0 && s_idx == f_idx;
+        for (int a = 0; a < 3; ++a) { ph[2 + a] = nxt[a]; ph[5 + a] = zero_len ? HB_NAN : nxt[a]; }
       }
     }
   }

@@ -10,7 +10,7 @@ struct Point { double x = 0, y = 0, z = 0; };
 struct Vector3 { double x = 0, y = 0, z = 0; };
 struct Quaternion { double x = 0, y = 0, z = 0, w = 1; };
 struct Pose { Point position; Quaternion orientation; };
-struct Twist { Vector3 linear, angular; };
+struct Twist { Vector3 linear, angular; typedef std::shared_ptr<const Twist> ConstPtr; };
 struct PoseWithCovariance { Pose pose; std::array<double, 36> covariance{}; };
 struct TwistWithCovariance { Twist twist; std::array<double, 36> covariance{}; };
 struct PoseWithCovarianceStamped { std_msgs::Header header; PoseWithCovariance pose; };

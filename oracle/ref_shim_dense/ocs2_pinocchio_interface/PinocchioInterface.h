@@ -13,7 +13,8 @@ class PinocchioInterface {
     ++o.copies_;
   }
   PinocchioInterface(PinocchioInterface&& o) noexcept : model_(o.model_), data_(o.data_) {}
-  PinocchioInterface& operator=(const PinocchioInterface&) = delete;
+  PinocchioInterface& operator=(const PinocchioInterface& o) { model_ = o.model_; data_ = std::make_shared<pinocchio::Data>(); data_->role = o.data_->role; return *this; }
+  PinocchioInterface& operator=(PinocchioInterface&& o) noexcept { model_ = o.model_; data_ = o.data_; return *this; }
   const pinocchio::Model& getModel() const { return *model_; }
   pinocchio::Model& mutableModel() { return *model_; }
   pinocchio::Data& getData() { return *data_; }

@@ -128,24 +128,28 @@ def time_discretization(t0: float, tf: float, dt: float, event_times, dt_min: fl
 
 
 class CubicSegment:
-    """Hermite cubic between two (time, position, velocity) nodes (CubicSpline.cpp:46-124)."""
+    """Hermite cubic between two (time, position, velocity) nodes (CubicSpline.cpp:46-124).  IEEE arithmetic as the C++ does it:
+    a segment of zero duration (the stance spline of the window's first phase when the foot lifts off at the first event,
+    SwingTrajectoryPlanner.cpp:253-276 with findIndex's start = final = 0) evaluates to NaN — 0 * inf — at every time."""
 
     def __init__(self, n0, n1):
         (t0, p0, v0), (t1, p1, v1) = n0, n1
-        self.t0, self.t1, self.dt = t0, t1, t1 - t0
-        dp, dv = p1 - p0, v1 - v0
-        self.c0 = p0
+        self.t0, self.t1, self.dt = np.float64(t0), np.float64(t1), np.float64(t1) - np.float64(t0)
+        dp, dv = np.float64(p1) - np.float64(p0), np.float64(v1) - np.float64(v0)
+        self.c0 = np.float64(p0)
         self.c1 = v0 * self.dt
         self.c2 = -(3.0 * v0 + dv) * self.dt + 3.0 * dp
         self.c3 = (2.0 * v0 + dv) * self.dt - 2.0 * dp
 
     def position(self, t):
-        tn = (t - self.t0) / self.dt
-        return self.c3 * tn ** 3 + self.c2 * tn ** 2 + self.c1 * tn + self.c0
+        with np.errstate(all="ignore"):
+            tn = (np.float64(t) - self.t0) / self.dt
+            return float(self.c3 * tn * tn * tn + self.c2 * tn * tn + self.c1 * tn + self.c0)
 
     def velocity(self, t):
-        tn = (t - self.t0) / self.dt
-        return (3.0 * self.c3 * tn ** 2 + 2.0 * self.c2 * tn + self.c1) / self.dt
+        with np.errstate(all="ignore"):
+            tn = (np.float64(t) - self.t0) / self.dt
+            return float((3.0 * self.c3 * tn * tn + 2.0 * self.c2 * tn + self.c1) / self.dt)
 
 
 class MultiCubic:
@@ -335,10 +339,12 @@ class SwingTrajectoryPlanner:
                         last_final[j] = f_idx
                     self.traj[j].append(self._swing_splines(ts, tf, last[j], nxt[j]))
                 else:
-                    ts = ev[s_idx] if ev else 0.0
-                    tf = ev[f_idx] if ev and f_idx < len(ev) else ts + 1.0
-                    if tf <= ts:
-                        tf = ts + 1.0
+                    # stanceStartTime / stanceFinalTime = eventTimes[findIndex(p)] (SwingTrajectoryPlanner.cpp:253-257).  For the
+                    # window's first phase findIndex leaves start = 0, so a foot that lifts off at the first event gets a
+                    # zero-length stance spline, whose getters return NaN (see CubicSegment) — kept, as every consumer of the
+                    # reference sees it.  Only the schedule without any event (eventTimes[-1] in the reference: undefined
+                    # behaviour, never produced by GaitSchedule) gets a well-defined constant here.
+                    ts, tf = (ev[s_idx], ev[f_idx]) if ev else (0.0, 1.0)
                     const = lambda v: MultiCubic([(ts, v, 0.0), (tf, v, 0.0)])
                     self.traj[j].append((const(nxt[j][0]), const(nxt[j][1]), const(nxt[j][2])))
 
@@ -512,7 +518,11 @@ def _ik_iterate(model, q, leg, err_fn, step_fn):
     for _ in range(5):
         v = step_fn(q, err)
         new_q = q.copy()
-        new_q[6 + 5 * leg:11 + 5 * leg] = np.clip(q[6 + 5 * leg:11 + 5 * leg] + 0.7 * v, lo, hi)
+        # std::min(hi, std::max(lo, x)) (InverseKinematics.cpp:84-88): a NaN iterate (NaN foot target, see CubicSegment) lands on
+        # the LOWER limit, and every comparison below is false for a NaN error norm, so the iteration runs to its limit
+        cand = q[6 + 5 * leg:11 + 5 * leg] + 0.7 * v
+        cand = np.where(lo < cand, cand, lo)
+        new_q[6 + 5 * leg:11 + 5 * leg] = np.where(cand < hi, cand, hi)
         err = err_fn(new_q)
         n = np.linalg.norm(err)
         if n > last or abs(n - last) < 1e-3:
@@ -523,17 +533,66 @@ def _ik_iterate(model, q, leg, err_fn, step_fn):
     return q
 
 
+def _fullpiv_lu_kernel(A: np.ndarray) -> np.ndarray:
+    """Eigen::FullPivLU<MatrixXd>::kernel() ([Eigen-knowledge] Eigen/src/LU/FullPivLU.h: computeInPlace + kernel_retval::evalTo):
+    complete pivoting (biggest |entry| of the remaining corner, first one in column-major order on ties), rank = pivots above
+    epsilon * min(rows, cols) * |max pivot|, kernel = Q [-U11^-1 U12; I] — NOT an orthonormal basis: each kernel vector has a 1
+    on one non-pivot column.  The reference projects the rotation Jacobian on this basis (InverseKinematics.cpp:171) and then
+    applies its 0.01 rank threshold to the product, so the basis decides which directions survive."""
+    lu = np.array(A, dtype=float)
+    rows, cols = lu.shape
+    size = min(rows, cols)
+    q = list(range(cols))
+    nonzero, maxpivot = size, 0.0
+    for k in range(size):
+        sub = np.abs(lu[k:, k:])
+        bj, bi = divmod(int(np.argmax(sub.T.reshape(-1))), rows - k)      # column-major scan, first maximum
+        best = sub[bi, bj]
+        if best == 0.0:
+            nonzero = k
+            break
+        maxpivot = max(maxpivot, best)
+        bi, bj = bi + k, bj + k
+        lu[[k, bi], :] = lu[[bi, k], :]
+        lu[:, [k, bj]] = lu[:, [bj, k]]
+        q[k], q[bj] = q[bj], q[k]
+        lu[k + 1:, k] /= lu[k, k]
+        lu[k + 1:, k + 1:] -= np.outer(lu[k + 1:, k], lu[k, k + 1:])
+    pt = maxpivot * np.finfo(float).eps * size
+    piv = [i for i in range(nonzero) if abs(lu[i, i]) > pt]
+    rk = len(piv)
+    if rk == cols:
+        return np.zeros((cols, 1))
+    m = np.zeros((rk, cols))
+    for i in range(rk):
+        m[i, i:] = lu[piv[i], i:]
+    for i in range(rk):
+        if piv[i] != i:
+            m[:, [i, piv[i]]] = m[:, [piv[i], i]]
+    for c in range(rk, cols):
+        for i in range(rk - 1, -1, -1):
+            m[i, c] = (m[i, c] - m[i, i + 1:rk] @ m[i + 1:rk, c]) / m[i, i]
+    for i in range(rk - 1, -1, -1):
+        if piv[i] != i:
+            m[:, [i, piv[i]]] = m[:, [piv[i], i]]
+    ker = np.zeros((cols, cols - rk))
+    for i in range(rk):
+        ker[q[i], :] = -m[i, rk:]
+    for k in range(cols - rk):
+        ker[q[rk + k], k] = 1.0
+    return ker
+
+
 def compute_ik(model: dict, q16: np.ndarray, leg: int, foot_pos: np.ndarray, R_des: np.ndarray) -> np.ndarray:
     """InverseKinematics::computeIK(init_q, leg, des_foot_linear_xyz, des_foot_R_des) -> 5 joint angles."""
-    from scipy.linalg import null_space
     q = np.array(q16, dtype=float)
     q = _ik_iterate(model, q, leg, lambda qq: _leg_kinematics(model, qq, leg)[0] - foot_pos,
                     lambda qq, err: -_colpiv_qr_solve(_leg_kinematics(model, qq, leg)[2], err))
 
     def rot_step(qq, err):
         _, _, Jl, Ja = _leg_kinematics(model, qq, leg)
-        Nn = null_space(Jl, rcond=1e-12)
-        return -Nn @ _colpiv_qr_solve(Ja @ Nn, err) if Nn.size else np.zeros(5)
+        Nn = _fullpiv_lu_kernel(Jl)
+        return -Nn @ _colpiv_qr_solve(Ja @ Nn, err)
 
     q = _ik_iterate(model, q, leg, lambda qq: _log3(R_des.T @ _leg_kinematics(model, qq, leg)[1]), rot_step)
     return q[6 + 5 * leg:11 + 5 * leg]

@@ -60,6 +60,25 @@ def main():
             lib.refik_compute(h, which, _d(q), leg, _d(np.ascontiguousarray(des)), _d(R_des), _d(out))
             o[name] = out.tolist()
         cases.append(dict(q=q.tolist(), leg=leg, des_pos=des.tolist(), R_des=R_des.tolist(), feet=feet.tolist(), out=o))
+    # NaN foot targets: what calculateJointRef hands over while the swing planner's zero-length stance spline is queried
+    # (tests/golden/make_ref_refmgr.py); the translation iterates land on the lower joint limits and the rotation stage starts there
+    for k in range(8):
+        q = np.zeros(16)
+        q[0:3] = [0.3 * rng.standard_normal(), 0.3 * rng.standard_normal(), 0.63 + 0.02 * rng.standard_normal()]
+        q[3:6] = [rng.uniform(-3, 3), 0.05 * rng.standard_normal(), 0.05 * rng.standard_normal()]
+        q[6:] = qj0 + 0.05 * rng.standard_normal(10)
+        leg = k % 2
+        state = np.concatenate([np.zeros(6), q])
+        feet = np.zeros(12)
+        lib.refik_foot_pos(h, _d(state), _d(feet))
+        des = np.full(3, np.nan)
+        R_des = np.ascontiguousarray(refgen.zyx_to_rotation(q[3:6]))
+        o = {}
+        for which, name in ((0, "translation"), (1, "rotation"), (2, "ik")):
+            out = np.zeros(5)
+            lib.refik_compute(h, which, _d(q), leg, _d(des), _d(R_des), _d(out))
+            o[name] = out.tolist()
+        cases.append(dict(q=q.tolist(), leg=leg, des_pos=des.tolist(), R_des=R_des.tolist(), feet=feet.tolist(), out=o, nan_target=True))
     lib.refik_destroy(h)
     dst = ROOT / "tests/golden/ref_ik.json"
     dst.write_text(json.dumps(dict(cases=cases), indent=0))

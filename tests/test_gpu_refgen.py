@@ -3,6 +3,8 @@ SwitchedModelReferenceManager::modifyReferences / SwingTrajectoryPlanner (joint 
 import numpy as np
 import pytest
 
+from _cmp import maxdiff_nan
+
 from hunter_bipedal_control_amd import abi, workload
 from oracle import refgen
 
@@ -52,7 +54,7 @@ def test_device_reference_generation_matches_host_over_two_calls(params):
                 assert np.abs(got["t"][i] - ref["t"]).max() < 1e-12
                 assert np.array_equal(got["mode"][i], ref["mode"])
                 assert np.abs(got["x_ref"][i] - ref["x_ref"]).max() < 1e-12
-                assert np.abs(got["swing"][i] - ref["swing"]).max() < 1e-10, (call, i, gaits[i])
+                assert maxdiff_nan(got["swing"][i], ref["swing"]) < 1e-10, (call, i, gaits[i])
     finally:
         s.close()
 
@@ -89,7 +91,7 @@ def test_device_tables_against_reference_compiled_vectors(params):
                 for j, st in enumerate(steps):
                     assert got["n_nodes"][j] == st["n_nodes"]
                     worst_x = max(worst_x, np.abs(got["x_ref"][j][0][:12] - np.array(st["target_x"][0])[:12]).max())
-                    worst_sw = max(worst_sw, np.abs(got["swing"][j][st["node_idx"]] - np.array(st["node_refs"])).max())
+                    worst_sw = max(worst_sw, maxdiff_nan(got["swing"][j][st["node_idx"]], st["node_refs"]))
         finally:
             s.close()
     assert worst_x < 1e-12 and worst_sw < 1e-12, (worst_x, worst_sw)
@@ -117,7 +119,7 @@ def test_mpc_on_device_generated_references_equals_uploaded_references(params):
                 s.refgen_set_schedule(scheds)
                 assert s.refgen_update(t0, horizon, x0, cmds).max() == 0
                 got = s.get_references()
-                assert np.abs(got["x_ref"] - tables["x_ref"]).max() < 1e-9 and np.abs(got["swing"] - tables["swing"]).max() < 1e-10
+                assert np.abs(got["x_ref"] - tables["x_ref"]).max() < 1e-9 and maxdiff_nan(got["swing"], tables["swing"]) < 1e-10
                 assert np.abs(got["x_ref"][:, :, 12:] - np.array(params["config"]["default_joint_state"])).max() > 0.01  # IK moved them
             else:
                 s.set_references(tables)

@@ -21,6 +21,8 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+from _cmp import maxdiff_nan
+
 from hunter_bipedal_control_amd import abi, gait
 from oracle import refgen
 
@@ -162,7 +164,7 @@ def test_swing_planner_update_sequences(golden, params):
             pl.update(sched, targets, step["t_init"])
             ref = np.array(step["out"]["refs"])
             got = np.array([[pl.swing_ref(f, t) for f in range(4)] for t in step["times"]])
-            worst = max(worst, np.abs(got - ref).max())
+            worst = max(worst, maxdiff_nan(got, ref))
     assert worst < TOL, worst
 
 
@@ -197,7 +199,7 @@ def test_device_planner_and_targets_on_the_host_emulator(golden, params, emu_lib
                                           C.c_double(case["horizon"]), _p(x), _p(cmd), _p(ls), _p(times), C.c_int(len(times)), _p(tgt), _p(out))
             assert rc == 0
             worst_tg = max(worst_tg, np.abs(tgt - np.array(step["target_x"])).max())
-            worst_sw = max(worst_sw, np.abs(out - np.array(step["out"]["refs"])).max())
+            worst_sw = max(worst_sw, maxdiff_nan(out, step["out"]["refs"]))
     assert worst_tg < TOL and worst_sw < TOL, (worst_tg, worst_sw)
 
 

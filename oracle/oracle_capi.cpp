@@ -1,10 +1,15 @@
 // TEST INFRASTRUCTURE — CPU oracle of the hunter NMPC + WBC hot path (C ABI for ctypes).
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
 //
-// PARITY UNPINNED: the reference ships no golden vectors for this path (only the property test
-// legged_wbc/test/HoQp_test.cpp), and OCS2 / HPIPM / pinocchio / qpOASES cannot be built here, so this is a
-// from-scratch restatement pinned by invariants (tests/test_oracle_*.py) and by the few known answers the
-// reference does hold (total mass, FK of the default stance, relaxed-barrier formula).
+// PINNING.  The reference ships no golden vectors for this path (only the property test legged_wbc/test/HoQp_test.cpp), and
+// OCS2 / HPIPM / pinocchio / qpOASES cannot be built here.  Pinned to the reference's OWN sources compiled in place
+// (oracle/Makefile target ref -> oracle/_ref/, golden vectors under tests/golden/): the WBC task builders,
+// WeightedWbc, HierarchicalWbc, HoQp and Task (wbc.hpp, hoqp.hpp: tests/test_ref_wbc.py), the friction-cone and zero-force terms
+// (ocp.hpp: tests/test_ref_constraints.py), the Kalman filter (estimator.hpp: tests/test_ref_kf.py).
+// PARITY UNPINNED for what the reference delegates to absent libraries: the centroidal dynamics and their sensitivities
+// (model.hpp, ocp.hpp), the SQP / projection / Riccati / line search (sqp.hpp) and the rigid-body terms M, nle, J, dJ (model.hpp):
+// a from-scratch restatement held by invariants (tests/test_oracle_*.py) and by the known answers the reference does hold
+// (total mass, FK of the default stance, relaxed-barrier formula).
 #include <atomic>
 #include <cstdio>
 #include <thread>

@@ -1,8 +1,10 @@
 """TEST INFRASTRUCTURE — CPU checker of the device reference generation (hb_refgen_*): gait schedule, OCS2-style time
 discretisation, swing-foot splines, target trajectories -> the per-node tables ``hb_mpc_set_references`` consumes.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it; the product path never does.
-Pinned to the reference's own compiled code (GaitSchedule.cpp, SwingTrajectoryPlanner.cpp, TargetTrajectoriesPublisher.cpp
-built in place into oracle/_ref/libref_refgen.so) by tests/golden/ref_refgen.json — tests/test_ref_refgen.py.
+Pinned to the reference's own compiled code: GaitSchedule.cpp, SwingTrajectoryPlanner.cpp, TargetTrajectoriesPublisher.cpp
+(oracle/_ref/libref_refgen.so, tests/test_ref_refgen.py), InverseKinematics.cpp (libref_ik.so, tests/test_ref_ik.py) and the whole
+SwitchedModelReferenceManager::preSolverRun pipeline over command sequences (libref_refmgr.so, tests/test_ref_refmgr.py).
+The OCS2 time discretisation is the one piece restated without a compiled counterpart.
 
 Restates (host logic, runs once per MPC call per instance in the reference):
   * ModeSchedule::modeAtTime / GaitSchedule::{tileModeSequenceTemplate, insertModeSequenceTemplate, getModeSchedule}

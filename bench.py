@@ -198,21 +198,23 @@ def _full_tick(params, s, w, steps, dt_mpc):
     qj_s, qdj_s, cmd_s = pin(rbd[:, 6:16]), pin(rbd[:, 22:32]), pin(w["cmd"])
 
     def tick(k):
+        # enqueue-only forms (include/hunter_hip.h): the sensor arrays and time stamps go through the library's pinned staging, no
+        # call synchronises with the device, so the host runs a few ticks ahead and the device never waits for a launch
         s.set_resident_time(t + dt_mpc * k)
-        s.estimator_update(0.002, quat, w_loc, a_loc, qj_s, qdj_s, contact, to_resident=True)
-        status = s.refgen_update(t + dt_mpc * k, w["horizon"], None, cmd_s)
+        s.estimator_update(0.002, quat, w_loc, a_loc, qj_s, qdj_s, contact, to_resident=True, want_outputs=False)
+        s.refgen_update(t + dt_mpc * k, w["horizon"], None, cmd_s, want_status=False)
         s.step_resident()
-        return status
 
     for k in range(3):
         tick(k)
     s.sync()
+    bad = int(s.refgen_status().max())
     t0 = time.perf_counter()
-    bad = 0
     for k in range(steps):
-        bad = max(bad, int(tick(3 + k).max()))
+        tick(3 + k)
     s.sync()
     el = time.perf_counter() - t0
+    bad = max(bad, int(s.refgen_status().max()))
     sol, status = s.get_wbc_solution()
     return {"updates_per_s": B * steps / el, "ms_per_step": 1e3 * el / steps, "steps": steps,
             "refgen_status_max": bad, "wbc_status_histogram": [int((status == i).sum()) for i in range(4)],

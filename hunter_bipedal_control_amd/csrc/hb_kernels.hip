@@ -755,6 +755,14 @@ struct hb_ctx {
   // cross-stream ordering points that are NOT timing events: 0 / 1 resident-input writers (plant, estimator) wait for the MPC
   // stream / the MPC stream waits for them; 2 / 3 fork of the chunk streams from the MPC / WBC streams; 4.. join of chunk c
   hipEvent_t ev_sync[4 + 8]{};
+  // Pinned staging for the asynchronous forms of hb_set_resident_time / hb_estimator_update / hb_refgen_update: a caller-owned host
+  // array is copied into a library-owned pinned slot and uploaded from there, so the call returns without a device
+  // synchronisation and the caller's array is free again.  STAGE_DEPTH slots per array, each guarded by the event of its last upload:
+  // the host can run at most STAGE_DEPTH ticks ahead of the device.
+  static constexpr int STAGE_ARRAYS = 10, STAGE_DEPTH = 4;
+  struct StageSlot { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
+  StageSlot stage[STAGE_ARRAYS][STAGE_DEPTH];
+  unsigned stage_turn[STAGE_ARRAYS]{};
   bool grid_saved = false;  // tp / modep / np_nodes hold the grid the iterate lives on; the tables have changed since
   bool policy_read_pending = false;
   bool refs_set = false, traj_set = false, timed = false;
@@ -940,6 +948,11 @@ void hb_destroy(hb_ctx* ctx) {
   for (void* p : ctx->allocs) (void)hipFree(p);
   for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_sync) (void)hipEventDestroy(ev);
+  for (auto& arr : ctx->stage)
+    for (auto& sl : arr) {
+      if (sl.done) (void)hipEventDestroy(sl.done);
+      if (sl.host) (void)hipHostFree(sl.host);
+    }
   (void)hipStreamDestroy(ctx->s_mpc);
   (void)hipStreamDestroy(ctx->s_wbc);
   for (auto& row : ctx->chunk_graph)
@@ -947,6 +960,25 @@ void hb_destroy(hb_ctx* ctx) {
       if (g) (void)hipGraphExecDestroy(g);
   for (auto& sc : ctx->s_chunk) (void)hipStreamDestroy(sc);
   delete ctx;
+}
+
+// Upload of a caller-owned host array through pinned staging (see hb_ctx::stage): returns as soon as the bytes are in the slot.
+enum StageId { ST_TNOW = 0, ST_QUAT, ST_W, ST_A, ST_QJ, ST_QDJ, ST_CONTACT, ST_T0, ST_CMD, ST_X0 };
+static int32_t stage_upload(hb_ctx* ctx, int id, void* dst, const void* src, size_t bytes, hipStream_t s) {
+  hb_ctx::StageSlot& sl = ctx->stage[id][ctx->stage_turn[id]++ % hb_ctx::STAGE_DEPTH];
+  if (sl.pending) { HB_HIP(hipEventSynchronize(sl.done)); sl.pending = false; }
+  if (sl.cap < bytes) {
+    if (sl.host) HB_HIP(hipHostFree(sl.host));
+    sl.host = nullptr; sl.cap = 0;
+    HB_HIP(hipHostMalloc(&sl.host, bytes, hipHostMallocDefault));
+    sl.cap = bytes;
+  }
+  if (!sl.done) HB_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  std::memcpy(sl.host, src, bytes);
+  HB_HIP(hipMemcpyAsync(dst, sl.host, bytes, hipMemcpyHostToDevice, s));
+  HB_HIP(hipEventRecord(sl.done, s));
+  sl.pending = true;
+  return HB_OK;
 }
 
 // Chunked hb_step_resident calls free-run: every chunk of instances is its own stream that goes from one step straight into the
@@ -1199,18 +1231,40 @@ int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const do
     int32_t rc = save_grid_before_table_update(ctx, 0, ctx->B);
     if (rc != HB_OK) return rc;
   }
-  HB_HIP(hipMemcpyAsync(r.t0, t0, B * 8, hipMemcpyHostToDevice, s));
-  HB_HIP(hipMemcpyAsync(r.cmd, cmd_vel, B * 4 * 8, hipMemcpyHostToDevice, s));
-  if (x_now) HB_HIP(hipMemcpyAsync(ctx->b.x0, x_now, B * HB_NX * 8, hipMemcpyHostToDevice, s));
+  if (status) {
+    HB_HIP(hipMemcpyAsync(r.t0, t0, B * 8, hipMemcpyHostToDevice, s));
+    HB_HIP(hipMemcpyAsync(r.cmd, cmd_vel, B * 4 * 8, hipMemcpyHostToDevice, s));
+    if (x_now) HB_HIP(hipMemcpyAsync(ctx->b.x0, x_now, B * HB_NX * 8, hipMemcpyHostToDevice, s));
+  } else {  // enqueue-only form (status through hb_refgen_get_status)
+    int32_t rc;
+    if ((rc = stage_upload(ctx, ST_T0, r.t0, t0, B * 8, s)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_CMD, r.cmd, cmd_vel, B * 4 * 8, s)) != HB_OK) return rc;
+    if (x_now && (rc = stage_upload(ctx, ST_X0, ctx->b.x0, x_now, B * HB_NX * 8, s)) != HB_OK) return rc;
+  }
   hipLaunchKernelGGL(k_refgen, dim3((ctx->B + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
   if (ctx->rg_cfg.joint_ik)
     hipLaunchKernelGGL(k_refgen_ik, dim3((2 * ctx->B + 7) / 8), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
   hipLaunchKernelGGL(k_refgen_nodes, dim3((ctx->B * ctx->Nmax + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->rg_cfg);
   HB_HIP(hipGetLastError());
   r.init_stance = 0;
-  if (status) HB_HIP(hipMemcpyAsync(status, r.status, B * sizeof(int), hipMemcpyDeviceToHost, s));
-  HB_HIP(hipStreamSynchronize(s));
+  if (status) {
+    HB_HIP(hipMemcpyAsync(status, r.status, B * sizeof(int), hipMemcpyDeviceToHost, s));
+    HB_HIP(hipStreamSynchronize(s));
+  }
   ctx->refs_set = true;
+  return HB_OK;
+}
+
+int32_t hb_refgen_get_status(hb_ctx* ctx, int32_t* status) {
+  if (ctx) lazy_join(ctx);
+  if (!ctx || !status) return HB_ERR_ARG;
+  if (!ctx->rg_ready) {
+    ctx->err = "hb_refgen_get_status: call hb_refgen_reset first";
+    return HB_ERR_STATE;
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  HB_HIP(hipMemcpyAsync(status, ctx->rg.status, size_t(ctx->B) * sizeof(int), hipMemcpyDeviceToHost, ctx->s_mpc));
+  HB_HIP(hipStreamSynchronize(ctx->s_mpc));
   return HB_OK;
 }
 
@@ -1290,7 +1344,7 @@ static int32_t estimator_run(hb_ctx* ctx, double dt, int32_t to_resident, double
   }
   if (rbd) HB_HIP(hipMemcpyAsync(rbd, e.rbd, B * HB_NRBD * 8, hipMemcpyDeviceToHost, s));
   if (x_state) HB_HIP(hipMemcpyAsync(x_state, e.x, B * HB_NX * 8, hipMemcpyDeviceToHost, s));
-  HB_HIP(hipStreamSynchronize(s));
+  if (rbd || x_state) HB_HIP(hipStreamSynchronize(s));  // without host outputs the call is enqueue-only
   return HB_OK;
 }
 
@@ -1307,12 +1361,22 @@ int32_t hb_estimator_update(hb_ctx* ctx, double dt, const double* quat, const do
   const size_t B = ctx->B;
   EstBatch e = ctx->est;
   hipStream_t s = ctx->s_wbc;  // the estimator belongs to the control-thread side (LeggedController::update)
-  HB_HIP(hipMemcpyAsync(const_cast<double*>(e.quat), quat, B * 4 * 8, hipMemcpyHostToDevice, s));
-  HB_HIP(hipMemcpyAsync(const_cast<double*>(e.w_local), ang_vel_local, B * 3 * 8, hipMemcpyHostToDevice, s));
-  HB_HIP(hipMemcpyAsync(const_cast<double*>(e.a_local), lin_acc_local, B * 3 * 8, hipMemcpyHostToDevice, s));
-  HB_HIP(hipMemcpyAsync(const_cast<double*>(e.qj), joint_pos, B * 10 * 8, hipMemcpyHostToDevice, s));
-  HB_HIP(hipMemcpyAsync(const_cast<double*>(e.qdj), joint_vel, B * 10 * 8, hipMemcpyHostToDevice, s));
-  HB_HIP(hipMemcpyAsync(const_cast<int*>(e.contact), contact_flag, B * 4 * sizeof(int), hipMemcpyHostToDevice, s));
+  if (rbd || x_state) {
+    HB_HIP(hipMemcpyAsync(const_cast<double*>(e.quat), quat, B * 4 * 8, hipMemcpyHostToDevice, s));
+    HB_HIP(hipMemcpyAsync(const_cast<double*>(e.w_local), ang_vel_local, B * 3 * 8, hipMemcpyHostToDevice, s));
+    HB_HIP(hipMemcpyAsync(const_cast<double*>(e.a_local), lin_acc_local, B * 3 * 8, hipMemcpyHostToDevice, s));
+    HB_HIP(hipMemcpyAsync(const_cast<double*>(e.qj), joint_pos, B * 10 * 8, hipMemcpyHostToDevice, s));
+    HB_HIP(hipMemcpyAsync(const_cast<double*>(e.qdj), joint_vel, B * 10 * 8, hipMemcpyHostToDevice, s));
+    HB_HIP(hipMemcpyAsync(const_cast<int*>(e.contact), contact_flag, B * 4 * sizeof(int), hipMemcpyHostToDevice, s));
+  } else {  // enqueue-only form: the sensor arrays go through pinned staging and are the caller's again on return
+    int32_t rc;
+    if ((rc = stage_upload(ctx, ST_QUAT, const_cast<double*>(e.quat), quat, B * 4 * 8, s)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_W, const_cast<double*>(e.w_local), ang_vel_local, B * 3 * 8, s)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_A, const_cast<double*>(e.a_local), lin_acc_local, B * 3 * 8, s)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_QJ, const_cast<double*>(e.qj), joint_pos, B * 10 * 8, s)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_QDJ, const_cast<double*>(e.qdj), joint_vel, B * 10 * 8, s)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_CONTACT, const_cast<int*>(e.contact), contact_flag, B * 4 * sizeof(int), s)) != HB_OK) return rc;
+  }
   return estimator_run(ctx, dt, to_resident, rbd, x_state);
 }
 
@@ -1793,9 +1857,7 @@ int32_t hb_set_resident_time(hb_ctx* ctx, const double* t_now) {
   if (ctx) lazy_join(ctx);
   if (!ctx || !t_now) return HB_ERR_ARG;
   HB_HIP(hipSetDevice(ctx->device));
-  HB_HIP(hipMemcpyAsync(ctx->w.t_now, t_now, size_t(ctx->B) * 8, hipMemcpyHostToDevice, ctx->s_wbc));
-  HB_HIP(hipStreamSynchronize(ctx->s_wbc));  // host buffer is caller-owned
-  return HB_OK;
+  return stage_upload(ctx, ST_TNOW, ctx->w.t_now, t_now, size_t(ctx->B) * 8, ctx->s_wbc);  // no device synchronisation
 }
 
 int32_t hb_set_resident_x0_sequence(hb_ctx* ctx, int32_t n_seq, const double* x0_seq) {

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
     "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd", "hb_plant_reset", "hb_plant_step",
     "hb_plant_get_state", "hb_hoqp_solve", "hb_mpc_reset_masked", "hb_mpc_get_status", "hb_joint_set_flags",
-    "hb_joint_get_emergency_stop", "hb_set_resident_time", "hb_get_wbc_iterations", "hb_ik_solve", "hb_debug_chunk_counters",
+    "hb_joint_get_emergency_stop", "hb_set_resident_time", "hb_get_wbc_iterations", "hb_ik_solve", "hb_debug_chunk_counters", "hb_refgen_get_status",
 ]
 # include/hunter_lcm.h
 LCM_SYMBOLS = ["hb_lcm_fingerprint", "hb_lcm_encoded_size", "hb_lcm_field_count", "hb_lcm_encode", "hb_lcm_decode", "hb_lcm_frame", "hb_lcm_unframe",
@@ -312,11 +312,17 @@ class HunterSolver:
         self._check(self.lib.hb_refgen_set_schedule(self.ctx, C.c_int32(inst_begin), C.c_int32(cnt), _p(n_ev), _p(ev), _p(modes)),
                     "hb_refgen_set_schedule")
 
-    def refgen_update(self, t0, horizon, x_now, cmd_vel):
-        status = np.zeros(self.B, dtype=np.int32)
+    def refgen_update(self, t0, horizon, x_now, cmd_vel, want_status=True):
+        """want_status=False: the enqueue-only form (no device synchronisation; status later through refgen_status())."""
+        status = np.zeros(self.B, dtype=np.int32) if want_status else None
         x = None if x_now is None else _f64(x_now, (self.B, 22))
         self._check(self.lib.hb_refgen_update(self.ctx, _p(_f64(t0, (self.B,))), C.c_double(horizon), _p(x), _p(_f64(cmd_vel, (self.B, 4))),
                                               _p(status)), "hb_refgen_update")
+        return status
+
+    def refgen_status(self):
+        status = np.zeros(self.B, dtype=np.int32)
+        self._check(self.lib.hb_refgen_get_status(self.ctx, _p(status)), "hb_refgen_get_status")
         return status
 
     def get_references(self):
@@ -333,9 +339,11 @@ class HunterSolver:
         self._est_cfg = est_cfg
         self._check(self.lib.hb_estimator_reset(self.ctx, C.byref(est_cfg), _p(x0)), "hb_estimator_reset")
 
-    def estimator_update(self, dt, quat, ang_vel_local, lin_acc_local, joint_pos, joint_vel, contact_flag, to_resident=False):
-        """-> rbd[B][32], x_state[B][22] (what WbcBase::update and the MPC observation take)."""
-        rbd, x = np.zeros((self.B, 32)), np.zeros((self.B, 22))
+    def estimator_update(self, dt, quat, ang_vel_local, lin_acc_local, joint_pos, joint_vel, contact_flag, to_resident=False,
+                         want_outputs=True):
+        """-> rbd[B][32], x_state[B][22] (what WbcBase::update and the MPC observation take).  want_outputs=False: the enqueue-only
+        form (results stay on the device, no synchronisation) -> (None, None)."""
+        rbd, x = (np.zeros((self.B, 32)), np.zeros((self.B, 22))) if want_outputs else (None, None)
         self._check(self.lib.hb_estimator_update(
             self.ctx, C.c_double(dt), _p(_f64(quat, (self.B, 4))), _p(_f64(ang_vel_local, (self.B, 3))),
             _p(_f64(lin_acc_local, (self.B, 3))), _p(_f64(joint_pos, (self.B, 10))), _p(_f64(joint_vel, (self.B, 10))),

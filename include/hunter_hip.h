@@ -238,7 +238,8 @@ int32_t hb_plant_get_state(hb_ctx* ctx, double* q, double* v, double* rbd, doubl
 int32_t hb_set_resident_inputs(hb_ctx* ctx, const double* x0, const double* t_now, const double* rbd,
                                const int32_t* walk_flag);
 /* The device-resident controller time alone ([batch], host).  hb_plant_step(to_resident) advances it by itself; an estimator
- * with to_resident (which replaces the resident observation and rbd state but knows no clock) leaves it to the caller. */
+ * with to_resident (which replaces the resident observation and rbd state but knows no clock) leaves it to the caller.
+ * Enqueue-only (pinned staging, no device synchronisation). */
 int32_t hb_set_resident_time(hb_ctx* ctx, const double* t_now);
 int32_t hb_step_resident(hb_ctx* ctx, double dt);
 /* Optional: a device-resident cyclic sequence of measured states x0_seq[n_seq][batch][22]; step k of
@@ -273,7 +274,9 @@ int32_t hb_estimator_reset(hb_ctx* ctx, const hb_estimator_config* cfg, const do
  * lin_acc_local[batch][3], joint_pos[batch][10], joint_vel[batch][10], contact_flag[batch][4] (contact order
  * L_f1 R_f1 L_f2 R_f2).  Host out (either may be NULL): rbd[batch][32] (the vector WbcBase::update takes),
  * x_state[batch][22] (the MPC observation state).  to_resident != 0 additionally stores both into the
- * device-resident inputs of hb_step_resident, so that estimate -> MPC -> WBC never leaves the GPU. */
+ * device-resident inputs of hb_step_resident, so that estimate -> MPC -> WBC never leaves the GPU.
+ * With rbd == NULL and x_state == NULL the call is ENQUEUE-ONLY (sensor arrays through pinned staging, no device
+ * synchronisation; see hb_refgen_update). */
 int32_t hb_estimator_update(hb_ctx* ctx, double dt, const double* quat, const double* ang_vel_local,
                             const double* lin_acc_local, const double* joint_pos, const double* joint_vel,
                             const int32_t* contact_flag, int32_t to_resident, double* rbd, double* x_state);
@@ -307,9 +310,14 @@ int32_t hb_refgen_set_schedule(hb_ctx* ctx, int32_t inst_begin, int32_t inst_cou
                                const double* event_times, const int32_t* modes);
 /* Generate the references of every instance for the horizon [t0[i], t0[i] + horizon].  x_now[batch][22] is the
  * observation (NULL: the device-resident x0, e.g. the estimator's output); cmd_vel[batch][4] = (vx, vy, vz, yaw rate).
- * status[batch] (may be NULL): 0 ok, 1 a swing phase runs out of the schedule, 2 grid longer than max_nodes. */
+ * status[batch] (may be NULL): 0 ok, 1 a swing phase runs out of the schedule, 2 grid longer than max_nodes.
+ * With status == NULL the call is ENQUEUE-ONLY: the host arrays are copied into library-owned pinned staging (they are the
+ * caller's again on return), no device synchronisation takes place, and the status words are read later with
+ * hb_refgen_get_status — a driver that feeds a batch every tick can then run a few ticks ahead of the device. */
 int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const double* x_now, const double* cmd_vel,
                          int32_t* status);
+/* Status words of the last hb_refgen_update (synchronises). */
+int32_t hb_refgen_get_status(hb_ctx* ctx, int32_t* status /*[batch]*/);
 /* Node tables back to the host (any pointer may be NULL); layouts as in hb_mpc_set_references. */
 int32_t hb_mpc_get_references(hb_ctx* ctx, int32_t inst_begin, int32_t inst_count, int32_t* n_nodes, double* t,
                               int32_t* mode, double* x_ref, double* swing_ref);

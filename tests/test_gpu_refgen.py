@@ -147,3 +147,56 @@ def test_refgen_error_conventions(params):
         assert (st == 2).all()                        # 100 intervals do not fit max_nodes = 10
     finally:
         s.close()
+
+
+def test_enqueue_only_tick_equals_the_synchronous_calls(params):
+    """hb_set_resident_time / hb_estimator_update(rbd = x_state = NULL) / hb_refgen_update(status = NULL) return without a device
+    synchronisation (pinned staging inside the library).  Six ticks of estimator -> references -> step on two contexts, one through
+    the synchronous forms, one through the enqueue-only forms with the caller's arrays OVERWRITTEN right after every call (they
+    must have been copied): identical tables, MPC iterate, WBC solution and status words."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B, N = 48, 40
+    c = params["config"]
+    horizon = N * c["dt"]
+    rng = np.random.default_rng(11)
+    out = []
+    for enqueue_only in (False, True):
+        s = HunterSolver(params, batch=B, max_nodes=N + 6)
+        try:
+            w = workload.device_trot_batch(s, params, n_intervals=N)
+            s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+            s.set_chunks(2)
+            xh0 = np.zeros((B, 18))
+            xh0[:, 0:3] = w["rbd"][:, 3:6]
+            xh0[:, 6:18] = np.asarray(s.eval_foot_kinematics(w["x0"], np.zeros((B, 22)))[0]).reshape(B, 12)
+            s.estimator_reset(abi.make_estimator_config(params), xh0)
+            srng = np.random.default_rng(5)
+            for k in range(6):
+                tk = w["t_now"] + 0.01 * (k + 1)
+                quat = np.tile([0.0, 0.0, 0.0, 1.0], (B, 1)) + 0.01 * srng.standard_normal((B, 4))
+                quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+                wl, al = 0.05 * srng.standard_normal((B, 3)), np.tile([0.0, 0.0, 9.81], (B, 1)) + 0.1 * srng.standard_normal((B, 3))
+                qj, qdj = w["rbd"][:, 6:16] + 0.01 * srng.standard_normal((B, 10)), 0.1 * srng.standard_normal((B, 10))
+                contact = np.ones((B, 4), dtype=np.int32)
+                cmd = w["cmd"].copy()
+                if enqueue_only:
+                    s.set_resident_time(tk)
+                    s.estimator_update(0.002, quat, wl, al, qj, qdj, contact, to_resident=True, want_outputs=False)
+                    assert s.refgen_update(tk, horizon, None, cmd, want_status=False) is None
+                    for a in (tk, quat, wl, al, qj, qdj, cmd):
+                        a[...] = rng.standard_normal(a.shape)      # the library must not be reading the caller's arrays any more
+                    contact[...] = 0
+                    s.step_resident()
+                else:
+                    s.set_resident_time(tk)
+                    s.estimator_update(0.002, quat, wl, al, qj, qdj, contact, to_resident=True)
+                    assert s.refgen_update(tk, horizon, None, cmd).max() == 0
+                    s.step_resident()
+            assert s.refgen_status().max() == 0
+            out.append((s.get_references(), s.get_solution(), s.get_wbc_solution(), s.mpc_status()))
+        finally:
+            s.close()
+    (ra, sa, wa, ma), (rb, sb, wb, mb) = out
+    assert np.array_equal(ra["t"], rb["t"]) and np.array_equal(ra["mode"], rb["mode"]) and np.array_equal(ra["x_ref"], rb["x_ref"])
+    assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
+    assert np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1]) and np.array_equal(ma, mb)

@@ -3,7 +3,7 @@
     python tools/perf_quick.py [--lib path/to/variant.so] [--ablate-lq] [--ablate-ric] [--steps K]
 Prints one JSON line per run: phase times from HIP events (hb_get_stats) and the step rate."""
 import argparse, json, os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default=None)
@@ -11,6 +11,8 @@ ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--ablate-lq", action="store_true")
 ap.add_argument("--ablate-ric", action="store_true")
 ap.add_argument("--batch", type=int, default=4096)
+ap.add_argument("--chunks", type=int, default=1)
+ap.add_argument("--stop", type=int, default=None, help="run ONLY this ablation stop (HB_ABLATE build), few steps: for counter passes")
 args = ap.parse_args()
 from pathlib import Path
 from hunter_bipedal_control_amd import ingest, workload, solver as _solver_mod
@@ -27,6 +29,7 @@ def run(reserved=0, steps=args.steps):
     w = workload.device_trot_batch(s, P, n_intervals=N)
     s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
     s.set_resident_x0_sequence(bench.x0_sequence(w["x0"], 0))
+    s.set_chunks(args.chunks)
     for _ in range(3):
         s.step_resident()
     s.sync()
@@ -36,6 +39,7 @@ def run(reserved=0, steps=args.steps):
     s.sync()
     el = time.perf_counter() - t0
     acc = {}
+    s.set_chunks(1)
     for _ in range(5):
         s.step_resident()
         st = s.stats()
@@ -48,6 +52,10 @@ def run(reserved=0, steps=args.steps):
                 **{k: round(v, 3) for k, v in acc.items()})
 
 
+if args.stop is not None:
+    r = run(args.stop, steps=3)
+    print(json.dumps(dict(stop=args.stop, ms_lq=r["ms_lq"])))
+    sys.exit(0)
 print(json.dumps(dict(lib=args.lib or "default", **run())))
 if args.ablate_lq:
     for stop in (10, 6, 7, 9, 1, 2, 3, 4, 5, 30, 31, 32, 33, 34):

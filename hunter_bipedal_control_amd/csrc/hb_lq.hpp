@@ -324,8 +324,6 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* scal = lds + LqLds::scal;
   int* ints = reinterpret_cast<int*>(lds + LqLds::ints);
   int* perm = ints;          // [10]
-  int* eqs = ints + 12;      // [12] eq slot list
-  int* softs = ints + 24;    // [8] soft slot list
 
   const double dt = in.dt;
   bool cf[HB_NC];
@@ -380,20 +378,11 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     xplus[i] = (i < 12) ? xs[i] + 0.5 * dt * (fv[i] + fv[12 + i]) : xs[i] + dt * us[i];
   cx.sync();
   HB_ABLATE_STOP(C.debug_stop == 1);
-  // slot classification (uniform)
-  int n_eq = 0, n_soft = 0, n_f = 0;
-  for (int i = 0; i < HB_NC; ++i) {
-    if (cf[i]) {
-      n_f += 3;
-      if (cx.lane == 0) { eqs[n_eq] = 3 * i; eqs[n_eq + 1] = 3 * i + 1; eqs[n_eq + 2] = 3 * i + 2; }
-      n_eq += 3;
-    } else {
-      if (cx.lane == 0) { eqs[n_eq] = 3 * i; softs[n_soft] = 3 * i + 1; softs[n_soft + 1] = 3 * i + 2; }
-      n_eq += 1;
-      n_soft += 2;
-    }
-  }
-  cx.sync();
+  // slot classification (uniform): contact foot = 3 equality rows (zero velocity), swing foot = 1 equality row (normal velocity,
+  // slot 3i) + 2 soft rows (xy reference, slots 3i+1, 3i+2)
+  int n_f = 0;
+  for (int i = 0; i < HB_NC; ++i)
+    if (cf[i]) n_f += 3;
 
   // -------------------------------------------------------------- phase 2: G'G, G'[C e], pivoted Cholesky
   // joint-velocity directions are 34..43.  One masked Gram product on the matrix cores gives both:
@@ -411,9 +400,16 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       else GtG[k * 10 + r - 22] = v;
     });
   }
+  // (masked sums over the 12 constraint slots, unrolled with 0 / 1 weights: walking the index lists eqs / softs made every term a
+  // chain of dependent LDS reads — index, then operands — of up to 12 round trips; the terms come in the same order, so the sums
+  // are the same to the last bit)
   for (int k = cx.lane; k < 10; k += cx.nlanes) {
     double s = 0;
-    for (int a = 0; a < n_eq; ++a) s += CDt[(22 + k) * 12 + eqs[a]] * rowval[eqs[a]];
+#pragma unroll
+    for (int slot = 0; slot < 12; ++slot) {
+      const double w = (((cfm >> (slot / 3)) & 1) || slot % 3 == 0) ? 1.0 : 0.0;
+      s += (w * CDt[(22 + k) * 12 + slot]) * rowval[slot];
+    }
     W[k * 23 + 22] = s;
   }
   cx.sync();
@@ -718,15 +714,15 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
 #endif
   HB_ABLATE_STOP(C.debug_stop == 4);
   // soft rows: gradients and the dense pieces P_j, R_jj
-  for (int c = cx.lane; c < 22; c += cx.nlanes) {
+  for (int c = cx.lane; c < 32; c += cx.nlanes) {  // rows 0..21: state directions -> q_x; rows 22..31: joint-rate directions -> r_u
     double s = 0;
-    for (int t = 0; t < n_soft; ++t) s += rowval[softs[t]] * CDt[c * 12 + softs[t]];
-    qx[c] += C.soft_w * s;
-  }
-  for (int k = cx.lane; k < 10; k += cx.nlanes) {
-    double s = 0;
-    for (int t = 0; t < n_soft; ++t) s += rowval[softs[t]] * CDt[(22 + k) * 12 + softs[t]];
-    ru[12 + k] += C.soft_w * s;
+#pragma unroll
+    for (int slot = 0; slot < 12; ++slot) {
+      const double w = (slot % 3 != 0 && !((cfm >> (slot / 3)) & 1)) ? 1.0 : 0.0;
+      s += (w * rowval[slot]) * CDt[c * 12 + slot];
+    }
+    if (c < 22) qx[c] += C.soft_w * s;
+    else ru[12 + c - 22] += C.soft_w * s;
   }
   {
     const double sw = C.soft_w;

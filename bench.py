@@ -248,9 +248,9 @@ def backtracking_figure(params, device, B, N, first, random_cmd, steps):
         perf = s.get_performance()
         return {"updates_per_s": B * steps / el, "ms_per_step": 1e3 * el / steps, "steps": steps, "linesearch_ms": ls,
                 "line_search_step_histogram": {"full": int((perf[:, 3] == 1.0).sum()), "backtracked": int(((perf[:, 3] < 1.0) & (perf[:, 3] > 0.0)).sum()),
-                                               "rejected": int((perf[:, 3] == 0.0).sum())},
+                                               "no_step": int((perf[:, 3] == 0.0).sum())},
                 "mpc_status_histogram": [int((s.mpc_status() == i).sum()) for i in range(4)],
-                "what": "fixed x0 (no measurement noise): repeated SQP iterations on a converging iterate; the filter line search backtracks"}
+                "what": "fixed x0 (no measurement noise): repeated SQP iterations on a converging iterate; the filter line search backtracks until a step passes or, once alpha |dx| and alpha |du| are below sqp.deltaTol, gives up without a step (no_step; status OK = converged; MAXITER = alpha_min reached)"}
     finally:
         s.close()
 
@@ -461,7 +461,7 @@ def main():
                              "wbc_active_set_iterations_histogram_all_ranks": {f"{lo}..{hi - 1}" if hi < (1 << 30) else f">={lo}": n
                                                                                for lo, hi, n in zip(it_edges, it_edges[1:], it_hist)},
                              "wbc_active_set_iterations_min_max_rank0": [int(wbc_iters.min()), int(wbc_iters.max())],
-                             "line_search_step_histogram_all_ranks": {"full": step_hist[0], "backtracked": step_hist[1], "rejected": step_hist[2]},
+                             "line_search_step_histogram_all_ranks": {"full": step_hist[0], "backtracked": step_hist[1], "no_step": step_hist[2]},
                              "nodes_per_instance_min_max": [int(n_nodes.min()), int(n_nodes.max())],
                              "chunk_step_counters_rank0": chunk_counters},
         }

@@ -52,6 +52,7 @@ class HbConfig(C.Structure):
         ("wbc_eps_reg", C.c_double),
         ("wbc_max_iter", C.c_int32), ("reserved", C.c_int32),
         ("default_joint_state", C.c_double * NJ),
+        ("delta_tol", C.c_double),
     ]
 
 
@@ -121,6 +122,7 @@ def make_config(params: dict, **overrides) -> HbConfig:
     out.wbc_eps_reg = 1e-8
     out.wbc_max_iter = 120
     _fill(out.default_joint_state, c["default_joint_state"])
+    out.delta_tol = c["delta_tol"]
     for k, v in overrides.items():
         if isinstance(v, (list, tuple)):
             _fill(getattr(out, k), v)

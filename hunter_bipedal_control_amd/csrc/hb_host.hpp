@@ -82,7 +82,7 @@ inline DevConfig make_dev_config(const hb_config& c, const DevModel& M) {
   d.kp_normal = c.position_error_gain; d.zv_gain = c.zero_vel_z_gain; d.zv_off = c.zero_vel_z_offset;
   d.xy_gain = c.xy_ref_gain;
   d.g_max = c.g_max; d.g_min = c.g_min; d.alpha_decay = c.alpha_decay; d.alpha_min = c.alpha_min;
-  d.gamma_c = c.gamma_c; d.armijo = c.armijo_factor;
+  d.gamma_c = c.gamma_c; d.armijo = c.armijo_factor; d.delta_tol = c.delta_tol;
   for (int i = 0; i < 5; ++i) d.torque_limits[i] = c.torque_limits[i];
   d.wbc_mu = c.wbc_friction_mu; d.swing_kp = c.swing_kp; d.swing_kd = c.swing_kd;
   d.bh_kp = c.base_height_kp; d.bh_kd = c.base_height_kd; d.ba_kp = c.base_angular_kp; d.ba_kd = c.base_angular_kd;

@@ -181,7 +181,7 @@ __global__ void k_mpc_status(Batch b, int first_iteration) {
                       (!b.accepted[i] || (isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2])));
   int st = HB_INST_OK;
   if (b.ric_fail[i] || !finite) st = HB_INST_NAN;
-  else if (!b.accepted[i]) st = HB_INST_MAXITER;
+  else if (!b.accepted[i]) st = HB_INST_MAXITER;   // (accepted = 2: the search stopped on deltaTol — converged, no step — is OK)
   // sticky over the SQP iterations of one call: the worst word any iteration produced (NAN > INFEASIBLE > MAXITER > OK)
   b.mpc_status[i] = first_iteration ? st : max(b.mpc_status[i], st);
 }
@@ -437,7 +437,23 @@ __global__ __launch_bounds__(64) void k_ls_tail(Batch b, const DevModel* __restr
   const double armijo = b.acc[inst * 4 + 0], base_merit = b.acc[inst * 4 + 1];
   const double base_viol = sqrt(b.acc[inst * 4 + 2] + b.acc[inst * 4 + 3]);
   const bool ric_ok = !b.ric_fail[inst];
+  // |dx|, |du| over the whole trajectory: the search gives up once alpha |dx| and alpha |du| are both below sqp.deltaTol
+  // ([OCS2-knowledge] SqpSolver::takeStep, "detect too small step size during back-tracking to escape early"): no step, like
+  // reaching alpha_min, but the instance is converged, not failed (accepted = 2 -> HB_INST_OK)
+  double nx2 = 0, nu2 = 0;
+  {
+    const size_t xo = size_t(inst) * (b.Nmax + 1) * HB_NX, uo = size_t(inst) * b.Nmax * HB_NU;
+    for (int i = lane; i < (n + 1) * HB_NX; i += 64) nx2 += b.dx[xo + i] * b.dx[xo + i];
+    for (int i = lane; i < n * HB_NU; i += 64) nu2 += b.du[uo + i] * b.du[uo + i];
+    nx2 = wave_sum(nx2);
+    nu2 = wave_sum(nu2);
+  }
+  const double dx_norm = sqrt(nx2), du_norm = sqrt(nu2), delta_tol = C->delta_tol;
   for (double alpha = alpha0; alpha >= alpha_min; alpha *= decay) {
+    if (alpha * du_norm < delta_tol && alpha * dx_norm < delta_tol) {
+      if (lane == 0) b.accepted[inst] = 2;
+      return;
+    }
     double m = 0, d = 0, e = 0;
     for (int k = lane; k < n; k += 64) {
       const size_t nd = size_t(inst) * b.Nmax + k;

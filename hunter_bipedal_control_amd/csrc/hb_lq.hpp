@@ -28,7 +28,7 @@ struct DevConfig {
   double soft_w;
   double pos_b[2], vel_b[2], force_b[2], force_lim[2];
   double kp_normal, zv_gain, zv_off, xy_gain;
-  double g_max, g_min, alpha_decay, alpha_min, gamma_c, armijo;
+  double g_max, g_min, alpha_decay, alpha_min, gamma_c, armijo, delta_tol;
   // WBC
   double torque_limits[5];
   double wbc_mu, swing_kp, swing_kd, bh_kp, bh_kd, ba_kp, ba_kd, w_swing, w_base, w_force, wbc_eps;

@@ -49,7 +49,8 @@ typedef enum hb_status {
 /* Per-instance solver status words written by the device (SURVEY.md §5 "failure detection"). */
 #define HB_INST_OK 0
 #define HB_INST_MAXITER 1   /* WBC QP hit its working-set-change limit: previous solution reused
-                               (legged_wbc/src/WeightedWbc.cpp:57-65) */
+                               (legged_wbc/src/WeightedWbc.cpp:57-65); MPC: the line search reached alpha_min without
+                               an acceptable step (a search that stops on deltaTol — converged — is HB_INST_OK) */
 #define HB_INST_INFEASIBLE 2
 #define HB_INST_NAN 3       /* non-finite value / non-positive Riccati pivot */
 
@@ -100,6 +101,9 @@ typedef struct hb_config {
   int32_t wbc_max_iter;            /* working-set-change limit; reference nWSR = 20 (WeightedWbc.cpp:50) */
   int32_t reserved;
   double default_joint_state[HB_NJ]; /* reference.info:7-19 */
+  double delta_tol;                /* sqp.deltaTol, task.info:84: the line search gives up (no step, as at alpha_min) once
+                                      alpha |dx| and alpha |du| — l2 norms over the whole trajectory — are both below it
+                                      ([OCS2-knowledge] SqpSolver::takeStep "escape early"); 0 disables */
 } hb_config;
 
 typedef struct hb_ctx hb_ctx;

@@ -267,6 +267,7 @@ inline void readConfig(const std::string& taskFile, const std::string& reference
   c.wbc_max_iter = 120;
   const std::vector<double> dj = ref.matrix("defaultJointState", 10, 1);
   for (int j = 0; j < HB_NJ; ++j) c.default_joint_state[j] = dj[size_t(j)];
+  c.delta_tol = task.number("sqp.deltaTol");
   p.timeHorizon = task.number("mpc.timeHorizon");
   p.mpcFrequency = task.number("mpc.mpcDesiredFrequency");
   p.phaseTransitionStanceTime = task.number("model_settings.phaseTransitionStanceTime");

@@ -117,6 +117,7 @@ struct SqpResult {
   double armijo = 0;
   bool ok = true;
   int accepted_type = 0;  // 0 none, 1 cost, 2 constraint
+  bool early_exit = false;  // the search stopped on deltaTol (no step)
 };
 
 // One SQP iteration in place on in.x / in.u (x[0] is overwritten with the measured state).
@@ -156,6 +157,12 @@ inline SqpResult sqp_iteration(const Problem& pb, MpcInstance& in, const double*
 
   // filter line search (OCS2 FilterLinesearch::acceptStep)
   const double base_viol = base.violation();
+  // |dx|, |du|: l2 norms over the whole trajectory ([OCS2-knowledge] SqpSolver::trajectoryNorm)
+  double dx_norm = 0, du_norm = 0;
+  for (int k = 0; k <= N; ++k) dx_norm += dot(dx[k], dx[k]);
+  for (int k = 0; k < N; ++k) du_norm += dot(du[k], du[k]);
+  dx_norm = std::sqrt(dx_norm);
+  du_norm = std::sqrt(du_norm);
   double alpha = 1.0;
   std::vector<double> xn(in.x.size()), un(in.u.size());
   while (alpha >= c.alpha_min) {
@@ -187,6 +194,11 @@ inline SqpResult sqp_iteration(const Problem& pb, MpcInstance& in, const double*
       return res;
     }
     alpha *= c.alpha_decay;
+    // "Detect too small step size during back-tracking to escape early" ([OCS2-knowledge] SqpSolver::takeStep, sqp.deltaTol)
+    if (alpha * du_norm < c.delta_tol && alpha * dx_norm < c.delta_tol) {
+      res.early_exit = true;
+      break;
+    }
   }
   // no step accepted: keep the trajectory (OCS2 returns step size 0)
   res.accepted = base;

@@ -78,6 +78,11 @@ double emu_sqp_iteration(const hb_model* m, const hb_config* c, int N, const dou
   if (dx_out) std::memcpy(dx_out, dx.data(), dx.size() * 8);
   if (du_out) std::memcpy(du_out, du.data(), du.size() * 8);
   double alpha = 1.0;
+  double dx_norm = 0, du_norm = 0;  // k_ls_tail: the search gives up once alpha |dx|, alpha |du| are both below sqp.deltaTol
+  for (double v : dx) dx_norm += v * v;
+  for (double v : du) du_norm += v * v;
+  dx_norm = std::sqrt(dx_norm);
+  du_norm = std::sqrt(du_norm);
   std::vector<double> xt((N + 1) * 22), ut(N * 22);
   perf4[0] = base_merit; perf4[1] = fl[FwdLds::acc + 2]; perf4[2] = fl[FwdLds::acc + 3]; perf4[3] = 0.0;
   while (alpha >= dc.alpha_min) {
@@ -97,6 +102,7 @@ double emu_sqp_iteration(const hb_model* m, const hb_config* c, int N, const dou
       return alpha;
     }
     alpha *= dc.alpha_decay;
+    if (alpha * du_norm < dc.delta_tol && alpha * dx_norm < dc.delta_tol) break;
   }
   return 0.0;
 }

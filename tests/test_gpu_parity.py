@@ -107,6 +107,45 @@ def test_sqp_iterations_match_oracle(params, oracle, solver_small):
     assert perf_g[:, 1].max() < 1e-6
 
 
+def test_line_search_gives_up_on_delta_tol_like_the_oracle(params, oracle):
+    """sqp.deltaTol (task.info:84; [OCS2-knowledge] SqpSolver::takeStep "escape early"): repeated iterations on a fixed observation
+    converge; once a step is rejected and alpha |dx|, alpha |du| are below deltaTol the filter line search stops without a step.
+    Device and oracle take the same step sizes iteration by iteration; an instance that stops this way ends the call with step 0
+    and status OK (converged), where the same call with delta_tol = 0 walks on (a smaller step, or alpha_min -> MAXITER)."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B, nmax, iters = 6, 40, 16
+    refs, x0, rbd, t_now = workloads.trot_batch(params, B, n_intervals=40, cmd_vel=(0.2, 0.0, 0.0, 0.0), max_nodes=nmax)
+    out = {}
+    for tol in (params["config"]["delta_tol"], 0.0):
+        s = HunterSolver(params, batch=B, max_nodes=nmax, delta_tol=tol)
+        try:
+            s.set_references(refs)
+            s.reset(x0)
+            xo, uo = s.get_solution()
+            xo, uo = xo.copy(), uo.copy()
+            steps, status = [], []
+            for it in range(iters):
+                if tol > 0.0:
+                    perf_o = oracle.mpc_solve(refs, x0, xo, uo, iters=1, threads=4)
+                s.mpc_solve(x0)
+                perf_g = s.get_performance()
+                if tol > 0.0:
+                    assert np.array_equal(perf_g[:, 3], perf_o[:, 3]), (it, perf_g[:, 3], perf_o[:, 3])
+                steps.append(perf_g[:, 3].copy())
+                status.append(s.mpc_status().copy())
+            out[tol] = (np.array(steps), np.array(status))
+        finally:
+            s.close()
+    steps, status = out[params["config"]["delta_tol"]]
+    stopped = np.argwhere(steps == 0.0)
+    assert len(stopped) >= 1, steps                   # the case occurs ...
+    assert (status[steps == 0.0] == 0).all()          # ... and is "converged", not a failed line search
+    it, inst = stopped[0]                              # up to here both runs did identical arithmetic
+    steps0, status0 = out[0.0]
+    assert np.array_equal(steps0[:it, inst], steps[:it, inst])
+    assert steps0[it, inst] > 0.0 or status0[it, inst] == 1
+
+
 def test_wbc_direct_matches_oracle(params, oracle):
     from hunter_bipedal_control_amd.solver import HunterSolver
     B = 64

@@ -151,8 +151,17 @@ inline ConeTerms friction_cone_terms(const hb_config& c, double Fx, double Fy, d
   return o;
 }
 
+// Pieces of stage_terms as it computes them, for the tests that hold them to the reference's own compiled files
+// (tests/test_ref_ocp.py): the foot kinematics with their derivatives, the tracking cost on its own, the xy soft rows.
+struct StageDebug {
+  FootKin<D44> fk;
+  double track_cost = 0;
+  Vec track_q, track_r;
+  D44 xy[HB_NC][2];
+};
+
 inline void stage_terms(const Problem& pb, const NodeRef& ref, const double* x, const double* u, NodeValue& val,
-                        NodeLQ* lq) {
+                        NodeLQ* lq, StageDebug* dbg = nullptr) {
   const hb_config& c = pb.cfg;
   bool cf[HB_NC];
   mode_to_contact_flags(ref.mode, cf);
@@ -167,6 +176,7 @@ inline void stage_terms(const Problem& pb, const NodeRef& ref, const double* x, 
     for (int i = 0; i < HB_NU; ++i) ud[i] = D44::seed(u[i], HB_NX + i);
     foot_kinematics<D44>(pb.mdl, xd, ud, fk.pos, fk.vel);
   }
+  if (dbg) dbg->fk = fk;
 
   Mat Q(HB_NX, HB_NX), R = pb.R, P(HB_NU, HB_NX);
   Vec q(HB_NX, 0.0), r(HB_NU, 0.0);
@@ -188,6 +198,7 @@ inline void stage_terms(const Problem& pb, const NodeRef& ref, const double* x, 
       cost += 0.5 * du[i] * s;
     }
   }
+  if (dbg) { dbg->track_cost = cost; dbg->track_q = q; dbg->track_r = r; }
   // ---- friction cone soft constraint, contact feet (FrictionConeConstraint.cpp:70-233)
   const RelaxedBarrier fb{c.friction_barrier_mu, c.friction_barrier_delta};
   for (int i = 0; i < HB_NC; ++i) {
@@ -213,6 +224,7 @@ inline void stage_terms(const Problem& pb, const NodeRef& ref, const double* x, 
     const double* sw = ref.swing + 6 * i;
     for (int a = 0; a < 2; ++a) {
       const D44 g = c.xy_ref_gain * fk.pos[i][a] + fk.vel[i][a] - (sw[3 + a] + c.xy_ref_gain * sw[a]);
+      if (dbg) dbg->xy[i][a] = g;
       cost += 0.5 * c.soft_swing_weight * g.v * g.v;
       for (int m = 0; m < HB_NX; ++m) {
         q[m] += c.soft_swing_weight * g.v * g.d[m];

@@ -5,7 +5,8 @@
 // OCS2 / HPIPM / pinocchio / qpOASES cannot be built here.  Pinned to the reference's OWN sources compiled in place
 // (oracle/Makefile target ref -> oracle/_ref/, golden vectors under tests/golden/): the WBC task builders,
 // WeightedWbc, HierarchicalWbc, HoQp and Task (wbc.hpp, hoqp.hpp: tests/test_ref_wbc.py), the friction-cone and zero-force terms
-// (ocp.hpp: tests/test_ref_constraints.py), the Kalman filter (estimator.hpp: tests/test_ref_kf.py).
+// (ocp.hpp: tests/test_ref_constraints.py), the end-effector constraint rows, xy soft rows, tracking cost and initializer of a node
+// (ocp.hpp / sqp.hpp: tests/test_ref_ocp.py), the Kalman filter (estimator.hpp: tests/test_ref_kf.py).
 // PARITY UNPINNED for what the reference delegates to absent libraries: the centroidal dynamics and their sensitivities
 // (model.hpp, ocp.hpp), the SQP / projection / Riccati / line search (sqp.hpp) and the rigid-body terms M, nle, J, dJ (model.hpp):
 // a from-scratch restatement held by invariants (tests/test_oracle_*.py) and by the known answers the reference does hold
@@ -205,6 +206,36 @@ int orc_node_lq(void* h, double dt, int mode, const double* x_ref, const double*
   if (Px) copy_mat(lq.Px, Px);
   if (Pe) std::memcpy(Pe, lq.Pe.data(), 22 * 8);
   return lq.C.r;
+}
+
+// Pieces of one node's stage terms (StageDebug): foot kinematics pos / vel [4][3] with gradients [4][3][44] over (x, u), the tracking
+// cost alone (value, q[22], r[22]), the xy soft rows of the swing feet (value [4][2], gradient [4][2][44]; zero for contact feet).
+void orc_stage_pieces(void* h, int mode, const double* x_ref, const double* swing, const double* x, const double* u, double* pos,
+                      double* vel, double* dpos, double* dvel, double* track3, double* track_q, double* track_r, double* xy_val,
+                      double* xy_grad) {
+  const Problem& pb = *static_cast<Problem*>(h);
+  NodeRef ref;
+  ref.dt = 0.015; ref.mode = mode; ref.x_ref = x_ref; ref.swing = swing;
+  NodeValue val;
+  NodeLQ lq;
+  StageDebug dbg;
+  stage_terms(pb, ref, x, u, val, &lq, &dbg);
+  for (int c = 0; c < HB_NC; ++c)
+    for (int a = 0; a < 3; ++a) {
+      pos[3 * c + a] = dbg.fk.pos[c][a].v;
+      vel[3 * c + a] = dbg.fk.vel[c][a].v;
+      for (int j = 0; j < 44; ++j) {
+        dpos[(3 * c + a) * 44 + j] = dbg.fk.pos[c][a].d[j];
+        dvel[(3 * c + a) * 44 + j] = dbg.fk.vel[c][a].d[j];
+      }
+    }
+  track3[0] = dbg.track_cost;
+  for (int i = 0; i < HB_NX; ++i) { track_q[i] = dbg.track_q[i]; track_r[i] = dbg.track_r[i]; }
+  for (int c = 0; c < HB_NC; ++c)
+    for (int a = 0; a < 2; ++a) {
+      xy_val[2 * c + a] = dbg.xy[c][a].v;
+      for (int j = 0; j < 44; ++j) xy_grad[(2 * c + a) * 44 + j] = dbg.xy[c][a].d[j];
+    }
 }
 
 // Generic unconstrained LQ solve (dense stage data, nu inputs per stage) — checks the Riccati restatement

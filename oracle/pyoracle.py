@@ -135,6 +135,18 @@ class Oracle:
         o["cost"], o["rank"], o["m"] = cost.value, rank.value, m
         return o
 
+    def stage_pieces(self, mode, x_ref, swing, x, u):
+        """Pieces of one node's stage terms as stage_terms computes them (ocp.hpp StageDebug): foot kinematics with gradients over
+        (x, u), the tracking cost on its own, the xy soft rows of the swing feet."""
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        x_ref, swing, x, u = c(x_ref), c(swing), c(x), c(u)
+        o = dict(pos=np.zeros((4, 3)), vel=np.zeros((4, 3)), dpos=np.zeros((4, 3, 44)), dvel=np.zeros((4, 3, 44)), track=np.zeros(3),
+                 track_q=np.zeros(22), track_r=np.zeros(22), xy=np.zeros((4, 2)), dxy=np.zeros((4, 2, 44)))
+        self.lib.orc_stage_pieces(self.h, C.c_int(mode), _opt(x_ref), _opt(swing), _opt(x), _opt(u), _opt(o["pos"]), _opt(o["vel"]),
+                                  _opt(o["dpos"]), _opt(o["dvel"]), _opt(o["track"]), _opt(o["track_q"]), _opt(o["track_r"]), _opt(o["xy"]),
+                                  _opt(o["dxy"]))
+        return o
+
     def riccati(self, A, B, b, Q, R, P, q, r, dx0):
         c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         A, B, b, Q, R, P, q, r, dx0 = map(c, (A, B, b, Q, R, P, q, r, dx0))

@@ -8,6 +8,12 @@ template <class V>
 Eigen::Matrix<scalar_t, 3, 1> getContactForces(const V& input, size_t contactIndex, const CentroidalModelInfo&) {
   return Eigen::Matrix<scalar_t, 3, 1>(input(3 * int(contactIndex)), input(3 * int(contactIndex) + 1), input(3 * int(contactIndex) + 2));
 }
+// writable views (OCS2 returns Eigen blocks): legged_interface/common/utils.h assigns the contact force of an input vector,
+// LeggedRobotInitializer.cpp zeroes the normalised momentum of a state vector
+inline Eigen::BlockRef<scalar_t> getContactForces(vector_t& input, size_t contactIndex, const CentroidalModelInfo&) {
+  return input.segment(3 * int(contactIndex), 3);
+}
+inline Eigen::BlockRef<scalar_t> getNormalizedMomentum(vector_t& state, const CentroidalModelInfo&) { return state.segment(0, 6); }
 template <class V>
 vector_t getJointVelocities(const V& input, const CentroidalModelInfo& info) {
   return input.segment(int(3 * info.numThreeDofContacts + 6 * info.numSixDofContacts), int(info.actuatedDofNum));

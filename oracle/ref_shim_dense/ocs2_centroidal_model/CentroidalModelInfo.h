@@ -10,4 +10,5 @@ struct CentroidalModelInfo {
   size_t generalizedCoordinatesNum = 16, actuatedDofNum = 10, stateDim = 22, inputDim = 22;
   scalar_t robotMass = 0.0;
 };
+template <class SCALAR_T> using CentroidalModelInfoTpl = CentroidalModelInfo;  // (the scalar type only matters for CppAD)
 }  // namespace ocs2

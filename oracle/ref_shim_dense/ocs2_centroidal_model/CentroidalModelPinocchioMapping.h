@@ -7,6 +7,7 @@ namespace ocs2 {
 class CentroidalModelPinocchioMapping {
  public:
   explicit CentroidalModelPinocchioMapping(CentroidalModelInfo info) : info_(std::move(info)) {}
+  CentroidalModelPinocchioMapping* clone() const { return new CentroidalModelPinocchioMapping(*this); }
   void setPinocchioInterface(const PinocchioInterface&) {}
   vector_t getPinocchioJointPosition(const vector_t& state) const { return state.tail(int(info_.generalizedCoordinatesNum)); }
   vector_t getPinocchioJointVelocity(const vector_t&, const vector_t&) const { return vector_t::Zero(int(info_.generalizedCoordinatesNum)); }

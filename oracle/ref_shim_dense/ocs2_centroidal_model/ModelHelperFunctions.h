@@ -4,4 +4,5 @@
 #include <ocs2_pinocchio_interface/PinocchioInterface.h>
 namespace ocs2 {
 template <class Q> void updateCentroidalDynamics(PinocchioInterface&, const CentroidalModelInfo&, const Q&) {}
+template <class Q, class V> void updateCentroidalDynamicsDerivatives(PinocchioInterface&, const CentroidalModelInfo&, const Q&, const V&) {}
 }  // namespace ocs2

@@ -14,6 +14,16 @@ using vector_t = Eigen::Matrix<scalar_t, Eigen::Dynamic, 1>;
 using matrix_t = Eigen::Matrix<scalar_t, Eigen::Dynamic, Eigen::Dynamic>;
 using vector_array_t = std::vector<vector_t>;
 using matrix_array_t = std::vector<matrix_t>;
-struct VectorFunctionLinearApproximation { vector_t f; matrix_t dfdx, dfdu; };
+struct VectorFunctionLinearApproximation {
+  vector_t f;
+  matrix_t dfdx, dfdu;
+  static VectorFunctionLinearApproximation Zero(size_t nv, size_t nx, size_t nu) {
+    VectorFunctionLinearApproximation a;
+    a.f = vector_t::Zero(int(nv));
+    a.dfdx = matrix_t::Zero(int(nv), int(nx));
+    a.dfdu = matrix_t::Zero(int(nv), int(nu));
+    return a;
+  }
+};
 struct VectorFunctionQuadraticApproximation { vector_t f; matrix_t dfdx, dfdu; matrix_array_t dfdxx, dfdux, dfduu; };
 }  // namespace ocs2

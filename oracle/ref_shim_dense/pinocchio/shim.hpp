@@ -38,6 +38,7 @@ template <class Q, class V> void forwardKinematics(const Model&, Data&, const Q&
 inline void computeJointJacobians(const Model&, Data&) {}
 template <class Q> void computeJointJacobians(const Model&, Data&, const Q&) {}
 inline void updateFramePlacements(const Model&, Data&) {}
+inline void updateGlobalPlacements(const Model&, Data&) {}
 template <class Q, class V> void computeJointJacobiansTimeVariation(const Model&, Data&, const Q&, const V&) {}
 template <class Q> void crba(const Model& m, Data& d, const Q&) {
   d.M.setZero(m.nv, m.nv);

@@ -194,16 +194,14 @@ def _full_tick(params, s, w, steps, dt_mpc):
             return torch.from_numpy(a).pin_memory().numpy()
         except Exception:  # noqa: BLE001  (no torch HIP runtime in this process: pageable memory then)
             return a
+    s.set_chunks(4 if B >= 64 else 1)   # instance ranges: every range runs its own slice of the whole tick (hb_tick_resident)
     quat, w_loc, a_loc, contact = pin(quat), pin(w_loc), pin(a_loc), pin(contact)
     qj_s, qdj_s, cmd_s = pin(rbd[:, 6:16]), pin(rbd[:, 22:32]), pin(w["cmd"])
 
     def tick(k):
-        # enqueue-only forms (include/hunter_hip.h): the sensor arrays and time stamps go through the library's pinned staging, no
-        # call synchronises with the device, so the host runs a few ticks ahead and the device never waits for a launch
-        s.set_resident_time(t + dt_mpc * k)
-        s.estimator_update(0.002, quat, w_loc, a_loc, qj_s, qdj_s, contact, to_resident=True, want_outputs=False)
-        s.refgen_update(t + dt_mpc * k, w["horizon"], None, cmd_s, want_status=False)
-        s.step_resident()
+        # hb_tick_resident (include/hunter_hip.h): the sensor arrays and time stamps go through the library's pinned staging, nothing
+        # synchronises with the device, and every instance range runs its slice of estimator + references + step on its own stream
+        s.tick_resident(0.002, quat, w_loc, a_loc, qj_s, qdj_s, contact, t + dt_mpc * k, w["horizon"], cmd_s)
 
     for k in range(3):
         tick(k)

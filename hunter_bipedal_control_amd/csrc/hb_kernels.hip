@@ -779,6 +779,12 @@ struct hb_ctx {
   struct StageSlot { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
   StageSlot stage[STAGE_ARRAYS][STAGE_DEPTH];
   unsigned stage_turn[STAGE_ARRAYS]{};
+  // hb_tick_resident: device-side upload targets of one tick's host inputs (read early in every instance range's tick, so that
+  // the next tick's upload only has to wait for that early point), the upload stream and its events
+  struct TickUpload { double *quat = nullptr, *w = nullptr, *a = nullptr, *qj = nullptr, *qdj = nullptr, *tnow = nullptr, *t0 = nullptr, *cmd = nullptr; int* contact = nullptr; } up;
+  hipStream_t s_up = nullptr;
+  hipEvent_t ev_up = nullptr, ev_consumed[8]{};
+  int consumed_pending = 0;
   bool grid_saved = false;  // tp / modep / np_nodes hold the grid the iterate lives on; the tables have changed since
   bool policy_read_pending = false;
   bool refs_set = false, traj_set = false, timed = false;
@@ -964,6 +970,10 @@ void hb_destroy(hb_ctx* ctx) {
   for (void* p : ctx->allocs) (void)hipFree(p);
   for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_sync) (void)hipEventDestroy(ev);
+  if (ctx->s_up) (void)hipStreamDestroy(ctx->s_up);
+  if (ctx->ev_up) (void)hipEventDestroy(ctx->ev_up);
+  for (auto& ev : ctx->ev_consumed)
+    if (ev) (void)hipEventDestroy(ev);
   for (auto& arr : ctx->stage)
     for (auto& sl : arr) {
       if (sl.done) (void)hipEventDestroy(sl.done);
@@ -1532,6 +1542,7 @@ int32_t hb_sync(hb_ctx* ctx) {
   HB_HIP(hipStreamSynchronize(ctx->s_mpc));
   HB_HIP(hipStreamSynchronize(ctx->s_wbc));
   for (auto& sc : ctx->s_chunk) HB_HIP(hipStreamSynchronize(sc));
+  if (ctx->s_up) HB_HIP(hipStreamSynchronize(ctx->s_up));
   return HB_OK;
 }
 
@@ -2017,6 +2028,149 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
     std::lock_guard<std::mutex> lk(ctx->mtx);
     ctx->w.policy_valid = true;
     ctx->policy_read_pending = false;  // the lazy join orders the next policy write (by another entry point) after these readers
+    ctx->stats.n_wbc_solves += ctx->B;
+  }
+  return HB_OK;
+}
+
+// One whole tick on the resident state — controller time, estimator, reference generation at that time, one MPC iteration, publish,
+// policy evaluation, WBC — enqueue-only.  With instance ranges (hb_set_chunks > 1) every range runs ITS slice of all of that on its
+// own stream and goes from one tick straight into the next: the small per-instance kernels of the estimator and the reference
+// generation (thread- or wave-per-instance, a fraction of the chip each) and the serial sweeps of one range run under the LQ
+// kernel of the others instead of in a whole-batch prologue between two steps.  The host inputs of a tick are uploaded once, on
+// their own stream, into buffers that every range reads EARLY in its tick (estimator, reference generation, a private copy of the
+// time): the next tick's upload waits only for that point, so ranges may be up to one tick apart.
+int32_t hb_tick_resident(hb_ctx* ctx, double dt_est, const double* quat, const double* ang_vel_local, const double* lin_acc_local,
+                         const double* joint_pos, const double* joint_vel, const int32_t* contact_flag, const double* t_now, double horizon,
+                         const double* cmd_vel, double dt_wbc) {
+  if (!ctx || !quat || !ang_vel_local || !lin_acc_local || !joint_pos || !joint_vel || !contact_flag || !t_now || !cmd_vel || !(dt_est > 0.0) ||
+      !(horizon > 0.0))
+    return HB_ERR_ARG;
+  if (ctx->n_chunks <= 1) {  // one stream: the four calls themselves (enqueue-only forms)
+    int32_t rc = hb_set_resident_time(ctx, t_now);
+    if (rc == HB_OK) rc = hb_estimator_update(ctx, dt_est, quat, ang_vel_local, lin_acc_local, joint_pos, joint_vel, contact_flag, 1, nullptr, nullptr);
+    if (rc == HB_OK) rc = hb_refgen_update(ctx, t_now, horizon, nullptr, cmd_vel, nullptr);
+    if (rc == HB_OK) rc = hb_step_resident(ctx, dt_wbc);
+    return rc;
+  }
+  if (!ctx->est_ready || !ctx->rg_ready || !ctx->refs_set || !ctx->traj_set) {
+    ctx->err = "hb_tick_resident: estimator / reference generation / references / trajectory not initialised";
+    return HB_ERR_STATE;
+  }
+  for (int v : ctx->rg_have_schedule)
+    if (!v) {
+      ctx->err = "hb_tick_resident: an instance has no mode schedule (hb_refgen_set_schedule)";
+      return HB_ERR_STATE;
+    }
+  HB_HIP(hipSetDevice(ctx->device));
+  const size_t B = ctx->B, N = ctx->Nmax;
+  if (!ctx->s_up) {
+    HB_HIP(hipStreamCreateWithFlags(&ctx->s_up, hipStreamNonBlocking));
+    HB_HIP(hipEventCreateWithFlags(&ctx->ev_up, hipEventDisableTiming));
+    for (auto& ev : ctx->ev_consumed) HB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HB_HIP(dalloc(ctx, &ctx->up.quat, B * 4)); HB_HIP(dalloc(ctx, &ctx->up.w, B * 3)); HB_HIP(dalloc(ctx, &ctx->up.a, B * 3));
+    HB_HIP(dalloc(ctx, &ctx->up.qj, B * 10)); HB_HIP(dalloc(ctx, &ctx->up.qdj, B * 10)); HB_HIP(dalloc(ctx, &ctx->up.contact, B * 4));
+    HB_HIP(dalloc(ctx, &ctx->up.tnow, B)); HB_HIP(dalloc(ctx, &ctx->up.t0, B)); HB_HIP(dalloc(ctx, &ctx->up.cmd, B * 4));
+  }
+  // fork from the library streams when another entry point ran since the last tick (or this is the first one)
+  const bool fork = ctx->fork_needed || ctx->grid_saved || ctx->chunks_pending != ctx->n_chunks;
+  if (fork) {
+    ++ctx->dbg_forks;
+    lazy_join(ctx);
+    int32_t rc = warm_start_onto_new_tables(ctx);
+    if (rc != HB_OK) return rc;
+    HB_HIP(hipEventRecord(ctx->ev_sync[2], ctx->s_mpc));
+    HB_HIP(hipEventRecord(ctx->ev_sync[3], ctx->s_wbc));
+  }
+  // this tick's host inputs: one upload, after every range has read the previous tick's
+  {
+    hipStream_t su = ctx->s_up;
+    for (int c = 0; c < ctx->consumed_pending; ++c) HB_HIP(hipStreamWaitEvent(su, ctx->ev_consumed[c], 0));
+    int32_t rc;
+    if ((rc = stage_upload(ctx, ST_QUAT, ctx->up.quat, quat, B * 4 * 8, su)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_W, ctx->up.w, ang_vel_local, B * 3 * 8, su)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_A, ctx->up.a, lin_acc_local, B * 3 * 8, su)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_QJ, ctx->up.qj, joint_pos, B * 10 * 8, su)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_QDJ, ctx->up.qdj, joint_vel, B * 10 * 8, su)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_CONTACT, ctx->up.contact, contact_flag, B * 4 * sizeof(int), su)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_TNOW, ctx->up.tnow, t_now, B * 8, su)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_T0, ctx->up.t0, t_now, B * 8, su)) != HB_OK) return rc;
+    if ((rc = stage_upload(ctx, ST_CMD, ctx->up.cmd, cmd_vel, B * 4 * 8, su)) != HB_OK) return rc;
+    HB_HIP(hipEventRecord(ctx->ev_up, su));
+  }
+  // the tables change for every instance: the previous iterate becomes the source of the warm start (as warm_start_onto_new_tables)
+  std::swap(ctx->b.x, ctx->b.xp);
+  std::swap(ctx->b.u, ctx->b.up);
+  ++ctx->graph_epoch;
+  const int per = (ctx->B + ctx->n_chunks - 1) / ctx->n_chunks;
+  int used = 0;
+  for (int c = 0; c < ctx->n_chunks; ++c) {
+    const int i0 = c * per, cnt = std::min(per, ctx->B - i0);
+    if (cnt <= 0) break;
+    hipStream_t s = ctx->s_chunk[c];
+    const size_t o = size_t(i0);
+    if (fork) {
+      HB_HIP(hipStreamWaitEvent(s, ctx->ev_sync[2], 0));
+      HB_HIP(hipStreamWaitEvent(s, ctx->ev_sync[3], 0));
+    }
+    HB_HIP(hipStreamWaitEvent(s, ctx->ev_up, 0));
+    const Batch b = batch_view(ctx->b, i0, cnt);
+    const WbcBatch w = wbc_view(ctx->w, ctx->Nmax, i0, cnt);
+    // controller time + estimator -> resident rbd state and observation of the range
+    HB_HIP(hipMemcpyAsync(w.t_now, ctx->up.tnow + o, size_t(cnt) * 8, hipMemcpyDeviceToDevice, s));
+    EstBatch e = ctx->est;
+    e.B = cnt;
+    e.xhat += o * 18; e.P += o * 324; e.yaw_last += o; e.rbd += o * HB_NRBD; e.x += o * HB_NX;
+    e.quat = ctx->up.quat + o * 4; e.w_local = ctx->up.w + o * 3; e.a_local = ctx->up.a + o * 3;
+    e.qj = ctx->up.qj + o * 10; e.qdj = ctx->up.qdj + o * 10; e.contact = ctx->up.contact + o * 4;
+    e.res_rbd = w.rbd;
+    e.res_x0 = b.x0;
+    hipLaunchKernelGGL(k_estimator, dim3(cnt), dim3(64), 0, s, e, ctx->dmodel, ctx->est_cfg, dt_est);
+    // reference generation at the new time (the grid that is about to be replaced is kept for the warm start)
+    HB_HIP(hipMemcpyAsync(b.tp, b.t, size_t(cnt) * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemcpyAsync(b.modep, b.mode, size_t(cnt) * N * sizeof(int), hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemcpyAsync(b.np_nodes, b.n_nodes, size_t(cnt) * sizeof(int), hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.grid_dirty), 1, size_t(cnt), s));
+    RefgenBatch r = ctx->rg;
+    r.B = cnt;
+    r.n_ev += o; r.ev += o * HB_MAX_EVENTS; r.modes += o * (HB_MAX_EVENTS + 1); r.stance += o * 12;
+    r.phases += o * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE; r.status += o; r.n_knots += o; r.knot_t += o * RG_MAX_KNOTS;
+    r.knot_x += o * RG_MAX_KNOTS * HB_NX;
+    r.t0 = ctx->up.t0 + o;
+    r.cmd = ctx->up.cmd + o * 4;
+    hipLaunchKernelGGL(k_refgen, dim3((cnt + 63) / 64), dim3(64), 0, s, b, r, ctx->dmodel, ctx->rg_cfg, horizon);
+    if (ctx->rg_cfg.joint_ik)
+      hipLaunchKernelGGL(k_refgen_ik, dim3((2 * cnt + 7) / 8), dim3(64), 0, s, b, r, ctx->dmodel, ctx->rg_cfg, horizon);
+    hipLaunchKernelGGL(k_refgen_nodes, dim3((cnt * ctx->Nmax + 63) / 64), dim3(64), 0, s, b, r, ctx->rg_cfg);
+    HB_HIP(hipEventRecord(ctx->ev_consumed[c], s));  // the upload buffers are free for the next tick
+    // warm start onto the new tables, MPC iteration, publish, policy evaluation, WBC
+    hipLaunchKernelGGL(k_warm_shift, dim3(ctx->Nmax + 1, cnt), dim3(64), 0, s, b, ctx->dmodel);
+    hipLaunchKernelGGL(k_grid_clean, dim3((cnt + 255) / 256), dim3(256), 0, s, b);
+    int32_t rc = mpc_iterations(ctx, i0, cnt, s);
+    if (rc != HB_OK) return rc;
+    HB_HIP(hipMemcpyAsync(w.px, b.x, size_t(cnt) * (N + 1) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemcpyAsync(w.pu, b.u, size_t(cnt) * N * HB_NU * 8, hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemcpyAsync(w.pt, b.t, size_t(cnt) * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemcpyAsync(w.pmode, b.mode, size_t(cnt) * N * sizeof(int), hipMemcpyDeviceToDevice, s));
+    HB_HIP(hipMemcpyAsync(w.pn, b.n_nodes, size_t(cnt) * sizeof(int), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_policy_eval, dim3((cnt + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
+    if (ctx->config.wbc_type == 1)
+      hipLaunchKernelGGL(k_hwbc, dim3(cnt), dim3(64), HoLdsDev::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
+    else
+      hipLaunchKernelGGL(k_wbc, dim3(cnt), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
+    HB_HIP(hipGetLastError());
+    HB_HIP(hipEventRecord(ctx->ev_sync[4 + c], s));
+    used = c + 1;
+  }
+  ctx->rg.init_stance = 0;
+  ctx->chunks_pending = used;
+  ctx->consumed_pending = used;
+  ctx->fork_needed = false;
+  ctx->steady_chunked_steps = 0;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    ctx->w.policy_valid = true;
+    ctx->policy_read_pending = false;
     ctx->stats.n_wbc_solves += ctx->B;
   }
   return HB_OK;

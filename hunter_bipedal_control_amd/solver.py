@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
     "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd", "hb_plant_reset", "hb_plant_step",
     "hb_plant_get_state", "hb_hoqp_solve", "hb_mpc_reset_masked", "hb_mpc_get_status", "hb_joint_set_flags",
-    "hb_joint_get_emergency_stop", "hb_set_resident_time", "hb_get_wbc_iterations", "hb_ik_solve", "hb_debug_chunk_counters", "hb_refgen_get_status",
+    "hb_joint_get_emergency_stop", "hb_set_resident_time", "hb_get_wbc_iterations", "hb_ik_solve", "hb_debug_chunk_counters", "hb_refgen_get_status", "hb_tick_resident",
 ]
 # include/hunter_lcm.h
 LCM_SYMBOLS = ["hb_lcm_fingerprint", "hb_lcm_encoded_size", "hb_lcm_field_count", "hb_lcm_encode", "hb_lcm_decode", "hb_lcm_frame", "hb_lcm_unframe",
@@ -262,6 +262,14 @@ class HunterSolver:
         x0_seq = _f64(x0_seq)
         assert x0_seq.ndim == 3 and x0_seq.shape[1:] == (self.B, 22)
         self._check(self.lib.hb_set_resident_x0_sequence(self.ctx, C.c_int32(x0_seq.shape[0]), _p(x0_seq)), "hb_set_resident_x0_sequence")
+
+    def tick_resident(self, dt_est, quat, ang_vel_local, lin_acc_local, joint_pos, joint_vel, contact_flag, t_now, horizon, cmd_vel, dt=0.002):
+        """Controller time + estimator + reference generation + MPC iteration + publish + policy + WBC on the resident state,
+        enqueue-only (hb_tick_resident); per instance range when set_chunks(n > 1)."""
+        self._check(self.lib.hb_tick_resident(
+            self.ctx, C.c_double(dt_est), _p(_f64(quat, (self.B, 4))), _p(_f64(ang_vel_local, (self.B, 3))), _p(_f64(lin_acc_local, (self.B, 3))),
+            _p(_f64(joint_pos, (self.B, 10))), _p(_f64(joint_vel, (self.B, 10))), _p(_i32(contact_flag, (self.B, 4))), _p(_f64(t_now, (self.B,))),
+            C.c_double(horizon), _p(_f64(cmd_vel, (self.B, 4))), C.c_double(dt)), "hb_tick_resident")
 
     def set_chunks(self, n_chunks: int):
         self._check(self.lib.hb_set_chunks(self.ctx, C.c_int32(n_chunks)), "hb_set_chunks")

@@ -246,6 +246,15 @@ int32_t hb_set_resident_inputs(hb_ctx* ctx, const double* x0, const double* t_no
  * Enqueue-only (pinned staging, no device synchronisation). */
 int32_t hb_set_resident_time(hb_ctx* ctx, const double* t_now);
 int32_t hb_step_resident(hb_ctx* ctx, double dt);
+/* One whole tick on the resident state, enqueue-only: hb_set_resident_time(t_now) + hb_estimator_update(dt_est, sensors,
+ * to_resident) + hb_refgen_update(t_now, horizon, x_now = the estimate, cmd_vel) + hb_step_resident(dt_wbc) — what
+ * LeggedController::update and its MPC thread do per MPC period (LeggedController.cpp:137-185, 396-412) for the whole batch.  With
+ * instance ranges (hb_set_chunks > 1) every range runs its slice of ALL of it on its own stream, tick after tick, without a
+ * whole-batch stage between two steps; results are identical to the four calls.  Host arrays as in hb_estimator_update /
+ * hb_refgen_update; they are the caller's again on return (pinned staging). */
+int32_t hb_tick_resident(hb_ctx* ctx, double dt_est, const double* quat, const double* ang_vel_local, const double* lin_acc_local,
+                         const double* joint_pos, const double* joint_vel, const int32_t* contact_flag, const double* t_now,
+                         double horizon, const double* cmd_vel, double dt_wbc);
 /* Optional: a device-resident cyclic sequence of measured states x0_seq[n_seq][batch][22]; step k of
  * hb_step_resident starts its MPC solve from x0_seq[k % n_seq] (emulates the estimator feeding a new state each
  * MPC call, LeggedController.cpp:141-144).  n_seq = 0 disables it. */

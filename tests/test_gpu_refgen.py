@@ -200,3 +200,54 @@ def test_enqueue_only_tick_equals_the_synchronous_calls(params):
     assert np.array_equal(ra["t"], rb["t"]) and np.array_equal(ra["mode"], rb["mode"]) and np.array_equal(ra["x_ref"], rb["x_ref"])
     assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
     assert np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1]) and np.array_equal(ma, mb)
+
+
+def test_tick_resident_on_instance_ranges_equals_the_four_calls(params):
+    """hb_tick_resident with three instance ranges (every range runs its slice of time + estimator + references + warm start +
+    MPC + WBC on its own stream, ranges up to a tick apart) against hb_set_resident_time / hb_estimator_update / hb_refgen_update /
+    hb_step_resident on one stream: identical tables, iterate, WBC solution, filter state and status words after seven ticks with
+    changing sensors and commands; the caller's arrays are overwritten right after every call."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B, N = 50, 40
+    c = params["config"]
+    horizon = N * c["dt"]
+    rng = np.random.default_rng(12)
+    out = []
+    for ranges in (1, 3):
+        s = HunterSolver(params, batch=B, max_nodes=N + 6)
+        try:
+            w = workload.device_trot_batch(s, params, n_intervals=N)
+            s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+            s.set_chunks(ranges)
+            xh0 = np.zeros((B, 18))
+            xh0[:, 0:3] = w["rbd"][:, 3:6]
+            xh0[:, 6:18] = np.asarray(s.eval_foot_kinematics(w["x0"], np.zeros((B, 22)))[0]).reshape(B, 12)
+            s.estimator_reset(abi.make_estimator_config(params), xh0)
+            srng = np.random.default_rng(6)
+            for k in range(7):
+                tk = w["t_now"] + 0.01 * (k + 1)
+                quat = np.tile([0.0, 0.0, 0.0, 1.0], (B, 1)) + 0.01 * srng.standard_normal((B, 4))
+                quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+                wl, al = 0.05 * srng.standard_normal((B, 3)), np.tile([0.0, 0.0, 9.81], (B, 1)) + 0.1 * srng.standard_normal((B, 3))
+                qj, qdj = w["rbd"][:, 6:16] + 0.01 * srng.standard_normal((B, 10)), 0.1 * srng.standard_normal((B, 10))
+                contact = np.ones((B, 4), dtype=np.int32)
+                cmd = w["cmd"] + 0.02 * srng.standard_normal(w["cmd"].shape)
+                if ranges == 1:
+                    s.set_resident_time(tk)
+                    s.estimator_update(0.002, quat, wl, al, qj, qdj, contact, to_resident=True)
+                    assert s.refgen_update(tk, horizon, None, cmd).max() == 0
+                    s.step_resident()
+                else:
+                    s.tick_resident(0.002, quat, wl, al, qj, qdj, contact, tk, horizon, cmd)
+                    for a in (tk, quat, wl, al, qj, qdj, cmd):
+                        a[...] = rng.standard_normal(a.shape)
+                    contact[...] = 0
+            assert s.refgen_status().max() == 0
+            out.append((s.get_references(), s.get_solution(), s.get_wbc_solution(), s.mpc_status(), s.estimator_filter()))
+        finally:
+            s.close()
+    (ra, sa, wa, ma, ea), (rb, sb, wb, mb, eb) = out
+    assert np.array_equal(ra["t"], rb["t"]) and np.array_equal(ra["mode"], rb["mode"]) and np.array_equal(ra["x_ref"], rb["x_ref"])
+    assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
+    assert np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1]) and np.array_equal(ma, mb)
+    assert np.array_equal(ea[0], eb[0]) and np.array_equal(ea[1], eb[1])

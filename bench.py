@@ -130,6 +130,9 @@ def config1_latency(params, device, n_list=(54, 100), reps=250):
             for _ in range(10):  # warm-up of the control tick as well: the first hb_wbc_update pays the lazy load of its kernels
                 s.wbc_update(t_now, rbd, dt=0.002)   # (36 ms in the round-2 line, against a 2 ms budget)
             t_mpc, t_wbc = [], []
+            import gc
+            gc.collect()
+            gc.disable()   # a collection of the previous figures' arrays inside one timed call showed up as a 10 ms "MPC call"
             for k in range(reps):
                 t0 = time.perf_counter()
                 s.mpc_solve(seq[k % len(seq)])
@@ -142,7 +145,9 @@ def config1_latency(params, device, n_list=(54, 100), reps=250):
                 assert out_w["status"][0] == 0
                 t_mpc.append(1e3 * (t1 - t0))
                 t_wbc.append(1e3 * (t3 - t2))
-            out[f"N{N}"] = {"ticks": reps,
+            gc.enable()
+            out[f"N{N}"] = {"ticks": reps, "mpc_calls_over_budget": int((np.array(t_mpc) > 10.0).sum()),
+                            "wbc_ticks_over_budget": int((np.array(t_wbc) > 2.0).sum()),
                             "mpc_ms_median": float(np.median(t_mpc)), "mpc_ms_p99": float(np.percentile(t_mpc, 99)), "mpc_ms_max": float(np.max(t_mpc)),
                             "wbc_tick_ms_median": float(np.median(t_wbc)), "wbc_tick_ms_p99": float(np.percentile(t_wbc, 99)),
                             "wbc_tick_ms_max": float(np.max(t_wbc))}

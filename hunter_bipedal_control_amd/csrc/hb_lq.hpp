@@ -136,7 +136,7 @@ struct LqLds {
 static_assert(LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are still being read");
 static_assert(LqLds::Qd >= LqLds::p1_end && LqLds::ru >= LqLds::p1_end, "the reference / next state are parked in Qd / ru during phase 1");
 static_assert(LqLds::rjk + 10 <= LqLds::RZ, "P_j | R_jj | r_j must fit over G'G | W");
-static_assert(LqLds::total * 8 <= 16384, "k_lq: LDS per node must allow 10 workgroups per CU");
+static_assert(LqLds::total * 8 <= 16640, "k_lq: LDS per node must allow 9 workgroups per CU (13 allocation granules of 1280 B, DESIGN.md 3.1)");
 // row of CDt that holds direction d (d < 22 or d >= 34)
 HB_HD int cd_row(int dir) { return dir < 22 ? dir : dir - 12; }
 // row of J1 / J2 that holds direction d (momentum 0..5, zyx 9..11, joints 12..21, joint rates 34..43) and its inverse

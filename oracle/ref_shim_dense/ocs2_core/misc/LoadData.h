@@ -24,6 +24,11 @@ void loadCppDataType(const std::string& file, const std::string& name, T& value)
   boost::property_tree::read_info(file, pt);
   value = T(pt.root.number(name));
 }
+inline void loadCppDataType(const std::string& file, const std::string& name, bool& value) {
+  boost::property_tree::ptree pt;
+  boost::property_tree::read_info(file, pt);
+  value = pt.root.boolean(name);
+}
 template <class M>
 void loadEigenMatrix(const std::string& file, const std::string& name, M& m) {
   const hunter_hip::InfoNode root = hunter_hip::read_info_file(file);

@@ -11,8 +11,8 @@ class ReferenceManager {
   explicit ReferenceManager(TargetTrajectories t = TargetTrajectories(), ModeSchedule m = ModeSchedule()) : targetTrajectories_(std::move(t)), modeSchedule_(std::move(m)) {}
   virtual ~ReferenceManager() = default;
   void preSolverRun(scalar_t initTime, scalar_t finalTime, const vector_t& initState) { modifyReferences(initTime, finalTime, initState, targetTrajectories_, modeSchedule_); }
-  const ModeSchedule& getModeSchedule() const { return modeSchedule_; }
-  const TargetTrajectories& getTargetTrajectories() const { return targetTrajectories_; }
+  virtual const ModeSchedule& getModeSchedule() const { return modeSchedule_; }
+  virtual const TargetTrajectories& getTargetTrajectories() const { return targetTrajectories_; }
   virtual void setModeSchedule(const ModeSchedule& m) { modeSchedule_ = m; }
   virtual void setTargetTrajectories(const TargetTrajectories& t) { targetTrajectories_ = t; }
  protected:

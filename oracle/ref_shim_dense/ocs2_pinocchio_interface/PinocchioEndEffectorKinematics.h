@@ -8,6 +8,8 @@ namespace ocs2 {
 class PinocchioEndEffectorKinematics {
  public:
   using vector3_t = Eigen::Matrix<scalar_t, 3, 1>;
+  PinocchioEndEffectorKinematics() = default;
+  template <class Mapping, class Names> PinocchioEndEffectorKinematics(const PinocchioInterface& i, const Mapping&, const Names&) : iface_(&i) {}
   PinocchioEndEffectorKinematics* clone() const { return new PinocchioEndEffectorKinematics(*this); }
   void setPinocchioInterface(const PinocchioInterface& i) { iface_ = &i; }
   std::vector<vector3_t> getPosition(const vector_t&) const { return get(ref_feed::feed().role[iface_->getData().role].ee_pos); }

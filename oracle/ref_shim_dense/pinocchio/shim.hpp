@@ -105,6 +105,7 @@ template <class M3> Eigen::Matrix<double, 3, 1> log3(const M3& R) {
   return Eigen::Matrix<double, 3, 1>(t * (R(2, 1) - R(1, 2)), t * (R(0, 2) - R(2, 0)), t * (R(1, 0) - R(0, 1)));
 }
 // declared for legged_estimation/src/StateEstimateBase.cpp::estContactForce, which the golden vectors never run
-inline void getCoriolisMatrix(const Model&, Data&) {}
-template <class Q> void computeGeneralizedGravity(const Model&, Data&, const Q&) {}
+// (StateEstimateBase::estContactForce reads data.C and data.g; its result has no consumer in the reference: zeros of the right shape)
+inline void getCoriolisMatrix(const Model& m, Data& d) { d.C.setZero(m.nv, m.nv); }
+template <class Q> void computeGeneralizedGravity(const Model& m, Data& d, const Q&) { d.g.setZero(m.nv); }
 }  // namespace pinocchio

@@ -13,6 +13,7 @@ struct Duration {
   Duration() = default;
   explicit Duration(double v) : s(v) {}
   double toSec() const { return s; }
+  Duration& fromSec(double v) { s = v; return *this; }
 };
 struct Time {
   double t = 0.0;
@@ -22,6 +23,7 @@ struct Time {
   static Time now() { return Time(); }
 };
 inline Time operator+(const Time& a, const Duration& d) { return Time(a.t + d.s); }
+inline Time operator-(const Time& a, const Duration& d) { return Time(a.t - d.s); }
 inline bool operator<(const Time& a, const Time& b) { return a.t < b.t; }
 struct Subscriber {};
 struct Publisher { template <class M> void publish(const M&) const {} };
@@ -40,7 +42,10 @@ class NodeHandle {
  public:
   NodeHandle() = default;
   explicit NodeHandle(const std::string&) {}
-  template <class M, class T> Subscriber subscribe(const std::string&, int, void (T::*)(const typename M::ConstPtr&), T*) { return Subscriber(); }
+  template <class M, class T> Subscriber subscribe(const std::string& topic, int, void (T::*m)(const typename M::ConstPtr&), T* obj) {
+    ref_shim::callbacks()[topic] = [m, obj](const std::shared_ptr<const void>& p) { (obj->*m)(std::static_pointer_cast<const M>(p)); };
+    return Subscriber();
+  }
   template <class M, class F> Subscriber subscribe(const std::string& topic, int, F cb) {
     ref_shim::callbacks()[topic] = [cb](const std::shared_ptr<const void>& p) { cb(std::static_pointer_cast<const M>(p)); };
     return Subscriber();

@@ -989,6 +989,8 @@ void hb_destroy(hb_ctx* ctx) {
 }
 
 // Upload of a caller-owned host array through pinned staging (see hb_ctx::stage): returns as soon as the bytes are in the slot.
+// Each array id belongs to one side of the two-thread split (control side: time, sensors; MPC side: t0, cmd, x0; hb_tick_resident,
+// which uses all of them, is a single-thread entry point), so a ring is only ever advanced by one thread.
 enum StageId { ST_TNOW = 0, ST_QUAT, ST_W, ST_A, ST_QJ, ST_QDJ, ST_CONTACT, ST_T0, ST_CMD, ST_X0 };
 static int32_t stage_upload(hb_ctx* ctx, int id, void* dst, const void* src, size_t bytes, hipStream_t s) {
   hb_ctx::StageSlot& sl = ctx->stage[id][ctx->stage_turn[id]++ % hb_ctx::STAGE_DEPTH];
@@ -1906,6 +1908,24 @@ int32_t hb_set_resident_x0_sequence(hb_ctx* ctx, int32_t n_seq, const double* x0
   return HB_OK;
 }
 
+// Publish + policy evaluation + WBC of the instance range [i0, i0 + cnt) on stream s: the tail of one range's step / tick.
+static int32_t range_publish_policy_wbc(hb_ctx* ctx, int i0, int cnt, hipStream_t s) {
+  const size_t N = ctx->Nmax;
+  const Batch b = batch_view(ctx->b, i0, cnt);
+  const WbcBatch w = wbc_view(ctx->w, ctx->Nmax, i0, cnt);
+  HB_HIP(hipMemcpyAsync(w.px, b.x, size_t(cnt) * (N + 1) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
+  HB_HIP(hipMemcpyAsync(w.pu, b.u, size_t(cnt) * N * HB_NU * 8, hipMemcpyDeviceToDevice, s));
+  HB_HIP(hipMemcpyAsync(w.pt, b.t, size_t(cnt) * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
+  HB_HIP(hipMemcpyAsync(w.pmode, b.mode, size_t(cnt) * N * sizeof(int), hipMemcpyDeviceToDevice, s));
+  HB_HIP(hipMemcpyAsync(w.pn, b.n_nodes, size_t(cnt) * sizeof(int), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_policy_eval, dim3((cnt + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
+  if (ctx->config.wbc_type == 1)
+    hipLaunchKernelGGL(k_hwbc, dim3(cnt), dim3(64), HoLdsDev::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
+  else
+    hipLaunchKernelGGL(k_wbc, dim3(cnt), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
+  return HB_OK;
+}
+
 int32_t hb_step_resident(hb_ctx* ctx, double dt) {
   if (!ctx) return HB_ERR_ARG;
   if (!ctx->refs_set || !ctx->traj_set) {
@@ -1967,19 +1987,7 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
         HB_HIP(hipMemcpyAsync(ctx->b.x0 + size_t(i0) * HB_NX, x0_next + size_t(i0) * HB_NX, size_t(cnt) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
       int32_t rc = mpc_iterations(ctx, i0, cnt, s);
       if (rc != HB_OK) return rc;
-      const Batch b = batch_view(ctx->b, i0, cnt);
-      const WbcBatch w = wbc_view(ctx->w, ctx->Nmax, i0, cnt);
-      HB_HIP(hipMemcpyAsync(w.px, b.x, size_t(cnt) * (N + 1) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
-      HB_HIP(hipMemcpyAsync(w.pu, b.u, size_t(cnt) * N * HB_NU * 8, hipMemcpyDeviceToDevice, s));
-      HB_HIP(hipMemcpyAsync(w.pt, b.t, size_t(cnt) * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
-      HB_HIP(hipMemcpyAsync(w.pmode, b.mode, size_t(cnt) * N * sizeof(int), hipMemcpyDeviceToDevice, s));
-      HB_HIP(hipMemcpyAsync(w.pn, b.n_nodes, size_t(cnt) * sizeof(int), hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(k_policy_eval, dim3((cnt + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
-      if (ctx->config.wbc_type == 1)
-        hipLaunchKernelGGL(k_hwbc, dim3(cnt), dim3(64), HoLdsDev::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
-      else
-        hipLaunchKernelGGL(k_wbc, dim3(cnt), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
-      return HB_OK;
+      return range_publish_policy_wbc(ctx, i0, cnt, s);
     };
     // steady state (no fork for a few steps, the x0 slot fits): replay the step as one graph launch
     const int slot = ctx->n_seq > 0 ? seq_slot : 0;
@@ -2148,16 +2156,8 @@ int32_t hb_tick_resident(hb_ctx* ctx, double dt_est, const double* quat, const d
     hipLaunchKernelGGL(k_grid_clean, dim3((cnt + 255) / 256), dim3(256), 0, s, b);
     int32_t rc = mpc_iterations(ctx, i0, cnt, s);
     if (rc != HB_OK) return rc;
-    HB_HIP(hipMemcpyAsync(w.px, b.x, size_t(cnt) * (N + 1) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
-    HB_HIP(hipMemcpyAsync(w.pu, b.u, size_t(cnt) * N * HB_NU * 8, hipMemcpyDeviceToDevice, s));
-    HB_HIP(hipMemcpyAsync(w.pt, b.t, size_t(cnt) * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
-    HB_HIP(hipMemcpyAsync(w.pmode, b.mode, size_t(cnt) * N * sizeof(int), hipMemcpyDeviceToDevice, s));
-    HB_HIP(hipMemcpyAsync(w.pn, b.n_nodes, size_t(cnt) * sizeof(int), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_policy_eval, dim3((cnt + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
-    if (ctx->config.wbc_type == 1)
-      hipLaunchKernelGGL(k_hwbc, dim3(cnt), dim3(64), HoLdsDev::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);
-    else
-      hipLaunchKernelGGL(k_wbc, dim3(cnt), dim3(64), 0, s, w, ctx->dmodel, ctx->dconfig);
+    rc = range_publish_policy_wbc(ctx, i0, cnt, s);
+    if (rc != HB_OK) return rc;
     HB_HIP(hipGetLastError());
     HB_HIP(hipEventRecord(ctx->ev_sync[4 + c], s));
     used = c + 1;

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64, 3) void k_lq(Batch b, const DevModel* __restric
   in.xref = b.xref + nd * HB_NX;
   in.swing = b.swing + nd * 24;
   in.dt = tt[k + 1] - tt[k];
-  in.mode = b.mode[nd];
+  in.mode = __builtin_amdgcn_readfirstlane(b.mode[nd]);  // (uniform by construction; tells the compiler so: mode tests become scalar)
   lq_node(WaveCtx(), *M, *C, in, lds, b.recs + nd * REC_SIZE);
 }
 

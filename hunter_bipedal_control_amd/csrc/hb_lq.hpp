@@ -145,6 +145,20 @@ HB_HD int j_dir(int row) { return row < 6 ? row : (row < 19 ? row + 3 : row + 15
 // column of J1 / J2 that holds row i (3..11) of f: [3 4 5 | 9 10 11 | 6 7 8], and its inverse
 HB_HD int j_col(int frow) { return frow < 6 ? frow - 3 : (frow < 9 ? frow : frow - 6); }
 HB_HD int j_frow(int col) { return col < 3 ? col + 3 : (col < 6 ? col + 6 : col); }
+// Constraint slot of (contact point i, row a): the xy rows (a = 1, 2: zero velocity of a contact foot, soft xy reference of a swing
+// foot) come first, grouped by LEG (contact points i and i + 2 sit on leg i & 1), the normal rows (a = 0) last.  A K-step of four
+// slots of the matrix-core products over the slots is then one leg's xy rows or the four normal rows, and a step whose rows all
+// carry zero weight (the soft rows of a stance leg, the hard xy rows of a swing leg, the normal rows in the soft products) is
+// skipped as a whole (wave-uniform): in single support the soft-row products take one step instead of three.
+HB_HD int c_slot(int i, int a) { return a == 0 ? 8 + i : 4 * (i & 1) + 2 * (i >> 1) + (a - 1); }
+HB_HD int slot_foot(int s) { return s < 8 ? (s >> 2) + 2 * ((s >> 1) & 1) : s - 8; }
+HB_HD bool slot_normal(int s) { return s >= 8; }
+// weight 1 of an equality row (contact foot: all three rows, swing foot: the normal row), of a soft row (swing foot: xy rows)
+HB_HD bool slot_is_eq(int s, int cfm) { return slot_normal(s) || ((cfm >> slot_foot(s)) & 1); }
+HB_HD bool slot_is_soft(int s, int cfm) { return !slot_normal(s) && !((cfm >> slot_foot(s)) & 1); }
+// K-step j of four slots: does any of its rows carry weight?  (legs: bit pattern 0b0101 = leg 0, 0b1010 = leg 1)
+struct EqStepLive { int cfm; HB_HD bool operator()(int j) const { return j == 2 || ((cfm >> j) & 5) != 0; } };
+struct SoftStepLive { int cfm; HB_HD bool operator()(int j) const { return j != 2 && ((~cfm >> j) & 5) != 0; } };
 
 struct NodeIn {
   const double* x;      // 22
@@ -330,6 +344,22 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   mode_flags(in.mode, cf);
   const LqP1 P1 = lq_p1(lds);
   double* xs = P1.xs; double* us = P1.us; double* fv = P1.fv; double* J1 = P1.J1; double* J2 = P1.J2;
+  // The model phase leaves the constraint rows in contact-point order (slot 3i + a; a contact foot's rows are its (x, y, z)
+  // velocities, a swing foot's the normal row and the two xy rows).  Everything below works in the order of c_slot (xy rows by leg,
+  // normal rows last): one pass over the 32 direction rows of CDt and the row values (rowval is the 33rd row), a row per lane, in
+  // place.  The first barrier of the compose orders it against the readers.
+  for (int r = cx.lane; r < 33; r += cx.nlanes) {
+    double v[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) v[e] = CDt[r * 12 + e];
+#pragma unroll
+    for (int i = 0; i < HB_NC; ++i) {
+      const int s_n = c_slot(i, 0), s_x = c_slot(i, 1);
+      CDt[r * 12 + s_n] = cf[i] ? v[3 * i + 2] : v[3 * i];
+      CDt[r * 12 + s_x] = cf[i] ? v[3 * i] : v[3 * i + 1];
+      CDt[r * 12 + s_x + 1] = cf[i] ? v[3 * i + 1] : v[3 * i + 2];
+    }
+  }
   // ---- compose  x+ = x + dt/2 (f1 + f2(x + dt f1)) :
   //   d x+_i / d dir = [dir==i] + dt/2 (J1 + J2)[dir][i] + dt^2/2 ( sum_{c<12} J2[c][i] J1[dir][c] + sum_j J2[12+j][i] [dir==34+j] )
   // rows 3..11 of x+ for the 29 stored directions: the 29 x 6 x 9 contraction (f depends on the state directions angular
@@ -387,14 +417,18 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   // -------------------------------------------------------------- phase 2: G'G, G'[C e], pivoted Cholesky
   // joint-velocity directions are 34..43.  One masked Gram product on the matrix cores gives both:
   //   out(k, r) = sum_{slot in eq} CDt[22+k][slot] CDt[r][slot]   ->  W(k, r) for r < 22,  G'G(k, r-22) for r >= 22
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (the contact flags are wave-uniform, but booleans live in lane masks and their integer image would be built on the vector
+  // side: one readfirstlane puts the mask into a scalar register, and every test of it below is scalar)
+  const int cfm = __builtin_amdgcn_readfirstlane((cf[0] ? 1 : 0) | (cf[1] ? 2 : 0) | (cf[2] ? 4 : 0) | (cf[3] ? 8 : 0));
+#else
   const int cfm = (cf[0] ? 1 : 0) | (cf[1] ? 2 : 0) | (cf[2] ? 4 : 0) | (cf[3] ? 8 : 0);
+#endif
   {
     WaveTile<1, 2> tg;
     tile_init(cx, tg, 10, 32, [](int, int) { return 0.0; });
-    tile_mma<12, 12, false, 12, true>(cx, tg, CDt + 22 * 12, CDt, 10, 32, [cfm](int slot) {
-      const int foot = slot / 3;
-      return (((cfm >> foot) & 1) || slot - 3 * foot == 0) ? 1.0 : 0.0;  // contact foot: 3 rows, swing foot: slot 3i
-    });
+    tile_mma<12, 12, false, 12, true>(cx, tg, CDt + 22 * 12, CDt, 10, 32, [cfm](int slot) { return slot_is_eq(slot, cfm) ? 1.0 : 0.0; },
+                                      EqStepLive{cfm});
     tile_store(cx, tg, 10, 32, [W, GtG](int k, int r, double v) {
       if (r < 22) W[k * 23 + r] = v;
       else GtG[k * 10 + r - 22] = v;
@@ -407,7 +441,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     double s = 0;
 #pragma unroll
     for (int slot = 0; slot < 12; ++slot) {
-      const double w = (((cfm >> (slot / 3)) & 1) || slot % 3 == 0) ? 1.0 : 0.0;
+      const double w = slot_is_eq(slot, cfm) ? 1.0 : 0.0;
       s += (w * CDt[(22 + k) * 12 + slot]) * rowval[slot];
     }
     W[k * 23 + 22] = s;
@@ -665,9 +699,9 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         ru[12 + k] = sacc + bd1;
         scal[4 + k] = bd2 + shift_sum;  // joint diagonal additions to R_jj
       } else if (role < 56) {
-        const int sl = role - 44, foot = sl / 3, a = sl % 3;
+        const int sl = role - 44;
         const double rv = rowval[sl];
-        if (cf[foot] || a == 0) pe += rv * rv;          // equality slot
+        if (slot_is_eq(sl, cfm)) pe += rv * rv;         // equality slot
         else pc += 0.5 * C.soft_w * rv * rv;            // xy soft-reference slot
       } else if (role < 60) {
         const int foot = role - 56;
@@ -717,8 +751,8 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   for (int c = cx.lane; c < 32; c += cx.nlanes) {  // rows 0..21: state directions -> q_x; rows 22..31: joint-rate directions -> r_u
     double s = 0;
 #pragma unroll
-    for (int slot = 0; slot < 12; ++slot) {
-      const double w = (slot % 3 != 0 && !((cfm >> (slot / 3)) & 1)) ? 1.0 : 0.0;
+    for (int slot = 0; slot < 8; ++slot) {  // (the normal rows, slots 8..11, are never soft)
+      const double w = slot_is_soft(slot, cfm) ? 1.0 : 0.0;
       s += (w * rowval[slot]) * CDt[c * 12 + slot];
     }
     if (c < 22) qx[c] += C.soft_w * s;
@@ -729,10 +763,8 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     const double* Rc = C.R_jj;
     WaveTile<1, 2> tg;
     tile_init(cx, tg, 10, 32, [Rc, scal](int k, int r) { return r >= 22 ? Rc[k * 10 + r - 22] + (r - 22 == k ? scal[4 + k] : 0.0) : 0.0; });
-    tile_mma<12, 12, false, 12, true>(cx, tg, CDt + 22 * 12, CDt, 10, 32, [cfm, sw](int slot) {
-      const int foot = slot / 3;
-      return (slot - 3 * foot != 0 && !((cfm >> foot) & 1)) ? sw : 0.0;
-    });
+    tile_mma<12, 12, false, 12, true>(cx, tg, CDt + 22 * 12, CDt, 10, 32, [cfm, sw](int slot) { return slot_is_soft(slot, cfm) ? sw : 0.0; },
+                                      SoftStepLive{cfm});
     tile_store(cx, tg, 10, 32, [Pj, Rjj](int k, int r, double v) {
       if (r < 22) Pj[k * 22 + r] = v;
       else Rjj[k * 10 + r - 22] = v;
@@ -826,16 +858,14 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   // instead of 36 — and the off-diagonal tile is stored twice (k_ric_bwd mirrors the upper triangle anyway).
   {
     const double sw = C.soft_w;
-    auto soft = [cfm, sw](int slot) {  // soft rows are slots 3i+1, 3i+2 of the swing feet
-      const int foot = slot / 3;
-      return (slot - 3 * foot != 0 && !((cfm >> foot) & 1)) ? sw : 0.0;
-    };
+    auto soft = [cfm, sw](int slot) { return slot_is_soft(slot, cfm) ? sw : 0.0; };  // soft rows: the xy rows of the swing feet
+    const SoftStepLive soft_live{cfm};
     WaveTile<1, 2> t0;  // rows 0..15
     WaveTile<1, 1> t1;  // rows 16..21, columns 16..21
     tile_init(cx, t0, 16, 22, [Qd](int a, int b) { return a == b ? Qd[a] : 0.0; });
     tile_init(cx, t1, 6, 6, [Qd](int a, int b) { return a == b ? Qd[16 + a] : 0.0; });
-    tile_mma<12, 12, false, 12, true>(cx, t0, CDt, CDt, 16, 22, soft);
-    tile_mma<12, 12, false, 12, true>(cx, t1, CDt + 16 * 12, CDt + 16 * 12, 6, 6, soft);
+    tile_mma<12, 12, false, 12, true>(cx, t0, CDt, CDt, 16, 22, soft, soft_live);
+    tile_mma<12, 12, false, 12, true>(cx, t1, CDt + 16 * 12, CDt + 16 * 12, 6, 6, soft, soft_live);
     tile_mma<12, 23, true, 22, false, 10>(cx, t0, Kx, Mm, 16, 22);
     tile_mma<12, 23, true, 22, false, 10>(cx, t1, Kx + 16, Mm + 16, 6, 6);
     tile_mma<12, 22, true, 23, false, 10>(cx, t0, Pj, Kx, 16, 22);

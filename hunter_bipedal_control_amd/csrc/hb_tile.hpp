@@ -42,9 +42,11 @@ HB_HD void tile_init(const Ctx& cx, WaveTile<MT, NT>& t, int Mr, int Nr, FC c_in
 // must then be zero-padded in k on both sides, and out-of-range rows / columns only feed discarded outputs.  With
 // KR < K the fragments of the last step are selected to zero beyond KR (the memory behind them only has to be mapped).
 struct NoScale { HB_HD double operator()(int) const { return 1.0; } };
-// `wk(k)` is an optional weight of the k-th term (diagonal scaling between A and B), e.g. a 0/1 row mask.
-template <int K, int LDA, bool TA, int LDB, bool TB = false, int KR = K, int MT, int NT, class Ctx, class FW = NoScale>
-HB_HD void tile_mma(const Ctx& cx, WaveTile<MT, NT>& t, const double* A, const double* B, int Mr, int Nr, FW wk = FW()) {
+struct AllSteps { HB_HD bool operator()(int) const { return true; } };
+// `wk(k)` is an optional weight of the k-th term (diagonal scaling between A and B), e.g. a 0/1 row mask.  `step_live(j)` says
+// whether K-step j (terms 4j .. 4j+3) contributes at all: it must be wave-uniform, and a step it rules out must have zero weights.
+template <int K, int LDA, bool TA, int LDB, bool TB = false, int KR = K, int MT, int NT, class Ctx, class FW = NoScale, class FL = AllSteps>
+HB_HD void tile_mma(const Ctx& cx, WaveTile<MT, NT>& t, const double* A, const double* B, int Mr, int Nr, FW wk = FW(), FL step_live = FL()) {
   constexpr bool weighted = !std::is_same<FW, NoScale>::value;
 #if defined(__HIP_DEVICE_COMPILE__)
   (void)Mr; (void)Nr;
@@ -53,6 +55,7 @@ HB_HD void tile_mma(const Ctx& cx, WaveTile<MT, NT>& t, const double* A, const d
   const double* bp = B + (TB ? li * LDB + lk : lk * LDB + li);
 #pragma unroll
   for (int k0 = 0; k0 < K; k0 += 4) {
+    if (!step_live(k0 / 4)) continue;
     double av[MT], bv[NT];
     const bool live = (k0 + 4 <= KR) || (k0 + lk < KR);
     double w = 1.0;
@@ -79,7 +82,7 @@ HB_HD void tile_mma(const Ctx& cx, WaveTile<MT, NT>& t, const double* A, const d
     for (int j = 0; j < Nr; ++j) {
       double acc = t.c[i][j];
       for (int k = 0; k < KR; ++k)
-        acc += (weighted ? wk(k) : 1.0) * (TA ? A[k * LDA + i] : A[i * LDA + k]) * (TB ? B[j * LDB + k] : B[k * LDB + j]);
+        if (step_live(k / 4)) acc += (weighted ? wk(k) : 1.0) * (TA ? A[k * LDA + i] : A[i * LDA + k]) * (TB ? B[j * LDB + k] : B[k * LDB + j]);
       t.c[i][j] = acc;
     }
 #endif

@@ -111,13 +111,12 @@ struct LqLds {
   static constexpr int W = GtG + 100;        // 10x23 (G'C | G'e)
   static constexpr int Pj = GtG;             // 10x22   } over G'G | W
   static constexpr int Rjj = Pj + 220;       // 10x10   }
-  static constexpr int rjk = Rjj + 100;      // 10: r_j + R_jj ke (the last ten doubles of W)
-  static constexpr int RZ = W + 230;         // 10x6: R_jj Z
-  static constexpr int btmp = RZ + 60;       // 12: B_j ke
-  static constexpr int Kx = btmp + 12;       // 10x23 (Kx | ke)
-  static constexpr int Z = Kx + 230;         // 10x6
-  static constexpr int Mm = Z + 60;          // 10x22
-  static constexpr int RFF = Mm + 220;       // 4 blocks 3x3
+  static constexpr int LDK = 29;             // row length of [Kx | ke | Z] and of [M | r_j + R_jj ke | R_jj Z]
+  static constexpr int Kx = W + 230;         // 10 x LDK: [Kx (22) | ke | Z (6)] — one right operand for every product with the projection
+  static constexpr int Z = Kx + 23;          //   (columns 23..28 of the rows of Kx)
+  static constexpr int Mm = Kx + 10 * LDK;   // 10 x LDK: [M = P_j + R_jj Kx | r_j + R_jj ke | R_jj Z]
+  static constexpr int btmp = rowval;        // 12: B_j ke (the row values are dead once the soft rows have been folded into the gradients)
+  static constexpr int RFF = Mm + 10 * LDK;  // 4 blocks 3x3
   static constexpr int qx = RFF + 36;        // 22 (continuous-time gradient wrt x)
   static constexpr int ru = qx + 22;         // 22 (wrt u)
   static constexpr int Qd = ru + 22;         // 22 diagonal of Q incl. barriers/shift
@@ -135,7 +134,7 @@ struct LqLds {
 };
 static_assert(LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are still being read");
 static_assert(LqLds::Qd >= LqLds::p1_end && LqLds::ru >= LqLds::p1_end, "the reference / next state are parked in Qd / ru during phase 1");
-static_assert(LqLds::rjk + 10 <= LqLds::RZ, "P_j | R_jj | r_j must fit over G'G | W");
+static_assert(LqLds::Rjj + 100 <= LqLds::Kx, "P_j | R_jj must fit over G'G | W");
 static_assert(LqLds::total * 8 <= 16640, "k_lq: LDS per node must allow 9 workgroups per CU (13 allocation granules of 1280 B, DESIGN.md 3.1)");
 // row of CDt that holds direction d (d < 22 or d >= 34)
 HB_HD int cd_row(int dir) { return dir < 22 ? dir : dir - 12; }
@@ -325,7 +324,6 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* rowval = lds + LqLds::rowval;
   double* GtG = lds + LqLds::GtG;
   double* W = lds + LqLds::W;
-  double* rjk = lds + LqLds::rjk;
   double* Kx = lds + LqLds::Kx;
   double* Z = lds + LqLds::Z;
   double* Pj = lds + LqLds::Pj;
@@ -341,7 +339,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
 
   const double dt = in.dt;
   bool cf[HB_NC];
-  mode_flags(in.mode, cf);
+  const int cfm = mode_flags_uniform(in.mode, cf);  // (flags and mask in scalar registers)
   const LqP1 P1 = lq_p1(lds);
   double* xs = P1.xs; double* us = P1.us; double* fv = P1.fv; double* J1 = P1.J1; double* J2 = P1.J2;
   // The model phase leaves the constraint rows in contact-point order (slot 3i + a; a contact foot's rows are its (x, y, z)
@@ -417,13 +415,6 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   // -------------------------------------------------------------- phase 2: G'G, G'[C e], pivoted Cholesky
   // joint-velocity directions are 34..43.  One masked Gram product on the matrix cores gives both:
   //   out(k, r) = sum_{slot in eq} CDt[22+k][slot] CDt[r][slot]   ->  W(k, r) for r < 22,  G'G(k, r-22) for r >= 22
-#if defined(__HIP_DEVICE_COMPILE__)
-  // (the contact flags are wave-uniform, but booleans live in lane masks and their integer image would be built on the vector
-  // side: one readfirstlane puts the mask into a scalar register, and every test of it below is scalar)
-  const int cfm = __builtin_amdgcn_readfirstlane((cf[0] ? 1 : 0) | (cf[1] ? 2 : 0) | (cf[2] ? 4 : 0) | (cf[3] ? 8 : 0));
-#else
-  const int cfm = (cf[0] ? 1 : 0) | (cf[1] ? 2 : 0) | (cf[2] ? 4 : 0) | (cf[3] ? 8 : 0);
-#endif
   {
     WaveTile<1, 2> tg;
     tile_init(cx, tg, 10, 32, [](int, int) { return 0.0; });
@@ -556,8 +547,24 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       for (int t = 0; t < a; ++t) Lr[a * (a - 1) / 2 + t] = Lc[t * 10 + pm[a]];
     }
     cx.sync();
+    // (the results land in the rows of [Kx | ke | Z], the storage of Lc: the device's lanes have all read their L21 before any of
+    // them writes; the serial host keeps the columns aside and writes them once every column has been solved)
+    auto write_col = [Kx, Z, &pm, rank](int c, bool zlive, int pf, const double* y) {
+      if (c < 23) {
+#pragma unroll
+        for (int a = 0; a < 10; ++a) Kx[pm[a] * LqLds::LDK + c] = y[a];
+      } else {
+#pragma unroll
+        for (int a = 0; a < 10; ++a) Z[pm[a] * LqLds::LDK + c - 23] = zlive ? (a < rank ? -y[a] : (pm[a] == pf ? 1.0 : 0.0)) : 0.0;
+      }
+    };
+#if !defined(__HIP_DEVICE_COMPILE__)
+    double ycols[29][10];
+    bool ylive[29];
+    int ypf[29];
+#endif
     for (int cc = cx.lane; cc < 29; cc += cx.nlanes) {
-      const int c = 28 - cc;  // kernel columns first: a serial host reads L21 out of Lc before Kx (same storage) is written
+      const int c = 28 - cc;
       const bool isz = c >= 23;
       const int bz = c - 23;
       const bool zlive = isz && bz < nz;
@@ -581,14 +588,18 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         for (int t = a + 1; t < 10; ++t) sacc -= Lr[t * (t - 1) / 2 + a] * y[t];
         y[a] = sacc * dinv[a];
       }
-      if (!isz) {
-#pragma unroll
-        for (int a = 0; a < 10; ++a) Kx[pm[a] * 23 + c] = y[a];
-      } else {
-#pragma unroll
-        for (int a = 0; a < 10; ++a) Z[pm[a] * 6 + bz] = zlive ? (a < rank ? -y[a] : (pm[a] == pf ? 1.0 : 0.0)) : 0.0;
-      }
+#if defined(__HIP_DEVICE_COMPILE__)
+      write_col(c, zlive, pf, y);
+#else
+      for (int a = 0; a < 10; ++a) ycols[c][a] = y[a];
+      ylive[c] = zlive;
+      ypf[c] = pf;
+#endif
     }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    cx.sync();
+    for (int cc = cx.lane; cc < 29; cc += cx.nlanes) write_col(cc, ylive[cc], ypf[cc], ycols[cc]);
+#endif
   }
 
   HB_ABLATE_STOP(C.debug_stop == 3);
@@ -771,22 +782,13 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     });
   }
   cx.sync();
-  // M = P_j + R_jj Kx  (10x22),  and the vector R_jj ke + r_j (10)
+  // [M | r_j + R_jj ke | R_jj Z] = [P_j | r_j | 0] + R_jj [Kx | ke | Z]   (10 x 29, one product)
+  constexpr int LDK = LqLds::LDK;
   {
     WaveTile<1, 2> tm;
     tile_init(cx, tm, 10, 23, [Pj, ru](int k, int c) { return c < 22 ? Pj[k * 22 + c] : ru[12 + k]; });
-    tile_mma<12, 10, false, 23, false, 10>(cx, tm, Rjj, Kx, 10, 23);
-    tile_store(cx, tm, 10, 23, [Mm, rjk](int k, int c, double v) {
-      if (c < 22) Mm[k * 22 + c] = v;
-      else rjk[k] = v;  // r_j + R_jj ke
-    });
-  }
-  double* RZ = lds + LqLds::RZ;  // R_jj Z (10x6), for R~ = Z' R_jj Z
-  for (int idx = cx.lane; idx < 60; idx += cx.nlanes) {
-    const int k = idx / 6, b = idx - 6 * k;
-    double s = 0;
-    for (int l = 0; l < 10; ++l) s += Rjj[k * 10 + l] * Z[l * 6 + b];
-    RZ[idx] = s;
+    tile_mma<12, 10, false, LDK, false, 10>(cx, tm, Rjj, Kx, 10, LDK);
+    tile_store_rm<LDK>(cx, tm, 10, LDK, Mm);
   }
   cx.sync();
 
@@ -801,25 +803,22 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   // A~ = A + B_j Kx   and the kernel columns of B~ = B_j Z.  Momentum / base rows (0..11) on the matrix cores; the joint
   // rows are the closed form  A~ = [0 I] + dt Kx,  B~ = dt Z  (no force columns),  b~ = defect + dt ke.
-  double* btmp = lds + LqLds::btmp;  // 12: B_j ke, the dynamic part of b~ (column 22 of the A~ tile: Kx carries ke in its column 22)
+  // One product [A~ | B_j ke | B_j Z] = [A | 0 | 0] + B_j [Kx | ke | Z]: column 22 is the dynamic part of b~, columns 23.. the
+  // kernel columns of B~ (they go behind the n_f contact-force columns of the record).
+  double* btmp = lds + LqLds::btmp;  // 12: B_j ke
   {
     WaveTile<1, 2> ta;
-    tile_init(cx, ta, 12, 23, [ABt](int row, int c) { return c < 22 ? ABt[c * 12 + row] : 0.0; });
-    tile_mma<12, 12, true, 23, false, 10>(cx, ta, ABt + 34 * 12, Kx, 12, 23);
-    tile_store(cx, ta, 12, 23, [rec, btmp](int row, int c, double v) {
-      if (c < 22) rec[rec_A(row, c)] = v;
-      else btmp[row] = v;
-    });
-    WaveTile<1, 1> tb;
-    tile_init(cx, tb, 12, 6, [](int, int) { return 0.0; });
-    tile_mma<12, 12, true, 6, false, 10>(cx, tb, ABt + 34 * 12, Z, 12, 6);
-    tile_store_rm<REC_LD>(cx, tb, 12, nz, rec + rec_B(0, n_f));
+    tile_init(cx, ta, 12, 22, [ABt](int row, int c) { return ABt[c * 12 + row]; });
+    tile_mma<12, 12, true, LDK, false, 10>(cx, ta, ABt + 34 * 12, Kx, 12, LDK);
+    tile_store_rm_cols<REC_LD>(cx, ta, 12, 0, 22, rec + rec_A(0, 0));
+    tile_store_rm_cols<1>(cx, ta, 12, 22, 23, btmp - 22);
+    tile_store_rm_cols<REC_LD>(cx, ta, 12, 23, 23 + nz, rec + rec_A(0, 0) + n_f);
   }
   // joint rows of A~ and the recovery copy of Kx: one row per (uniform) step, one column per lane
   for (int c = cx.lane; c < 22; c += cx.nlanes) {
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
-      const double kx = Kx[j * 23 + c];
+      const double kx = Kx[j * LDK + c];
       rec[rec_A(12 + j, c)] = (c == 12 + j ? 1.0 : 0.0) + dt * kx;
       rec[REC_KX + j * 22 + c] = kx;
     }
@@ -837,7 +836,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       } else if (col >= ntil) {
         rec[rec_B(row, col)] = 0.0;
       } else if (row >= 12) {
-        rec[rec_B(row, col)] = dt * Z[(row - 12) * 6 + col - n_f];
+        rec[rec_B(row, col)] = dt * Z[(row - 12) * LDK + col - n_f];
       }
     }
     double s = xplus[row];  // the shooting defect of this row (stored by the cost phase)
@@ -848,7 +847,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         if (!cf[i])
           for (int a = 0; a < 3; ++a) s -= ABt[(22 + 3 * i + a) * 12 + row] * us[3 * i + a];
     } else {
-      s += dt * Kx[(row - 12) * 23 + 22];
+      s += dt * Kx[(row - 12) * LDK + 22];
     }
     rec[rec_b(row)] = s;
   }
@@ -866,31 +865,38 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     tile_init(cx, t1, 6, 6, [Qd](int a, int b) { return a == b ? Qd[16 + a] : 0.0; });
     tile_mma<12, 12, false, 12, true>(cx, t0, CDt, CDt, 16, 22, soft, soft_live);
     tile_mma<12, 12, false, 12, true>(cx, t1, CDt + 16 * 12, CDt + 16 * 12, 6, 6, soft, soft_live);
-    tile_mma<12, 23, true, 22, false, 10>(cx, t0, Kx, Mm, 16, 22);
-    tile_mma<12, 23, true, 22, false, 10>(cx, t1, Kx + 16, Mm + 16, 6, 6);
-    tile_mma<12, 22, true, 23, false, 10>(cx, t0, Pj, Kx, 16, 22);
-    tile_mma<12, 22, true, 23, false, 10>(cx, t1, Pj + 16, Kx + 16, 6, 6);
-    tile_store(cx, t0, 16, 22, [rec, dt](int a, int b, double v) {
-      rec[REC_QT + a * 22 + b] = dt * v;
-      if (b >= 16) rec[REC_QT + b * 22 + a] = dt * v;
+    // column 22 of the same tiles is q~ = q_x + Kx' (r_j + R_jj ke) + P_j' ke: the right operands carry r_j + R_jj ke and ke in
+    // their column 22 (the soft-row product left the derivative of a joint-rate direction there: overwritten with q_x)
+    tile_set_col(cx, t0, 22, 16, [qx](int a) { return qx[a]; });
+    tile_set_col(cx, t1, 6, 6, [qx](int a) { return qx[16 + a]; });
+    tile_mma<12, LDK, true, LDK, false, 10>(cx, t0, Kx, Mm, 16, 23);
+    tile_mma<12, LDK, true, LDK, false, 10>(cx, t1, Kx + 16, Mm + 16, 6, 7);
+    tile_mma<12, 22, true, LDK, false, 10>(cx, t0, Pj, Kx, 16, 23);
+    tile_mma<12, 22, true, LDK, false, 10>(cx, t1, Pj + 16, Kx + 16, 6, 7);
+    tile_store(cx, t0, 16, 23, [rec, dt](int a, int b, double v) {
+      if (b < 22) {
+        rec[REC_QT + a * 22 + b] = dt * v;
+        if (b >= 16) rec[REC_QT + b * 22 + a] = dt * v;
+      } else {
+        rec[REC_qT + a] = dt * v;
+      }
     });
-    tile_store_rm<22>(cx, t1, 6, 6, rec + REC_QT + 16 * 22 + 16, dt);
+    tile_store_rm_cols<22>(cx, t1, 6, 0, 6, rec + REC_QT + 16 * 22 + 16, dt);
+    tile_store_rm_cols<1>(cx, t1, 6, 6, 7, rec + REC_qT + 16 - 6, dt);
   }
   HB_ABLATE_STOP(C.debug_stop == 32);
-  // q~ = q + Kx' r_j + M' ke
   for (int a = cx.lane; a < 22; a += cx.nlanes) {
-    double s = qx[a];
-    for (int k = 0; k < 10; ++k) s += Kx[k * 23 + a] * ru[12 + k] + Mm[k * 22 + a] * Kx[k * 23 + 22];
-    rec[REC_qT + a] = dt * s;
     rec[REC_QF + a] = dt * qx[a];
     rec[REC_RF + a] = dt * ru[a];
   }
-  // P~ (12x22): force rows zero, kernel rows Z' M
+  // [P~ | r~ | R~] rows of the kernel directions: Z' [M | r_j + R_jj ke | R_jj Z]  (the force rows of P~ are zero; the kernel block
+  // of R~ goes behind the n_f contact-force columns)
   {
     WaveTile<1, 2> tp;
     tile_init(cx, tp, 6, 22, [](int, int) { return 0.0; });
-    tile_mma<12, 6, true, 22, false, 10>(cx, tp, Z, Mm, 6, 22);
-    tile_store_rm<REC_LD>(cx, tp, nz, 22, rec + rec_P(n_f, 0), dt);
+    tile_mma<12, LDK, true, LDK, false, 10>(cx, tp, Z, Mm, 6, LDK);
+    tile_store_rm_cols<REC_LD>(cx, tp, nz, 0, 23, rec + rec_P(n_f, 0), dt);
+    tile_store_rm_cols<REC_LD>(cx, tp, nz, 23, 23 + nz, rec + rec_P(n_f, 0) + n_f, dt);
   }
   for (int c = cx.lane; c < 22; c += cx.nlanes) {
 #pragma unroll
@@ -909,8 +915,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         s = RFF[9 * foot + 3 * (ca % 3) + (cb % 3)];
       }
     } else if (ca >= n_f && ca < ntil && cb >= n_f && cb < ntil) {
-      const int ba = ca - n_f, bb = cb - n_f;
-      for (int k = 0; k < 10; ++k) s += Z[k * 6 + ba] * RZ[k * 6 + bb];
+      continue;  // kernel block Z' R_jj Z: stored with the P~ tile above
     } else if (ca >= ntil && ca == cb) {
       pad_diag = true;
     }
@@ -923,15 +928,14 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       const int foot = (flist >> (2 * (col / 3))) & 3;
       s = ru[3 * foot + col % 3];
     } else if (col < ntil) {
-      const int b = col - n_f;
-      for (int k = 0; k < 10; ++k) s += Z[k * 6 + b] * rjk[k];
+      continue;  // kernel directions: column 22 of the P~ tile above
     }
     rec[rec_r(col)] = dt * s;
   }
   HB_ABLATE_STOP(C.debug_stop == 34);
   // recovery data
-  for (int k = cx.lane; k < 10; k += cx.nlanes) rec[REC_KE + k] = Kx[k * 23 + 22];
-  for (int idx = cx.lane; idx < 60; idx += cx.nlanes) rec[REC_Z + idx] = Z[idx];
+  for (int k = cx.lane; k < 10; k += cx.nlanes) rec[REC_KE + k] = Kx[k * LDK + 22];
+  for (int idx = cx.lane; idx < 60; idx += cx.nlanes) rec[REC_Z + idx] = Z[(idx / 6) * LDK + idx % 6];
   for (int i = cx.lane; i < 12; i += cx.nlanes) rec[REC_DF + i] = cf[i / 3] ? 0.0 : -us[i];
   if (cx.lane == 0) {
     rec[REC_META + 0] = double(n_f);

@@ -707,5 +707,18 @@ HB_HD void mode_flags(int mode, bool* cf) {
   const bool L = (mode == 2 || mode == 3), R = (mode == 1 || mode == 3);
   cf[0] = L; cf[1] = R; cf[2] = L; cf[3] = R;
 }
+// The same for a mode every lane of the wavefront shares; returns the flags as a bit mask too.  Device: booleans live in lane
+// masks and integer images of them are built on the vector side, so the mask goes through one readfirstlane into a scalar register
+// and the flags are re-derived from it: every test of them (and of the mask) is then a scalar instruction.
+HB_HD int mode_flags_uniform(int mode, bool* cf) {
+  mode_flags(mode, cf);
+  int cfm = (cf[0] ? 1 : 0) | (cf[1] ? 2 : 0) | (cf[2] ? 4 : 0) | (cf[3] ? 8 : 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+  cfm = __builtin_amdgcn_readfirstlane(cfm);
+#pragma unroll
+  for (int i = 0; i < HB_NC; ++i) cf[i] = (cfm >> i) & 1;
+#endif
+  return cfm;
+}
 
 }  // namespace hb

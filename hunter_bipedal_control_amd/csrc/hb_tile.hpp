@@ -144,4 +144,46 @@ HB_HD void tile_store_rm(const Ctx& cx, const WaveTile<MT, NT>& t, int Mr, int N
 #endif
 }
 
+// The same for a window of columns [c0, c1) of the tile (dst is the address of element (0, 0) of the tile in the destination, so a
+// caller that wants the window moved sideways passes a shifted base).
+template <int LD, int MT, int NT, class Ctx>
+HB_HD void tile_store_rm_cols(const Ctx& cx, const WaveTile<MT, NT>& t, int Mr, int c0, int c1, double* dst, double scale = 1.0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+  double* p0 = dst + lk * LD + li;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tm + lk + 4 * r, col = 16 * tn + li;
+        if (row < Mr && col >= c0 && col < c1) p0[(16 * tm + 4 * r) * LD + 16 * tn] = scale * t.acc[tm][tn][r];
+      }
+#else
+  (void)cx;
+  for (int i = 0; i < Mr; ++i)
+    for (int j = c0; j < c1; ++j) dst[i * LD + j] = scale * t.c[i][j];
+#endif
+}
+// Overwrite column `col` of the tile: t(row, col) = f(row) for row < Mr.
+template <int MT, int NT, class Ctx, class FV>
+HB_HD void tile_set_col(const Ctx& cx, WaveTile<MT, NT>& t, int col, int Mr, FV f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tm + lk + 4 * r;
+        if (16 * tn + li == col && row < Mr) t.acc[tm][tn][r] = f(row);
+      }
+#else
+  (void)cx;
+  for (int i = 0; i < Mr; ++i) t.c[i][col] = f(i);
+#endif
+}
+
 }  // namespace hb

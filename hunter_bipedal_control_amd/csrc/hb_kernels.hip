@@ -202,7 +202,12 @@ __global__ __launch_bounds__(64, 3) void k_lq(Batch b, const DevModel* __restric
   in.u = b.u + nd * HB_NU;
   in.xref = b.xref + nd * HB_NX;
   in.swing = b.swing + nd * 24;
-  in.dt = tt[k + 1] - tt[k];
+  {
+    const double dtv = tt[k + 1] - tt[k];  // (uniform: kept in a scalar register pair for the whole node)
+    const long long bits = __builtin_bit_cast(long long, dtv);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(bits)), hi = __builtin_amdgcn_readfirstlane(unsigned(bits >> 32));
+    in.dt = __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+  }
   in.mode = __builtin_amdgcn_readfirstlane(b.mode[nd]);  // (uniform by construction; tells the compiler so: mode tests become scalar)
   lq_node(WaveCtx(), *M, *C, in, lds, b.recs + nd * REC_SIZE);
 }

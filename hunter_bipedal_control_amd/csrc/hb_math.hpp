@@ -20,7 +20,13 @@
 // (the exits also bounded the compiler's code motion across phases: without any ordering point at these places k_lq hoists loads
 // over whole phases and spills 12 B/lane; a compiler-only ordering point keeps the schedule of the variant they were tuned on)
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(HB_PHASE_MARK)  // tools/asm_count.sh --phases: the ordering point leaves a comment in the assembly (same code otherwise)
+#define HB_PHASE_STR2(x) #x
+#define HB_PHASE_STR(x) HB_PHASE_STR2(x)
+#define HB_ABLATE_STOP(cond) asm volatile("; HB_PHASE line " HB_PHASE_STR(__LINE__) ::: "memory")
+#else
 #define HB_ABLATE_STOP(cond) asm volatile("" ::: "memory")
+#endif
 #else
 #define HB_ABLATE_STOP(cond) do { } while (0)
 #endif

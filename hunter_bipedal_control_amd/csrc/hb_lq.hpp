@@ -458,12 +458,12 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     const bool own = cx.lane < 55;
     const bool diag = own && ei0 == ej0;
     double g = own ? GtG[ei0 * 10 + ej0] : 0.0;
-    const double tol = 1e-10 * fmax(wave_max_f64(diag ? g : 0.0), 0.0);
+    const double tol = 1e-10 * wave_max_nonneg_f64(diag ? g : 0.0);
     for (int i = cx.lane; i < 124; i += cx.nlanes) Kx[i] = 0.0;
     cx.sync();
     for (int st = 0; st < 10; ++st) {
       const double v = (diag && !((donemask >> ei0) & 1)) ? g : -1.0;
-      const double best = wave_max_f64(v);
+      const double best = wave_max_nonneg_f64(v);  // (a non-positive maximum ends the factorisation either way: tol >= 0)
       if (!(best > tol)) break;
       const unsigned long long hit = __ballot(v == best);
       const int ps = __builtin_amdgcn_readlane(ei0, __ffsll(hit) - 1);

@@ -146,6 +146,25 @@ HB_HD void sincos_known(double sv, double cv, Dual1 a, Dual1& s, Dual1& c) {
   c = {cv, -sv * a.d};
 }
 #if defined(__HIP_DEVICE_COMPILE__)
+// A DPP move of an f64 costs two v_mov_b32_dpp; what it costs BESIDES them is the `old` operand (the value of lanes the move does not
+// write): the compiler has to put it into the destination registers first, two more moves per shift.  Two forms avoid that:
+//   dpp_full_f64   every lane is written (row and bank masks 0xf, bound_ctrl: lanes without a source read 0): no `old` at all;
+//   dpp_carry_f64  a partial bank mask; the lanes it leaves alone keep what the CARRIER holds there.  The carrier is the result of
+//                  the previous shift with the SAME mask (zero before the first one): its unwritten lanes are zero and stay zero,
+//                  the written ones are overwritten again, so it never has to be re-initialised.  (bound_ctrl as above.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_full_f64(double v) {
+  const int lo_ = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi_ = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi_, lo_);
+}
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_carry_f64(double v, double& carrier) {
+  const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(carrier), __double2loint(v), CTRL, 0xf, BANK, true);
+  const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(carrier), __double2hiint(v), CTRL, 0xf, BANK, true);
+  carrier = __hiloint2double(hi_, lo_);
+  return carrier;
+}
 // Maximum over the 64 lanes of a wavefront, returned uniformly: DPP row shifts inside the rows of 16, row broadcasts
 // across them (gfx9 row_bcast:15 / :31), lane 63 read back — 18 VALU instructions, no LDS traffic.
 __device__ __forceinline__ double wave_max_f64(double v) {
@@ -165,6 +184,33 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 #undef HB_DPP_MAX
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+// max(0, maximum over the 64 lanes), returned uniformly: the same ladder for values whose maximum only matters when it is positive
+// (the pivot search of the rank-revealing Cholesky).  Lanes without a source read zero (bound_ctrl) instead of keeping a copy of
+// their own value, and the maximum is the bare v_max_f64 (fmax() canonicalises both operands first): 22 VALU instructions
+// instead of 38.
+__device__ __forceinline__ double wave_max_nonneg_f64(double v) {
+#define HB_DPP_MAX0(ctrl, rmask)                                                                            \
+  {                                                                                                         \
+    const int lo2_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, true);             \
+    const int hi2_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, true);             \
+    const double o_ = __hiloint2double(hi2_, lo2_);                                                         \
+    asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o_));                                                \
+  }
+#define HB_DPP_MAXF(ctrl)                                                                                   \
+  {                                                                                                         \
+    const double o_ = dpp_full_f64<ctrl>(v);                                                                \
+    asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o_));                                                \
+  }
+  HB_DPP_MAXF(0x111)
+  HB_DPP_MAXF(0x112)
+  HB_DPP_MAXF(0x114)
+  HB_DPP_MAXF(0x118)
+#undef HB_DPP_MAXF
+  HB_DPP_MAX0(0x142, 0xa)
+  HB_DPP_MAX0(0x143, 0xc)
+#undef HB_DPP_MAX0
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 // Sum over the 64 lanes of a wavefront, returned uniformly (same DPP ladder; lanes without a source add zero).
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #define HB_DPP_ADD(ctrl, rmask)                                                              \
@@ -173,10 +219,10 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     const int hi2_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, false); \
     v += __hiloint2double(hi2_, lo2_);                                                       \
   }
-  HB_DPP_ADD(0x111, 0xf)
-  HB_DPP_ADD(0x112, 0xf)
-  HB_DPP_ADD(0x114, 0xf)
-  HB_DPP_ADD(0x118, 0xf)
+  v += dpp_full_f64<0x111>(v);
+  v += dpp_full_f64<0x112>(v);
+  v += dpp_full_f64<0x114>(v);
+  v += dpp_full_f64<0x118>(v);
   HB_DPP_ADD(0x142, 0xa)
   HB_DPP_ADD(0x143, 0xc)
 #undef HB_DPP_ADD
@@ -203,31 +249,31 @@ __device__ __forceinline__ double dpp_shift_f64_old(double v, double neutral) {
   const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(neutral), __double2hiint(v), CTRL, 0xf, BANK, false);
   return __hiloint2double(hi_, lo_);
 }
+// Carriers of the two partial bank masks of the scans below (dpp_carry_f64), three of each so that the three components of a vector
+// do not queue behind one register pair.  One object per kernel phase that scans, constructed where the phase starts.
+struct Seg8Carry {
+  double s5[3] = {0.0, 0.0, 0.0};   // bank mask 0x5 (suffix sums)
+  double pa[3] = {0.0, 0.0, 0.0};   // bank mask 0xa (last step of the prefix sums)
+};
 // lane k of a group <- sum over lanes k .. 4 of the group
-__device__ __forceinline__ double seg8_suffix_sum(double v) {
-  v += dpp_shift_f64<0x101, 0x5>(v);  // row_shl:1
-  v += dpp_shift_f64<0x102, 0x5>(v);  // row_shl:2
-  v += dpp_shift_f64<0x104, 0x5>(v);  // row_shl:4
+__device__ __forceinline__ double seg8_suffix_sum(double v, double& c5) {
+  v += dpp_carry_f64<0x101, 0x5>(v, c5);  // row_shl:1
+  v += dpp_carry_f64<0x102, 0x5>(v, c5);  // row_shl:2
+  v += dpp_carry_f64<0x104, 0x5>(v, c5);  // row_shl:4
   return v;
 }
 // lane k of a group <- sum over lanes 0 .. k of the group (lanes 5..7 end up with garbage: nobody reads them)
-__device__ __forceinline__ double seg8_prefix_sum(double v) {
-  v += dpp_shift_f64<0x111, 0xf>(v);  // row_shr:1
-  v += dpp_shift_f64<0x112, 0xf>(v);  // row_shr:2
-  v += dpp_shift_f64<0x114, 0xa>(v);  // row_shr:4, lanes 4..7 of each group only
+__device__ __forceinline__ double seg8_prefix_sum(double v, double& ca) {
+  v += dpp_full_f64<0x111>(v);            // row_shr:1
+  v += dpp_full_f64<0x112>(v);            // row_shr:2
+  v += dpp_carry_f64<0x114, 0xa>(v, ca);  // row_shr:4, lanes 4..7 of each group only
   return v;
 }
+
 // Sum over each aligned group of four lanes (all four must be active), returned to all of them: two quad_perm adds.
 __device__ __forceinline__ double quad_sum_f64(double v) {
-#define HB_DPP_QADD(ctrl)                                                                    \
-  {                                                                                          \
-    const int lo2_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false); \
-    const int hi2_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false); \
-    v += __hiloint2double(hi2_, lo2_);                                                       \
-  }
-  HB_DPP_QADD(0xB1)  // quad_perm:[1,0,3,2]
-  HB_DPP_QADD(0x4E)  // quad_perm:[2,3,0,1]
-#undef HB_DPP_QADD
+  v += dpp_full_f64<0xB1>(v);  // quad_perm:[1,0,3,2]
+  v += dpp_full_f64<0x4E>(v);  // quad_perm:[2,3,0,1]
   return v;
 }
 #endif
@@ -380,17 +426,24 @@ template <class T> HB_HD Mat3<T> axis_rot_sc(const double* ax, T s, T c) {
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// the scans of the three components of a vector, each on its own carrier
+__device__ __forceinline__ Vec3<double> seg8_suffix_sum(const Vec3<double>& v, Seg8Carry& c) {
+  return {seg8_suffix_sum(v.x, c.s5[0]), seg8_suffix_sum(v.y, c.s5[1]), seg8_suffix_sum(v.z, c.s5[2])};
+}
+__device__ __forceinline__ Vec3<double> seg8_prefix_sum(const Vec3<double>& v, Seg8Carry& c) {
+  return {seg8_prefix_sum(v.x, c.pa[0]), seg8_prefix_sum(v.y, c.pa[1]), seg8_prefix_sum(v.z, c.pa[2])};
+}
 // All-reduce over each aligned group of eight lanes: two quad permutes and the half-row mirror (lane i <-> 7 - i).
 __device__ __forceinline__ double seg8_allsum(double v) {
-  v += dpp_shift_f64<0xB1, 0xf>(v);   // quad_perm:[1,0,3,2]
-  v += dpp_shift_f64<0x4E, 0xf>(v);   // quad_perm:[2,3,0,1]
-  v += dpp_shift_f64<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_full_f64<0xB1>(v);   // quad_perm:[1,0,3,2]
+  v += dpp_full_f64<0x4E>(v);   // quad_perm:[2,3,0,1]
+  v += dpp_full_f64<0x141>(v);  // row_half_mirror
   return v;
 }
 __device__ __forceinline__ double seg8_allmax(double v) {
-  v = fmax(v, dpp_shift_f64<0xB1, 0xf>(v));
-  v = fmax(v, dpp_shift_f64<0x4E, 0xf>(v));
-  v = fmax(v, dpp_shift_f64<0x141, 0xf>(v));
+  v = fmax(v, dpp_full_f64<0xB1>(v));
+  v = fmax(v, dpp_full_f64<0x4E>(v));
+  v = fmax(v, dpp_full_f64<0x141>(v));
   return v;
 }
 // value of lane `k` (0..7, may differ per group) of the caller's group of eight
@@ -399,11 +452,20 @@ __device__ __forceinline__ double seg8_get(double v, int k) { return __shfl(v, (
 #if defined(__HIP_DEVICE_COMPILE__)
 // One step of an inclusive prefix PRODUCT of 3x3 matrices over groups of eight lanes (see seg8_prefix_sum): P <- S P with S the
 // matrix of the lane CTRL shifts in, the identity for lanes the shift leaves alone.
+// (the off-diagonal entries take the cheap forms of the shift: their neutral element is the zero that bound_ctrl / a zero carrier
+// deliver; the diagonal needs the explicit 1)
+template <int CTRL, int BANK>
+__device__ __forceinline__ double seg8_shift_entry(double v, int e, double& carrier) {
+  if (e == 0 || e == 4 || e == 8) return dpp_shift_f64_old<CTRL, BANK>(v, 1.0);
+  if (BANK == 0xf) return dpp_full_f64<CTRL>(v);
+  return dpp_carry_f64<CTRL, BANK>(v, carrier);
+}
 template <int CTRL, int BANK>
 __device__ __forceinline__ void seg8_prefix_mat3(Mat3<double>& P) {
   Mat3<double> S;
+  double carrier = 0.0;
 #pragma unroll
-  for (int e = 0; e < 9; ++e) S.m[e] = dpp_shift_f64_old<CTRL, BANK>(P.m[e], (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0);
+  for (int e = 0; e < 9; ++e) S.m[e] = seg8_shift_entry<CTRL, BANK>(P.m[e], e, carrier);
   P = S * P;
 }
 #endif

@@ -295,12 +295,14 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
     Mat3<double> Rm;
 #pragma unroll
     for (int e = 0; e < 9; ++e) {
-      const double sh = dpp_shift_f64_old<0x111, 0xf>(P.m[e], (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0);
+      double unused = 0.0;
+      const double sh = seg8_shift_entry<0x111, 0xf>(P.m[e], e, unused);
       Rm.m[e] = (dk == 0) ? ((e == 0 || e == 4 || e == 8) ? 1.0 : 0.0) : sh;
     }
     // joint origins: o_k = sum_{m <= k} R_m^- origin_m
     const Vec3<double> ot = on * (Rm * Vec3<double>(jc.org[0], jc.org[1], jc.org[2]));
-    const Vec3<double> o(seg8_prefix_sum(ot.x), seg8_prefix_sum(ot.y), seg8_prefix_sum(ot.z));
+    Seg8Carry sc;  // (zero carriers of the scans' partial bank masks, hb_math.hpp)
+    const Vec3<double> o = seg8_prefix_sum(ot, sc);
     // contact points behind the last joint (frame P_4): lane 4 of the group publishes them
     if (dvalid && dk == 4) {
 #pragma unroll
@@ -317,24 +319,24 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
     const double mb = on * jc.m;
     const Vec3<double> c = o + P * Vec3<double>(jc.com[0], jc.com[1], jc.com[2]);
     // C + D: suffix sums (joints k .. 4) of mass, first moment, inertia about the base origin; prefix sums of the joint-rate twist
-    const double ms = seg8_suffix_sum(mb);
+    const double ms = seg8_suffix_sum(mb, sc.s5[0]);
     const Vec3<double> mck = mb * c;
-    const Vec3<double> mc(seg8_suffix_sum(mck.x), seg8_suffix_sum(mck.y), seg8_suffix_sum(mck.z));
+    const Vec3<double> mc = seg8_suffix_sum(mck, sc);
     const Sym3<double> IOk = rotate_inertia<double>(P, jc.in) + point_inertia<double>(mb, c);
     Sym3<double> IO;
-    IO.xx = seg8_suffix_sum(on * IOk.xx); IO.xy = seg8_suffix_sum(on * IOk.xy); IO.xz = seg8_suffix_sum(on * IOk.xz);
-    IO.yy = seg8_suffix_sum(on * IOk.yy); IO.yz = seg8_suffix_sum(on * IOk.yz); IO.zz = seg8_suffix_sum(on * IOk.zz);
+    IO.xx = seg8_suffix_sum(on * IOk.xx, sc.s5[0]); IO.xy = seg8_suffix_sum(on * IOk.xy, sc.s5[1]); IO.xz = seg8_suffix_sum(on * IOk.xz, sc.s5[2]);
+    IO.yy = seg8_suffix_sum(on * IOk.yy, sc.s5[0]); IO.yz = seg8_suffix_sum(on * IOk.yz, sc.s5[1]); IO.zz = seg8_suffix_sum(on * IOk.zz, sc.s5[2]);
     const Vec3<double> tw = qd * a, tww = qd * cross(a, o);
-    const Vec3<double> om(seg8_prefix_sum(tw.x) - tw.x, seg8_prefix_sum(tw.y) - tw.y, seg8_prefix_sum(tw.z) - tw.z);
-    const Vec3<double> w(seg8_prefix_sum(tww.x) - tww.x, seg8_prefix_sum(tww.y) - tww.y, seg8_prefix_sum(tww.z) - tww.z);
+    const Vec3<double> om = seg8_prefix_sum(tw, sc) - tw;
+    const Vec3<double> w = seg8_prefix_sum(tww, sc) - tww;
     const Vec3<double> l = cross(a, mc - ms * o);
     const Vec3<double> L = IO * a - cross(mc, cross(a, o));
     // E: suffix sums of the joint-rate momenta and of the joint-induced contact-point velocities
     const Vec3<double> ql = qd * l, qL = qd * L, q0 = qd * cross(a, p0 - o), q1 = qd * cross(a, p1 - o);
-    const Vec3<double> lin(seg8_suffix_sum(ql.x), seg8_suffix_sum(ql.y), seg8_suffix_sum(ql.z));
-    const Vec3<double> ang(seg8_suffix_sum(qL.x), seg8_suffix_sum(qL.y), seg8_suffix_sum(qL.z));
-    const Vec3<double> v0(seg8_suffix_sum(q0.x), seg8_suffix_sum(q0.y), seg8_suffix_sum(q0.z));
-    const Vec3<double> v1(seg8_suffix_sum(q1.x), seg8_suffix_sum(q1.y), seg8_suffix_sum(q1.z));
+    const Vec3<double> lin = seg8_suffix_sum(ql, sc);
+    const Vec3<double> ang = seg8_suffix_sum(qL, sc);
+    const Vec3<double> v0 = seg8_suffix_sum(q0, sc);
+    const Vec3<double> v1 = seg8_suffix_sum(q1, sc);
     if (dvalid) {
       st3(B + LEGJ_A, a);
       st3(B + LEGJ_O, o);

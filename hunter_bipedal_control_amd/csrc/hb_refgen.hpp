@@ -390,13 +390,15 @@ __device__ __forceinline__ void ik_kin(const IkLane& L, const Mat3<double>& R0, 
 #pragma unroll
   for (int e = 0; e < 9; ++e) {
     const double idv = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
-    const double sh = dpp_shift_f64_old<0x111, 0xf>(P.m[e], idv);
+    double unused = 0.0;
+    const double sh = seg8_shift_entry<0x111, 0xf>(P.m[e], e, unused);
     Pex.m[e] = (L.k == 0) ? idv : sh;
   }
   const Mat3<double> Rm = R0 * Pex;           // frame in front of this joint
   const double on = L.joint ? 1.0 : 0.0;
   const Vec3<double> ot = on * (Rm * Vec3<double>(L.org[0], L.org[1], L.org[2]));
-  const Vec3<double> org(p0.x + seg8_prefix_sum(ot.x), p0.y + seg8_prefix_sum(ot.y), p0.z + seg8_prefix_sum(ot.z));
+  Seg8Carry sc;  // (zero carriers of the scan's partial bank mask, hb_math.hpp)
+  const Vec3<double> org = p0 + seg8_prefix_sum(ot, sc);
   const Vec3<double> axw = Rm * Vec3<double>(L.ax[0], L.ax[1], L.ax[2]);
   const Mat3<double> Rl = R0 * P;             // on lane 4: the frame behind the last joint
   const Vec3<double> fl = org + Rl * Vec3<double>(L.off[0], L.off[1], L.off[2]);

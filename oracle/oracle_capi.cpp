@@ -6,7 +6,9 @@
 // (oracle/Makefile target ref -> oracle/_ref/, golden vectors under tests/golden/): the WBC task builders,
 // WeightedWbc, HierarchicalWbc, HoQp and Task (wbc.hpp, hoqp.hpp: tests/test_ref_wbc.py), the friction-cone and zero-force terms
 // (ocp.hpp: tests/test_ref_constraints.py), the end-effector constraint rows, xy soft rows, tracking cost and initializer of a node
-// (ocp.hpp / sqp.hpp: tests/test_ref_ocp.py), the Kalman filter (estimator.hpp: tests/test_ref_kf.py).
+// (ocp.hpp / sqp.hpp: tests/test_ref_ocp.py), the Kalman filter (estimator.hpp: tests/test_ref_kf.py), the list of terms of the optimal
+// control problem with their parameters and the input cost weight R as the reference's LeggedInterface.cpp assembles them when it is
+// executed on the reference's own task.info (tests/test_ref_interface.py).
 // PARITY UNPINNED for what the reference delegates to absent libraries: the centroidal dynamics and their sensitivities
 // (model.hpp, ocp.hpp), the SQP / projection / Riccati / line search (sqp.hpp) and the rigid-body terms M, nle, J, dJ (model.hpp):
 // a from-scratch restatement held by invariants (tests/test_oracle_*.py) and by the known answers the reference does hold

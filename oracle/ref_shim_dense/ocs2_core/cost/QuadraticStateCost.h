@@ -3,11 +3,11 @@
 #pragma once
 #include <ocs2_core/cost/QuadraticStateInputCost.h>
 namespace ocs2 {
-class QuadraticStateCost {
+class QuadraticStateCost : public StateCost {
  public:
   explicit QuadraticStateCost(matrix_t Q) : Q_(std::move(Q)) {}
-  virtual ~QuadraticStateCost() = default;
-  virtual QuadraticStateCost* clone() const = 0;
+  ~QuadraticStateCost() override = default;
+  QuadraticStateCost* clone() const override = 0;
   scalar_t getValue(scalar_t time, const vector_t& state, const TargetTrajectories& tt, const PreComputation&) const {
     const vector_t d = getStateDeviation(time, state, tt);
     const vector_t Qx = Q_ * d;

@@ -9,11 +9,24 @@
 #include <ocs2_core/reference/TargetTrajectories.h>
 namespace ocs2 {
 struct ScalarFunctionQuadraticApproximation { scalar_t f = 0; vector_t dfdx, dfdu; matrix_t dfdxx, dfdux, dfduu; };
-class QuadraticStateInputCost {
+// [OCS2-knowledge: published interfaces] what the cost collections of the optimal control problem hold (ref_shim_li/: LeggedInterface.cpp)
+class StateInputCost {
+ public:
+  virtual ~StateInputCost() = default;
+  virtual StateInputCost* clone() const = 0;
+};
+class StateCost {
+ public:
+  virtual ~StateCost() = default;
+  virtual StateCost* clone() const = 0;
+};
+class QuadraticStateInputCost : public StateInputCost {
  public:
   QuadraticStateInputCost(matrix_t Q, matrix_t R) : Q_(std::move(Q)), R_(std::move(R)) {}
-  virtual ~QuadraticStateInputCost() = default;
-  virtual QuadraticStateInputCost* clone() const = 0;
+  ~QuadraticStateInputCost() override = default;
+  QuadraticStateInputCost* clone() const override = 0;
+  const matrix_t& weightQ() const { return Q_; }   // (read by oracle/ref_interface_capi.cpp)
+  const matrix_t& weightR() const { return R_; }
   scalar_t getValue(scalar_t time, const vector_t& state, const vector_t& input, const TargetTrajectories& tt, const PreComputation&) const {
     const std::pair<vector_t, vector_t> d = getStateInputDeviation(time, state, input, tt);
     const vector_t Qx = Q_ * d.first, Ru = R_ * d.second;

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE (oracle/_ref build only). Stand-in for OCS2's <ocs2_core/reference/ModeSchedule.h> [OCS2-knowledge:
 // published definition]: event times, mode sequence (one more entry), modeAtTime = modeSequence[findIndexInTimeArray].
 #pragma once
+#include <ostream>
 #include <ocs2_core/Types.h>
 #include <ocs2_core/misc/Lookup.h>
 namespace ocs2 {
@@ -15,4 +16,11 @@ struct ModeSchedule {
   std::vector<scalar_t> eventTimes;
   std::vector<size_t> modeSequence;
 };
+inline std::ostream& operator<<(std::ostream& os, const ModeSchedule& m) {
+  os << "event times: {";
+  for (scalar_t t : m.eventTimes) os << t << ", ";
+  os << "}, mode sequence: {";
+  for (size_t v : m.modeSequence) os << v << ", ";
+  return os << "}\n";
+}
 }  // namespace ocs2

@@ -22,21 +22,33 @@ struct SE3 {
 struct Model {
   int nq = 16, nv = 16;
   const hb_model* hb = nullptr;  // set by the entry points that need real kinematics (inverse kinematics)
-  Eigen::Matrix<double, Eigen::Dynamic, 1> lowerPositionLimit, upperPositionLimit;
-  int getBodyId(const std::string&) const { return BASE_LINK_FRAME; }
-  int getFrameId(const std::string&) const { return BASE_LINK_FRAME; }
+  Eigen::Matrix<double, Eigen::Dynamic, 1> lowerPositionLimit, upperPositionLimit, velocityLimit;
+  std::vector<std::string> frame_names;          // contact frames by name (frame id = contact index); anything else is the base link
+  int getBodyId(const std::string& n) const { return getFrameId(n); }
+  int getFrameId(const std::string& n) const {
+    for (size_t i = 0; i < frame_names.size(); ++i)
+      if (frame_names[i] == n) return int(i);
+    return BASE_LINK_FRAME;
+  }
 };
 struct Data {
   int role = 0;
   Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic> M, C;
   Eigen::Matrix<double, Eigen::Dynamic, 1> nle, g;
   std::vector<SE3> oMf = std::vector<SE3>(4);   // the four contact frames (frame id = contact index)
+  bool real_kin = false;                        // computeJointJacobians(model, data, q) on a model with kinematics: q kept for getFrameJacobian
+  double q_kin[16] = {0};
 };
 inline const ref_feed::Rbd& fed(const Data& d) { return ref_feed::feed().role[d.role]; }
 template <class Q> void forwardKinematics(const Model&, Data&, const Q&) {}
 template <class Q, class V> void forwardKinematics(const Model&, Data&, const Q&, const V&) {}
 inline void computeJointJacobians(const Model&, Data&) {}
-template <class Q> void computeJointJacobians(const Model&, Data&, const Q&) {}
+template <class Q> void computeJointJacobians(const Model& m, Data& d, const Q& q) {
+  if (m.hb) {  // (the fed-Jacobian users — WBC, estimator — never give the model kinematics)
+    d.real_kin = true;
+    for (int i = 0; i < 16; ++i) d.q_kin[i] = q(i);
+  }
+}
 inline void updateFramePlacements(const Model&, Data&) {}
 inline void updateGlobalPlacements(const Model&, Data&) {}
 template <class Q, class V> void computeJointJacobiansTimeVariation(const Model&, Data&, const Q&, const V&) {}
@@ -61,7 +73,21 @@ template <class JAC> void frame_jac(const Model& m, const Data& d, int frame, JA
       for (int c = 0; c < m.nv; ++c) jac(r, c) = src[(3 * frame + r) * m.nv + c];  // angular rows stay as the caller initialised them (zero)
   }
 }
-template <class JAC> void getFrameJacobian(const Model& m, const Data& d, size_t frame, ReferenceFrame, JAC& jac) { frame_jac(m, d, int(frame), jac, false); }
+template <class JAC> void getFrameJacobian(const Model& m, const Data& d, size_t frame, ReferenceFrame rf, JAC& jac) {
+  if (d.real_kin && int(frame) != BASE_LINK_FRAME) {  // the oracle's kinematics at the q of computeJointJacobians (see computeFrameJacobian)
+    orc::Kin<double> k;
+    k.compute(*m.hb, d.q_kin);
+    const int i = int(frame), b = m.hb->contact_body[i];
+    const orc::V3<double> p = k.contact_point(*m.hb, i);
+    for (int c = 0; c < m.nv; ++c) {
+      orc::V3<double> l = k.lin_jac(b, p, c), a = k.ang_jac(b, c);
+      if (rf == LOCAL) { const orc::M3<double> Rt = orc::transpose(k.R[b]); l = Rt * l; a = Rt * a; }
+      for (int r = 0; r < 3; ++r) { jac(r, c) = l[r]; jac(3 + r, c) = a[r]; }
+    }
+    return;
+  }
+  frame_jac(m, d, int(frame), jac, false);
+}
 template <class JAC> void getFrameJacobianTimeVariation(const Model& m, const Data& d, size_t frame, ReferenceFrame, JAC& jac) { frame_jac(m, d, int(frame), jac, true); }
 // ---- entry points with real kinematics (legged_interface/src/foot_planner/InverseKinematics.cpp): evaluated with the oracle's
 // forward kinematics at the q passed in.  Frame i = contact point i, rigidly attached to the last link of leg (i & 1) with the

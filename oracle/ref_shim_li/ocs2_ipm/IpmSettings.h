@@ -1,0 +1,10 @@
+// TEST INFRASTRUCTURE (oracle/_ref build only).  ipm::Settings / loadSettings as LeggedInterface.cpp:94-99 calls them: the solver
+// settings are read by OCS2 code that is not here, so this keeps only where they were asked for (file, block name).
+#pragma once
+#include <string>
+namespace ocs2 {
+namespace ipm {
+struct Settings { std::string file, block; };
+inline Settings loadSettings(const std::string& file, const std::string& block = "ipm", bool = true) { return Settings{file, block}; }
+}  // namespace ipm
+}  // namespace ocs2

@@ -114,14 +114,16 @@ struct LqLds {
   static constexpr int LDK = 29;             // row length of [Kx | ke | Z] and of [M | r_j + R_jj ke | R_jj Z]
   static constexpr int Kx = W + 230;         // 10 x LDK: [Kx (22) | ke | Z (6)] — one right operand for every product with the projection
   static constexpr int Z = Kx + 23;          //   (columns 23..28 of the rows of Kx)
-  static constexpr int Mm = Kx + 10 * LDK;   // 10 x LDK: [M = P_j + R_jj Kx | r_j + R_jj ke | R_jj Z]
-  static constexpr int btmp = rowval;        // 12: B_j ke (the row values are dead once the soft rows have been folded into the gradients)
+  static constexpr int btmp = GtG;           // 12: B_j ke (the Gram matrix is dead once it has been factorised; P_j lands there later)
+  static constexpr int ints = Kx + 10 * LDK; // 32 ints packed in 16 doubles: perm[10], rank, eq slots...
+  static constexpr int park = ints + 16;     // 44: reference state and next node's state, fetched while the compose runs (device)
+  static constexpr int tail_end = park + 44;
+  // over ABt, which is dead once A~, B~ and b~ have been written (they are formed right behind the projection, before the cost phase):
+  static constexpr int Mm = ABt;             // 10 x LDK: [M = P_j + R_jj Kx | r_j + R_jj ke | R_jj Z]
   static constexpr int RFF = Mm + 10 * LDK;  // 4 blocks 3x3
   static constexpr int qx = RFF + 36;        // 22 (continuous-time gradient wrt x)
   static constexpr int ru = qx + 22;         // 22 (wrt u)
   static constexpr int Qd = ru + 22;         // 22 diagonal of Q incl. barriers/shift
-  static constexpr int ints = Qd + 22;       // 32 ints packed in 16 doubles: perm[10], rank, eq slots...
-  static constexpr int tail_end = ints + 16;
   // phase-1 view of the aliased region
   static constexpr int LJ = ABt;             // 4 x LEGJ_SIZE (824)
   static constexpr int J1 = LJ + 4 * LEGJ_SIZE;  // [29][9]
@@ -133,7 +135,8 @@ struct LqLds {
   static constexpr int total = p1_end > tail_end ? p1_end : tail_end;
 };
 static_assert(LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are still being read");
-static_assert(LqLds::Qd >= LqLds::p1_end && LqLds::ru >= LqLds::p1_end, "the reference / next state are parked in Qd / ru during phase 1");
+static_assert(LqLds::Qd + 22 <= LqLds::ABt + 528, "M | R_FF | q_x | r_u | Q-diagonal must fit over ABt");
+static_assert(LqLds::park >= LqLds::J1, "the parked states are written while the compose may still read FR / the leg values: they lie over J1 / J2, which it has finished with by then");
 static_assert(LqLds::Rjj + 100 <= LqLds::Kx, "P_j | R_jj must fit over G'G | W");
 static_assert(LqLds::total * 8 <= 16640, "k_lq: LDS per node must allow 9 workgroups per CU (13 allocation granules of 1280 B, DESIGN.md 3.1)");
 // row of CDt that holds direction d (d < 22 or d >= 34)
@@ -337,11 +340,17 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   int* ints = reinterpret_cast<int*>(lds + LqLds::ints);
   int* perm = ints;          // [10]
 
+  constexpr int LDK = LqLds::LDK;
   const double dt = in.dt;
   bool cf[HB_NC];
   const int cfm = mode_flags_uniform(in.mode, cf);  // (flags and mask in scalar registers)
   const LqP1 P1 = lq_p1(lds);
   double* xs = P1.xs; double* us = P1.us; double* fv = P1.fv; double* J1 = P1.J1; double* J2 = P1.J2;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // requested now, parked behind the compose (see lq_node): the round trip to memory is hidden under it
+  double xref_reg = 0.0, xnext_reg = 0.0;
+  if (cx.lane < 22) { xref_reg = in.xref[cx.lane]; xnext_reg = in.xnext[cx.lane]; }
+#endif
   // The model phase leaves the constraint rows in contact-point order (slot 3i + a; a contact foot's rows are its (x, y, z)
   // velocities, a swing foot's the normal row and the two xy rows).  Everything below works in the order of c_slot (xy rows by leg,
   // normal rows last): one pass over the 32 direction rows of CDt and the row values (rowval is the 33rd row), a row per lane, in
@@ -405,6 +414,9 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   for (int i = cx.lane; i < 22; i += cx.nlanes)
     xplus[i] = (i < 12) ? xs[i] + 0.5 * dt * (fv[i] + fv[12 + i]) : xs[i] + dt * us[i];
   cx.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (cx.lane < 22) { lds[LqLds::park + cx.lane] = xref_reg; lds[LqLds::park + 22 + cx.lane] = xnext_reg; }  // (ordered by the barriers of the projection)
+#endif
   HB_ABLATE_STOP(C.debug_stop == 1);
   // slot classification (uniform): contact foot = 3 equality rows (zero velocity), swing foot = 1 equality row (normal velocity,
   // slot 3i) + 2 soft rows (xy reference, slots 3i+1, 3i+2)
@@ -603,6 +615,68 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
 
   HB_ABLATE_STOP(C.debug_stop == 3);
+  // The shooting defect x+ - x_next: from here on the x+ slot holds it (read by b~ right below and by the cost phase).
+  for (int i = cx.lane; i < 22; i += cx.nlanes) xplus[i] -= xnext_at(i);
+  cx.sync();
+  // -------------------------------------------------------------- phase 3+4b: write the projected record
+  const int ntil = n_f + nz;
+  int flist = 0;  // contact feet in foot order, two bits each: projected force column block j belongs to foot (flist >> 2j) & 3
+  {
+    int cnt = 0;
+    for (int i = 0; i < HB_NC; ++i)
+      if (cf[i]) { flist |= i << (2 * cnt); ++cnt; }
+  }
+  // A~ = A + B_j Kx   and the kernel columns of B~ = B_j Z.  Momentum / base rows (0..11) on the matrix cores; the joint
+  // rows are the closed form  A~ = [0 I] + dt Kx,  B~ = dt Z  (no force columns),  b~ = defect + dt ke.
+  // One product [A~ | B_j ke | B_j Z] = [A | 0 | 0] + B_j [Kx | ke | Z]: column 22 is the dynamic part of b~, columns 23.. the
+  // kernel columns of B~ (they go behind the n_f contact-force columns of the record).
+  double* btmp = lds + LqLds::btmp;  // 12: B_j ke
+  {
+    WaveTile<1, 2> ta;
+    tile_init(cx, ta, 12, 22, [ABt](int row, int c) { return ABt[c * 12 + row]; });
+    tile_mma<12, 12, true, LDK, false, 10>(cx, ta, ABt + 34 * 12, Kx, 12, LDK);
+    tile_store_rm_cols<REC_LD>(cx, ta, 12, 0, 22, rec + rec_A(0, 0));
+    tile_store_rm_cols<1>(cx, ta, 12, 22, 23, btmp - 22);
+    tile_store_rm_cols<REC_LD>(cx, ta, 12, 23, 23 + nz, rec + rec_A(0, 0) + n_f);
+  }
+  // joint rows of A~ and the recovery copy of Kx: one row per (uniform) step, one column per lane
+  for (int c = cx.lane; c < 22; c += cx.nlanes) {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const double kx = Kx[j * LDK + c];
+      rec[rec_A(12 + j, c)] = (c == 12 + j ? 1.0 : 0.0) + dt * kx;
+      rec[REC_KX + j * 22 + c] = kx;
+    }
+  }
+  cx.sync();
+  HB_ABLATE_STOP(C.debug_stop == 30);
+  // B~ columns: contact forces (foot order) first, zero padding after the kernel directions; one column per (uniform)
+  // step, one row per lane (the kernel columns of rows 0..11 came from the tile above)
+  for (int row = cx.lane; row < 22; row += cx.nlanes) {
+#pragma unroll
+    for (int col = 0; col < NU_T; ++col) {
+      if (col < n_f) {
+        const int foot = (flist >> (2 * (col / 3))) & 3;  // force index of the (col/3)-th contact foot
+        rec[rec_B(row, col)] = row < 12 ? ABt[(22 + 3 * foot + col % 3) * 12 + row] : 0.0;
+      } else if (col >= ntil) {
+        rec[rec_B(row, col)] = 0.0;
+      } else if (row >= 12) {
+        rec[rec_B(row, col)] = dt * Z[(row - 12) * LDK + col - n_f];
+      }
+    }
+    double s = xplus[row];  // the shooting defect of this row
+    if (row >= 12) rec[REC_DQ + row - 12] = s;
+    if (row < 12) {
+      s += btmp[row];
+      for (int i = 0; i < HB_NC; ++i)
+        if (!cf[i])
+          for (int a = 0; a < 3; ++a) s -= ABt[(22 + 3 * i + a) * 12 + row] * us[3 * i + a];
+    } else {
+      s += dt * Kx[(row - 12) * LDK + 22];
+    }
+    rec[rec_b(row)] = s;
+  }
+  HB_ABLATE_STOP(C.debug_stop == 31);
   // -------------------------------------------------------------- phase 4a: cost pieces, one "role" per lane
   // roles 0..21 state entries, 22..43 input entries, 44..55 constraint slots, 56..59 friction barrier values.
   // Partial sums (cost, defect^2, equality^2) are reduced through LDS (scratch aliases Mm, not live yet).
@@ -641,8 +715,6 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       if (cf[i]) shift_sum += -coneb[12 * i + 8] * C.friction_shift;
     for (int role = cx.lane; role < 64; role += cx.nlanes) {
       double pc = 0, pd = 0, pe = 0;
-      // (device: x_next is parked in the ru buffer, which the input roles below overwrite — read it before any role writes)
-      const double xnext_i = role < 22 ? xnext_at(role) : 0.0;
       // two-sided relaxed barrier of this role, evaluated once on a common path (joint position limits, F_z limits,
       // joint velocity limits): value, first and second derivative sums
       double bval = 0.0, bd1 = 0.0, bd2 = 0.0;
@@ -683,9 +755,8 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         }
         Qd[i] = qd_;
         qx[i] = qg;
-        const double dd = xplus[i] - xnext_i;
+        const double dd = xplus[i];  // the shooting defect (formed behind the projection)
         pd += dd * dd;
-        xplus[i] = dd;  // from here on the slot holds the shooting defect x+ - x_next (b~ below is its only other reader)
       } else if (role < 34) {
         const int m = role - 22, foot = m / 3, a = m % 3;
         const double du = us[m] - ((a == 2 && cf[foot]) ? fz_nom : 0.0);
@@ -783,7 +854,6 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   cx.sync();
   // [M | r_j + R_jj ke | R_jj Z] = [P_j | r_j | 0] + R_jj [Kx | ke | Z]   (10 x 29, one product)
-  constexpr int LDK = LqLds::LDK;
   {
     WaveTile<1, 2> tm;
     tile_init(cx, tm, 10, 23, [Pj, ru](int k, int c) { return c < 22 ? Pj[k * 22 + c] : ru[12 + k]; });
@@ -793,65 +863,6 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   cx.sync();
 
   HB_ABLATE_STOP(C.debug_stop == 5);
-  // -------------------------------------------------------------- phase 3+4b: write the projected record
-  const int ntil = n_f + nz;
-  int flist = 0;  // contact feet in foot order, two bits each: projected force column block j belongs to foot (flist >> 2j) & 3
-  {
-    int cnt = 0;
-    for (int i = 0; i < HB_NC; ++i)
-      if (cf[i]) { flist |= i << (2 * cnt); ++cnt; }
-  }
-  // A~ = A + B_j Kx   and the kernel columns of B~ = B_j Z.  Momentum / base rows (0..11) on the matrix cores; the joint
-  // rows are the closed form  A~ = [0 I] + dt Kx,  B~ = dt Z  (no force columns),  b~ = defect + dt ke.
-  // One product [A~ | B_j ke | B_j Z] = [A | 0 | 0] + B_j [Kx | ke | Z]: column 22 is the dynamic part of b~, columns 23.. the
-  // kernel columns of B~ (they go behind the n_f contact-force columns of the record).
-  double* btmp = lds + LqLds::btmp;  // 12: B_j ke
-  {
-    WaveTile<1, 2> ta;
-    tile_init(cx, ta, 12, 22, [ABt](int row, int c) { return ABt[c * 12 + row]; });
-    tile_mma<12, 12, true, LDK, false, 10>(cx, ta, ABt + 34 * 12, Kx, 12, LDK);
-    tile_store_rm_cols<REC_LD>(cx, ta, 12, 0, 22, rec + rec_A(0, 0));
-    tile_store_rm_cols<1>(cx, ta, 12, 22, 23, btmp - 22);
-    tile_store_rm_cols<REC_LD>(cx, ta, 12, 23, 23 + nz, rec + rec_A(0, 0) + n_f);
-  }
-  // joint rows of A~ and the recovery copy of Kx: one row per (uniform) step, one column per lane
-  for (int c = cx.lane; c < 22; c += cx.nlanes) {
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
-      const double kx = Kx[j * LDK + c];
-      rec[rec_A(12 + j, c)] = (c == 12 + j ? 1.0 : 0.0) + dt * kx;
-      rec[REC_KX + j * 22 + c] = kx;
-    }
-  }
-  cx.sync();
-  HB_ABLATE_STOP(C.debug_stop == 30);
-  // B~ columns: contact forces (foot order) first, zero padding after the kernel directions; one column per (uniform)
-  // step, one row per lane (the kernel columns of rows 0..11 came from the tile above)
-  for (int row = cx.lane; row < 22; row += cx.nlanes) {
-#pragma unroll
-    for (int col = 0; col < NU_T; ++col) {
-      if (col < n_f) {
-        const int foot = (flist >> (2 * (col / 3))) & 3;  // force index of the (col/3)-th contact foot
-        rec[rec_B(row, col)] = row < 12 ? ABt[(22 + 3 * foot + col % 3) * 12 + row] : 0.0;
-      } else if (col >= ntil) {
-        rec[rec_B(row, col)] = 0.0;
-      } else if (row >= 12) {
-        rec[rec_B(row, col)] = dt * Z[(row - 12) * LDK + col - n_f];
-      }
-    }
-    double s = xplus[row];  // the shooting defect of this row (stored by the cost phase)
-    if (row >= 12) rec[REC_DQ + row - 12] = s;
-    if (row < 12) {
-      s += btmp[row];
-      for (int i = 0; i < HB_NC; ++i)
-        if (!cf[i])
-          for (int a = 0; a < 3; ++a) s -= ABt[(22 + 3 * i + a) * 12 + row] * us[3 * i + a];
-    } else {
-      s += dt * Kx[(row - 12) * LDK + 22];
-    }
-    rec[rec_b(row)] = s;
-  }
-  HB_ABLATE_STOP(C.debug_stop == 31);
   // Q~ = Q + Kx' M + P_j' Kx ,  Q = diag(Qd) + w sum_soft c c'      (three accumulating GEMMs on the matrix cores)
   // Q~ is symmetric up to rounding: only its upper block triangle is formed — tiles (0,0), (0,1) and (1,1), 27 MFMAs
   // instead of 36 — and the off-diagonal tile is stored twice (k_ric_bwd mirrors the upper triangle anyway).
@@ -970,14 +981,11 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     xe[i] = in.x[i];
   }
 #if defined(__HIP_DEVICE_COMPILE__)
-  // the reference state and the next node's state wait in the Q-diagonal / input-gradient buffers, which nothing touches before
-  // the cost phase (there lane i reads entry i of both, then overwrites them; the defect x+ - x_next it forms stays in the x+
-  // slot for b~): no register is held across the model phase and the projection for them
-  double* xref_lds = lds + LqLds::Qd;
-  double* xnext_lds = lds + LqLds::ru;
-  if (cx.lane < 22) { xref_lds[cx.lane] = in.xref[cx.lane]; xnext_lds[cx.lane] = in.xnext[cx.lane]; }
-  auto xref_at = [xref_lds](int i) { return xref_lds[i]; };
-  auto xnext_at = [xnext_lds](int i) { return xnext_lds[i]; };
+  // the reference state and the next node's state are fetched by lq_tail while its compose runs and wait in LqLds::park (over the
+  // Jacobian buffers, dead by then): the model phase holds no register and no LDS for them
+  const double* park_lds = lds + LqLds::park;
+  auto xref_at = [park_lds](int i) { return park_lds[i]; };
+  auto xnext_at = [park_lds](int i) { return park_lds[22 + i]; };
 #else
   auto xref_at = [&in](int i) { return in.xref[i]; };
   auto xnext_at = [&in](int i) { return in.xnext[i]; };

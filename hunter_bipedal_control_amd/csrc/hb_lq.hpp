@@ -128,10 +128,24 @@ struct LqLds {
   static constexpr int LJ = ABt;             // 4 x LEGJ_SIZE (824)
   static constexpr int J1 = LJ + 4 * LEGJ_SIZE;  // [29][9]
   static constexpr int J2 = J1 + 29 * 9;     // [29][9]
-  static constexpr int FR = J2 + 29 * 9;     // 2 x 12: (contact point - COM) at the two points
-  static constexpr int LV = FR + 24;         // 2 points x 2 legs x 27 leg values
-  static constexpr int SC = LV + 108;        // 2 x 6: sin / cos of the ZYX angles at the two RK2 points
+  static constexpr int LVS = 21, LVP = 2 * LVS;   // leg values per (point, leg) — compact form, hb_model.hpp LegLayout — and per point
+  static constexpr int LV = J2 + 29 * 9;     // 2 points x 2 legs x 21 leg values
+#if defined(__HIP_DEVICE_COMPILE__)
+  // One wavefront in lockstep: a buffer may be overwritten by ONE lane's result as soon as every lane has read it, in program order.
+  //   FR (contact point - COM, 3 doubles per point and contact, written by the lane of direction 0) lands on the velocity of that
+  //   contact point among the leg values, which every lane has read at the top of the same loop iteration;
+  //   SC (sin / cos of the ZYX angles of both points) sits in the second half of fv, which receives the flow-map values of the
+  //   second point at the very end of the directional pass.
+  static constexpr int p1_end = LV + 2 * LVP;
+  static constexpr int SC = fv + 12;
+  HB_HD static constexpr int fr_slot(int pt, int i) { return LV + pt * LVP + (i & 1) * LVS + 15 + 3 * (i >> 1); }
+#else
+  // (the host emulator runs the lanes one after the other: separate buffers)
+  static constexpr int FRh = LV + 2 * LVP;   // 2 x 12
+  static constexpr int SC = FRh + 24;        // 2 x 6
   static constexpr int p1_end = SC + 12;
+  HB_HD static constexpr int fr_slot(int pt, int i) { return FRh + 12 * pt + 3 * i; }
+#endif
   static constexpr int total = p1_end > tail_end ? p1_end : tail_end;
 };
 static_assert(LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are still being read");
@@ -162,6 +176,9 @@ HB_HD bool slot_is_soft(int s, int cfm) { return !slot_normal(s) && !((cfm >> sl
 struct EqStepLive { int cfm; HB_HD bool operator()(int j) const { return j == 2 || ((cfm >> j) & 5) != 0; } };
 struct SoftStepLive { int cfm; HB_HD bool operator()(int j) const { return j != 2 && ((~cfm >> j) & 5) != 0; } };
 
+// leg values of k_lq: compact (LqLds::LVS per leg)
+HB_HD LegLayout lq_leg_layout() { LegLayout l; l.compact = true; return l; }
+
 struct NodeIn {
   const double* x;      // 22
   const double* u;      // 22
@@ -174,7 +191,7 @@ struct NodeIn {
 
 // Pointers into the phase-1 view of one node's LDS region (LqLds).
 struct LqP1 {
-  double *xs, *us, *xe, *fv, *FR, *LV_all, *SC, *J1, *J2, *CDt, *rowval, *LJ_all;
+  double *xs, *us, *xe, *fv, *LV_all, *SC, *J1, *J2, *CDt, *rowval, *LJ_all;
 };
 HB_HD LqP1 lq_p1(double* lds) {
   LqP1 p;
@@ -182,7 +199,6 @@ HB_HD LqP1 lq_p1(double* lds) {
   p.us = lds + LqLds::us;
   p.xe = lds + LqLds::xe;
   p.fv = lds + LqLds::fv;
-  p.FR = lds + LqLds::FR;
   p.LV_all = lds + LqLds::LV;
   p.SC = lds + LqLds::SC;
   p.J1 = lds + LqLds::J1;   // rows 3..11 of d f / d direction at point 1 (see LqLds)
@@ -200,7 +216,7 @@ HB_HD LqP1 lq_p1(double* lds) {
 // value pre-pass: its first-point pass delivers f(x, u) itself).
 HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int mode, const double* swing, int pt, int ti, bool first_point_values) {
   const LqP1 P = lq_p1(lds);
-  double* xs = P.xs; double* us = P.us; double* xe = P.xe; double* fv = P.fv; double* FR = P.FR; double* LV_all = P.LV_all;
+  double* xs = P.xs; double* us = P.us; double* xe = P.xe; double* fv = P.fv; double* LV_all = P.LV_all;
   double* SC = P.SC; double* CDt = P.CDt; double* rowval = P.rowval;
   double* LJ_all = P.LJ_all;
   bool cf[HB_NC];
@@ -208,7 +224,7 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
   const int dir = ti < 6 ? ti : (ti < 19 ? ti + 3 : ti + 15);
   double* Jp = (pt == 0 ? P.J1 : P.J2) + j_row(dir) * 9;  // this direction's row: d f(rows 3..11), columns j_col
   const double* LJ = LJ_all + pt * 2 * LEGJ_SIZE;
-  const double* LV = LV_all + pt * 54;
+  const double* LV = LV_all + pt * LqLds::LVP;
   const double* xb = pt == 0 ? xs : xe;
   {
     // which leg tangent (if any) feeds this direction
@@ -226,7 +242,7 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
 #pragma unroll
       for (int e = 0; e < 15; ++e) t[e] = 0.0;
     }
-    auto S = [LV, &t](int e) { return Dual1(LV[e] + LV[27 + e], t[e]); };
+    auto S = [LV, &t](int e) { return Dual1(LV[e] + LV[LqLds::LVS + e], t[e]); };
     CentroidalCore<Dual1> core;
     {
       Dual1 zyx[3], hn[6];
@@ -248,17 +264,18 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
 #pragma unroll 1
     for (int i = 0; i < HB_NC; ++i) {
       const int leg = i & 1, f = i >> 1;
-      const double* v = LV + leg * 27 + 15 + 3 * f;
+      const double* vp = LJ + leg * LEGJ_SIZE + LEGJ_FEET + 3 * f;    // contact-point position (leg block)
+      const double* vv = LV + leg * LqLds::LVS + 15 + 3 * f;          // its velocity (leg values)
       Vec3<double> tp, tv;
       if (tl == leg) leg_tangent_foot(LJs, ts % 5, ts >= 5, f, tp, tv);
-      const Vec3<Dual1> fb{Dual1(v[0], tp.x), Dual1(v[1], tp.y), Dual1(v[2], tp.z)};
-      const Vec3<Dual1> vb{Dual1(v[6], tv.x), Dual1(v[7], tv.y), Dual1(v[8], tv.z)};
+      const Vec3<Dual1> fb{Dual1(vp[0], tp.x), Dual1(vp[1], tp.y), Dual1(vp[2], tp.z)};
+      const Vec3<Dual1> vb{Dual1(vv[0], tv.x), Dual1(vv[1], tv.y), Dual1(vv[2], tv.z)};
       Vec3<Dual1> fr, fvel;
       centroidal_foot<Dual1>(core, fb, vb, fr, fvel);
       const Vec3<Dual1> rr = fr - core.com_rel;
       const Vec3<Dual1> F{Dual1(us[3 * i]), Dual1(us[3 * i + 1]), Dual1(us[3 * i + 2])};
       ms = ms + cross(rr, F);
-      if (dir == 0) { FR[12 * pt + 3 * i] = rr.x.v; FR[12 * pt + 3 * i + 1] = rr.y.v; FR[12 * pt + 3 * i + 2] = rr.z.v; }
+      if (dir == 0) { double* fr_out = lds + LqLds::fr_slot(pt, i); fr_out[0] = rr.x.v; fr_out[1] = rr.y.v; fr_out[2] = rr.z.v; }  // (LqLds: over this contact's velocity)
       if (pt == 0) {
         // constraint rows: slot 3i+a  (base position enters only through the closed-form lanes below)
         const Dual1 pz = Dual1(xs[8]) + fr.z;
@@ -374,7 +391,6 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   // (sum F / m - g at both points) and the base-position directions are closed form
   {
     const double inv_m = rcp_t(M.total_mass);
-    const double* FR = P1.FR;
     WaveTile<2, 1> tl;
     tile_init(cx, tl, 29, 9, [J2](int r, int c) { return r >= 19 ? J2[(r - 10) * 9 + c] : 0.0; });  // joint-rate direction 34 + j: row of joint 12 + j
     tile_mma<8, 9, false, 9, false, 6>(cx, tl, J1, J2 + 27, 29, 9);
@@ -389,7 +405,8 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         double g1[3], g2[3];  // (r x e_a) / m at the two points
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-          const double rx = FR[12 * pt + 3 * j], ry = FR[12 * pt + 3 * j + 1], rz = FR[12 * pt + 3 * j + 2];
+          const double* fr_in = lds + LqLds::fr_slot(pt, j);
+          const double rx = fr_in[0], ry = fr_in[1], rz = fr_in[2];
           double* g = pt == 0 ? g1 : g2;
           g[0] = (a == 1 ? -rz : (a == 2 ? ry : 0.0)) * inv_m;
           g[1] = (a == 0 ? rz : (a == 2 ? -rx : 0.0)) * inv_m;
@@ -1001,7 +1018,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* LJ_all = lds + LqLds::LJ;  // 4 x LEGJ_SIZE; its head is overwritten by ABt in the final compose
   leg_value_pass_coop(cx, M, 4, [](int g) { return g & 1; },
                       [xs, us, dt](int g, int j) { return xs[12 + j] + ((g >> 1) ? dt : 0.0) * us[12 + j]; },
-                      [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all, 3, [xs](int i) { return xs[9 + i]; }, SC);
+                      [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all, 3, [xs](int i) { return xs[9 + i]; }, SC, lq_leg_layout());
   HB_ABLATE_STOP(C.debug_stop == 6);
   // ---- value of the flow map at the first RK2 point (plain doubles): the second point x + dt f(x, u) must be known before
   // its directional pass can start, and a value-only evaluation costs well under half a dual pass.  Device: four lanes run
@@ -1010,7 +1027,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
 #if defined(__HIP_DEVICE_COMPILE__)
   if (cx.lane < 4) {
     const double* LV = LV_all;
-    auto S = [LV](int e) { return LV[e] + LV[27 + e]; };
+    auto S = [LV](int e) { return LV[e] + LV[LqLds::LVS + e]; };
     CentroidalCore<double> core;
     Sym3<double> IOs;
     IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
@@ -1019,9 +1036,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     // (keeps the compiler from clustering the LDS reads of the whole value pass up front: that alone cost 20 registers)
     asm volatile("" ::: "memory");
     const int i = cx.lane;
-    const double* v = LV + (i & 1) * 27 + 15 + 3 * (i >> 1);
     Vec3<double> fr, fvel;
-    centroidal_foot<double>(core, ld3(v), ld3(v + 6), fr, fvel);
+    centroidal_foot<double>(core, ld3(LJ_all + (i & 1) * LEGJ_SIZE + LEGJ_FEET + 3 * (i >> 1)), ld3(LV + (i & 1) * LqLds::LVS + 15 + 3 * (i >> 1)), fr, fvel);
     const Vec3<double> F(us[3 * i], us[3 * i + 1], us[3 * i + 2]);
     const Vec3<double> mi = cross(fr - core.com_rel, F);
     const double msx = quad_sum_f64(mi.x), msy = quad_sum_f64(mi.y), msz = quad_sum_f64(mi.z);
@@ -1042,7 +1058,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
 #else
   for (int l = cx.lane; l < 1; l += cx.nlanes) {
     const double* LV = LV_all;
-    auto S = [LV](int e) { return LV[e] + LV[27 + e]; };
+    auto S = [LV](int e) { return LV[e] + LV[LqLds::LVS + e]; };
     CentroidalCore<double> core;
     Sym3<double> IOs;
     IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
@@ -1051,9 +1067,8 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     Vec3<double> msum;
     double fsx = 0, fsy = 0, fsz = 0;
     for (int i = 0; i < HB_NC; ++i) {
-      const double* v = LV + (i & 1) * 27 + 15 + 3 * (i >> 1);
       Vec3<double> fr, fvel;
-      centroidal_foot<double>(core, ld3(v), ld3(v + 6), fr, fvel);
+      centroidal_foot<double>(core, ld3(LJ_all + (i & 1) * LEGJ_SIZE + LEGJ_FEET + 3 * (i >> 1)), ld3(LV + (i & 1) * LqLds::LVS + 15 + 3 * (i >> 1)), fr, fvel);
       const Vec3<double> F(us[3 * i], us[3 * i + 1], us[3 * i + 2]);
       msum = msum + cross(fr - core.com_rel, F);
       fsx += F.x; fsy += F.y; fsz += F.z;

@@ -240,10 +240,14 @@ HB_HD void leg_value_pass(const DevModel& M, int leg, QF qj, QDF qdj, double* bl
 struct NoExtraAngles { HB_HD double operator()(int) const { return 0.0; } };
 // Where group g keeps its data when the groups of one call belong to several nodes (k_lq works on node pairs): groups
 // [n gpb, (n + 1) gpb) live `hi` doubles behind those of node n - 1; `xpn` extra angles per node, their (sin, cos) pairs likewise.
+// `compact`: the contact-point positions are not repeated among the leg values (they stay in the leg block, LEGJ_FEET): a leg then
+// has 21 values — [mc 3 | IO 6 | lin 3 | ang 3 | contact-point velocities 2 x 3] — instead of 27.
 struct LegLayout {
   int gpb = 1 << 20, hi = 0, xpn = 1 << 20;
+  bool compact = false;
+  HB_HD int nval() const { return compact ? 21 : 27; }
   HB_HD int blk(int g) const { return (g / gpb) * hi + (g % gpb) * LEGJ_SIZE; }
-  HB_HD int val(int g) const { return (g / gpb) * hi + (g % gpb) * 27; }
+  HB_HD int val(int g) const { return (g / gpb) * hi + (g % gpb) * nval(); }
   HB_HD int xsc(int i) const { return (i / xpn) * hi + 2 * (i % xpn); }
 };
 template <class Ctx, class LEG, class QF, class QDF, class XA = NoExtraAngles>
@@ -354,7 +358,8 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
       if (dk == 0) {
         double* val = val_all + lay.val(g);
         st3(val + 0, mc); st6(val + 3, IO); st3(val + 9, lin); st3(val + 12, ang);
-        st3(val + 15, p0); st3(val + 18, p1); st3(val + 21, v0); st3(val + 24, v1);
+        if (lay.compact) { st3(val + 15, v0); st3(val + 18, v1); }
+        else { st3(val + 15, p0); st3(val + 18, p1); st3(val + 21, v0); st3(val + 24, v1); }
       }
     }
     cx.sync();
@@ -487,7 +492,8 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
     if (k == 0) {
       double* val = val_all + lay.val(g);
       st3(val + 0, ld3(B + LEGJ_MC)); st6(val + 3, ld6(B + LEGJ_IO)); st3(val + 9, lin); st3(val + 12, ang);
-      st3(val + 15, p0); st3(val + 18, p1); st3(val + 21, v0); st3(val + 24, v1);
+      if (lay.compact) { st3(val + 15, v0); st3(val + 18, v1); }
+      else { st3(val + 15, p0); st3(val + 18, p1); st3(val + 21, v0); st3(val + 24, v1); }
     }
   }
   cx.sync();

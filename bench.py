@@ -149,6 +149,7 @@ def config1_latency(params, device, n_list=(54, 100), reps=250):
             out[f"N{N}"] = {"ticks": reps, "mpc_calls_over_budget": int((np.array(t_mpc) > 10.0).sum()),
                             "wbc_ticks_over_budget": int((np.array(t_wbc) > 2.0).sum()),
                             "mpc_ms_median": float(np.median(t_mpc)), "mpc_ms_p99": float(np.percentile(t_mpc, 99)), "mpc_ms_max": float(np.max(t_mpc)),
+                            "mpc_ms_max_at_tick": int(np.argmax(t_mpc)),
                             "wbc_tick_ms_median": float(np.median(t_wbc)), "wbc_tick_ms_p99": float(np.percentile(t_wbc, 99)),
                             "wbc_tick_ms_max": float(np.max(t_wbc))}
         finally:

@@ -80,8 +80,7 @@ struct RelaxedBarrierD {
   HB_HD double d2(double h) const { const double r = rcp_t(h > delta ? h : delta); return mu * r * r; }
 };
 
-// LDS carve (doubles).  At most 2048 doubles = 16 384 B per node -> 10 single-wave workgroups per CU (k_lq runs faster
-// with every additional resident wavefront, DESIGN.md 3.1, so every double here is throughput).
+// LDS carve (doubles).  k_lq runs faster with every additional resident wavefront, so every double here is throughput.
 //   fixed:     CDt [32][12] (constraint-row derivatives; the 12 contact-force directions are identically zero and are not
 //              stored: direction d < 22 -> row d, joint-rate direction 34 + k -> row 22 + k), rowval, xs, us, fv (later the
 //              scalars of the cost phase), and xe: the state of the second RK2 point during phase 1, x+ afterwards
@@ -96,7 +95,10 @@ struct RelaxedBarrierD {
 //   compose:   ABt [44][12] over the head of LJ.  Only rows 0..11 of x+ are stored; the joint rows q+ = q + dt qd are
 //              the closed form  d q+_j / d dir = [dir == 12 + j] + dt [dir == 34 + j]  and are expanded where used
 //   phase 2+:  every later buffer aliases the rest of the phase-1 region (dead after the compose); P_j and R_jj (written
-//              after the projection) lie over G'G and G'[C e] (dead after the projection)
+//              after the projection) lie over G'G and G'[C e] (dead after the projection); A~, B~ and b~ are written right behind
+//              the projection, so M and the cost-phase vectors lie over ABt (dead from there on)
+// 1916 doubles = 15 328 B: ten single-wave workgroups per CU (the allocation granule is 1280 B).  The model phase (486 + 4 leg
+// blocks 824 + J1 | J2 522 + leg values 84) sets the size; the tail needs 1694.
 struct LqLds {
   static constexpr int CDt = 0;              // [32][12]
   static constexpr int rowval = CDt + 384;   // 12
@@ -152,7 +154,9 @@ static_assert(LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are s
 static_assert(LqLds::Qd + 22 <= LqLds::ABt + 528, "M | R_FF | q_x | r_u | Q-diagonal must fit over ABt");
 static_assert(LqLds::park >= LqLds::J1, "the parked states are written while the compose may still read FR / the leg values: they lie over J1 / J2, which it has finished with by then");
 static_assert(LqLds::Rjj + 100 <= LqLds::Kx, "P_j | R_jj must fit over G'G | W");
-static_assert(LqLds::total * 8 <= 16640, "k_lq: LDS per node must allow 9 workgroups per CU (13 allocation granules of 1280 B, DESIGN.md 3.1)");
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host emulator keeps FR / SC apart, see LqLds)
+static_assert(LqLds::total * 8 <= 15360, "k_lq: LDS per node must allow 10 workgroups per CU (12 allocation granules of 1280 B, DESIGN.md 3.1)");
+#endif
 // row of CDt that holds direction d (d < 22 or d >= 34)
 HB_HD int cd_row(int dir) { return dir < 22 ? dir : dir - 12; }
 // row of J1 / J2 that holds direction d (momentum 0..5, zyx 9..11, joints 12..21, joint rates 34..43) and its inverse

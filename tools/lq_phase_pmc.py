@@ -6,8 +6,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 from pmc_summary import per_kernel
 
 ORDER = [(10, "loads"), (6, "leg value pass"), (7, "value pre-pass"), (9, "direction pass"), (1, "compose"), (2, "Gram + pivoted Cholesky"),
-         (3, "solves"), (4, "cost"), (5, "soft rows, Pj, M"), (30, "A~ B~ tiles"), (31, "B~ columns, b~"), (32, "Q~"), (33, "q~ P~"),
-         (34, "R~ r~"), (0, "recovery data, end")]
+         (3, "solves"), (30, "defect, A~ B~ tiles"), (31, "B~ columns, b~"), (4, "cost"), (5, "soft rows, Pj, M"), (32, "Q~ q~"), (33, "P~ r~"),
+         (34, "R~"), (0, "recovery data, end")]   # (code order: A~ / B~ / b~ are formed right behind the projection)
 root = Path(sys.argv[1])
 prev = None
 print(f"{'phase':26s} {'us':>8s} {'VALU':>7s} {'SALU':>7s} {'LDS':>6s} {'kcyc/wave':>10s} {'stall%':>7s} {'wait%':>6s}   (increments; counters per wavefront)")

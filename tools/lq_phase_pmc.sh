@@ -6,7 +6,7 @@ tag=${1:-r03}; out=$PWD/gpurun_out/$tag/lqpmc; mkdir -p $out
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp
-for stop in 10 6 7 9 1 2 3 4 5 30 31 32 33 34 0; do
+for stop in 10 6 7 9 1 2 3 30 31 4 5 32 33 34 0; do
   timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $out/s$stop -o p -- \
     python $R/tools/perf_quick.py --lib $R/variants/libhunter_hip_ablate.so --stop $stop > $out/s$stop.log 2>&1
 done

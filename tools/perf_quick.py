@@ -61,7 +61,7 @@ if args.chunks > 1:
     run(steps=3)  # throwaway context: the first context of a process overlaps its chunk streams worse
 print(json.dumps(dict(lib=args.lib or "default", **run(steps=max(args.steps, 30 * 4096 // B)))))
 if args.ablate_lq:
-    for stop in (10, 6, 7, 9, 1, 2, 3, 4, 5, 30, 31, 32, 33, 34):
+    for stop in (10, 6, 7, 9, 1, 2, 3, 30, 31, 4, 5, 32, 33, 34):  # (code order)
         r = run(stop, steps=5)
         print(json.dumps(dict(stop=stop, ms_lq=r["ms_lq"])))
 if args.ablate_ric:

@@ -97,8 +97,9 @@ struct RelaxedBarrierD {
 //   phase 2+:  every later buffer aliases the rest of the phase-1 region (dead after the compose); P_j and R_jj (written
 //              after the projection) lie over G'G and G'[C e] (dead after the projection); A~, B~ and b~ are written right behind
 //              the projection, so M and the cost-phase vectors lie over ABt (dead from there on)
-// 1916 doubles = 15 328 B: ten single-wave workgroups per CU (the allocation granule is 1280 B).  The model phase (486 + 4 leg
-// blocks 824 + J1 | J2 522 + leg values 84) sets the size; the tail needs 1694.
+// 1694 doubles = 13 552 B: ELEVEN single-wave workgroups per CU (the allocation granule is 1280 B: 11 x 14 080 B).  The tail sets
+// the size (486 + ABt 528 + G'G | W 330 + [Kx | ke | Z] 290 + ints 16 + parked states 44); the model phase needs 1620 (486 + 4 leg
+// blocks 824, J1 | J2 522 of which 296 inside the leg blocks, leg values 84).
 struct LqLds {
   static constexpr int CDt = 0;              // [32][12]
   static constexpr int rowval = CDt + 384;   // 12
@@ -128,7 +129,14 @@ struct LqLds {
   static constexpr int Qd = ru + 22;         // 22 diagonal of Q incl. barriers/shift
   // phase-1 view of the aliased region
   static constexpr int LJ = ABt;             // 4 x LEGJ_SIZE (824)
-  static constexpr int J1 = LJ + 4 * LEGJ_SIZE;  // [29][9]
+#if defined(__HIP_DEVICE_COMPILE__)
+  // The Jacobian rows are the LAST thing a direction task writes (after its last read of the leg blocks), and the wavefront runs its
+  // tasks in lockstep: J1 | J2 start inside the leg blocks, right behind the part that ABt will cover (the compose reads J while it
+  // writes ABt).  296 of their 522 doubles cost no LDS.
+  static constexpr int J1 = ABt + 528;       // [29][9]
+#else
+  static constexpr int J1 = LJ + 4 * LEGJ_SIZE;  // [29][9]  (the host emulator runs the tasks one after the other: separate buffers)
+#endif
   static constexpr int J2 = J1 + 29 * 9;     // [29][9]
   static constexpr int LVS = 21, LVP = 2 * LVS;   // leg values per (point, leg) — compact form, hb_model.hpp LegLayout — and per point
   static constexpr int LV = J2 + 29 * 9;     // 2 points x 2 legs x 21 leg values
@@ -155,7 +163,7 @@ static_assert(LqLds::Qd + 22 <= LqLds::ABt + 528, "M | R_FF | q_x | r_u | Q-diag
 static_assert(LqLds::park >= LqLds::J1, "the parked states are written while the compose may still read FR / the leg values: they lie over J1 / J2, which it has finished with by then");
 static_assert(LqLds::Rjj + 100 <= LqLds::Kx, "P_j | R_jj must fit over G'G | W");
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host emulator keeps FR / SC apart, see LqLds)
-static_assert(LqLds::total * 8 <= 15360, "k_lq: LDS per node must allow 10 workgroups per CU (12 allocation granules of 1280 B, DESIGN.md 3.1)");
+static_assert(LqLds::total * 8 <= 14080, "k_lq: LDS per node must allow 11 workgroups per CU (11 allocation granules of 1280 B, DESIGN.md 3.1)");
 #endif
 // row of CDt that holds direction d (d < 22 or d >= 34)
 HB_HD int cd_row(int dir) { return dir < 22 ? dir : dir - 12; }
@@ -259,9 +267,9 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
       centroidal_core<Dual1>(M, Vec3<Dual1>(S(0), S(1), S(2)), IOs, Vec3<Dual1>(S(9), S(10), S(11)),
                              Vec3<Dual1>(S(12), S(13), S(14)), zyx, hn, core, SC + 6 * pt);
     }
-    // the base-velocity rows of this direction are final: out of the registers before the contact loop
-#pragma unroll
-    for (int i = 0; i < 3; ++i) Jp[3 + i] = comp(core.euler_rate, i).d;
+    // (the euler-rate derivatives are final here, but they are stored with the rest at the end: the row may lie over leg blocks the
+    // contact loop below still reads, LqLds::J1)
+    const Vec3<double> euler_rate_d(core.euler_rate.x.d, core.euler_rate.y.d, core.euler_rate.z.d);
     const Vec3<double> euler_rate_v(core.euler_rate.x.v, core.euler_rate.y.v, core.euler_rate.z.v);
     // contact points one at a time (rolled loop keeps the register footprint small)
     Vec3<Dual1> ms;
@@ -310,7 +318,7 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
     const Dual1 f[12] = {Dual1(0.0), Dual1(0.0), Dual1(0.0), inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
                          core.v_lin.x, core.v_lin.y, core.v_lin.z, Dual1(euler_rate_v.x), Dual1(euler_rate_v.y), Dual1(euler_rate_v.z)};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { Jp[i] = f[3 + i].d; Jp[6 + i] = f[6 + i].d; }
+    for (int i = 0; i < 3; ++i) { Jp[i] = f[3 + i].d; Jp[3 + i] = comp(euler_rate_d, i); Jp[6 + i] = f[6 + i].d; }
     if (dir == 0 && (pt == 1 || first_point_values)) {  // values of this point (single-node form: the first point's come from the pre-pass)
       double fsx = 0, fsy = 0, fsz = 0;
       for (int i = 0; i < HB_NC; ++i) { fsx += us[3 * i]; fsy += us[3 * i + 1]; fsz += us[3 * i + 2]; }

@@ -110,23 +110,25 @@ struct LqLds {
   static constexpr int xe = fv + 24;         // 22
   static constexpr int xplus = xe;
   static constexpr int ABt = xe + 22;        // [44][12]
-  static constexpr int GtG = ABt + 528;      // 10x10
-  static constexpr int W = GtG + 100;        // 10x23 (G'C | G'e)
-  static constexpr int Pj = GtG;             // 10x22   } over G'G | W
-  static constexpr int Rjj = Pj + 220;       // 10x10   }
+  static constexpr int W = ABt + 528;        // 10x23 (G'C | G'e)
+  static constexpr int Pj = W;               // 10x22, over W (dead after the projection)
   static constexpr int LDK = 29;             // row length of [Kx | ke | Z] and of [M | r_j + R_jj ke | R_jj Z]
   static constexpr int Kx = W + 230;         // 10 x LDK: [Kx (22) | ke | Z (6)] — one right operand for every product with the projection
   static constexpr int Z = Kx + 23;          //   (columns 23..28 of the rows of Kx)
-  static constexpr int btmp = GtG;           // 12: B_j ke (the Gram matrix is dead once it has been factorised; P_j lands there later)
+  static constexpr int GtG = Kx + 124;       // 10x10 Gram matrix: behind the factor columns (Lc | col | Linv: 124 doubles over the head of
+                                             //   Kx); it is consumed before the projection writes the rows of [Kx | ke | Z]
+  static constexpr int btmp = fv;            // 12: B_j ke (the next node's state parked there has just been consumed by the defect)
   static constexpr int ints = Kx + 10 * LDK; // 32 ints packed in 16 doubles: perm[10], rank, eq slots...
-  static constexpr int park = ints + 16;     // 44: reference state and next node's state, fetched while the compose runs (device)
-  static constexpr int tail_end = park + 44;
+  static constexpr int park = ints + 16;     // 22: the reference state, fetched while the compose runs (device)
+  static constexpr int xnext_park = fv;      // 22: the next node's state, likewise (the flow-map values are dead behind the compose)
+  static constexpr int tail_end = park + 22;
   // over ABt, which is dead once A~, B~ and b~ have been written (they are formed right behind the projection, before the cost phase):
   static constexpr int Mm = ABt;             // 10 x LDK: [M = P_j + R_jj Kx | r_j + R_jj ke | R_jj Z]
   static constexpr int RFF = Mm + 10 * LDK;  // 4 blocks 3x3
   static constexpr int qx = RFF + 36;        // 22 (continuous-time gradient wrt x)
   static constexpr int ru = qx + 22;         // 22 (wrt u)
   static constexpr int Qd = ru + 22;         // 22 diagonal of Q incl. barriers/shift
+  static constexpr int Rjj = Qd + 22;        // 10x10 (and, before it, the friction-cone data of the cost phase)
   // phase-1 view of the aliased region
   static constexpr int LJ = ABt;             // 4 x LEGJ_SIZE (824)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -159,9 +161,8 @@ struct LqLds {
   static constexpr int total = p1_end > tail_end ? p1_end : tail_end;
 };
 static_assert(LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are still being read");
-static_assert(LqLds::Qd + 22 <= LqLds::ABt + 528, "M | R_FF | q_x | r_u | Q-diagonal must fit over ABt");
-static_assert(LqLds::park >= LqLds::J1, "the parked states are written while the compose may still read FR / the leg values: they lie over J1 / J2, which it has finished with by then");
-static_assert(LqLds::Rjj + 100 <= LqLds::Kx, "P_j | R_jj must fit over G'G | W");
+static_assert(LqLds::park >= LqLds::J1, "the parked states are written behind the compose: they lie over J1 / J2 / the leg values, which it has finished with by then");
+static_assert(LqLds::Rjj + 100 <= LqLds::ABt + 528, "M | R_FF | q_x | r_u | Q-diagonal | R_jj must fit over ABt");
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host emulator keeps FR / SC apart, see LqLds)
 static_assert(LqLds::total * 8 <= 14080, "k_lq: LDS per node must allow 11 workgroups per CU (11 allocation granules of 1280 B, DESIGN.md 3.1)");
 #endif
@@ -444,7 +445,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     xplus[i] = (i < 12) ? xs[i] + 0.5 * dt * (fv[i] + fv[12 + i]) : xs[i] + dt * us[i];
   cx.sync();
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (cx.lane < 22) { lds[LqLds::park + cx.lane] = xref_reg; lds[LqLds::park + 22 + cx.lane] = xnext_reg; }  // (ordered by the barriers of the projection)
+  if (cx.lane < 22) { lds[LqLds::park + cx.lane] = xref_reg; lds[LqLds::xnext_park + cx.lane] = xnext_reg; }  // (ordered by the barriers of the projection)
 #endif
   HB_ABLATE_STOP(C.debug_stop == 1);
   // slot classification (uniform): contact foot = 3 equality rows (zero velocity), swing foot = 1 equality row (normal velocity,
@@ -1013,8 +1014,9 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   // the reference state and the next node's state are fetched by lq_tail while its compose runs and wait in LqLds::park (over the
   // Jacobian buffers, dead by then): the model phase holds no register and no LDS for them
   const double* park_lds = lds + LqLds::park;
+  const double* xnext_lds = lds + LqLds::xnext_park;
   auto xref_at = [park_lds](int i) { return park_lds[i]; };
-  auto xnext_at = [park_lds](int i) { return park_lds[22 + i]; };
+  auto xnext_at = [xnext_lds](int i) { return xnext_lds[i]; };
 #else
   auto xref_at = [&in](int i) { return in.xref[i]; };
   auto xnext_at = [&in](int i) { return in.xnext[i]; };

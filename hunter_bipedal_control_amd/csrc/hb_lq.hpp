@@ -97,9 +97,10 @@ struct RelaxedBarrierD {
 //   phase 2+:  every later buffer aliases the rest of the phase-1 region (dead after the compose); P_j and R_jj (written
 //              after the projection) lie over G'G and G'[C e] (dead after the projection); A~, B~ and b~ are written right behind
 //              the projection, so M and the cost-phase vectors lie over ABt (dead from there on)
-// 1694 doubles = 13 552 B: ELEVEN single-wave workgroups per CU (the allocation granule is 1280 B: 11 x 14 080 B).  The tail sets
-// the size (486 + ABt 528 + G'G | W 330 + [Kx | ke | Z] 290 + ints 16 + parked states 44); the model phase needs 1620 (486 + 4 leg
-// blocks 824, J1 | J2 522 of which 296 inside the leg blocks, leg values 84).
+// 1590 doubles = 12 720 B: TWELVE single-wave workgroups per CU (the allocation granule is 1280 B: 10 granules), which is also what
+// the 168 registers allow (three wavefronts per SIMD).  The model phase sets the size (486 + 4 leg blocks 824, J1 | J2 522 of which
+// 296 inside the leg blocks, leg values 54); the tail needs 1572 (486 + ABt 528 + W 230 + [Kx | ke | Z] 290 + ints 16 + parked
+// reference state 22).
 struct LqLds {
   static constexpr int CDt = 0;              // [32][12]
   static constexpr int rowval = CDt + 384;   // 12
@@ -140,8 +141,9 @@ struct LqLds {
   static constexpr int J1 = LJ + 4 * LEGJ_SIZE;  // [29][9]  (the host emulator runs the tasks one after the other: separate buffers)
 #endif
   static constexpr int J2 = J1 + 29 * 9;     // [29][9]
-  static constexpr int LVS = 21, LVP = 2 * LVS;   // leg values per (point, leg) — compact form, hb_model.hpp LegLayout — and per point
-  static constexpr int LV = J2 + 29 * 9;     // 2 points x 2 legs x 21 leg values
+  static constexpr int LVP = 27;             // leg values per evaluation point: the two legs' composites summed (15), then each leg's
+                                             //   contact-point velocities (2 x 6) — hb_model.hpp LegLayout::pair_sum
+  static constexpr int LV = J2 + 29 * 9;     // 2 points x 27
 #if defined(__HIP_DEVICE_COMPILE__)
   // One wavefront in lockstep: a buffer may be overwritten by ONE lane's result as soon as every lane has read it, in program order.
   //   FR (contact point - COM, 3 doubles per point and contact, written by the lane of direction 0) lands on the velocity of that
@@ -150,7 +152,7 @@ struct LqLds {
   //   second point at the very end of the directional pass.
   static constexpr int p1_end = LV + 2 * LVP;
   static constexpr int SC = fv + 12;
-  HB_HD static constexpr int fr_slot(int pt, int i) { return LV + pt * LVP + (i & 1) * LVS + 15 + 3 * (i >> 1); }
+  HB_HD static constexpr int fr_slot(int pt, int i) { return LV + pt * LVP + 15 + 6 * (i & 1) + 3 * (i >> 1); }
 #else
   // (the host emulator runs the lanes one after the other: separate buffers)
   static constexpr int FRh = LV + 2 * LVP;   // 2 x 12
@@ -164,7 +166,7 @@ static_assert(LqLds::J1 >= LqLds::ABt + 528, "ABt is written while J1 / J2 are s
 static_assert(LqLds::park >= LqLds::J1, "the parked states are written behind the compose: they lie over J1 / J2 / the leg values, which it has finished with by then");
 static_assert(LqLds::Rjj + 100 <= LqLds::ABt + 528, "M | R_FF | q_x | r_u | Q-diagonal | R_jj must fit over ABt");
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host emulator keeps FR / SC apart, see LqLds)
-static_assert(LqLds::total * 8 <= 14080, "k_lq: LDS per node must allow 11 workgroups per CU (11 allocation granules of 1280 B, DESIGN.md 3.1)");
+static_assert(LqLds::total * 8 <= 12800, "k_lq: LDS per node must allow 12 workgroups per CU (10 allocation granules of 1280 B, DESIGN.md 3.1)");
 #endif
 // row of CDt that holds direction d (d < 22 or d >= 34)
 HB_HD int cd_row(int dir) { return dir < 22 ? dir : dir - 12; }
@@ -189,8 +191,8 @@ HB_HD bool slot_is_soft(int s, int cfm) { return !slot_normal(s) && !((cfm >> sl
 struct EqStepLive { int cfm; HB_HD bool operator()(int j) const { return j == 2 || ((cfm >> j) & 5) != 0; } };
 struct SoftStepLive { int cfm; HB_HD bool operator()(int j) const { return j != 2 && ((~cfm >> j) & 5) != 0; } };
 
-// leg values of k_lq: compact (LqLds::LVS per leg)
-HB_HD LegLayout lq_leg_layout() { LegLayout l; l.compact = true; return l; }
+// leg values of k_lq: LqLds::LVP per evaluation point
+HB_HD LegLayout lq_leg_layout() { LegLayout l; l.compact = true; l.pair_sum = true; return l; }
 
 struct NodeIn {
   const double* x;      // 22
@@ -255,7 +257,7 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
 #pragma unroll
       for (int e = 0; e < 15; ++e) t[e] = 0.0;
     }
-    auto S = [LV, &t](int e) { return Dual1(LV[e] + LV[LqLds::LVS + e], t[e]); };
+    auto S = [LV, &t](int e) { return Dual1(LV[e], t[e]); };   // (both legs' composites arrive summed)
     CentroidalCore<Dual1> core;
     {
       Dual1 zyx[3], hn[6];
@@ -278,7 +280,7 @@ HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int 
     for (int i = 0; i < HB_NC; ++i) {
       const int leg = i & 1, f = i >> 1;
       const double* vp = LJ + leg * LEGJ_SIZE + LEGJ_FEET + 3 * f;    // contact-point position (leg block)
-      const double* vv = LV + leg * LqLds::LVS + 15 + 3 * f;          // its velocity (leg values)
+      const double* vv = LV + 15 + 6 * leg + 3 * f;                   // its velocity (leg values)
       Vec3<double> tp, tv;
       if (tl == leg) leg_tangent_foot(LJs, ts % 5, ts >= 5, f, tp, tv);
       const Vec3<Dual1> fb{Dual1(vp[0], tp.x), Dual1(vp[1], tp.y), Dual1(vp[2], tp.z)};
@@ -1041,7 +1043,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
 #if defined(__HIP_DEVICE_COMPILE__)
   if (cx.lane < 4) {
     const double* LV = LV_all;
-    auto S = [LV](int e) { return LV[e] + LV[LqLds::LVS + e]; };
+    auto S = [LV](int e) { return LV[e]; };
     CentroidalCore<double> core;
     Sym3<double> IOs;
     IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
@@ -1051,7 +1053,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     asm volatile("" ::: "memory");
     const int i = cx.lane;
     Vec3<double> fr, fvel;
-    centroidal_foot<double>(core, ld3(LJ_all + (i & 1) * LEGJ_SIZE + LEGJ_FEET + 3 * (i >> 1)), ld3(LV + (i & 1) * LqLds::LVS + 15 + 3 * (i >> 1)), fr, fvel);
+    centroidal_foot<double>(core, ld3(LJ_all + (i & 1) * LEGJ_SIZE + LEGJ_FEET + 3 * (i >> 1)), ld3(LV + 15 + 6 * (i & 1) + 3 * (i >> 1)), fr, fvel);
     const Vec3<double> F(us[3 * i], us[3 * i + 1], us[3 * i + 2]);
     const Vec3<double> mi = cross(fr - core.com_rel, F);
     const double msx = quad_sum_f64(mi.x), msy = quad_sum_f64(mi.y), msz = quad_sum_f64(mi.z);
@@ -1072,7 +1074,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
 #else
   for (int l = cx.lane; l < 1; l += cx.nlanes) {
     const double* LV = LV_all;
-    auto S = [LV](int e) { return LV[e] + LV[LqLds::LVS + e]; };
+    auto S = [LV](int e) { return LV[e]; };
     CentroidalCore<double> core;
     Sym3<double> IOs;
     IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
@@ -1082,7 +1084,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     double fsx = 0, fsy = 0, fsz = 0;
     for (int i = 0; i < HB_NC; ++i) {
       Vec3<double> fr, fvel;
-      centroidal_foot<double>(core, ld3(LJ_all + (i & 1) * LEGJ_SIZE + LEGJ_FEET + 3 * (i >> 1)), ld3(LV + (i & 1) * LqLds::LVS + 15 + 3 * (i >> 1)), fr, fvel);
+      centroidal_foot<double>(core, ld3(LJ_all + (i & 1) * LEGJ_SIZE + LEGJ_FEET + 3 * (i >> 1)), ld3(LV + 15 + 6 * (i & 1) + 3 * (i >> 1)), fr, fvel);
       const Vec3<double> F(us[3 * i], us[3 * i + 1], us[3 * i + 2]);
       msum = msum + cross(fr - core.com_rel, F);
       fsx += F.x; fsy += F.y; fsz += F.z;

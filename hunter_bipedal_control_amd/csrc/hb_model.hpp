@@ -245,9 +245,13 @@ struct NoExtraAngles { HB_HD double operator()(int) const { return 0.0; } };
 struct LegLayout {
   int gpb = 1 << 20, hi = 0, xpn = 1 << 20;
   bool compact = false;
+  // `pair_sum` (groups 2p, 2p + 1 = the two legs of evaluation point p): only the SUM of the two legs' composites is kept — the
+  // whole-body combine never needs them apart — followed by each leg's contact-point velocities: 27 values per point,
+  // [mc 3 | IO 6 | lin 3 | ang 3 (both legs) | velocities of leg 0 (2 x 3) | of leg 1].  val(g) is then the point's block.
+  bool pair_sum = false;
   HB_HD int nval() const { return compact ? 21 : 27; }
   HB_HD int blk(int g) const { return (g / gpb) * hi + (g % gpb) * LEGJ_SIZE; }
-  HB_HD int val(int g) const { return (g / gpb) * hi + (g % gpb) * nval(); }
+  HB_HD int val(int g) const { return pair_sum ? (g >> 1) * 27 : (g / gpb) * hi + (g % gpb) * nval(); }
   HB_HD int xsc(int i) const { return (i / xpn) * hi + 2 * (i % xpn); }
 };
 template <class Ctx, class LEG, class QF, class QDF, class XA = NoExtraAngles>
@@ -341,6 +345,17 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
     const Vec3<double> ang = seg8_suffix_sum(qL, sc);
     const Vec3<double> v0 = seg8_suffix_sum(q0, sc);
     const Vec3<double> v1 = seg8_suffix_sum(q1, sc);
+    // (pair_sum: the partner leg's group sits eight lanes away in the same DPP row; every lane takes part in the exchange)
+    Vec3<double> mc2 = mc, lin2 = lin, ang2 = ang;
+    Sym3<double> IO2 = IO;
+    if (lay.pair_sum) {
+      auto plus_partner = [](double v) { return v + dpp_full_f64<0x128>(v); };   // row_ror:8
+      mc2 = Vec3<double>(plus_partner(mc.x), plus_partner(mc.y), plus_partner(mc.z));
+      lin2 = Vec3<double>(plus_partner(lin.x), plus_partner(lin.y), plus_partner(lin.z));
+      ang2 = Vec3<double>(plus_partner(ang.x), plus_partner(ang.y), plus_partner(ang.z));
+      IO2.xx = plus_partner(IO.xx); IO2.xy = plus_partner(IO.xy); IO2.xz = plus_partner(IO.xz);
+      IO2.yy = plus_partner(IO.yy); IO2.yz = plus_partner(IO.yz); IO2.zz = plus_partner(IO.zz);
+    }
     if (dvalid) {
       st3(B + LEGJ_A, a);
       st3(B + LEGJ_O, o);
@@ -357,9 +372,14 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
       st3(B + LEGJ_VJ + 3, v1);
       if (dk == 0) {
         double* val = val_all + lay.val(g);
-        st3(val + 0, mc); st6(val + 3, IO); st3(val + 9, lin); st3(val + 12, ang);
-        if (lay.compact) { st3(val + 15, v0); st3(val + 18, v1); }
-        else { st3(val + 15, p0); st3(val + 18, p1); st3(val + 21, v0); st3(val + 24, v1); }
+        if (lay.pair_sum) {
+          if ((g & 1) == 0) { st3(val + 0, mc2); st6(val + 3, IO2); st3(val + 9, lin2); st3(val + 12, ang2); }
+          st3(val + 15 + 6 * (g & 1), v0); st3(val + 18 + 6 * (g & 1), v1);
+        } else {
+          st3(val + 0, mc); st6(val + 3, IO); st3(val + 9, lin); st3(val + 12, ang);
+          if (lay.compact) { st3(val + 15, v0); st3(val + 18, v1); }
+          else { st3(val + 15, p0); st3(val + 18, p1); st3(val + 21, v0); st3(val + 24, v1); }
+        }
       }
     }
     cx.sync();
@@ -491,9 +511,17 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
     st3(B + LEGJ_VJ + 3, v1);
     if (k == 0) {
       double* val = val_all + lay.val(g);
-      st3(val + 0, ld3(B + LEGJ_MC)); st6(val + 3, ld6(B + LEGJ_IO)); st3(val + 9, lin); st3(val + 12, ang);
-      if (lay.compact) { st3(val + 15, v0); st3(val + 18, v1); }
-      else { st3(val + 15, p0); st3(val + 18, p1); st3(val + 21, v0); st3(val + 24, v1); }
+      if (lay.pair_sum) {  // (serial: the even group of a pair comes first and stores, the odd one adds: leg 0 + leg 1, as on the device)
+        const Vec3<double> mcg = ld3(B + LEGJ_MC);
+        const Sym3<double> IOg = ld6(B + LEGJ_IO);
+        if ((g & 1) == 0) { st3(val + 0, mcg); st6(val + 3, IOg); st3(val + 9, lin); st3(val + 12, ang); }
+        else { st3(val + 0, ld3(val + 0) + mcg); st6(val + 3, ld6(val + 3) + IOg); st3(val + 9, ld3(val + 9) + lin); st3(val + 12, ld3(val + 12) + ang); }
+        st3(val + 15 + 6 * (g & 1), v0); st3(val + 18 + 6 * (g & 1), v1);
+      } else {
+        st3(val + 0, ld3(B + LEGJ_MC)); st6(val + 3, ld6(B + LEGJ_IO)); st3(val + 9, lin); st3(val + 12, ang);
+        if (lay.compact) { st3(val + 15, v0); st3(val + 18, v1); }
+        else { st3(val + 15, p0); st3(val + 18, p1); st3(val + 21, v0); st3(val + 24, v1); }
+      }
     }
   }
   cx.sync();

@@ -133,7 +133,20 @@ __global__ __launch_bounds__(64) void k_warm_shift(Batch b, const DevModel* __re
   const int* mp = b.modep + size_t(inst) * N;
   const double t = b.t[size_t(inst) * (N + 1) + k];
   // old interval that contains t: the largest i in [0, np - 1] with tp[i] <= t (0 if there is none)
+  // Between two MPC calls the grid moves by a fraction of an interval, so the answer is k, k + 1 or k - 1 almost always: those three
+  // candidates are tested first with loads that do not depend on one another (one round trip); the bisection (up to seven dependent
+  // loads per block) is the fallback.  tp is non-decreasing: i is the answer iff tp[i] <= t and (i is the last or tp[i + 1] > t).
   int lo = 0, hi = np > 0 ? np - 1 : 0;
+  {
+    const int last = hi;
+    const int c0 = min(max(k - 1, 0), last);
+    const double t0 = tp[c0], t1 = tp[min(c0 + 1, last)], t2 = tp[min(c0 + 2, last)], t3 = tp[min(c0 + 3, last)];
+    const double tc[4] = {t0, t1, t2, t3};
+    for (int d = 0; d < 3; ++d) {
+      const int c = c0 + d;
+      if (c <= last && tc[d] <= t && (c == last || tc[d + 1] > t)) { lo = hi = c; break; }
+    }
+  }
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
     if (tp[mid] <= t) lo = mid; else hi = mid - 1;

@@ -56,6 +56,13 @@ def x0_sequence(x0, seed, n_seq=8, sigma=0.01):
     return seq
 
 
+def default_chunks(B: int) -> int:
+    """Instance ranges per GPU (hb_set_chunks) when --chunks is not given.  Measured on one MI355X (tools/chunk_sweep.sh, N = 100,
+    updates/s at 1 / 2 / 4 ranges): 4096 instances 467 k / 463 k / 489 k, 2048: 454 / 441 / 470, 1024: 370 / 394 / 426,
+    512: 291 / 300 / 285 — below 1024 instances a range of a quarter of the batch no longer fills the chip with its LQ kernel."""
+    return 4 if B >= 1024 else (2 if B >= 128 else 1)
+
+
 def usable_cores() -> int:
     """Host cores this process may actually use: scheduler affinity capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -200,7 +207,7 @@ def _full_tick(params, s, w, steps, dt_mpc):
             return torch.from_numpy(a).pin_memory().numpy()
         except Exception:  # noqa: BLE001  (no torch HIP runtime in this process: pageable memory then)
             return a
-    s.set_chunks(4 if B >= 64 else 1)   # instance ranges: every range runs its own slice of the whole tick (hb_tick_resident)
+    s.set_chunks(default_chunks(B))   # instance ranges: every range runs its own slice of the whole tick (hb_tick_resident)
     quat, w_loc, a_loc, contact = pin(quat), pin(w_loc), pin(a_loc), pin(contact)
     qj_s, qdj_s, cmd_s = pin(rbd[:, 6:16]), pin(rbd[:, 22:32]), pin(w["cmd"])
 
@@ -306,14 +313,14 @@ def main():
     # (gpurun_out r03: tools/chunk_debug.py): the FIRST context a process creates overlaps its chunk streams
     # worse than any later one (4096 x 100, 4 chunks: 370 k vs 405 k updates/s; one stream: 389 k either way) — a first-use
     # effect of the ROCm runtime's queue / memory set-up that no ordering of our own stream creation or allocations reproduces.
-    if (args.chunks if args.chunks > 0 else 4) > 1:
+    if (args.chunks if args.chunks > 0 else default_chunks(B)) > 1:
         HunterSolver(params, batch=B, max_nodes=N, device=local_rank).close()
     s = HunterSolver(params, batch=B, max_nodes=N, device=local_rank, wbc_type=1 if args.hierarchical else 0)
     t_setup = time.perf_counter()
     w = workload.device_trot_batch(s, params, n_intervals=N, first_inst=first, cmd_vel_random=args.random_cmd)
     s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
     s.set_resident_x0_sequence(x0_sequence(w["x0"], rank))
-    n_chunks = args.chunks if args.chunks > 0 else (4 if B >= 64 else 1)
+    n_chunks = args.chunks if args.chunks > 0 else default_chunks(B)
     s.set_chunks(n_chunks)
     if n_chunks > 1:
         # priming (setup, untimed): the library captures one hipGraph per (chunk, x0-sequence slot) once the chunk streams are in

@@ -650,7 +650,8 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   // The shooting defect x+ - x_next: from here on the x+ slot holds it (read by b~ right below and by the cost phase).
   for (int i = cx.lane; i < 22; i += cx.nlanes) xplus[i] -= xnext_at(i);
   cx.sync();
-  // -------------------------------------------------------------- phase 3+4b: write the projected record
+  // -------------------------------------------------------------- phase 3: dynamics part of the projected record (A~, B~, b~)
+  // (before the cost phase: ABt is dead from here on and the cost-phase buffers, M and R_jj reuse it — LqLds)
   const int ntil = n_f + nz;
   int flist = 0;  // contact feet in foot order, two bits each: projected force column block j belongs to foot (flist >> 2j) & 3
   {
@@ -709,7 +710,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     rec[rec_b(row)] = s;
   }
   HB_ABLATE_STOP(C.debug_stop == 31);
-  // -------------------------------------------------------------- phase 4a: cost pieces, one "role" per lane
+  // -------------------------------------------------------------- phase 4: cost pieces, one "role" per lane; then the cost part of the record
   // roles 0..21 state entries, 22..43 input entries, 44..55 constraint slots, 56..59 friction barrier values.
   // Partial sums (cost, defect^2, equality^2) are reduced through LDS (scratch aliases Mm, not live yet).
   double* red = Mm;  // 3 x 64

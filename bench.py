@@ -240,7 +240,7 @@ def backtracking_figure(params, device, B, N, first, random_cmd, steps):
     headline's timed region never sees."""
     from hunter_bipedal_control_amd import workload
     from hunter_bipedal_control_amd.solver import HunterSolver
-    s = HunterSolver(params, batch=B, max_nodes=N, device=device)
+    s = HunterSolver(params, batch=B, max_nodes=N + (8 if random_cmd else 0), device=device)
     try:
         w = workload.device_trot_batch(s, params, n_intervals=N, first_inst=first, cmd_vel_random=random_cmd)
         s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
@@ -309,13 +309,15 @@ def main():
     else:
         B, first = args.batch, rank * args.batch
         total_instances = args.batch * world
+    # (per-instance commands select per-instance gaits: the event-clipped grid of some instances needs a few more than N intervals)
+    Nmax = N + (8 if args.random_cmd else 0)
     # Runtime warm-up (setup, untimed): a context of the same size is created and destroyed first.  Measured on this stack
     # (gpurun_out r03: tools/chunk_debug.py): the FIRST context a process creates overlaps its chunk streams
     # worse than any later one (4096 x 100, 4 chunks: 370 k vs 405 k updates/s; one stream: 389 k either way) — a first-use
     # effect of the ROCm runtime's queue / memory set-up that no ordering of our own stream creation or allocations reproduces.
     if (args.chunks if args.chunks > 0 else default_chunks(B)) > 1:
-        HunterSolver(params, batch=B, max_nodes=N, device=local_rank).close()
-    s = HunterSolver(params, batch=B, max_nodes=N, device=local_rank, wbc_type=1 if args.hierarchical else 0)
+        HunterSolver(params, batch=B, max_nodes=Nmax, device=local_rank).close()
+    s = HunterSolver(params, batch=B, max_nodes=Nmax, device=local_rank, wbc_type=1 if args.hierarchical else 0)
     t_setup = time.perf_counter()
     w = workload.device_trot_batch(s, params, n_intervals=N, first_inst=first, cmd_vel_random=args.random_cmd)
     s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])

@@ -43,4 +43,20 @@ if r.returncode == 0 and line:
           "note": "configs[4] (batch 8192, N = 200, 3-priority stack) sharded 1024 per GPU, no collective"}
 else:
     c4 = {"error": (r.stderr or r.stdout)[-400:]}
-print(json.dumps({"sweep": rows, "prediction": pred, "configs4_one_gpu_share": c4}, indent=1))
+# configs[3]'s own commands: per-instance cmd_vel (walkGait-selected gaits, a few more than N intervals for some instances)
+rc = []
+for B in (512, 4096):
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--batch", str(B), "--random-cmd", "--steps", str(max(50, 200 * 512 // B)), "--warmup", "5",
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        rc.append({"batch": B, "error": (r.stderr or r.stdout)[-400:]})
+        continue
+    j = json.loads(line[-1])
+    rc.append({"batch": B, "updates_per_s": j["value"], "ms_per_step": j["ms_per_step"],
+               "mpc_status_histogram": j["solver_state"]["mpc_status_histogram_all_ranks"],
+               "nodes_per_instance_min_max": j["solver_state"]["nodes_per_instance_min_max"]})
+if len(rc) == 2 and all("updates_per_s" in r for r in rc):
+    rc.append({"frac_of_4096_rate": rc[0]["updates_per_s"] / rc[1]["updates_per_s"],
+               "predicted_8gpu_strong_scaling_updates_per_s": 8 * rc[0]["updates_per_s"]})
+print(json.dumps({"sweep": rows, "prediction": pred, "random_cmd": rc, "configs4_one_gpu_share": c4}, indent=1))

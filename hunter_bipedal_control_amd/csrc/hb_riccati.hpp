@@ -119,6 +119,57 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
     // (156 VGPRs) next to the record prefetch was what put 100 B/lane of this kernel into scratch memory.
     static_assert(NT == 12, "blocked factorisation: 9 + 3");
     bool bad = ric_chol_block<9>(cx, Hu, Lr);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Device: every lane continues redundantly in registers (the 9 x 9 block is still there): rows 9..11 of the factor by forward
+    // substitution against it, the 3 x 3 Schur complement and its factor — no LDS round trip inside, one barrier at the end.
+    // (Rows of Huu are read before lane 0 of ric_chol_block overwrote the leading triangle only: rows 9..11 are untouched.)
+    {
+      double l21[3][9], S[6];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          double sacc = Hu[(9 + r) * RicLds::LDW + RicLds::CU + j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) sacc -= l21[r][k] * Lr[j * (j + 1) / 2 + k];
+          l21[r][j] = sacc * Lr[j * (j + 1) / 2 + j];
+        }
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+          double sacc = Hu[(9 + r) * RicLds::LDW + RicLds::CU + 9 + c];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) sacc -= l21[r][k] * l21[c][k];
+          S[r * (r + 1) / 2 + c] = sacc;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double d = S[j * (j + 1) / 2 + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= S[j * (j + 1) / 2 + k] * S[j * (j + 1) / 2 + k];
+        if (!(d > 0.0)) { bad = true; d = 1.0; }
+        const double inv = rsqrt_t(d);
+        S[j * (j + 1) / 2 + j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < 3; ++i) {
+          double sacc = S[i * (i + 1) / 2 + j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) sacc -= S[i * (i + 1) / 2 + k] * S[j * (j + 1) / 2 + k];
+          S[i * (i + 1) / 2 + j] = sacc * inv;
+        }
+      }
+      cx.sync();   // every lane has read rows 9..11 of Huu before lane 0 overwrites them with the factor
+      if (cx.lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int j = 0; j < 9; ++j) Hu[(9 + r) * RicLds::LDW + RicLds::CU + j] = l21[r][j];
+#pragma unroll
+          for (int c = 0; c <= r; ++c) Hu[(9 + r) * RicLds::LDW + RicLds::CU + 9 + c] = S[r * (r + 1) / 2 + c];
+        }
+      }
+    }
+#else
     cx.sync();
     const double* Lm = Hu + RicLds::CU;   // L(i, j) = Lm[i * LDW + j]
     for (int r = 9 + cx.lane; r < 12; r += cx.nlanes) {   // L21 row r: forward substitution with L11 (diagonal = reciprocals)
@@ -170,14 +221,22 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
           for (int j = 0; j <= i; ++j) Hu[(9 + i) * RicLds::LDW + RicLds::CU + 9 + j] = S[i * (i + 1) / 2 + j];
       }
     }
+#endif
     if (bad && cx.lane == 0) lds[RicLds::flag] = 1.0;
   }
   if (!reg_factor) cx.sync();
   {
     const double* Lm = Hu + RicLds::CU;  // L(i, j) = Lm[i * LDW + j], j <= i; diagonal holds the reciprocals
+#if defined(__HIP_DEVICE_COMPILE__)
+    // 12-wide (double support): the leading 9 x 9 block of the factor is still in this lane's registers (ric_chol_block left it
+    // there); only rows 9..11 come from LDS
+    constexpr int NREG = NT <= 9 ? NT : 9;
+#else
+    constexpr int NREG = 0;
+#endif
     auto Lf = [&Lr, Lm](int i, int j) {
-      if constexpr (reg_factor) return Lr[i * (i + 1) / 2 + j];
-      else return Lm[i * RicLds::LDW + j];
+      if (i < NREG) return Lr[i * (i + 1) / 2 + j];
+      return Lm[i * RicLds::LDW + j];
     };
     for (int c = cx.lane; c < 23; c += cx.nlanes) {  // columns 0..21 = Hux, 22 = hu
       double y[NU_T];
@@ -188,8 +247,8 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
         for (int k = 0; k < a; ++k) sacc -= Lf(a, k) * y[k];
         y[a] = sacc * Lf(a, a);
 #if defined(__HIP_DEVICE_COMPILE__)
-        // 12-wide: keep the factor loads row by row — hoisted all at once (132 of them) they took the register file
-        if (NT > 9) asm volatile("" ::: "memory");
+        // 12-wide: keep the factor loads of rows 9..11 row by row — hoisted all at once they took the register file
+        if (NT > 9 && a >= 8) asm volatile("" ::: "memory");
 #endif
       }
 #pragma unroll
@@ -199,7 +258,8 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
         for (int k = a + 1; k < NT; ++k) sacc -= Lf(k, a) * y[k];
         y[a] = sacc * Lf(a, a);
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (NT > 9) asm volatile("" ::: "memory");
+        // (below row 9 only the three entries L(9..11, a) of every column come from LDS: their loads may run three columns ahead)
+        if (NT > 9 && (a >= 9 || a % 3 == 0)) asm volatile("" ::: "memory");
 #endif
       }
 #pragma unroll

@@ -935,7 +935,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   // [P~ | r~ | R~] rows of the kernel directions: Z' [M | r_j + R_jj ke | R_jj Z]  (the force rows of P~ are zero; the kernel block
   // of R~ goes behind the n_f contact-force columns)
-  {
+  if (nz > 0) {  // (double support has no kernel direction: nothing to form)
     WaveTile<1, 2> tp;
     tile_init(cx, tp, 6, 22, [](int, int) { return 0.0; });
     tile_mma<12, LDK, true, LDK, false, 10>(cx, tp, Z, Mm, 6, LDK);

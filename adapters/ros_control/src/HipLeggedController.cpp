@@ -94,10 +94,8 @@ void HipLeggedController::mpcPass() {
   referenceManager_->preSolverRun(initTime, timeHorizon_, cmdVel, &obs.state);     // modifyReferences
   if (!coldStarted_) { mpcMrtInterface_->resetMpcNode(obs.state); coldStarted_ = true; }
   mpcMrtInterface_->setCurrentObservation(obs);
-  mpcMrtInterface_->advanceMpc();                                                  // :406 (solve + publish, both on this thread)
-  std::vector<int32_t> status(1);
-  ctx_->check(hb_mpc_get_status(ctx_->get(), status.data()), "hb_mpc_get_status");
-  if (status[0] == HB_INST_NAN) throw std::runtime_error("SQP iteration failed (non-finite value / Riccati pivot)");
+  mpcMrtInterface_->advanceMpc();                                  // :406 (solve, wait, publish the FINISHED policy: this thread)
+  if (mpcMrtInterface_->mpcStatus()[0] == HB_INST_NAN) throw std::runtime_error("SQP iteration failed (non-finite value / Riccati pivot)");
   firstStartMpc_ = true;
 }
 

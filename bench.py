@@ -311,6 +311,35 @@ def backtracking_figure(params, device, B, N, first, random_cmd, steps):
         s.close()
 
 
+def launch_ranks_if_needed(args):
+    """`--gpus N` is the number of ranks of the job (one process per GPU).  Under `torch.distributed.run` (the
+    driver's launch line) WORLD_SIZE must equal it; started bare with N > 1, this process replaces itself by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py <same arguments>`, after
+    checking that the node has N GPUs.  It never prints an n_gpus = 1 line for a request of N."""
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}: launch with --nproc-per-node {args.gpus} "
+                             f"(or drop the launcher: `python bench.py --gpus {args.gpus}` starts the ranks itself)")
+        return
+    if args.gpus == 1:
+        return
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} MI355X on this node, found {have}; "
+                         "the solver has no CPU fallback and no rank is started")
+    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between the ranks' processes needs it on this stack
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,6 +357,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the full-tick figure and the config-1 latency block")
     args = ap.parse_args()
+    launch_ranks_if_needed(args)
 
     import torch
     from hunter_bipedal_control_amd import ingest, sharding, workload
@@ -338,6 +368,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the solver has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, this node shows {torch.cuda.device_count()} "
+                         f"(--gpus {args.gpus} needs one MI355X per rank)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:

@@ -189,7 +189,8 @@ __global__ void k_mpc_status(Batch b, int first_iteration) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.B) return;
   const double* p = b.perf + size_t(i) * 4;
-  // (perf is only rewritten when a step is accepted; acc is the baseline of THIS iteration, rewritten by every forward sweep)
+  // (every forward sweep resets perf to the baseline of THIS iteration with step size 0 — what a no-step exit of the line search
+  // reports, like the oracle's res.step = 0 —; an accepted step overwrites it.  acc is the same baseline, kept for the filter.)
   const bool finite = isfinite(b.acc[i * 4 + 0]) && isfinite(b.acc[i * 4 + 1]) && isfinite(b.acc[i * 4 + 2]) && isfinite(b.acc[i * 4 + 3]) &&
                       (!b.accepted[i] || (isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2])));
   int st = HB_INST_OK;
@@ -824,7 +825,8 @@ struct hb_ctx {
   hipGraphExec_t chunk_graph[8][GRAPH_SLOTS]{};
   uint64_t chunk_graph_epoch[8][GRAPH_SLOTS]{};
   uint64_t graph_epoch = 1;
-  int64_t dbg_graph_launches = 0, dbg_direct = 0, dbg_forks = 0, dbg_captures = 0;
+  int64_t dbg_graph_launches = 0, dbg_direct = 0, dbg_forks = 0, dbg_captures = 0, dbg_capture_failures = 0;
+  bool graph_disabled = false;   // a capture / instantiation failed once: direct launches from then on (until hb_set_chunks)
   int steady_chunked_steps = 0;   // chunked steps since the last fork: graphs are only captured in steady state
   int chunks_pending = 0;    // chunk streams of the last chunked hb_step_resident not yet joined into the library streams
   bool fork_needed = true;   // something may have been queued on the library streams since the last chunked step
@@ -2014,22 +2016,31 @@ int32_t hb_step_resident(hb_ctx* ctx, double dt) {
     if (graphable) {
       hipGraphExec_t& ge = ctx->chunk_graph[c][slot];
       if (ge && ctx->chunk_graph_epoch[c][slot] != ctx->graph_epoch) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
-      if (!ge) {
+      if (!ge && !ctx->graph_disabled) {
         hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const hipError_t be = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        bool ok = false;
+        if (be == hipSuccess) {
           const int32_t rc = enqueue();
           const hipError_t ce = hipStreamEndCapture(s, &g);
           ++ctx->dbg_captures;
-          if (rc == HB_OK && ce == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
-            ctx->chunk_graph_epoch[c][slot] = ctx->graph_epoch;
+          if (rc == HB_OK) {  // the capture pass counted a solve that was never enqueued: the launch / direct pass below counts the real one
             std::lock_guard<std::mutex> lk(ctx->mtx);
-            ctx->stats.n_mpc_solves -= cnt;  // (counted by the capture pass; the launch below counts the real one)
-          } else {
-            ge = nullptr;
+            ctx->stats.n_mpc_solves -= cnt;
           }
+          ok = rc == HB_OK && ce == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
           if (g) (void)hipGraphDestroy(g);
-          (void)hipGetLastError();
         }
+        if (ok) {
+          ctx->chunk_graph_epoch[c][slot] = ctx->graph_epoch;
+        } else {
+          // a capture / instantiation that fails once is not retried on every step (it would double the host cost for good):
+          // this context steps its ranges with direct launches from now on; hb_debug_chunk_counters reports the failure
+          ge = nullptr;
+          ctx->graph_disabled = true;
+          ++ctx->dbg_capture_failures;
+        }
+        (void)hipGetLastError();
       }
       if (ge && hipGraphLaunch(ge, s) == hipSuccess) {
         launched = true;
@@ -2200,12 +2211,19 @@ int32_t hb_debug_chunk_counters(hb_ctx* ctx, int64_t* out4) {
   return HB_OK;
 }
 
+int32_t hb_debug_graph_state(hb_ctx* ctx, int64_t* out2) {
+  if (!ctx || !out2) return HB_ERR_ARG;
+  out2[0] = ctx->dbg_capture_failures; out2[1] = ctx->graph_disabled ? 1 : 0;
+  return HB_OK;
+}
+
 int32_t hb_set_chunks(hb_ctx* ctx, int32_t n_chunks) {
   if (ctx) lazy_join(ctx);
   if (!ctx || n_chunks < 1 || n_chunks > 8) return HB_ERR_ARG;
   int32_t rc = hb_sync(ctx);
   if (rc != HB_OK) return rc;
   ctx->n_chunks = n_chunks;
+  ctx->graph_disabled = false;  // a new set of ranges gets a new chance to capture
   ++ctx->graph_epoch;
   return HB_OK;
 }

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
     "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd", "hb_plant_reset", "hb_plant_step",
     "hb_plant_get_state", "hb_hoqp_solve", "hb_mpc_reset_masked", "hb_mpc_get_status", "hb_joint_set_flags",
-    "hb_joint_get_emergency_stop", "hb_set_resident_time", "hb_get_wbc_iterations", "hb_ik_solve", "hb_debug_chunk_counters", "hb_refgen_get_status", "hb_tick_resident",
+    "hb_joint_get_emergency_stop", "hb_set_resident_time", "hb_get_wbc_iterations", "hb_ik_solve", "hb_debug_chunk_counters", "hb_debug_graph_state", "hb_refgen_get_status", "hb_tick_resident",
 ]
 # include/hunter_lcm.h
 LCM_SYMBOLS = ["hb_lcm_fingerprint", "hb_lcm_encoded_size", "hb_lcm_field_count", "hb_lcm_encode", "hb_lcm_decode", "hb_lcm_frame", "hb_lcm_unframe",
@@ -430,7 +430,10 @@ class HunterSolver:
     def chunk_counters(self):
         out = np.zeros(4, dtype=np.int64)
         self._check(self.lib.hb_debug_chunk_counters(self.ctx, _p(out)), "hb_debug_chunk_counters")
-        return dict(graph_launches=int(out[0]), direct=int(out[1]), forks=int(out[2]), captures=int(out[3]))
+        g = np.zeros(2, dtype=np.int64)
+        self._check(self.lib.hb_debug_graph_state(self.ctx, _p(g)), "hb_debug_graph_state")
+        return dict(graph_launches=int(out[0]), direct=int(out[1]), forks=int(out[2]), captures=int(out[3]),
+                    capture_failures=int(g[0]), graphs_disabled=int(g[1]))
 
     def ik_solve(self, q16, leg, des_pos, R_des):
         """n independent InverseKinematics::computeIK problems on the device (hb_ik_solve) -> joint angles [n][5]."""

@@ -166,7 +166,12 @@ int32_t hb_mpc_set_trajectory(hb_ctx* ctx, const double* x, const double* u);
  * Asynchronous on the library's MPC stream. x0 is a host pointer [batch][22] or NULL to keep the
  * device-resident x0 (previous call). */
 int32_t hb_mpc_solve(hb_ctx* ctx, const double* x0);
-/* Make the last solution the active policy (MPC_MRT_Interface::updatePolicy, LeggedController.cpp:154). */
+/* Make the last solution the active policy (MPC_MRT_Interface::updatePolicy, LeggedController.cpp:154).  Enqueue-only: five
+ * device-to-device copies on the MPC stream, which the WBC stream then waits for.  Real-time note for the two-thread split: called
+ * while the solve is still in flight, the copies — and with them the control thread's next hb_wbc_update — queue behind the whole
+ * solve.  A caller whose control tick must never wait for the solver publishes AFTER the solve has completed: hb_mpc_solve,
+ * hb_mpc_get_status (synchronises the MPC stream), hb_mpc_publish, all on the MPC thread (hunter_hip.hpp MpcMrtInterface::advanceMpc
+ * does exactly that); the control thread keeps evaluating the previous policy until then, as the reference does. */
 int32_t hb_mpc_publish(hb_ctx* ctx);
 /* Copy trajectories to the host (PrimalSolution, LeggedController.cpp:269); any pointer may be NULL.
  * x [count][max_nodes+1][22], u [count][max_nodes][22]. Synchronises the MPC stream. */
@@ -266,7 +271,11 @@ int32_t hb_get_wbc_iterations(hb_ctx* ctx, int32_t* iters /*[batch]*/);
 /* Pipelining of hb_step_resident: the batch is cut into n_chunks (1..8) instance ranges, each a linear
  * MPC -> publish -> WBC sequence on its own HIP stream so that the per-instance sweeps of one range overlap the
  * per-node kernels of another.  Results are identical for every n_chunks; hb_get_stats phase times are only
- * recorded with n_chunks = 1 (the default). */
+ * recorded with n_chunks = 1 (the default).
+ * THREADING: hb_tick_resident and hb_step_resident with n_chunks > 1 are SINGLE-THREAD entry points — they share the pinned
+ * staging rings and the lazy range join with the enqueue-only calls (hb_set_resident_time, hb_estimator_update, hb_refgen_update),
+ * which are not locked.  The two-thread split of hb_last_error's note (MPC thread / control thread) applies to n_chunks = 1 and
+ * the non-resident entry points only; do not mix it with chunked stepping on one context. */
 int32_t hb_set_chunks(hb_ctx* ctx, int32_t n_chunks);
 
 /* ---- state estimator (the step immediately before the path every tick) ------------------
@@ -375,6 +384,9 @@ int32_t hb_hoqp_solve(hb_ctx* ctx, int32_t n_problems, int32_t n_vars, int32_t n
 /* Diagnostics of the chunked hb_step_resident: out4 = [graph launches, directly enqueued chunk steps, forks from the library streams,
  * graph captures] since hb_create. */
 int32_t hb_debug_chunk_counters(hb_ctx* ctx, int64_t* out4);
+/* out2 = [graph captures / instantiations that FAILED since hb_create, 1 if this context has therefore given up on graphs and steps
+ * its ranges with direct launches (until the next hb_set_chunks)].  A failed capture is not retried on every step. */
+int32_t hb_debug_graph_state(hb_ctx* ctx, int64_t* out2);
 /* n independent inverse-kinematics problems of the joint-reference generator (InverseKinematics::computeIK(init_q, leg, pos, R_des),
  * legged_interface/src/foot_planner/InverseKinematics.cpp:36-231): q16[n][16] = [base pos, zyx, joints] start configurations,
  * leg[n] in {0 left, 1 right}, des_pos[n][3] target of contact f1 of the leg, R_des[n][9] row-major desired foot rotation;

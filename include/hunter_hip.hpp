@@ -131,15 +131,22 @@ class MpcMrtInterface {
     }
   }
   void setCurrentObservation(const SystemObservation& obs) { setCurrentObservation(std::vector<SystemObservation>{obs}); }
-  // MPC_MRT_Interface::advanceMpc (LeggedController.cpp:406): one SQP solve from the current observation (asynchronous
-  // on the library's MPC stream, like the reference's MPC thread), then the hand-over of the new policy.  hb_mpc_publish is an
-  // MPC-THREAD call (include/hunter_hip.h): it must be ordered with the table updates and the warm start that precede the
-  // solve on this thread — published from the control thread it could pair the previous iterate with the next call's time /
-  // mode tables.  The policy evaluation of the control thread (hb_wbc_update) picks the new buffers up through stream events.
+  // MPC_MRT_Interface::advanceMpc (LeggedController.cpp:406): one SQP solve from the current observation on the library's MPC
+  // stream; this (MPC) thread then WAITS for it — advanceMpc is a blocking call in the reference as well — and only then hands
+  // the finished policy over.  The order matters for the control thread: hb_mpc_publish makes the WBC stream wait for the copies
+  // it enqueues on the MPC stream, so published BEHIND an in-flight solve it would make the next 500 Hz hb_wbc_update wait for
+  // that whole solve; published after hb_mpc_get_status (which synchronises the MPC stream) the control thread waits for five
+  // short device-to-device copies at most and keeps evaluating the previous policy until then, like LeggedController::update
+  // with MPC_MRT_Interface::updatePolicy.  hb_mpc_publish is an MPC-THREAD call (include/hunter_hip.h): it must be ordered with
+  // the table updates and the warm start that precede the solve on this thread.
   void advanceMpc() {
     ctx_.check(hb_mpc_solve(ctx_.get(), x0_.data()), "hb_mpc_solve");
+    mpcStatus_.resize(size_t(ctx_.batch()));
+    ctx_.check(hb_mpc_get_status(ctx_.get(), mpcStatus_.data()), "hb_mpc_get_status");   // returns when the solve has finished
     ctx_.check(hb_mpc_publish(ctx_.get()), "hb_mpc_publish");
   }
+  // per-instance status word of the last advanceMpc (HB_INST_OK / HB_INST_MAXITER / HB_INST_NAN)
+  const std::vector<int32_t>& mpcStatus() const { return mpcStatus_; }
   // MPC_MRT_Interface::updatePolicy (LeggedController.cpp:154): kept for call-site parity; the hand-over already happened in
   // advanceMpc on the MPC thread, nothing is left to do on the control thread
   void updatePolicy() {}
@@ -164,6 +171,7 @@ class MpcMrtInterface {
   }
   Context ctx_;
   vector_t x0_;
+  std::vector<int32_t> mpcStatus_;
 };
 
 // ---- WBC side: legged::WbcBase / WeightedWbc / HierarchicalWbc ----------------------------------------------------

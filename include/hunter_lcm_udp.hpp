@@ -13,7 +13,9 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -40,13 +42,15 @@ class LcmUdp {
     const size_t c = rest.find(':');
     const std::string host = c == std::string::npos ? rest : rest.substr(0, c);
     const int port = c == std::string::npos ? 7667 : std::atoi(rest.c_str() + c + 1);
+    if (port < 1 || port > 65535) throw std::invalid_argument("[hunter_hip] LCM url port out of range: " + url);
+    if (ttl < 0 || ttl > 255) throw std::invalid_argument("[hunter_hip] LCM url ttl out of range: " + url);
     std::memset(&dest_, 0, sizeof(dest_));
     dest_.sin_family = AF_INET;
     dest_.sin_port = htons(uint16_t(port));
     if (inet_pton(AF_INET, host.c_str(), &dest_.sin_addr) != 1) throw std::invalid_argument("[hunter_hip] LCM url host: " + host);
     rx_ = ::socket(AF_INET, SOCK_DGRAM, 0);
     tx_ = ::socket(AF_INET, SOCK_DGRAM, 0);
-    if (rx_ < 0 || tx_ < 0) throw std::runtime_error("[hunter_hip] LCM: socket() failed");
+    if (rx_ < 0 || tx_ < 0) { closeAll(); throw std::runtime_error("[hunter_hip] LCM: socket() failed"); }   // (no destructor runs for a throwing constructor)
     const int one = 1;
     ::setsockopt(rx_, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
 #ifdef SO_REUSEPORT
@@ -63,8 +67,13 @@ class LcmUdp {
       mreq.imr_interface.s_addr = htonl(INADDR_ANY);
       if (::setsockopt(rx_, IPPROTO_IP, IP_ADD_MEMBERSHIP, &mreq, sizeof(mreq)) != 0) { closeAll(); throw std::runtime_error("[hunter_hip] LCM: cannot join the multicast group (no multicast route?)"); }
       const unsigned char t = static_cast<unsigned char>(ttl), loop = 1;
-      ::setsockopt(tx_, IPPROTO_IP, IP_MULTICAST_TTL, &t, sizeof(t));
-      ::setsockopt(tx_, IPPROTO_IP, IP_MULTICAST_LOOP, &loop, sizeof(loop));
+      // ttl = 0 keeps the datagrams on this host and LOOP delivers them to the other endpoints of it: without either the bus is
+      // silently something else than the reference's, so a failure is an error
+      if (::setsockopt(tx_, IPPROTO_IP, IP_MULTICAST_TTL, &t, sizeof(t)) != 0 ||
+          ::setsockopt(tx_, IPPROTO_IP, IP_MULTICAST_LOOP, &loop, sizeof(loop)) != 0) {
+        closeAll();
+        throw std::runtime_error("[hunter_hip] LCM: cannot set the multicast ttl / loop options");
+      }
     }
   }
   ~LcmUdp() { closeAll(); }
@@ -81,9 +90,16 @@ class LcmUdp {
   // one datagram; false on timeout.  Malformed datagrams are dropped (like liblcm) and the wait continues.
   bool receive(std::string& channel, std::vector<uint8_t>& payload, int timeout_ms) {
     uint8_t buf[65536];
+    // ONE deadline for the call: foreign / malformed datagrams on a busy port do not restart the wait
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms);
     for (;;) {
+      int wait_ms = -1;   // (timeout_ms < 0: wait for ever, as poll does)
+      if (timeout_ms >= 0) {
+        const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+        wait_ms = left > 0 ? int(left) : 0;
+      }
       pollfd pfd{rx_, POLLIN, 0};
-      if (::poll(&pfd, 1, timeout_ms) <= 0) return false;
+      if (::poll(&pfd, 1, wait_ms) <= 0) return false;
       const ssize_t n = ::recv(rx_, buf, sizeof(buf), 0);
       if (n <= 0) return false;
       char ch[64];

@@ -119,7 +119,7 @@ def make_config(params: dict, **overrides) -> HbConfig:
     out.base_angular_kp, out.base_angular_kd = c["base_angular_kp"], c["base_angular_kd"]
     out.weight_swing_leg, out.weight_base_accel = c["weight_swing_leg"], c["weight_base_accel"]
     out.weight_contact_force = c["weight_contact_force"]
-    out.wbc_eps_reg = 1e-8
+    out.wbc_eps_reg = 1e-8    # the regularised-minimiser rule (why not qpOASES's 5e3 * EPS, with measurements)
     out.wbc_max_iter = 120
     _fill(out.default_joint_state, c["default_joint_state"])
     out.delta_tol = c["delta_tol"]

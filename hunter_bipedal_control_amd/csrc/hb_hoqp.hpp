@@ -6,8 +6,9 @@
 //            D z - v <= f  is the piecewise quadratic  min 1/2|A z - b|^2 + 1/2|(D z - f)_+|^2 : solved by
 //            re-factorising over the set of violated rows until it is stable (empty in normal operation), so the
 //            38 + 40 variable QP of the reference is never formed.  v0 = (D z - f)_+.
-//   kernels  orthonormal bases from a Householder QR with column pivoting of A'  (reference: Eigen FullPivLU
-//            kernel; only the subspace matters).
+//   kernels  the reference's own null-space bases: Eigen's FullPivLU::kernel() (HoQp.cpp:162) reproduced step by step
+//            (fullpivlu_kernel below) — every level regularises its QP in the coordinates of its basis, so the basis is
+//            part of the answer on rank-deficient levels (rounds 1-3 took orthonormal bases).
 //   level 1  base acceleration, level 2  0.1 * contact force + swing legs: small dense QPs (<= 12 variables, <= 40
 //            hard rows D Z z <= f - D x_prev + v0) by a serial Goldfarb–Idnani on one lane.
 #pragma once
@@ -16,63 +17,79 @@
 namespace hb {
 
 // ---------------------------------------------------------------------------------------------------------
-// Householder QR with column pivoting of T (n x m, row-major, leading dimension ldt), accumulating Q (n x n).
-// Returns the numerical rank; columns rank..n-1 of Q are an orthonormal basis of the kernel of T'.
+// Null-space basis of T (m x n, row-major, leading dimension ld, m <= 28, n <= 38) as `T.fullPivLu().kernel()` gives it
+// (HoQp::buildZMatrix, legged_wbc/src/HoQp.cpp:155-166).  [Eigen-knowledge] (Eigen/src/LU/FullPivLU.h is not in /root/reference):
+// complete pivoting — at step k the entry of largest magnitude of the trailing block, the FIRST one in a column-by-column scan,
+// goes to (k, k) by a row and a column transposition; all min(m, n) steps run unless the block is exactly zero —, rank = pivots
+// with |u_ii| > epsilon * min(m, n) * (largest pivot), kernel = Q [-U11^-1 U12; I].  Only WHICH columns stay free enters the
+// result (the basis is the one with an identity on them), so rounding differences against Eigen's arithmetic do not matter as long
+// as the pivoting picks the same columns; the tie rule is Eigen's.  T is overwritten by its LU factors.
+// One column per lane in the scans and the elimination, one free column per lane in the back substitution; plain loops over
+// cx.lane, so the host emulator and the device run THIS code.  Z (n x ldz): columns 0 .. dimker - 1 are written.  Returns dimker,
+// or -1 if it exceeds zcap (nothing is written then).  work: 80 doubles.
 template <class Ctx>
-HB_HD int householder_qr_pivot(const Ctx& cx, double* T, int n, int m, int ldt, double* Q, double* work) {
-  double* nrm = work;       // m
-  double* v = work + 40;    // n
-  for (int idx = cx.lane; idx < n * n; idx += cx.nlanes) Q[idx] = (idx / n == idx % n) ? 1.0 : 0.0;
+HB_HD int fullpivlu_kernel(const Ctx& cx, double* T, int m, int n, int ld, double* Z, int ldz, int zcap, double* work) {
+  double* cb = work;                                  // [n <= 38] largest magnitude of column j in the trailing block
+  int* ci = reinterpret_cast<int*>(work + 38);        // [38] its row (first one met)
+  int* q = reinterpret_cast<int*>(work + 58);         // [38] q[position] = original column
+  for (int j = cx.lane; j < n; j += cx.nlanes) q[j] = j;
+  const int size = m < n ? m : n;
+  int nonzero = size;
+  double maxpivot = 0.0;
   cx.sync();
-  double r00 = 0.0;
-  int rank = 0;
-  const int steps = n < m ? n : m;
-  for (int j = 0; j < steps; ++j) {
-    for (int c = j + cx.lane; c < m; c += cx.nlanes) {
-      double s = 0.0;
-      for (int i = j; i < n; ++i) s += T[i * ldt + c] * T[i * ldt + c];
-      nrm[c] = s;
-    }
-    cx.sync();
-    int pv = j;
-    double best = nrm[j];
-    for (int c = j + 1; c < m; ++c)
-      if (nrm[c] > best) { best = nrm[c]; pv = c; }
-    const double rjj = sqrt(best);
-    if (j == 0) r00 = rjj;
-    if (!(rjj > 1e-9 * r00) || rjj == 0.0) break;
-    cx.sync();
-    if (pv != j)
-      for (int i = cx.lane; i < n; i += cx.nlanes) {
-        const double t = T[i * ldt + j];
-        T[i * ldt + j] = T[i * ldt + pv];
-        T[i * ldt + pv] = t;
+  for (int k = 0; k < size; ++k) {
+    for (int j = k + cx.lane; j < n; j += cx.nlanes) {
+      double best = -1.0;
+      int bi = k;
+      for (int i = k; i < m; ++i) {
+        const double a = fabs(T[i * ld + j]);
+        if (a > best) { best = a; bi = i; }
       }
-    cx.sync();
-    // reflector from column j, rows j..n-1
-    const double x0 = T[j * ldt + j];
-    const double alpha = x0 > 0.0 ? -rjj : rjj;
-    for (int i = cx.lane; i < n; i += cx.nlanes) v[i] = (i < j) ? 0.0 : (i == j ? x0 - alpha : T[i * ldt + j]);
-    cx.sync();
-    const double vtv = best - x0 * x0 + (x0 - alpha) * (x0 - alpha);
-    const double beta = 2.0 * rcp_t(vtv);
-    for (int c = j + cx.lane; c < m; c += cx.nlanes) {
-      double s = 0.0;
-      for (int i = j; i < n; ++i) s += v[i] * T[i * ldt + c];
-      s *= beta;
-      for (int i = j; i < n; ++i) T[i * ldt + c] -= s * v[i];
-    }
-    for (int q = cx.lane; q < n; q += cx.nlanes) {
-      double s = 0.0;
-      for (int i = j; i < n; ++i) s += Q[q * n + i] * v[i];
-      s *= beta;
-      for (int i = j; i < n; ++i) Q[q * n + i] -= s * v[i];
+      cb[j] = best;
+      ci[j] = bi;
     }
     cx.sync();
-    rank = j + 1;
+    double best = -1.0;
+    int bj = k;
+    for (int j = k; j < n; ++j)
+      if (cb[j] > best) { best = cb[j]; bj = j; }
+    const int bi = ci[bj];
+    cx.sync();
+    if (best == 0.0) { nonzero = k; break; }
+    if (best > maxpivot) maxpivot = best;
+    if (bi != k)
+      for (int j = cx.lane; j < n; j += cx.nlanes) { const double t = T[k * ld + j]; T[k * ld + j] = T[bi * ld + j]; T[bi * ld + j] = t; }
+    cx.sync();
+    if (bj != k) {
+      for (int i = cx.lane; i < m; i += cx.nlanes) { const double t = T[i * ld + k]; T[i * ld + k] = T[i * ld + bj]; T[i * ld + bj] = t; }
+      if (cx.lane == 0) { const int t = q[k]; q[k] = q[bj]; q[bj] = t; }
+    }
+    cx.sync();
+    const double pkk = T[k * ld + k];
+    for (int i = k + 1 + cx.lane; i < m; i += cx.nlanes) T[i * ld + k] /= pkk;
+    cx.sync();
+    for (int j = k + 1 + cx.lane; j < n; j += cx.nlanes) {
+      const double tkj = T[k * ld + j];
+      for (int i = k + 1; i < m; ++i) T[i * ld + j] -= T[i * ld + k] * tkj;
+    }
+    cx.sync();
+  }
+  const double pt = maxpivot * (2.220446049250313e-16 * double(size));
+  int rk = 0;   // (pivots above the threshold are the leading ones: complete pivoting eliminates into rounding noise after them)
+  while (rk < nonzero && fabs(T[rk * ld + rk]) > pt) ++rk;
+  const int dimker = n - rk;
+  if (dimker > zcap) return -1;
+  for (int kk = cx.lane; kk < dimker; kk += cx.nlanes) {
+    const int c = rk + kk;
+    for (int i = rk - 1; i >= 0; --i) {
+      double sacc = T[i * ld + c];
+      for (int j = i + 1; j < rk; ++j) sacc += T[i * ld + j] * Z[q[j] * ldz + kk];   // (Z holds -x_j)
+      Z[q[i] * ldz + kk] = -(sacc / T[i * ld + i]);
+    }
+    for (int t = 0; t < dimker; ++t) Z[q[rk + t] * ldz + kk] = (t == kk) ? 1.0 : 0.0;
   }
   cx.sync();
-  return rank;
+  return dimker;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -82,9 +99,12 @@ HB_HD int householder_qr_pivot(const Ctx& cx, double* T, int n, int m, int ldt, 
 // 0 solved / 1 iteration limit / 2 infeasible.  All control flow is decided on values every lane reads from LDS or on
 // wave reductions, so it is uniform; one constraint per lane in the violation scan, one row / column per lane in the
 // factor updates.
+// The first n_shift variables are regularised with eps + shift instead of eps: the null-space coordinates z of a cascade level
+// that has equality rows, whose Hessian block the reference builds as (A Z)'(A Z) + 1e-12 I (HoQp.cpp:74-78); the slack
+// variables behind them are not shifted.
 template <class Ctx>
 HB_HD int small_lsqp(const Ctx& cx, int n, int mA, const double* A, const double* b, double eps, int mD, const double* D,
-                     const double* f, int max_iter, double* x, double* ws) {
+                     const double* f, int max_iter, double* x, double* ws, int n_shift = 0, double shift = 0.0) {
   constexpr int LD = 12;
   double* J = ws;            // n x n
   double* R = ws + 144;      // n x n upper
@@ -98,7 +118,7 @@ HB_HD int small_lsqp(const Ctx& cx, int n, int mA, const double* A, const double
   int* is_act = act + 12;                     // mD <= 40 ints
   double* viol = g + 12 + 26;                 // 40: violation of the inactive constraints (host reduction only)
   // R~ by Givens row insertion into sqrt(eps) I (stored in R), then J = R~^-1
-  const double se = sqrt(eps);
+  const double se_tail = sqrt(eps), se_head = sqrt(eps + shift);
 #if defined(__HIP_DEVICE_COMPILE__)
   // Device: n structured Householder reflectors on lane-owned columns (registers, wave-uniform broadcasts) instead of mA x n
   // Givens rotations with two ordering points each — see the level-0 factorisation in hwbc_solve.
@@ -122,6 +142,7 @@ HB_HD int small_lsqp(const Ctx& cx, int n, int mA, const double* A, const double
         ck[rr] = wave_bcast_f64(acol[rr], k);
         dot += ck[rr] * acol[rr];
       }
+      const double se = k < n_shift ? se_head : se_tail;
       const double sig2 = se * se + wave_bcast_f64(dot, k);
       const double alpha = -sqrt(sig2);
       const double v0 = se - alpha;
@@ -136,7 +157,7 @@ HB_HD int small_lsqp(const Ctx& cx, int n, int mA, const double* A, const double
   }
   for (int rw = 0; rw < 0; ++rw) {
 #else
-  for (int idx = cx.lane; idx < n * LD; idx += cx.nlanes) R[idx] = (idx / LD == idx % LD) ? se : 0.0;
+  for (int idx = cx.lane; idx < n * LD; idx += cx.nlanes) R[idx] = (idx / LD == idx % LD) ? (idx / LD < n_shift ? se_head : se_tail) : 0.0;
   for (int i = cx.lane; i < n; i += cx.nlanes) g[i] = 0.0;
   cx.sync();
   for (int rw = 0; rw < mA; ++rw) {
@@ -317,12 +338,13 @@ HB_HD int small_lsqp(const Ctx& cx, int n, int mA, const double* A, const double
 
 // ---------------------------------------------------------------------------------------------------------
 // Generic HoQp cascade on small dense tasks — HoQp.cpp:21-198 for tasks {A x = b (least squares), D x <= f (slacked)} given as
-// plain matrices: the same building blocks the WBC cascade above uses from level 1 on (small_lsqp, householder_qr_pivot),
+// plain matrices: the same building blocks the WBC cascade above uses from level 1 on (small_lsqp, fullpivlu_kernel),
 // without the structure of the whole-body problem.  It exists so that the reference's own unit test
 // (legged_wbc/test/HoQp_test.cpp:18-55, two random tasks on four variables) can be run against DEVICE code (hb_hoqp_solve).
 // Level k solves, over  x = x_{k-1} + Z_k z  and the slack v >= 0 of its own inequalities,
 //     min 1/2 |A_k x - b_k|^2 + 1/2 |v|^2    s.t.  D_k x - v <= f_k,   D_j x <= f_j + v_j*  (j < k)
 // (HoQp::buildHMatrix / buildCVector / buildDMatrix / buildFVector), then Z_{k+1} = Z_k kernel(A_k Z_k).
+constexpr double kHoqpHessianShift = 1e-12;   // HoQp::buildHMatrix: zTaTaz + 1e-12 I (HoQp.cpp:78)
 constexpr int HQ_N = 8;    // variables
 constexpr int HQ_M = 8;    // rows per block (A_k, D_k)
 constexpr int HQ_L = 3;    // levels
@@ -429,7 +451,7 @@ HB_HD int hoqp_generic(const Ctx& cx, int n, int n_levels, const int* mA, const 
       ft[r] = s;
     }
     cx.sync();
-    const int rc = small_lsqp(cx, nvar, ma + nv, AZ, rhs, eps, n_rows, DZ, ft, max_iter, zs, qpw);
+    const int rc = small_lsqp(cx, nvar, ma + nv, AZ, rhs, eps, n_rows, DZ, ft, max_iter, zs, qpw, ma > 0 ? nz : 0, kHoqpHessianShift);
     cx.sync();
     if (rc > status) status = rc;
     for (int i = cx.lane; i < n; i += cx.nlanes) {
@@ -441,17 +463,16 @@ HB_HD int hoqp_generic(const Ctx& cx, int n, int n_levels, const int* mA, const 
     for (int i = cx.lane; i < n; i += cx.nlanes) { x[i] = work[i]; x_levels[k * HQ_N + i] = work[i]; }
     for (int i = cx.lane; i < nv; i += cx.nlanes) { v[k * HQ_M + i] = zs[nz + i]; slack[k * HQ_M + i] = zs[nz + i]; }
     cx.sync();
-    // kernel of A_k Z (ma x nz): QR of its transpose (nz x ma)
+    // kernel of A_k Z (ma x nz), as the reference takes it: FullPivLU::kernel()
     if (ma > 0 && nz > 0 && k + 1 < n_levels) {
-      for (int idx = cx.lane; idx < nz * ma; idx += cx.nlanes) Tm[idx] = AZ[(idx % ma) * 12 + idx / ma];
+      for (int idx = cx.lane; idx < ma * nz; idx += cx.nlanes) Tm[idx] = AZ[(idx / nz) * 12 + idx % nz];
       cx.sync();
-      const int r = householder_qr_pivot(cx, Tm, nz, ma, ma, Qm, work);
-      const int nzn = nz - r;
+      const int nzn = fullpivlu_kernel(cx, Tm, ma, nz, nz, Qm, HQ_N, HQ_N, work);
       for (int idx = cx.lane; idx < HQ_N * 12; idx += cx.nlanes) {
         const int i = idx / 12, j = idx % 12;
         double s = 0.0;
         if (j < nzn && i < n)
-          for (int c = 0; c < nz; ++c) s += Z[i * 12 + c] * Qm[c * nz + r + j];
+          for (int c = 0; c < nz; ++c) s += Z[i * 12 + c] * Qm[c * HQ_N + j];
         Zn[idx] = s;
       }
       cx.sync();
@@ -474,7 +495,8 @@ struct HoLds {
   static constexpr int R = J + NW * NW;           // 38x38
   static constexpr int Q = R + NW * NW;           // 38x38 orthogonal factor / kernel bases
   static constexpr int Q2 = Q;                    // orthogonal factor of the second (small) QR
-  static constexpr int T = Q + NW * NW;           // 38x28 (A0') then scratch
+  static constexpr int T = Q + NW * NW;           // 38x28: LU work matrix of the level-0 kernel (28 x 38), then scratch
+  static constexpr int LU = T;
   static constexpr int Ee = T + NW * 28;          // 16x38
   static constexpr int Jc = Ee + 16 * NW;         // 12x16
   static constexpr int dJv = Jc + 192;            // 12
@@ -496,8 +518,9 @@ struct HoLds {
   static constexpr int qpw = zs + 12;             // small QP workspace 2*144 + 72 + 26 + 40
   static constexpr int work = qpw + 440;          // 80 (householder)
   static constexpr int ints = work + 80;          // 64 ints: violated flags (40), misc
-  static constexpr int xprev = ints + 32;         // 38: previous level-0 point (damped passes)
-  static constexpr int total = xprev + NW;
+  static constexpr int xprev = ints + 32;         // 38: previous level-0 point (line search of the later passes)
+  static constexpr int ls = xprev + NW;           // 2 x 40: per-row offsets / slopes of the exact line search
+  static constexpr int total = ls + 80;
 };
 struct HoLdsDev {
   // persistent
@@ -514,8 +537,9 @@ struct HoLdsDev {
   static constexpr int v0 = np + NW;              // 40 slack of level 0
   static constexpr int work = v0 + 40;            // 80 (reflector scalars, householder)
   static constexpr int ints = work + 80;          // 64 ints
-  static constexpr int xprev = ints + 32;         // 38: previous level-0 point (damped passes)
-  static constexpr int shared = xprev + NW;
+  static constexpr int xprev = ints + 32;         // 38: previous level-0 point (line search of the later passes)
+  static constexpr int ls = xprev + NW;           // 2 x 40: per-row offsets / slopes of the exact line search
+  static constexpr int shared = ls + 80;
   // level 0 (and phase A's workspace)
   static constexpr int J = shared;                // 38x38
   static constexpr int R = J + NW * NW;           // 38x38
@@ -523,9 +547,10 @@ struct HoLdsDev {
   static constexpr int Z1 = shared;               // 38x12  } the 28 reflectors (28 x 38) lie over Z1 | Z2 | AZ: they are dead
   static constexpr int Z2 = Z1 + NW * 12;         // 38x6   } before the first of these is written
   static constexpr int AZ = Z2 + NW * 12;         // 24x12
-  static constexpr int Q = Z1;                    // reflectors of the kernel QR (28 x 38)
+  static constexpr int Q = Z1;                    // (host layout's name for the orthogonal-factor buffer; unused on the device)
   static constexpr int rhs = AZ + 288;            // 24
   static constexpr int DZ = rhs + 24;             // 40x12
+  static constexpr int LU = DZ;                   // 28x38 work matrix of the level-0 kernel: over DZ | ft | zs | qpw | T | Q2, all written later
   static constexpr int ft = DZ + 480;             // 40
   static constexpr int zs = ft + 40;              // 12
   static constexpr int qpw = zs + 12;             // 440
@@ -534,7 +559,8 @@ struct HoLdsDev {
   static constexpr int late_end = Q2 + 144;
   static constexpr int total = (R + NW * NW > late_end) ? R + NW * NW : late_end;
 };
-static_assert(HoLdsDev::Q + 28 * NW <= HoLdsDev::rhs, "the reflectors must not reach buffers that are written while they are live");
+static_assert(HoLdsDev::LU + 28 * NW <= HoLdsDev::late_end && HoLdsDev::LU >= HoLdsDev::AZ + 288,
+              "the LU work matrix of the level-0 kernel must not reach Z1 / Z2 / AZ (Z1 is its output)");
 static_assert(HoLdsDev::total * 8 <= 40960, "k_hwbc: 4 instances per CU");
 
 template <class Ctx>
@@ -547,7 +573,6 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
 #endif
   double* Jm = lds + L::J;
   double* Rm = lds + L::R;
-  double* Qm = lds + L::Q;
   double* Tm = lds + L::T;
   double* Q2 = lds + L::Q2;
   double* Ee = lds + L::Ee;
@@ -619,36 +644,13 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
 
   // ------------------------------------------------------------------ level 0
   int status = 0;
-  const double se = sqrt(C.wbc_eps);
-  // phi(p) = 1/2 |A0 p - b0|^2 + 1/2 |(D p - f)_+|^2 + eps/2 |p|^2 : the convex piecewise quadratic that level 0 minimises.
-  // One term per lane (28 task rows, <= 40 inequality rows: 64 lanes hold at most 68 -> two trips), summed through `work`.
-  auto phi = [&](const double* pnt) -> double {
-    double part = 0.0;
-    for (int rw = cx.lane; rw < mA0 + wc.n_in; rw += cx.nlanes) {
-      double sres;
-      if (rw < mA0) {
-        sres = -a0_rhs(rw);
-        for (int i = 0; i < NW; ++i) sres += a0_row(rw, i) * pnt[i];
-      } else {
-        int idx[3];
-        double cfv[3], rh;
-        const int nn = sparse_row(wc, C, wc.n_eq + rw - mA0, idx, cfv, &rh);
-        sres = -rh;
-        for (int t = 0; t < nn; ++t) sres += cfv[t] * pnt[idx[t]];
-        sres = sres > 0.0 ? sres : 0.0;
-      }
-      part += 0.5 * sres * sres;
-    }
-    for (int i = cx.lane; i < NW; i += cx.nlanes) part += 0.5 * C.wbc_eps * pnt[i] * pnt[i];
-    work[cx.lane] = part;
-    cx.sync();
-    double tot = 0.0;
-    for (int l = 0; l < cx.nlanes; ++l) tot += work[l];
-    cx.sync();
-    return tot;
-  };
+  // level 0 has equality rows: its Hessian block is A0'A0 + 1e-12 I in the reference (HoQp.cpp:74-78), on top of the
+  // regularised-minimiser rule's eps
+  const double eps0 = C.wbc_eps + kHoqpHessianShift;
+  const double se = sqrt(eps0);
+  // phi(p) = 1/2 |A0 p - b0|^2 + 1/2 |(D p - f)_+|^2 + eps0/2 |p|^2 is the convex piecewise quadratic that level 0 minimises.
   double* xprev = lds + L::xprev;
-  constexpr int kMaxPass = 30, kDampFrom = 6;
+  constexpr int kMaxPass = 30;
   for (int it = 0; it < kMaxPass; ++it) {
     bool full_step = true;
     if (it == 0) {
@@ -808,18 +810,88 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
       x[i] = s;
     }
     cx.sync();
-    // x is the minimiser of the quadratic piece of the previous point's violated set: a descent direction of phi from
-    // xprev, but the full step may overshoot into other pieces and the pass can cycle (seen with joint rates of several
-    // rad/s).  Plain passes settle within a handful in every case met so far; from pass kDampFrom on the step backtracks
-    // on phi (convex, C1), which makes the sequence converge.
-    if (it >= kDampFrom) {
-      const double phi_prev = phi(xprev);
-      for (int bt = 0; bt < 10; ++bt) {
-        if (phi(x) <= phi_prev) break;
-        full_step = false;  // (the point is then not the minimiser of its piece: another pass follows whatever the set does)
-        for (int i = cx.lane; i < NW; i += cx.nlanes) x[i] = xprev[i] + 0.5 * (x[i] - xprev[i]);
-        cx.sync();
+    // x is the minimiser of the quadratic piece of the previous point's violated set: a descent direction d = x - xprev of phi
+    // from xprev, but the full step may overshoot into other pieces and the passes can cycle (joint rates of several rad/s; with
+    // the small eps of the qpOASES rule the pieces are nearly flat in the ten directions no level-0 row sees, and a plain or
+    // crudely damped iteration no longer settles).  EXACT line search instead: along d, phi'(t) = s1 + t s2 + sum_c (a_c + t b_c)_+ b_c
+    // is piecewise linear and increasing (a = D xprev - f, b = D d; s1, s2 from the smooth part); one lane per breakpoint
+    // t_c = -a_c / b_c evaluates phi' there, the root lies between the last negative and the first non-negative one, where phi'
+    // is linear.  A semismooth Newton step with exact line search on a strictly convex piecewise quadratic terminates finitely.
+    {
+      double* la = lds + L::ls;        // a_c, then phi'(t_c)
+      double* lb = la + 40;            // b_c
+      for (int i = cx.lane; i < NW; i += cx.nlanes) z[i] = x[i] - xprev[i];   // d
+      cx.sync();
+      double p1 = 0.0, p2 = 0.0;
+      for (int rw = cx.lane; rw < mA0 + NW; rw += cx.nlanes) {
+        if (rw < mA0) {
+          double rr = -a0_rhs(rw), ad = 0.0;
+          for (int i = 0; i < NW; ++i) { const double a = a0_row(rw, i); rr += a * xprev[i]; ad += a * z[i]; }
+          p1 += rr * ad;
+          p2 += ad * ad;
+        } else {
+          const int i = rw - mA0;
+          p1 += eps0 * xprev[i] * z[i];
+          p2 += eps0 * z[i] * z[i];
+        }
       }
+      for (int c = cx.lane; c < wc.n_in; c += cx.nlanes) {
+        int idx[3];
+        double cfv[3], rh;
+        const int nn = sparse_row(wc, C, wc.n_eq + c, idx, cfv, &rh);
+        double a = -rh, bb = 0.0;
+        for (int t = 0; t < nn; ++t) { a += cfv[t] * xprev[idx[t]]; bb += cfv[t] * z[idx[t]]; }
+        la[c] = a;
+        lb[c] = bb;
+      }
+      work[cx.lane] = p1;
+      cx.sync();
+      double s1 = 0.0;
+      for (int l = 0; l < cx.nlanes; ++l) s1 += work[l];
+      cx.sync();
+      work[cx.lane] = p2;
+      cx.sync();
+      double s2 = 0.0;
+      for (int l = 0; l < cx.nlanes; ++l) s2 += work[l];
+      cx.sync();
+      auto dphi = [&](double t) -> double {
+        double v = s1 + t * s2;
+        for (int c = 0; c < wc.n_in; ++c) {
+          const double r = la[c] + t * lb[c];
+          v += r > 0.0 ? r * lb[c] : 0.0;
+        }
+        return v;
+      };
+      // bracket of the root among the breakpoints (every lane scans the <= 40 candidates its neighbours evaluated)
+      double* tc = g;                  // g | z | np are contiguous (38 each): t_c in g[0..39], phi'(t_c) behind them (z is dead now)
+      double* dp = g + 40;
+      cx.sync();
+      for (int c = cx.lane; c < wc.n_in; c += cx.nlanes) {
+        const double t = lb[c] != 0.0 ? -la[c] / lb[c] : -1.0;
+        tc[c] = t;
+        dp[c] = t > 0.0 ? dphi(t) : 0.0;
+      }
+      cx.sync();
+      double t_lo = 0.0, t_hi = 1e300;
+      for (int c = 0; c < wc.n_in; ++c) {
+        const double t = tc[c];
+        if (!(t > 0.0)) continue;
+        if (dp[c] < 0.0) { if (t > t_lo) t_lo = t; }
+        else if (t < t_hi) t_hi = t;
+      }
+      const double p_lo = dphi(t_lo);
+      const double t_mid = t_hi < 1e300 ? 0.5 * (t_lo + t_hi) : t_lo + 1.0;
+      double slope = s2;
+      for (int c = 0; c < wc.n_in; ++c)
+        if (la[c] + t_mid * lb[c] > 0.0) slope += lb[c] * lb[c];
+      double t_star = (p_lo < 0.0 && slope > 0.0) ? t_lo - p_lo / slope : t_lo;
+      if (t_star > t_hi) t_star = t_hi;
+      cx.sync();
+      if (fabs(t_star - 1.0) > 1e-9) {
+        full_step = false;  // (the point is then not the minimiser of its piece: another pass follows whatever the set does)
+        for (int i = cx.lane; i < NW; i += cx.nlanes) x[i] = xprev[i] + t_star * (x[i] - xprev[i]);
+      }
+      cx.sync();
     }
     }
     // violated set of the new point
@@ -838,6 +910,18 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
     }
     cx.sync();
     if (!imisc[0] && full_step) break;
+    // A row that sits ON its bound at the minimiser ((D x - f) = 0 to rounding) flickers in and out of the violated set for ever
+    // while the point no longer moves — the pieces on both sides of the kink share the minimiser.  (Seen with the small eps of the
+    // qpOASES rule, where the rounding noise of x exceeds the 1e-10 of the set test.)  A full step that leaves the point where
+    // it was is convergence as well — and so is a line-searched step of length zero.
+    if (it > 0) {
+      for (int i = cx.lane; i < NW; i += cx.nlanes) { z[i] = fabs(x[i] - xprev[i]); g[i] = fabs(x[i]); }
+      cx.sync();
+      double dmax = 0.0, xmax = 1.0;
+      for (int i = 0; i < NW; ++i) { dmax = fmax(dmax, z[i]); xmax = fmax(xmax, g[i]); }
+      cx.sync();
+      if (dmax <= 1e-9 * xmax) break;
+    }
     if (it == kMaxPass - 1) status = HB_INST_MAXITER;
   }
   if (max_level <= 1) {
@@ -845,84 +929,20 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
     if (cx.lane == 0) *status_out = status;
     return;
   }
-  // ------------------------------------------------------------------ kernel of the level-0 task: Z1
-#if defined(__HIP_DEVICE_COMPILE__)
-  // Column-pivoted Householder QR of A0' with lane c owning column c of it (= row c of A0, 38 registers): the column norms
-  // are per-lane sums, the pivot is a wave maximum, the reflector reaches the other lanes through LDS (where it also waits
-  // for the back-application) and every lane updates its own column — no orthogonal factor is accumulated.  The kernel
-  // basis is H_0 ... H_(r-1) applied to the unit vectors e_r ..: lane b carries column b of it.
-  int r0 = 0;
-  {
-    constexpr int MT = 28;
-    const int c = cx.lane;
-    double t[NW];
-#pragma unroll
-    for (int i = 0; i < NW; ++i) t[i] = c < MT ? a0_row(c, i) : 0.0;
-    bool done = c >= MT;
-    double* Vs = Qm;        // reflector j: Vs[j * NW + i]
-    double* betas = work;   // [28]
-    double r00 = 0.0;
-#pragma unroll 1
-    for (int j = 0; j < MT; ++j) {  // (rolled: every access to t[] below has a compile-time index; rows above j are masked / zero)
-      double nr = 0.0;
-#pragma unroll
-      for (int i = 0; i < NW; ++i) nr += i >= j ? t[i] * t[i] : 0.0;
-      const double best = wave_max_f64(done ? -1.0 : nr);
-      const double rjj = sqrt(best);
-      if (j == 0) r00 = rjj;
-      if (!(rjj > 1e-9 * r00) || rjj == 0.0) break;
-      const int pv = __ffsll(__ballot(!done && nr == best)) - 1;
-      if (c == pv) {
-        double x0 = 0.0;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) x0 = i == j ? t[i] : x0;
-        const double alpha = x0 > 0.0 ? -rjj : rjj;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) Vs[j * NW + i] = i < j ? 0.0 : (i == j ? x0 - alpha : t[i]);
-        betas[j] = 2.0 * rcp_t(best - x0 * x0 + (x0 - alpha) * (x0 - alpha));
-        done = true;
-      }
-      cx.sync();
-      if (!done) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) sacc += Vs[j * NW + i] * t[i];
-        sacc *= betas[j];
-#pragma unroll
-        for (int i = 0; i < NW; ++i) t[i] -= sacc * Vs[j * NW + i];
-      }
-      r0 = j + 1;
-    }
-    const int nk = NW - r0;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) t[i] = (i == r0 + c) ? 1.0 : 0.0;
-#pragma unroll 1
-    for (int j = r0 - 1; j >= 0; --j) {
-      double sacc = 0.0;
-#pragma unroll
-      for (int i = 0; i < NW; ++i) sacc += Vs[j * NW + i] * t[i];
-      sacc *= betas[j];
-#pragma unroll
-      for (int i = 0; i < NW; ++i) t[i] -= sacc * Vs[j * NW + i];
-    }
-    if (c < 12) {
-#pragma unroll
-      for (int i = 0; i < NW; ++i) Z1[i * 12 + c] = c < nk ? t[i] : 0.0;
-    }
+  // ------------------------------------------------------------------ kernel of the level-0 task: Z1 = kernel(A0)
+  // Eigen's FullPivLU::kernel() of the 28 x 38 task matrix (HoQp.cpp:162), one column per lane; the work matrix lies over buffers
+  // that are written only after Z1 exists (device layout).  rank(A0) = 26 (double support: two rigid feet, rank 5 each) .. 28,
+  // so the basis has 10 .. 12 columns; a stance leg in a kinematic singularity would leave more — the solve is then given up
+  // (previous solution kept, WeightedWbc.cpp:57-65 semantics) instead of overrunning the 12-column buffers.
+  double* LU = lds + L::LU;
+  for (int idx = cx.lane; idx < 28 * NW; idx += cx.nlanes) LU[idx] = a0_row(idx / NW, idx % NW);
+  for (int idx = cx.lane; idx < NW * 12; idx += cx.nlanes) Z1[idx] = 0.0;
+  cx.sync();
+  const int n1 = fullpivlu_kernel(cx, LU, mA0, NW, NW, Z1, 12, 12, work);  // 10..12
+  if (n1 < 0) {
+    if (cx.lane == 0) *status_out = HB_INST_MAXITER;
+    return;
   }
-  const int n1 = NW - r0;  // 10..12
-  cx.sync();
-#else
-  for (int idx = cx.lane; idx < NW * 28; idx += cx.nlanes) Tm[idx] = a0_row(idx % 28, idx / 28);
-  cx.sync();
-  const int r0 = householder_qr_pivot(cx, Tm, NW, mA0, 28, Qm, work);
-  const int n1 = NW - r0;  // 10..12
-  for (int idx = cx.lane; idx < NW * 12; idx += cx.nlanes) {
-    const int i = idx / 12, j = idx % 12;
-    Z1[idx] = j < n1 ? Qm[i * NW + r0 + j] : 0.0;
-  }
-  cx.sync();
-#endif
   HB_ABLATE_STOP(C.debug_stop == 43);  // profiling ablation: level 0 + kernel basis
   // ------------------------------------------------------------------ level 1: base acceleration
   const double* A1 = Aw + 3 * wc.n_sw * 16;
@@ -950,7 +970,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   }
   cx.sync();
   {
-    const int rc1 = small_lsqp(cx, n1, 6, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw);
+    const int rc1 = small_lsqp(cx, n1, 6, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw, n1, kHoqpHessianShift);
     cx.sync();
     if (rc1 > status) status = rc1;
   }
@@ -962,16 +982,16 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   cx.sync();
   for (int i = cx.lane; i < NW; i += cx.nlanes) x[i] = g[i];
   HB_ABLATE_STOP(C.debug_stop == 44);  // profiling ablation: ... + level-1 QP
-  // kernel of A1 Z1 (6 x n1): QR of its transpose (n1 x 6)
-  for (int idx = cx.lane; idx < n1 * 6; idx += cx.nlanes) Tm[idx] = AZ[(idx % 6) * 12 + idx / 6];
+  // kernel of A1 Z1 (6 x n1), again as the reference takes it; Z2 = Z1 kernel(A1 Z1)
+  for (int idx = cx.lane; idx < 6 * n1; idx += cx.nlanes) Tm[idx] = AZ[(idx / n1) * 12 + idx % n1];
+  for (int idx = cx.lane; idx < 144; idx += cx.nlanes) Q2[idx] = 0.0;
   cx.sync();
-  const int r1 = householder_qr_pivot(cx, Tm, n1, 6, 6, Q2, work);
-  const int n2 = n1 - r1;
+  const int n2 = fullpivlu_kernel(cx, Tm, 6, n1, n1, Q2, 12, 12, work);
   for (int idx = cx.lane; idx < NW * 12; idx += cx.nlanes) {
     const int i = idx / 12, j = idx % 12;
     double s = 0.0;
     if (j < n2)
-      for (int k = 0; k < n1; ++k) s += Z1[i * 12 + k] * Q2[k * n1 + r1 + j];
+      for (int k = 0; k < n1; ++k) s += Z1[i * 12 + k] * Q2[k * 12 + j];
     Z2[idx] = s;
   }
   cx.sync();
@@ -1006,7 +1026,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
       if (j == 0) ft[c] = rh - dx + v0[c];
     }
     cx.sync();
-    const int rc2 = small_lsqp(cx, n2, m2, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw);
+    const int rc2 = small_lsqp(cx, n2, m2, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw, n2, kHoqpHessianShift);
     cx.sync();
     if (rc2 > status) status = rc2;
     for (int i = cx.lane; i < NW; i += cx.nlanes) {

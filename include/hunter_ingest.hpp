@@ -263,7 +263,7 @@ inline void readConfig(const std::string& taskFile, const std::string& reference
   c.base_angular_kp = task.number("baseAngularTask.kp"); c.base_angular_kd = task.number("baseAngularTask.kd");
   c.weight_swing_leg = task.number("weight.swingLeg"); c.weight_base_accel = task.number("weight.baseAccel");
   c.weight_contact_force = task.number("weight.contactForce");
-  c.wbc_eps_reg = 1e-8;
+  c.wbc_eps_reg = 1e-8;   // the regularised-minimiser rule (why not qpOASES's 5e3 * EPS, with measurements)
   c.wbc_max_iter = 120;
   const std::vector<double> dj = ref.matrix("defaultJointState", 10, 1);
   for (int j = 0; j < HB_NJ; ++j) c.default_joint_state[j] = dj[size_t(j)];

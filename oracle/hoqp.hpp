@@ -4,33 +4,76 @@
 // and HierarchicalWbc::update (legged_wbc/src/HierarchicalWbc.cpp:18-30).  Each level solves
 //     min 1/2 |A Z z + A x_prev - b|^2 + 1/2 |v|^2
 //     s.t. v >= 0,  D_prev Z z <= f_prev - D_prev x_prev + v_prev,  D Z z - v <= f - D x_prev
-// then x = x_prev + Z z and Z <- Z kernel(A Z).  The kernel basis is orthonormalised (the reference takes
-// Eigen's FullPivLU kernel; the solution only depends on the subspace, and with an orthonormal basis the
-// solver's Tikhonov term eps |z|^2 = eps |x - x_prev|^2 is basis independent).
+// then x = x_prev + Z z and Z <- Z kernel(A Z), the kernel taken as the reference takes it (Eigen's FullPivLU::kernel(),
+// kernel_basis below; rounds 1-3 used an orthonormal basis and missed the reference's minimiser on rank-deficient levels).
 #pragma once
+#include <limits>
 #include "wbc.hpp"
 
 namespace orc {
 
-// Orthonormal basis of the kernel of A (m x n): eigenvectors of A'A below Eigen's rank threshold.
+// Kernel basis of A (m x n) as HoQp::buildZMatrix takes it (legged_wbc/src/HoQp.cpp:155-166): Eigen's
+// `A.fullPivLu().kernel()`.  [Eigen-knowledge] (Eigen/src/LU/FullPivLU.h, not in /root/reference): LU with COMPLETE pivoting —
+// at step k the entry of largest magnitude of the trailing block, the first one met in a column-by-column scan, is brought to
+// (k, k) by a row and a column transposition; the elimination runs over all min(m, n) steps unless the block is exactly zero —,
+// rank = number of pivots with |u_ii| > epsilon * min(m, n) * (largest pivot), and kernel() = Q [-U11^-1 U12; I]: the basis of
+// the null space that carries an identity on the columns the pivoting left free.  NOT orthonormal, and that matters: every level
+// of the cascade regularises its QP in the coordinates of this basis (the qpOASES stand-in's eps |z|^2), so a
+// rank-deficient level picks the minimiser the reference picks only if the coordinates are the reference's.  Only the set of free
+// columns (and their order, a permutation of z that changes nothing) enters; the order of the pivots does not.
 inline Mat kernel_basis(const Mat& A) {
-  const int n = A.c;
-  if (n == 0) return Mat(0, 0);
-  if (A.r == 0) return Mat::identity(n);
-  Mat G = A.T() * A;
-  Vec w;
-  Mat V;
-  sym_eig(G, w, V);
-  const double wmax = std::max(w.back(), 0.0);
-  // eig(A'A) resolves the squared singular values only to ~1e-16 * wmax, so the rank decision is taken on w itself:
-  // w <= 1e-12 wmax  (sigma <= 1e-6 sigma_max).  The structural rank deficiencies of the WBC tasks are exact
-  // (two contact points per rigid foot), the smallest genuine singular values are ~1e-2 sigma_max.
-  int nz = 0;
-  for (int j = 0; j < n; ++j)
-    if (w[j] <= 1e-12 * wmax) ++nz;
-  Mat Z(n, nz);
-  for (int j = 0; j < nz; ++j)
-    for (int i = 0; i < n; ++i) Z(i, j) = V(i, j);
+  const int rows = A.r, cols = A.c;
+  if (cols == 0) return Mat(0, 0);
+  if (rows == 0) return Mat::identity(cols);
+  const int size = std::min(rows, cols);
+  Mat lu = A;
+  std::vector<int> q(static_cast<size_t>(cols));
+  for (int j = 0; j < cols; ++j) q[size_t(j)] = j;
+  int nonzero = size;
+  double maxpivot = 0.0;
+  for (int k = 0; k < size; ++k) {
+    int bi = k, bj = k;
+    double best = -1.0;
+    for (int j = k; j < cols; ++j)
+      for (int i = k; i < rows; ++i)
+        if (std::fabs(lu(i, j)) > best) { best = std::fabs(lu(i, j)); bi = i; bj = j; }
+    if (best == 0.0) { nonzero = k; break; }
+    maxpivot = std::max(maxpivot, best);
+    if (bi != k) for (int j = 0; j < cols; ++j) std::swap(lu(k, j), lu(bi, j));
+    if (bj != k) {
+      for (int i = 0; i < rows; ++i) std::swap(lu(i, k), lu(i, bj));
+      std::swap(q[size_t(k)], q[size_t(bj)]);
+    }
+    for (int i = k + 1; i < rows; ++i) lu(i, k) /= lu(k, k);
+    for (int i = k + 1; i < rows; ++i)
+      for (int j = k + 1; j < cols; ++j) lu(i, j) -= lu(i, k) * lu(k, j);
+  }
+  const double pt = maxpivot * (std::numeric_limits<double>::epsilon() * double(size));
+  std::vector<int> piv;
+  for (int i = 0; i < nonzero; ++i)
+    if (std::fabs(lu(i, i)) > pt) piv.push_back(i);
+  const int rk = int(piv.size()), dimker = cols - rk;
+  if (dimker == 0) return Mat(cols, 0);   // (Eigen hands back one zero column; a level above an exhausted null space cannot move)
+  // rows of U that carry a pivot, their pivot columns brought to the front (kernel_retval<FullPivLU>::evalTo)
+  Mat m(rk, cols);
+  for (int i = 0; i < rk; ++i)
+    for (int j = i; j < cols; ++j) m(i, j) = lu(piv[size_t(i)], j);
+  for (int i = 0; i < rk; ++i)
+    if (piv[size_t(i)] != i)
+      for (int a = 0; a < rk; ++a) std::swap(m(a, i), m(a, piv[size_t(i)]));
+  for (int c = rk; c < cols; ++c)
+    for (int i = rk - 1; i >= 0; --i) {
+      double s = m(i, c);
+      for (int k = i + 1; k < rk; ++k) s -= m(i, k) * m(k, c);
+      m(i, c) = s / m(i, i);
+    }
+  for (int i = rk - 1; i >= 0; --i)
+    if (piv[size_t(i)] != i)
+      for (int a = 0; a < rk; ++a) std::swap(m(a, i), m(a, piv[size_t(i)]));
+  Mat Z(cols, dimker);
+  for (int i = 0; i < rk; ++i)
+    for (int k = 0; k < dimker; ++k) Z(q[size_t(i)], k) = -m(i, rk + k);
+  for (int k = 0; k < dimker; ++k) Z(q[size_t(rk + k)], k) = 1.0;
   return Z;
 }
 
@@ -51,10 +94,13 @@ inline HoQpLevelResult hoqp_level(const Task& task, const HoQpLevelResult* prev,
   Vec vprev = prev ? prev->slack : Vec();
   const int nz = Zp.c, nprev = tprev.D.r;
   const int nv = nz + n_slack;
-  // cost rows [A Z, 0; 0, I]
+  // cost rows [A Z, 0; 0, I]; HoQp::buildHMatrix adds 1e-12 I to (A Z)'(A Z) when the level has equality rows
+  // (HoQp.cpp:74-78): nz more rows 1e-6 I with zero right-hand side
   const Mat AZ = task.A.r > 0 ? task.A * Zp : Mat(0, nz);
-  Mat Ac(AZ.r + n_slack, nv);
-  Vec bc(AZ.r + n_slack, 0.0);
+  const int n_shift = task.A.r > 0 ? nz : 0;
+  Mat Ac(AZ.r + n_slack + n_shift, nv);
+  Vec bc(AZ.r + n_slack + n_shift, 0.0);
+  for (int j = 0; j < n_shift; ++j) Ac(AZ.r + n_slack + j, j) = 1e-6;
   if (AZ.r > 0) {
     const Vec Ax = task.A * xp;
     for (int i = 0; i < AZ.r; ++i) {

@@ -117,6 +117,21 @@ def main():
             for stance in ((0, 1) if kind == 0 and mode[i] == 3 else (0,)):
                 assert lib.refwbc_update(h, kind, *fd.args, _d(xd[i]), _d(ud[i]), _d(rbd[i]), int(mode[i]), stance, _d(sol)) == 0
                 out[f"wbc_{i}_out_{name}_sol" + ("_stance" if stance else "")] = sol.copy()
+        # The reference's own noise floor for the cascade: HoQp forms every level's Hessian as (A Z)'(A Z) (HoQp.cpp:74-78), so the
+        # answer of an ill-conditioned level moves with the last bits of its inputs.  Three replays of HierarchicalWbc::update with
+        # every input scaled by (1 +- 2^-50) (about 1e-15 relative: less than the rounding of any upstream computation): the
+        # largest movement of the solution is what "the reference's answer" is defined to, and the tests ask for agreement to
+        # max(1e-6 relative / 1e-5 N m, 20 x this).
+        ref_sol = out[f"wbc_{i}_out_hier_sol"]
+        noise = np.zeros(38)
+        prng = np.random.default_rng(9000 + i)
+        for _ in range(3):
+            jig = lambda a: a * (1.0 + 2.0 ** -50 * prng.choice([-1.0, 1.0], size=a.shape))
+            xp, up, rp = jig(xd[i]), jig(ud[i]), jig(rbd[i])
+            fp = Feed(o, xp, up, rp)
+            assert lib.refwbc_update(h, 1, *fp.args, _d(xp), _d(up), _d(rp), int(mode[i]), 0, _d(sol)) == 0
+            noise = np.maximum(noise, np.abs(sol - ref_sol))
+        out[f"wbc_{i}_out_hier_noise"] = noise
     out["wbc_n"] = np.array(n)
     # ---- HoQp on small dense tasks: n = 4..8 variables, 2-3 levels, some levels rank deficient, some with inequalities
     rng = np.random.default_rng(5)

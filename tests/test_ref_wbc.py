@@ -11,12 +11,12 @@ priority inequalities, null-space projection through FullPivLU::kernel()).
 CPU tests hold the ORACLE to the vectors; the -m gpu tests hold the DEVICE (through the C-ABI) to the same vectors.
 
 Tolerances.  Task rows: 1e-12 (same arithmetic on the same inputs).  WeightedWbc solution: 1e-6 relative, torques 1e-6 N m.
-HierarchicalWbc / HoQp solutions: the cascade regularises each level in the coordinates of its null-space basis (the
-reference: LU kernel basis, not orthonormal; oracle / device: orthonormal bases), so where a level is ill-conditioned — single
-support asks for six base accelerations through a line contact and gets the sixth from swing-leg reaction, with joint
-accelerations of 1e2..1e4 rad/s^2 — the minimisers differ at the level of the regularisation: they are compared at 1e-3
-relative to |x|_inf, torques at 2e-3 N m, and through basis-independent quantities: every level's residual VECTOR at
-1e-4 relative.
+HierarchicalWbc / HoQp solutions: 1e-6 relative to |x|_inf, torques 1e-5 N m, every level's residual vector
+1e-6 relative — on ALL cases, single support and flight included (joint accelerations up to 3.4e3 rad/s^2).  This needs the
+cascade to regularise every level in the REFERENCE's coordinates: oracle and device take Eigen's FullPivLU::kernel() basis
+(HoQp.cpp:162) and the 1e-12 I of HoQp::buildHMatrix (HoQp.cpp:78) — with the orthonormal bases of rounds 1-3 the same cases
+agreed to 1e-3 only.  The oracle lands within 2e-10 of the compiled reference cascade, i.e. on the reference's own noise floor
+(the golden file carries it: the movement of the reference's answer under a 2^-50 jiggle of its inputs).
 """
 from pathlib import Path
 
@@ -103,13 +103,17 @@ def _check_weighted(sol, gold, i, tag="weighted_sol"):
 
 
 def _check_hier(sol, gold, i):
+    """SURVEY.md 8d tolerance for the WBC: 1e-6 relative on the solution, 1e-5 N m on the torques — or 20 x the reference's OWN
+    movement under a 2^-50 relative jiggle of its inputs (wbc_<i>_out_hier_noise, tests/golden/make_ref_wbc.py), whichever is
+    larger (it never is on the committed cases: the floor is 1e-12 .. 5e-10)."""
     ref = gold[f"wbc_{i}_out_hier_sol"]
+    noise = gold[f"wbc_{i}_out_hier_noise"]
     scale = max(1.0, np.abs(ref).max())
-    assert np.abs(sol - ref).max() / scale < 1e-3, (i, np.abs(sol - ref).max(), scale)
-    assert np.abs(sol[28:] - ref[28:]).max() < 2e-3
+    assert np.abs(sol - ref).max() < max(1e-6 * scale, 20 * noise.max()), (i, np.abs(sol - ref).max(), scale)
+    assert np.abs(sol[28:] - ref[28:]).max() < max(1e-5, 20 * noise[28:].max()), (i, np.abs(sol[28:] - ref[28:]).max())
     for l, lv in enumerate(_levels(gold, i)):
         r_mine, r_ref = lv["A"] @ sol - lv["b"], lv["A"] @ ref - lv["b"]
-        assert np.abs(r_mine - r_ref).max() < 1e-4 * max(1.0, np.abs(lv["b"]).max(), np.abs(r_ref).max()), (i, l)
+        assert np.abs(r_mine - r_ref).max() < 1e-6 * max(1.0, np.abs(lv["b"]).max(), np.abs(r_ref).max()), (i, l)
         if lv["D"].shape[0]:
             assert (lv["D"] @ sol - lv["f"]).max() < 1e-6
 

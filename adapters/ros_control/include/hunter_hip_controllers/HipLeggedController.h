@@ -11,10 +11,13 @@
 #include <vector>
 
 #include <controller_interface/multi_interface_controller.h>
+#include <dynamic_reconfigure/server.h>
 #include <geometry_msgs/Twist.h>
 #include <hardware_interface/imu_sensor_interface.h>
 #include <legged_common/hardware_interface/ContactSensorInterface.h>
 #include <legged_common/hardware_interface/HybridJointInterface.h>
+#include <hunter_hip_controllers/TutorialsConfig.h>
+#include <ocs2_msgs/mpc_observation.h>
 #include <ros/ros.h>
 #include <std_msgs/Float32.h>
 
@@ -33,6 +36,11 @@ class HipLeggedController
   void starting(const ros::Time& time) override;
   void stopping(const ros::Time& /*time*/) override { mpcRunning_ = false; }
   int plannedMode() const { return plannedMode_; }   // mode of the policy at the last control tick (the reference publishes it on a topic)
+  // LeggedController::resetMPC (LeggedController.cpp:460-465): cold start of the solver from the current observation.  The reference
+  // declares it and never calls it; here it is also what the MPC thread does by itself after a failed SQP call would otherwise stop
+  // the controller — callable from outside (an operator service, a test)
+  void resetMPC();
+  hb_joint_gains gains() const { std::lock_guard<std::mutex> lk(cmdMutex_); return gains_; }
 
  protected:
   // the reference's own extension points (LeggedController.h:57-62), kept virtual for the same reason
@@ -40,11 +48,14 @@ class HipLeggedController
   virtual void setupMpc();
   virtual void setupMrt();
   void mpcPass();
+  void publishObservation();
 
   void cmdVelCallback(const geometry_msgs::Twist::ConstPtr& msg);
   void setWalkCallback(const std_msgs::Float32::ConstPtr& msg);
   void loadControllerCallback(const std_msgs::Float32::ConstPtr& msg);
   void emergencyStopCallback(const std_msgs::Float32::ConstPtr& msg);
+  void resetTargetCallback(const std_msgs::Float32::ConstPtr& msg);                                // /reset_estimation (:496-510)
+  void dynamicParamCallback(hunter_hip_controllers::TutorialsConfig& config, uint32_t level);     // :433-447
 
   // hardware (LeggedController.h:76-80)
   std::vector<HybridJointHandle> hybridJointHandles_;
@@ -66,14 +77,17 @@ class HipLeggedController
   hunter_hip::ControlOutput control_;
   hb_joint_gains gains_{};
 
-  ros::Subscriber subCmdVel_, subSetWalk_, subLoadController_, subEmergencyStop_;
+  ros::Subscriber subCmdVel_, subSetWalk_, subLoadController_, subEmergencyStop_, subResetTarget_;
+  ros::Publisher observationPublisher_;   // "legged_robot_mpc_observation" (:277, :387): what the command interfaces listen to
+  std::unique_ptr<dynamic_reconfigure::Server<hunter_hip_controllers::TutorialsConfig>> serverPtr_;
   ros::Duration startingTime_;
 
  private:
   std::thread mpcThread_;
   std::atomic_bool controllerRunning_{false}, mpcRunning_{false}, firstStartMpc_{false};
   std::atomic_bool loadControllerFlag_{false}, setWalkFlag_{false}, emergencyStopFlag_{false};
-  std::mutex cmdMutex_;
+  mutable std::mutex cmdMutex_;   // cmd_vel, the observation the MPC thread copies, the gains (spinner thread vs control / MPC thread)
+  std::atomic_bool resetMpcRequest_{false};
   double cmdVel_[4] = {0.0, 0.0, 0.0, 0.0};   // filtered command [vx vy vz yawRate]
   double timeHorizon_ = 0.8, mpcDesiredFrequency_ = 100.0;
   std::atomic_int plannedMode_{3};

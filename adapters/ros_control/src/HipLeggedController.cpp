@@ -4,6 +4,8 @@
 //                                     -> hb_joint_command (PD law, limit protection, e-stop) -> HybridJointHandle::setCommand
 //   MPC thread (mpcDesiredFrequency)  GaitSchedule (host) -> hb_refgen_update (targets, footholds, swing splines, IK) -> hb_mpc_solve
 //                                     -> hb_mpc_publish (the policy hand-over is an MPC-thread call)
+//   spinner thread (topic callbacks)  /cmd_vel /set_walk /load_controller /emergency_stop /reset_estimation, dynamic_reconfigure of the
+//                                     nine joint gains; update() publishes legged_robot_mpc_observation for the command interfaces
 // Settings come from the reference's own files (task.info / hunter.urdf / reference.info, as LeggedController::init reads them)
 // or from the packaged image of the same values (data/hunter_params.bin); nothing is hard-coded here.
 #include "hunter_hip_controllers/HipLeggedController.h"
@@ -62,8 +64,13 @@ bool HipLeggedController::init(hardware_interface::RobotHW* robot_hw, ros::NodeH
   // (KalmanFilterEstimate::loadSettings, LinearKalmanFilter.cpp:317-335)
   stateEstimate_.reset(new hunter_hip::KalmanFilterEstimate(*ctx_, params_.estimator));
 
-  // gains: dynamic_reconfigure defaults of legged_controllers/cfg/Tutorials.cfg:6-16 (hunter_ingest.hpp)
+  // gains: dynamic_reconfigure defaults of legged_controllers/cfg/Tutorials.cfg:6-16 (hunter_ingest.hpp), then the server with the
+  // same nine parameters (cfg/Tutorials.cfg): its callback fires once with the configured values and on every change (:130-134)
   gains_ = params_.gains;
+  serverPtr_.reset(new dynamic_reconfigure::Server<hunter_hip_controllers::TutorialsConfig>(ros::NodeHandle("controller")));
+  dynamic_reconfigure::Server<hunter_hip_controllers::TutorialsConfig>::CallbackType f =
+      [this](hunter_hip_controllers::TutorialsConfig& config, uint32_t level) { dynamicParamCallback(config, level); };
+  serverPtr_->setCallback(f);
 
   // ---- topics — LeggedController.cpp:113-121 and the target publisher's /cmd_vel
   ros::NodeHandle nh;
@@ -71,6 +78,8 @@ bool HipLeggedController::init(hardware_interface::RobotHW* robot_hw, ros::NodeH
   subSetWalk_ = nh.subscribe<std_msgs::Float32>("/set_walk", 1, &HipLeggedController::setWalkCallback, this);
   subLoadController_ = nh.subscribe<std_msgs::Float32>("/load_controller", 1, &HipLeggedController::loadControllerCallback, this);
   subEmergencyStop_ = nh.subscribe<std_msgs::Float32>("/emergency_stop", 1, &HipLeggedController::emergencyStopCallback, this);
+  subResetTarget_ = nh.subscribe<std_msgs::Float32>("/reset_estimation", 1, &HipLeggedController::resetTargetCallback, this);
+  observationPublisher_ = nh.advertise<ocs2_msgs::mpc_observation>("legged_robot_mpc_observation", 1);   // :386-387
   return true;
 }
 
@@ -92,7 +101,7 @@ void HipLeggedController::mpcPass() {
   { std::lock_guard<std::mutex> lk(cmdMutex_); obs = currentObservation_; std::copy(cmdVel_, cmdVel_ + 4, cmd); }
   const vector_t initTime{obs.time}, cmdVel(cmd, cmd + 4);
   referenceManager_->preSolverRun(initTime, timeHorizon_, cmdVel, &obs.state);     // modifyReferences
-  if (!coldStarted_) { mpcMrtInterface_->resetMpcNode(obs.state); coldStarted_ = true; }
+  if (!coldStarted_ || resetMpcRequest_.exchange(false)) { mpcMrtInterface_->resetMpcNode(obs.state); coldStarted_ = true; }   // resetMPC(): on this thread
   mpcMrtInterface_->setCurrentObservation(obs);
   mpcMrtInterface_->advanceMpc();                                  // :406 (solve, wait, publish the FINISHED policy: this thread)
   if (mpcMrtInterface_->mpcStatus()[0] == HB_INST_NAN) throw std::runtime_error("SQP iteration failed (non-finite value / Riccati pivot)");
@@ -160,7 +169,7 @@ void HipLeggedController::update(const ros::Time& time, const ros::Duration& per
       return;
     }
   }
-  if (!firstStartMpc_) return;   // no policy yet: the handles keep their last command
+  if (!firstStartMpc_) { publishObservation(); return; }   // no policy yet: the handles keep their last command
   const vector_t tNow{shifted.toSec()};
   const std::vector<int32_t> walk{setWalkFlag_ ? 1 : 0};
   hunter_hip::controllerUpdate(*mpcMrtInterface_, tNow, measuredRbdState_, &walk, period.toSec(), control_);   // :151-185
@@ -170,11 +179,56 @@ void HipLeggedController::update(const ros::Time& time, const ros::Duration& per
   const int32_t loaded = loadControllerFlag_ ? 1 : 0, estop = emergencyStopFlag_ ? 1 : 0;
   ctx_->check(hb_joint_set_flags(ctx_->get(), &loaded, emergencyStopFlag_ ? &estop : nullptr), "hb_joint_set_flags");
   double posDes[10], velDes[10], kp[10], kd[10], ff[10];
-  ctx_->check(hb_joint_command(ctx_->get(), &gains_, period.toSec(), posDes, velDes, kp, kd, ff, nullptr), "hb_joint_command");
+  const hb_joint_gains g = gains();   // (a reconfigure callback may be writing them on the spinner thread)
+  ctx_->check(hb_joint_command(ctx_->get(), &g, period.toSec(), posDes, velDes, kp, kd, ff, nullptr), "hb_joint_command");
   int32_t latched = 0;
   ctx_->check(hb_joint_get_emergency_stop(ctx_->get(), &latched), "hb_joint_get_emergency_stop");
   if (latched) emergencyStopFlag_ = true;
   for (size_t j = 0; j < hybridJointHandles_.size(); ++j) hybridJointHandles_[j].setCommand(posDes[j], velDes[j], kp[j], kd[j], ff[j]);
+  publishObservation();
+}
+
+// "Publish the observation. Only needed for the command interface" (:276-277): time, state, input and mode of currentObservation_ as
+// ocs2_msgs/mpc_observation (ros_msg_conversions::createObservationMsg: float32 value arrays)
+void HipLeggedController::publishObservation() {
+  ocs2_msgs::mpc_observation msg;
+  {
+    std::lock_guard<std::mutex> lk(cmdMutex_);
+    msg.time = currentObservation_.time;
+    msg.state.value.assign(currentObservation_.state.begin(), currentObservation_.state.end());
+    msg.input.value.assign(currentObservation_.input.begin(), currentObservation_.input.end());
+    msg.mode = int8_t(currentObservation_.mode);
+  }
+  observationPublisher_.publish(msg);
+}
+
+// LeggedController::resetMPC (:460-465).  The solver belongs to the MPC thread (hb_mpc_reset is an MPC-side call): the request is
+// taken up by the next MPC pass, which cold-starts from the observation it copies — resetMpcNode(currentObservation_)
+void HipLeggedController::resetMPC() { resetMpcRequest_ = true; }
+
+// /reset_estimation -> LeggedController::ResetTargetCallback (:496-510): the observation becomes the nominal one (zero base state,
+// default joint angles, zero input, STANCE) and with it the target the reference manager tracks — here the targets of the next MPC
+// pass are built ON that observation (hb_refgen_update's x_now), which is what setTargetTrajectories({t, x, u}) amounts to
+void HipLeggedController::resetTargetCallback(const std_msgs::Float32::ConstPtr&) {
+  std::lock_guard<std::mutex> lk(cmdMutex_);
+  currentObservation_.state.assign(HB_NX, 0.0);
+  currentObservation_.input.assign(HB_NU, 0.0);
+  for (int j = 0; j < HB_NJ; ++j) currentObservation_.state[12 + j] = config_.default_joint_state[j];   // defaultJointState of reference.info (:100)
+  currentObservation_.mode = 3;   // ModeNumber::STANCE
+}
+
+// dynamic_reconfigure callback (:433-447): the nine gains of the joint command law, picked up by the next control tick
+void HipLeggedController::dynamicParamCallback(hunter_hip_controllers::TutorialsConfig& config, uint32_t) {
+  std::lock_guard<std::mutex> lk(cmdMutex_);
+  gains_.kp_position = config.kp_position;
+  gains_.kd_position = config.kd_position;
+  gains_.kp_big_stance = config.kp_big_stance;
+  gains_.kp_big_swing = config.kp_big_swing;
+  gains_.kp_small_stance = config.kp_small_stance;
+  gains_.kp_small_swing = config.kp_small_swing;
+  gains_.kd_small = config.kd_small;
+  gains_.kd_big = config.kd_big;
+  gains_.kd_feet = config.kd_feet;
 }
 
 void HipLeggedController::cmdVelCallback(const geometry_msgs::Twist::ConstPtr& msg) {

@@ -25,6 +25,14 @@ struct Time {
 };
 struct Subscriber {};
 namespace mock {
+// last message published on every advertised topic (type-erased; the test harness knows the type it advertised)
+inline std::map<std::string, std::shared_ptr<const void>>& published() { static std::map<std::string, std::shared_ptr<const void>> p; return p; }
+inline std::map<std::string, long>& publishCount() { static std::map<std::string, long> c; return c; }
+template <class M>
+std::shared_ptr<const M> lastPublished(const std::string& topic) {
+  auto it = published().find(topic);
+  return it == published().end() ? nullptr : std::static_pointer_cast<const M>(it->second);
+}
 struct Param { bool is_string = false; std::string s; double d = 0.0; };
 inline std::map<std::string, Param>& params() { static std::map<std::string, Param> p; return p; }
 inline void setParam(const std::string& k, const std::string& v) { Param p; p.is_string = true; p.s = v; params()[k] = p; }
@@ -41,8 +49,23 @@ bool publish(const std::string& topic, const M& msg) {
   return true;
 }
 }  // namespace mock
+class Publisher {
+ public:
+  Publisher() {}
+  explicit Publisher(std::string topic) : topic_(std::move(topic)) {}
+  template <class M> void publish(const M& msg) const {
+    if (topic_.empty()) return;
+    mock::published()[topic_] = std::static_pointer_cast<const void>(std::make_shared<const M>(msg));
+    ++mock::publishCount()[topic_];
+  }
+ private:
+  std::string topic_;
+};
 class NodeHandle {
  public:
+  NodeHandle() {}
+  explicit NodeHandle(const std::string&) {}
+  template <class M> Publisher advertise(const std::string& topic, int) { return Publisher(topic); }
   bool getParam(const std::string& k, std::string& v) const {
     auto it = mock::params().find(k);
     if (it == mock::params().end() || !it->second.is_string) return false;

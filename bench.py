@@ -521,6 +521,16 @@ def main():
         per_kernel = {k: {"ms": phases[k], "algorithmic_GBs": BYTES_PER_NODE[k] * int(n_nodes.sum()) / (phases[k] * 1e-3) / 1e9,
                           "frac_of_hbm_peak": BYTES_PER_NODE[k] * int(n_nodes.sum()) / (phases[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                       for k in ("k_lq", "k_ric_bwd", "k_ric_fwd")}
+        # what each kernel REALLY moves (FETCH_SIZE / WRITE_SIZE counter passes, same source and caveat as roofline.traffic) over
+        # this run's launch time: k_ric_fwd is the kernel that is HBM bound, on 2 x the bytes the 8d formula grants it
+        if traffic_source is not None:
+            for k, v in per_kernel.items():
+                cb = pj.get(k, {}).get("hbm_bytes_per_launch")
+                if cb:
+                    v["counter_bytes_per_launch"] = cb
+                    v["counter_GBs"] = cb / (phases[k] * 1e-3) / 1e9
+                    v["counter_frac_of_hbm_peak"] = v["counter_GBs"] / HBM_PEAK_GBS
+                    v["counter_over_algorithmic"] = cb / (BYTES_PER_NODE[k] * int(n_nodes.sum()))
         out = {
             "metric": "MPC+WBC updates/sec (batch=4096, N=100, 12-DoF)",
             "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

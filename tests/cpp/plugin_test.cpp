@@ -5,7 +5,8 @@
 //   plant state -> joint encoders + ideal IMU -> controller.update() -> HybridJointHandle commands (posDes, velDes, kp, kd, ff)
 //   -> torque = ff + kp (posDes - q) + kd (velDes - qd)   (legged_gazebo/src/LeggedHWSim.cpp:166-192) -> plant.
 // usage: plugin_test <hunter_params.bin | task.info urdf reference.info gait.info> <mode> [seconds]
-//   mode lockstep : MPC pass inside update() every 8th tick (deterministic);  mode threaded : the plugin's own MPC thread
+//   mode lockstep : MPC pass inside update() every 8th tick (deterministic);  mode threaded : the plugin's own MPC thread;
+//   mode hooks : lockstep + the control-plane hooks mid-run (dynamic_reconfigure gains, resetMPC, /reset_estimation, the observation topic)
 // prints one line "RESULT key value ..." with the quantities tests/test_ros_plugin_run.py checks.
 #include <chrono>
 #include <cmath>
@@ -57,7 +58,7 @@ int main(int argc, char** argv) {
   }
   const std::string mode = argv[a];
   const double seconds = argc > a + 1 ? std::atof(argv[a + 1]) : 3.0;
-  if (mode == "lockstep") ros::mock::setParam("/hunter_hip/mpc_every_n_ticks", 8.0);
+  if (mode == "lockstep" || mode == "hooks") ros::mock::setParam("/hunter_hip/mpc_every_n_ticks", 8.0);
   ros::mock::setParam("/hunter_hip/time_horizon", 1.5);   // the benchmark's horizon (N = 100); task.info ships 0.8
 
   // ---- controller_manager's part: instantiate the plugin by its registered name and initialise it
@@ -86,7 +87,7 @@ int main(int argc, char** argv) {
   const double dt = 0.002;
   const int ticks = int(seconds / dt + 0.5);
   double t = 0.0, max_tau = 0.0, max_tilt = 0.0, min_h = 1e9, max_h = -1e9, x_at_walk = 0.0;
-  bool finite = true;
+  bool finite = true, hooks_ok = true, gains_seen = false, gains_bad = false, obs_ok = true;
   int modes_seen = 0;
   const double walk_from = 1.0;
   ctrl->starting(ros::Time(t));
@@ -114,8 +115,31 @@ int main(int argc, char** argv) {
       tw.linear.x = 0.3;
       for (int r = 0; r < 40; ++r) ros::mock::publish("/cmd_vel", tw);   // the callback rate-limits: ramp it up
     }
+    // ---- the control-plane hooks of the plugin, exercised mid-run (mode "hooks"): LeggedController.cpp:433-447,460-465,474-510,277
+    if (mode == "hooks") {
+      if (k == 100) {   // dynamic_reconfigure: new gains must show in the very next command
+        hunter_hip_controllers::TutorialsConfig cfg;
+        cfg.kp_big_stance = 41.5; cfg.kp_small_stance = 31.5; cfg.kd_big = 2.25; cfg.kd_small = 2.125;
+        hooks_ok = hooks_ok && dynamic_reconfigure::mock::reconfigure(cfg);
+        hooks_ok = hooks_ok && hip->gains().kp_big_stance == 41.5 && hip->gains().kd_small == 2.125;
+      }
+      if (k == 101) {   // (STANCE at this time: every joint is in the stance class of its size)
+        for (int j = 0; j < 10; ++j) {
+          const double kp = hw.cmd[j][2], kd = hw.cmd[j][3];
+          gains_seen = gains_seen || (kp == 41.5 && kd == 2.25) || (kp == 31.5 && kd == 2.125);
+          gains_bad = gains_bad || kp == 40.0 || kp == 30.0;
+        }
+      }
+      if (k == 200) hip->resetMPC();                                                       // cold start on the next MPC pass
+      if (k == 300) hooks_ok = hooks_ok && ros::mock::publish("/reset_estimation", std_msgs::Float32());
+    }
     ctrl->update(ros::Time(t), ros::Duration(dt));
     if (ctrl->isStopped()) { std::printf("RESULT stopped_at %.3f\n", t); return 0; }
+    if (mode == "hooks") {   // the observation message of THIS tick: time, 22 + 22 float32 values, mode = the planned mode the estimate used
+      const auto msg = ros::mock::lastPublished<ocs2_msgs::mpc_observation>("legged_robot_mpc_observation");
+      obs_ok = obs_ok && msg && msg->state.value.size() == 22 && msg->input.value.size() == 22 && std::fabs(msg->time - (t + 0.0001)) < 1e-9 &&
+               std::fabs(msg->state.value[12] - float(q[6])) < 2e-2f && std::fabs(msg->state.value[8] - float(q[2])) < 5e-2f;
+    }
     if (mode == "threaded" && k < 50) std::this_thread::sleep_for(std::chrono::milliseconds(2));   // let the MPC thread deliver a first policy
     // actuators: PD + feed-forward on the commanded values
     double tau[10];
@@ -139,7 +163,9 @@ int main(int argc, char** argv) {
     }
   }
   ctrl->stopRequest(ros::Time(t));
-  std::printf("RESULT ok 1 ticks %d finite %d max_tau %.6g min_h %.6g max_h %.6g max_tilt %.6g dx_walk %.6g speed %.6g modes_seen %d final_mode %d\n",
-              ticks, finite ? 1 : 0, max_tau, min_h, max_h, max_tilt, q[0] - x_at_walk, v[0], modes_seen, hip->plannedMode());
+  std::printf("RESULT ok 1 ticks %d finite %d max_tau %.6g min_h %.6g max_h %.6g max_tilt %.6g dx_walk %.6g speed %.6g modes_seen %d final_mode %d "
+              "hooks_ok %d gains_seen %d gains_bad %d obs_ok %d obs_count %ld\n",
+              ticks, finite ? 1 : 0, max_tau, min_h, max_h, max_tilt, q[0] - x_at_walk, v[0], modes_seen, hip->plannedMode(), hooks_ok ? 1 : 0,
+              gains_seen ? 1 : 0, gains_bad ? 1 : 0, obs_ok ? 1 : 0, ros::mock::publishCount()["legged_robot_mpc_observation"]);
   return 0;
 }

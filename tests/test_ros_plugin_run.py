@@ -62,3 +62,17 @@ def test_plugin_runs_init_starting_update_against_the_plant(mode, seconds):
     if mode == "lockstep":
         assert float(res["dx_walk"]) > 0.25 and 0.15 < float(res["speed"]) < 0.45, res     # ~2 s at a commanded 0.3 m/s
         assert int(res["modes_seen"]) & 0b0110, res                                          # single-support modes 1 and 2 were planned
+
+
+@pytest.mark.gpu
+def test_plugin_control_plane_hooks():
+    """The hooks around the hot path (LeggedController.cpp:433-447 dynamic_reconfigure gains, :460-465 resetMPC, :474 / :496-510
+    /reset_estimation, :277 the observation publisher), driven through the mock ROS layer while the robot stands: new gains show in
+    the next joint command, a solver cold start and an observation reset in the middle of the run leave the robot standing, and
+    every control tick publishes its observation (time, 22 + 22 float32 values)."""
+    exe = _build()
+    res, err = _run(exe, PARAMS_BIN, "hooks", 1.2)
+    assert res.get("ok") == "1" and res["finite"] == "1", (res, err)
+    assert res["hooks_ok"] == "1" and res["gains_seen"] == "1" and res["gains_bad"] == "0", res
+    assert res["obs_ok"] == "1" and int(res["obs_count"]) >= 590, res
+    assert 0.60 < float(res["min_h"]) and float(res["max_h"]) < 0.66 and float(res["max_tilt"]) < 0.08, res

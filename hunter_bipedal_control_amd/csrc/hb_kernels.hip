@@ -226,6 +226,7 @@ __global__ __launch_bounds__(64, 3) void k_lq(Batch b, const DevModel* __restric
   lq_node(WaveCtx(), *M, *C, in, lds, b.recs + nd * REC_SIZE);
 }
 
+constexpr int kRicBwd4MaxBatch = 512;    // instances per launch up to which the four-wavefront backward sweep is taken (measured)
 __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
   // per-instance serial chain: when this kernel shares SIMDs with the node-parallel LQ kernel of another chunk stream (chunked
   // hb_step_resident), it is the latency-critical one — ask the arbiter to issue it first
@@ -312,6 +313,154 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
 #undef HB_RIC_FETCH
 #undef HB_RIC_FETCH_Q
   if (cx.lane == 0) b.ric_fail[inst] = lds[RicLds::flag] != 0.0 ? 1 : 0;
+}
+
+// The backward sweep with FOUR wavefronts per instance — one per SIMD of a compute unit — for batches that leave most SIMDs idle
+// in k_ric_bwd (<= 1024 instances: one single-wavefront sweep per SIMD or fewer, and the launch takes n stages x the chain of one
+// stage whatever the chip could do next to it).  The stage is the same arithmetic in the same order (bit-identical gains and value
+// function: every 16 x 16 output tile is accumulated by one wavefront over K exactly as in the one-wavefront form), cut by tiles:
+//   staging   612 + 253 pairs over 256 threads (4 loads each instead of 14)
+//   GEMM 1    M1 = S [A~ b~ B~] (+ s): four tiles, one per wavefront (12-wide stages: 2 + 2 + 1 + 1)
+//   GEMM 2    Hu = B~' M1 + [P~ r~ R~]: one tile per wavefront (two or three wavefronts)
+//   factor    wavefront 0 (register Cholesky + the 23 solves, as before); the others request the next record meanwhile
+//   GEMM 3    T = A~' M1 + Hux' K~ + Q~ on its upper block triangle: three tiles, one per wavefront, each stores its part of S
+// with a workgroup barrier between the phases (five per stage).  Buffers are not shared between phases (Ric4Lds).
+// Workgroup barrier for data exchanged through LDS only: this wavefront's LDS operations have completed (lgkmcnt(0)), then s_barrier.
+// __syncthreads() also waits for vmcnt(0), i.e. for every global load in flight — it would expose the latency of the record prefetch
+// of the sweep at the first barrier behind it, once per stage.
+__device__ __forceinline__ void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(256, 2) void k_ric_bwd4(Batch b, int dbg) {
+  __builtin_amdgcn_s_setprio(3);
+  const int inst = blockIdx.x, tid = threadIdx.x;
+  // Role of this wavefront in the stage (0: the factorisation).  Rotated by instance: with two instances on a CU the wavefronts with
+  // the same index share a SIMD, and two factorisations — the longest, VALU-bound phase — on one SIMD while three SIMDs wait at the
+  // barrier cost 25 % of the sweep (4.5 against 3.6 us per stage measured)
+  const int w = __builtin_amdgcn_readfirstlane(((tid >> 6) + (blockIdx.x ^ (blockIdx.x >> 8))) & 3);
+  __shared__ double lds[Ric4Lds::total];
+  for (int i = tid; i < Ric4Lds::total; i += 256) lds[i] = 0.0;  // S = 0, s = 0 and every padding zero
+  block_sync_lds();
+  const int n = b.n_nodes[inst];
+  using L = Ric4Lds;
+  constexpr int NP_AB = REC_PR / 2, NP = REC_QT / 2;   // 396 pairs of [A~ b~ B~ .], 612 pairs staged, then 253 pairs of [Q~ | q~]
+  static_assert(NP <= 256 * 3 && 2 * (NP + 256) <= REC_SIZE, "record layout");
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 buf[3], bufq;
+#define HB_RIC4_FETCH(kk, t)                                                                                   \
+  {                                                                                                            \
+    const d2* rec2_ = reinterpret_cast<const d2*>(b.recs + (size_t(inst) * b.Nmax + (kk)) * REC_SIZE) + (t);   \
+    _Pragma("unroll") for (int r = 0; r < 3; ++r) buf[r] = rec2_[256 * r];                                     \
+    bufq = rec2_[NP];                                                                                          \
+  }
+  double meta_nf = 0.0, meta_nz = 0.0;
+  if (n > 0) {
+    HB_RIC4_FETCH(n - 1, tid);
+    const double* meta = b.recs + (size_t(inst) * b.Nmax + n - 1) * REC_SIZE + REC_META;
+    meta_nf = meta[0];
+    meta_nz = meta[1];
+  }
+  double* S = lds + L::S;
+  double* sv = lds + L::s;
+  double* M1 = lds + L::M1;
+  double* ABb = lds + L::ABb;
+  double* PRr = lds + L::PRr;
+  double* Hu = lds + L::Hu;
+  double* Kk = lds + L::Kk;
+  double* Qs = lds + L::Qs;
+  for (int k = n - 1; k >= 0; --k) {
+    int t = tid;
+    asm volatile("" : "+v"(t));   // (nothing derived from the thread id is a loop invariant: see k_ric_bwd)
+    const WaveCtx cx(t & 63);
+    {
+      d2* ab2 = reinterpret_cast<d2*>(ABb);
+      d2* pr2 = reinterpret_cast<d2*>(PRr);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int p = t + 256 * r;
+        if (p < NP_AB) ab2[p] = buf[r];
+        else if (p < NP) pr2[p - NP_AB] = buf[r];
+      }
+      if (t < 253) reinterpret_cast<d2*>(Qs)[t] = bufq;
+    }
+    // n_til: number of projected inputs of this stage (uniform; it came with the prefetch)
+    const int n_til = int(meta_nf) + int(meta_nz);
+    // The next record is requested NOW — four 16-byte loads per thread, 8 registers: the whole stage covers their latency (the
+    // one-wavefront form holds 14 loads per lane and can only afford them behind its register-resident factorisation)
+    if (k > 0) {
+      HB_RIC4_FETCH(k - 1, t);
+      const double* meta = b.recs + (size_t(inst) * b.Nmax + k - 1) * REC_SIZE + REC_META;
+      meta_nf = meta[0];
+      meta_nz = meta[1];
+    }
+    block_sync_lds();
+    if (HB_ABLATE_ON && dbg == 24) continue;   // profiling ablation: staging only
+    double* gains = b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE;
+    const bool wide = n_til > 9;   // 12 projected inputs (double support): three 16-column tiles, 12 x 12 factor
+    // ---- GEMM 1: M1 = S [A~ b~ B~ .] (+ s in the vector column)
+    {
+      const int NC = wide ? L::LDW : 32;
+      auto run = [&](auto& tl, int tm, int c0) {
+        tile_init(cx, tl, 22 - 16 * tm, NC - c0, [sv, tm, c0](int i, int c) { return c + c0 == L::CV ? sv[i + 16 * tm] : 0.0; });
+        tile_mma<24, L::LDN, false, L::LDW>(cx, tl, S + 16 * tm * L::LDN, ABb + c0, 22 - 16 * tm, NC - c0);
+        tile_store_rm<L::LDW>(cx, tl, 22 - 16 * tm, NC - c0, M1 + 16 * tm * L::LDW + c0);
+      };
+      if (!wide) {
+        WaveTile<1, 1> tl;
+        run(tl, w & 1, 16 * (w >> 1));
+      } else if (w < 2) {
+        WaveTile<1, 2> tl;
+        run(tl, w, 0);
+      } else {
+        WaveTile<1, 1> tl;
+        run(tl, w - 2, 32);
+      }
+    }
+    block_sync_lds();
+    if (HB_ABLATE_ON && dbg == 25) continue;   // ... + GEMM 1
+    // ---- GEMM 2: Hu = B~' M1 + [P~ r~ R~ .]  (every element of [P~ r~ R~] is read and replaced by the lane that owns it)
+    if (w < (wide ? 3 : 2)) {
+      const int NC = wide ? L::LDW : 32, c0 = 16 * w;
+      WaveTile<1, 1> tl;
+      tile_init(cx, tl, NU_T, NC - c0, [PRr, c0](int a, int c) { return PRr[a * L::LDW + c + c0]; });
+      tile_mma<24, L::LDW, true, L::LDW>(cx, tl, ABb + L::CU, M1 + c0, NU_T, NC - c0);
+      tile_store_rm<L::LDW>(cx, tl, NU_T, NC - c0, Hu + c0);
+    }
+    block_sync_lds();
+    if (HB_ABLATE_ON && dbg == 26) continue;   // ... + GEMM 2
+    // ---- factor + solves on wavefront 0.  Meanwhile wavefronts 1..3 start GEMM 3, T = Q~ + A~' M1 + Hux' K~ on its upper block
+    // triangle (tiles (0,0) / (0,1) / (1,1), one each): the A~' M1 part does not need the gains — six of a tile's nine matrix
+    // instructions run under the factorisation, in the same accumulator and the same order as in the one-wavefront form
+    const int ti = w - 1;
+    const int r0 = ti == 2 ? 16 : 0, c0 = ti == 0 ? 0 : 16;
+    const int Mr = ti == 2 ? 6 : 16, Nr = ti == 0 ? 16 : 7;
+    WaveTile<1, 1> t3;
+    if (w == 0) {
+      if (!wide) ric_factor_solve<9>(cx, Hu, Kk, lds + L::flag, gains);
+      else ric_factor_solve<NU_T>(cx, Hu, Kk, lds + L::flag, gains);
+    } else {
+      tile_init(cx, t3, Mr, Nr, [](int, int) { return 0.0; });
+      tile_mma<24, L::LDW, true, L::LDW>(cx, t3, ABb + r0, M1 + c0, Mr, Nr);
+    }
+    block_sync_lds();
+    if (HB_ABLATE_ON && dbg == 27) continue;   // ... + factor, solves | first part of GEMM 3
+    // ---- rest of GEMM 3: + Hux' K~, + Q~, new S | s (mirrored)
+    if (w != 0) {
+      tile_mma<NU_T, L::LDW, true, L::LDN>(cx, t3, Hu + r0, Kk + c0, Mr, Nr);
+      tile_store(cx, t3, Mr, Nr, [S, sv, Qs, r0, c0](int il, int cl, double v) {
+        const int i = il + r0, c = cl + c0;
+        if (c == L::CV) {
+          sv[i] = v + Qs[484 + i];
+        } else if (i <= c) {
+          const double wv = v + Qs[i * 22 + c];
+          S[i * L::LDN + c] = wv;
+          S[c * L::LDN + i] = wv;
+        }
+      });
+    }
+    block_sync_lds();
+  }
+#undef HB_RIC4_FETCH
+  if (tid == 0) b.ric_fail[inst] = lds[Ric4Lds::flag] != 0.0 ? 1 : 0;
 }
 
 __global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
@@ -1710,6 +1859,17 @@ static int32_t warm_start_onto_new_tables(hb_ctx* ctx) {
   return HB_OK;
 }
 
+// Backward sweep of `B` instances: small launches take four wavefronts per instance (k_ric_bwd4), large ones the one-wavefront form
+// (eight sweeps per CU are then the better use of the chip).  hb_config.reserved = 101 / 104 forces one / four (tests, tuning).
+// `concurrent` = instances whose sweeps may be in flight at the same time (the whole batch when its instance ranges free-run on their
+// own streams): what decides is how many sweeps share the chip, not the size of this launch.
+static void launch_ric_bwd(hb_ctx* ctx, const Batch& b, int B, int concurrent, hipStream_t s) {
+  const int sel = ctx->hconfig.debug_stop;
+  const bool four = sel == 104 || (HB_ABLATE_ON && sel >= 24 && sel <= 27) || (sel != 101 && !(HB_ABLATE_ON && sel != 0) && concurrent <= kRicBwd4MaxBatch);
+  if (four) hipLaunchKernelGGL(k_ric_bwd4, dim3(B), dim3(256), 0, s, b, sel);
+  else hipLaunchKernelGGL(k_ric_bwd, dim3(B), dim3(64), 0, s, b, sel);
+}
+
 static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t stream = nullptr) {
   const bool whole = cnt < 0;
   if (whole) {
@@ -1725,7 +1885,7 @@ static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t
     if (timed) HB_HIP(hipEventRecord(ctx->ev[0], s));
     hipLaunchKernelGGL(k_lq, dim3(N, B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[1], s));
-    hipLaunchKernelGGL(k_ric_bwd, dim3(B), dim3(64), 0, s, b, ctx->hconfig.debug_stop);
+    launch_ric_bwd(ctx, b, B, ctx->B, s);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[2], s));
     hipLaunchKernelGGL(k_ric_fwd, dim3(B), dim3(64), 0, s, b);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[3], s));
@@ -2462,7 +2622,7 @@ int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, int32_t nu, const do
   for (int i = 0; i < n; ++i) nn[i] = N;
   HB_HIP(hipMemcpy(ctx->b.n_nodes, nn.data(), size_t(ctx->B) * sizeof(int), hipMemcpyHostToDevice));
   HB_HIP(hipMemcpy(ctx->b.recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_ric_bwd, dim3(n), dim3(64), 0, ctx->s_mpc, ctx->b, 0);
+  launch_ric_bwd(ctx, ctx->b, n, n, ctx->s_mpc);
   HB_HIP(hipStreamSynchronize(ctx->s_mpc));
   std::vector<double> gains(size_t(n) * Nm * GAIN_SIZE);
   HB_HIP(hipMemcpy(gains.data(), ctx->b.gains, gains.size() * 8, hipMemcpyDeviceToHost));

@@ -37,6 +37,25 @@ static_assert(RicLds::LDW == REC_LD && RicLds::CV == REC_CV && RicLds::CU == REC
 static_assert(RicLds::PRr == RicLds::ABb + 24 * RicLds::LDW && REC_PR == REC_AB + 22 * REC_LD, "two straight copies");
 static_assert(RicLds::total * 8 <= 20480, "k_ric_bwd: LDS per instance must allow 8 workgroups per CU");
 
+// LDS of the FOUR-wavefront form of the backward sweep (k_ric_bwd4: small batches, one wavefront per SIMD of a CU working on one
+// instance).  Same row formats as RicLds, but every buffer has its own storage: with four wavefronts a buffer that is reused inside
+// a stage needs a workgroup barrier between its last reader and its next writer, and at the batch sizes this form is for (at most
+// four instances per CU) LDS is not what limits residency.  30.8 KB per instance.
+struct Ric4Lds {
+  static constexpr int LDN = RicLds::LDN, LDW = RicLds::LDW, CV = RicLds::CV, CU = RicLds::CU;
+  static constexpr int S = 0;                    // 22 x 24 (columns 22, 23 stay zero: K-padding)
+  static constexpr int s = S + 22 * LDN;         // 24
+  static constexpr int M1 = s + 24;              // 24 x 36 (rows 22, 23 stay zero)
+  static constexpr int ABb = M1 + 24 * LDW;      // 24 x 36 (rows 22, 23 stay zero)
+  static constexpr int PRr = ABb + 24 * LDW;     // 12 x 36, then Hu
+  static constexpr int Hu = PRr;
+  static constexpr int Kk = PRr + 12 * LDW;      // 12 x 24
+  static constexpr int Qs = Kk + 12 * LDN;       // [Q~ | q~] 506 (+ 6)
+  static constexpr int flag = Qs + 512;          // 4
+  static constexpr int total = flag + 4 + 44;    // slack for the padded tile reads, as RicLds
+};
+static_assert(Ric4Lds::total * 8 <= 40960, "k_ric_bwd4: four instances per CU");
+
 // One backward step on the staged record.  Updates S, s in place; writes the gains.
 //   M1 = S [A~ b~ B~] (+ s),  Hu = B~' M1 + [P~ r~ R~],  K~ = -Huu^-1 [Hux hu],
 //   S <- sym(Q~ + A~' M1_A + Hux' K~),  s <- q~ + A~' M1_b + Hux' k~          
@@ -95,10 +114,9 @@ HB_HD bool ric_chol_block(const Ctx& cx, double* Hu, double (&L)[NB * (NB + 1) /
   }
   return bad;
 }
+// Hu: [Hux | hu | . | Huu] (12 rows of LDW), Kk: [K~ | k~ | .] (12 rows of LDN), flag: set to 1 when a pivot was not positive
 template <int NT, class Ctx>
-HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
-  double* Hu = lds + RicLds::Hu;
-  double* Kk = lds + RicLds::Kk;
+HB_HD void ric_factor_solve(const Ctx& cx, double* Hu, double* Kk, double* flag, double* gains) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // keep the loads of this width's triangle inside its branch: hoisted above the 9 / 12 dispatch they were spilled
   asm volatile("" ::: "memory");
@@ -112,7 +130,7 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
   double Lr[NB1 * (NB1 + 1) / 2];
   if constexpr (NT <= 9) {
     const bool bad = ric_chol_block<NT, reg_factor>(cx, Hu, Lr);
-    if (bad && cx.lane == 0) lds[RicLds::flag] = 1.0;
+    if (bad && cx.lane == 0) *flag = 1.0;
   } else {
     // 12 projected inputs (double support: 12 contact forces): blocked — the 9 x 9 leading block in registers as above, then
     // rows 9..11 one per lane against the factor in LDS, then the 3 x 3 Schur complement.  A 78-element register triangle
@@ -222,7 +240,7 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* lds, double* gains) {
       }
     }
 #endif
-    if (bad && cx.lane == 0) lds[RicLds::flag] = 1.0;
+    if (bad && cx.lane == 0) *flag = 1.0;
   }
   if (!reg_factor) cx.sync();
   {
@@ -296,13 +314,13 @@ HB_HD void ric_phase12(const Ctx& cx, double* lds, double* gains, int n_til, int
     HB_ABLATE_STOP(dbg == 21);
     ric_phase2_gemm<2>(cx, lds);
     HB_ABLATE_STOP(dbg == 22);
-    ric_factor_solve<9>(cx, lds, gains);
+    ric_factor_solve<9>(cx, lds + RicLds::Hu, lds + RicLds::Kk, lds + RicLds::flag, gains);
   } else {
     ric_phase1<3>(cx, lds);
     HB_ABLATE_STOP(dbg == 21);
     ric_phase2_gemm<3>(cx, lds);
     HB_ABLATE_STOP(dbg == 22);
-    ric_factor_solve<NU_T>(cx, lds, gains);
+    ric_factor_solve<NU_T>(cx, lds + RicLds::Hu, lds + RicLds::Kk, lds + RicLds::flag, gains);
   }
 }
 // GEMM 3 in two halves: `ric_phase3_mma` accumulates T - [Q~ q~] = A~' [M1_A M1_b] + Hux' [K~ k~]; the caller then drops

@@ -807,3 +807,79 @@ def test_randomised_command_workload_parity_two_iterations(params, oracle):
         assert np.allclose(perfs[it][:, :3], po[:, :3], rtol=1e-6, atol=1e-9)
     assert np.abs(x - xo).max() < 1e-6 and np.abs(u - uo).max() < 1e-5
 
+
+
+@pytest.mark.parametrize("nu", [9, 12, 6])
+def test_riccati_one_and_four_wavefront_sweeps(params, oracle, nu):
+    """Both forms of the backward sweep (hb_config.reserved = 101: one wavefront per instance, k_ric_bwd; 104: four, k_ric_bwd4 —
+    the product picks by batch size) on the unit problem of test_riccati: each against the oracle at 1e-9, and BIT-IDENTICAL to
+    each other (the four-wavefront form cuts the stage by output tiles; every tile is accumulated exactly as before)."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    rng = np.random.default_rng(2 + nu)
+    n, N = 5, 30
+    A = np.eye(22) + 0.05 * rng.standard_normal((n, N, 22, 22))
+    Bm = 0.1 * rng.standard_normal((n, N, 22, nu))
+    b = 0.01 * rng.standard_normal((n, N, 22))
+    def spd(k, shape):
+        m = rng.standard_normal(shape + (k, k))
+        return m @ np.swapaxes(m, -1, -2) + 0.5 * np.eye(k)
+    Q, R = spd(22, (n, N)), spd(nu, (n, N))
+    P = 0.05 * rng.standard_normal((n, N, nu, 22))
+    q, r = rng.standard_normal((n, N, 22)), rng.standard_normal((n, N, nu))
+    dx0 = 0.1 * rng.standard_normal((n, 22))
+    out = {}
+    for variant in (101, 104):
+        s = HunterSolver(params, batch=8, max_nodes=N, reserved=variant)
+        try:
+            out[variant] = s.riccati_solve(A, Bm, b, Q, R, P, q, r, dx0)
+        finally:
+            s.close()
+    for i in range(n):
+        dxo, duo = oracle.riccati(A[i], Bm[i], b[i], Q[i], R[i], P[i], q[i], r[i], dx0[i])
+        scale = max(1.0, np.abs(dxo).max())
+        for variant in (101, 104):
+            assert np.abs(out[variant][0][i] - dxo).max() < 1e-9 * scale and np.abs(out[variant][1][i] - duo).max() < 1e-9 * scale
+    assert np.array_equal(out[101][0], out[104][0]) and np.array_equal(out[101][1], out[104][1])
+
+
+@pytest.mark.parametrize("gait", ["trot", "stance", "ragged"])
+def test_sqp_step_identical_with_either_backward_sweep(params, gait):
+    """Three SQP iterations + WBC of a whole batch with the one- and the four-wavefront backward sweep: bit-identical iterate, step,
+    performance index and WBC solution — trot (9-wide stages), a standing batch (12-wide stages: three tiles, 12 x 12 factor) and
+    ragged horizons with all four modes (incl. a single interval and the 6-wide flight stages)."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    if gait == "trot":
+        refs, x0, rbd, t_now = workloads.trot_batch(params, 40, n_intervals=36, max_nodes=44)
+    elif gait == "stance":
+        refs, x0, rbd, t_now = workloads.stance_batch(params, 40, n_intervals=36, max_nodes=44)
+        assert (refs["mode"][:, :36] == 3).all()      # every stage in double support: the 12-wide form is what runs
+    else:
+        specs = [("trot", 0.03, 0.6), ("standing_trot", 0.03, 0.6), ("flying_trot", 0.03, 0.6), ("trot", 0.1, 0.015),
+                 ("flying_trot", 0.26, 0.2), ("stance", 0.0, 0.3), ("trot", 0.37, 0.5), ("standing_trot", 0.2, 0.33)]
+        tabs, xs = [], []
+        for i, (g, t0, hor) in enumerate(specs):
+            xi = workload.perturbed_state(params, 100 + i)
+            tabs.append(refgen.make_trot_problem(params, t0, hor, xi, (0.25, 0.05, 0.0, 0.2), 44, gait=g))
+            xs.append(xi)
+        refs, x0 = refgen.stack_tables(tabs), np.stack(xs)
+        rbd = np.stack([workload.rbd_from_state(x0[i], i) for i in range(len(specs))])
+        t_now = refs["t"][:, 0] + 0.004
+    B = x0.shape[0]
+    res = {}
+    for variant in (101, 104):
+        s = HunterSolver(params, batch=B, max_nodes=44, reserved=variant)
+        try:
+            s.set_references(refs)
+            s.reset(x0)
+            s.set_resident_inputs(x0, t_now, rbd)
+            for _ in range(3):
+                s.step_resident()
+            xs_, us_ = s.get_solution()
+            dx_, du_ = s.get_step()
+            sol_, st_ = s.get_wbc_solution()
+            res[variant] = (xs_, us_, dx_, du_, s.get_performance(), sol_, st_, s.mpc_status())
+        finally:
+            s.close()
+    for k, (p, q) in enumerate(zip(res[101], res[104])):
+        assert np.array_equal(p, q), (gait, k)
+    assert res[101][7].max() == 0 and np.isfinite(res[101][0]).all()

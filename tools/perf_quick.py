@@ -65,6 +65,9 @@ if args.ablate_lq:
         r = run(stop, steps=5)
         print(json.dumps(dict(stop=stop, ms_lq=r["ms_lq"])))
 if args.ablate_ric:
+    for stop in (24, 25, 26, 27, 104):   # four-wavefront sweep (k_ric_bwd4): staging / + GEMM 1 / + GEMM 2 / + factor, solves / whole
+        r = run(stop, steps=5)
+        print(json.dumps(dict(stop=stop, ms_ric_bwd4=r["ms_riccati_bwd"])))
     for stop in (20, 21, 22, 23):
         r = run(stop, steps=5)
         print(json.dumps(dict(stop=stop, ms_ric_bwd=r["ms_riccati_bwd"])))

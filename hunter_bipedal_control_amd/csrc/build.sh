@@ -1,7 +1,5 @@
 #!/bin/bash
 # Builds libhunter_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
-# (k_ls_tail is exempt on purpose: it is the backtracking tail of the line search, entered only by instances whose full step was
-# rejected — none in the steady-state timed region — and carries 452 B/lane of scratch next to its 256 + 256 registers.)
 # The build FAILS if one of the hot kernels of the update (either WBC flavour included) spills to scratch memory: every scratch reload is followed by
 # s_waitcnt vmcnt(0), which drains the software-pipelined record prefetch of the sweeps.
 set -e
@@ -15,7 +13,7 @@ $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Rpass-analysis=kernel
 grep -E "error|warning:" "$LOG" | grep -v "Wcomment" >&2 || true
 python3 - "$LOG" <<'PY'
 import re, sys
-hot = ["k_lqE", "k_ric_bwdE", "k_ric_bwd4E", "k_ric_fwdE", "5k_wbcE", "6k_hwbcE", "k_ls_evalE", "k_policy_evalE"]
+hot = ["k_lqE", "k_ric_bwdE", "k_ric_bwd4E", "k_ric_fwdE", "5k_wbcE", "6k_hwbcE", "k_ls_evalE", "k_ls_tail_evalE", "k_ls_tail_decideE", "k_policy_evalE"]
 txt = open(sys.argv[1]).read()
 rows, bad = [], []
 for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?LDS Size \[bytes/block\]: (\d+)", txt, re.S):

@@ -46,6 +46,7 @@ struct WaveCtx {
 
 // ---------------------------------------------------------------------------------------------------------
 // device-resident problem data of a batch
+constexpr int LS_TAIL_MAX = 16;   // step sizes the backtracking tail evaluates side by side (decay 0.5, alpha_min 1e-4: 13 of them)
 struct Batch {
   int B, Nmax;
   int* n_nodes;     // [B]
@@ -62,6 +63,8 @@ struct Batch {
   double* du;       // [B][Nmax][22]
   double* acc;      // [B][4] armijo, base merit, base dyn, base eq
   double* partial;  // [B][Nmax][3]
+  double* ls_norm;  // [B][2]: |dx|, |du| (l2, whole trajectory) of the instances whose full step was refused (k_ls_decide)
+  double* ls_tail;  // [B][LS_TAIL_MAX][Nmax][3]: per-node line-search partials of the backtracking step sizes, evaluated side by side
   int* accepted;    // [B]
   double* perf;     // [B][4] merit dyn eq step
   int* ric_fail;    // [B]
@@ -575,9 +578,19 @@ __global__ __launch_bounds__(64) void k_ls_decide(Batch b, const DevConfig* __re
   const double armijo = b.acc[inst * 4 + 0], base_merit = b.acc[inst * 4 + 1];
   const double base_viol = sqrt(b.acc[inst * 4 + 2] + b.acc[inst * 4 + 3]);
   const bool ok = filter_accept(*C, base_merit, base_viol, m, sqrt(d + e), alpha, armijo) && !b.ric_fail[inst];
-  if (!ok) return;
-  // commit the step
   const size_t xo = size_t(inst) * (b.Nmax + 1) * HB_NX, uo = size_t(inst) * b.Nmax * HB_NU;
+  if (!ok) {
+    // refused: the backtracking tail follows.  It needs |dx|, |du| over the whole trajectory (the search gives up once alpha |dx| and
+    // alpha |du| are both below sqp.deltaTol, [OCS2-knowledge] SqpSolver::takeStep "escape early") before it evaluates anything
+    double nx2 = 0, nu2 = 0;
+    for (int i = lane; i < (n + 1) * HB_NX; i += 64) nx2 += b.dx[xo + i] * b.dx[xo + i];
+    for (int i = lane; i < n * HB_NU; i += 64) nu2 += b.du[uo + i] * b.du[uo + i];
+    nx2 = wave_sum(nx2);
+    nu2 = wave_sum(nu2);
+    if (lane == 0) { b.ls_norm[inst * 2] = sqrt(nx2); b.ls_norm[inst * 2 + 1] = sqrt(nu2); }
+    return;
+  }
+  // commit the step
   for (int i = lane; i < (n + 1) * HB_NX; i += 64) b.x[xo + i] += alpha * b.dx[xo + i];
   for (int i = lane; i < n * HB_NU; i += 64) b.u[uo + i] += alpha * b.du[uo + i];
   if (lane == 0) {
@@ -589,62 +602,79 @@ __global__ __launch_bounds__(64) void k_ls_decide(Batch b, const DevConfig* __re
   }
 }
 
-// Backtracking tail of the filter line search in ONE launch: an instance that did not accept the full step walks the
-// remaining step sizes alpha0, alpha0 * decay, ... >= alpha_min by itself (block = instance, thread = node, same node
-// evaluation, same summation order and acceptance test as k_ls_eval + k_ls_decide).  Instances that accepted alpha = 1 —
-// nearly all, in steady state — leave at once; the 26 mostly empty launches of the per-alpha loop are gone.
-__global__ __launch_bounds__(64) void k_ls_tail(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C, double alpha0,
-                                                double decay, double alpha_min) {
+// Backtracking tail of the filter line search.  An instance that did not accept the full step tries alpha0, alpha0 * decay, ...
+// >= alpha_min in that order and takes the first one the filter accepts (OCS2 FilterLinesearch); before every trial it gives up — no
+// step, converged — once alpha |dx| and alpha |du| are both below sqp.deltaTol.  The trials do not depend on each other, so they are
+// EVALUATED SIDE BY SIDE (k_ls_tail_eval: k_ls_eval once per step size, thread = node, per-node partials; the same node evaluation
+// and the same summation order as k_ls_eval + k_ls_decide) and a second kernel walks the sequence with exactly the sequential rules (k_ls_tail_decide):
+// identical decisions, but the launch takes ONE trial's time instead of up to 13 in a row (an instance that walks down to
+// alpha_min used to hold the whole batch back: 2.4 ms of line search per step in the backtracking figure), and without the loop over
+// the step sizes around the node evaluation the kernel no longer spills (the one-launch form carried 476 B / lane of scratch).
+// Instances that accepted alpha = 1 — all of them in steady state — leave at once.
+__global__ __launch_bounds__(64) void k_ls_tail_eval(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C, double alpha0,
+                                                     double decay, double alpha_min) {
+  // (k_ls_eval with the step size of blockIdx.y; one node per thread and no loop around the node evaluation: no scratch)
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x, ai = blockIdx.y;
+  const int inst = gid / b.Nmax, k = gid % b.Nmax;
+  if (inst >= b.B) return;
+  if (b.accepted[inst] || k >= b.n_nodes[inst]) return;
+  double alpha = alpha0;
+  for (int j = 0; j < ai; ++j) alpha *= decay;   // (the sequential search multiplies step by step: the same rounding)
+  if (!(alpha >= alpha_min)) return;
+  // step sizes the sequential search never reaches are not evaluated: it stops (no step) at the first alpha with alpha |dx| and
+  // alpha |du| below deltaTol, and the condition is monotone in alpha — a converged instance evaluates nothing, as before
+  if (alpha * b.ls_norm[inst * 2 + 1] < C->delta_tol && alpha * b.ls_norm[inst * 2] < C->delta_tol) return;
+  const size_t nd = size_t(inst) * b.Nmax + k;
+  const size_t xo = (size_t(inst) * (b.Nmax + 1) + k) * HB_NX;
+  __shared__ double tp[64 * 45];
+  double* x = tp + threadIdx.x * 45;
+  double* u = x + HB_NX;
+#pragma unroll
+  for (int i = 0; i < HB_NX; ++i) {
+    x[i] = b.x[xo + i] + alpha * b.dx[xo + i];
+    u[i] = b.u[nd * HB_NU + i] + alpha * b.du[nd * HB_NU + i];
+  }
+  const double* tt = b.t + size_t(inst) * (b.Nmax + 1);
+  const double* xn0 = b.x + xo + HB_NX;
+  const double* dxn = b.dx + xo + HB_NX;
+  double o3[3];
+  node_value(*M, *C, x, u, [xn0, dxn, alpha](int i) { return xn0[i] + alpha * dxn[i]; }, b.xref + nd * HB_NX, b.swing + nd * 24,
+             tt[k + 1] - tt[k], b.mode[nd], o3);
+  double* o = b.ls_tail + ((size_t(inst) * LS_TAIL_MAX + ai) * b.Nmax + k) * 3;
+  o[0] = o3[0];
+  o[1] = o3[1];
+  o[2] = o3[2];
+}
+__global__ __launch_bounds__(64) void k_ls_tail_decide(Batch b, const DevConfig* __restrict__ C, double alpha0, double decay, double alpha_min,
+                                                       int n_alpha) {
   const int inst = blockIdx.x, lane = threadIdx.x;
   if (b.accepted[inst]) return;
   const int n = b.n_nodes[inst];
-  __shared__ double tp[64 * 45];
-  double* x = tp + lane * 45;
-  double* u = x + HB_NX;
-  const double* tt = b.t + size_t(inst) * (b.Nmax + 1);
   const double armijo = b.acc[inst * 4 + 0], base_merit = b.acc[inst * 4 + 1];
   const double base_viol = sqrt(b.acc[inst * 4 + 2] + b.acc[inst * 4 + 3]);
   const bool ric_ok = !b.ric_fail[inst];
-  // |dx|, |du| over the whole trajectory: the search gives up once alpha |dx| and alpha |du| are both below sqp.deltaTol
-  // ([OCS2-knowledge] SqpSolver::takeStep, "detect too small step size during back-tracking to escape early"): no step, like
-  // reaching alpha_min, but the instance is converged, not failed (accepted = 2 -> HB_INST_OK)
-  double nx2 = 0, nu2 = 0;
-  {
-    const size_t xo = size_t(inst) * (b.Nmax + 1) * HB_NX, uo = size_t(inst) * b.Nmax * HB_NU;
-    for (int i = lane; i < (n + 1) * HB_NX; i += 64) nx2 += b.dx[xo + i] * b.dx[xo + i];
-    for (int i = lane; i < n * HB_NU; i += 64) nu2 += b.du[uo + i] * b.du[uo + i];
-    nx2 = wave_sum(nx2);
-    nu2 = wave_sum(nu2);
-  }
-  const double dx_norm = sqrt(nx2), du_norm = sqrt(nu2), delta_tol = C->delta_tol;
-  for (double alpha = alpha0; alpha >= alpha_min; alpha *= decay) {
+  // no step once alpha |dx| and alpha |du| are both below sqp.deltaTol — like reaching alpha_min, but the instance is converged, not
+  // failed (accepted = 2 -> HB_INST_OK); the norms were left by k_ls_decide when it refused the full step
+  const size_t xo = size_t(inst) * (b.Nmax + 1) * HB_NX, uo = size_t(inst) * b.Nmax * HB_NU;
+  const double dx_norm = b.ls_norm[inst * 2], du_norm = b.ls_norm[inst * 2 + 1], delta_tol = C->delta_tol;
+  double alpha = alpha0;
+  for (int ai = 0; ai < n_alpha && alpha >= alpha_min; ++ai, alpha *= decay) {
     if (alpha * du_norm < delta_tol && alpha * dx_norm < delta_tol) {
       if (lane == 0) b.accepted[inst] = 2;
       return;
     }
+    // (the sums of k_ls_decide, in its order: per-lane partial sums over the lane's nodes, then the wave reduction)
     double m = 0, d = 0, e = 0;
     for (int k = lane; k < n; k += 64) {
-      const size_t nd = size_t(inst) * b.Nmax + k;
-      const size_t xo = (size_t(inst) * (b.Nmax + 1) + k) * HB_NX;
-#pragma unroll
-      for (int i = 0; i < HB_NX; ++i) {
-        x[i] = b.x[xo + i] + alpha * b.dx[xo + i];
-        u[i] = b.u[nd * HB_NU + i] + alpha * b.du[nd * HB_NU + i];
-      }
-      const double* xn0 = b.x + xo + HB_NX;
-      const double* dxn = b.dx + xo + HB_NX;
-      double o3[3];
-      node_value(*M, *C, x, u, [xn0, dxn, alpha](int i) { return xn0[i] + alpha * dxn[i]; }, b.xref + nd * HB_NX, b.swing + nd * 24,
-                 tt[k + 1] - tt[k], b.mode[nd], o3);
-      m += o3[0];
-      d += o3[1];
-      e += o3[2];
+      const double* p = b.ls_tail + ((size_t(inst) * LS_TAIL_MAX + ai) * b.Nmax + k) * 3;
+      m += p[0];
+      d += p[1];
+      e += p[2];
     }
     m = wave_sum(m);
     d = wave_sum(d);
     e = wave_sum(e);
     if (filter_accept(*C, base_merit, base_viol, m, sqrt(d + e), alpha, armijo) && ric_ok) {
-      const size_t xo = size_t(inst) * (b.Nmax + 1) * HB_NX, uo = size_t(inst) * b.Nmax * HB_NU;
       for (int i = lane; i < (n + 1) * HB_NX; i += 64) b.x[xo + i] += alpha * b.dx[xo + i];
       for (int i = lane; i < n * HB_NU; i += 64) b.u[uo + i] += alpha * b.du[uo + i];
       if (lane == 0) {
@@ -1092,6 +1122,8 @@ int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch,
   A(b.du, B * N * HB_NU);
   A(b.acc, B * 4);
   A(b.partial, B * N * 3);
+  A(b.ls_tail, B * LS_TAIL_MAX * N * 3);
+  A(b.ls_norm, B * 2);
   A(b.accepted, B);
   A(b.perf, B * 4);
   A(b.ric_fail, B);
@@ -1830,7 +1862,7 @@ static Batch batch_view(const Batch& b, int i0, int cnt) {
   v.B = cnt;
   v.n_nodes += o; v.t += o * (N + 1); v.mode += o * N; v.xref += o * N * HB_NX; v.swing += o * N * 24;
   v.x += o * (N + 1) * HB_NX; v.u += o * N * HB_NU; v.x0 += o * HB_NX; v.recs += o * N * REC_SIZE; v.gains += o * N * GAIN_SIZE;
-  v.dx += o * (N + 1) * HB_NX; v.du += o * N * HB_NU; v.acc += o * 4; v.partial += o * N * 3; v.accepted += o; v.perf += o * 4;
+  v.dx += o * (N + 1) * HB_NX; v.du += o * N * HB_NU; v.acc += o * 4; v.partial += o * N * 3; v.ls_tail += o * LS_TAIL_MAX * N * 3; v.ls_norm += o * 2; v.accepted += o; v.perf += o * 4;
   v.ric_fail += o; v.mpc_status += o; v.xp += o * (N + 1) * HB_NX; v.up += o * N * HB_NU; v.tp += o * (N + 1); v.modep += o * N;
   v.np_nodes += o; v.grid_dirty += o;
   return v;
@@ -1892,9 +1924,15 @@ static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t
     // filter line search: the full step for every instance, node-parallel; then the backtracking tail in one launch
     hipLaunchKernelGGL(k_ls_eval, dim3((B * N + 63) / 64), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, 1.0);
     hipLaunchKernelGGL(k_ls_decide, dim3(B), dim3(64), 0, s, b, ctx->dconfig, 1.0);
-    if (ctx->config.alpha_decay > 0.0 && ctx->config.alpha_decay < 1.0 && ctx->config.alpha_decay >= ctx->config.alpha_min)
-      hipLaunchKernelGGL(k_ls_tail, dim3(B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, ctx->config.alpha_decay,
+    if (ctx->config.alpha_decay > 0.0 && ctx->config.alpha_decay < 1.0 && ctx->config.alpha_decay >= ctx->config.alpha_min) {
+      // step sizes alpha_decay^1, ^2, ... >= alpha_min (at most LS_TAIL_MAX = 16 trials: the shipped 0.5 / 1e-4 makes 13)
+      int n_alpha = 0;
+      for (double a = ctx->config.alpha_decay; a >= ctx->config.alpha_min && n_alpha < LS_TAIL_MAX; a *= ctx->config.alpha_decay) ++n_alpha;
+      hipLaunchKernelGGL(k_ls_tail_eval, dim3((B * N + 63) / 64, n_alpha), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, ctx->config.alpha_decay,
                          ctx->config.alpha_decay, ctx->config.alpha_min);
+      hipLaunchKernelGGL(k_ls_tail_decide, dim3(B), dim3(64), 0, s, b, ctx->dconfig, ctx->config.alpha_decay, ctx->config.alpha_decay,
+                         ctx->config.alpha_min, n_alpha);
+    }
     if (timed) HB_HIP(hipEventRecord(ctx->ev[4], s));
     // evaluated per iteration: ric_fail / accepted are overwritten by the next one
     hipLaunchKernelGGL(k_mpc_status, dim3((B + 255) / 256), dim3(256), 0, s, b, it == 0 ? 1 : 0);

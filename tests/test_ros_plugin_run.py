@@ -3,6 +3,7 @@ init -> starting -> update x N against the batched plant stub behind mock Hybrid
 (tests/cpp/plugin_test.cpp over the mock ros_control layer of adapters/ros_control/test_shims) — LeggedController.cpp:41-135
 (init), :112-135 (starting), :137-278 (update), :396-421 (MPC thread), legged_controllers_plugins.xml:3-8.
 CPU: the harness builds and init() returns false, loudly, without a GPU.  -m gpu: the robot stands, then trots on /cmd_vel."""
+import os
 import subprocess
 from pathlib import Path
 
@@ -24,10 +25,15 @@ def _build():
     deps = [src, lib, ROOT / "adapters/ros_control/src/HipLeggedController.cpp", ROOT / "adapters/ros_control/include/hunter_hip_controllers/HipLeggedController.h",
             ROOT / "include/hunter_hip.hpp", ROOT / "include/hunter_ingest.hpp"]
     deps += list((ROOT / "adapters/ros_control/test_shims").rglob("*.h*"))
-    if not exe.exists() or exe.stat().st_mtime < max(d.stat().st_mtime for d in deps):
-        subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-I", str(ROOT / "include"), "-I", str(ROOT / "adapters/ros_control/test_shims"),
-                               "-I", str(ROOT / "adapters/ros_control/include"), str(src), "-L", str(PKG), "-lhunter_hip", f"-Wl,-rpath,{PKG}",
-                               "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", str(exe)])
+    import fcntl
+    with open(out / "plugin_test.lock", "w") as lock:   # (pytest-xdist workers may want the same harness at the same time)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not exe.exists() or exe.stat().st_mtime < max(d.stat().st_mtime for d in deps):
+            tmp = out / f"plugin_test.{os.getpid()}"
+            subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-I", str(ROOT / "include"), "-I", str(ROOT / "adapters/ros_control/test_shims"),
+                                   "-I", str(ROOT / "adapters/ros_control/include"), str(src), "-L", str(PKG), "-lhunter_hip", f"-Wl,-rpath,{PKG}",
+                                   "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", str(tmp)])
+            os.replace(tmp, exe)
     return exe
 
 

@@ -224,112 +224,209 @@ HB_HD LqP1 lq_p1(double* lds) {
   return p;
 }
 
-// Whole-body combine of ONE (node, RK2 point, nonlinear direction) task: directions h, zyx, joints, joint rates run on duals
-// assembled from the stage-1 leg tangents (29 of the 44 directions; ti = 0..28).  Writes column `dir` of the point's Jacobian,
-// for the first point the constraint-row derivatives / values, and — on the lane of direction 0 — the point's values:
-// always for the second point; for the first point only with `first_point_values` (the node-pair kernel has no separate
-// value pre-pass: its first-point pass delivers f(x, u) itself).
-HB_HD void lq_dual_task(const DevModel& M, const DevConfig& C, double* lds, int mode, const double* swing, int pt, int ti, bool first_point_values) {
-  const LqP1 P = lq_p1(lds);
-  double* xs = P.xs; double* us = P.us; double* xe = P.xe; double* fv = P.fv; double* LV_all = P.LV_all;
-  double* SC = P.SC; double* CDt = P.CDt; double* rowval = P.rowval;
-  double* LJ_all = P.LJ_all;
+// ---- uniform values of one RK2 point, shared by the direction lanes (round 4) ------------------------------------------------
+// The direction pass used to carry the whole-body combine on one-tangent dual numbers: every lane recomputed the VALUE of every
+// intermediate (identical on all lanes of a point) next to its tangent — about half of the pass's instructions.  Now the values are
+// computed once per point by the value pass (four lanes) and left where the direction lanes read them; the lanes propagate tangents
+// only (lq_tangent_task).  Homes of the values (all inside buffers that are dead at that time, see LqLds):
+//   R (9) and 1 / cos(pitch)      the LEGJ_MS slots of the point's two leg blocks (the suffix masses are read by the leg pass only)
+//   I_com^-1 (6), w_b (3)         over the summed leg composites mc | IO of the point's leg values (consumed by the value pass itself)
+//   P = COM in the base frame (3) over the summed joint-rate angular momentum (likewise); l_j stays where the leg pass left it
+//   h_b = R' (m h_ang) (3)        xe[12 + 3 pt ..] (the joint part of x_e is never read: the leg pass forms q + dt qd itself)
+//   f(x_e, u) rows 0..11          xe[0 .. 11], written by the second value pass after its last read of x_e
+HB_HD int lq_ms_slot(int pt, int e) { return (2 * pt + e / 5) * LEGJ_SIZE + (e % 5) * LEGJ_STRIDE + LEGJ_MS; }
+constexpr int LQ_CV_IINV = 0, LQ_CV_WB = 6, LQ_CV_LJ = 9, LQ_CV_P = 12;   // offsets inside the point's leg values (LqLds::LVP)
+struct LqPointValues {
+  Vec3<double> fr[HB_NC], fvel[HB_NC];   // contact point minus base origin, contact-point velocity (world): filled per foot by the caller
+  Mat3<double> R;
+  Vec3<double> wb, P, hb, lj, omega, euler_rate, v_lin, com_rel;
+  Sym3<double> Iinv;
+  double icy;
+};
+// whole-body values of one point from the summed leg composites (plain doubles): what centroidal_core computes, plus the pieces the
+// tangent lanes need (inverse inertia about the COM, base-frame angular velocity / momentum, COM in the base frame)
+HB_HD void lq_point_values(const DevModel& M, const double* LV, const double* zyx_sc /* sz cz sy cy sx cx */, const double* hn, LqPointValues& o) {
+  const double mb = M.mass[0], mt = M.total_mass;
+  const Vec3<double> cb(M.com[0][0], M.com[0][1], M.com[0][2]);
+  Sym3<double> Ib;
+  Ib.xx = M.inertia[0][0]; Ib.xy = M.inertia[0][1]; Ib.xz = M.inertia[0][2];
+  Ib.yy = M.inertia[0][3]; Ib.yz = M.inertia[0][4]; Ib.zz = M.inertia[0][5];
+  const Vec3<double> mc = ld3(LV + 0) + mb * cb;
+  const Sym3<double> IO = ld6(LV + 3) + Ib + point_inertia<double>(mb, cb);
+  o.lj = ld3(LV + 9);
+  const Vec3<double> LjO = ld3(LV + 12);
+  const double inv_m = rcp_t(mt);
+  o.P = inv_m * mc;
+  Sym3<double> Ic = IO;
+  {
+    const Sym3<double> sh = point_inertia<double>(mt, o.P);
+    Ic.xx -= sh.xx; Ic.xy -= sh.xy; Ic.xz -= sh.xz; Ic.yy -= sh.yy; Ic.yz -= sh.yz; Ic.zz -= sh.zz;
+  }
+  {
+    const double c00 = Ic.yy * Ic.zz - Ic.yz * Ic.yz, c01 = Ic.xz * Ic.yz - Ic.xy * Ic.zz, c02 = Ic.xy * Ic.yz - Ic.xz * Ic.yy;
+    const double c11 = Ic.xx * Ic.zz - Ic.xz * Ic.xz, c12 = Ic.xy * Ic.xz - Ic.xx * Ic.yz, c22 = Ic.xx * Ic.yy - Ic.xy * Ic.xy;
+    const double inv = rcp_t(Ic.xx * c00 + Ic.xy * c01 + Ic.xz * c02);
+    o.Iinv.xx = inv * c00; o.Iinv.xy = inv * c01; o.Iinv.xz = inv * c02; o.Iinv.yy = inv * c11; o.Iinv.yz = inv * c12; o.Iinv.zz = inv * c22;
+  }
+  const double sz = zyx_sc[0], cz = zyx_sc[1], sy = zyx_sc[2], cy = zyx_sc[3], sx = zyx_sc[4], cx = zyx_sc[5];
+  Mat3<double>& R = o.R;
+  R.m[0] = cz * cy; R.m[1] = cz * sy * sx - sz * cx; R.m[2] = cz * sy * cx + sz * sx;
+  R.m[3] = sz * cy; R.m[4] = sz * sy * sx + cz * cx; R.m[5] = sz * sy * cx - cz * sx;
+  R.m[6] = -sy;     R.m[7] = cy * sx;                R.m[8] = cy * cx;
+  o.icy = rcp_t(cy);
+  o.hb = tmul(R, Vec3<double>(mt * hn[3], mt * hn[4], mt * hn[5]));
+  const Vec3<double> Lj = LjO - cross(o.P, o.lj);   // joint-rate momentum about the COM
+  o.wb = o.Iinv * (o.hb - Lj);
+  o.omega = R * o.wb;
+  {
+    const double roll_rate = (cz * o.omega.x + sz * o.omega.y) * o.icy;
+    o.euler_rate = Vec3<double>(o.omega.z + sy * roll_rate, cz * o.omega.y - sz * o.omega.x, roll_rate);
+  }
+  o.com_rel = R * o.P;
+  o.v_lin = Vec3<double>(hn[0], hn[1], hn[2]) - cross(o.omega, o.com_rel) - inv_m * (R * o.lj);
+}
+// leave the point's values where the tangent lanes read them (one lane; see the table above).  `LJ_all`: the four leg blocks.
+HB_HD void lq_store_point_values(const LqPointValues& v, int pt, double* LJ_all, double* LV, double* xe) {
+#pragma unroll
+  for (int e = 0; e < 9; ++e) LJ_all[lq_ms_slot(pt, e)] = v.R.m[e];
+  LJ_all[lq_ms_slot(pt, 9)] = v.icy;
+  st6(LV + LQ_CV_IINV, v.Iinv);
+  st3(LV + LQ_CV_WB, v.wb);
+  st3(LV + LQ_CV_P, v.P);
+  st3(xe + 12 + 3 * pt, v.hb);
+}
+// constraint rows of contact point i at the first point (values): slot 3 i + a in contact-point order (lq_tail regroups them)
+HB_HD void lq_row_values(const DevConfig& C, bool contact, double pz, double px, double py, const Vec3<double>& fvel, const double* sw, double* out3) {
+  if (contact) {  // zero velocity (LeggedInterface.cpp:436-444)
+    out3[0] = fvel.x;
+    out3[1] = fvel.y;
+    out3[2] = fvel.z + C.zv_gain * pz + C.zv_off;
+  } else {        // normal velocity + xy soft reference (LeggedRobotPreComputation.cpp:96-117)
+    out3[0] = fvel.z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
+    out3[1] = C.xy_gain * px + fvel.x - (sw[3] + C.xy_gain * sw[0]);
+    out3[2] = C.xy_gain * py + fvel.y - (sw[4] + C.xy_gain * sw[1]);
+  }
+}
+
+// Tangent of the whole-body combine for ONE (RK2 point, nonlinear direction) task: directions h, zyx, joints, joint rates (29 of the
+// 44; ti = 0..28).  Everything is linear in the direction's seed; the values it multiplies are the point's uniform values.  With
+// dth = the base-frame rotation vector of the direction (dR = R [dth]x: a column of the ZYX rate map for a zyx direction, else 0):
+//   dP   = dmc / m                         dIcom = dIO - (2 (P . dmc) I - dmc P' - P dmc')
+//   dLj  = dLjO - dP x lj - P x dlj         dwb   = Icom^-1 (hb x dth + R' m dh_ang - dLj - dIcom wb)
+//   dw_b = dwb + dth x wb                   d omega = R dw_b,   d euler rates = E^-1 d omega (+ dE^-1 omega for a zyx direction)
+//   p'   = dP + dth x P  (d com_rel = R p')
+//   dv   = dh_lin - R (dw_b x P + wb x p' + (dlj + dth x lj) / m)
+//   contact point:  a = dfoot_b + dth x foot_b,  b = dvj_b + dth x vj_b
+//                   d foot_rel = R a,   d foot_vel = dv + R (dw_b x foot_b + wb x a + b),   d moment += (R a - R p') x F
+// Writes column `dir` of the point's Jacobian (rows 3..11 of f) and, for the first point, the constraint-row derivatives.
+HB_HD void lq_tangent_task(const DevModel& M, const DevConfig& C, double* lds, int mode, int pt, int ti) {
+  const LqP1 P1 = lq_p1(lds);
+  const double* us = P1.us;
+  const double* SCp = P1.SC + 6 * pt;
+  double* CDt = P1.CDt;
+  const double* LJ_all = P1.LJ_all;
   bool cf[HB_NC];
   mode_flags(mode, cf);
   const int dir = ti < 6 ? ti : (ti < 19 ? ti + 3 : ti + 15);
-  double* Jp = (pt == 0 ? P.J1 : P.J2) + j_row(dir) * 9;  // this direction's row: d f(rows 3..11), columns j_col
+  double* Jp = (pt == 0 ? P1.J1 : P1.J2) + j_row(dir) * 9;  // this direction's row: d f(rows 3..11), columns j_col
   const double* LJ = LJ_all + pt * 2 * LEGJ_SIZE;
-  const double* LV = LV_all + pt * LqLds::LVP;
-  const double* xb = pt == 0 ? xs : xe;
+  const double* LV = P1.LV_all + pt * LqLds::LVP;
+  const double mt = M.total_mass, inv_m = rcp_t(mt);
+  // which leg tangent (if any) feeds this direction
+  int tl = -1, ts = 0;
+  if (dir >= 12 && dir < 22) { tl = (dir - 12) / 5; ts = (dir - 12) % 5; }
+  if (dir >= 34) { tl = (dir - 34) / 5; ts = 5 + (dir - 34) % 5; }
+  double t[15];
+  const double* LJs = LJ + (tl >= 0 ? tl : 0) * LEGJ_SIZE;
+  if (tl >= 0) {
+    leg_tangent_body(LJs, ts % 5, ts >= 5, t);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 15; ++e) t[e] = 0.0;
+  }
+  // uniform values of the point
+  Mat3<double> R;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) R.m[e] = LJ_all[lq_ms_slot(pt, e)];
+  const double icy = LJ_all[lq_ms_slot(pt, 9)];
+  const Sym3<double> Iinv = ld6(LV + LQ_CV_IINV);
+  const Vec3<double> wb = ld3(LV + LQ_CV_WB), lj = ld3(LV + LQ_CV_LJ), P = ld3(LV + LQ_CV_P), hb = ld3(P1.xe + 12 + 3 * pt);
+  const double sz = SCp[0], cz = SCp[1], sy = SCp[2], cy = SCp[3], sx = SCp[4], cx = SCp[5];
+  // the direction's seeds
+  const Vec3<double> dmc(t[0], t[1], t[2]), dlj(t[9], t[10], t[11]), dLjO(t[12], t[13], t[14]);
+  Vec3<double> dth;   // zyx direction: column of the ZYX rate map in the base frame — yaw: third row of R, pitch: (0, cx, -sx), roll: e_x
+  if (dir == 9) dth = Vec3<double>(R.m[6], R.m[7], R.m[8]);
+  else if (dir == 10) dth = Vec3<double>(0.0, cx, -sx);
+  else if (dir == 11) dth = Vec3<double>(1.0, 0.0, 0.0);
+  const Vec3<double> dhlin(dir == 0 ? 1.0 : 0.0, dir == 1 ? 1.0 : 0.0, dir == 2 ? 1.0 : 0.0);
+  Vec3<double> dhb;   // R' m dh_ang: m x row (dir - 3) of R
+  // (selected with compares: indexed by the direction, the matrix would live in scratch memory)
+  if (dir == 3) dhb = Vec3<double>(mt * R.m[0], mt * R.m[1], mt * R.m[2]);
+  else if (dir == 4) dhb = Vec3<double>(mt * R.m[3], mt * R.m[4], mt * R.m[5]);
+  else if (dir == 5) dhb = Vec3<double>(mt * R.m[6], mt * R.m[7], mt * R.m[8]);
+  const Vec3<double> dP = inv_m * dmc;
+  Vec3<double> dIw;   // dIcom wb
   {
-    // which leg tangent (if any) feeds this direction
-    int tl = -1, ts = 0;
-    if (dir >= 12 && dir < 22) { tl = (dir - 12) / 5; ts = (dir - 12) % 5; }
-    if (dir >= 34) { tl = (dir - 34) / 5; ts = 5 + (dir - 34) % 5; }
-    // leg sums (value of both legs, tangent of the one leg this direction seeds — closed form, in registers).  Only the 15
-    // tangents of the leg composite are formed here; those of a contact point are formed when the point is processed (all 27
-    // up front kept 24 more registers live through the whole-body combine: the kernel's register peak)
-    double t[15];
-    const double* LJs = LJ + (tl >= 0 ? tl : 0) * LEGJ_SIZE;
-    if (tl >= 0) {
-      leg_tangent_body(LJs, ts % 5, ts >= 5, t);
+    const double tr = 2.0 * dot(P, dmc);
+    Sym3<double> dI;
+    dI.xx = t[3] - (tr - 2.0 * P.x * dmc.x);
+    dI.yy = t[6] - (tr - 2.0 * P.y * dmc.y);
+    dI.zz = t[8] - (tr - 2.0 * P.z * dmc.z);
+    dI.xy = t[4] + (dmc.x * P.y + P.x * dmc.y);
+    dI.xz = t[5] + (dmc.x * P.z + P.x * dmc.z);
+    dI.yz = t[7] + (dmc.y * P.z + P.y * dmc.z);
+    dIw = dI * wb;
+  }
+  const Vec3<double> dLj = dLjO - cross(dP, lj) - cross(P, dlj);
+  const Vec3<double> dwb = Iinv * (cross(hb, dth) + dhb - dLj - dIw);
+  const Vec3<double> dwB = dwb + cross(dth, wb);          // d (R' omega)
+  const Vec3<double> dom = R * dwB;                        // d omega (world)
+  Vec3<double> der;                                        // d euler rates (yaw, pitch, roll)
+  {
+    double droll = (cz * dom.x + sz * dom.y) * icy, dpitch = cz * dom.y - sz * dom.x;
+    if (dir == 9 || dir == 10) {   // the rate map itself depends on yaw and pitch
+      const Vec3<double> om = R * wb;
+      const double roll = (cz * om.x + sz * om.y) * icy;
+      if (dir == 9) { droll += (cz * om.y - sz * om.x) * icy; dpitch -= sz * om.y + cz * om.x; }
+      else { droll += roll * sy * icy; }
+      der.x = dom.z + sy * droll + (dir == 10 ? cy * roll : 0.0);
     } else {
-#pragma unroll
-      for (int e = 0; e < 15; ++e) t[e] = 0.0;
+      der.x = dom.z + sy * droll;
     }
-    auto S = [LV, &t](int e) { return Dual1(LV[e], t[e]); };   // (both legs' composites arrive summed)
-    CentroidalCore<Dual1> core;
-    {
-      Dual1 zyx[3], hn[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) hn[i] = Dual1(xb[i], dir == i ? 1.0 : 0.0);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) zyx[i] = Dual1(xb[9 + i], dir == 9 + i ? 1.0 : 0.0);
-      Sym3<Dual1> IOs;
-      IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
-      centroidal_core<Dual1>(M, Vec3<Dual1>(S(0), S(1), S(2)), IOs, Vec3<Dual1>(S(9), S(10), S(11)),
-                             Vec3<Dual1>(S(12), S(13), S(14)), zyx, hn, core, SC + 6 * pt);
-    }
-    // (the euler-rate derivatives are final here, but they are stored with the rest at the end: the row may lie over leg blocks the
-    // contact loop below still reads, LqLds::J1)
-    const Vec3<double> euler_rate_d(core.euler_rate.x.d, core.euler_rate.y.d, core.euler_rate.z.d);
-    const Vec3<double> euler_rate_v(core.euler_rate.x.v, core.euler_rate.y.v, core.euler_rate.z.v);
-    // contact points one at a time (rolled loop keeps the register footprint small)
-    Vec3<Dual1> ms;
+    der.y = dpitch;
+    der.z = droll;
+  }
+  const Vec3<double> pp = dP + cross(dth, P);              // d com_rel = R pp
+  const Vec3<double> Rpp = R * pp;
+  const Vec3<double> dv = dhlin - R * (cross(dwB, P) + cross(wb, pp) + inv_m * (dlj + cross(dth, lj)));
+  Vec3<double> dms;
 #pragma unroll 1
-    for (int i = 0; i < HB_NC; ++i) {
-      const int leg = i & 1, f = i >> 1;
-      const double* vp = LJ + leg * LEGJ_SIZE + LEGJ_FEET + 3 * f;    // contact-point position (leg block)
-      const double* vv = LV + 15 + 6 * leg + 3 * f;                   // its velocity (leg values)
-      Vec3<double> tp, tv;
-      if (tl == leg) leg_tangent_foot(LJs, ts % 5, ts >= 5, f, tp, tv);
-      const Vec3<Dual1> fb{Dual1(vp[0], tp.x), Dual1(vp[1], tp.y), Dual1(vp[2], tp.z)};
-      const Vec3<Dual1> vb{Dual1(vv[0], tv.x), Dual1(vv[1], tv.y), Dual1(vv[2], tv.z)};
-      Vec3<Dual1> fr, fvel;
-      centroidal_foot<Dual1>(core, fb, vb, fr, fvel);
-      const Vec3<Dual1> rr = fr - core.com_rel;
-      const Vec3<Dual1> F{Dual1(us[3 * i]), Dual1(us[3 * i + 1]), Dual1(us[3 * i + 2])};
-      ms = ms + cross(rr, F);
-      if (dir == 0) { double* fr_out = lds + LqLds::fr_slot(pt, i); fr_out[0] = rr.x.v; fr_out[1] = rr.y.v; fr_out[2] = rr.z.v; }  // (LqLds: over this contact's velocity)
-      if (pt == 0) {
-        // constraint rows: slot 3i+a  (base position enters only through the closed-form lanes below)
-        const Dual1 pz = Dual1(xs[8]) + fr.z;
-        Dual1 r0, r1, r2;
-        if (cf[i]) {  // zero velocity (LeggedInterface.cpp:436-444)
-          r0 = fvel.x;
-          r1 = fvel.y;
-          r2 = fvel.z + C.zv_gain * pz + C.zv_off;
-        } else {      // normal velocity + xy soft reference (LeggedRobotPreComputation.cpp:96-117)
-          const double* sw = swing + 6 * i;  // (uniform address: scalar loads)
-          const Dual1 px = Dual1(xs[6]) + fr.x, py = Dual1(xs[7]) + fr.y;
-          r0 = fvel.z + C.kp_normal * pz - (sw[5] + C.kp_normal * sw[2]);
-          r1 = C.xy_gain * px + fvel.x - (sw[3] + C.xy_gain * sw[0]);
-          r2 = C.xy_gain * py + fvel.y - (sw[4] + C.xy_gain * sw[1]);
-        }
-        const int cdr = cd_row(dir);
-        CDt[cdr * 12 + 3 * i + 0] = r0.d;
-        CDt[cdr * 12 + 3 * i + 1] = r1.d;
-        CDt[cdr * 12 + 3 * i + 2] = r2.d;
-        if (dir == 0) {
-          rowval[3 * i + 0] = r0.v;
-          rowval[3 * i + 1] = r1.v;
-          rowval[3 * i + 2] = r2.v;
-        }
-      }
-    }
-    const double inv_m = rcp_t(M.total_mass);
-    const Dual1 f[12] = {Dual1(0.0), Dual1(0.0), Dual1(0.0), inv_m * ms.x, inv_m * ms.y, inv_m * ms.z,
-                         core.v_lin.x, core.v_lin.y, core.v_lin.z, Dual1(euler_rate_v.x), Dual1(euler_rate_v.y), Dual1(euler_rate_v.z)};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { Jp[i] = f[3 + i].d; Jp[3 + i] = comp(euler_rate_d, i); Jp[6 + i] = f[6 + i].d; }
-    if (dir == 0 && (pt == 1 || first_point_values)) {  // values of this point (single-node form: the first point's come from the pre-pass)
-      double fsx = 0, fsy = 0, fsz = 0;
-      for (int i = 0; i < HB_NC; ++i) { fsx += us[3 * i]; fsy += us[3 * i + 1]; fsz += us[3 * i + 2]; }
-      fv[12 * pt] = inv_m * fsx; fv[12 * pt + 1] = inv_m * fsy; fv[12 * pt + 2] = inv_m * fsz - M.gravity;
-#pragma unroll
-      for (int i = 3; i < 12; ++i) fv[12 * pt + i] = f[i].v;
+  for (int i = 0; i < HB_NC; ++i) {
+    const int leg = i & 1, f = i >> 1;
+    const Vec3<double> fb = ld3(LJ + leg * LEGJ_SIZE + LEGJ_FEET + 3 * f);   // contact-point position (leg block)
+    const Vec3<double> vj = ld3(LV + 15 + 6 * leg + 3 * f);                  // its joint-induced velocity (leg values)
+    Vec3<double> tp, tv;
+    if (tl == leg) leg_tangent_foot(LJs, ts % 5, ts >= 5, f, tp, tv);
+    const Vec3<double> a = tp + cross(dth, fb);
+    const Vec3<double> dfr = R * a;
+    const Vec3<double> dfv = dv + R * (cross(dwB, fb) + cross(wb, a) + tv + cross(dth, vj));
+    const Vec3<double> F(us[3 * i], us[3 * i + 1], us[3 * i + 2]);
+    dms = dms + cross(dfr - Rpp, F);
+    if (pt == 0) {
+      // constraint rows: slot 3i+a  (base position enters only through the closed-form lanes, lq_closed_task)
+      double r0, r1, r2;
+      if (cf[i]) { r0 = dfv.x; r1 = dfv.y; r2 = dfv.z + C.zv_gain * dfr.z; }
+      else { r0 = dfv.z + C.kp_normal * dfr.z; r1 = C.xy_gain * dfr.x + dfv.x; r2 = C.xy_gain * dfr.y + dfv.y; }
+      const int cdr = cd_row(dir);
+      CDt[cdr * 12 + 3 * i + 0] = r0;
+      CDt[cdr * 12 + 3 * i + 1] = r1;
+      CDt[cdr * 12 + 3 * i + 2] = r2;
     }
   }
+  // (the row may lie over leg blocks the contact loop above still read, LqLds::J1: stored last)
+  Jp[0] = inv_m * dms.x; Jp[1] = inv_m * dms.y; Jp[2] = inv_m * dms.z;
+  Jp[3] = der.x; Jp[4] = der.y; Jp[5] = der.z;
+  Jp[6] = dv.x; Jp[7] = dv.y; Jp[8] = dv.z;
 }
 
 // Constraint-row derivatives of the base-position directions (6..8; first RK2 point): closed form.  ti = 0..2.
@@ -443,8 +540,9 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     }
   }
   // joint rows q+ = q + dt qd: closed form, never stored (see LqLds)
+  // (f(x_e, u) waits in the x+ slot itself — lq_node's second value pass; entry i is read and replaced by the same lane)
   for (int i = cx.lane; i < 22; i += cx.nlanes)
-    xplus[i] = (i < 12) ? xs[i] + 0.5 * dt * (fv[i] + fv[12 + i]) : xs[i] + dt * us[i];
+    xplus[i] = (i < 12) ? xs[i] + 0.5 * dt * (fv[i] + xplus[i]) : xs[i] + dt * us[i];
   cx.sync();
 #if defined(__HIP_DEVICE_COMPILE__)
   if (cx.lane < 22) { lds[LqLds::park + cx.lane] = xref_reg; lds[LqLds::xnext_park + cx.lane] = xnext_reg; }  // (ordered by the barriers of the projection)
@@ -1037,75 +1135,99 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
                       [xs, us, dt](int g, int j) { return xs[12 + j] + ((g >> 1) ? dt : 0.0) * us[12 + j]; },
                       [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all, 3, [xs](int i) { return xs[9 + i]; }, SC, lq_leg_layout());
   HB_ABLATE_STOP(C.debug_stop == 6);
-  // ---- value of the flow map at the first RK2 point (plain doubles): the second point x + dt f(x, u) must be known before
-  // its directional pass can start, and a value-only evaluation costs well under half a dual pass.  Device: four lanes run
-  // the (identical) whole-body part and take one contact point each — the moment sum is a DPP add inside the quad — and
-  // the sine / cosine of the second point's ZYX angles come straight from the registers of lanes 0..2.
+  // ---- values of BOTH RK2 points (plain doubles), one after the other: flow map, constraint-row values of the first point, and the
+  // uniform values the direction lanes multiply their tangents with (lq_point_values / lq_store_point_values).  The second point
+  // x + dt f(x, u) needs the first one's flow map.  Device: four lanes run the (identical) whole-body part and take one contact
+  // point each — the moment sum is a DPP add inside the quad —, the sine / cosine of the second point's ZYX angles come straight
+  // from the registers of lanes 0..2, and (contact point - COM) of each contact waits in the CDt rows of the base-position directions
+  // (written after the direction pass): its own slot lies over data the pass still reads (LqLds::fr_slot).
+  double* rowval = P1.rowval;
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (cx.lane < 4) {
-    const double* LV = LV_all;
-    auto S = [LV](int e) { return LV[e]; };
-    CentroidalCore<double> core;
-    Sym3<double> IOs;
-    IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
-    centroidal_core<double>(M, Vec3<double>(S(0), S(1), S(2)), IOs, Vec3<double>(S(9), S(10), S(11)),
-                            Vec3<double>(S(12), S(13), S(14)), xs + 9, xs, core, SC);
-    // (keeps the compiler from clustering the LDS reads of the whole value pass up front: that alone cost 20 registers)
-    asm volatile("" ::: "memory");
-    const int i = cx.lane;
-    Vec3<double> fr, fvel;
-    centroidal_foot<double>(core, ld3(LJ_all + (i & 1) * LEGJ_SIZE + LEGJ_FEET + 3 * (i >> 1)), ld3(LV + 15 + 6 * (i & 1) + 3 * (i >> 1)), fr, fvel);
-    const Vec3<double> F(us[3 * i], us[3 * i + 1], us[3 * i + 2]);
-    const Vec3<double> mi = cross(fr - core.com_rel, F);
-    const double msx = quad_sum_f64(mi.x), msy = quad_sum_f64(mi.y), msz = quad_sum_f64(mi.z);
-    const double fsx = quad_sum_f64(F.x), fsy = quad_sum_f64(F.y), fsz = quad_sum_f64(F.z);
-    const double inv_m = rcp_t(M.total_mass);
-    if (i == 0) {
-      fv[0] = inv_m * fsx; fv[1] = inv_m * fsy; fv[2] = inv_m * fsz - M.gravity;
-      fv[3] = inv_m * msx; fv[4] = inv_m * msy; fv[5] = inv_m * msz;
-      fv[6] = core.v_lin.x; fv[7] = core.v_lin.y; fv[8] = core.v_lin.z;
-      fv[9] = core.euler_rate.x; fv[10] = core.euler_rate.y; fv[11] = core.euler_rate.z;
-    }
-    if (i < 3) sincos_t(xs[9 + i] + dt * comp(core.euler_rate, i), SC[6 + 2 * i], SC[6 + 2 * i + 1]);
-  }
-  cx.sync();
-  // second evaluation point of Heun's method: x + dt f(x,u), same input
-  if (cx.lane < 22) xe[cx.lane] = xs[cx.lane] + dt * (cx.lane < 12 ? fv[cx.lane] : us[cx.lane]);
-  cx.sync();
-#else
-  for (int l = cx.lane; l < 1; l += cx.nlanes) {
-    const double* LV = LV_all;
-    auto S = [LV](int e) { return LV[e]; };
-    CentroidalCore<double> core;
-    Sym3<double> IOs;
-    IOs.xx = S(3); IOs.xy = S(4); IOs.xz = S(5); IOs.yy = S(6); IOs.yz = S(7); IOs.zz = S(8);
-    centroidal_core<double>(M, Vec3<double>(S(0), S(1), S(2)), IOs, Vec3<double>(S(9), S(10), S(11)),
-                            Vec3<double>(S(12), S(13), S(14)), xs + 9, xs, core, SC);
-    Vec3<double> msum;
-    double fsx = 0, fsy = 0, fsz = 0;
-    for (int i = 0; i < HB_NC; ++i) {
-      Vec3<double> fr, fvel;
-      centroidal_foot<double>(core, ld3(LJ_all + (i & 1) * LEGJ_SIZE + LEGJ_FEET + 3 * (i >> 1)), ld3(LV + 15 + 6 * (i & 1) + 3 * (i >> 1)), fr, fvel);
+  double* fr_wait = P1.CDt + 6 * 12;   // rows of the base-position directions: written by lq_closed_task, after the direction pass
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    if (cx.lane < 4) {
+      const int i = cx.lane;
+      double* LV = LV_all + pt * LqLds::LVP;
+      LqPointValues pv;
+      lq_point_values(M, LV, SC + 6 * pt, pt == 0 ? xs : xe, pv);
+      // (keeps the compiler from clustering the LDS reads of the whole value pass up front: that alone cost 20 registers)
+      asm volatile("" ::: "memory");
+      const Vec3<double> fr = pv.R * ld3(LJ_all + (2 * pt + (i & 1)) * LEGJ_SIZE + LEGJ_FEET + 3 * (i >> 1));
+      const Vec3<double> fvel = pv.v_lin + cross(pv.omega, fr) + pv.R * ld3(LV + 15 + 6 * (i & 1) + 3 * (i >> 1));
       const Vec3<double> F(us[3 * i], us[3 * i + 1], us[3 * i + 2]);
-      msum = msum + cross(fr - core.com_rel, F);
-      fsx += F.x; fsy += F.y; fsz += F.z;
+      const Vec3<double> rr = fr - pv.com_rel;
+      st3(fr_wait + 12 * pt + 3 * i, rr);
+      const Vec3<double> mi = cross(rr, F);
+      const double msx = quad_sum_f64(mi.x), msy = quad_sum_f64(mi.y), msz = quad_sum_f64(mi.z);
+      const double fsx = quad_sum_f64(F.x), fsy = quad_sum_f64(F.y), fsz = quad_sum_f64(F.z);
+      const double inv_m = rcp_t(M.total_mass);
+      if (pt == 0) lq_row_values(C, cf[i], xs[8] + fr.z, xs[6] + fr.x, xs[7] + fr.y, fvel, in.swing + 6 * i, rowval + 3 * i);
+      if (i == 0) {   // (every lane of the quad has read the leg composites and x_e by now: one wavefront in lockstep)
+        double* fo = pt == 0 ? fv : xe;   // f(x_e, u) waits in x_e's slot: the tail forms x+ there
+        fo[0] = inv_m * fsx; fo[1] = inv_m * fsy; fo[2] = inv_m * fsz - M.gravity;
+        fo[3] = inv_m * msx; fo[4] = inv_m * msy; fo[5] = inv_m * msz;
+        fo[6] = pv.v_lin.x; fo[7] = pv.v_lin.y; fo[8] = pv.v_lin.z;
+        fo[9] = pv.euler_rate.x; fo[10] = pv.euler_rate.y; fo[11] = pv.euler_rate.z;
+        lq_store_point_values(pv, pt, LJ_all, LV, xe);
+      }
+      if (pt == 0 && i < 3) sincos_t(xs[9 + i] + dt * comp(pv.euler_rate, i), SC[6 + 2 * i], SC[6 + 2 * i + 1]);
     }
-    const double inv_m = rcp_t(M.total_mass);
-    fv[0] = inv_m * fsx; fv[1] = inv_m * fsy; fv[2] = inv_m * fsz - M.gravity;
-    fv[3] = inv_m * msum.x; fv[4] = inv_m * msum.y; fv[5] = inv_m * msum.z;
-    fv[6] = core.v_lin.x; fv[7] = core.v_lin.y; fv[8] = core.v_lin.z;
-    fv[9] = core.euler_rate.x; fv[10] = core.euler_rate.y; fv[11] = core.euler_rate.z;
-    for (int i = 0; i < 22; ++i) xe[i] = xs[i] + dt * (i < 12 ? fv[i] : us[i]);
+    cx.sync();
+    if (pt == 0) {
+      // second evaluation point of Heun's method: x + dt f(x,u), same input (rows 0..11: the leg pass formed q + dt qd itself)
+      if (cx.lane < 12) xe[cx.lane] = xs[cx.lane] + dt * fv[cx.lane];
+      cx.sync();
+    }
   }
-  cx.sync();
-  for (int i = cx.lane; i < 3; i += cx.nlanes) sincos_t(xe[9 + i], SC[6 + 2 * i], SC[6 + 2 * i + 1]);
-  cx.sync();
+#else
+  double* FRh = lds + LqLds::FRh;
+  for (int pt = 0; pt < 2; ++pt) {
+    for (int l = cx.lane; l < 1; l += cx.nlanes) {
+      double* LV = LV_all + pt * LqLds::LVP;
+      LqPointValues pv;
+      lq_point_values(M, LV, SC + 6 * pt, pt == 0 ? xs : xe, pv);
+      Vec3<double> msum;
+      double fsx = 0, fsy = 0, fsz = 0;
+      for (int i = 0; i < HB_NC; ++i) {
+        const Vec3<double> fr = pv.R * ld3(LJ_all + (2 * pt + (i & 1)) * LEGJ_SIZE + LEGJ_FEET + 3 * (i >> 1));
+        const Vec3<double> fvel = pv.v_lin + cross(pv.omega, fr) + pv.R * ld3(LV + 15 + 6 * (i & 1) + 3 * (i >> 1));
+        const Vec3<double> F(us[3 * i], us[3 * i + 1], us[3 * i + 2]);
+        const Vec3<double> rr = fr - pv.com_rel;
+        st3(FRh + 12 * pt + 3 * i, rr);
+        msum = msum + cross(rr, F);
+        fsx += F.x; fsy += F.y; fsz += F.z;
+        if (pt == 0) lq_row_values(C, cf[i], xs[8] + fr.z, xs[6] + fr.x, xs[7] + fr.y, fvel, in.swing + 6 * i, rowval + 3 * i);
+      }
+      const double inv_m = rcp_t(M.total_mass);
+      double* fo = pt == 0 ? fv : xe;
+      fo[0] = inv_m * fsx; fo[1] = inv_m * fsy; fo[2] = inv_m * fsz - M.gravity;
+      fo[3] = inv_m * msum.x; fo[4] = inv_m * msum.y; fo[5] = inv_m * msum.z;
+      fo[6] = pv.v_lin.x; fo[7] = pv.v_lin.y; fo[8] = pv.v_lin.z;
+      fo[9] = pv.euler_rate.x; fo[10] = pv.euler_rate.y; fo[11] = pv.euler_rate.z;
+      lq_store_point_values(pv, pt, LJ_all, LV, xe);
+      if (pt == 0) {
+        for (int i = 0; i < 12; ++i) xe[i] = xs[i] + dt * fv[i];
+        for (int i = 0; i < 3; ++i) sincos_t(xe[9 + i], SC[6 + 2 * i], SC[6 + 2 * i + 1]);
+      }
+    }
+    cx.sync();
+  }
 #endif
   HB_ABLATE_STOP(C.debug_stop == 7);
-  // ---- stage 2: whole-body combine per (point, direction).  Only 29 of the 44 directions are nonlinear (momentum 0..5,
-  // zyx 9..11, joints 12..21, joint rates 34..43), so both RK2 points fit ONE pass of the wave: task = 29 pt + index.
-  for (int task = cx.lane; task < 58; task += cx.nlanes) lq_dual_task(M, C, lds, in.mode, in.swing, task >= 29 ? 1 : 0, task >= 29 ? task - 29 : task, false);
+  // ---- stage 2: tangents of the whole-body combine per (point, direction).  Only 29 of the 44 directions are nonlinear (momentum
+  // 0..5, zyx 9..11, joints 12..21, joint rates 34..43), so both RK2 points fit ONE pass of the wave: task = 29 pt + index.
+  for (int task = cx.lane; task < 58; task += cx.nlanes) lq_tangent_task(M, C, lds, in.mode, task >= 29 ? 1 : 0, task >= 29 ? task - 29 : task);
   cx.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (contact point - COM) of both points for the contact-force directions of the compose: from their waiting place to the slot of the
+  // contact's velocity, which the pass has finished with
+  if (cx.lane < 24) {
+    const int pt = cx.lane / 12, e = cx.lane - 12 * pt;
+    lds[LqLds::fr_slot(pt, e / 3) + e % 3] = (P1.CDt + 6 * 12)[cx.lane];
+  }
+  cx.sync();
+#endif
   HB_ABLATE_STOP(C.debug_stop == 9);
   // constraint rows of the base-position directions (closed form)
   for (int task = cx.lane; task < 3; task += cx.nlanes) lq_closed_task(C, lds, in.mode, task);

@@ -12,6 +12,7 @@ ap.add_argument("--ablate-lq", action="store_true")
 ap.add_argument("--ablate-ric", action="store_true")
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--chunks", type=int, default=1)
+ap.add_argument("--no-tail", action="store_true", help="A/B: alpha_decay = 0, i.e. no backtracking-tail launches")
 ap.add_argument("--stop", type=int, default=None, help="run ONLY this ablation stop (HB_ABLATE build), few steps: for counter passes")
 args = ap.parse_args()
 from pathlib import Path
@@ -25,7 +26,7 @@ B, N = args.batch, 100
 
 
 def run(reserved=0, steps=args.steps):
-    s = HunterSolver(P, batch=B, max_nodes=N, reserved=reserved)
+    s = HunterSolver(P, batch=B, max_nodes=N, reserved=reserved, **({"alpha_decay": 0.0} if args.no_tail else {}))
     w = workload.device_trot_batch(s, P, n_intervals=N)
     s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
     s.set_resident_x0_sequence(bench.x0_sequence(w["x0"], 0))

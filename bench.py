@@ -373,7 +373,7 @@ def main():
                          f"(--gpus {args.gpus} needs one MI355X per rank)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:   # under the launcher (any world size, 1 included): barrier / reductions / gather go through RCCL
         import torch.distributed as dist
         dist.init_process_group(backend="nccl")  # RCCL
 

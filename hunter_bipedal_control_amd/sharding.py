@@ -12,7 +12,7 @@ def shard_range(total: int, world: int, rank: int) -> tuple[int, int]:
 
 
 def max_over_ranks(value: float, dist=None, device="cpu") -> float:
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():   # (a process group of one rank still goes through the collective: same code path)
         return float(value)
     import torch
     t = torch.tensor([value], dtype=torch.float64, device=device)
@@ -24,7 +24,7 @@ def sum_over_ranks(values, dist=None, device="cpu"):
     """All-reduce (sum) of a small integer vector, e.g. {n_ok, n_maxiter, n_infeasible, n_nan}."""
     import torch
     t = torch.tensor(list(values), dtype=torch.int64, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(v) for v in t.tolist()]
 

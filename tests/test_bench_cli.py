@@ -56,3 +56,26 @@ def test_launcher_command_line(monkeypatch):
     assert a[a.index("--master-addr") + 1] == "127.0.0.1"
     assert a[-4:] == ["--gpus", "4", "--steps", "7"] and a[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_under_the_launcher_goes_through_rccl_even_with_one_rank():
+    """The driver's multi-GPU launch line with ONE rank on the one GPU of this box: process group on the nccl (= RCCL) backend,
+    barrier, MAX / SUM all-reduces of the timing and the status histograms on device tensors, and the optional all-gather of the
+    outputs — the code the 2 / 4 / 8-rank runs execute, minus the peers."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", str(ROOT / "bench.py"), "--gpus", "1", "--total-batch", "96", "--nodes", "24", "--steps", "4",
+                        "--warmup", "1", "--random-cmd", "--gather", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+    j = json.loads(lines[-1])
+    assert j["n_gpus"] == 1 and j["scaling"] == "strong" and j["config"]["total_instances"] == 96
+    assert j["gather"]["bytes_per_rank"] > 0 and j["gather"]["ms_per_step"] > 0
+    assert sum(j["solver_state"]["mpc_status_histogram_all_ranks"]) == 96

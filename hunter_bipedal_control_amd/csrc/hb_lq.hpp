@@ -745,6 +745,23 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
 
   HB_ABLATE_STOP(C.debug_stop == 3);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the per-role constants of the cost phase (lane = role): weight and the two limits of the role's relaxed barrier, requested HERE —
+  // behind the projection, whose factor has left the registers — so that their global-memory round trip runs under the record's dynamics
+  // part instead of in the middle of the cost phase
+  double cw_reg = 0.0, clo_reg = 0.0, chi_reg = 0.0;
+  {
+    const int role = cx.lane;
+    if (role < 22) {
+      cw_reg = C.Q_diag[role];
+      if (role >= 12) { clo_reg = M.q_lower[role - 12]; chi_reg = M.q_upper[role - 12]; }
+    } else if (role < 34) {
+      cw_reg = C.R_FF_diag[role - 22];
+    } else if (role < 44) {
+      clo_reg = M.qd_limit[role - 34];
+    }
+  }
+#endif
   // The shooting defect x+ - x_next: from here on the x+ slot holds it (read by b~ right below and by the cost phase).
   for (int i = cx.lane; i < 22; i += cx.nlanes) xplus[i] -= xnext_at(i);
   cx.sync();
@@ -855,7 +872,12 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         if (role >= 12 && role < 22) {
           const int j = role - 12;
           const double h = xs[role];
+#if defined(__HIP_DEVICE_COMPILE__)
+          (void)j;
+          hasb = true; h1 = h - clo_reg; h2 = chi_reg - h; bmu = bp.mu; bdel = bp.delta;
+#else
           hasb = true; h1 = h - M.q_lower[j]; h2 = M.q_upper[j] - h; bmu = bp.mu; bdel = bp.delta;
+#endif
         } else if (role >= 22 && role < 34) {
           const int m = role - 22;
           if (m - 3 * (m / 3) == 2) {
@@ -864,7 +886,11 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
           }
         } else if (role >= 34 && role < 44) {
           const int k = role - 34;
+#if defined(__HIP_DEVICE_COMPILE__)
+          const double hv = us[12 + k], vl = clo_reg;
+#else
           const double hv = us[12 + k], vl = M.qd_limit[k];
+#endif
           hasb = true; h1 = hv + vl; h2 = vl - hv; bmu = bv.mu; bdel = bv.delta;
         }
         if (hasb) {
@@ -877,8 +903,13 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       if (role < 22) {
         const int i = role;
         const double dxv = xs[i] - xref_at(i);  // i == lane
-        double qd_ = C.Q_diag[i] + shift_sum, qg = C.Q_diag[i] * dxv;
-        pc += 0.5 * C.Q_diag[i] * dxv * dxv;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double Qi = cw_reg;
+#else
+        const double Qi = C.Q_diag[i];
+#endif
+        double qd_ = Qi + shift_sum, qg = Qi * dxv;
+        pc += 0.5 * Qi * dxv * dxv;
         if (i >= 12) {
           pc += bval;
           qg += bd1;
@@ -891,8 +922,13 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       } else if (role < 34) {
         const int m = role - 22, foot = m / 3, a = m % 3;
         const double du = us[m] - ((a == 2 && cf[foot]) ? fz_nom : 0.0);
-        double rg = C.R_FF_diag[m] * du;
-        pc += 0.5 * C.R_FF_diag[m] * du * du;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double Rm_ = cw_reg;
+#else
+        const double Rm_ = C.R_FF_diag[m];
+#endif
+        double rg = Rm_ * du;
+        pc += 0.5 * Rm_ * du * du;
         if (cf[foot]) {
           rg += coneb[12 * foot + 8] * coneb[12 * foot + 1 + a];
         } else {
@@ -1106,6 +1142,16 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* xs = P1.xs; double* us = P1.us; double* xe = P1.xe; double* fv = P1.fv; double* LV_all = P1.LV_all; double* SC = P1.SC;
   // (xs, us stay valid to the end of the kernel — no later buffer reaches them — and every later phase reads x and u from
   // these LDS copies instead of going back to global memory)
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the model constants of this lane's (leg evaluation, joint) task of the leg pass: requested together with x and u (one global-memory
+  // round trip instead of two in a row; the lane -> task map is the one of leg_value_pass_coop)
+  LegJointConst jc_pre;
+  {
+    const int dg = cx.lane >> 3, dk = cx.lane & 7;
+    const bool dvalid = dk < 5 && dg < 4;
+    leg_joint_const_load(M, 5 * ((dvalid ? dg : 0) & 1) + (dvalid ? dk : 0), jc_pre);
+  }
+#endif
   for (int i = cx.lane; i < 22; i += cx.nlanes) {
     xs[i] = in.x[i];
     us[i] = in.u[i];
@@ -1133,7 +1179,11 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* LJ_all = lds + LqLds::LJ;  // 4 x LEGJ_SIZE; its head is overwritten by ABt in the final compose
   leg_value_pass_coop(cx, M, 4, [](int g) { return g & 1; },
                       [xs, us, dt](int g, int j) { return xs[12 + j] + ((g >> 1) ? dt : 0.0) * us[12 + j]; },
-                      [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all, 3, [xs](int i) { return xs[9 + i]; }, SC, lq_leg_layout());
+                      [us](int, int j) { return us[12 + j]; }, LJ_all, LV_all, 3, [xs](int i) { return xs[9 + i]; }, SC, lq_leg_layout()
+#if defined(__HIP_DEVICE_COMPILE__)
+                      , &jc_pre
+#endif
+                      );
   HB_ABLATE_STOP(C.debug_stop == 6);
   // ---- values of BOTH RK2 points (plain doubles), one after the other: flow map, constraint-row values of the first point, and the
   // uniform values the direction lanes multiply their tangents with (lq_point_values / lq_store_point_values).  The second point

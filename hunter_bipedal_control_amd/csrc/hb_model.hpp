@@ -254,20 +254,26 @@ struct LegLayout {
   HB_HD int val(int g) const { return pair_sum ? (g >> 1) * 27 : (g / gpb) * hi + (g % gpb) * nval(); }
   HB_HD int xsc(int i) const { return (i / xpn) * hi + 2 * (i % xpn); }
 };
+// Model constants of one joint and the body behind it (what a (group, joint) task of the cooperative leg pass needs).
+struct LegJointConst { double ax[3], org[3], com[3], in[6], m; };
+HB_HD void leg_joint_const_load(const DevModel& M, int j, LegJointConst& c) {
+  const int b = j + 1;
+  for (int e = 0; e < 3; ++e) { c.ax[e] = M.axis[j][e]; c.org[e] = M.origin[j][e]; c.com[e] = M.com[b][e]; }
+  for (int e = 0; e < 6; ++e) c.in[e] = M.inertia[b][e];
+  c.m = M.mass[b];
+}
+// `pre` (device): the constants of THIS lane's task, requested by the caller earlier — k_lq asks for them together with the node's state
+// and input, so that the model struct's global-memory round trip runs under the one of x and u instead of behind it.
 template <class Ctx, class LEG, class QF, class QDF, class XA = NoExtraAngles>
 HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LEG leg_of, QF qj, QDF qdj, double* blk_all, double* val_all,
-                               int n_extra = 0, XA extra = XA(), double* extra_sc = nullptr, LegLayout lay = LegLayout()) {
+                               int n_extra = 0, XA extra = XA(), double* extra_sc = nullptr, LegLayout lay = LegLayout(),
+                               const LegJointConst* pre = nullptr) {
   const int ntask = 5 * ngroups;
   // Model constants of this lane's (group, joint) task, requested ONCE up front (device: one task per lane): read where they
   // are used, every stage paid a global-memory round trip on the model struct — five of them inside the serial frame chain.
   // The joint origin goes to the chain through LDS (slots 15..17 of the joint block, free until stage B).
-  struct JC { double ax[3], org[3], com[3], in[6], m; };
-  auto load_jc = [&M](int j, JC& c) {
-    const int b = j + 1;
-    for (int e = 0; e < 3; ++e) { c.ax[e] = M.axis[j][e]; c.org[e] = M.origin[j][e]; c.com[e] = M.com[b][e]; }
-    for (int e = 0; e < 6; ++e) c.in[e] = M.inertia[b][e];
-    c.m = M.mass[b];
-  };
+  using JC = LegJointConst;
+  auto load_jc = [&M](int j, JC& c) { leg_joint_const_load(M, j, c); };
 #if defined(__HIP_DEVICE_COMPILE__)
   // Device: the whole pass is register resident, one (group, joint) pair per lane, group g on lanes 8 g .. 8 g + 4 (at most four
   // groups).  A group never straddles a DPP row of 16 and its lanes 5..7 carry neutral elements, so everything that runs along
@@ -282,7 +288,8 @@ HB_HD void leg_value_pass_coop(const Ctx& cx, const DevModel& M, int ngroups, LE
     const int g = dvalid ? dg : 0, k = dvalid ? dk : 0;
     const double on = dvalid ? 1.0 : 0.0;   // padding lanes contribute zeros to the sums
     JC jc;
-    load_jc(5 * leg_of(g) + k, jc);
+    if (pre) jc = *pre;
+    else load_jc(5 * leg_of(g) + k, jc);
     double* blk = blk_all + lay.blk(g);
     double* B = blk + k * LEGJ_STRIDE;
     // A: local joint rotations (extra angles ride on lanes 32 ..)

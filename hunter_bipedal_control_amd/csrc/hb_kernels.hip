@@ -209,7 +209,6 @@ __global__ void k_mpc_status(Batch b, int first_iteration) {
 #endif
 __global__ __launch_bounds__(64, 3) void k_lq(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
   const int k = blockIdx.x, inst = blockIdx.y;
-  if (k >= b.n_nodes[inst]) return;
   __shared__ double lds[LqLds::total + HB_LQ_LDS_PAD];
   const size_t nd = size_t(inst) * b.Nmax + k;
   const double* tt = b.t + size_t(inst) * (b.Nmax + 1);
@@ -219,13 +218,24 @@ __global__ __launch_bounds__(64, 3) void k_lq(Batch b, const DevModel* __restric
   in.u = b.u + nd * HB_NU;
   in.xref = b.xref + nd * HB_NX;
   in.swing = b.swing + nd * 24;
+  // Everything the node's entry reads from global memory is requested BEFORE the node-count test (every node slot of the arrays
+  // exists): node count, interval, mode, this lane's entry of x and u, the lane's leg-pass constants — one round trip, not four in a row
+  const int n_nodes = b.n_nodes[inst];
+  LegJointConst jc;
+  lq_leg_const_of_lane(*M, threadIdx.x, jc);
+  if (threadIdx.x < HB_NX) { in.x_lane = in.x[threadIdx.x]; in.u_lane = in.u[threadIdx.x]; }
+  in.jc = &jc;
+  in.preloaded = true;
+  const double t_a = tt[k], t_b = tt[k + 1];
+  const int mode_v = b.mode[nd];
+  if (k >= n_nodes) return;
   {
-    const double dtv = tt[k + 1] - tt[k];  // (uniform: kept in a scalar register pair for the whole node)
+    const double dtv = t_b - t_a;  // (uniform: kept in a scalar register pair for the whole node)
     const long long bits = __builtin_bit_cast(long long, dtv);
     const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(bits)), hi = __builtin_amdgcn_readfirstlane(unsigned(bits >> 32));
     in.dt = __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
   }
-  in.mode = __builtin_amdgcn_readfirstlane(b.mode[nd]);  // (uniform by construction; tells the compiler so: mode tests become scalar)
+  in.mode = __builtin_amdgcn_readfirstlane(mode_v);  // (uniform by construction; tells the compiler so: mode tests become scalar)
   lq_node(WaveCtx(), *M, *C, in, lds, b.recs + nd * REC_SIZE);
 }
 

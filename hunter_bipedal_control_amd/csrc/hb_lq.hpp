@@ -202,6 +202,12 @@ struct NodeIn {
   const double* swing;  // 24
   double dt;
   int mode;
+  // device kernel: entry `lane` of x and u and the leg-pass constants of the lane's task, REQUESTED BY THE KERNEL BEFORE it knows whether
+  // the node exists (the addresses are valid for every node slot): all the global-memory round trips of the kernel's entry — node count,
+  // interval, mode, state, input, model constants — then run side by side instead of one behind the other
+  bool preloaded = false;
+  double x_lane = 0.0, u_lane = 0.0;
+  const LegJointConst* jc = nullptr;
 };
 
 // Pointers into the phase-1 view of one node's LDS region (LqLds).
@@ -1126,6 +1132,12 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
 }
 
+// model constants of the (leg evaluation, joint) task lane `lane` has in k_lq's leg pass (leg_value_pass_coop: group lane >> 3, joint lane & 7)
+HB_HD void lq_leg_const_of_lane(const DevModel& M, int lane, LegJointConst& jc) {
+  const int dg = lane >> 3, dk = lane & 7;
+  const bool dvalid = dk < 5 && dg < 4;
+  leg_joint_const_load(M, 5 * ((dvalid ? dg : 0) & 1) + (dvalid ? dk : 0), jc);
+}
 template <class Ctx>
 HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const NodeIn& in, double* lds, double* rec) {
   const double dt = in.dt;
@@ -1144,13 +1156,13 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   // these LDS copies instead of going back to global memory)
 #if defined(__HIP_DEVICE_COMPILE__)
   // the model constants of this lane's (leg evaluation, joint) task of the leg pass: requested together with x and u (one global-memory
-  // round trip instead of two in a row; the lane -> task map is the one of leg_value_pass_coop)
-  LegJointConst jc_pre;
-  {
-    const int dg = cx.lane >> 3, dk = cx.lane & 7;
-    const bool dvalid = dk < 5 && dg < 4;
-    leg_joint_const_load(M, 5 * ((dvalid ? dg : 0) & 1) + (dvalid ? dk : 0), jc_pre);
-  }
+  // round trip instead of two in a row; the lane -> task map is the one of leg_value_pass_coop) — by the kernel itself when it can
+  LegJointConst jc_own;
+  if (!in.preloaded) lq_leg_const_of_lane(M, cx.lane, jc_own);
+  const LegJointConst& jc_pre = in.preloaded ? *in.jc : jc_own;
+  if (in.preloaded) {
+    if (cx.lane < 22) { xs[cx.lane] = in.x_lane; us[cx.lane] = in.u_lane; xe[cx.lane] = in.x_lane; }
+  } else
 #endif
   for (int i = cx.lane; i < 22; i += cx.nlanes) {
     xs[i] = in.x[i];
@@ -1194,6 +1206,10 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   double* rowval = P1.rowval;
 #if defined(__HIP_DEVICE_COMPILE__)
   double* fr_wait = P1.CDt + 6 * 12;   // rows of the base-position directions: written by lq_closed_task, after the direction pass
+  // the swing reference of this lane's contact point (first value pass): requested here, a whole value computation ahead of its use
+  double sw_pre[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) sw_pre[e] = in.swing[6 * (cx.lane & 3) + e];
 #pragma unroll
   for (int pt = 0; pt < 2; ++pt) {
     if (cx.lane < 4) {
@@ -1212,7 +1228,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       const double msx = quad_sum_f64(mi.x), msy = quad_sum_f64(mi.y), msz = quad_sum_f64(mi.z);
       const double fsx = quad_sum_f64(F.x), fsy = quad_sum_f64(F.y), fsz = quad_sum_f64(F.z);
       const double inv_m = rcp_t(M.total_mass);
-      if (pt == 0) lq_row_values(C, cf[i], xs[8] + fr.z, xs[6] + fr.x, xs[7] + fr.y, fvel, in.swing + 6 * i, rowval + 3 * i);
+      if (pt == 0) lq_row_values(C, cf[i], xs[8] + fr.z, xs[6] + fr.x, xs[7] + fr.y, fvel, sw_pre, rowval + 3 * i);
       if (i == 0) {   // (every lane of the quad has read the leg composites and x_e by now: one wavefront in lockstep)
         double* fo = pt == 0 ? fv : xe;   // f(x_e, u) waits in x_e's slot: the tail forms x+ there
         fo[0] = inv_m * fsx; fo[1] = inv_m * fsy; fo[2] = inv_m * fsz - M.gravity;

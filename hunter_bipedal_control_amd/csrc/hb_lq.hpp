@@ -406,7 +406,7 @@ HB_HD void lq_tangent_task(const DevModel& M, const DevConfig& C, double* lds, i
   const Vec3<double> Rpp = R * pp;
   const Vec3<double> dv = dhlin - R * (cross(dwB, P) + cross(wb, pp) + inv_m * (dlj + cross(dth, lj)));
   Vec3<double> dms;
-#pragma unroll 1
+#pragma unroll 2   // (two contact points per trip: their LDS round trips overlap; rolled, each trip waited for its own — 0.9 % of the kernel)
   for (int i = 0; i < HB_NC; ++i) {
     const int leg = i & 1, f = i >> 1;
     const Vec3<double> fb = ld3(LJ + leg * LEGJ_SIZE + LEGJ_FEET + 3 * f);   // contact-point position (leg block)

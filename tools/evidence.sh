@@ -34,6 +34,10 @@ prof rollout python $R/tools/bench_rollout.py
 # counters
 bash tools/gpu_pmc.sh ${tag}pmc > $out/pmc.log 2>&1
 cp gpurun_out/${tag}pmc/pmc.txt $out/${tag}_pmc.txt 2>/dev/null; cp gpurun_out/${tag}pmc/pmc.json $out/${tag}_pmc.json 2>/dev/null
+# the files name the round, not the scratch directories they were collected in
+sed -i "s/\"tag\": \"[^\"]*\"/\"tag\": \"$tag\"/" $out/${tag}_pmc.json 2>/dev/null
+sed -i "1s/(\([^)]*\))/($tag)/" $out/${tag}_pmc.txt 2>/dev/null
+sed -i "1s#of .*/prof_\([a-z0-9_]*\)/.*#of gpurun_out/$tag/prof_\1/run_results.db#" $out/${tag}_kernel_stats*.txt 2>/dev/null
 [ -f variants/libhunter_hip_ablate.so ] && bash tools/lq_phase_pmc.sh $tag > $out/lqpmc.log 2>&1 && cp gpurun_out/$tag/lqpmc/summary.txt $out/${tag}_lq_phase_pmc.txt
 ls -la $out
 head -c 900 $out/${tag}_bench.json

@@ -476,7 +476,19 @@ __global__ __launch_bounds__(256, 2) void k_ric_bwd4(Batch b, int dbg) {
   if (tid == 0) b.ric_fail[inst] = lds[Ric4Lds::flag] != 0.0 ? 1 : 0;
 }
 
-__global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
+// Forward sweep, one wavefront per instance.  Two forms of the same arithmetic (hb_riccati.hpp: every dot product in four partial
+// sums, (p0 + p1) + (p2 + p3)), bit-identical (test_sqp_step_identical_with_either_form_of_the_sweeps):
+//   WAVE = false  a lane owns a row (riccati_fwd_node): 56 registers, a long chain of LDS reads per stage — a light resident that fills
+//                 the holes other instance ranges' kernels leave; what large batches want (k_ric_fwd moves 8.7 KB per stage and is at the
+//                 HBM rate, 4.8 TB/s, once a SIMD holds three or four of them);
+//   WAVE = true   four lanes per row, no divergence (riccati_fwd_stage_wave): the stage is ~ 2.5 x shorter — what a batch that leaves the
+//                 SIMDs one wavefront each wants (512 instances: 0.177 -> 0.11 ms, then also at the HBM rate, 4.2 TB/s).  130 registers;
+//                 on 1024 .. 4096 instances in four free-running ranges it measured 1 .. 5 % SLOWER than the row form (it is a worse
+//                 neighbour), hence the selection by concurrent instances in launch_ric_fwd.
+// (Requesting the records more than one stage ahead — four register sets — bought nothing in either regime.)
+template <bool WAVE>
+__device__ __forceinline__ void ric_fwd_body(const Batch& b) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the wave form of the step only exists in the device pass)
   __builtin_amdgcn_s_setprio(3);  // see k_ric_bwd
   const int inst = blockIdx.x;
   __shared__ double lds[FwdLds::total];
@@ -503,6 +515,9 @@ __global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
     _Pragma("unroll") for (int r = 0; r < N_G; ++r) bg[r] = (64 * r + 63 < P_G || l + 64 * r < P_G) ? pg_[64 * r] : d2{0.0, 0.0}; \
   }
   if (n > 0) HB_FWD_FETCH(0);
+  FwdLane L;
+  if (WAVE) fwd_lane_init(l, L);
+  double accp = 0.0, accm = 0.0;
   for (int k = 0; k < n; ++k) {
     {
       d2* sab = reinterpret_cast<d2*>(lds + FwdLds::AB) + l;
@@ -518,10 +533,16 @@ __global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
     cx.sync();
     if (k + 1 < n) HB_FWD_FETCH(k + 1);
     const size_t nd = size_t(inst) * b.Nmax + k;
-    riccati_fwd_node(cx, lds, lds + FwdLds::AB, lds + FwdLds::RX, lds + FwdLds::G,
-                     b.dx + (size_t(inst) * (b.Nmax + 1) + k) * HB_NX, b.du + nd * HB_NU);
+    double* dxo = b.dx + (size_t(inst) * (b.Nmax + 1) + k) * HB_NX;
+    if (WAVE) riccati_fwd_stage_wave(cx, lds, L, accp, accm, dxo, b.du + nd * HB_NU);
+    else riccati_fwd_node(cx, lds, lds + FwdLds::AB, lds + FwdLds::RX, lds + FwdLds::G, dxo, b.du + nd * HB_NU);
   }
 #undef HB_FWD_FETCH
+  if (WAVE) {   // (the row form keeps these sums in LDS)
+    if (cx.lane < 22) lds[FwdLds::accp + cx.lane] = accp;
+    else if (cx.lane < 25) lds[FwdLds::acc + cx.lane - 21] = accm;
+    cx.sync();
+  }
   riccati_fwd_finish(cx, lds);
   if (cx.lane < HB_NX) b.dx[(size_t(inst) * (b.Nmax + 1) + n) * HB_NX + cx.lane] = lds[FwdLds::dx + cx.lane];
   if (cx.lane < 4) b.acc[inst * 4 + cx.lane] = lds[FwdLds::acc + cx.lane];
@@ -532,7 +553,11 @@ __global__ __launch_bounds__(64) void k_ric_fwd(Batch b) {
     b.perf[inst * 4 + 2] = lds[FwdLds::acc + 3];
     b.perf[inst * 4 + 3] = 0.0;
   }
+#endif
 }
+__global__ __launch_bounds__(64) void k_ric_fwd(Batch b) { ric_fwd_body<false>(b); }
+__global__ __launch_bounds__(64) void k_ric_fwd_w(Batch b) { ric_fwd_body<true>(b); }
+constexpr int kRicFwdWaveMaxBatch = 512;
 
 // line search: value of trial point (x + alpha dx, u + alpha du), one thread per node
 __global__ __launch_bounds__(64) void k_ls_eval(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C,
@@ -1912,6 +1937,13 @@ static void launch_ric_bwd(hb_ctx* ctx, const Batch& b, int B, int concurrent, h
   else hipLaunchKernelGGL(k_ric_bwd, dim3(B), dim3(64), 0, s, b, sel);
 }
 
+// Forward sweep: the wave form while the batch leaves a SIMD one wavefront (hb_config.reserved = 111 / 114 force the row / the wave form)
+static void launch_ric_fwd(hb_ctx* ctx, const Batch& b, int B, int concurrent, hipStream_t s) {
+  const int sel = ctx->hconfig.debug_stop;
+  if (sel == 114 || (sel != 111 && concurrent <= kRicFwdWaveMaxBatch)) hipLaunchKernelGGL(k_ric_fwd_w, dim3(B), dim3(64), 0, s, b);
+  else hipLaunchKernelGGL(k_ric_fwd, dim3(B), dim3(64), 0, s, b);
+}
+
 static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t stream = nullptr) {
   const bool whole = cnt < 0;
   if (whole) {
@@ -1929,7 +1961,7 @@ static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t
     if (timed) HB_HIP(hipEventRecord(ctx->ev[1], s));
     launch_ric_bwd(ctx, b, B, ctx->B, s);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[2], s));
-    hipLaunchKernelGGL(k_ric_fwd, dim3(B), dim3(64), 0, s, b);
+    launch_ric_fwd(ctx, b, B, ctx->B, s);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[3], s));
     // filter line search: the full step for every instance, node-parallel; then the backtracking tail in one launch
     hipLaunchKernelGGL(k_ls_eval, dim3((B * N + 63) / 64), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, 1.0);

@@ -1119,7 +1119,7 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   HB_ABLATE_STOP(C.debug_stop == 34);
   // recovery data
   for (int k = cx.lane; k < 10; k += cx.nlanes) rec[REC_KE + k] = Kx[k * LDK + 22];
-  for (int idx = cx.lane; idx < 60; idx += cx.nlanes) rec[REC_Z + idx] = Z[(idx / 6) * LDK + idx % 6];
+  for (int idx = cx.lane; idx < 60; idx += cx.nlanes) rec[REC_Z + idx] = idx % 6 < nz ? Z[(idx / 6) * LDK + idx % 6] : 0.0;  // (zero-padded: the forward sweep runs six terms)
   for (int i = cx.lane; i < 12; i += cx.nlanes) rec[REC_DF + i] = cf[i / 3] ? 0.0 : -us[i];
   if (cx.lane == 0) {
     rec[REC_META + 0] = double(n_f);

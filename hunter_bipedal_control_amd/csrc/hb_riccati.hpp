@@ -383,13 +383,15 @@ HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, const double* rec, doubl
 }
 
 struct FwdLds {
-  static constexpr int dx = 0;        // 22 (+2)
+  static constexpr int dx = 0;        // 22 (+2: entries 22 / 23 stay 0.0 — the "zero slot" the padded terms of the wave form read)
   static constexpr int ut = 24;       // 12
   static constexpr int du = 36;       // 22 (+2)
   static constexpr int dxn = 60;      // 22 (+2)
   static constexpr int acc = 84;      // 4: armijo (filled by riccati_fwd_finish), merit, dyn, eq
   static constexpr int accp = 88;     // 22 (+2): per-entry partial sums of the Armijo directional derivative
-  static constexpr int small = 112;
+  static constexpr int uz = 112;      // 6 (+2): u~ of the kernel directions, u~[n_f + b]
+  static constexpr int pre = 120;     // 10 (+2): ke + Kx dx of the joint rows (formed next to u~ = k~ + K~ dx: both only need dx)
+  static constexpr int small = 132;
   // staged copy of what one forward step reads (device kernel): [A~ b~ B~ .] rows | recovery data | gains
   static constexpr int AB = small;                 // rows 0..11 of [A~ b~ B~ .] (12 rows of 36)
   static constexpr int RX = AB + 12 * REC_LD;      // record elements [REC_KX, REC_RX_END)
@@ -398,10 +400,17 @@ struct FwdLds {
 };
 static_assert((REC_RX_END - REC_KX) % 2 == 0 && (12 * REC_LD) % 2 == 0 && REC_KX % 2 == 0 && FwdLds::AB % 2 == 0, "16-byte staging");
 
-// One forward step.  `ab` = rows 0..11 of [A~ b~ B~ .] of the stage record (stride REC_LD; the joint rows are the closed
-// form q+ = q + dt qd and are formed from the recovered joint rates), `rx` = its recovery part (element
-// REC_KX onwards), `gains` = [K~ | k~]: pointers into global memory (host emulation) or into the staged LDS copy (kernel).
-// Advances dx in LDS and writes the full state/input step of this node.
+// One forward step:   u~ = k~ + K~ dx,   dx+ = [A~ dx + B~ u~ + b~ ; joint rows q + dt qd],   du = recovered input step.
+// Every dot product is split FOUR ways — partial q takes the entries q, q + 4, q + 8, ... and the partials are summed
+// (p0 + p1) + (p2 + p3) — so that the wave form below can give each row to four lanes: with one wavefront per SIMD (512
+// instances per GPU) the step is a chain of dependent LDS reads and FMAs, and its length is what the kernel costs.
+//   phase A (needs dx):        u~ (12 rows) and pre = ke + Kx dx (10 rows): 22 rows x 22 terms
+//   phase B (needs u~, pre):   dx+ rows 0..11: 34 terms over [dx ; u~];  joint rows: qd = pre + Z u~[n_f ..] (6 terms, Z zero-padded
+//                              by k_lq), dx+ = dq + dx + dt qd
+//   phase C:                   force rows of du (a copy of u~ or of the record), Armijo sums, outputs, dx <- dx+
+// Host form (emulator): `ab` = rows 0..11 of [A~ b~ B~ .] of the stage record (stride REC_LD), `rx` = its recovery part (element
+// REC_KX onwards), `gains` = [K~ | k~], all in ordinary memory.
+HB_HD double fwd_sum4(const double* p) { return (p[0] + p[1]) + (p[2] + p[3]); }
 template <class Ctx>
 HB_HD void riccati_fwd_node(const Ctx& cx, double* lds, const double* ab, const double* rx, const double* gains, double* dx_out,
                             double* du_out) {
@@ -411,6 +420,8 @@ HB_HD void riccati_fwd_node(const Ctx& cx, double* lds, const double* ab, const 
   double* dxn = lds + FwdLds::dxn;
   double* acc = lds + FwdLds::acc;
   double* accp = lds + FwdLds::accp;
+  double* uz = lds + FwdLds::uz;
+  double* pre = lds + FwdLds::pre;
   const double* KX = rx;
   const double* KE = rx + (REC_KE - REC_KX);
   const double* Zk = rx + (REC_Z - REC_KX);
@@ -420,59 +431,213 @@ HB_HD void riccati_fwd_node(const Ctx& cx, double* lds, const double* ab, const 
   const double* META = rx + (REC_META - REC_KX);
   const double* DQ = rx + (REC_DQ - REC_KX);
   const double dt = rx[REC_DT - REC_KX];
-  const int n_f = int(META[0]), nz = int(META[1]), mode = int(META[2]);
+  const int n_f = int(META[0]), mode = int(META[2]);
   bool cf[HB_NC];
   mode_flags(mode, cf);
-  for (int a = cx.lane; a < NU_T; a += cx.nlanes) {
-    double s = gains[264 + a];
-    for (int c = 0; c < 22; ++c) s += gains[a * 22 + c] * dx[c];
-    ut[a] = s;
-  }
-  cx.sync();
-  for (int i = cx.lane; i < 22 + 22; i += cx.nlanes) {
-    if (i < 12) {
-      const double* row = ab + i * REC_LD;
-      double s = row[REC_CV];
-      for (int c = 0; c < 22; ++c) s += row[c] * dx[c];
-      for (int a = 0; a < NU_T; ++a) s += row[REC_CU + a] * ut[a];
-      dxn[i] = s;
-    } else if (i >= 22) {
-      const int m = i - 22;
-      double s;
-      if (m < 12) {
-        const int foot = m / 3;
-        if (cf[foot]) {
-          int col = 0;
-          for (int f = 0; f < foot; ++f) col += cf[f] ? 3 : 0;
-          s = ut[col + m % 3];
-        } else {
-          s = DF[m];
-        }
-      } else {
-        const int k = m - 12;
-        s = KE[k];
-        for (int c = 0; c < 22; ++c) s += KX[k * 22 + c] * dx[c];
-        for (int b = 0; b < nz; ++b) s += Zk[k * 6 + b] * ut[n_f + b];
-        dxn[12 + k] = DQ[k] + dx[12 + k] + dt * s;  // joint row of the step: (q + dt qd)+ - q_next
-      }
-      du[m] = s;
+  for (int r = cx.lane; r < 22; r += cx.nlanes) {
+    const double* row = r < 12 ? gains + r * 22 : KX + (r - 12) * 22;
+    // the four partial sums side by side (partial q: entries q, q + 4, ...): four short chains instead of one of 22
+    double p[4] = {r < 12 ? gains[264 + r] : KE[r - 12], 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int c = 0; c < 20; c += 4) {
+      p[0] = fma(row[c], dx[c], p[0]);
+      p[1] = fma(row[c + 1], dx[c + 1], p[1]);
+      p[2] = fma(row[c + 2], dx[c + 2], p[2]);
+      p[3] = fma(row[c + 3], dx[c + 3], p[3]);
+    }
+    p[0] = fma(row[20], dx[20], p[0]);
+    p[1] = fma(row[21], dx[21], p[1]);
+    const double s = fwd_sum4(p);
+    if (r < 12) {
+      ut[r] = s;
+      if (r >= n_f && r - n_f < 6) uz[r - n_f] = s;
+    } else {
+      pre[r - 12] = s;
     }
   }
   cx.sync();
-  // Armijo directional derivative: one partial sum per entry, reduced once at the end of the sweep
+  for (int i = cx.lane; i < 22; i += cx.nlanes) {
+    if (i < 12) {
+      const double* row = ab + i * REC_LD;   // [A~ (22) | b~ | B~ (12)]: entry j of [dx ; u~] multiplies row[j] (j < 22) or row[j + 1]
+      double p[4] = {row[REC_CV], 0.0, 0.0, 0.0};
+#pragma unroll 1
+      for (int j = 0; j < 20; j += 4) {
+        p[0] = fma(row[j], dx[j], p[0]);
+        p[1] = fma(row[j + 1], dx[j + 1], p[1]);
+        p[2] = fma(row[j + 2], dx[j + 2], p[2]);
+        p[3] = fma(row[j + 3], dx[j + 3], p[3]);
+      }
+      p[0] = fma(row[20], dx[20], p[0]);
+      p[1] = fma(row[21], dx[21], p[1]);
+      p[2] = fma(row[23], ut[0], p[2]);
+      p[3] = fma(row[24], ut[1], p[3]);
+#pragma unroll 1
+      for (int j = 24; j < 32; j += 4) {
+        p[0] = fma(row[j + 1], ut[j - 22], p[0]);
+        p[1] = fma(row[j + 2], ut[j - 21], p[1]);
+        p[2] = fma(row[j + 3], ut[j - 20], p[2]);
+        p[3] = fma(row[j + 4], ut[j - 19], p[3]);
+      }
+      p[0] = fma(row[33], ut[10], p[0]);
+      p[1] = fma(row[34], ut[11], p[1]);
+      dxn[i] = fwd_sum4(p);
+    } else {
+      const int k = i - 12;
+      double s = pre[k];
+      for (int b = 0; b < 6; ++b) s = fma(Zk[k * 6 + b], uz[b], s);   // columns >= nz of Z are 0.0 in the record
+      du[i] = s;
+      dxn[i] = fma(dt, s, DQ[k] + dx[i]);  // joint row of the step: (q + dt qd)+ - q_next
+    }
+  }
+  cx.sync();
   for (int c = cx.lane; c < 22 + 3; c += cx.nlanes) {
     if (c < 22) {
-      accp[c] += QF[c] * dx[c] + RF[c] * du[c];
+      double duc;
+      if (c < 12) {
+        const int foot = c / 3;
+        int col = 0;
+        for (int f = 0; f < foot; ++f) col += cf[f] ? 3 : 0;
+        duc = cf[foot] ? ut[col + c % 3] : DF[c];
+      } else {
+        duc = du[c];
+      }
+      accp[c] += fma(QF[c], dx[c], RF[c] * duc);   // Armijo directional derivative: one partial sum per entry, reduced at the end
       dx_out[c] = dx[c];
-      du_out[c] = du[c];
+      du_out[c] = duc;
+      dx[c] = dxn[c];
     } else {
       acc[c - 21] += META[c - 19];  // merit, dyn, eq  <-  cost*dt, dyn_sse*dt, eq_sse*dt
     }
   }
   cx.sync();
-  for (int i = cx.lane; i < 22; i += cx.nlanes) dx[i] = dxn[i];
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Wave form of the same step, on the staged LDS copy of the record part and the gains (FwdLds::AB / RX / G).  What does not change from
+// stage to stage — which LDS words a lane multiplies — is worked out once per kernel (FwdLane); a term a lane does not have reads the
+// zero slot (0.0 x 0.0 added: the value is unchanged), so the 64 lanes run one instruction stream without a branch:
+//   phase A: lane = 4 row + q for rows 0..15, then the same for rows 16..21 (two independent chains of 6 FMAs);
+//   phase B: lanes 0..47 = 4 row + q of the twelve dx+ rows (9 FMAs), lanes 48..57 the joint rows (6 FMAs);
+//   phase C: lane = entry.
+struct FwdLane {
+  int mA1, mA1e, cA1, wA1, mA2, mA2e, cA2, wA2;   // phase A: row bases, the base of term 5 (entries 20..23), constant, destination
+  int mv[9], io, aDQ, aDX, wB;                    // phase B: LDS word of the matrix entry | of the vector entry << 16, per term
+  bool q0, rowB, jointB, hasA2;
+};
+__device__ inline void fwd_lane_init(int l, FwdLane& L) {
+  typedef FwdLds F;
+  constexpr int Z0 = F::dx + 22;
+  const int q = l & 3;
+  L.q0 = q == 0;
+  auto rowm = [](int r) { return r < 12 ? F::G + r * 22 : F::RX + (r - 12) * 22; };
+  auto rowc = [](int r) { return r < 12 ? F::G + 264 + r : F::RX + (REC_KE - REC_KX) + r - 12; };
+  auto roww = [](int r) { return r < 12 ? F::ut + r : F::pre + r - 12; };
+  const int r1 = l >> 2, r2 = 16 + r1 < 22 ? 16 + r1 : 21;
+  L.hasA2 = 16 + r1 < 22;
+  L.mA1 = rowm(r1) + q;  L.mA1e = q < 2 ? L.mA1 + 20 : Z0;  L.cA1 = q == 0 ? rowc(r1) : Z0;  L.wA1 = roww(r1);
+  L.mA2 = rowm(r2) + q;  L.mA2e = q < 2 ? L.mA2 + 20 : Z0;  L.cA2 = q == 0 ? rowc(r2) : Z0;  L.wA2 = roww(r2);
+  L.rowB = l < 48;
+  L.jointB = l >= 48 && l < 58;
+  L.aDQ = Z0; L.aDX = Z0; L.io = Z0; L.wB = F::dxn + 22;   // (dxn + 22: padding)
+#pragma unroll
+  for (int t = 0; t < 9; ++t) L.mv[t] = Z0 | (Z0 << 16);
+  if (L.rowB) {
+    const int i = l >> 2, mB = F::AB + i * REC_LD;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int j = q + 4 * t;
+      if (j < 34) L.mv[t] = (mB + (j < 22 ? j : j + 1)) | ((j < 22 ? F::dx + j : F::ut + j - 22) << 16);
+    }
+    if (q == 0) L.io = mB + REC_CV;
+    L.wB = F::dxn + i;
+  } else if (L.jointB) {
+    const int k = l - 48;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) L.mv[t] = (F::RX + (REC_Z - REC_KX) + k * 6 + t) | ((F::uz + t) << 16);
+    L.io = F::pre + k;
+    L.aDQ = F::RX + (REC_DQ - REC_KX) + k;
+    L.aDX = F::dx + 12 + k;
+    L.wB = F::dxn + 12 + k;
+  }
+}
+// accp / accm: this lane's running Armijo partial (lane = entry < 22) and merit / dyn / eq sum (lanes 22..24), kept in registers
+template <class Ctx>
+__device__ inline void riccati_fwd_stage_wave(const Ctx& cx, double* lds, const FwdLane& L, double& accp, double& accm, double* dx_out,
+                                              double* du_out) {
+  typedef FwdLds F;
+  const int l = cx.lane, q = l & 3;
+  const double* META = lds + F::RX + (REC_META - REC_KX);
+  const int n_f = __builtin_amdgcn_readfirstlane(int(META[0])), mode = __builtin_amdgcn_readfirstlane(int(META[2]));
+  // ---- phase A
+  {
+    double m1[6], m2[6], v[6];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      m1[t] = lds[L.mA1 + 4 * t];
+      m2[t] = lds[L.mA2 + 4 * t];
+      v[t] = lds[F::dx + q + 4 * t];
+    }
+    m1[5] = lds[L.mA1e];
+    m2[5] = lds[L.mA2e];
+    v[5] = lds[F::dx + q + 20];
+    double s1 = lds[L.cA1], s2 = lds[L.cA2];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      s1 = fma(m1[t], v[t], s1);
+      s2 = fma(m2[t], v[t], s2);
+    }
+    s1 = quad_sum_f64(s1);
+    s2 = quad_sum_f64(s2);
+    if (L.q0) {
+      lds[L.wA1] = s1;
+      const int b = (l >> 2) - n_f;
+      if (l < 48 && b >= 0 && b < 6) lds[F::uz + b] = s1;
+      if (L.hasA2) lds[L.wA2] = s2;
+    }
+  }
+  cx.sync();
+  // ---- phase B
+  {
+    double m[9], v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      m[t] = lds[L.mv[t] & 0xffff];
+      v[t] = lds[L.mv[t] >> 16];
+    }
+    double s = lds[L.io];
+    const double dq = lds[L.aDQ], dxk = lds[L.aDX], dt = lds[F::RX + (REC_DT - REC_KX)];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s = fma(m[t], v[t], s);
+    const double qs = quad_sum_f64(s);
+    if (L.rowB) {
+      if (L.q0) lds[L.wB] = qs;
+    } else if (L.jointB) {
+      lds[F::du + 12 + l - 48] = s;
+      lds[L.wB] = fma(dt, s, dq + dxk);
+    }
+  }
+  cx.sync();
+  // ---- phase C
+  if (l < 22) {
+    int a_du = F::du + l;
+    if (l < 12) {
+      const int cfm = (mode == 2 || mode == 3 ? 5 : 0) | (mode == 1 || mode == 3 ? 10 : 0);   // mode_flags as a mask (feet 0 / 2 left, 1 / 3 right)
+      const int foot = l / 3;
+      const int col = 3 * __builtin_popcount(cfm & ((1 << foot) - 1));
+      a_du = (cfm >> foot) & 1 ? F::ut + col + l - 3 * foot : F::RX + (REC_DF - REC_KX) + l;
+    }
+    const double dxc = lds[F::dx + l], duc = lds[a_du], qf = lds[F::RX + (REC_QF - REC_KX) + l], rf = lds[F::RX + (REC_RF - REC_KX) + l];
+    const double dxn_c = lds[F::dxn + l];
+    accp += fma(qf, dxc, rf * duc);
+    dx_out[l] = dxc;
+    du_out[l] = duc;
+    lds[F::dx + l] = dxn_c;
+  } else if (l < 25) {
+    accm += META[l - 19];
+  }
   cx.sync();
 }
+#endif
 template <class Ctx>
 HB_HD void riccati_fwd_finish(const Ctx& cx, double* lds) {
   if (cx.lane == 0) {

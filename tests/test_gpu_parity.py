@@ -843,10 +843,11 @@ def test_riccati_one_and_four_wavefront_sweeps(params, oracle, nu):
 
 
 @pytest.mark.parametrize("gait", ["trot", "stance", "ragged"])
-def test_sqp_step_identical_with_either_backward_sweep(params, gait):
-    """Three SQP iterations + WBC of a whole batch with the one- and the four-wavefront backward sweep: bit-identical iterate, step,
-    performance index and WBC solution — trot (9-wide stages), a standing batch (12-wide stages: three tiles, 12 x 12 factor) and
-    ragged horizons with all four modes (incl. a single interval and the 6-wide flight stages)."""
+def test_sqp_step_identical_with_either_form_of_the_sweeps(params, gait):
+    """Three SQP iterations + WBC of a whole batch with the one- and the four-wavefront backward sweep (hb_config.reserved = 101 / 104)
+    and with the row and the wave form of the forward sweep (111 / 114; the product picks each by batch size): bit-identical iterate,
+    step, performance index and WBC solution — trot (9-wide stages), a standing batch (12-wide stages: three tiles, 12 x 12 factor)
+    and ragged horizons with all four modes (incl. a single interval and the 6-wide flight stages)."""
     from hunter_bipedal_control_amd.solver import HunterSolver
     if gait == "trot":
         refs, x0, rbd, t_now = workloads.trot_batch(params, 40, n_intervals=36, max_nodes=44)
@@ -866,7 +867,7 @@ def test_sqp_step_identical_with_either_backward_sweep(params, gait):
         t_now = refs["t"][:, 0] + 0.004
     B = x0.shape[0]
     res = {}
-    for variant in (101, 104):
+    for variant in (101, 104, 111, 114):
         s = HunterSolver(params, batch=B, max_nodes=44, reserved=variant)
         try:
             s.set_references(refs)
@@ -880,6 +881,7 @@ def test_sqp_step_identical_with_either_backward_sweep(params, gait):
             res[variant] = (xs_, us_, dx_, du_, s.get_performance(), sol_, st_, s.mpc_status())
         finally:
             s.close()
-    for k, (p, q) in enumerate(zip(res[101], res[104])):
-        assert np.array_equal(p, q), (gait, k)
+    for variant in (104, 111, 114):
+        for k, (p, q) in enumerate(zip(res[101], res[variant])):
+            assert np.array_equal(p, q), (gait, variant, k)
     assert res[101][7].max() == 0 and np.isfinite(res[101][0]).all()

@@ -380,10 +380,17 @@ __global__ __launch_bounds__(256, 2) void k_ric_bwd4(Batch b, int dbg) {
   double* Hu = lds + L::Hu;
   double* Kk = lds + L::Kk;
   double* Qs = lds + L::Qs;
+#if defined(HB_ABLATE)
+  long long tr_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define HB_RIC4_MARK(i) if (dbg == 199 && blockIdx.x == 7 && k == 50) tr_[i] = __builtin_readcyclecounter();
+#else
+#define HB_RIC4_MARK(i)
+#endif
   for (int k = n - 1; k >= 0; --k) {
     int t = tid;
     asm volatile("" : "+v"(t));   // (nothing derived from the thread id is a loop invariant: see k_ric_bwd)
     const WaveCtx cx(t & 63);
+    HB_RIC4_MARK(0)
     {
       d2* ab2 = reinterpret_cast<d2*>(ABb);
       d2* pr2 = reinterpret_cast<d2*>(PRr);
@@ -406,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void k_ric_bwd4(Batch b, int dbg) {
       meta_nz = meta[1];
     }
     block_sync_lds();
+    HB_RIC4_MARK(1)
     if (HB_ABLATE_ON && dbg == 24) continue;   // profiling ablation: staging only
     double* gains = b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE;
     const bool wide = n_til > 9;   // 12 projected inputs (double support): three 16-column tiles, 12 x 12 factor
@@ -413,9 +421,12 @@ __global__ __launch_bounds__(256, 2) void k_ric_bwd4(Batch b, int dbg) {
     {
       const int NC = wide ? L::LDW : 32;
       auto run = [&](auto& tl, int tm, int c0) {
-        tile_init(cx, tl, 22 - 16 * tm, NC - c0, [sv, tm, c0](int i, int c) { return c + c0 == L::CV ? sv[i + 16 * tm] : 0.0; });
-        tile_mma<24, L::LDN, false, L::LDW>(cx, tl, S + 16 * tm * L::LDN, ABb + c0, 22 - 16 * tm, NC - c0);
+        tile_init_col(cx, tl, 22 - 16 * tm, L::CV - c0, sv + 16 * tm);   // (sv + 16 .. 31 runs into M1: mapped, selected away)
+        HB_RIC4_MARK(8)
+        tile_mma<24, L::LDN, true, L::LDW, false, 24, true>(cx, tl, S + 16 * tm, ABb + c0, 22 - 16 * tm, NC - c0);   // S(i, k) read as S(k, i): see ric_phase1
+        HB_RIC4_MARK(9)
         tile_store_rm<L::LDW>(cx, tl, 22 - 16 * tm, NC - c0, M1 + 16 * tm * L::LDW + c0);
+        HB_RIC4_MARK(10)
       };
       if (!wide) {
         WaveTile<1, 1> tl;
@@ -429,16 +440,18 @@ __global__ __launch_bounds__(256, 2) void k_ric_bwd4(Batch b, int dbg) {
       }
     }
     block_sync_lds();
+    HB_RIC4_MARK(2)
     if (HB_ABLATE_ON && dbg == 25) continue;   // ... + GEMM 1
     // ---- GEMM 2: Hu = B~' M1 + [P~ r~ R~ .]  (every element of [P~ r~ R~] is read and replaced by the lane that owns it)
     if (w < (wide ? 3 : 2)) {
       const int NC = wide ? L::LDW : 32, c0 = 16 * w;
       WaveTile<1, 1> tl;
-      tile_init(cx, tl, NU_T, NC - c0, [PRr, c0](int a, int c) { return PRr[a * L::LDW + c + c0]; });
-      tile_mma<24, L::LDW, true, L::LDW>(cx, tl, ABb + L::CU, M1 + c0, NU_T, NC - c0);
+      tile_init_rm<L::LDW>(cx, tl, NU_T, NC - c0, PRr + c0);
+      tile_mma<24, L::LDW, true, L::LDW, false, 24, true>(cx, tl, ABb + L::CU, M1 + c0, NU_T, NC - c0);
       tile_store_rm<L::LDW>(cx, tl, NU_T, NC - c0, Hu + c0);
     }
     block_sync_lds();
+    HB_RIC4_MARK(3)
     if (HB_ABLATE_ON && dbg == 26) continue;   // ... + GEMM 2
     // ---- factor + solves on wavefront 0.  Meanwhile wavefronts 1..3 start GEMM 3, T = Q~ + A~' M1 + Hux' K~ on its upper block
     // triangle (tiles (0,0) / (0,1) / (1,1), one each): the A~' M1 part does not need the gains — six of a tile's nine matrix
@@ -452,25 +465,27 @@ __global__ __launch_bounds__(256, 2) void k_ric_bwd4(Batch b, int dbg) {
       else ric_factor_solve<NU_T>(cx, Hu, Kk, lds + L::flag, gains);
     } else {
       tile_init(cx, t3, Mr, Nr, [](int, int) { return 0.0; });
-      tile_mma<24, L::LDW, true, L::LDW>(cx, t3, ABb + r0, M1 + c0, Mr, Nr);
+      tile_mma<24, L::LDW, true, L::LDW, false, 24, true>(cx, t3, ABb + r0, M1 + c0, Mr, Nr);
     }
+    HB_RIC4_MARK(4)
     block_sync_lds();
+    HB_RIC4_MARK(5)
     if (HB_ABLATE_ON && dbg == 27) continue;   // ... + factor, solves | first part of GEMM 3
     // ---- rest of GEMM 3: + Hux' K~, + Q~, new S | s (mirrored)
     if (w != 0) {
-      tile_mma<NU_T, L::LDW, true, L::LDN>(cx, t3, Hu + r0, Kk + c0, Mr, Nr);
-      tile_store(cx, t3, Mr, Nr, [S, sv, Qs, r0, c0](int il, int cl, double v) {
-        const int i = il + r0, c = cl + c0;
-        if (c == L::CV) {
-          sv[i] = v + Qs[484 + i];
-        } else if (i <= c) {
-          const double wv = v + Qs[i * 22 + c];
-          S[i * L::LDN + c] = wv;
-          S[c * L::LDN + i] = wv;
-        }
-      });
+      tile_mma<NU_T, L::LDW, true, L::LDN, false, NU_T, true>(cx, t3, Hu + r0, Kk + c0, Mr, Nr);
+      HB_RIC4_MARK(11)
+      ric_store_T<L::LDN>(cx, t3, Mr, Nr, r0, c0, S, sv, Qs, lds + L::flag + 2);
     }
+    HB_RIC4_MARK(6)
     block_sync_lds();
+    HB_RIC4_MARK(7)
+#if defined(HB_ABLATE)
+    if (dbg == 199 && blockIdx.x == 7 && k == 50 && (tid & 63) == 0)
+      printf("ric4 trace role %d: stage-in %lld gemm1 %lld (init %lld mma %lld store %lld barrier %lld) gemm2 %lld | own work %lld wait %lld | gemm3b %lld (mma %lld) wait %lld  (cycles)\n", w,
+             tr_[1] - tr_[0], tr_[2] - tr_[1], tr_[8] - tr_[1], tr_[9] - tr_[8], tr_[10] - tr_[9], tr_[2] - tr_[10], tr_[3] - tr_[2], tr_[4] - tr_[3], tr_[5] - tr_[4],
+             tr_[6] - tr_[5], tr_[11] - tr_[5], tr_[7] - tr_[6]);
+#endif
   }
 #undef HB_RIC4_FETCH
   if (tid == 0) b.ric_fail[inst] = lds[Ric4Lds::flag] != 0.0 ? 1 : 0;
@@ -1932,7 +1947,7 @@ static int32_t warm_start_onto_new_tables(hb_ctx* ctx) {
 // own streams): what decides is how many sweeps share the chip, not the size of this launch.
 static void launch_ric_bwd(hb_ctx* ctx, const Batch& b, int B, int concurrent, hipStream_t s) {
   const int sel = ctx->hconfig.debug_stop;
-  const bool four = sel == 104 || (HB_ABLATE_ON && sel >= 24 && sel <= 27) || (sel != 101 && !(HB_ABLATE_ON && sel != 0) && concurrent <= kRicBwd4MaxBatch);
+  const bool four = sel == 104 || (HB_ABLATE_ON && ((sel >= 24 && sel <= 27) || sel == 199)) || (sel != 101 && !(HB_ABLATE_ON && sel != 0) && concurrent <= kRicBwd4MaxBatch);
   if (four) hipLaunchKernelGGL(k_ric_bwd4, dim3(B), dim3(256), 0, s, b, sel);
   else hipLaunchKernelGGL(k_ric_bwd, dim3(B), dim3(64), 0, s, b, sel);
 }

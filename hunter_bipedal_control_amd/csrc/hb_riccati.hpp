@@ -67,18 +67,41 @@ HB_HD void ric_phase1(const Ctx& cx, double* lds) {
   double* M1 = lds + RicLds::M1;
   constexpr int NC = NTW * 16 < RicLds::LDW ? NTW * 16 : RicLds::LDW;
   WaveTile<2, NTW> t;
-  tile_init(cx, t, 22, NC, [sv](int i, int c) { return c == RicLds::CV ? sv[i] : 0.0; });
-  tile_mma<24, RicLds::LDN, false, RicLds::LDW>(cx, t, lds + RicLds::S, lds + RicLds::ABb, 22, NC);
+  tile_init(cx, t, 22, NC, [sv](int i, int c) { return c == RicLds::CV ? sv[i] : 0.0; });   // (tile_init_col: scratch in this kernel)
+  // S is EXACTLY symmetric (the previous stage stored the upper triangle of T mirrored; S = 0 at the end of the horizon), so the left operand
+  // is read transposed, S(i, k) as S(k, i): 16 lanes then read 16 consecutive doubles instead of 16 doubles 24 apart (a four-way
+  // bank conflict on every operand read).  The K-padding rows 22 / 23 of this view are s and stale finite words; the zero rows 22 / 23
+  // of [A~ b~ B~] cancel them.
+  tile_mma<24, RicLds::LDN, true, RicLds::LDW>(cx, t, lds + RicLds::S, lds + RicLds::ABb, 22, NC);
   // M1 overwrites S | s: every operand read above precedes these stores in the wave's program order
   tile_store(cx, t, 22, NC, [M1](int i, int c, double v) { M1[i * RicLds::LDW + c] = v; });
   cx.sync();
 }
-// Cholesky of the leading NT x NT block of Huu and the 23 triangular solves.  Every lane factors the (uniform) block
-// redundantly in registers, lane c < 23 then solves its own right-hand side.  NT = 9 serves every stage with at most
-// 9 projected inputs (single support: 6 contact-force + 3 kernel coordinates; flight: 6) — the padding rows of the
-// record are R~ = I, B~ = 0, P~ = 0, r~ = 0, so their gains are exactly zero and the factor work drops by ~(9/12)^3.
-// Cholesky factor of the leading NB x NB block of Huu, redundantly per lane in registers; lane 0 writes it back over the
-// (dead) lower triangle of Huu with the RECIPROCALS of the diagonal.  Returns true when a pivot was not positive.
+// Factorisation of the leading NT x NT block of Huu and the 23 solves.  Every lane factors the (uniform) block redundantly in
+// registers, lane c < 23 then solves its own right-hand side.  NT = 9 serves every stage with at most 9 projected inputs (single
+// support: 6 contact-force + 3 kernel coordinates; flight: 6) — the padding rows of the record are R~ = I, B~ = 0, P~ = 0, r~ = 0,
+// so their gains are exactly zero and the factor work drops by ~(9/12)^3.
+//
+// The factorisation is ROOT-FREE:  Huu = U D U',  U unit lower triangular, kept as U (strictly lower part) and r = 1 / d (diagonal).
+// What a stage of the sweep costs on a small batch is the length of this dependency chain (one wavefront per SIMD: 512 instances
+// spent 0.16 of k_ric_bwd4's 0.44 ms in the 9 x 9 LL' factorisation, 415 cycles per pivot through d > 0 ? -> select -> v_rsq_f64 ->
+// refinement -> class select -> column scaling -> next diagonal).  Per pivot the chain is now
+//     r_j = 1 / d_j (v_rcp_f64 + one cubic correction, 4 levels) -> select on d_j > 0 -> d_(j+1) -= t^2 r_j  (one FMA)
+// — six levels instead of twelve — and the substitutions have no multiplication on their chains (unit diagonal):
+//     z = U^-1 b,  w = r z,  y = U'^-1 w.
+// A pivot that is not positive is replaced by 1 and reported (as before).
+HB_HD double ric_rcp(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double r0 = __builtin_amdgcn_rcp(d);   // ~ 2^-23 relative
+  const double e = fma(-d, r0, 1.0);
+  return fma(r0, fma(e, e, e), r0);            // r0 (1 + e + e^2): error e^3
+#else
+  return 1.0 / d;
+#endif
+}
+// U D U' of the leading NB x NB block of Huu, redundantly per lane in registers: on return L holds U below the diagonal and the
+// reciprocals r on it.  Unless KEEP, lane 0 writes it back over the (dead) lower triangle of Huu.  Returns true when a pivot was
+// not positive.
 template <int NB, bool KEEP = false, class Ctx>
 HB_HD bool ric_chol_block(const Ctx& cx, double* Hu, double (&L)[NB * (NB + 1) / 2]) {
 #pragma unroll
@@ -87,19 +110,19 @@ HB_HD bool ric_chol_block(const Ctx& cx, double* Hu, double (&L)[NB * (NB + 1) /
     for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = Hu[i * RicLds::LDW + RicLds::CU + j];
   bool bad = false;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    double d = L[j * (j + 1) / 2 + j];
+  for (int j = 0; j < NB; ++j) {   // right-looking: column j, then the rank-one update of what is left
+    const double d = L[j * (j + 1) / 2 + j];
+    const bool pos = d > 0.0;
+    bad = bad || !pos;
+    const double r = pos ? ric_rcp(d) : 1.0;
+    L[j * (j + 1) / 2 + j] = r;
 #pragma unroll
-    for (int k = 0; k < j; ++k) d -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
-    if (!(d > 0.0)) { bad = true; d = 1.0; }
-    const double inv = rsqrt_t(d);
-    L[j * (j + 1) / 2 + j] = inv;  // store the reciprocal of the diagonal
+    for (int i = j + 1; i < NB; ++i) {   // row i: t = unnormalised entry (i, j); the rows above are already normalised (u)
+      const double t = L[i * (i + 1) / 2 + j];
 #pragma unroll
-    for (int i = j + 1; i < NB; ++i) {
-      double sacc = L[i * (i + 1) / 2 + j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) sacc -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
-      L[i * (i + 1) / 2 + j] = sacc * inv;
+      for (int k = j + 1; k < i; ++k) L[i * (i + 1) / 2 + k] = fma(-t, L[k * (k + 1) / 2 + j], L[i * (i + 1) / 2 + k]);
+      L[i * (i + 1) / 2 + i] = fma(-(t * t), r, L[i * (i + 1) / 2 + i]);   // the next pivots: one level behind r
+      L[i * (i + 1) / 2 + j] = t * r;
     }
   }
   // The factor (lane-uniform) goes back to LDS over the lower triangle of Huu, which is dead from here on: the solves
@@ -111,6 +134,47 @@ HB_HD bool ric_chol_block(const Ctx& cx, double* Hu, double (&L)[NB * (NB + 1) /
     for (int i = 0; i < NB; ++i)
 #pragma unroll
       for (int j = 0; j <= i; ++j) Hu[i * RicLds::LDW + RicLds::CU + j] = L[i * (i + 1) / 2 + j];
+  }
+  return bad;
+}
+// Rows 9..11 of the 12 x 12 factor against the leading block (U11, r1 in Lr): for each row the unnormalised entries t = U11^-1 a
+// (unit lower: no division), the 3 x 3 Schur complement S = A22 - T21 diag(r1) T21' and its own U D U'.  Redundantly per lane;
+// `rd(r, j)` reads entry j of row 9 + r of Huu.  Outputs: t21 (the rows BEFORE normalisation: u = t r1), S (U below, r on the diagonal).
+template <class RD>
+HB_HD bool ric_factor_tail(const double (&Lr)[45], RD rd, double (&t21)[3][9], double (&S)[6]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      double sacc = rd(r, j);
+#pragma unroll
+      for (int k = 0; k < j; ++k) sacc = fma(-t21[r][k], Lr[j * (j + 1) / 2 + k], sacc);
+      t21[r][j] = sacc;
+    }
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      double sacc = rd(r, 9 + c);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) sacc = fma(-(t21[r][k] * t21[c][k]), Lr[k * (k + 1) / 2 + k], sacc);
+      S[r * (r + 1) / 2 + c] = sacc;
+    }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double d = S[j * (j + 1) / 2 + j];
+    const bool pos = d > 0.0;
+    bad = bad || !pos;
+    const double r = pos ? ric_rcp(d) : 1.0;
+    S[j * (j + 1) / 2 + j] = r;
+#pragma unroll
+    for (int i = j + 1; i < 3; ++i) {
+      const double t = S[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = j + 1; k < i; ++k) S[i * (i + 1) / 2 + k] = fma(-t, S[k * (k + 1) / 2 + j], S[i * (i + 1) / 2 + k]);
+      S[i * (i + 1) / 2 + i] = fma(-(t * t), r, S[i * (i + 1) / 2 + i]);
+      S[i * (i + 1) / 2 + j] = t * r;
+    }
   }
   return bad;
 }
@@ -133,110 +197,44 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* Hu, double* Kk, double* flag,
     if (bad && cx.lane == 0) *flag = 1.0;
   } else {
     // 12 projected inputs (double support: 12 contact forces): blocked — the 9 x 9 leading block in registers as above, then
-    // rows 9..11 one per lane against the factor in LDS, then the 3 x 3 Schur complement.  A 78-element register triangle
-    // (156 VGPRs) next to the record prefetch was what put 100 B/lane of this kernel into scratch memory.
+    // rows 9..11 against it and the 3 x 3 Schur complement (ric_factor_tail).  A 78-element register triangle (156 VGPRs) next to
+    // the record prefetch was what put 100 B/lane of this kernel into scratch memory.
     static_assert(NT == 12, "blocked factorisation: 9 + 3");
-    bool bad = ric_chol_block<9>(cx, Hu, Lr);
 #if defined(__HIP_DEVICE_COMPILE__)
-    // Device: every lane continues redundantly in registers (the 9 x 9 block is still there): rows 9..11 of the factor by forward
-    // substitution against it, the 3 x 3 Schur complement and its factor — no LDS round trip inside, one barrier at the end.
-    // (Rows of Huu are read before lane 0 of ric_chol_block overwrote the leading triangle only: rows 9..11 are untouched.)
+    // Device: every lane continues redundantly in registers (the 9 x 9 block is still there) — no LDS round trip inside, one
+    // barrier at the end.  (ric_chol_block<9, KEEP> leaves Huu untouched: rows 9..11 are read from it.)
+    bool bad = ric_chol_block<9, true>(cx, Hu, Lr);
     {
-      double l21[3][9], S[6];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-          double sacc = Hu[(9 + r) * RicLds::LDW + RicLds::CU + j];
-#pragma unroll
-          for (int k = 0; k < j; ++k) sacc -= l21[r][k] * Lr[j * (j + 1) / 2 + k];
-          l21[r][j] = sacc * Lr[j * (j + 1) / 2 + j];
-        }
-#pragma unroll
-        for (int c = 0; c <= r; ++c) {
-          double sacc = Hu[(9 + r) * RicLds::LDW + RicLds::CU + 9 + c];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) sacc -= l21[r][k] * l21[c][k];
-          S[r * (r + 1) / 2 + c] = sacc;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        double d = S[j * (j + 1) / 2 + j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d -= S[j * (j + 1) / 2 + k] * S[j * (j + 1) / 2 + k];
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        const double inv = rsqrt_t(d);
-        S[j * (j + 1) / 2 + j] = inv;
-#pragma unroll
-        for (int i = j + 1; i < 3; ++i) {
-          double sacc = S[i * (i + 1) / 2 + j];
-#pragma unroll
-          for (int k = 0; k < j; ++k) sacc -= S[i * (i + 1) / 2 + k] * S[j * (j + 1) / 2 + k];
-          S[i * (i + 1) / 2 + j] = sacc * inv;
-        }
-      }
+      double t21[3][9], S[6];
+      bad = ric_factor_tail(Lr, [Hu](int r, int j) { return Hu[(9 + r) * RicLds::LDW + RicLds::CU + j]; }, t21, S) || bad;
       cx.sync();   // every lane has read rows 9..11 of Huu before lane 0 overwrites them with the factor
       if (cx.lane == 0) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
 #pragma unroll
-          for (int j = 0; j < 9; ++j) Hu[(9 + r) * RicLds::LDW + RicLds::CU + j] = l21[r][j];
+          for (int j = 0; j < 9; ++j) Hu[(9 + r) * RicLds::LDW + RicLds::CU + j] = t21[r][j] * Lr[j * (j + 1) / 2 + j];
 #pragma unroll
           for (int c = 0; c <= r; ++c) Hu[(9 + r) * RicLds::LDW + RicLds::CU + 9 + c] = S[r * (r + 1) / 2 + c];
         }
       }
     }
 #else
-    cx.sync();
-    const double* Lm = Hu + RicLds::CU;   // L(i, j) = Lm[i * LDW + j]
-    for (int r = 9 + cx.lane; r < 12; r += cx.nlanes) {   // L21 row r: forward substitution with L11 (diagonal = reciprocals)
-      double l[9];
-#pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        double sacc = Lm[r * RicLds::LDW + j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) sacc -= l[k] * Lm[j * RicLds::LDW + k];
-        l[j] = sacc * Lm[j * RicLds::LDW + j];
-      }
-#pragma unroll
-      for (int j = 0; j < 9; ++j) Hu[r * RicLds::LDW + RicLds::CU + j] = l[j];
-    }
-    cx.sync();
+    // Host emulator (the lanes run one after the other): the same arithmetic from copies of the rows, then the whole factor to LDS
+    bool bad = ric_chol_block<9, true>(cx, Hu, Lr);
     {
-      // Schur complement of the trailing 3 x 3 block and its factor, redundantly per lane (6 elements)
-      double S[6];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-          double sacc = Lm[(9 + i) * RicLds::LDW + 9 + j];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) sacc -= Lm[(9 + i) * RicLds::LDW + k] * Lm[(9 + j) * RicLds::LDW + k];
-          S[i * (i + 1) / 2 + j] = sacc;
-        }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        double d = S[j * (j + 1) / 2 + j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d -= S[j * (j + 1) / 2 + k] * S[j * (j + 1) / 2 + k];
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        const double inv = rsqrt_t(d);
-        S[j * (j + 1) / 2 + j] = inv;
-#pragma unroll
-        for (int i = j + 1; i < 3; ++i) {
-          double sacc = S[i * (i + 1) / 2 + j];
-#pragma unroll
-          for (int k = 0; k < j; ++k) sacc -= S[i * (i + 1) / 2 + k] * S[j * (j + 1) / 2 + k];
-          S[i * (i + 1) / 2 + j] = sacc * inv;
-        }
-      }
-      cx.sync();   // every lane has read the trailing block before lane 0 overwrites it
+      double rows[3][12];
+      for (int r = 0; r < 3; ++r)
+        for (int j = 0; j < 12; ++j) rows[r][j] = Hu[(9 + r) * RicLds::LDW + RicLds::CU + j];
+      double t21[3][9], S[6];
+      bad = ric_factor_tail(Lr, [&rows](int r, int j) { return rows[r][j]; }, t21, S) || bad;
+      cx.sync();
       if (cx.lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j <= i; ++j) Hu[(9 + i) * RicLds::LDW + RicLds::CU + 9 + j] = S[i * (i + 1) / 2 + j];
+        for (int i = 0; i < 9; ++i)
+          for (int j = 0; j <= i; ++j) Hu[i * RicLds::LDW + RicLds::CU + j] = Lr[i * (i + 1) / 2 + j];
+        for (int r = 0; r < 3; ++r) {
+          for (int j = 0; j < 9; ++j) Hu[(9 + r) * RicLds::LDW + RicLds::CU + j] = t21[r][j] * Lr[j * (j + 1) / 2 + j];
+          for (int c = 0; c <= r; ++c) Hu[(9 + r) * RicLds::LDW + RicLds::CU + 9 + c] = S[r * (r + 1) / 2 + c];
+        }
       }
     }
 #endif
@@ -244,7 +242,7 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* Hu, double* Kk, double* flag,
   }
   if (!reg_factor) cx.sync();
   {
-    const double* Lm = Hu + RicLds::CU;  // L(i, j) = Lm[i * LDW + j], j <= i; diagonal holds the reciprocals
+    const double* Lm = Hu + RicLds::CU;  // U(i, j) = Lm[i * LDW + j], j < i; the diagonal holds the reciprocals r
 #if defined(__HIP_DEVICE_COMPILE__)
     // 12-wide (double support): the leading 9 x 9 block of the factor is still in this lane's registers (ric_chol_block left it
     // there); only rows 9..11 come from LDS
@@ -259,24 +257,24 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* Hu, double* Kk, double* flag,
     for (int c = cx.lane; c < 23; c += cx.nlanes) {  // columns 0..21 = Hux, 22 = hu
       double y[NU_T];
 #pragma unroll
-      for (int a = 0; a < NT; ++a) {
+      for (int a = 0; a < NT; ++a) {   // z = U^-1 (-h)
         double sacc = -Hu[a * RicLds::LDW + c];
 #pragma unroll
-        for (int k = 0; k < a; ++k) sacc -= Lf(a, k) * y[k];
-        y[a] = sacc * Lf(a, a);
+        for (int k = 0; k < a; ++k) sacc = fma(-Lf(a, k), y[k], sacc);
+        y[a] = sacc;
 #if defined(__HIP_DEVICE_COMPILE__)
         // 12-wide: keep the factor loads of rows 9..11 row by row — hoisted all at once they took the register file
         if (NT > 9 && a >= 8) asm volatile("" ::: "memory");
 #endif
       }
 #pragma unroll
-      for (int a = NT - 1; a >= 0; --a) {
-        double sacc = y[a];
+      for (int a = NT - 1; a >= 0; --a) {   // y = U'^-1 (r z)
+        double sacc = y[a] * Lf(a, a);
 #pragma unroll
-        for (int k = a + 1; k < NT; ++k) sacc -= Lf(k, a) * y[k];
-        y[a] = sacc * Lf(a, a);
+        for (int k = a + 1; k < NT; ++k) sacc = fma(-Lf(k, a), y[k], sacc);
+        y[a] = sacc;
 #if defined(__HIP_DEVICE_COMPILE__)
-        // (below row 9 only the three entries L(9..11, a) of every column come from LDS: their loads may run three columns ahead)
+        // (below row 9 only the three entries U(9..11, a) of every column come from LDS: their loads may run three columns ahead)
         if (NT > 9 && (a >= 9 || a % 3 == 0)) asm volatile("" ::: "memory");
 #endif
       }
@@ -300,7 +298,7 @@ HB_HD void ric_phase2_gemm(const Ctx& cx, double* lds) {
   double* Hu = lds + RicLds::Hu;
   constexpr int NC = NTW * 16 < RicLds::LDW ? NTW * 16 : RicLds::LDW;
   WaveTile<1, NTW> t;
-  tile_init(cx, t, NU_T, NC, [PRr](int a, int c) { return PRr[a * RicLds::LDW + c]; });
+  tile_init(cx, t, NU_T, NC, [PRr](int a, int c) { return PRr[a * RicLds::LDW + c]; });   // (tile_init_rm: 52 B of scratch in this kernel)
   tile_mma<24, RicLds::LDW, true, RicLds::LDW>(cx, t, lds + RicLds::ABb + RicLds::CU, lds + RicLds::M1, NU_T, NC);
   tile_store(cx, t, NU_T, NC, [Hu](int a, int c, double v) { Hu[a * RicLds::LDW + c] = v; });  // over [P~ r~ R~]
   cx.sync();
@@ -342,6 +340,59 @@ HB_HD void ric_phase3_mma(const Ctx& cx, double* lds, RicT3& t) {
   tile_mma<NU_T, RicLds::LDW, true, RicLds::LDN>(cx, t.t1, lds + RicLds::Hu + 16, lds + RicLds::Kk + 16, 6, 7);
   cx.sync();
 }
+// Store of a block of T = new S | s (rows r0.., columns c0.. of the 22 x 23 result): element (i, c), i <= c < 22, goes to S(i, c) and S(c, i)
+// with [Q~] added, column 22 is the vector s with q~ added.  Device: the (up to) four Q~ words of a lane are requested together, in front
+// of the stores — element by element (each with its own branch, LDS read and wait) this store was 1 000 .. 1 650 cycles of a 8 700-cycle
+// stage of k_ric_bwd4, more than the matrix instructions before it.
+template <int LDN_, int MT, int NT, class Ctx>
+HB_HD void ric_store_T(const Ctx& cx, const WaveTile<MT, NT>& t, int Mr, int Nr, int r0, int c0, double* S, double* sv, const double* Qs,
+                       double* trash) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Branch-free: a lane's column is the same for its four elements, the Q~ word of element r is (first word) + r x (4 or 88), and an element
+  // that is not stored goes to `trash` (one dead LDS word) — no lane-mask arithmetic between the matrix instructions and the stores (written
+  // with a branch per element, the mask juggling through scalar registers was ~ 600 of the stage's 8 700 cycles).
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      const int cl = 16 * tn + li, c = cl + c0, il0 = 16 * tm + lk, i0 = il0 + r0;
+      const bool colv = c == RicLds::CV, colok = cl < Nr;
+      const int q0 = colv ? 484 + i0 : i0 * 22 + c, qs = colv ? 4 : 88;
+      double q[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = q0 + r * qs;
+        q[r] = Qs[idx < 511 ? idx : 511];
+      }
+      double* const pv = sv + i0;                  // + 4 r
+      double* const pa = S + i0 * LDN_ + c;        // + 4 r LDN
+      double* const pb = S + c * LDN_ + i0;        // + 4 r
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool in = colok && il0 + 4 * r < Mr;
+        const bool mat = in && !colv && i0 + 4 * r <= c;
+        const double w = t.acc[tm][tn][r] + q[r];
+        double* a1 = mat ? pa + 4 * r * LDN_ : ((in && colv) ? pv + 4 * r : trash);
+        double* a2 = mat ? pb + 4 * r : trash;
+        *a1 = w;
+        *a2 = w;
+      }
+    }
+#else
+  (void)trash;
+  tile_store(cx, t, Mr, Nr, [S, sv, Qs, r0, c0](int il, int cl, double v) {
+    const int i = il + r0, c = cl + c0;
+    if (c == RicLds::CV) {
+      sv[i] = v + Qs[484 + i];
+    } else if (i <= c) {
+      const double w = v + Qs[i * 22 + c];
+      S[i * LDN_ + c] = w;
+      S[c * LDN_ + i] = w;
+    }
+  });
+#endif
+}
 template <class Ctx>
 HB_HD void ric_phase3_finish(const Ctx& cx, double* lds, const RicT3& t) {
   double* S = lds + RicLds::S;
@@ -350,17 +401,8 @@ HB_HD void ric_phase3_finish(const Ctx& cx, double* lds, const RicT3& t) {
   cx.sync();
   // The new S | s overwrite M1 (narrow rows): every operand read of the GEMMs precedes these stores in the wave's program
   // order.  Element (i, c), i <= c < 22, goes to S(i, c) and S(c, i); column 22 is the vector s.
-  auto put = [S, sv, Qs](int i, int c, double v) {
-    if (c == RicLds::CV) {
-      sv[i] = v + Qs[484 + i];
-    } else if (i <= c) {
-      const double w = v + Qs[i * 22 + c];
-      S[i * RicLds::LDN + c] = w;
-      S[c * RicLds::LDN + i] = w;
-    }
-  };
-  tile_store(cx, t.t0, 16, 23, put);
-  tile_store(cx, t.t1, 6, 7, [put](int i, int c, double v) { put(16 + i, 16 + c, v); });
+  ric_store_T<RicLds::LDN>(cx, t.t0, 16, 23, 0, 0, S, sv, Qs, lds + RicLds::flag + 2);
+  ric_store_T<RicLds::LDN>(cx, t.t1, 6, 7, 16, 16, S, sv, Qs, lds + RicLds::flag + 2);
   // restore the zero K-padding of S (columns 22, 23 were covered by M1)
   for (int idx = cx.lane; idx < 44; idx += cx.nlanes) S[(idx >> 1) * RicLds::LDN + RicLds::CV + (idx & 1)] = 0.0;
   cx.sync();

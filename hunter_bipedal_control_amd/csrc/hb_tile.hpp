@@ -37,6 +37,56 @@ HB_HD void tile_init(const Ctx& cx, WaveTile<MT, NT>& t, int Mr, int Nr, FC c_in
     for (int j = 0; j < NT * 16; ++j) t.c[i][j] = (i < Mr && j < Nr) ? c_init(i, j) : 0.0;
 #endif
 }
+// Accumulator start values from a row-major source, t(row, col) = src[row * LD + col] inside Mr x Nr and 0 outside.  Device: the four
+// elements of a lane are requested unconditionally (one per-lane base + compile-time offsets, one wait) and selected afterwards — the
+// lambda form above reads each element inside its own branch, four LDS round trips in a row.  The words of a whole 16-row tile behind
+// `src` must be mapped (they are: every caller's source sits inside a larger LDS block).
+template <int LD, int MT, int NT, class Ctx>
+HB_HD void tile_init_rm(const Ctx& cx, WaveTile<MT, NT>& t, int Mr, int Nr, const double* src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+  const double* p0 = src + lk * LD + li;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      double v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = p0[(16 * tm + 4 * r) * LD + 16 * tn];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tm + lk + 4 * r, col = 16 * tn + li;
+        t.acc[tm][tn][r] = (row < Mr && col < Nr) ? v[r] : 0.0;
+      }
+    }
+#else
+  (void)cx;
+  for (int i = 0; i < MT * 16; ++i)
+    for (int j = 0; j < NT * 16; ++j) t.c[i][j] = (i < Mr && j < Nr) ? src[i * LD + j] : 0.0;
+#endif
+}
+// Accumulator start values that are zero except in ONE column: t(row, csel) = vec[row] for row < Mr.  (vec must be mapped up to
+// element 16 MT - 1.)
+template <int MT, int NT, class Ctx>
+HB_HD void tile_init_col(const Ctx& cx, WaveTile<MT, NT>& t, int Mr, int csel, const double* vec) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm) {
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = vec[16 * tm + lk + 4 * r];
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t.acc[tm][tn][r] = (16 * tm + lk + 4 * r < Mr && 16 * tn + li == csel) ? v[r] : 0.0;
+  }
+#else
+  (void)cx;
+  for (int i = 0; i < MT * 16; ++i)
+    for (int j = 0; j < NT * 16; ++j) t.c[i][j] = (i < Mr && j == csel) ? vec[i] : 0.0;
+#endif
+}
 // t += A B over K.  A(i,k) = TA ? A[k*LDA + i] : A[i*LDA + k],  B(k,j) = TB ? B[j*LDB + k] : B[k*LDB + j].
 // K is padded to a multiple of 4; KR <= K is the real depth.  With KR == K there are no masks at all: the operands
 // must then be zero-padded in k on both sides, and out-of-range rows / columns only feed discarded outputs.  With
@@ -45,7 +95,11 @@ struct NoScale { HB_HD double operator()(int) const { return 1.0; } };
 struct AllSteps { HB_HD bool operator()(int) const { return true; } };
 // `wk(k)` is an optional weight of the k-th term (diagonal scaling between A and B), e.g. a 0/1 row mask.  `step_live(j)` says
 // whether K-step j (terms 4j .. 4j+3) contributes at all: it must be wave-uniform, and a step it rules out must have zero weights.
-template <int K, int LDA, bool TA, int LDB, bool TB = false, int KR = K, int MT, int NT, class Ctx, class FW = NoScale, class FL = AllSteps>
+// PRE: request the operands of ALL K-steps before the first matrix instruction (K / 4 x (MT + NT) doubles in registers): the product is then
+// one LDS latency + K / 4 dependent matrix instructions instead of K / 8 round trips — for the sweeps of small batches, whose stage is a
+// latency chain (k_ric_bwd4: GEMM 1 of a stage 2 240 cycles before, cycle-counter trace of the ablation build).
+template <int K, int LDA, bool TA, int LDB, bool TB = false, int KR = K, bool PRE = false, int MT, int NT, class Ctx, class FW = NoScale,
+          class FL = AllSteps>
 HB_HD void tile_mma(const Ctx& cx, WaveTile<MT, NT>& t, const double* A, const double* B, int Mr, int Nr, FW wk = FW(), FL step_live = FL()) {
   constexpr bool weighted = !std::is_same<FW, NoScale>::value;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -53,6 +107,34 @@ HB_HD void tile_mma(const Ctx& cx, WaveTile<MT, NT>& t, const double* A, const d
   const int li = cx.lane & 15, lk = cx.lane >> 4;
   const double* ap = A + (TA ? lk * LDA + li : li * LDA + lk);
   const double* bp = B + (TB ? li * LDB + lk : lk * LDB + li);
+  if constexpr (PRE) {
+    static_assert(!weighted && std::is_same<FL, AllSteps>::value, "plain products only");
+    constexpr int KS = (K + 3) / 4;
+    double av[KS][MT], bv[KS][NT];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k0 = 4 * s;
+      const bool live = (k0 + 4 <= KR) || (k0 + lk < KR);
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm) {
+        av[s][tm] = ap[TA ? k0 * LDA + 16 * tm : 16 * tm * LDA + k0];
+        if (k0 + 4 > KR) av[s][tm] = live ? av[s][tm] : 0.0;
+      }
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        bv[s][tn] = bp[TB ? 16 * tn * LDB + k0 : k0 * LDB + 16 * tn];
+        if (k0 + 4 > KR) bv[s][tn] = live ? bv[s][tn] : 0.0;
+      }
+    }
+    asm volatile("" ::: "memory");   // (the reads stay in front of the matrix instructions)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) t.acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s][tm], bv[s][tn], t.acc[tm][tn], 0, 0, 0);
+    return;
+  }
 #pragma unroll
   for (int k0 = 0; k0 < K; k0 += 4) {
     if (!step_live(k0 / 4)) continue;

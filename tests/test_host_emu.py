@@ -18,8 +18,8 @@ HERE = Path(__file__).resolve().parent / "host_emu"
 
 @pytest.fixture(scope="module")
 def emu(params):
-    so = HERE / "libhostemu.so"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", str(so), str(HERE / "hostemu.cpp")])
+    import _hostemu
+    so = _hostemu.build()
     lib = C.CDLL(str(so))
     lib.emu_sqp_iteration.restype = C.c_double
     return lib, abi.make_model(params), abi.make_config(params)

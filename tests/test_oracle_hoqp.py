@@ -122,8 +122,8 @@ def test_device_generic_cascade_on_host_emulator_matches_oracle(oracle):
     import subprocess
     from pathlib import Path
     here = Path(__file__).resolve().parent
-    so = here / "host_emu/libhostemu.so"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", str(so), str(here / "host_emu/hostemu.cpp")])
+    import _hostemu
+    so = _hostemu.build()
     lib = C.CDLL(str(so))
     _p = lambda a: a.ctypes.data_as(C.c_void_p)
     rng = np.random.default_rng(0)

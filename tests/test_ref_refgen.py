@@ -170,8 +170,8 @@ def test_swing_planner_update_sequences(golden, params):
 
 @pytest.fixture(scope="module")
 def emu_lib():
-    so = HERE / "host_emu/libhostemu.so"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-o", str(so), str(HERE / "host_emu/hostemu.cpp")])
+    import _hostemu
+    so = _hostemu.build()
     return C.CDLL(str(so))
 
 

@@ -13,6 +13,7 @@ ap.add_argument("--ablate-ric", action="store_true")
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--chunks", type=int, default=1)
 ap.add_argument("--no-tail", action="store_true", help="A/B: alpha_decay = 0, i.e. no backtracking-tail launches")
+ap.add_argument("--standing", action="store_true", help="every instance stands (mode STANCE at every node: the 12-wide stages of the sweeps)")
 ap.add_argument("--stop", type=int, default=None, help="run ONLY this ablation stop (HB_ABLATE build), few steps: for counter passes")
 args = ap.parse_args()
 from pathlib import Path
@@ -26,8 +27,19 @@ B, N = args.batch, 100
 
 
 def run(reserved=0, steps=args.steps):
-    s = HunterSolver(P, batch=B, max_nodes=N, reserved=reserved, **({"alpha_decay": 0.0} if args.no_tail else {}))
-    w = workload.device_trot_batch(s, P, n_intervals=N)
+    s = HunterSolver(P, batch=B, max_nodes=N + (8 if args.standing else 0), reserved=reserved, **({"alpha_decay": 0.0} if args.no_tail else {}))
+    if args.standing:
+        from hunter_bipedal_control_amd import abi, gait
+        hor = N * P["config"]["dt"]
+        x0, rbd, cmd = workload.batch_inputs(P, B, 0, (0.0, 0.0, 0.0, 0.0), False)
+        sched = gait.schedule_window(gait.gait_schedule(P, "stance", 0.1, 0.1 + 2 * hor + 2.0), 0.1 - hor - 1.0, 1e9)
+        s.refgen_reset(abi.make_refgen_config(P, joint_ik=True))
+        s.refgen_set_schedule([sched] * B)
+        assert s.refgen_update(np.full(B, 0.1), hor, x0, cmd).max() == 0
+        s.reset(x0)
+        w = dict(x0=x0, rbd=rbd, t_now=np.full(B, 0.104))
+    else:
+        w = workload.device_trot_batch(s, P, n_intervals=N)
     s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
     s.set_resident_x0_sequence(bench.x0_sequence(w["x0"], 0))
     s.set_chunks(args.chunks)

@@ -510,12 +510,16 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   {
     const double inv_m = rcp_t(M.total_mass);
     WaveTile<2, 1> tl;
-    tile_init(cx, tl, 29, 9, [J2](int r, int c) { return r >= 19 ? J2[(r - 10) * 9 + c] : 0.0; });  // joint-rate direction 34 + j: row of joint 12 + j
-    tile_mma<8, 9, false, 9, false, 6>(cx, tl, J1, J2 + 27, 29, 9);
-    tile_store(cx, tl, 29, 9, [ABt, J1, J2, dt](int r, int c, double acc) {
-      const int dir = j_dir(r), i = j_frow(c);
-      ABt[dir * 12 + i] = (dir == i ? 1.0 : 0.0) + 0.5 * dt * (J1[r * 9 + c] + J2[r * 9 + c]) + 0.5 * dt * dt * acc;
+    tile_init(cx, tl, 29, 9, [J2](int r, int c) {   // joint-rate direction 34 + j: row of joint 12 + j
+      const double v = J2[((r >= 19 ? r : 19) - 10) * 9 + c];   // (read at a clamped row, then selected: no branch around the load)
+      return r >= 19 ? v : 0.0;
     });
+    tile_mma<8, 9, false, 9, false, 6>(cx, tl, J1, J2 + 27, 29, 9);
+    tile_store_pre(cx, tl, 29, 9, [J1, J2](int r, int c) { return J1[r * 9 + c] + J2[r * 9 + c]; },
+                   [ABt, dt](int r, int c, double acc, double j12) {
+                     const int dir = j_dir(r), i = j_frow(c);
+                     ABt[dir * 12 + i] = (dir == i ? 1.0 : 0.0) + 0.5 * dt * j12 + 0.5 * dt * dt * acc;
+                   });
     for (int idx = cx.lane; idx < 108 + 132 + 27; idx += cx.nlanes) {
       if (idx < 108) {
         // contact-force direction (j, a), row j_frow(c):  d f / d F_(j,a) = e_a / m (rows 0..2), (r_j x e_a) / m (rows 3..5)
@@ -569,8 +573,8 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     tile_mma<12, 12, false, 12, true>(cx, tg, CDt + 22 * 12, CDt, 10, 32, [cfm](int slot) { return slot_is_eq(slot, cfm) ? 1.0 : 0.0; },
                                       EqStepLive{cfm});
     tile_store(cx, tg, 10, 32, [W, GtG](int k, int r, double v) {
-      if (r < 22) W[k * 23 + r] = v;
-      else GtG[k * 10 + r - 22] = v;
+      double* dst = r < 22 ? W + k * 23 + r : GtG + k * 10 + r - 22;   // (one store at a selected address)
+      *dst = v;
     });
   }
   // (masked sums over the 12 constraint slots, unrolled with 0 / 1 weights: walking the index lists eqs / softs made every term a
@@ -1017,19 +1021,26 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     const double sw = C.soft_w;
     const double* Rc = C.R_jj;
     WaveTile<1, 2> tg;
-    tile_init(cx, tg, 10, 32, [Rc, scal](int k, int r) { return r >= 22 ? Rc[k * 10 + r - 22] + (r - 22 == k ? scal[4 + k] : 0.0) : 0.0; });
+    tile_init(cx, tg, 10, 32, [Rc, scal](int k, int r) {
+      const int rr = (r >= 22 ? r : 22) - 22;
+      const double v = Rc[k * 10 + rr], sc = scal[4 + k];
+      return r >= 22 ? v + (rr == k ? sc : 0.0) : 0.0;
+    });
     tile_mma<12, 12, false, 12, true>(cx, tg, CDt + 22 * 12, CDt, 10, 32, [cfm, sw](int slot) { return slot_is_soft(slot, cfm) ? sw : 0.0; },
                                       SoftStepLive{cfm});
     tile_store(cx, tg, 10, 32, [Pj, Rjj](int k, int r, double v) {
-      if (r < 22) Pj[k * 22 + r] = v;
-      else Rjj[k * 10 + r - 22] = v;
+      double* dst = r < 22 ? Pj + k * 22 + r : Rjj + k * 10 + r - 22;
+      *dst = v;
     });
   }
   cx.sync();
   // [M | r_j + R_jj ke | R_jj Z] = [P_j | r_j | 0] + R_jj [Kx | ke | Z]   (10 x 29, one product)
   {
     WaveTile<1, 2> tm;
-    tile_init(cx, tm, 10, 23, [Pj, ru](int k, int c) { return c < 22 ? Pj[k * 22 + c] : ru[12 + k]; });
+    tile_init(cx, tm, 10, 23, [Pj, ru](int k, int c) {
+      const double a = Pj[k * 22 + (c < 22 ? c : 21)], b = ru[12 + k];
+      return c < 22 ? a : b;
+    });
     tile_mma<12, 10, false, LDK, false, 10>(cx, tm, Rjj, Kx, 10, LDK);
     tile_store_rm<LDK>(cx, tm, 10, LDK, Mm);
   }
@@ -1045,8 +1056,8 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     const SoftStepLive soft_live{cfm};
     WaveTile<1, 2> t0;  // rows 0..15
     WaveTile<1, 1> t1;  // rows 16..21, columns 16..21
-    tile_init(cx, t0, 16, 22, [Qd](int a, int b) { return a == b ? Qd[a] : 0.0; });
-    tile_init(cx, t1, 6, 6, [Qd](int a, int b) { return a == b ? Qd[16 + a] : 0.0; });
+    tile_init(cx, t0, 16, 22, [Qd](int a, int b) { const double d = Qd[a]; return a == b ? d : 0.0; });
+    tile_init(cx, t1, 6, 6, [Qd](int a, int b) { const double d = Qd[16 + a]; return a == b ? d : 0.0; });
     tile_mma<12, 12, false, 12, true>(cx, t0, CDt, CDt, 16, 22, soft, soft_live);
     tile_mma<12, 12, false, 12, true>(cx, t1, CDt + 16 * 12, CDt + 16 * 12, 6, 6, soft, soft_live);
     // column 22 of the same tiles is q~ = q_x + Kx' (r_j + R_jj ke) + P_j' ke: the right operands carry r_j + R_jj ke and ke in

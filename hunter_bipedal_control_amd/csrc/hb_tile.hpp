@@ -29,8 +29,12 @@ HB_HD void tile_init(const Ctx& cx, WaveTile<MT, NT>& t, int Mr, int Nr, FC c_in
     for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        // c_init is evaluated for EVERY element, at indices clamped into the tile's live range, and the result is selected afterwards:
+        // evaluated under the range test, the four elements of a lane were four branches with an LDS round trip each (c_init must
+        // be free of side effects and must not branch around its own loads either — callers clamp and select the same way)
         const int row = 16 * tm + lk + 4 * r, col = 16 * tn + li;
-        t.acc[tm][tn][r] = (row < Mr && col < Nr) ? c_init(row, col) : 0.0;
+        const double v = c_init(row < Mr ? row : Mr - 1, col < Nr ? col : Nr - 1);
+        t.acc[tm][tn][r] = (row < Mr && col < Nr) ? v : 0.0;
       }
 #else
   for (int i = 0; i < MT * 16; ++i)
@@ -202,6 +206,35 @@ HB_HD void tile_store(const Ctx& cx, const WaveTile<MT, NT>& t, int Mr, int Nr, 
 #endif
 }
 
+// Store with operands: `pre(row, col)` reads what the store of element (row, col) needs besides the accumulator — evaluated for every
+// element at clamped indices, all loads of a lane in flight together — and `store(row, col, acc, pre)` runs inside the range test.
+template <int MT, int NT, class Ctx, class FP, class FS>
+HB_HD void tile_store_pre(const Ctx& cx, const WaveTile<MT, NT>& t, int Mr, int Nr, FP pre, FS store) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+#pragma unroll
+  for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      double p[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tm + lk + 4 * r, col = 16 * tn + li;
+        p[r] = pre(row < Mr ? row : Mr - 1, col < Nr ? col : Nr - 1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tm + lk + 4 * r, col = 16 * tn + li;
+        if (row < Mr && col < Nr) store(row, col, t.acc[tm][tn][r], p[r]);
+      }
+    }
+#else
+  (void)cx;
+  for (int i = 0; i < Mr; ++i)
+    for (int j = 0; j < Nr; ++j) store(i, j, t.c[i][j], pre(i, j));
+#endif
+}
+
 // Store into a plain row-major destination dst[row * LD + col] (times `scale`): the address of every element is one
 // per-lane base plus a compile-time offset, so the store carries an immediate instead of rebuilding a 64-bit address
 // per element as the generic lambda form does.
@@ -260,7 +293,8 @@ HB_HD void tile_set_col(const Ctx& cx, WaveTile<MT, NT>& t, int col, int Mr, FV 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * tm + lk + 4 * r;
-        if (16 * tn + li == col && row < Mr) t.acc[tm][tn][r] = f(row);
+        const double v = f(row < Mr ? row : Mr - 1);
+        if (16 * tn + li == col && row < Mr) t.acc[tm][tn][r] = v;
       }
 #else
   (void)cx;

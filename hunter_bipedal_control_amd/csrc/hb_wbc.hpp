@@ -353,6 +353,7 @@ struct PhaseAWork {
   LegAcc LA[4];
   double q[HB_NV], v[HB_NV], qd[HB_NV], vd[HB_NV];
   double sc[16];  // acc_lin(3) acc_ang(3) err(3) of the base task
+  LegOut<double> LO[2];  // the two legs of the desired state's centroidal evaluation (one lane each)
 };
 constexpr int PHASE_A_WORK_DOUBLES = (sizeof(PhaseAWork) + 7) / 8;
 
@@ -373,8 +374,20 @@ HB_HD void wbc_phase_a(const Ctx& cx, const DevModel& M, const DevConfig& C, con
   double* v = K.v;
   BodyPass& P = K.P;
   BodyPass& D = K.D;
-  // ---- step 1: rigid-body passes of the measured and of the desired state (WbcBase.cpp:85-136), split over lanes:
-  // 1a base frames (2 lanes), 1b the four kinematic chains (4 lanes), 1c sums and the desired base acceleration (2 lanes)
+  // ---- step 1: rigid-body passes of the measured and of the desired state (WbcBase.cpp:85-136), split over lanes.  Lanes that run
+  // DIFFERENT code are executed one after the other (divergence), lanes that run the same code on different data side by side: every
+  // stage below is ONE call whose lanes only differ in the data they point at.
+  //   1a the two legs of the desired state's centroidal evaluation (2 lanes: base velocity from the normalised momentum)
+  //   1b state vectors: measured (lane 0), desired incl. the combine of 1a (lane 1); then the base frames of both (2 lanes)
+  //   1c the four kinematic chains (4 lanes), 1d sums (2 lanes) and the desired base acceleration (lane 1)
+  if (!stance_mode) {
+    for (int task = cx.lane; task < 2; task += cx.nlanes) {
+      const double* qj = xdes + 12;
+      const double* qdj = udes + 12;
+      leg_eval<double>(M, task, PtrAccessor<double>{qj}, PtrAccessor<double>{qdj}, K.LO[task]);
+    }
+    cx.sync();
+  }
   for (int task = cx.lane; task < 2; task += cx.nlanes) {
     if (task == 0) {
       for (int i = 0; i < 3; ++i) {
@@ -391,33 +404,32 @@ HB_HD void wbc_phase_a(const Ctx& cx, const DevModel& M, const DevConfig& C, con
       sincos_t(q[4], sy, cy);
       const Vec3<double> er = euler_rates_from_omega<double>(sz, cz, sy, cy, Vec3<double>(rbd[HB_NV], rbd[HB_NV + 1], rbd[HB_NV + 2]));
       v[3] = er.x; v[4] = er.y; v[5] = er.z;
-      body_pass_base(M, q, v, P, K.BA[0]);
     } else if (!stance_mode) {
       Centroidal<double> cd;
-      centroidal_eval<double>(M, xdes + 9, xdes + 12, xdes, udes + 12, cd);
+      centroidal_combine<double>(M, K.LO[0], K.LO[1], xdes + 9, xdes, cd);
       double* qd_ = K.qd;
       double* vd_ = K.vd;
       for (int i = 0; i < HB_NV; ++i) qd_[i] = xdes[6 + i];
       vd_[0] = cd.v_lin.x; vd_[1] = cd.v_lin.y; vd_[2] = cd.v_lin.z;
       vd_[3] = cd.euler_rate.x; vd_[4] = cd.euler_rate.y; vd_[5] = cd.euler_rate.z;
       for (int j = 0; j < HB_NJ; ++j) vd_[6 + j] = udes[12 + j];
-      body_pass_base(M, qd_, vd_, D, K.BA[1]);
     }
   }
   cx.sync();
+  for (int task = cx.lane; task < (stance_mode ? 1 : 2); task += cx.nlanes)
+    body_pass_base(M, task ? K.qd : q, task ? K.vd : v, task ? D : P, K.BA[task]);
+  cx.sync();
   HB_ABLATE_STOP(C.debug_stop == 13);  // profiling ablation markers 13..16 (hb_config.reserved): phase A step by step
-  for (int task = cx.lane; task < 4; task += cx.nlanes) {
+  for (int task = cx.lane; task < (stance_mode ? 2 : 4); task += cx.nlanes) {
     const int pass = task >> 1, leg = task & 1;
-    if (pass == 0) body_pass_leg(M, q, v, P, K.W[task], leg, K.LA[task]);
-    else if (!stance_mode) body_pass_leg(M, K.qd, K.vd, D, K.W[task], leg, K.LA[task]);
+    body_pass_leg(M, pass ? K.qd : q, pass ? K.vd : v, pass ? D : P, K.W[task], leg, K.LA[task]);
   }
   cx.sync();
   HB_ABLATE_STOP(C.debug_stop == 14);
+  for (int task = cx.lane; task < (stance_mode ? 1 : 2); task += cx.nlanes)
+    body_pass_finish(task ? D : P, K.BA[task], K.LA[2 * task], K.LA[2 * task + 1]);
   for (int task = cx.lane; task < 2; task += cx.nlanes) {
-    if (task == 0) {
-      body_pass_finish(P, K.BA[0], K.LA[0], K.LA[1]);
-    } else if (!stance_mode) {
-      body_pass_finish(D, K.BA[1], K.LA[2], K.LA[3]);
+    if (task == 1 && !stance_mode) {
       // base acceleration desired: A_b qdd_b = m hdot_norm(x,u) - Adot v   (zero joint accelerations)
       const Vec3<double> comr = (1.0 / D.mass) * D.mc;
       Vec3<double> fs, ms;
@@ -505,10 +517,19 @@ HB_HD void wbc_phase_a(const Ctx& cx, const DevModel& M, const DevConfig& C, con
 }
 
 // One WBC solve.  xdes/udes/rbd: this instance's inputs; sol in/out (kept when the QP fails).
+#if defined(HB_ABLATE) && defined(__HIP_DEVICE_COMPILE__)
+#define HB_WBC_MARK(i) if (C.debug_stop == 198 && blockIdx.x == 5) wt_[i] = __builtin_readcyclecounter();
+#else
+#define HB_WBC_MARK(i)
+#endif
 template <class Ctx>
 HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const double* xdes, const double* udes,
                      const double* rbd, int mode, bool stance_mode, double* lds, double* sol, int* status_out,
                      int* iters_out) {
+#if defined(HB_ABLATE) && defined(__HIP_DEVICE_COMPILE__)
+  long long wt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  HB_WBC_MARK(0)
   double* Jm = lds + WbcLds::J;
   double* Rm = lds + WbcLds::R;
   double* Ee = lds + WbcLds::Eeom;
@@ -545,6 +566,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   wbc_phase_a(cx, M, C, xdes, udes, rbd, wc, stance_mode, C.w_swing, C.w_base, Rm, Ee, beom, Aw, bw, nullptr, nullptr, Jm);
   if (cx.lane == 0) misc[0] = 0.0;  // status
   cx.sync();
+  HB_WBC_MARK(1)
 
   HB_ABLATE_STOP(C.debug_stop == 11 || (C.debug_stop >= 13 && C.debug_stop <= 15));
   // ------------------------------------------------------------------ phase B: R~ by Givens row insertion
@@ -596,6 +618,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
     }
     cx.sync();
   }
+  HB_WBC_MARK(2)
 #else
   for (int rw = 0; rw < n_aw; ++rw) {
     for (int i = cx.lane; i < NW; i += cx.nlanes) np[i] = (i < 16) ? Aw[rw * 16 + i] : 0.0;
@@ -650,6 +673,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Rm[idx] = 0.0;
   for (int i = cx.lane; i < 64; i += cx.nlanes) is_active[i] = 0;
   cx.sync();
+  HB_WBC_MARK(3)
 
   HB_ABLATE_STOP(C.debug_stop == 12);
   // ------------------------------------------------------------------ phase C: Goldfarb–Idnani iterations
@@ -734,6 +758,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
     ++iter;
     cx.sync();
   }
+  HB_WBC_MARK(4)
   if (status == 0 && q > 0) {
     // residuals s_p = n_p'x - b_p (lane p), then R'y = s by substitution, then x -= J1 y
     for (int pp = cx.lane; pp < NW; pp += cx.nlanes) {
@@ -779,6 +804,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
 #endif
     cx.sync();
   }
+  HB_WBC_MARK(5)
   const int next_eq_active = q;  // equalities in the active set (never dropped)
   const int n_cons = wc.n_eq + wc.n_in;
   const double inf = 1e300;
@@ -945,6 +971,12 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
     if (status != 0) break;
   }
   cx.sync();
+  HB_WBC_MARK(6)
+#if defined(HB_ABLATE) && defined(__HIP_DEVICE_COMPILE__)
+  if (C.debug_stop == 198 && blockIdx.x == 5 && cx.lane == 0)
+    printf("wbc trace: phase A %lld | Householder of A_w %lld | J = R^-1, x0 %lld | equality block (%d rows) %lld | primal update %lld | inequalities (%d iterations) %lld  (cycles)\n",
+           wt_[1] - wt_[0], wt_[2] - wt_[1], wt_[3] - wt_[2], next_eq_active, wt_[4] - wt_[3], wt_[5] - wt_[4], iter - next_eq_active, wt_[6] - wt_[5]);
+#endif
   if (status == 0)
     for (int i = cx.lane; i < NW; i += cx.nlanes) sol[i] = x[i];
   if (cx.lane == 0) {

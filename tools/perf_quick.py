@@ -68,7 +68,7 @@ def run(reserved=0, steps=args.steps):
 
 if args.stop is not None:
     r = run(args.stop, steps=3)
-    print(json.dumps(dict(stop=args.stop, ms_lq=r["ms_lq"])))
+    print(json.dumps(dict(stop=args.stop, ms_lq=r["ms_lq"], ms_wbc=r["ms_wbc"], ms_ric_bwd=r["ms_riccati_bwd"])))
     sys.exit(0)
 if args.chunks > 1:
     run(steps=3)  # throwaway context: the first context of a process overlaps its chunk streams worse

@@ -99,7 +99,9 @@ typedef struct hb_config {
   double weight_swing_leg, weight_base_accel, weight_contact_force;
   double wbc_eps_reg;              /* Tikhonov term of the regularised-minimiser rule */
   int32_t wbc_max_iter;            /* working-set-change limit; reference nWSR = 20 (WeightedWbc.cpp:50) */
-  int32_t reserved;
+  int32_t reserved;                /* 0.  Tests and tuning only: 101 / 104 force the one- / four-wavefront backward sweep, 111 / 114 the row /
+                                      wave form of the forward sweep (the library picks both by the number of instances in flight; the forms
+                                      are bit-identical); other values are phase-by-phase exits of the profiling build (-DHB_ABLATE) */
   double default_joint_state[HB_NJ]; /* reference.info:7-19 */
   double delta_tol;                /* sqp.deltaTol, task.info:84: the line search gives up (no step, as at alpha_min) once
                                       alpha |dx| and alpha |du| — l2 norms over the whole trajectory — are both below it

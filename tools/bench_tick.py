@@ -13,6 +13,7 @@ from hunter_bipedal_control_amd.solver import HunterSolver
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--batch", type=int, default=4096)
+ap.add_argument("--no-attribution", action="store_true", help="only the free-running tick (for a kernel timeline of it)")
 args = ap.parse_args()
 P = ingest.load_packaged()
 B, N = args.batch, 100
@@ -21,6 +22,9 @@ s = HunterSolver(P, batch=B, max_nodes=N + 8)
 w = workload.device_trot_batch(s, P, n_intervals=N)
 r = bench._full_tick(P, s, w, args.steps, 0.010)
 print(json.dumps({"full_tick": {k: r[k] for k in ("updates_per_s", "ms_per_step")}}))
+if args.no_attribution:
+    s.close()
+    sys.exit(0)
 # attribution: same calls, a sync after each
 rbd = w["rbd"]
 quat = np.tile([0.0, 0.0, 0.0, 1.0], (B, 1))

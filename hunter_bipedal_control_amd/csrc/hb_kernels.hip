@@ -258,12 +258,12 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
   // Staging of a stage record through registers, 16-byte loads, every load of a lane issued before the first is
   // consumed.  The Riccati part of the record is the LDS image (hb_lq.hpp REC_* layout), so staging is two straight copies:
   //   buf[r]    pair l + 64 r of doubles [0, REC_QT): rows of [A~ b~ B~ .] -> RicLds::ABb, rows of [P~ r~ R~ .] -> RicLds::PRr
-  //   bufq[r]   pair l + 64 r of [Q~ | q~] (253 pairs), dropped over the dead A~ block at the end of the stage (RicLds::Qs)
+  //   bufq[r]   pair l + 64 r of [Q~ (upper triangle, packed) | q~] (138 pairs), dropped over the dead A~ block at the end of the stage (RicLds::Qs)
   // Slots beyond a block read a few doubles further inside the same record and are never stored.
   // Software pipeline (WaveCtx::sync does not drain global loads): [Q~ q~] of stage k and the staged part of stage k-1
   // are requested between the factorisation and the last GEMM of stage k — requested earlier they would be live across
   // the register-resident Cholesky, the register peak of the kernel.
-  constexpr int NL = 10, NQ = 4, NP_AB = REC_PR / 2, NP = REC_QT / 2;  // 396 pairs of [A~ b~ B~ .], 612 pairs staged
+  constexpr int NL = 10, NPQ = (REC_QT_PACKED + 22) / 2, NQ = (NPQ + 63) / 64, NP_AB = REC_PR / 2, NP = REC_QT / 2;  // 396 pairs of [A~ b~ B~ .], 612 pairs staged; 138 of [Q~ | q~]
   static_assert(NP <= 64 * NL && 64 * NL * 2 + 2 * 64 * NQ <= REC_SIZE && REC_QT % 2 == 0 && REC_PR % 2 == 0, "record layout");
   typedef double d2 __attribute__((ext_vector_type(2)));  // (HIP's double2 struct kept the buffers in scratch memory)
   d2 buf[NL], bufq[NQ];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
       d2* Qs2 = reinterpret_cast<d2*>(lds + RicLds::Qs) + l;
 #pragma unroll
       for (int r = 0; r < NQ; ++r)
-        if (l + 64 * r < 253) Qs2[64 * r] = bufq[r];
+        if (l + 64 * r < NPQ) Qs2[64 * r] = bufq[r];
     }
     ric_phase3_finish(cxk, lds, t);
   }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void k_ric_bwd4(Batch b, int dbg) {
   block_sync_lds();
   const int n = b.n_nodes[inst];
   using L = Ric4Lds;
-  constexpr int NP_AB = REC_PR / 2, NP = REC_QT / 2;   // 396 pairs of [A~ b~ B~ .], 612 pairs staged, then 253 pairs of [Q~ | q~]
+  constexpr int NP_AB = REC_PR / 2, NP = REC_QT / 2, NPQ = (REC_QT_PACKED + 22) / 2;   // 396 pairs of [A~ b~ B~ .], 612 pairs staged, then 138 pairs of [Q~ | q~]
   static_assert(NP <= 256 * 3 && 2 * (NP + 256) <= REC_SIZE, "record layout");
   typedef double d2 __attribute__((ext_vector_type(2)));
   d2 buf[3], bufq;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void k_ric_bwd4(Batch b, int dbg) {
         if (p < NP_AB) ab2[p] = buf[r];
         else if (p < NP) pr2[p - NP_AB] = buf[r];
       }
-      if (t < 253) reinterpret_cast<d2*>(Qs)[t] = bufq;
+      if (t < NPQ) reinterpret_cast<d2*>(Qs)[t] = bufq;
     }
     // n_til: number of projected inputs of this stage (uniform; it came with the prefetch)
     const int n_til = int(meta_nf) + int(meta_nz);
@@ -2700,7 +2700,8 @@ int32_t hb_riccati_solve(hb_ctx* ctx, int32_t n, int32_t N, int32_t nu, const do
       double* rec = recs.data() + (size_t(i) * Nm + k) * REC_SIZE;
       const size_t sk = size_t(i) * N + k;
       for (int row = 0; row < 22; ++row) std::memcpy(rec + rec_A(row, 0), A + sk * 484 + row * 22, 22 * 8);
-      std::memcpy(rec + REC_QT, Q + sk * 484, 484 * 8);
+      for (int i = 0; i < 22; ++i)   // the record holds the upper triangle of Q~, packed
+        for (int c = i; c < 22; ++c) rec[REC_QT + rec_Qidx(i, c)] = Q[sk * 484 + i * 22 + c];
       for (int row = 0; row < 22; ++row) rec[rec_b(row)] = bv[sk * 22 + row];
       std::memcpy(rec + REC_qT, q + sk * 22, 22 * 8);
       for (int row = 0; row < 22; ++row)

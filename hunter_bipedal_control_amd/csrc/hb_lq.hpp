@@ -47,8 +47,10 @@ constexpr int NU_T = 12;                 // projected input width (padded)
 constexpr int REC_LD = 36, REC_CV = 22, REC_CU = 23;
 constexpr int REC_AB = 0;                // 22 rows: [A~ | b~ | B~ | .]
 constexpr int REC_PR = 792;              // 12 rows: [P~ | r~ | R~ | .]
-constexpr int REC_QT = 1224;             // 22x22
-constexpr int REC_qT = 1708;             // 22
+constexpr int REC_QT = 1224;             // Q~: the UPPER triangle, packed by rows (253 + 1 pad): the backward sweep mirrors it and never reads the rest
+constexpr int REC_QT_PACKED = 254;
+constexpr int REC_qT = REC_QT + REC_QT_PACKED;   // 22, right behind it: [Q~ | q~] is one block of 276 doubles for the sweep
+HB_HD constexpr int rec_Qidx(int i, int c) { return (i * (43 - i)) / 2 + c; }   // i <= c < 22: i*22 - i(i-1)/2 + (c - i)
 constexpr int REC_RICCATI_END = 1730;
 constexpr int REC_KX = 1730;             // 10x22
 constexpr int REC_KE = 1950;             // 10
@@ -1068,16 +1070,15 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     tile_mma<12, LDK, true, LDK, false, 10>(cx, t1, Kx + 16, Mm + 16, 6, 7);
     tile_mma<12, 22, true, LDK, false, 10>(cx, t0, Pj, Kx, 16, 23);
     tile_mma<12, 22, true, LDK, false, 10>(cx, t1, Pj + 16, Kx + 16, 6, 7);
+    // (only the upper triangle goes into the record, packed: what the diagonal tiles hold below it is not used by anyone)
     tile_store(cx, t0, 16, 23, [rec, dt](int a, int b, double v) {
-      if (b < 22) {
-        rec[REC_QT + a * 22 + b] = dt * v;
-        if (b >= 16) rec[REC_QT + b * 22 + a] = dt * v;
-      } else {
-        rec[REC_qT + a] = dt * v;
-      }
+      double* dst = b < 22 ? rec + REC_QT + rec_Qidx(a, b) : rec + REC_qT + a;
+      if (a <= b) *dst = dt * v;
     });
-    tile_store_rm_cols<22>(cx, t1, 6, 0, 6, rec + REC_QT + 16 * 22 + 16, dt);
-    tile_store_rm_cols<1>(cx, t1, 6, 6, 7, rec + REC_qT + 16 - 6, dt);
+    tile_store(cx, t1, 6, 7, [rec, dt](int a, int b, double v) {
+      double* dst = b < 6 ? rec + REC_QT + rec_Qidx(16 + a, 16 + b) : rec + REC_qT + 16 + a;
+      if (a <= b) *dst = dt * v;
+    });
   }
   HB_ABLATE_STOP(C.debug_stop == 32);
   for (int a = cx.lane; a < 22; a += cx.nlanes) {

@@ -29,7 +29,7 @@ struct RicLds {
   static constexpr int PRr = ABb + 24 * LDW;     // 12 x 36
   static constexpr int Hu = PRr;                 // 12 x 36 : [Hux | hu | . | Huu]
   static constexpr int Kk = PRr + 12 * LDW;      // 12 x 24 : [K~ | k~ | .]
-  static constexpr int Qs = ABb;                 // [Q~ | q~] 506, dropped over A~ between GEMM 3 and the store of T
+  static constexpr int Qs = ABb;                 // [Q~ upper triangle, packed | q~] 276, dropped over A~ between GEMM 3 and the store of T
   static constexpr int flag = Kk + 12 * LDN;     // 4
   static constexpr int total = flag + 4 + 44;    // slack: padded tile reads run up to 40 doubles past Kk
 };
@@ -50,7 +50,7 @@ struct Ric4Lds {
   static constexpr int PRr = ABb + 24 * LDW;     // 12 x 36, then Hu
   static constexpr int Hu = PRr;
   static constexpr int Kk = PRr + 12 * LDW;      // 12 x 24
-  static constexpr int Qs = Kk + 12 * LDN;       // [Q~ | q~] 506 (+ 6)
+  static constexpr int Qs = Kk + 12 * LDN;       // [Q~ upper triangle, packed | q~] 276 (the buffer keeps its 512)
   static constexpr int flag = Qs + 512;          // 4
   static constexpr int total = flag + 4 + 44;    // slack for the padded tile reads, as RicLds
 };
@@ -358,12 +358,12 @@ HB_HD void ric_store_T(const Ctx& cx, const WaveTile<MT, NT>& t, int Mr, int Nr,
     for (int tn = 0; tn < NT; ++tn) {
       const int cl = 16 * tn + li, c = cl + c0, il0 = 16 * tm + lk, i0 = il0 + r0;
       const bool colv = c == RicLds::CV, colok = cl < Nr;
-      const int q0 = colv ? 484 + i0 : i0 * 22 + c, qs = colv ? 4 : 88;
       double q[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int idx = q0 + r * qs;
-        q[r] = Qs[idx < 511 ? idx : 511];
+      for (int r = 0; r < 4; ++r) {   // Qs = [Q~ upper triangle packed | q~] as in the record
+        const int i = i0 + 4 * r;
+        const int idx = colv ? REC_QT_PACKED + i : rec_Qidx(i, c);
+        q[r] = Qs[(idx >= 0 && idx < REC_QT_PACKED + 22) ? idx : 0];
       }
       double* const pv = sv + i0;                  // + 4 r
       double* const pa = S + i0 * LDN_ + c;        // + 4 r LDN
@@ -384,9 +384,9 @@ HB_HD void ric_store_T(const Ctx& cx, const WaveTile<MT, NT>& t, int Mr, int Nr,
   tile_store(cx, t, Mr, Nr, [S, sv, Qs, r0, c0](int il, int cl, double v) {
     const int i = il + r0, c = cl + c0;
     if (c == RicLds::CV) {
-      sv[i] = v + Qs[484 + i];
+      sv[i] = v + Qs[REC_QT_PACKED + i];
     } else if (i <= c) {
-      const double w = v + Qs[i * 22 + c];
+      const double w = v + Qs[rec_Qidx(i, c)];
       S[i * LDN_ + c] = w;
       S[c * LDN_ + i] = w;
     }
@@ -420,7 +420,7 @@ HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, const double* rec, doubl
   RicT3 t;
   ric_phase3_mma(cx, lds, t);
   double* Qs = lds + RicLds::Qs;
-  for (int e = cx.lane; e < 506; e += cx.nlanes) Qs[e] = rec[e < 484 ? REC_QT + e : REC_qT + e - 484];
+  for (int e = cx.lane; e < REC_QT_PACKED + 22; e += cx.nlanes) Qs[e] = rec[REC_QT + e];
   ric_phase3_finish(cx, lds, t);
 }
 

@@ -284,7 +284,15 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
     meta_nf = meta[0];
     meta_nz = meta[1];
   }
+#if defined(HB_ABLATE)
+  // cycle-counter trace of one stage (tools/perf_quick.py --stop 197): the marks live in the slack words behind RicLds::flag, not in registers
+  long long* t1_ = reinterpret_cast<long long*>(lds + RicLds::flag + 8);
+#define HB_RIC1_MARK(i) if (dbg == 197 && blockIdx.x == 9 && k == 50 && cx.lane == 0) t1_[i] = __builtin_readcyclecounter();
+#else
+#define HB_RIC1_MARK(i)
+#endif
   for (int k = n - 1; k >= 0; --k) {
+    HB_RIC1_MARK(0)
     // Per-lane addresses are rebuilt every stage from an opaque copy of the lane id: as loop invariants the compiler
     // hoisted ~100 of them out of the loop and then spilled them to scratch around the Cholesky, and every scratch
     // reload drains the prefetch (s_waitcnt vmcnt(0)).
@@ -307,7 +315,9 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
     if (HB_ABLATE_ON && dbg == 20) { if (k > 0) HB_RIC_FETCH(k - 1, l); continue; }  // profiling ablation: staging only
     // n_til: number of projected inputs of this stage (uniform; requested one stage ahead with the prefetch)
     const int n_til = int(meta_nf) + int(meta_nz);
+    HB_RIC1_MARK(1)
     ric_phase12(cxk, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE, n_til, dbg);
+    HB_RIC1_MARK(2)
     asm volatile("" : "+v"(l));
     cxk.lane = l;
     HB_RIC_FETCH_Q(k, l);
@@ -319,7 +329,9 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
     }
     if (HB_ABLATE_ON && (dbg == 21 || dbg == 22 || dbg == 23)) continue;
     RicT3 t;
+    HB_RIC1_MARK(3)
     ric_phase3_mma(cxk, lds, t);
+    HB_RIC1_MARK(4)
     {
       d2* Qs2 = reinterpret_cast<d2*>(lds + RicLds::Qs) + l;
 #pragma unroll
@@ -327,6 +339,12 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
         if (l + 64 * r < NPQ) Qs2[64 * r] = bufq[r];
     }
     ric_phase3_finish(cxk, lds, t);
+    HB_RIC1_MARK(5)
+#if defined(HB_ABLATE)
+    if (dbg == 197 && blockIdx.x == 9 && k == 50 && cx.lane == 0)
+      printf("ric1 trace: stage-in %lld | GEMM 1 + GEMM 2 + factor + solves %lld | fetch %lld | GEMM 3 %lld | Q~ + store %lld  (cycles)\n", t1_[1] - t1_[0], t1_[2] - t1_[1],
+             t1_[3] - t1_[2], t1_[4] - t1_[3], t1_[5] - t1_[4]);
+#endif
   }
 #undef HB_RIC_FETCH
 #undef HB_RIC_FETCH_Q
@@ -1953,7 +1971,7 @@ static int32_t warm_start_onto_new_tables(hb_ctx* ctx) {
 // own streams): what decides is how many sweeps share the chip, not the size of this launch.
 static void launch_ric_bwd(hb_ctx* ctx, const Batch& b, int B, int concurrent, hipStream_t s) {
   const int sel = ctx->hconfig.debug_stop;
-  const bool four = sel == 104 || (HB_ABLATE_ON && ((sel >= 24 && sel <= 27) || sel == 199)) || (sel != 101 && !(HB_ABLATE_ON && sel != 0) && concurrent <= kRicBwd4MaxBatch);
+  const bool four = sel == 104 || (HB_ABLATE_ON && ((sel >= 24 && sel <= 27) || sel == 199)) || (sel != 101 && !(HB_ABLATE_ON && sel != 0 && sel != 198) && concurrent <= kRicBwd4MaxBatch);
   if (four) hipLaunchKernelGGL(k_ric_bwd4, dim3(B), dim3(256), 0, s, b, sel);
   else hipLaunchKernelGGL(k_ric_bwd, dim3(B), dim3(64), 0, s, b, sel);
 }

@@ -37,25 +37,39 @@ HB_HD int fullpivlu_kernel(const Ctx& cx, double* T, int m, int n, int ld, doubl
   int nonzero = size;
   double maxpivot = 0.0;
   cx.sync();
-  for (int k = 0; k < size; ++k) {
-    for (int j = k + cx.lane; j < n; j += cx.nlanes) {
-      double best = -1.0;
-      int bi = k;
-      for (int i = k; i < m; ++i) {
-        const double a = fabs(T[i * ld + j]);
-        if (a > best) { best = a; bi = i; }
-      }
-      cb[j] = best;
-      ci[j] = bi;
+  // column maxima of the whole matrix; from then on the elimination of a step leaves the maxima of ITS trailing block behind (the
+  // next step's search range exactly), so the matrix is walked once per step instead of twice
+  for (int j = cx.lane; j < n; j += cx.nlanes) {
+    double best = -1.0;
+    int bi = 0;
+    for (int i = 0; i < m; ++i) {
+      const double a = fabs(T[i * ld + j]);
+      if (a > best) { best = a; bi = i; }
     }
-    cx.sync();
+    cb[j] = best;
+    ci[j] = bi;
+  }
+  cx.sync();
+  for (int k = 0; k < size; ++k) {
     double best = -1.0;
     int bj = k;
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+      // the first column (lowest index) that holds the largest magnitude: wave maximum + ballot instead of every lane walking all columns
+      static_assert(Ctx::nlanes == 64, "one column per lane");
+      const int j = k + cx.lane;
+      const double mine = j < n ? cb[j] : -1.0;
+      best = wave_max_f64(mine);
+      const unsigned long long hit = __ballot(mine == best && j < n);
+      bj = hit ? k + (__ffsll(hit) - 1) : k;
+    }
+#else
     for (int j = k; j < n; ++j)
       if (cb[j] > best) { best = cb[j]; bj = j; }
+#endif
     const int bi = ci[bj];
     cx.sync();
-    if (best == 0.0) { nonzero = k; break; }
+    if (!(best > 0.0)) { nonzero = k; break; }
     if (best > maxpivot) maxpivot = best;
     if (bi != k)
       for (int j = cx.lane; j < n; j += cx.nlanes) { const double t = T[k * ld + j]; T[k * ld + j] = T[bi * ld + j]; T[bi * ld + j] = t; }
@@ -70,7 +84,29 @@ HB_HD int fullpivlu_kernel(const Ctx& cx, double* T, int m, int n, int ld, doubl
     cx.sync();
     for (int j = k + 1 + cx.lane; j < n; j += cx.nlanes) {
       const double tkj = T[k * ld + j];
-      for (int i = k + 1; i < m; ++i) T[i * ld + j] -= T[i * ld + k] * tkj;
+      double cbest = -1.0;
+      int cbi = k + 1;
+      int i = k + 1;
+      for (; i + 3 < m; i += 4) {   // four rows at a time: the eight operand reads are in flight together (row by row every read waited for the store before it)
+        double a4[4], l4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a4[r] = T[(i + r) * ld + j]; l4[r] = T[(i + r) * ld + k]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double v = a4[r] - l4[r] * tkj;
+          T[(i + r) * ld + j] = v;
+          const double a = fabs(v);
+          if (a > cbest) { cbest = a; cbi = i + r; }
+        }
+      }
+      for (; i < m; ++i) {
+        const double v = T[i * ld + j] - T[i * ld + k] * tkj;
+        T[i * ld + j] = v;
+        const double a = fabs(v);
+        if (a > cbest) { cbest = a; cbi = i; }
+      }
+      cb[j] = cbest;
+      ci[j] = cbi;
     }
     cx.sync();
   }
@@ -80,12 +116,23 @@ HB_HD int fullpivlu_kernel(const Ctx& cx, double* T, int m, int n, int ld, doubl
   const int dimker = n - rk;
   if (dimker > zcap) return -1;
   for (int kk = cx.lane; kk < dimker; kk += cx.nlanes) {
+    // back substitution of free column c in place: T(i, c) <- -x_i (the right-hand side entry is read once, then the slot holds the solution),
+    // so the inner products run over T alone — through Z every term was two dependent reads (the permutation, then the entry)
     const int c = rk + kk;
     for (int i = rk - 1; i >= 0; --i) {
       double sacc = T[i * ld + c];
-      for (int j = i + 1; j < rk; ++j) sacc += T[i * ld + j] * Z[q[j] * ldz + kk];   // (Z holds -x_j)
-      Z[q[i] * ldz + kk] = -(sacc / T[i * ld + i]);
+      int j = i + 1;
+      for (; j + 3 < rk; j += 4) {
+        double a4[4], y4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a4[r] = T[i * ld + j + r]; y4[r] = T[(j + r) * ld + c]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc += a4[r] * y4[r];
+      }
+      for (; j < rk; ++j) sacc += T[i * ld + j] * T[j * ld + c];
+      T[i * ld + c] = -(sacc / T[i * ld + i]);
     }
+    for (int i = 0; i < rk; ++i) Z[q[i] * ldz + kk] = T[i * ld + c];
     for (int t = 0; t < dimker; ++t) Z[q[rk + t] * ldz + kk] = (t == kk) ? 1.0 : 0.0;
   }
   cx.sync();

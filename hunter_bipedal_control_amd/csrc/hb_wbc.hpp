@@ -644,6 +644,28 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   // involve the accelerations) followed by a diagonal: columns >= 16 of the inverse are the reciprocal diagonal.
   for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Jm[idx] = 0.0;
   cx.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Device: a lane keeps ITS column of the inverse in registers (fixed 16-step loops, entries beyond the column masked to zero) and
+  // writes it once — in place every term was an LDS round trip behind the store of the row before it (17 k cycles of a 290 k solve)
+  if (cx.lane < NW) {
+    const int col = cx.lane;
+    if (col >= 16) {
+      Jm[col * NW + col] = rcp_t(Rm[col * NW + col]);
+    } else {
+      double xc[16];
+#pragma unroll
+      for (int i = 15; i >= 0; --i) {
+        double s = (i == col) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = i + 1; k < 16; ++k) s -= Rm[i * NW + k] * (k <= col ? xc[k] : 0.0);
+        xc[i] = i <= col ? s * rcp_t(Rm[i * NW + i]) : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i <= col) Jm[i * NW + col] = xc[i];
+    }
+  }
+#else
   for (int col = cx.lane; col < NW; col += cx.nlanes) {
     if (col >= 16) {
       Jm[col * NW + col] = rcp_t(Rm[col * NW + col]);
@@ -655,6 +677,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       }
     }
   }
+#endif
   cx.sync();
   // unconstrained minimiser x = J J' g
   for (int k = cx.lane; k < NW; k += cx.nlanes) {

@@ -761,6 +761,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
 #endif
   for (int p = 0; p < 16 + 3 * HB_NC; ++p) {  // (fixed trip count: unrolled on the device, q = p is then a constant in `reflect`)
     if (p >= wc.n_eq || status != 0) break;
+    if (p == 5) { HB_WBC_MARK(7) }
     if (p < 16) {
       for (int k = cx.lane; k < NW; k += cx.nlanes) {
         double sa[4] = {0.0, 0.0, 0.0, 0.0};
@@ -773,7 +774,9 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       for (int k = cx.lane; k < NW; k += cx.nlanes) d[k] = Jm[sidx * NW + k];
     }
     cx.sync();
+    if (p == 5) { HB_WBC_MARK(8) }
     reflect(q);
+    if (p == 5) { HB_WBC_MARK(9) }
     if (!(fabs(d[q]) > 1e-13 * fmax(1.0, fabs(Rm[0])))) { status = HB_INST_INFEASIBLE; break; }  // dependent equality rows
     for (int i = cx.lane; i <= q; i += cx.nlanes) Rm[i * NW + q] = d[i];
     if (cx.lane == 0) { act[q] = p; lam[q] = 0.0; is_active[p] = 1; }
@@ -997,8 +1000,8 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   HB_WBC_MARK(6)
 #if defined(HB_ABLATE) && defined(__HIP_DEVICE_COMPILE__)
   if (C.debug_stop == 198 && blockIdx.x == 5 && cx.lane == 0)
-    printf("wbc trace: phase A %lld | Householder of A_w %lld | J = R^-1, x0 %lld | equality block (%d rows) %lld | primal update %lld | inequalities (%d iterations) %lld  (cycles)\n",
-           wt_[1] - wt_[0], wt_[2] - wt_[1], wt_[3] - wt_[2], next_eq_active, wt_[4] - wt_[3], wt_[5] - wt_[4], iter - next_eq_active, wt_[6] - wt_[5]);
+    printf("wbc trace: phase A %lld | Householder of A_w %lld | J = R^-1, x0 %lld | equality block (%d rows) %lld | primal update %lld | inequalities (%d iterations) %lld | row 5: d = J'n %lld, reflector %lld  (cycles)\n",
+           wt_[1] - wt_[0], wt_[2] - wt_[1], wt_[3] - wt_[2], next_eq_active, wt_[4] - wt_[3], wt_[5] - wt_[4], iter - next_eq_active, wt_[6] - wt_[5], wt_[8] - wt_[7], wt_[9] - wt_[8]);
 #endif
   if (status == 0)
     for (int i = cx.lane; i < NW; i += cx.nlanes) sol[i] = x[i];

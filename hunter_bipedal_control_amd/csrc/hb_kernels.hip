@@ -2073,6 +2073,28 @@ int32_t hb_mpc_get_performance(hb_ctx* ctx, double* perf) {
   return HB_OK;
 }
 
+// MPC_MRT_Interface::updatePolicy as ONE launch: the iterate (x, u), its time grid, mode sequence and node counts of `cnt` instances become
+// the policy the controller evaluates (five device-to-device copies before: five launches with their gaps in every step of every range).
+__global__ __launch_bounds__(256) void k_publish(const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ t,
+                                                 const int* __restrict__ mode, const int* __restrict__ n_nodes, double* __restrict__ px,
+                                                 double* __restrict__ pu, double* __restrict__ pt, int* __restrict__ pmode, int* __restrict__ pn,
+                                                 size_t nx, size_t nu, size_t nt, size_t nm, size_t nn) {
+  const size_t total = nx + nu + nt + nm + nn, stride = size_t(gridDim.x) * blockDim.x;
+  for (size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+    if (e < nx) px[e] = x[e];
+    else if (e < nx + nu) pu[e - nx] = u[e - nx];
+    else if (e < nx + nu + nt) pt[e - nx - nu] = t[e - nx - nu];
+    else if (e < nx + nu + nt + nm) pmode[e - nx - nu - nt] = mode[e - nx - nu - nt];
+    else pn[e - nx - nu - nt - nm] = n_nodes[e - nx - nu - nt - nm];
+  }
+}
+static void launch_publish(const Batch& b, const WbcBatch& w, size_t cnt, size_t N, hipStream_t s) {
+  const size_t nx = cnt * (N + 1) * HB_NX, nu = cnt * N * HB_NU, nt = cnt * (N + 1), nm = cnt * N, nn = cnt;
+  const size_t total = nx + nu + nt + nm + nn;
+  const unsigned blocks = unsigned(std::min<size_t>((total + 256 * 4 - 1) / (256 * 4), 8192));   // four elements per thread, grid-stride beyond
+  hipLaunchKernelGGL(k_publish, dim3(blocks), dim3(256), 0, s, b.x, b.u, b.t, b.mode, b.n_nodes, w.px, w.pu, w.pt, w.pmode, w.pn, nx, nu, nt, nm, nn);
+}
+
 int32_t hb_mpc_publish(hb_ctx* ctx) {
   if (ctx) lazy_join(ctx);
   if (!ctx) return HB_ERR_ARG;
@@ -2087,11 +2109,7 @@ int32_t hb_mpc_publish(hb_ctx* ctx) {
     HB_HIP(hipStreamWaitEvent(s, ctx->ev[8], 0));
     ctx->policy_read_pending = false;
   }
-  HB_HIP(hipMemcpyAsync(ctx->w.px, ctx->b.x, B * (N + 1) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
-  HB_HIP(hipMemcpyAsync(ctx->w.pu, ctx->b.u, B * N * HB_NU * 8, hipMemcpyDeviceToDevice, s));
-  HB_HIP(hipMemcpyAsync(ctx->w.pt, ctx->b.t, B * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
-  HB_HIP(hipMemcpyAsync(ctx->w.pmode, ctx->b.mode, B * N * sizeof(int), hipMemcpyDeviceToDevice, s));
-  HB_HIP(hipMemcpyAsync(ctx->w.pn, ctx->b.n_nodes, B * sizeof(int), hipMemcpyDeviceToDevice, s));
+  launch_publish(ctx->b, ctx->w, B, N, s);
   HB_HIP(hipEventRecord(ctx->ev[7], s));
   HB_HIP(hipStreamWaitEvent(ctx->s_wbc, ctx->ev[7], 0));
   ctx->w.policy_valid = true;
@@ -2212,11 +2230,7 @@ static int32_t range_publish_policy_wbc(hb_ctx* ctx, int i0, int cnt, hipStream_
   const size_t N = ctx->Nmax;
   const Batch b = batch_view(ctx->b, i0, cnt);
   const WbcBatch w = wbc_view(ctx->w, ctx->Nmax, i0, cnt);
-  HB_HIP(hipMemcpyAsync(w.px, b.x, size_t(cnt) * (N + 1) * HB_NX * 8, hipMemcpyDeviceToDevice, s));
-  HB_HIP(hipMemcpyAsync(w.pu, b.u, size_t(cnt) * N * HB_NU * 8, hipMemcpyDeviceToDevice, s));
-  HB_HIP(hipMemcpyAsync(w.pt, b.t, size_t(cnt) * (N + 1) * 8, hipMemcpyDeviceToDevice, s));
-  HB_HIP(hipMemcpyAsync(w.pmode, b.mode, size_t(cnt) * N * sizeof(int), hipMemcpyDeviceToDevice, s));
-  HB_HIP(hipMemcpyAsync(w.pn, b.n_nodes, size_t(cnt) * sizeof(int), hipMemcpyDeviceToDevice, s));
+  launch_publish(b, w, size_t(cnt), N, s);
   hipLaunchKernelGGL(k_policy_eval, dim3((cnt + 63) / 64), dim3(64), 0, s, w, ctx->Nmax, ctx->dconfig);
   if (ctx->config.wbc_type == 1)
     hipLaunchKernelGGL(k_hwbc, dim3(cnt), dim3(64), HoLdsDev::total * sizeof(double), s, w, ctx->dmodel, ctx->dconfig);

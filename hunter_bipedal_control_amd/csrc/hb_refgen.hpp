@@ -680,7 +680,9 @@ HB_HD int refgen_plan(const DevModel& M, const RefgenConfig& K, int n_ev, const 
   rg_make_target(K, t0, horizon, x_now, cmd_vel, knot_x + size_t(RG_MAX_KNOTS - 2) * HB_NX, knot_x + size_t(RG_MAX_KNOTS - 1) * HB_NX, T);
   const double tf_h = T.tf;
   // ---- current feet (InverseKinematics::computeFootPos) ------------------------------------------------------------
-  Vec3<double> feet[HB_NC];
+  // A foot that is in contact now refreshes its latest stance position (SwingTrajectoryPlanner::update).  (Written here, leg by leg:
+  // kept in a local array for the loop over the feet below, the positions were indexed by the loop variable and lived in scratch.)
+  const int mode_now = modes[rg_bisect_left(ev, n_ev, t0 + 0.001)];
   {
     const Mat3<double> R0 = rg_rot_zyx(x_now + 9);
     const Vec3<double> p0(x_now[6], x_now[7], x_now[8]);
@@ -688,16 +690,20 @@ HB_HD int refgen_plan(const DevModel& M, const RefgenConfig& K, int n_ev, const 
     for (int leg = 0; leg < 2; ++leg) {
       LegOut<double> L;
       leg_eval<double>(M, leg, [qj](int j) { return qj[j]; }, [](int) { return 0.0; }, L);
-      feet[leg] = p0 + R0 * L.foot[0];
-      feet[leg + 2] = p0 + R0 * L.foot[1];
+      for (int f = 0; f < 2; ++f) {
+        const int j = leg + 2 * f;
+        if (rg_contact(mode_now, j)) {
+          const Vec3<double> foot = p0 + R0 * L.foot[f];
+          latest_stance[3 * j] = foot.x;
+          latest_stance[3 * j + 1] = foot.y;
+        }
+      }
     }
   }
   // ---- swing planner update (SwingTrajectoryPlanner::update) ----------------------------------------------------------
-  const int mode_now = modes[rg_bisect_left(ev, n_ev, t0 + 0.001)];
   int status = 0;
   for (int j = 0; j < HB_NC; ++j) {
     double* ls = latest_stance + 3 * j;
-    if (rg_contact(mode_now, j)) { ls[0] = feet[j].x; ls[1] = feet[j].y; }
     ls[2] = K.next_position_z;
     double last[3] = {ls[0], ls[1], ls[2]}, nxt[3] = {ls[0], ls[1], ls[2]};
     int last_final = 0;

@@ -917,27 +917,32 @@ struct RefgenBatch {
   int init_stance;  // take the current feet as latest stance positions (first update after a reset without state)
 };
 
+// planner step: FOUR lanes per instance, one per foot (refgen_plan: the four planner loops and the leg evaluations side by side; the lane
+// of foot 0 finishes with the shooting grid and the knots) — thread-per-instance the kernel was a 0.26 ms chain on 64 wavefronts
 __global__ __launch_bounds__(64) void k_refgen(Batch b, RefgenBatch r, const DevModel* __restrict__ M, hb_refgen_config K, double horizon) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b.B) return;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid >> 2, foot = gid & 3;
+  if (i >= b.B) return;   // (a whole group of four leaves together)
   const double* x_now = b.x0 + size_t(i) * HB_NX;
   double* stance = r.stance + size_t(i) * 12;
   if (r.init_stance) {
     const Mat3<double> R0 = rg_rot_zyx(x_now + 9);
     const Vec3<double> p0(x_now[6], x_now[7], x_now[8]);
     const double* qj = x_now + 12;
-    for (int leg = 0; leg < 2; ++leg) {
-      LegOut<double> L;
-      leg_eval<double>(*M, leg, [qj](int j) { return qj[j]; }, [](int) { return 0.0; }, L);
-      st3(stance + 3 * leg, p0 + R0 * L.foot[0]);
-      st3(stance + 3 * (leg + 2), p0 + R0 * L.foot[1]);
-    }
+    LegOut<double> L;
+    leg_eval<double>(*M, foot & 1, [qj](int j) { return qj[j]; }, [](int) { return 0.0; }, L);
+    st3(stance + 3 * foot, p0 + R0 * ((foot >> 1) ? L.foot[1] : L.foot[0]));
   }
   const size_t N = b.Nmax;
-  r.status[i] = refgen_plan(*M, K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.modes + size_t(i) * (HB_MAX_EVENTS + 1), r.t0[i], horizon, x_now,
-                            r.cmd + size_t(i) * 4, stance, r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, b.Nmax, b.n_nodes + i,
-                            b.t + size_t(i) * (N + 1), r.n_knots + i, r.knot_t + size_t(i) * RG_MAX_KNOTS,
-                            r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX);
+  const int st = refgen_plan(*M, K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.modes + size_t(i) * (HB_MAX_EVENTS + 1), r.t0[i], horizon, x_now,
+                             r.cmd + size_t(i) * 4, stance, r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, b.Nmax, b.n_nodes + i,
+                             b.t + size_t(i) * (N + 1), r.n_knots + i, r.knot_t + size_t(i) * RG_MAX_KNOTS,
+                             r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX, foot, 4);
+  // status of the instance: 2 (grid too long, from the lane of foot 0) wins, else 1 if any foot reported a phase without its events
+  int any = st == 1 ? 1 : 0;
+  any |= __shfl_xor(any, 1, 64);
+  any |= __shfl_xor(any, 2, 64);
+  if (foot == 0) r.status[i] = st == 2 ? 2 : any;
 }
 // joint-reference IK: eight lanes per (instance, leg), eight pairs per wavefront (hb_refgen.hpp refgen_ik_group)
 __global__ __launch_bounds__(64) void k_refgen_ik(Batch b, RefgenBatch r, const DevModel* __restrict__ M, hb_refgen_config K, double horizon) {
@@ -1543,7 +1548,7 @@ int32_t hb_refgen_update(hb_ctx* ctx, const double* t0, double horizon, const do
     if ((rc = stage_upload(ctx, ST_CMD, r.cmd, cmd_vel, B * 4 * 8, s)) != HB_OK) return rc;
     if (x_now && (rc = stage_upload(ctx, ST_X0, ctx->b.x0, x_now, B * HB_NX * 8, s)) != HB_OK) return rc;
   }
-  hipLaunchKernelGGL(k_refgen, dim3((ctx->B + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
+  hipLaunchKernelGGL(k_refgen, dim3((4 * ctx->B + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
   if (ctx->rg_cfg.joint_ik)
     hipLaunchKernelGGL(k_refgen_ik, dim3((2 * ctx->B + 7) / 8), dim3(64), 0, s, ctx->b, r, ctx->dmodel, ctx->rg_cfg, horizon);
   hipLaunchKernelGGL(k_refgen_nodes, dim3((ctx->B * ctx->Nmax + 63) / 64), dim3(64), 0, s, ctx->b, r, ctx->rg_cfg);
@@ -2468,7 +2473,7 @@ int32_t hb_tick_resident(hb_ctx* ctx, double dt_est, const double* quat, const d
     r.knot_x += o * RG_MAX_KNOTS * HB_NX;
     r.t0 = ctx->up.t0 + o;
     r.cmd = ctx->up.cmd + o * 4;
-    hipLaunchKernelGGL(k_refgen, dim3((cnt + 63) / 64), dim3(64), 0, s, b, r, ctx->dmodel, ctx->rg_cfg, horizon);
+    hipLaunchKernelGGL(k_refgen, dim3((4 * cnt + 63) / 64), dim3(64), 0, s, b, r, ctx->dmodel, ctx->rg_cfg, horizon);
     if (ctx->rg_cfg.joint_ik)
       hipLaunchKernelGGL(k_refgen_ik, dim3((2 * cnt + 7) / 8), dim3(64), 0, s, b, r, ctx->dmodel, ctx->rg_cfg, horizon);
     hipLaunchKernelGGL(k_refgen_nodes, dim3((cnt * ctx->Nmax + 63) / 64), dim3(64), 0, s, b, r, ctx->rg_cfg);

@@ -672,9 +672,13 @@ __device__ __forceinline__ void refgen_ik_group(const DevModel& M, const RefgenC
 // [4][RG_MAX_EVENTS + 1][RG_PHASE]; `latest_stance` [4][3] persists between calls
 // (SwingTrajectoryPlanner::latestStanceposition_).  Returns 0, or 1 if a swing phase has no take-off / touch-down time
 // inside the schedule, 2 if the grid needs more than max_nodes intervals.
+// `foot0`, `foot_step`: the feet this caller plans (foot0, foot0 + foot_step, ...).  (0, 1) is the whole planner step on one thread (host
+// emulator, tests); the device gives every foot of an instance its own lane, (lane, 4): the four planner loops — the bulk of the work —
+// and the leg evaluation behind a foot's current position run side by side, the lane of foot 0 then lays out the shooting grid and the knots.
+// Returns the status of what THIS caller did (k_refgen combines the four).
 HB_HD int refgen_plan(const DevModel& M, const RefgenConfig& K, int n_ev, const double* ev, const int* modes, double t0, double horizon,
                       const double* x_now, const double* cmd_vel, double* latest_stance, double* phases, int max_nodes,
-                      int* n_nodes_out, double* t_out, int* n_knots_out, double* knot_t, double* knot_x) {
+                      int* n_nodes_out, double* t_out, int* n_knots_out, double* knot_t, double* knot_x, int foot0 = 0, int foot_step = 1) {
   const int n_ph = n_ev + 1;
   RgTarget T;
   rg_make_target(K, t0, horizon, x_now, cmd_vel, knot_x + size_t(RG_MAX_KNOTS - 2) * HB_NX, knot_x + size_t(RG_MAX_KNOTS - 1) * HB_NX, T);
@@ -687,22 +691,32 @@ HB_HD int refgen_plan(const DevModel& M, const RefgenConfig& K, int n_ev, const 
     const Mat3<double> R0 = rg_rot_zyx(x_now + 9);
     const Vec3<double> p0(x_now[6], x_now[7], x_now[8]);
     const double* qj = x_now + 12;
-    for (int leg = 0; leg < 2; ++leg) {
-      LegOut<double> L;
-      leg_eval<double>(M, leg, [qj](int j) { return qj[j]; }, [](int) { return 0.0; }, L);
-      for (int f = 0; f < 2; ++f) {
-        const int j = leg + 2 * f;
-        if (rg_contact(mode_now, j)) {
-          const Vec3<double> foot = p0 + R0 * L.foot[f];
-          latest_stance[3 * j] = foot.x;
-          latest_stance[3 * j + 1] = foot.y;
+    if (foot_step == 1) {
+      for (int leg = 0; leg < 2; ++leg) {
+        LegOut<double> L;
+        leg_eval<double>(M, leg, [qj](int j) { return qj[j]; }, [](int) { return 0.0; }, L);
+        for (int f = 0; f < 2; ++f) {
+          const int j = leg + 2 * f;
+          if (rg_contact(mode_now, j)) {
+            const Vec3<double> foot = p0 + R0 * L.foot[f];
+            latest_stance[3 * j] = foot.x;
+            latest_stance[3 * j + 1] = foot.y;
+          }
         }
+      }
+    } else {   // one foot per caller: its leg as DATA of one call (the lanes of an instance then run the same instruction stream)
+      LegOut<double> L;
+      leg_eval<double>(M, foot0 & 1, [qj](int j) { return qj[j]; }, [](int) { return 0.0; }, L);
+      if (rg_contact(mode_now, foot0)) {
+        const Vec3<double> foot = p0 + R0 * ((foot0 >> 1) ? L.foot[1] : L.foot[0]);
+        latest_stance[3 * foot0] = foot.x;
+        latest_stance[3 * foot0 + 1] = foot.y;
       }
     }
   }
   // ---- swing planner update (SwingTrajectoryPlanner::update) ----------------------------------------------------------
   int status = 0;
-  for (int j = 0; j < HB_NC; ++j) {
+  for (int j = foot0; j < HB_NC; j += foot_step) {
     double* ls = latest_stance + 3 * j;
     ls[2] = K.next_position_z;
     double last[3] = {ls[0], ls[1], ls[2]}, nxt[3] = {ls[0], ls[1], ls[2]};
@@ -761,6 +775,7 @@ HB_HD int refgen_plan(const DevModel& M, const RefgenConfig& K, int n_ev, const 
       }
     }
   }
+  if (foot0 != 0) return status;
   // ---- shooting grid with event clipping (refgen.time_discretization) ---------------------------------------------
   const double dt = K.dt, dt_min = 1e-5;
   int N = 0;

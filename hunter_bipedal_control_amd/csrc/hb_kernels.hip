@@ -972,17 +972,36 @@ __global__ __launch_bounds__(64) void k_ik_solve(int n, const DevModel* __restri
   if (gid < n && L.joint) out[size_t(p) * 5 + L.k] = qk;
 #endif
 }
-// node tables: one thread per (instance, node), consecutive lanes = consecutive nodes of one instance
+// node tables: one thread per (instance, node), consecutive lanes = consecutive nodes.  A thread's 22 + 24 values go to LDS and the
+// wavefront writes them out in memory order (the rows of 64 consecutive nodes are one contiguous block of xref and one of swing): written
+// by their own threads, every store instruction touched 64 cache lines and the kernel ran at the speed of its uncoalesced stores.
 __global__ __launch_bounds__(64) void k_refgen_nodes(Batch b, RefgenBatch r, hb_refgen_config K) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = gid / b.Nmax, k = gid - i * b.Nmax;
-  if (i >= b.B) return;
-  const size_t N = b.Nmax;
-  const size_t nd = size_t(i) * N + k;
-  refgen_node(K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.modes + size_t(i) * (HB_MAX_EVENTS + 1), r.n_knots[i],
-              r.knot_t + size_t(i) * RG_MAX_KNOTS, r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX,
-              r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, k, b.n_nodes[i], b.t[size_t(i) * (N + 1) + k], b.mode + nd,
-              b.xref + nd * HB_NX, b.swing + nd * 24);
+  constexpr int NS = HB_NC * HB_SWING_REF, LDT = HB_NX + NS + 1;   // 22 + 24 (+ 1: the rows of two lanes start in different banks)
+  static_assert(NS == 24, "swing block of a node");
+  __shared__ double stage[64 * LDT];
+  const int gid0 = blockIdx.x * blockDim.x, lane = threadIdx.x, gid = gid0 + lane;
+  const int total = b.B * b.Nmax;
+  if (gid < total) {
+    const int i = gid / b.Nmax, k = gid - i * b.Nmax;
+    const size_t N = b.Nmax;
+    refgen_node(K, r.n_ev[i], r.ev + size_t(i) * HB_MAX_EVENTS, r.modes + size_t(i) * (HB_MAX_EVENTS + 1), r.n_knots[i],
+                r.knot_t + size_t(i) * RG_MAX_KNOTS, r.knot_x + size_t(i) * RG_MAX_KNOTS * HB_NX,
+                r.phases + size_t(i) * 4 * (HB_MAX_EVENTS + 1) * RG_PHASE, k, b.n_nodes[i], b.t[size_t(i) * (N + 1) + k], b.mode + gid,
+                stage + lane * LDT, stage + lane * LDT + HB_NX);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int nn = total - gid0 < 64 ? total - gid0 : 64;   // nodes of this wavefront
+  double* xo = b.xref + size_t(gid0) * HB_NX;
+  double* so = b.swing + size_t(gid0) * NS;
+  for (int e = lane; e < nn * HB_NX; e += 64) {
+    const int nd = e / HB_NX, c = e - nd * HB_NX;
+    xo[e] = stage[nd * LDT + c];
+  }
+  for (int e = lane; e < nn * NS; e += 64) {
+    const int nd = e / NS, c = e - nd * NS;
+    so[e] = stage[nd * LDT + HB_NX + c];
+  }
 }
 
 // ---- state estimator: one wave per instance ----------------------------------------------------------------------

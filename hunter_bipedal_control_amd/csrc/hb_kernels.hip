@@ -114,18 +114,19 @@ __global__ void k_cold_start(Batch b, const DevModel* __restrict__ M, const unsi
 // interval holds its input.  One thread per (instance, node); instances whose tables did not change are left alone.
 constexpr int kWarmShiftThreads = 256;
 __global__ __launch_bounds__(kWarmShiftThreads) void k_warm_shift(Batch b, const DevModel* __restrict__ M) {
-  // one thread per (node, entry) of an instance, the 44 entries of a node (22 state, 22 input) on consecutive threads: every lane of
-  // a wavefront has work (one block per node used 44 of 64 lanes; the kernel is a chain of three dependent round trips per thread, so
-  // what it costs is wavefronts / resident wavefronts).  Instances whose tables did
+  // one thread per (node, entry index) of an instance: it moves state entry e AND input entry e of its node (the interval lookup is the
+  // same for both), consecutive threads = consecutive entries, every lane of a wavefront has work (one block per node used 44 of 64
+  // lanes; the kernel is a chain of three dependent round trips per thread, so what it costs is wavefronts / resident wavefronts).
+  // Instances whose tables did
   // not change keep their iterate (plain copy from the previous buffers: the host swapped them); the others are interpolated
   // from the previous solution on ITS time grid.  The old interval that contains the node time is found by bisection (a
   // linear scan was a chain of up to N dependent loads per block: 0.51 ms per 4096 x 100 launch, 0.06 ms of it memory traffic).
   const int flat = blockIdx.x * kWarmShiftThreads + threadIdx.x, inst = blockIdx.y;
-  const int k = flat / (HB_NX + HB_NU), lane = flat - k * (HB_NX + HB_NU);
+  static_assert(HB_NX == HB_NU, "one thread moves entry e of the state and of the input");
+  const int k = flat / HB_NX, e = flat - k * HB_NX;
   const size_t N = b.Nmax;
   if (k > int(N)) return;
-  const bool is_x = lane < HB_NX, is_u = !is_x;
-  const int e = is_x ? lane : lane - HB_NX;
+  constexpr bool is_x = true, is_u = true;
   const double* xp = b.xp + size_t(inst) * (N + 1) * HB_NX;
   const double* up = b.up + size_t(inst) * N * HB_NU;
   double* xk = b.x + (size_t(inst) * (N + 1) + k) * HB_NX;
@@ -1981,7 +1982,7 @@ static int32_t warm_start_onto_new_tables(hb_ctx* ctx) {
   std::swap(b.x, b.xp);
   std::swap(b.u, b.up);
   ++ctx->graph_epoch;  // captured chunk graphs hold the old pointers
-  hipLaunchKernelGGL(k_warm_shift, dim3(((ctx->Nmax + 1) * (HB_NX + HB_NU) + kWarmShiftThreads - 1) / kWarmShiftThreads, ctx->B), dim3(kWarmShiftThreads), 0, ctx->s_mpc, b,
+  hipLaunchKernelGGL(k_warm_shift, dim3(((ctx->Nmax + 1) * HB_NX + kWarmShiftThreads - 1) / kWarmShiftThreads, ctx->B), dim3(kWarmShiftThreads), 0, ctx->s_mpc, b,
                      ctx->dmodel);
   hipLaunchKernelGGL(k_grid_clean, dim3((ctx->B + 255) / 256), dim3(256), 0, ctx->s_mpc, b);
   HB_HIP(hipGetLastError());
@@ -2498,7 +2499,7 @@ int32_t hb_tick_resident(hb_ctx* ctx, double dt_est, const double* quat, const d
     hipLaunchKernelGGL(k_refgen_nodes, dim3((cnt * ctx->Nmax + 63) / 64), dim3(64), 0, s, b, r, ctx->rg_cfg);
     HB_HIP(hipEventRecord(ctx->ev_consumed[c], s));  // the upload buffers are free for the next tick
     // warm start onto the new tables, MPC iteration, publish, policy evaluation, WBC
-    hipLaunchKernelGGL(k_warm_shift, dim3(((ctx->Nmax + 1) * (HB_NX + HB_NU) + kWarmShiftThreads - 1) / kWarmShiftThreads, cnt), dim3(kWarmShiftThreads), 0, s, b, ctx->dmodel);
+    hipLaunchKernelGGL(k_warm_shift, dim3(((ctx->Nmax + 1) * HB_NX + kWarmShiftThreads - 1) / kWarmShiftThreads, cnt), dim3(kWarmShiftThreads), 0, s, b, ctx->dmodel);
     hipLaunchKernelGGL(k_grid_clean, dim3((cnt + 255) / 256), dim3(256), 0, s, b);
     int32_t rc = mpc_iterations(ctx, i0, cnt, s);
     if (rc != HB_OK) return rc;

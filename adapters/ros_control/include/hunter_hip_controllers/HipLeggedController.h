@@ -36,9 +36,9 @@ class HipLeggedController
   void starting(const ros::Time& time) override;
   void stopping(const ros::Time& /*time*/) override { mpcRunning_ = false; }
   int plannedMode() const { return plannedMode_; }   // mode of the policy at the last control tick (the reference publishes it on a topic)
-  // LeggedController::resetMPC (LeggedController.cpp:460-465): cold start of the solver from the current observation.  The reference
-  // declares it and never calls it; here it is also what the MPC thread does by itself after a failed SQP call would otherwise stop
-  // the controller — callable from outside (an operator service, a test)
+  // LeggedController::resetMPC (LeggedController.cpp:460-465): cold start of the solver from the current observation, taken up by the
+  // next MPC pass.  The reference declares it and never calls it; nothing here calls it either — it is for an operator service or a
+  // test.  A failed SQP call (non-finite value / Riccati pivot) stops the controller as in the reference (:413-418), it is NOT retried.
   void resetMPC();
   hb_joint_gains gains() const { std::lock_guard<std::mutex> lk(cmdMutex_); return gains_; }
 
@@ -73,6 +73,7 @@ class HipLeggedController
   hunter_hip::CmdVelFilter cmdVelFilter_;
 
   hunter_hip::SystemObservation currentObservation_;
+  hunter_hip::vector_t pendingResetTarget_;   // /reset_estimation: the nominal state the next MPC pass builds its targets on (then cleared)
   hunter_hip::vector_t measuredRbdState_;
   hunter_hip::ControlOutput control_;
   hb_joint_gains gains_{};

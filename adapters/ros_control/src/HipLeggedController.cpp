@@ -98,9 +98,16 @@ void HipLeggedController::setupMpc() {   // ≙ LeggedController::setupMpc (:376
 void HipLeggedController::mpcPass() {
   hunter_hip::SystemObservation obs;
   double cmd[4];
-  { std::lock_guard<std::mutex> lk(cmdMutex_); obs = currentObservation_; std::copy(cmdVel_, cmdVel_ + 4, cmd); }
+  vector_t targetFrom;   // state the targets of this pass are built on: the observation, or once the pending /reset_estimation target
+  {
+    std::lock_guard<std::mutex> lk(cmdMutex_);
+    obs = currentObservation_;
+    std::copy(cmdVel_, cmdVel_ + 4, cmd);
+    targetFrom = pendingResetTarget_.empty() ? obs.state : pendingResetTarget_;
+    pendingResetTarget_.clear();
+  }
   const vector_t initTime{obs.time}, cmdVel(cmd, cmd + 4);
-  referenceManager_->preSolverRun(initTime, timeHorizon_, cmdVel, &obs.state);     // modifyReferences
+  referenceManager_->preSolverRun(initTime, timeHorizon_, cmdVel, &targetFrom);    // modifyReferences (x0 of the solve stays obs.state)
   if (!coldStarted_ || resetMpcRequest_.exchange(false)) { mpcMrtInterface_->resetMpcNode(obs.state); coldStarted_ = true; }   // resetMPC(): on this thread
   mpcMrtInterface_->setCurrentObservation(obs);
   mpcMrtInterface_->advanceMpc();                                  // :406 (solve, wait, publish the FINISHED policy: this thread)
@@ -206,15 +213,15 @@ void HipLeggedController::publishObservation() {
 // taken up by the next MPC pass, which cold-starts from the observation it copies — resetMpcNode(currentObservation_)
 void HipLeggedController::resetMPC() { resetMpcRequest_ = true; }
 
-// /reset_estimation -> LeggedController::ResetTargetCallback (:496-510): the observation becomes the nominal one (zero base state,
-// default joint angles, zero input, STANCE) and with it the target the reference manager tracks — here the targets of the next MPC
-// pass are built ON that observation (hb_refgen_update's x_now), which is what setTargetTrajectories({t, x, u}) amounts to
+// /reset_estimation -> LeggedController::ResetTargetCallback (:496-510): the reference manager's target becomes the nominal state
+// (zero base state, default joint angles, zero input) — setTargetTrajectories({t, x_nominal, 0}).  Here the targets are rebuilt by every
+// MPC pass from the command and a state (hb_refgen_update's x_now), so the reset is handed to the NEXT pass as that state, once.  The
+// reference also overwrites currentObservation_ itself on the spinner thread (the next control tick restores it 2 ms later); that write
+// is not reproduced: an MPC pass that copied the observation inside that window would solve from x0 = 0 and publish the policy.
 void HipLeggedController::resetTargetCallback(const std_msgs::Float32::ConstPtr&) {
   std::lock_guard<std::mutex> lk(cmdMutex_);
-  currentObservation_.state.assign(HB_NX, 0.0);
-  currentObservation_.input.assign(HB_NU, 0.0);
-  for (int j = 0; j < HB_NJ; ++j) currentObservation_.state[12 + j] = config_.default_joint_state[j];   // defaultJointState of reference.info (:100)
-  currentObservation_.mode = 3;   // ModeNumber::STANCE
+  pendingResetTarget_.assign(HB_NX, 0.0);
+  for (int j = 0; j < HB_NJ; ++j) pendingResetTarget_[12 + j] = config_.default_joint_state[j];   // defaultJointState of reference.info (:100)
 }
 
 // dynamic_reconfigure callback (:433-447): the nine gains of the joint command law, picked up by the next control tick

@@ -53,6 +53,7 @@ class HbConfig(C.Structure):
         ("wbc_max_iter", C.c_int32), ("reserved", C.c_int32),
         ("default_joint_state", C.c_double * NJ),
         ("delta_tol", C.c_double),
+        ("wbc_reg_steps", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 
@@ -123,6 +124,7 @@ def make_config(params: dict, **overrides) -> HbConfig:
     out.wbc_max_iter = 120
     _fill(out.default_joint_state, c["default_joint_state"])
     out.delta_tol = c["delta_tol"]
+    out.wbc_reg_steps = 1     # qpOASES setToMPC(): numRegularisationSteps = 1 (WeightedWbc.cpp:47-48, HoQp.cpp:175-176)
     for k, v in overrides.items():
         if isinstance(v, (list, tuple)):
             _fill(getattr(out, k), v)

@@ -26,7 +26,7 @@ namespace hb {
 // as the pivoting picks the same columns; the tie rule is Eigen's.  T is overwritten by its LU factors.
 // One column per lane in the scans and the elimination, one free column per lane in the back substitution; plain loops over
 // cx.lane, so the host emulator and the device run THIS code.  Z (n x ldz): columns 0 .. dimker - 1 are written.  Returns dimker,
-// or -1 if it exceeds zcap (nothing is written then).  work: 80 doubles.
+// or -1 if it exceeds zcap or the pivots above the rank threshold are not the leading ones (nothing is written then).  work: 80 doubles.
 template <class Ctx>
 HB_HD int fullpivlu_kernel(const Ctx& cx, double* T, int m, int n, int ld, double* Z, int ldz, int zcap, double* work) {
   double* cb = work;                                  // [n <= 38] largest magnitude of column j in the trailing block
@@ -111,8 +111,14 @@ HB_HD int fullpivlu_kernel(const Ctx& cx, double* T, int m, int n, int ld, doubl
     cx.sync();
   }
   const double pt = maxpivot * (2.220446049250313e-16 * double(size));
-  int rk = 0;   // (pivots above the threshold are the leading ones: complete pivoting eliminates into rounding noise after them)
+  // Eigen counts EVERY pivot above the threshold (FullPivLU::rank) and kernel() keeps exactly those rows.  With complete pivoting the
+  // trailing block can grow by up to 2 x per step, so a pivot just under the threshold may be followed by one just above it; the
+  // construction below needs the kept pivots to be the leading ones, which is checked — the solve is given up (previous solution
+  // kept, like an over-full kernel) in the one-in-a-blue-moon case where they are not, instead of quietly picking other free columns.
+  int rk = 0, n_above = 0;
   while (rk < nonzero && fabs(T[rk * ld + rk]) > pt) ++rk;
+  for (int i = 0; i < nonzero; ++i) n_above += fabs(T[i * ld + i]) > pt ? 1 : 0;
+  if (n_above != rk) return -1;
   const int dimker = n - rk;
   if (dimker > zcap) return -1;
   for (int kk = cx.lane; kk < dimker; kk += cx.nlanes) {
@@ -151,7 +157,7 @@ HB_HD int fullpivlu_kernel(const Ctx& cx, double* T, int m, int n, int ld, doubl
 // variables behind them are not shifted.
 template <class Ctx>
 HB_HD int small_lsqp(const Ctx& cx, int n, int mA, const double* A, const double* b, double eps, int mD, const double* D,
-                     const double* f, int max_iter, double* x, double* ws, int n_shift = 0, double shift = 0.0) {
+                     const double* f, int max_iter, double* x, double* ws, int n_shift = 0, double shift = 0.0, int reg_steps = 0) {
   constexpr int LD = 12;
   double* J = ws;            // n x n
   double* R = ws + 144;      // n x n upper
@@ -280,7 +286,28 @@ HB_HD int small_lsqp(const Ctx& cx, int n, int mA, const double* A, const double
         if (viol[c] > 0.0 && (p < 0 || viol[c] > sp)) { p = c; sp = viol[c]; }
 #endif
     }
-    if (p < 0) return 0;
+    if (p < 0) {
+      // regularisation steps on the final working set (see wbc_solve): x_{k+1} = x_k + eps J2 J2' (x_k - x_{k-1}), x_{-1} = 0.
+      // The prox term is the solver's eps on EVERY variable; the 1e-12 shift of the z block is part of the reference's own Hessian.
+      for (int i = cx.lane; i < n; i += cx.nlanes) r[i] = x[i];
+      cx.sync();
+      for (int s = 0; s < reg_steps; ++s) {
+        for (int k = cx.lane; k < n; k += cx.nlanes) {
+          double sacc = 0.0;
+          for (int i = 0; i < n; ++i) sacc += J[i * LD + k] * r[i];
+          d[k] = k >= q ? sacc : 0.0;
+        }
+        cx.sync();
+        for (int i = cx.lane; i < n; i += cx.nlanes) {
+          double sacc = 0.0;
+          for (int j = q; j < n; ++j) sacc += J[i * LD + j] * d[j];
+          r[i] = eps * sacc;
+          x[i] += eps * sacc;
+        }
+        cx.sync();
+      }
+      return 0;
+    }
     for (int j = cx.lane; j < n; j += cx.nlanes) np[j] = D[p * LD + j];
     cx.sync();
     double lam_p = 0.0;
@@ -415,7 +442,7 @@ struct HqLds {
 // Returns 0 solved / 1 iteration limit / 2 infeasible / 3 size limit.
 template <class Ctx>
 HB_HD int hoqp_generic(const Ctx& cx, int n, int n_levels, const int* mA, const int* mD, const double* A, const double* b, const double* D,
-                       const double* f, double eps, int max_iter, double* x_levels, double* slack, double* lds) {
+                       const double* f, double eps, int max_iter, double* x_levels, double* slack, double* lds, int reg_steps = 0) {
   double* Z = lds + HqLds::Z;
   double* Zn = lds + HqLds::Zn;
   double* AZ = lds + HqLds::AZ;
@@ -498,7 +525,7 @@ HB_HD int hoqp_generic(const Ctx& cx, int n, int n_levels, const int* mA, const 
       ft[r] = s;
     }
     cx.sync();
-    const int rc = small_lsqp(cx, nvar, ma + nv, AZ, rhs, eps, n_rows, DZ, ft, max_iter, zs, qpw, ma > 0 ? nz : 0, kHoqpHessianShift);
+    const int rc = small_lsqp(cx, nvar, ma + nv, AZ, rhs, eps, n_rows, DZ, ft, max_iter, zs, qpw, ma > 0 ? nz : 0, kHoqpHessianShift, reg_steps);
     cx.sync();
     if (rc > status) status = rc;
     for (int i = cx.lane; i < n; i += cx.nlanes) {
@@ -515,6 +542,7 @@ HB_HD int hoqp_generic(const Ctx& cx, int n, int n_levels, const int* mA, const 
       for (int idx = cx.lane; idx < ma * nz; idx += cx.nlanes) Tm[idx] = AZ[(idx / nz) * 12 + idx % nz];
       cx.sync();
       const int nzn = fullpivlu_kernel(cx, Tm, ma, nz, nz, Qm, HQ_N, HQ_N, work);
+      if (nzn < 0) { status = 3; break; }
       for (int idx = cx.lane; idx < HQ_N * 12; idx += cx.nlanes) {
         const int i = idx / 12, j = idx % 12;
         double s = 0.0;
@@ -698,7 +726,9 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   // phi(p) = 1/2 |A0 p - b0|^2 + 1/2 |(D p - f)_+|^2 + eps0/2 |p|^2 is the convex piecewise quadratic that level 0 minimises.
   double* xprev = lds + L::xprev;
   constexpr int kMaxPass = 30;
+  int last_pass = 0;
   for (int it = 0; it < kMaxPass; ++it) {
+    last_pass = it;
     bool full_step = true;
     if (it == 0) {
       // First pass (no violated inequality rows yet — in normal operation the only pass): the triangular factor of
@@ -752,7 +782,25 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
           if (j == k) gj = xk;
           if (j < k) gj -= Rm[j * NW + k] * xk;
         }
-        if (j < NW) x[j] = gj;
+        // regularisation steps (see wbc_solve; no working set here: J2 = J = R^-1):  x_{k+1} = x_k + eps R^-1 R^-T (x_k - x_{k-1})
+        double xj = gj, dj = gj;
+        for (int s = 0; s < C.wbc_reg_steps; ++s) {
+#pragma unroll 1
+          for (int k = 0; k < NW; ++k) {
+            const double yk = wave_bcast_f64(dj * rinv, k);
+            if (j == k) dj = yk;
+            if (j > k && j < NW) dj -= Rm[k * NW + j] * yk;
+          }
+#pragma unroll 1
+          for (int k = NW - 1; k >= 0; --k) {
+            const double xk = wave_bcast_f64(dj * rinv, k);
+            if (j == k) dj = xk;
+            if (j < k) dj -= Rm[j * NW + k] * xk;
+          }
+          dj *= C.wbc_eps;
+          xj += dj;
+        }
+        if (j < NW) x[j] = xj;
         cx.sync();
       }
 #else
@@ -800,6 +848,20 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
             for (int jj = 0; jj < k; ++jj) g[jj] -= Rm[jj * NW + k] * xk;
           }
           for (int k = 0; k < NW; ++k) x[k] = g[k];
+          // regularisation steps: x_{k+1} = x_k + eps R^-1 R^-T (x_k - x_{k-1})
+          for (int s = 0; s < C.wbc_reg_steps; ++s) {
+            for (int k = 0; k < NW; ++k) {
+              const double yk = g[k] / Rm[k * NW + k];
+              g[k] = yk;
+              for (int jj = k + 1; jj < NW; ++jj) g[jj] -= Rm[k * NW + jj] * yk;
+            }
+            for (int k = NW - 1; k >= 0; --k) {
+              const double xk = g[k] / Rm[k * NW + k];
+              g[k] = xk;
+              for (int jj = 0; jj < k; ++jj) g[jj] -= Rm[jj * NW + k] * xk;
+            }
+            for (int k = 0; k < NW; ++k) { g[k] *= C.wbc_eps; x[k] += g[k]; }
+          }
         }
         cx.sync();
       }
@@ -971,6 +1033,37 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
     }
     if (it == kMaxPass - 1) status = HB_INST_MAXITER;
   }
+  if (last_pass > 0 && status == 0) {
+    // the point came from a pass with violated rows: its factor is J = R^-1 of [sqrt(eps0) I; A0; violated rows] in LDS.
+    // Regularisation steps as in the first pass, then the slack of the refined point.
+    for (int i = cx.lane; i < NW; i += cx.nlanes) g[i] = x[i];
+    cx.sync();
+    for (int s = 0; s < C.wbc_reg_steps; ++s) {
+      for (int k = cx.lane; k < NW; k += cx.nlanes) {
+        double sacc = 0.0;
+        for (int i = 0; i < NW; ++i) sacc += Jm[i * NW + k] * g[i];
+        z[k] = sacc;
+      }
+      cx.sync();
+      for (int i = cx.lane; i < NW; i += cx.nlanes) {
+        double sacc = 0.0;
+        for (int k = 0; k < NW; ++k) sacc += Jm[i * NW + k] * z[k];
+        g[i] = C.wbc_eps * sacc;
+        x[i] += C.wbc_eps * sacc;
+      }
+      cx.sync();
+    }
+    for (int c = cx.lane; c < wc.n_in; c += cx.nlanes) {
+      double rh;
+      int idx[3];
+      double cfv[3];
+      const int nn = sparse_row(wc, C, wc.n_eq + c, idx, cfv, &rh);
+      double s = -rh;
+      for (int t = 0; t < nn; ++t) s += cfv[t] * x[idx[t]];
+      v0[c] = s > 0.0 ? s : 0.0;
+    }
+    cx.sync();
+  }
   if (max_level <= 1) {
     for (int i = cx.lane; i < NW; i += cx.nlanes) sol[i] = x[i];
     if (cx.lane == 0) *status_out = status;
@@ -1017,7 +1110,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   }
   cx.sync();
   {
-    const int rc1 = small_lsqp(cx, n1, 6, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw, n1, kHoqpHessianShift);
+    const int rc1 = small_lsqp(cx, n1, 6, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw, n1, kHoqpHessianShift, C.wbc_reg_steps);
     cx.sync();
     if (rc1 > status) status = rc1;
   }
@@ -1034,6 +1127,10 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   for (int idx = cx.lane; idx < 144; idx += cx.nlanes) Q2[idx] = 0.0;
   cx.sync();
   const int n2 = fullpivlu_kernel(cx, Tm, 6, n1, n1, Q2, 12, 12, work);
+  if (n2 < 0) {
+    if (cx.lane == 0) *status_out = HB_INST_MAXITER;
+    return;
+  }
   for (int idx = cx.lane; idx < NW * 12; idx += cx.nlanes) {
     const int i = idx / 12, j = idx % 12;
     double s = 0.0;
@@ -1073,7 +1170,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
       if (j == 0) ft[c] = rh - dx + v0[c];
     }
     cx.sync();
-    const int rc2 = small_lsqp(cx, n2, m2, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw, n2, kHoqpHessianShift);
+    const int rc2 = small_lsqp(cx, n2, m2, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw, n2, kHoqpHessianShift, C.wbc_reg_steps);
     cx.sync();
     if (rc2 > status) status = rc2;
     for (int i = cx.lane; i < NW; i += cx.nlanes) {
@@ -1093,13 +1190,13 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
 // generic cascade: one wave per problem (unit-level entry point hb_hoqp_solve)
 __global__ __launch_bounds__(64) void k_hoqp_generic(int n, int n_levels, const int* mA, const int* mD, const double* A, const double* b,
                                                      const double* D, const double* f, double eps, int max_iter, double* x_levels,
-                                                     double* slack, int* status) {
+                                                     double* slack, int* status, int reg_steps) {
   __shared__ double lds[HqLds::total];
   const int p = blockIdx.x;
   const WbcDeviceCtx cx;
   const size_t o = size_t(p) * HQ_L;
   const int rc = hoqp_generic(cx, n, n_levels, mA, mD, A + o * HQ_M * HQ_N, b + o * HQ_M, D + o * HQ_M * HQ_N, f + o * HQ_M, eps, max_iter,
-                              x_levels + o * HQ_N, slack + o * HQ_M, lds);
+                              x_levels + o * HQ_N, slack + o * HQ_M, lds, reg_steps);
   if (cx.lane == 0) status[p] = rc;
 }
 __global__ __launch_bounds__(64) void k_hwbc(WbcBatch w, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {

@@ -2031,13 +2031,21 @@ static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t
     hipLaunchKernelGGL(k_ls_eval, dim3((B * N + 63) / 64), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, 1.0);
     hipLaunchKernelGGL(k_ls_decide, dim3(B), dim3(64), 0, s, b, ctx->dconfig, 1.0);
     if (ctx->config.alpha_decay > 0.0 && ctx->config.alpha_decay < 1.0 && ctx->config.alpha_decay >= ctx->config.alpha_min) {
-      // step sizes alpha_decay^1, ^2, ... >= alpha_min (at most LS_TAIL_MAX = 16 trials: the shipped 0.5 / 1e-4 makes 13)
-      int n_alpha = 0;
-      for (double a = ctx->config.alpha_decay; a >= ctx->config.alpha_min && n_alpha < LS_TAIL_MAX; a *= ctx->config.alpha_decay) ++n_alpha;
-      hipLaunchKernelGGL(k_ls_tail_eval, dim3((B * N + 63) / 64, n_alpha), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, ctx->config.alpha_decay,
-                         ctx->config.alpha_decay, ctx->config.alpha_min);
-      hipLaunchKernelGGL(k_ls_tail_decide, dim3(B), dim3(64), 0, s, b, ctx->dconfig, ctx->config.alpha_decay, ctx->config.alpha_decay,
-                         ctx->config.alpha_min, n_alpha);
+      // step sizes alpha_decay^1, ^2, ... >= alpha_min, in windows of LS_TAIL_MAX = 16 evaluated side by side (the shipped 0.5 / 1e-4
+      // makes 13: one window).  A slower decay (0.9 / 1e-4: 88 step sizes) walks on window after window down to alpha_min as OCS2's
+      // FilterLinesearch does; an instance that has accepted or given up makes the later windows return at once.  The window's first
+      // step size is the running product the sequential search would hold there (same rounding as the kernels' own products).
+      double a_win = ctx->config.alpha_decay;
+      while (a_win >= ctx->config.alpha_min) {
+        int n_alpha = 0;
+        double a = a_win;
+        for (; a >= ctx->config.alpha_min && n_alpha < LS_TAIL_MAX; a *= ctx->config.alpha_decay) ++n_alpha;
+        hipLaunchKernelGGL(k_ls_tail_eval, dim3((B * N + 63) / 64, n_alpha), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, a_win,
+                           ctx->config.alpha_decay, ctx->config.alpha_min);
+        hipLaunchKernelGGL(k_ls_tail_decide, dim3(B), dim3(64), 0, s, b, ctx->dconfig, a_win, ctx->config.alpha_decay,
+                           ctx->config.alpha_min, n_alpha);
+        a_win = a;
+      }
     }
     if (timed) HB_HIP(hipEventRecord(ctx->ev[4], s));
     // evaluated per iteration: ric_fail / accepted are overwritten by the next one
@@ -2710,7 +2718,7 @@ int32_t hb_hoqp_solve(hb_ctx* ctx, int32_t n_problems, int32_t n_vars, int32_t n
   if (e == hipSuccess) e = hipMemset(ds, 0, nv * 8);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_hoqp_generic, dim3(n_problems), dim3(64), 0, ctx->s_wbc, n_vars, n_levels, dma, dmd, dA, db, dD, df, ctx->hconfig.wbc_eps,
-                       4 * ctx->hconfig.wbc_max_iter, dx, ds, dst);
+                       4 * ctx->hconfig.wbc_max_iter, dx, ds, dst, ctx->hconfig.wbc_reg_steps);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->s_wbc);

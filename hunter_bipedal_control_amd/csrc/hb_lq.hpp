@@ -35,7 +35,7 @@ struct DevConfig {
   int wbc_max_iter, wbc_type;
   double default_joint_state[HB_NJ];
   int debug_stop;  // >0: lq_node returns after that phase (profiling ablation only)
-  int pad_;
+  int wbc_reg_steps;
 };
 
 // ---- node record layout in HBM (doubles) ------------------------------------------------------------

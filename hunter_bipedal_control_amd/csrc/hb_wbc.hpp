@@ -997,6 +997,41 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
     if (status != 0) break;
   }
   cx.sync();
+  // ------------------------------------------------------------------ regularisation steps (qpOASES numRegularisationSteps,
+  // setToMPC: 1 — WeightedWbc.cpp:47-48).  Step k is the proximal-point step  argmin f + eps/2 |x - x_k|^2  on the FINAL working
+  // set: with J J' = (H + eps I)^-1 and J2 = J(:, q:) spanning the null space of the active normals, optimality of x_k for the
+  // step before gives  x_{k+1} = x_k + eps J2 J2' (x_k - x_{k-1}),  x_{-1} = 0.  The residual gradient is never formed (J2 J2'
+  // would amplify its rounding noise by 1 / eps in the directions no cost row sees).  One step moves the point from first to
+  // second order in eps / lambda away from the eps -> 0 limit, the minimum-norm minimiser: two products with J.
+  if (status == 0) {
+    for (int i = cx.lane; i < NW; i += cx.nlanes) r[i] = x[i];   // x_k - x_{k-1}
+    cx.sync();
+    for (int s = 0; s < C.wbc_reg_steps; ++s) {
+      for (int k = cx.lane; k < NW; k += cx.nlanes) {
+        double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < NW; ++i) sa[i & 3] += Jm[i * NW + k] * r[i];
+        d[k] = k >= q ? (sa[0] + sa[1]) + (sa[2] + sa[3]) : 0.0;
+      }
+      cx.sync();
+      for (int i = cx.lane; i < NW; i += cx.nlanes) {
+        double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          const double jij = jrow[j];
+#else
+          const double jij = Jm[i * NW + j];
+#endif
+          sa[j & 3] += jij * d[j];
+        }
+        const double dx = C.wbc_eps * ((sa[0] + sa[1]) + (sa[2] + sa[3]));
+        r[i] = dx;
+        x[i] += dx;
+      }
+      cx.sync();
+    }
+  }
   HB_WBC_MARK(6)
 #if defined(HB_ABLATE) && defined(__HIP_DEVICE_COMPILE__)
   if (C.debug_stop == 198 && blockIdx.x == 5 && cx.lane == 0)

@@ -77,7 +77,8 @@ typedef struct hb_config {
   int32_t sqp_iterations;
   int32_t wbc_type;                /* 0 WeightedWbc (LeggedController.cpp:85), 1 HierarchicalWbc */
   double g_max, g_min;             /* filter line search thresholds */
-  double alpha_decay, alpha_min, gamma_c, armijo_factor; /* OCS2 FilterLinesearch defaults 0.5 1e-4 1e-6 1e-4 */
+  double alpha_decay, alpha_min, gamma_c, armijo_factor; /* OCS2 FilterLinesearch defaults 0.5 1e-4 1e-6 1e-4.  Any decay in (0, 1): the
+                                      backtracking step sizes decay^k >= alpha_min are evaluated 16 at a time, window after window */
   /* cost, task.info:186-253 + LeggedInterface.cpp:263-312 */
   double Q_diag[HB_NX];
   double R_task_diag[24];          /* 12 contact-force weights, 12 foot-velocity (task space) weights */
@@ -106,6 +107,11 @@ typedef struct hb_config {
   double delta_tol;                /* sqp.deltaTol, task.info:84: the line search gives up (no step, as at alpha_min) once
                                       alpha |dx| and alpha |du| — l2 norms over the whole trajectory — are both below it
                                       ([OCS2-knowledge] SqpSolver::takeStep "escape early"); 0 disables */
+  int32_t wbc_reg_steps;           /* regularisation steps after the eps-regularised WBC solve: qpOASES Options::setToMPC() leaves
+                                      numRegularisationSteps = 1 (WeightedWbc.cpp:47-48, HoQp.cpp:175-176 [qpOASES-knowledge]).  Each step is
+                                      one proximal-point step x <- argmin f(x) + eps/2 |x - x_prev|^2 on the final working set; 1 removes
+                                      the first-order-in-eps bias of the regularised minimiser.  0 = plain Tikhonov point */
+  int32_t reserved2;               /* 0 */
 } hb_config;
 
 typedef struct hb_ctx hb_ctx;

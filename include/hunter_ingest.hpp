@@ -268,6 +268,7 @@ inline void readConfig(const std::string& taskFile, const std::string& reference
   const std::vector<double> dj = ref.matrix("defaultJointState", 10, 1);
   for (int j = 0; j < HB_NJ; ++j) c.default_joint_state[j] = dj[size_t(j)];
   c.delta_tol = task.number("sqp.deltaTol");
+  c.wbc_reg_steps = 1;    // qpOASES setToMPC(): numRegularisationSteps = 1 (WeightedWbc.cpp:47-48, HoQp.cpp:175-176)
   p.timeHorizon = task.number("mpc.timeHorizon");
   p.mpcFrequency = task.number("mpc.mpcDesiredFrequency");
   p.phaseTransitionStanceTime = task.number("model_settings.phaseTransitionStanceTime");

@@ -85,7 +85,7 @@ struct HoQpLevelResult {
   int status = 0;
 };
 
-inline HoQpLevelResult hoqp_level(const Task& task, const HoQpLevelResult* prev, int n_vars, double eps, int max_iter) {
+inline HoQpLevelResult hoqp_level(const Task& task, const HoQpLevelResult* prev, int n_vars, double eps, int max_iter, int reg_steps) {
   HoQpLevelResult res;
   const int n_slack = task.D.r;
   Mat Zp = prev ? prev->Z : Mat::identity(n_vars);
@@ -130,7 +130,7 @@ inline HoQpLevelResult hoqp_level(const Task& task, const HoQpLevelResult* prev,
       fc[n_slack + nprev + i] = task.f[i] - Dx[i];
     }
   }
-  const QpResult qp = solve_lsqp(Ac, bc, eps, Mat(0, nv), Vec(), Dc, fc, max_iter);
+  const QpResult qp = solve_lsqp(Ac, bc, eps, Mat(0, nv), Vec(), Dc, fc, max_iter, reg_steps);
   res.status = qp.status;
   Vec z(qp.x.begin(), qp.x.begin() + nz), v(qp.x.begin() + nz, qp.x.end());
   res.x = xp + Zp * z;
@@ -142,10 +142,10 @@ inline HoQpLevelResult hoqp_level(const Task& task, const HoQpLevelResult* prev,
 }
 
 // HoQp(task_k, HoQp(task_{k-1}, ... HoQp(task_0)))  — tasks ordered from highest to lowest priority.
-inline HoQpLevelResult hoqp_solve(const std::vector<Task>& tasks, int n_vars, double eps, int max_iter) {
+inline HoQpLevelResult hoqp_solve(const std::vector<Task>& tasks, int n_vars, double eps, int max_iter, int reg_steps) {
   HoQpLevelResult cur;
   for (size_t l = 0; l < tasks.size(); ++l) {
-    HoQpLevelResult nxt = hoqp_level(tasks[l], l == 0 ? nullptr : &cur, n_vars, eps, max_iter);
+    HoQpLevelResult nxt = hoqp_level(tasks[l], l == 0 ? nullptr : &cur, n_vars, eps, max_iter, reg_steps);
     const int st = std::max(cur.status, nxt.status);
     cur = nxt;
     if (l > 0) cur.status = st;
@@ -161,7 +161,7 @@ inline HoQpLevelResult hierarchical_wbc(const Problem& pb, const double* x_des, 
   tasks[0] = Task::stack(Task::stack(Task::stack(ws.eom(), ws.torque_limits()), ws.friction_cone()), ws.no_contact_motion());
   tasks[1] = ws.base_accel();
   tasks[2] = Task::stack(ws.contact_force(u_des).scaled(0.1), ws.swing_leg());
-  return hoqp_solve(tasks, HB_NWBC, pb.cfg.wbc_eps_reg, 4 * pb.cfg.wbc_max_iter);
+  return hoqp_solve(tasks, HB_NWBC, pb.cfg.wbc_eps_reg, 4 * pb.cfg.wbc_max_iter, pb.cfg.wbc_reg_steps);
 }
 
 }  // namespace orc

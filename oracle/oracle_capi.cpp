@@ -359,12 +359,12 @@ int orc_wbc_problem(void* h, const double* x_des, const double* u_des, const dou
 
 // Generic LS-QP entry (property tests of the QP restatement).
 int orc_lsqp(int n, int mA, const double* A, const double* b, double eps, int mE, const double* E, const double* e,
-             int mD, const double* D, const double* f, int max_iter, double* x, int* iters) {
+             int mD, const double* D, const double* f, int max_iter, int reg_steps, double* x, int* iters) {
   Mat Am(mA, n), Em(mE, n), Dm(mD, n);
   if (mA) std::memcpy(Am.a.data(), A, 8 * size_t(mA) * n);
   if (mE) std::memcpy(Em.a.data(), E, 8 * size_t(mE) * n);
   if (mD) std::memcpy(Dm.a.data(), D, 8 * size_t(mD) * n);
-  const QpResult r = solve_lsqp(Am, Vec(b, b + mA), eps, Em, Vec(e, e + mE), Dm, Vec(f, f + mD), max_iter);
+  const QpResult r = solve_lsqp(Am, Vec(b, b + mA), eps, Em, Vec(e, e + mE), Dm, Vec(f, f + mD), max_iter, reg_steps);
   std::memcpy(x, r.x.data(), 8 * n);
   if (iters) *iters = r.iterations;
   return r.status;
@@ -374,7 +374,7 @@ int orc_lsqp(int n, int mA, const double* A, const double* b, double eps, int mE
 // Generic hierarchical QP (property tests, legged_wbc/test/HoQp_test.cpp): L levels, highest priority first;
 // level l has mA[l] equality-type rows (A,b) and mD[l] inequality rows (D,f), all with n columns, concatenated.
 int orc_hoqp(int n, int L, const int* mA, const double* A, const double* b, const int* mD, const double* D, const double* f,
-             double eps, int max_iter, double* x, double* slack, int* n_slack_out) {
+             double eps, int max_iter, int reg_steps, double* x, double* slack, int* n_slack_out) {
   std::vector<Task> tasks(L);
   size_t oa = 0, od = 0;
   for (int l = 0; l < L; ++l) {
@@ -386,7 +386,7 @@ int orc_hoqp(int n, int L, const int* mA, const double* A, const double* b, cons
     t.f.assign(f + od, f + od + mD[l]);
     oa += mA[l]; od += mD[l];
   }
-  const HoQpLevelResult r = hoqp_solve(tasks, n, eps, max_iter);
+  const HoQpLevelResult r = hoqp_solve(tasks, n, eps, max_iter, reg_steps);
   std::memcpy(x, r.x.data(), 8 * n);
   if (slack) std::memcpy(slack, r.slack.data(), 8 * r.slack.size());
   if (n_slack_out) *n_slack_out = int(r.slack.size());

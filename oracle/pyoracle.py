@@ -218,19 +218,19 @@ class Oracle:
         return dict(Aeq=r(Aeq, ne.value), beq=beq[: ne.value].copy(), D=r(Din, ni.value), f=fin[: ni.value].copy(),
                     Aw=r(Aw, nw.value), bw=bw[: nw.value].copy())
 
-    def lsqp(self, A, b, eps, E, e, D, f, max_iter=200):
+    def lsqp(self, A, b, eps, E, e, D, f, max_iter=200, reg_steps=0):
         c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         A, b, E, e, D, f = map(c, (A, b, E, e, D, f))
         n = max(A.shape[1] if A.size else 0, E.shape[1] if E.size else 0, D.shape[1] if D.size else 0)
         x = np.zeros(n)
         it = C.c_int()
         st = self.lib.orc_lsqp(C.c_int(n), C.c_int(A.shape[0]), _opt(A), _opt(b), C.c_double(eps), C.c_int(E.shape[0]),
-                               _opt(E), _opt(e), C.c_int(D.shape[0]), _opt(D), _opt(f), C.c_int(max_iter), _opt(x),
+                               _opt(E), _opt(e), C.c_int(D.shape[0]), _opt(D), _opt(f), C.c_int(max_iter), C.c_int(reg_steps), _opt(x),
                                C.byref(it))
         return x, st, it.value
 
     # ---- hierarchical QP / HierarchicalWbc ------------------------------------------------------------
-    def hoqp(self, tasks, eps=1e-8, max_iter=500):
+    def hoqp(self, tasks, eps=1e-8, max_iter=500, reg_steps=1):
         """tasks: list (highest priority first) of dicts with optional A,b (A x = b) and D,f (D x <= f)."""
         n = max(max(t["A"].shape[1] if "A" in t and t["A"].size else 0, t["D"].shape[1] if "D" in t and t["D"].size else 0) for t in tasks)
         c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
@@ -242,7 +242,7 @@ class Oracle:
         mD = np.array([t.get("D", np.zeros((0, n))).reshape(-1, n).shape[0] for t in tasks], dtype=np.int32)
         x, slack, ns = np.zeros(n), np.zeros(max(1, int(mD.sum()))), C.c_int()
         st = self.lib.orc_hoqp(C.c_int(n), C.c_int(len(tasks)), _opt(mA), _opt(A), _opt(b), _opt(mD), _opt(D), _opt(f),
-                               C.c_double(eps), C.c_int(max_iter), _opt(x), _opt(slack), C.byref(ns))
+                               C.c_double(eps), C.c_int(max_iter), C.c_int(reg_steps), _opt(x), _opt(slack), C.byref(ns))
         return x, slack[: ns.value], st
 
     def hwbc_update(self, x_des, u_des, rbd, mode, threads=1):

@@ -8,6 +8,16 @@
 // not in the reference tree).  H = A'A is rank deficient in the WBC, so qpOASES regularises it
 // (enableRegularisation, [qpOASES-knowledge]); here the Tikhonov term eps makes the minimiser unique and
 // the Cholesky factor of H + eps I is taken from a QR of [A; sqrt(eps) I], never from H itself.
+//
+// Regularisation steps (round 5).  setToMPC() leaves numRegularisationSteps = 1 [qpOASES-knowledge: after the regularised
+// solve x0, QProblemB::regularise / solveRegularisedQP re-solves with the gradient g - eps x0, i.e. one proximal-point step
+//     x1 = argmin 1/2 |A x - b|^2 + eps/2 |x - x0|^2   s.t. the constraints ].
+// Here the step is taken ON THE FINAL WORKING SET of x0 (no second active-set loop): with J J' = (H + eps I)^-1 and J2 the
+// columns of J that span the null space of the active normals, optimality of x0 reads J2'(grad f(x0) + eps x0) = 0, so
+//     x1 = x0 - J2 J2' grad f(x0) = x0 + eps J2 (J2' x0).
+// The second form is the one evaluated: it never forms the residual gradient (whose rounding noise J2 J2' would amplify by
+// 1 / eps in the directions no cost row sees).  One step takes the distance to the eps -> 0 limit (the minimum-norm minimiser on
+// the working set) from first order in eps / lambda to second order.
 #pragma once
 #include <limits>
 
@@ -23,7 +33,7 @@ struct QpResult {
 };
 
 inline QpResult solve_lsqp(const Mat& A, const Vec& b, double eps, const Mat& E, const Vec& e, const Mat& D,
-                           const Vec& f, int max_iter) {
+                           const Vec& f, int max_iter, int reg_steps) {
   const int n = A.c > 0 ? A.c : (E.c > 0 ? E.c : D.c);
   const int me = E.r, mi = D.r;
   QpResult res;
@@ -219,6 +229,19 @@ inline QpResult solve_lsqp(const Mat& A, const Vec& b, double eps, const Mat& E,
       delete_constraint(l);
       sp = dot(np, x) - rhs;
     }
+  }
+  // regularisation steps on the final working set (header comment): step k solves argmin f + eps/2 |x - x_k|^2 there, and
+  // optimality of x_k for the step before gives x_{k+1} = x_k + eps J2 J2' (x_k - x_{k-1}), x_{-1} = 0
+  Vec x_before(n, 0.0);
+  for (int s = 0; s < reg_steps; ++s) {
+    Vec w(n, 0.0);
+    for (int j = q; j < n; ++j)
+      for (int k = 0; k < n; ++k) w[j] += J(k, j) * (x[k] - x_before[k]);
+    Vec dx(n, 0.0);
+    for (int k = 0; k < n; ++k)
+      for (int j = q; j < n; ++j) dx[k] += J(k, j) * w[j];
+    x_before = x;
+    for (int k = 0; k < n; ++k) x[k] += eps * dx[k];
   }
   res.x = x;
   res.iterations = iter;

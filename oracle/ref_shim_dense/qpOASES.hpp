@@ -17,6 +17,7 @@ enum PrintLevel { PL_DEBUG_ITER = -2, PL_TABULAR, PL_NONE, PL_LOW, PL_MEDIUM, PL
 enum BooleanType { BT_FALSE = 0, BT_TRUE = 1 };
 enum returnValue { SUCCESSFUL_RETURN = 0, RET_MAX_NWSR_REACHED = 64, RET_INIT_FAILED = 33 };
 inline double& shim_eps() { static double e = 1e-8; return e; }
+inline int& shim_reg_steps() { static int n = 1; return n; }   // Options::setToMPC(): numRegularisationSteps = 1
 struct Options {
   PrintLevel printLevel = PL_NONE;
   BooleanType enableEqualities = BT_FALSE;
@@ -75,7 +76,7 @@ class QProblem {
       for (int j = 0; j < n; ++j) D(int(le.size() + r), j) = -A[size_t(ge[r]) * n + j];
       f[le.size() + r] = -lbA[ge[r]];
     }
-    const orc::QpResult res = orc::solve_lsqp(Als, bls, shim_eps(), E, e, D, f, 2000);
+    const orc::QpResult res = orc::solve_lsqp(Als, bls, shim_eps(), E, e, D, f, 2000, shim_reg_steps());
     x_ = res.x;
     solved_ = res.status == 0;
     nWSR = res.iterations;

@@ -168,5 +168,6 @@ int ref_hoqp(int n, int L, const int* mA, const double* A, const double* b, cons
 }
 
 void ref_set_qp_eps(double eps) { qpOASES::shim_eps() = eps; }
+void ref_set_qp_reg_steps(int n) { qpOASES::shim_reg_steps() = n; }
 
 }  // extern "C"

@@ -367,7 +367,7 @@ inline QpResult weighted_wbc(const Problem& pb, const double* x_des, const doubl
                        ws.contact_force(u_des).scaled(pb.cfg.weight_contact_force));
   }
   if (ws_out) *ws_out = ws;
-  return solve_lsqp(cost.A, cost.b, pb.cfg.wbc_eps_reg, cons.A, cons.b, cons.D, cons.f, pb.cfg.wbc_max_iter);
+  return solve_lsqp(cost.A, cost.b, pb.cfg.wbc_eps_reg, cons.A, cons.b, cons.D, cons.f, pb.cfg.wbc_max_iter, pb.cfg.wbc_reg_steps);
 }
 
 }  // namespace orc

@@ -197,10 +197,10 @@ void emu_log_fd(const double* x, int n, double* y) {
 extern "C" {
 // generic HoQp cascade of the device code on the host (one problem)
 int emu_hoqp_generic(int n, int n_levels, const int* mA, const int* mD, const double* A, const double* b, const double* D, const double* f,
-                     double eps, int max_iter, double* x_levels, double* slack) {
+                     double eps, int max_iter, double* x_levels, double* slack, int reg_steps) {
   HostCtx cx;
   std::vector<double> lds(HqLds::total, 0.0);
-  return hoqp_generic(cx, n, n_levels, mA, mD, A, b, D, f, eps, max_iter, x_levels, slack, lds.data());
+  return hoqp_generic(cx, n, n_levels, mA, mD, A, b, D, f, eps, max_iter, x_levels, slack, lds.data(), reg_steps);
 }
 }
 #include "../../hunter_bipedal_control_amd/csrc/hb_refgen.hpp"

@@ -146,6 +146,42 @@ def test_line_search_gives_up_on_delta_tol_like_the_oracle(params, oracle):
     assert steps0[it, inst] > 0.0 or status0[it, inst] == 1
 
 
+def test_line_search_walks_a_slow_decay_down_to_alpha_min_like_the_oracle(params, oracle):
+    """alpha_decay / alpha_min are configuration (hb_config, OCS2 FilterLinesearch): decay 0.9 with alpha_min 1e-4 makes 88 backtracking
+    step sizes, which the device evaluates 16 at a time, window after window (round 4 stopped after the first 16 and reported a failed
+    search where the sequential walk still finds a step).  deltaTol is off so that converged instances walk the whole sequence.  Device
+    and oracle accept the same step size in every iteration — including step sizes beyond the first window and searches that end at
+    alpha_min (status MAXITER on both)."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    from oracle.pyoracle import Oracle
+    B, nmax, iters = 6, 40, 14
+    over = dict(alpha_decay=0.9, alpha_min=1e-4, delta_tol=0.0)
+    refs, x0, rbd, t_now = workloads.trot_batch(params, B, n_intervals=40, cmd_vel=(0.2, 0.0, 0.0, 0.0), max_nodes=nmax)
+    o = Oracle(params, **over)
+    s = HunterSolver(params, batch=B, max_nodes=nmax, **over)
+    try:
+        s.set_references(refs)
+        s.reset(x0)
+        xo, uo = s.get_solution()
+        xo, uo = xo.copy(), uo.copy()
+        steps, status = [], []
+        for it in range(iters):
+            perf_o = o.mpc_solve(refs, x0, xo, uo, iters=1, threads=4)
+            s.mpc_solve(x0)
+            perf_g = s.get_performance()
+            assert np.array_equal(perf_g[:, 3], perf_o[:, 3]), (it, perf_g[:, 3], perf_o[:, 3])
+            steps.append(perf_g[:, 3].copy())
+            status.append(s.mpc_status().copy())
+        xg, ug = s.get_solution()
+    finally:
+        s.close()
+    steps, status = np.array(steps), np.array(status)
+    assert np.abs(xg - xo).max() < 1e-7 and np.abs(ug - uo).max() < 1e-6
+    beyond_first_window = (steps > 0.0) & (steps < 0.9 ** 16)
+    walked_to_the_end = (steps == 0.0) & (status == 1)
+    assert beyond_first_window.any() or walked_to_the_end.any(), steps
+
+
 def test_wbc_direct_matches_oracle(params, oracle):
     from hunter_bipedal_control_amd.solver import HunterSolver
     B = 64

@@ -140,7 +140,7 @@ def test_device_generic_cascade_on_host_emulator_matches_oracle(oracle):
             A[l, :2, :4], b[l, :2], D[l, :2, :4], f[l, :2] = t["A"], t["b"], t["D"], t["f"]
         mA, mD = np.array([2, 2, 0], dtype=np.int32), np.array([2, 2, 0], dtype=np.int32)
         x, slack = np.zeros((3, 8)), np.zeros((3, 8))
-        rc = lib.emu_hoqp_generic(4, 2, _p(mA), _p(mD), _p(A), _p(b), _p(D), _p(f), C.c_double(EPS), C.c_int(500), _p(x), _p(slack))
+        rc = lib.emu_hoqp_generic(4, 2, _p(mA), _p(mD), _p(A), _p(b), _p(D), _p(f), C.c_double(EPS), C.c_int(500), _p(x), _p(slack), C.c_int(1))
         assert rc == 0
         xo0, so0, st0 = oracle.hoqp(tasks[:1], eps=EPS)
         xo1, so1, st1 = oracle.hoqp(tasks, eps=EPS)

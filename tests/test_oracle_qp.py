@@ -93,3 +93,123 @@ def test_wbc_rotation_error_is_finite_when_desired_equals_measured_orientation(p
         ud[2:12:3] = mass * 9.81 / 4
         sol, st, _ = oracle.wbc_update(xd[None], ud[None], rbd[None], np.array([3], dtype=np.int32), stance_flag=np.zeros(1, dtype=np.int32))
         assert st[0] == 0 and np.isfinite(sol).all(), trial
+
+
+# ---- regularisation steps (qpOASES Options::setToMPC(): numRegularisationSteps = 1; WeightedWbc.cpp:47-48, HoQp.cpp:175-176) ----
+def _working_set(D, f, x):
+    return np.where(D @ x - f > -1e-9)[0] if len(f) else np.zeros(0, dtype=int)
+
+
+def _equality_qp(H, g, N, rhs):
+    """argmin 1/2 x'Hx - g'x  s.t. N x = rhs  by its KKT system (numpy)."""
+    n, m = H.shape[0], N.shape[0]
+    K = np.block([[H, N.T], [N, np.zeros((m, m))]])
+    return np.linalg.solve(K, np.concatenate([g, rhs]))[:n]
+
+
+def _random_qp(rng, n=9):
+    A, b = rng.standard_normal((4, n)), rng.standard_normal(4)   # rank 4 of 9: H = A'A is singular like the WBC's
+    E = rng.standard_normal((1, n))
+    x_feas = rng.standard_normal(n)
+    D = rng.standard_normal((6, n))
+    return A, b, E, E @ x_feas, D, D @ x_feas + rng.uniform(0.0, 0.3, 6)
+
+
+def test_regularisation_step_is_the_proximal_point_step_on_the_final_working_set(oracle):
+    """x1 = argmin 1/2|Ax - b|^2 + eps/2 |x - x0|^2 on the working set of x0 — recomputed here from the KKT system of that
+    equality-constrained problem; the oracle evaluates it as x0 + eps J2 J2' x0 (oracle/qp.hpp header)."""
+    rng = np.random.default_rng(5)
+    eps = 1e-4
+    for trial in range(20):
+        A, b, E, e, D, f = _random_qp(rng)
+        x0, st0, _ = oracle.lsqp(A, b, eps, E, e, D, f, reg_steps=0)
+        x1, st1, _ = oracle.lsqp(A, b, eps, E, e, D, f, reg_steps=1)
+        x2, st2, _ = oracle.lsqp(A, b, eps, E, e, D, f, reg_steps=2)
+        assert st0 == 0 and st1 == 0 and st2 == 0
+        act = _working_set(D, f, x0)
+        N, rhs = np.vstack([E, D[act]]), np.concatenate([e, f[act]])
+        H = A.T @ A + eps * np.eye(A.shape[1])
+        assert np.abs(_equality_qp(H, A.T @ b, N, rhs) - x0).max() < 1e-9            # x0: the Tikhonov point on its working set
+        assert np.abs(_equality_qp(H, A.T @ b + eps * x0, N, rhs) - x1).max() < 1e-9  # one proximal step from x0
+        assert np.abs(_equality_qp(H, A.T @ b + eps * x1, N, rhs) - x2).max() < 1e-9  # and one more from x1
+        assert np.abs(N @ x1 - rhs).max() < 1e-10                                      # the working set stays active
+
+
+def test_regularisation_step_takes_the_bias_from_first_to_second_order_in_eps(oracle):
+    """Against the eps -> 0 limit on the working set (the minimum-norm minimiser, from pseudo-inverses): without the step the
+    distance is first order in eps, with one step second order, with two third order."""
+    rng = np.random.default_rng(6)
+    used = 0
+    for trial in range(20):
+        A, b, E, e, D, f = _random_qp(rng)
+        n = A.shape[1]
+        x0, _, _ = oracle.lsqp(A, b, 1e-6, E, e, D, f, reg_steps=0)
+        act = _working_set(D, f, x0)
+        N, rhs = np.vstack([E, D[act]]), np.concatenate([e, f[act]])
+        _, sv, vt = np.linalg.svd(N)
+        Z = vt[(sv > 1e-12).sum():].T
+        xp = np.linalg.pinv(N) @ rhs
+        x = xp + Z @ (np.linalg.pinv(A @ Z) @ (b - A @ xp))
+        _, sv2, vt2 = np.linalg.svd(A @ Z)
+        K = Z @ vt2[(sv2 > 1e-10).sum():].T           # directions on the working set that no cost row sees
+        x_lim = x - K @ (np.linalg.pinv(K) @ x) if K.shape[1] else x
+        dist, same_set = {}, True
+        for eps in (1e-3, 1e-4):
+            for reg in (0, 1, 2):
+                xr, st, _ = oracle.lsqp(A, b, eps, E, e, D, f, reg_steps=reg)
+                assert st == 0
+                same_set &= np.array_equal(_working_set(D, f, xr), act)
+                dist[eps, reg] = np.abs(xr - x_lim).max()
+        if not same_set:   # the working set itself depends on eps here: no common limit to measure against
+            continue
+        used += 1
+        for reg in (0, 1):   # a tenth of eps -> 10^-(reg + 1) of the distance (two steps reach the rounding floor: value only)
+            ratio = dist[1e-4, reg] / dist[1e-3, reg]
+            assert ratio < 2.0 * 10.0 ** -(reg + 1), (reg, ratio, dist)
+        assert dist[1e-4, 1] < 1e-2 * dist[1e-4, 0] and dist[1e-4, 2] < max(1e-2 * dist[1e-4, 1], 1e-10)
+    assert used >= 8
+
+
+def test_weighted_wbc_rule_with_the_step_is_second_order_in_eps_and_where_it_is_not(params, oracle):
+    """WeightedWbc problems of the headline workload's shape (trot, single support, perturbed states; the policy stood in for by the
+    initializer's input): between eps = 1e-8 (the rule) and 1e-10 the torques move by ~3e-3 N m (median) without the step and by less
+    than 1e-5 N m with it.  The instances that still move with the step are exactly those whose reduced Hessian Z'HZ (Z: null space of
+    the working set) has an eigenvalue within a few decades of eps: the limit itself is then conditioned like lambda_max / lambda_min
+    >= 1e9."""
+    from oracle.pyoracle import Oracle
+    rng = np.random.default_rng(7)
+    x0 = np.array(params["config"]["initial_state"])
+    m = sum(params["model"]["mass"])
+    n = 96
+    xd, ud, rbd, mode = np.zeros((n, 22)), np.zeros((n, 22)), np.zeros((n, 32)), np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        mode[i] = (2, 1, 3)[i % 3]
+        cf = refgen.mode_to_contact_flags(int(mode[i]))
+        for k in range(4):
+            if cf[k]:
+                ud[i, 3 * k + 2] = m * 9.81 / sum(cf)
+        ud[i, 12:] = 0.5 * rng.standard_normal(10)
+        xd[i] = workload.perturbed_state(params, 500 + i)
+        rbd[i] = workload.rbd_from_state(workload.perturbed_state(params, 900 + i), 900 + i)
+    sols = {}
+    for eps in (1e-8, 1e-10):
+        for reg in (0, 1):
+            o = Oracle(params, wbc_eps_reg=eps, wbc_reg_steps=reg)
+            sols[eps, reg], st, _ = o.wbc_update(xd, ud, rbd, mode, stance_flag=np.zeros(n, dtype=np.int32), threads=8)
+            assert st.max() == 0
+    mv = {reg: np.abs(sols[1e-8, reg] - sols[1e-10, reg])[:, 28:].max(axis=1) for reg in (0, 1)}
+    assert np.median(mv[0]) > 1e-4                      # first order: the rule alone is visible at the 1e-5 N m tolerance
+    assert np.median(mv[1]) < 1e-5                      # second order with the step
+    assert np.median(mv[1]) < 1e-2 * np.median(mv[0])
+    lam_min = np.zeros(n)
+    for i in range(n):
+        pr = oracle.wbc_problem(xd[i], ud[i], rbd[i], int(mode[i]), False)
+        act = _working_set(pr["D"], pr["f"], sols[1e-8, 1][i])
+        N = np.vstack([pr["Aeq"], pr["D"][act]])
+        _, sv, vt = np.linalg.svd(N)
+        Z = vt[(sv > 1e-10 * sv[0]).sum():].T
+        ev = np.linalg.eigvalsh(Z.T @ (pr["Aw"].T @ pr["Aw"]) @ Z)
+        lam_min[i] = ev[ev > 1e-12 * ev[-1]].min()
+    big = mv[1] > 1e-4
+    assert (lam_min[big] < 1e-5).all(), (lam_min[big], mv[1][big])   # eps / lambda >= 1e-3 there
+    assert (mv[1][lam_min > 1e-4] < 1e-5).all()

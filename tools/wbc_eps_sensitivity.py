@@ -3,7 +3,9 @@
 problems (policy of the first SQP iteration, the rbd states of the bench) solved with eps = 1e-8 (the rule) and with smaller /
 larger eps: max and percentiles of |delta tau| (N m), |delta qdd|, |delta F|.  H = A_w'A_w has rank <= 18 of 38 (contact-force
 weight 0), so the directions the cost does not see are fixed by eps alone; qpOASES regularises them with epsRegularisation =
-5e3 * EPS ~ 1.1e-12 (its default), which is below the f64 resolution of H.  python tools/wbc_eps_sensitivity.py [--batch B]"""
+5e3 * EPS ~ 1.1e-12 (its default), which is below the f64 resolution of H — and follows the regularised solve with ONE
+regularisation step (setToMPC: numRegularisationSteps = 1), which hb_config.wbc_reg_steps reproduces on the final working set:
+every comparison is made without (reg_steps 0, rounds 1-4) and with the step.  python tools/wbc_eps_sensitivity.py [--batch B]"""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -18,37 +20,46 @@ P = ingest.load_packaged()
 B, N = args.batch, args.nodes
 sols = {}
 for eps in (1e-6, 1e-8, 1e-10, 1e-12):
-    s = HunterSolver(P, batch=B, max_nodes=N, wbc_eps_reg=eps)
-    try:
-        w = workload.device_trot_batch(s, P, n_intervals=N)
-        s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
-        s.step_resident()
-        sol, status = s.get_wbc_solution()
-        sols[eps] = (sol, status, s.get_wbc_iterations())
-    finally:
-        s.close()
-ref, st_ref, _ = sols[1e-8]
-out = {"workload": f"{B} instances x N = {N}, first update of the headline workload (bench.py)", "reference_eps": 1e-8, "vs": {}}
-for eps, (sol, st, it) in sols.items():
-    if eps == 1e-8:
-        continue
-    ok = (st == 0) & (st_ref == 0)
-    d = np.abs(sol - ref)[ok]
-    out["vs"][f"{eps:g}"] = {
-        "n_compared": int(ok.sum()), "status_histogram": [int((st == k).sum()) for k in range(4)],
-        "tau_max_Nm": float(d[:, 28:].max()), "tau_p50_Nm": float(np.percentile(d[:, 28:].max(axis=1), 50)),
-        "tau_p99_Nm": float(np.percentile(d[:, 28:].max(axis=1), 99)),
-        "qdd_max": float(d[:, :16].max()), "force_max_N": float(d[:, 16:28].max()),
-        "active_set_iterations_max": int(it.max()),
-    }
-a, b = sols[1e-10][0], sols[1e-12][0]
-dd = np.abs(a - b)
-out["1e-10_vs_1e-12"] = {"tau_max_Nm": float(dd[:, 28:].max()), "tau_p50_Nm": float(np.percentile(dd[:, 28:].max(axis=1), 50)),
-                         "tau_p99_Nm": float(np.percentile(dd[:, 28:].max(axis=1), 99))}
-# where the rule matters: instances whose answer moves by more than 0.1 N m between eps = 1e-8 and 1e-10
-big = np.abs(sols[1e-10][0] - ref)[:, 28:].max(axis=1) > 0.1
-out["instances_moving_more_than_0.1_Nm"] = int(big.sum())
-out["their_median_max_abs_qdd"] = float(np.median(np.abs(ref[big, :16]).max(axis=1))) if big.any() else None
+    for reg in (0, 1):
+        s = HunterSolver(P, batch=B, max_nodes=N, wbc_eps_reg=eps, wbc_reg_steps=reg)
+        try:
+            w = workload.device_trot_batch(s, P, n_intervals=N)
+            s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+            s.step_resident()
+            sol, status = s.get_wbc_solution()
+            sols[(eps, reg)] = (sol, status, s.get_wbc_iterations())
+        finally:
+            s.close()
+
+
+def cmp(a, b):
+    (sa, sta, ita), (sb, stb, _) = sols[a], sols[b]
+    ok = (sta == 0) & (stb == 0)
+    d = np.abs(sa - sb)[ok]
+    t = d[:, 28:].max(axis=1)
+    return {"n_compared": int(ok.sum()), "status_histogram": [int((sta == k).sum()) for k in range(4)],
+            "tau_max_Nm": float(t.max()), "tau_p50_Nm": float(np.percentile(t, 50)), "tau_p99_Nm": float(np.percentile(t, 99)),
+            "n_above_1e-5_Nm": int((t > 1e-5).sum()), "n_above_1e-3_Nm": int((t > 1e-3).sum()), "n_above_0.1_Nm": int((t > 0.1).sum()),
+            "qdd_max": float(d[:, :16].max()), "force_max_N": float(d[:, 16:28].max()), "active_set_iterations_max": int(ita.max())}
+
+
+out = {"workload": f"{B} instances x N = {N}, first update of the headline workload (bench.py)",
+       "rule": "eps = 1e-8 + ONE regularisation step on the final working set (hb_config.wbc_reg_steps = 1; qpOASES setToMPC)",
+       "torque_movement_between_eps": {}}
+for reg in (0, 1):
+    blk = {}
+    for a, b in ((1e-6, 1e-8), (1e-8, 1e-10), (1e-10, 1e-12)):
+        blk[f"{a:g}_vs_{b:g}"] = cmp((a, reg), (b, reg))
+    out["torque_movement_between_eps"][f"reg_steps_{reg}"] = blk
+out["step_itself_at_1e-8 (reg 0 vs reg 1)"] = cmp((1e-8, 0), (1e-8, 1))
+# the instances whose answer still moves by more than 1e-3 N m between eps = 1e-8 and 1e-10 WITH the step: their reduced Hessian has an
+# eigenvalue of the order of eps itself (tests/test_oracle_qp.py::test_regularisation_step_* shows it on the oracle), i.e. eps / lambda ~ 1
+ref = sols[(1e-8, 1)][0]
+mv = np.abs(sols[(1e-10, 1)][0] - ref)[:, 28:].max(axis=1)
+big = np.where(mv > 1e-3)[0]
+out["instances_moving_more_than_1e-3_Nm_with_the_step"] = [
+    {"instance": int(i), "tau_move_Nm": float(mv[i]), "max_abs_qdd": float(np.abs(ref[i, :16]).max()),
+     "active_set_iterations": int(sols[(1e-8, 1)][2][i])} for i in big[np.argsort(-mv[big])][:32]]
 out["median_max_abs_qdd_all"] = float(np.median(np.abs(ref[:, :16]).max(axis=1)))
 out["tau_scale_Nm"] = float(np.abs(ref[:, 28:]).max())
 print(json.dumps(out, indent=1))

@@ -13,13 +13,14 @@ per-instance commands (seed 4321 + id, gait per instance from walkGait).
 
     python bench.py --gpus 1 --steps 200 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W [--total-batch 4096 [--gather]]
+        bench.py --gpus N --steps K --warmup W [--weak] [--gather]
 
 Multi-GPU: independent instances are sharded across ranks, no data-path collective (RCCL only for the barrier / the
-max-over-ranks of the timing / the status histogram).  Default = weak scaling, 4096 instances per GPU.  `--total-batch T`
-= strong scaling (configs[3]: 4096 split 512/GPU over 8 GPUs); `--gather` additionally times an RCCL all-gather of the
-status words and the solution trajectories after the timed region and reports the throughput with it included.
-Prints ONE JSON line on rank 0.
+max-over-ranks of the timing / the status histogram).  Default = the north-star metric: STRONG scaling of the 4096 batch
+("a batch of 4096 hunter instances at 1/2/4/8 MI355X": 4096 split into contiguous shards, 512 per GPU at 8 —
+configs[3]'s shape); `--weak` keeps `--batch` instances on every GPU instead (4096 x N in total).  `--gather` additionally
+times an RCCL all-gather of the status words and the solution trajectories after the timed region and reports the
+throughput with it included.  Prints ONE JSON line on rank 0 (with `roofline` and `cpu_baseline` at any world size).
 """
 from __future__ import annotations
 
@@ -311,6 +312,73 @@ def backtracking_figure(params, device, B, N, first, random_cmd, steps):
         s.close()
 
 
+def share_figure(params, device, B, N, random_cmd, hierarchical, steps, warmup=4):
+    """One GPU's share of a multi-GPU configuration, driver-timed like the headline (same resident step, same instance ranges):
+    configs[3] = 512 instances x N = 100 with per-instance commands, configs[4] = 1024 x N = 200 with HierarchicalWbc."""
+    from hunter_bipedal_control_amd import workload
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    Nmax = N + (8 if random_cmd else 0)
+    s = HunterSolver(params, batch=B, max_nodes=Nmax, device=device, wbc_type=1 if hierarchical else 0)
+    try:
+        w = workload.device_trot_batch(s, params, n_intervals=N, first_inst=0, cmd_vel_random=random_cmd)
+        s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+        s.set_resident_x0_sequence(x0_sequence(w["x0"], 11))
+        n_chunks = default_chunks(B)
+        s.set_chunks(n_chunks)
+        for _ in range((12 if n_chunks > 1 else 0) + warmup):   # graph capture passes + warm-up, untimed
+            s.step_resident()
+        s.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s.step_resident()
+        s.sync()
+        el = time.perf_counter() - t0
+        perf = s.get_performance()
+        _, status = s.get_wbc_solution()
+        modes = s.get_references()["mode"][:, 0]
+        return {"updates_per_s_per_gpu": B * steps / el, "ms_per_step": 1e3 * el / steps, "steps": steps, "batch_per_gpu": B, "horizon_nodes": N,
+                "wbc": "HierarchicalWbc" if hierarchical else "WeightedWbc", "instance_ranges": n_chunks,
+                "first_interval_mode_histogram": np.bincount(modes, minlength=4).tolist(),
+                "line_search_step_histogram": {"full": int((perf[:, 3] == 1.0).sum()), "backtracked": int(((perf[:, 3] < 1.0) & (perf[:, 3] > 0.0)).sum()),
+                                               "no_step": int((perf[:, 3] == 0.0).sum())},
+                "mpc_status_histogram": np.bincount(s.mpc_status(), minlength=4).tolist(),
+                "wbc_status_histogram": np.bincount(status, minlength=4).tolist()}
+    finally:
+        s.close()
+
+
+def plan_batch(args, world, rank):
+    """-> (strong, total_instances, instances of this rank, first instance id of this rank).  Default: the north-star metric, ONE batch
+    of --batch (4096) instances split into contiguous shards over the ranks (strong scaling; 512 per GPU at 8); --weak: --batch
+    instances on every rank."""
+    from hunter_bipedal_control_amd import sharding
+    if args.weak and args.total_batch > 0:
+        raise SystemExit("bench.py: --weak and --total-batch exclude each other")
+    if not args.weak:
+        total = args.total_batch if args.total_batch > 0 else args.batch
+        if total < world:
+            raise SystemExit(f"bench.py: {total} instances cannot be split over {world} ranks")
+        lo, hi = sharding.shard_range(total, world, rank)
+        return True, total, hi - lo, lo
+    return False, args.batch * world, args.batch, rank * args.batch
+
+
+def metric_string(strong, total_instances, B, world, N):
+    return (f"MPC+WBC updates/sec (batch={total_instances}, N={N}, 12-DoF)" if strong else
+            f"MPC+WBC updates/sec (batch={B} per GPU x {world} GPUs = {total_instances}, N={N}, 12-DoF)")
+
+
+def source_fingerprint():
+    """sha256 over the kernel sources of the running tree (csrc/*.hip, *.hpp, build.sh): what a counter file must have been collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "hunter_bipedal_control_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".hpp", ".sh"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()
+
+
 def launch_ranks_if_needed(args):
     """`--gpus N` is the number of ranks of the job (one process per GPU).  Under `torch.distributed.run` (the
     driver's launch line) WORLD_SIZE must equal it; started bare with N > 1, this process replaces itself by
@@ -345,8 +413,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU (weak scaling)")
-    ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: this many instances split over the ranks")
+    ap.add_argument("--batch", type=int, default=4096, help="the batch: split over the ranks (default, strong scaling) or per GPU with --weak")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --batch instances on EVERY GPU (default: --batch split over the GPUs)")
+    ap.add_argument("--total-batch", type=int, default=0, help="strong scaling of this many instances (same as --batch T without --weak)")
     ap.add_argument("--nodes", type=int, default=100, help="shooting intervals N")
     ap.add_argument("--chunks", type=int, default=0,
                     help="instance ranges free-running on separate HIP streams, their steps replayed as hipGraphs (0 = auto: 4, the number of "
@@ -379,14 +448,7 @@ def main():
 
     params = ingest.load_packaged()
     N = args.nodes
-    strong = args.total_batch > 0
-    if strong:
-        lo, hi = sharding.shard_range(args.total_batch, world, rank)
-        B, first = hi - lo, lo
-        total_instances = args.total_batch
-    else:
-        B, first = args.batch, rank * args.batch
-        total_instances = args.batch * world
+    strong, total_instances, B, first = plan_batch(args, world, rank)
     # (per-instance commands select per-instance gaits: the event-clipped grid of some instances needs a few more than N intervals)
     Nmax = N + (8 if args.random_cmd else 0)
     # Runtime warm-up (setup, untimed): a context of the same size is created and destroyed first.  Measured on this stack
@@ -484,6 +546,16 @@ def main():
     extras = {}
     s.close()
     if rank == 0 and world == 1 and not args.no_extras:
+        for key, kw in (("with_configs3_share", dict(B=512, N=100, random_cmd=True, hierarchical=False)),
+                        ("with_configs4_share", dict(B=1024, N=200, random_cmd=False, hierarchical=True))):
+            try:
+                extras[key] = share_figure(params, local_rank, steps=10, **kw)
+                extras[key]["what"] = ("one GPU's share of BASELINE.json configs[3] (4096 over 8 GPUs = 512 per GPU, per-instance cmd_vel seed 4321 + id, gait per "
+                                       "instance from walkGait)" if kw["random_cmd"] else
+                                       "one GPU's share of BASELINE.json configs[4] (8192 over 8 GPUs = 1024 per GPU, N = 200, swing constraints active, "
+                                       "HierarchicalWbc 3-priority cascade)") + "; 1 SQP iteration + WBC per update, inputs resident, measurement noise on x0 as in the headline"
+            except Exception as e:  # noqa: BLE001
+                extras[key] = {"error": repr(e)}
         try:
             extras["with_refgen_and_estimator"] = full_tick_figure(params, local_rank, B, N, first, args.random_cmd,
                                                                    steps=max(10, min(50, args.steps // 4)))
@@ -509,13 +581,18 @@ def main():
         achieved = alg_bytes / (phases[dom] * 1e-3) / 1e9
         traffic, traffic_source = None, None
         pmc = ROOT / "profiles" / "pmc_latest.json"
-        if pmc.exists() and B == 4096 and N == 100:
+        if pmc.exists() and B == 4096 and N == 100 and not args.random_cmd and not args.hierarchical:
             try:
                 pj = json.loads(pmc.read_text())
-                traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
-                traffic_source = ("profiles/pmc_latest.json" + (f" ({pj['tag']})" if "tag" in pj else "") +
-                                  ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload, collected in a separate run "
-                                  "(counters cannot be read inside the timed process), NOT measured in this run")
+                stamp = f"tag {pj.get('tag')}, commit {pj.get('git_head')}, kernel sources sha256 {str(pj.get('source_sha256'))[:12]}"
+                if pj.get("source_sha256") == source_fingerprint():
+                    traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+                    traffic_source = (f"profiles/pmc_latest.json ({stamp} = the running tree's kernel sources): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      "passes over this workload, collected in a separate run (counters cannot be read inside the timed process), "
+                                      "NOT measured in this run")
+                else:   # a counter file collected on other kernel sources says nothing about this run
+                    traffic_source = (f"profiles/pmc_latest.json ({stamp}) was collected on DIFFERENT kernel sources than the running tree "
+                                      f"(sha256 {source_fingerprint()[:12]}): traffic dropped")
             except Exception:
                 traffic = None
         per_kernel = {k: {"ms": phases[k], "algorithmic_GBs": BYTES_PER_NODE[k] * int(n_nodes.sum()) / (phases[k] * 1e-3) / 1e9,
@@ -523,7 +600,7 @@ def main():
                       for k in ("k_lq", "k_ric_bwd", "k_ric_fwd")}
         # what each kernel REALLY moves (FETCH_SIZE / WRITE_SIZE counter passes, same source and caveat as roofline.traffic) over
         # this run's launch time: k_ric_fwd is the kernel that is HBM bound, on 2 x the bytes the 8d formula grants it
-        if traffic_source is not None:
+        if traffic is not None:
             for k, v in per_kernel.items():
                 cb = pj.get(k, {}).get("hbm_bytes_per_launch")
                 if cb:
@@ -532,8 +609,8 @@ def main():
                     v["counter_frac_of_hbm_peak"] = v["counter_GBs"] / HBM_PEAK_GBS
                     v["counter_over_algorithmic"] = cb / (BYTES_PER_NODE[k] * int(n_nodes.sum()))
         out = {
-            "metric": "MPC+WBC updates/sec (batch=4096, N=100, 12-DoF)",
-            "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric_string(strong, total_instances, B, world, N),
+            "value": value, "value_per_gpu": value / world, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{total_instances} distinct hunter instances ({B}/GPU, state seed 1234 + id), "
@@ -545,7 +622,7 @@ def main():
                                      "x0 of every call perturbed by measurement noise (sigma 0.01) so that no call re-solves a converged problem: "
                                      "every line search accepts the full step, NO backtracking inside the timed region "
                                      "(the backtracking case is the separate figure with_backtracking_line_search), "
-                                     "inputs resident in HBM (BASELINE.json configs[" + ("4" if args.hierarchical else "3" if args.random_cmd or strong else "2") + "])",
+                                     "inputs resident in HBM (BASELINE.json configs[" + ("4" if args.hierarchical else "3" if args.random_cmd or world > 1 else "2") + "])",
                        "batch_per_gpu": B, "total_instances": total_instances, "horizon_nodes": N, "setup_s": t_setup,
                        "parallelism": (f"strong scaling: {total_instances} instances split over {world} rank(s)" if strong else
                                        f"weak scaling: {B} instances per rank x {world}") +
@@ -573,12 +650,14 @@ def main():
         if gather:
             out["gather"] = gather
         out.update(extras)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(params, N)
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the CPU leg runs on rank 0's host cores AFTER the final barrier (the other ranks are gone: nothing of it overlaps the timed region)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params, N)
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -257,8 +257,10 @@ HB_HD int small_lsqp(const Ctx& cx, int n, int mA, const double* A, const double
   for (int idx = cx.lane; idx < n * LD; idx += cx.nlanes) R[idx] = 0.0;
   for (int c = cx.lane; c < mD; c += cx.nlanes) is_act[c] = 0;
   cx.sync();
-  int q = 0, iter = 0;
+  int q = 0, iter = 0, phase = 0;
   const double inf = 1e300;
+  for (int i = cx.lane; i < n; i += cx.nlanes) g[i] = 0.0;   // prox centre x_{-1} = 0 (g has done its duty as A'b)
+  cx.sync();
   while (true) {
     // most violated inactive constraint, one constraint per lane
     int p = -1;
@@ -287,26 +289,34 @@ HB_HD int small_lsqp(const Ctx& cx, int n, int mA, const double* A, const double
 #endif
     }
     if (p < 0) {
-      // regularisation steps on the final working set (see wbc_solve): x_{k+1} = x_k + eps J2 J2' (x_k - x_{k-1}), x_{-1} = 0.
+      // optimal for this phase.  Next phase = one regularisation step (see wbc_solve): the proximal problem around the point just found,
+      // x <- x + eps J2 J2'(x - x_before), lam <- lam + eps R^-1 J1'(x - x_before) on the current working set, then the same loop goes on.
       // The prox term is the solver's eps on EVERY variable; the 1e-12 shift of the z block is part of the reference's own Hessian.
-      for (int i = cx.lane; i < n; i += cx.nlanes) r[i] = x[i];
+      if (phase >= reg_steps) return 0;
+      ++phase;
+      for (int i = cx.lane; i < n; i += cx.nlanes) { np[i] = x[i] - g[i]; g[i] = x[i]; }   // (g: prox centre of the step before)
       cx.sync();
-      for (int s = 0; s < reg_steps; ++s) {
-        for (int k = cx.lane; k < n; k += cx.nlanes) {
-          double sacc = 0.0;
-          for (int i = 0; i < n; ++i) sacc += J[i * LD + k] * r[i];
-          d[k] = k >= q ? sacc : 0.0;
-        }
-        cx.sync();
-        for (int i = cx.lane; i < n; i += cx.nlanes) {
-          double sacc = 0.0;
-          for (int j = q; j < n; ++j) sacc += J[i * LD + j] * d[j];
-          r[i] = eps * sacc;
-          x[i] += eps * sacc;
-        }
-        cx.sync();
+      for (int k = cx.lane; k < n; k += cx.nlanes) {
+        double sacc = 0.0;
+        for (int i = 0; i < n; ++i) sacc += J[i * LD + k] * np[i];
+        d[k] = sacc;
       }
-      return 0;
+      cx.sync();
+      for (int i = cx.lane; i < n; i += cx.nlanes) {
+        double sacc = 0.0;
+        for (int j = q; j < n; ++j) sacc += J[i * LD + j] * d[j];
+        x[i] += eps * sacc;
+      }
+      if (cx.lane == 0)
+        for (int i = q - 1; i >= 0; --i) {
+          double sacc = d[i];
+          for (int k = i + 1; k < q; ++k) sacc -= R[i * LD + k] * r[k];
+          r[i] = sacc * rcp_t(R[i * LD + i]);
+        }
+      cx.sync();
+      for (int j = cx.lane; j < q; j += cx.nlanes) lam[j] = fmax(0.0, lam[j] + eps * r[j]);
+      cx.sync();
+      continue;
     }
     for (int j = cx.lane; j < n; j += cx.nlanes) np[j] = D[p * LD + j];
     cx.sync();
@@ -521,6 +531,11 @@ HB_HD int hoqp_generic(const Ctx& cx, int n, int n_levels, const int* mA, const 
         const double* Dj = D + size_t(lv) * HQ_M * HQ_N;
         s = f[lv * HQ_M + rr] + v[lv * HQ_M + rr];
         for (int c = 0; c < n; ++c) s -= Dj[rr * HQ_N + c] * x[c];
+        // x satisfies the earlier levels' rows with their slack BY CONSTRUCTION (it is their accepted solution), i.e. to the relative
+        // tolerance of the QP that produced it (1e-9 max(1, |f|)).  Handed down unclamped, that residue — now measured against a
+        // right-hand side of ~0, where the same tolerance is absolute — turns into "row violated and nothing in the null space can
+        // move it": an infeasible level.  z = 0 is feasible, so the frozen right-hand side is never negative.
+        s = fmax(0.0, s);
       }
       ft[r] = s;
     }
@@ -595,7 +610,8 @@ struct HoLds {
   static constexpr int ints = work + 80;          // 64 ints: violated flags (40), misc
   static constexpr int xprev = ints + 32;         // 38: previous level-0 point (line search of the later passes)
   static constexpr int ls = xprev + NW;           // 2 x 40: per-row offsets / slopes of the exact line search
-  static constexpr int total = ls + 80;
+  static constexpr int xc = ls + 80;              // 38: prox centre of the current regularisation step (level 0)
+  static constexpr int total = xc + NW;
 };
 struct HoLdsDev {
   // persistent
@@ -614,7 +630,8 @@ struct HoLdsDev {
   static constexpr int ints = work + 80;          // 64 ints
   static constexpr int xprev = ints + 32;         // 38: previous level-0 point (line search of the later passes)
   static constexpr int ls = xprev + NW;           // 2 x 40: per-row offsets / slopes of the exact line search
-  static constexpr int shared = ls + 80;
+  static constexpr int xc = ls + 80;              // 38: prox centre of the current regularisation step (level 0)
+  static constexpr int shared = xc + NW;
   // level 0 (and phase A's workspace)
   static constexpr int J = shared;                // 38x38
   static constexpr int R = J + NW * NW;           // 38x38
@@ -724,13 +741,28 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
   const double eps0 = C.wbc_eps + kHoqpHessianShift;
   const double se = sqrt(eps0);
   // phi(p) = 1/2 |A0 p - b0|^2 + 1/2 |(D p - f)_+|^2 + eps0/2 |p|^2 is the convex piecewise quadratic that level 0 minimises.
+  // Phase 0 minimises phi; every further phase is one REGULARISATION STEP (see wbc_solve): the proximal problem around the point x_k
+  // just found, phi(p) - eps x_k'p (up to a constant: the solver's eps/2 |p|^2 recentred on x_k), minimised by the same passes.
+  // While no inequality row is violated the factor R of [sqrt(eps0) I; A0] of the first pass serves every phase:
+  // x_{k+1} = x_k + eps R^-1 R^-T (x_k - x_{k-1}), x_{-1} = 0 — two more substitutions; the residual gradient is never formed.
   double* xprev = lds + L::xprev;
+  double* xc = lds + L::xc;
+  for (int i = cx.lane; i < NW; i += cx.nlanes) xc[i] = 0.0;
+  cx.sync();
   constexpr int kMaxPass = 30;
-  int last_pass = 0;
+  bool fast_ok = false;   // Rm holds the factor of [sqrt(eps0) I; A0] and no inequality row is violated
+#if defined(__HIP_DEVICE_COMPILE__)
+  double rinv = 0.0;      // 1 / R_jj of that factor (lane j)
+#endif
+  for (int phase = 0; phase <= C.wbc_reg_steps && status == 0; ++phase) {
+  if (phase > 0) {
+    for (int i = cx.lane; i < NW; i += cx.nlanes) { np[i] = x[i] - xc[i]; xc[i] = x[i]; }   // x_k - x_{k-1}; the new centre
+    cx.sync();
+  }
   for (int it = 0; it < kMaxPass; ++it) {
-    last_pass = it;
     bool full_step = true;
-    if (it == 0) {
+    if (it == 0 && phase == 0) {
+      fast_ok = true;
       // First pass (no violated inequality rows yet — in normal operation the only pass): the triangular factor of
       // [sqrt(eps) I ; A0] by 38 structured Householder reflectors instead of 28 x 38 Givens rotations.  Reflector k has
       // its support on row k of the identity block and on the 28 rows of A0, so row k of the factor is final after step k
@@ -747,7 +779,6 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
           acol[r] = j < NW ? a0_row(r, j) : 0.0;
           gj += acol[r] * a0_rhs(r);
         }
-        double rinv = 0.0;  // 1 / R_jj once step j is done
 #pragma unroll 1
         for (int k = 0; k < NW; ++k) {
           double dot = 0.0;
@@ -782,25 +813,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
           if (j == k) gj = xk;
           if (j < k) gj -= Rm[j * NW + k] * xk;
         }
-        // regularisation steps (see wbc_solve; no working set here: J2 = J = R^-1):  x_{k+1} = x_k + eps R^-1 R^-T (x_k - x_{k-1})
-        double xj = gj, dj = gj;
-        for (int s = 0; s < C.wbc_reg_steps; ++s) {
-#pragma unroll 1
-          for (int k = 0; k < NW; ++k) {
-            const double yk = wave_bcast_f64(dj * rinv, k);
-            if (j == k) dj = yk;
-            if (j > k && j < NW) dj -= Rm[k * NW + j] * yk;
-          }
-#pragma unroll 1
-          for (int k = NW - 1; k >= 0; --k) {
-            const double xk = wave_bcast_f64(dj * rinv, k);
-            if (j == k) dj = xk;
-            if (j < k) dj -= Rm[j * NW + k] * xk;
-          }
-          dj *= C.wbc_eps;
-          xj += dj;
-        }
-        if (j < NW) x[j] = xj;
+        if (j < NW) x[j] = gj;
         cx.sync();
       }
 #else
@@ -848,28 +861,52 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
             for (int jj = 0; jj < k; ++jj) g[jj] -= Rm[jj * NW + k] * xk;
           }
           for (int k = 0; k < NW; ++k) x[k] = g[k];
-          // regularisation steps: x_{k+1} = x_k + eps R^-1 R^-T (x_k - x_{k-1})
-          for (int s = 0; s < C.wbc_reg_steps; ++s) {
-            for (int k = 0; k < NW; ++k) {
-              const double yk = g[k] / Rm[k * NW + k];
-              g[k] = yk;
-              for (int jj = k + 1; jj < NW; ++jj) g[jj] -= Rm[k * NW + jj] * yk;
-            }
-            for (int k = NW - 1; k >= 0; --k) {
-              const double xk = g[k] / Rm[k * NW + k];
-              g[k] = xk;
-              for (int jj = 0; jj < k; ++jj) g[jj] -= Rm[jj * NW + k] * xk;
-            }
-            for (int k = 0; k < NW; ++k) { g[k] *= C.wbc_eps; x[k] += g[k]; }
-          }
         }
         cx.sync();
       }
 #endif
+    } else if (it == 0 && fast_ok) {
+      // regularisation step on the first pass's factor (no violated row so far): x += eps R^-1 R^-T (x_k - x_{k-1}), the difference in np
+#if defined(__HIP_DEVICE_COMPILE__)
+      {
+        const int j = cx.lane;
+        double dj = j < NW ? np[j] : 0.0;
+#pragma unroll 1
+        for (int k = 0; k < NW; ++k) {
+          const double yk = wave_bcast_f64(dj * rinv, k);
+          if (j == k) dj = yk;
+          if (j > k && j < NW) dj -= Rm[k * NW + j] * yk;
+        }
+#pragma unroll 1
+        for (int k = NW - 1; k >= 0; --k) {
+          const double xk = wave_bcast_f64(dj * rinv, k);
+          if (j == k) dj = xk;
+          if (j < k) dj -= Rm[j * NW + k] * xk;
+        }
+        if (j < NW) x[j] += C.wbc_eps * dj;
+        cx.sync();
+      }
+#else
+      for (int l0 = cx.lane; l0 < 1; l0 += cx.nlanes) {
+        for (int k = 0; k < NW; ++k) {
+          const double yk = np[k] / Rm[k * NW + k];
+          np[k] = yk;
+          for (int jj = k + 1; jj < NW; ++jj) np[jj] -= Rm[k * NW + jj] * yk;
+        }
+        for (int k = NW - 1; k >= 0; --k) {
+          const double xk = np[k] / Rm[k * NW + k];
+          np[k] = xk;
+          for (int jj = 0; jj < k; ++jj) np[jj] -= Rm[jj * NW + k] * xk;
+        }
+        for (int k = 0; k < NW; ++k) x[k] += C.wbc_eps * np[k];
+      }
+      cx.sync();
+#endif
     } else {
+    fast_ok = false;
     for (int i = cx.lane; i < NW; i += cx.nlanes) xprev[i] = x[i];
     for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Rm[idx] = (idx / NW == idx % NW) ? se : 0.0;
-    for (int i = cx.lane; i < NW; i += cx.nlanes) g[i] = 0.0;
+    for (int i = cx.lane; i < NW; i += cx.nlanes) g[i] = C.wbc_eps * xc[i];   // the proximal term's share of the gradient (0 in phase 0)
     cx.sync();
     const int n_rows = mA0 + wc.n_in;
     for (int rw = 0; rw < n_rows; ++rw) {
@@ -940,7 +977,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
           p2 += ad * ad;
         } else {
           const int i = rw - mA0;
-          p1 += eps0 * xprev[i] * z[i];
+          p1 += (eps0 * xprev[i] - C.wbc_eps * xc[i]) * z[i];
           p2 += eps0 * z[i] * z[i];
         }
       }
@@ -1033,37 +1070,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
     }
     if (it == kMaxPass - 1) status = HB_INST_MAXITER;
   }
-  if (last_pass > 0 && status == 0) {
-    // the point came from a pass with violated rows: its factor is J = R^-1 of [sqrt(eps0) I; A0; violated rows] in LDS.
-    // Regularisation steps as in the first pass, then the slack of the refined point.
-    for (int i = cx.lane; i < NW; i += cx.nlanes) g[i] = x[i];
-    cx.sync();
-    for (int s = 0; s < C.wbc_reg_steps; ++s) {
-      for (int k = cx.lane; k < NW; k += cx.nlanes) {
-        double sacc = 0.0;
-        for (int i = 0; i < NW; ++i) sacc += Jm[i * NW + k] * g[i];
-        z[k] = sacc;
-      }
-      cx.sync();
-      for (int i = cx.lane; i < NW; i += cx.nlanes) {
-        double sacc = 0.0;
-        for (int k = 0; k < NW; ++k) sacc += Jm[i * NW + k] * z[k];
-        g[i] = C.wbc_eps * sacc;
-        x[i] += C.wbc_eps * sacc;
-      }
-      cx.sync();
-    }
-    for (int c = cx.lane; c < wc.n_in; c += cx.nlanes) {
-      double rh;
-      int idx[3];
-      double cfv[3];
-      const int nn = sparse_row(wc, C, wc.n_eq + c, idx, cfv, &rh);
-      double s = -rh;
-      for (int t = 0; t < nn; ++t) s += cfv[t] * x[idx[t]];
-      v0[c] = s > 0.0 ? s : 0.0;
-    }
-    cx.sync();
-  }
+  }  // phase
   if (max_level <= 1) {
     for (int i = cx.lane; i < NW; i += cx.nlanes) sol[i] = x[i];
     if (cx.lane == 0) *status_out = status;
@@ -1106,7 +1113,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
     double s = 0.0, dx = 0.0;
     for (int t = 0; t < nn; ++t) { s += cfv[t] * Z1[ix[t] * 12 + j]; dx += cfv[t] * x[ix[t]]; }
     DZ[idx] = s;
-    if (j == 0) ft[c] = rh - dx + v0[c];
+    if (j == 0) ft[c] = fmax(0.0, rh - dx + v0[c]);   // (z = 0 is feasible by construction: see hoqp_generic)
   }
   cx.sync();
   {
@@ -1167,7 +1174,7 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
       double s = 0.0, dx = 0.0;
       for (int t = 0; t < nn; ++t) { s += cfv[t] * Z2[ix[t] * 12 + j]; dx += cfv[t] * x[ix[t]]; }
       DZ[idx] = s;
-      if (j == 0) ft[c] = rh - dx + v0[c];
+      if (j == 0) ft[c] = fmax(0.0, rh - dx + v0[c]);   // (z = 0 is feasible by construction: see hoqp_generic)
     }
     cx.sync();
     const int rc2 = small_lsqp(cx, n2, m2, AZ, rhs, C.wbc_eps, wc.n_in, DZ, ft, 4 * C.wbc_max_iter, zs, qpw, n2, kHoqpHessianShift, C.wbc_reg_steps);

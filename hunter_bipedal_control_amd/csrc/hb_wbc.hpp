@@ -298,7 +298,8 @@ struct WbcLds {
   static constexpr int red = lam + NW;           // 64 reduction scratch
   static constexpr int misc = red + 64;          // 16 scalars
   static constexpr int iact = misc + 16;         // 38 ints (active ids) + 64 ints (is_active) -> 51 doubles
-  static constexpr int total = iact + 52;
+  static constexpr int xb = iact + 52;           // 38 prox centre of the regularisation step before (x_{-1} = 0)
+  static constexpr int total = xb + NW;
 };
 
 // constraint ids: [0,16) EoM rows, [16,16+3 nsw) zero force on swing feet, then inequalities:
@@ -546,6 +547,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   double* misc = lds + WbcLds::misc;
   int* act = reinterpret_cast<int*>(lds + WbcLds::iact);
   int* is_active = act + 40;
+  double* xb = lds + WbcLds::xb;
 
   bool cf[HB_NC];
   mode_flags(mode, cf);
@@ -834,6 +836,51 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   const int next_eq_active = q;  // equalities in the active set (never dropped)
   const int n_cons = wc.n_eq + wc.n_in;
   const double inf = 1e300;
+  // Phase 0 is the eps-regularised problem; every further phase is one REGULARISATION STEP (qpOASES numRegularisationSteps, setToMPC: 1 —
+  // WeightedWbc.cpp:47-48): the proximal-point problem  argmin f + eps/2 |x - x_k|^2  with the same constraints.  With J J' = (H + eps I)^-1,
+  // J'N = [R; 0] and J2 = J(:, q:), its solution on the current working set is  x_{k+1} = x_k + eps J2 J2'(x_k - x_{k-1}),  x_{-1} = 0,  with
+  // multipliers  lam + eps R^-1 J1'(x_k - x_{k-1})  — and that pair is what the dual method iterates on, so the same loop goes on from it
+  // (normally one scan that finds nothing violated).  The residual gradient is never formed (J2 J2' would amplify its rounding noise by
+  // 1 / eps in the directions no cost row sees).  One step moves the point from first to second order in eps / lambda away from the
+  // eps -> 0 limit, the minimum-norm minimiser.
+  for (int i = cx.lane; i < NW; i += cx.nlanes) xb[i] = 0.0;
+  cx.sync();
+  for (int phase = 0; phase <= C.wbc_reg_steps && status == 0; ++phase) {
+  if (phase > 0) {
+    for (int i = cx.lane; i < NW; i += cx.nlanes) { np[i] = x[i] - xb[i]; xb[i] = x[i]; }
+    cx.sync();
+    for (int k = cx.lane; k < NW; k += cx.nlanes) {   // d = J'(x_k - x_{k-1})
+      double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < NW; ++i) sa[i & 3] += Jm[i * NW + k] * np[i];
+      d[k] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    }
+    cx.sync();
+    for (int i = cx.lane; i < NW; i += cx.nlanes) {   // x += eps J2 d2
+      double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double jij = jrow[j];
+#else
+        const double jij = Jm[i * NW + j];
+#endif
+        sa[j & 3] += jij * (j >= q ? d[j] : 0.0);
+      }
+      x[i] += C.wbc_eps * ((sa[0] + sa[1]) + (sa[2] + sa[3]));
+      if (i < q) r[i] = d[i];
+    }
+    cx.sync();
+    // multipliers of the active INEQUALITIES (positions next_eq_active .. q - 1): R is upper triangular, so the back substitution of
+    // R dl = d1 from the bottom reaches them first and stops there
+    for (int i = q - 1; i >= next_eq_active; --i) {
+      const double ri = r[i] / Rm[i * NW + i];
+      cx.sync();
+      for (int k = next_eq_active + cx.lane; k < i; k += cx.nlanes) r[k] -= Rm[k * NW + i] * ri;
+      if (cx.lane == 0) lam[i] = fmax(0.0, lam[i] + C.wbc_eps * ri);   // (a multiplier that sat at zero: the row stays, at multiplier zero)
+      cx.sync();
+    }
+  }
   while (status == 0) {
     int p = -1;
     double sp = 0.0;
@@ -996,42 +1043,8 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
     }
     if (status != 0) break;
   }
+  }  // phase
   cx.sync();
-  // ------------------------------------------------------------------ regularisation steps (qpOASES numRegularisationSteps,
-  // setToMPC: 1 — WeightedWbc.cpp:47-48).  Step k is the proximal-point step  argmin f + eps/2 |x - x_k|^2  on the FINAL working
-  // set: with J J' = (H + eps I)^-1 and J2 = J(:, q:) spanning the null space of the active normals, optimality of x_k for the
-  // step before gives  x_{k+1} = x_k + eps J2 J2' (x_k - x_{k-1}),  x_{-1} = 0.  The residual gradient is never formed (J2 J2'
-  // would amplify its rounding noise by 1 / eps in the directions no cost row sees).  One step moves the point from first to
-  // second order in eps / lambda away from the eps -> 0 limit, the minimum-norm minimiser: two products with J.
-  if (status == 0) {
-    for (int i = cx.lane; i < NW; i += cx.nlanes) r[i] = x[i];   // x_k - x_{k-1}
-    cx.sync();
-    for (int s = 0; s < C.wbc_reg_steps; ++s) {
-      for (int k = cx.lane; k < NW; k += cx.nlanes) {
-        double sa[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int i = 0; i < NW; ++i) sa[i & 3] += Jm[i * NW + k] * r[i];
-        d[k] = k >= q ? (sa[0] + sa[1]) + (sa[2] + sa[3]) : 0.0;
-      }
-      cx.sync();
-      for (int i = cx.lane; i < NW; i += cx.nlanes) {
-        double sa[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__)
-          const double jij = jrow[j];
-#else
-          const double jij = Jm[i * NW + j];
-#endif
-          sa[j & 3] += jij * d[j];
-        }
-        const double dx = C.wbc_eps * ((sa[0] + sa[1]) + (sa[2] + sa[3]));
-        r[i] = dx;
-        x[i] += dx;
-      }
-      cx.sync();
-    }
-  }
   HB_WBC_MARK(6)
 #if defined(HB_ABLATE) && defined(__HIP_DEVICE_COMPILE__)
   if (C.debug_stop == 198 && blockIdx.x == 5 && cx.lane == 0)

@@ -118,7 +118,10 @@ inline HoQpLevelResult hoqp_level(const Task& task, const HoQpLevelResult* prev,
     const Vec Dpx = tprev.D * xp;
     for (int i = 0; i < nprev; ++i) {
       for (int j = 0; j < nz; ++j) Dc(n_slack + i, j) = DpZ(i, j);
-      fc[n_slack + i] = tprev.f[i] - Dpx[i] + vprev[i];
+      // xp satisfies the earlier rows with their slack by construction — to the relative tolerance of the QP that produced it.  Handed
+      // down unclamped that residue faces a right-hand side of ~0, where the same tolerance is absolute, and a row no null-space
+      // direction can move turns the level infeasible.  z = 0 is feasible: the frozen right-hand side is never negative.
+      fc[n_slack + i] = std::max(0.0, tprev.f[i] - Dpx[i] + vprev[i]);
     }
   }
   if (n_slack > 0) {

@@ -10,14 +10,19 @@
 // the Cholesky factor of H + eps I is taken from a QR of [A; sqrt(eps) I], never from H itself.
 //
 // Regularisation steps (round 5).  setToMPC() leaves numRegularisationSteps = 1 [qpOASES-knowledge: after the regularised
-// solve x0, QProblemB::regularise / solveRegularisedQP re-solves with the gradient g - eps x0, i.e. one proximal-point step
+// solve x0, QProblemB::regularise / solveRegularisedQP re-solves — hot-started from the solution — with the gradient g - eps x0,
+// i.e. one proximal-point step
 //     x1 = argmin 1/2 |A x - b|^2 + eps/2 |x - x0|^2   s.t. the constraints ].
-// Here the step is taken ON THE FINAL WORKING SET of x0 (no second active-set loop): with J J' = (H + eps I)^-1 and J2 the
-// columns of J that span the null space of the active normals, optimality of x0 reads J2'(grad f(x0) + eps x0) = 0, so
-//     x1 = x0 - J2 J2' grad f(x0) = x0 + eps J2 (J2' x0).
-// The second form is the one evaluated: it never forms the residual gradient (whose rounding noise J2 J2' would amplify by
-// 1 / eps in the directions no cost row sees).  One step takes the distance to the eps -> 0 limit (the minimum-norm minimiser on
-// the working set) from first order in eps / lambda to second order.
+// Here: (i) the step on the FINAL WORKING SET of x0 in closed form — with J J' = (H + eps I)^-1, J'N = [R; 0] and J2 the columns
+// of J that span the null space of the active normals, optimality of x0 reads J2'(grad f(x0) + eps x0) = 0, so
+//     x1 = x0 - J2 J2' grad f(x0) = x0 + eps J2 (J2' x0),     multipliers  lam1 = lam0 + eps R^-1 J1' x0
+// (the second form of x1 is the one evaluated: it never forms the residual gradient, whose rounding noise J2 J2' would amplify by
+// 1 / eps in the directions no cost row sees); (ii) (x1, working set) is then a solution pair of the proximal problem on that set, which is
+// exactly the invariant the dual method iterates on, so the SAME active-set loop simply goes on from there: inequalities the step
+// pushed over their bound (rows that sat ON their bound without being in the working set — every frozen higher-priority row of a
+// HoQp level does) are added, others dropped, until x1 solves the proximal problem with all its constraints.  In the common case
+// nothing is violated and (ii) is one scan.  One step takes the distance to the eps -> 0 limit (the minimum-norm minimiser)
+// from first order in eps / lambda to second order.
 #pragma once
 #include <limits>
 
@@ -127,6 +132,30 @@ inline QpResult solve_lsqp(const Mat& A, const Vec& b, double eps, const Mat& E,
   int iter = 0;
   const double inf = std::numeric_limits<double>::infinity();
   int next_eq = 0;
+  Vec x_before(n, 0.0);   // prox centre of the step before (x_{-1} = 0: the Tikhonov term)
+  for (int phase = 0; phase <= reg_steps; ++phase) {
+  if (phase > 0) {
+    // regularisation step on the current working set (header comment): x <- x + eps J2 J2'(x - x_before), lam <- lam + eps R^-1 J1'(x - x_before)
+    Vec dxp(n);
+    for (int k = 0; k < n; ++k) dxp[k] = x[k] - x_before[k];
+    const Vec w = tmul(J, dxp);   // J'(x_k - x_{k-1})
+    Vec dl(q, 0.0);
+    for (int i = q - 1; i >= 0; --i) {
+      double sacc = w[i];
+      for (int k = i + 1; k < q; ++k) sacc -= R(i, k) * dl[k];
+      dl[i] = sacc / R(i, i);
+    }
+    x_before = x;
+    for (int k = 0; k < n; ++k) {
+      double sacc = 0.0;
+      for (int j = q; j < n; ++j) sacc += J(k, j) * w[j];
+      x[k] += eps * sacc;
+    }
+    for (int j = 0; j < q; ++j) {
+      lam[j] += eps * dl[j];
+      if (act[j] >= me && lam[j] < 0.0) lam[j] = 0.0;   // (a multiplier that sat at zero: the row stays, at multiplier zero)
+    }
+  }
   while (true) {
     // pick the constraint to add: equalities first (in order), then the most violated inequality
     int p = -1;
@@ -230,19 +259,7 @@ inline QpResult solve_lsqp(const Mat& A, const Vec& b, double eps, const Mat& E,
       sp = dot(np, x) - rhs;
     }
   }
-  // regularisation steps on the final working set (header comment): step k solves argmin f + eps/2 |x - x_k|^2 there, and
-  // optimality of x_k for the step before gives x_{k+1} = x_k + eps J2 J2' (x_k - x_{k-1}), x_{-1} = 0
-  Vec x_before(n, 0.0);
-  for (int s = 0; s < reg_steps; ++s) {
-    Vec w(n, 0.0);
-    for (int j = q; j < n; ++j)
-      for (int k = 0; k < n; ++k) w[j] += J(k, j) * (x[k] - x_before[k]);
-    Vec dx(n, 0.0);
-    for (int k = 0; k < n; ++k)
-      for (int j = q; j < n; ++j) dx[k] += J(k, j) * w[j];
-    x_before = x;
-    for (int k = 0; k < n; ++k) x[k] += eps * dx[k];
-  }
+  }  // phase
   res.x = x;
   res.iterations = iter;
   res.active = act;

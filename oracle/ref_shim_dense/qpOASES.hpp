@@ -17,6 +17,7 @@ enum PrintLevel { PL_DEBUG_ITER = -2, PL_TABULAR, PL_NONE, PL_LOW, PL_MEDIUM, PL
 enum BooleanType { BT_FALSE = 0, BT_TRUE = 1 };
 enum returnValue { SUCCESSFUL_RETURN = 0, RET_MAX_NWSR_REACHED = 64, RET_INIT_FAILED = 33 };
 inline double& shim_eps() { static double e = 1e-8; return e; }
+inline int& shim_failures() { static int n = 0; return n; }    // QProblem::init calls that did not return SUCCESSFUL_RETURN
 inline int& shim_reg_steps() { static int n = 1; return n; }   // Options::setToMPC(): numRegularisationSteps = 1
 struct Options {
   PrintLevel printLevel = PL_NONE;
@@ -79,6 +80,7 @@ class QProblem {
     const orc::QpResult res = orc::solve_lsqp(Als, bls, shim_eps(), E, e, D, f, 2000, shim_reg_steps());
     x_ = res.x;
     solved_ = res.status == 0;
+    if (!solved_) ++shim_failures();
     nWSR = res.iterations;
     return solved_ ? SUCCESSFUL_RETURN : RET_INIT_FAILED;
   }

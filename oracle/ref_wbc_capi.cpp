@@ -169,5 +169,7 @@ int ref_hoqp(int n, int L, const int* mA, const double* A, const double* b, cons
 
 void ref_set_qp_eps(double eps) { qpOASES::shim_eps() = eps; }
 void ref_set_qp_reg_steps(int n) { qpOASES::shim_reg_steps() = n; }
+// number of QProblem::init calls that failed since the last call of this function (HoQp.cpp ignores the return value, :180-182)
+int ref_qp_failures() { const int n = qpOASES::shim_failures(); qpOASES::shim_failures() = 0; return n; }
 
 }  // extern "C"

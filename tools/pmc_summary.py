@@ -73,7 +73,16 @@ def main():
             for src in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_MFMA"):
                 if src in v:
                     v[src.lower() + "_per_wave"] = v[src] / v["SQ_WAVES"]
-    json.dump(dict(merged, tag=tag), open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+    # what the counters were collected ON: the sha256 of the kernel sources of the tree that ran (bench.source_fingerprint; there is no
+    # .git on the GPU box — tools/install_evidence.sh adds the commit when it copies the file into profiles/).  bench.py drops
+    # roofline.traffic when the running tree's sources differ from this stamp.
+    import importlib.util
+    import os
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    spec = importlib.util.spec_from_file_location("bench_for_fingerprint", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    json.dump(dict(merged, tag=tag, source_sha256=bench.source_fingerprint(), git_head=None), open(f"profiles/{tag}_pmc.json", "w"), indent=1)
     lines = [f"# rocprofv3 --pmc per-kernel means ({tag}); bytes corrected per MI355X_MICROARCH.md §HBM (FETCH x2 for wide reads)"]
     for k, v in sorted(merged.items(), key=lambda kv: -kv[1].get("avg_us_under_profiling", 0)):
         lines.append(k)

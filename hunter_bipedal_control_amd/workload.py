@@ -63,15 +63,19 @@ def gait_names(params: dict, x0: np.ndarray, cmd: np.ndarray, t0: float = 0.1):
 
 
 def device_trot_batch(solver, params: dict, n_intervals: int = 100, first_inst: int = 0, cmd_vel=(0.3, 0.0, 0.0, 0.0),
-                      cmd_vel_random: bool = False, joint_ik: bool = True, t0: float = 0.1, t_gait_start: float = 0.1):
+                      cmd_vel_random: bool = False, joint_ik: bool = True, t0: float = 0.1, t_gait_start: float = 0.1,
+                      stand_every: int = 0):
     """Initialises `solver` (a HunterSolver) with the config 2/3/4 workload, tables generated ON THE DEVICE:
     distinct instances first_inst .. first_inst + B - 1, mode schedules from the host gait scheduler, hb_refgen_update,
-    cold start.  -> dict(x0, rbd, cmd, t_now, horizon, schedules, gaits)."""
+    cold start.  -> dict(x0, rbd, cmd, t_now, horizon, schedules, gaits).  `stand_every` = k > 0: every k-th instance (id % k == k - 1)
+    gets a zero command, so walkGait keeps it standing — a mixed batch of trotting and standing robots."""
     c = params["config"]
     B = solver.B
     horizon = n_intervals * c["dt"]
     x0, rbd, cmd = batch_inputs(params, B, first_inst, cmd_vel, cmd_vel_random)
-    gaits = gait_names(params, x0, cmd, t0) if cmd_vel_random else ["trot"] * B
+    if stand_every > 0:
+        cmd[(first_inst + np.arange(B)) % stand_every == stand_every - 1] = 0.0
+    gaits = gait_names(params, x0, cmd, t0) if (cmd_vel_random or stand_every > 0) else ["trot"] * B
     cache = {}
     for g in set(gaits):
         # like GaitSchedule::getModeSchedule(t0 - T, t0 + 2 T), the schedule must reach PAST t0 + 2 T: the planner looks one stance

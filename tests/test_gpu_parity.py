@@ -667,6 +667,105 @@ def test_config5_long_horizon_hierarchical(params, oracle):
     assert (np.abs(sol[:, 28:]) <= tl + 1e-7).all()
 
 
+def _oracle_sample_after_one_step(oracle, refs, w, sample, nmax):
+    """One SQP iteration of the oracle from the cold start on the device-generated tables of the instances `sample`."""
+    sub = {k: np.ascontiguousarray(v[sample]) for k, v in refs.items()}
+    xo, uo = np.zeros((len(sample), nmax + 1, 22)), np.zeros((len(sample), nmax, 22))
+    for r, i in enumerate(sample):
+        n = int(refs["n_nodes"][i])
+        xo[r, :n + 1], uo[r, :n] = oracle.cold_start(refs["mode"][i, :n], w["x0"][i])
+    po = oracle.mpc_solve(sub, np.ascontiguousarray(w["x0"][sample]), xo, uo, iters=1, threads=16)
+    return xo, uo, po
+
+
+def _ragged_max_err(a, b, n_nodes, extra):
+    return max(np.abs(a[r, :int(n) + extra] - b[r, :int(n) + extra]).max() for r, n in enumerate(n_nodes))
+
+
+def test_configs3_share_512_random_commands_against_oracle(params, oracle):
+    """BASELINE.json configs[3] at ONE GPU's real share: 512 DISTINCT instances x N = 100 with per-instance commands (seed 4321 + id,
+    gait per instance from walkGait), node tables generated on the device, one resident step — at this occupancy the library runs the
+    four-wavefront backward sweep (k_ric_bwd4) and the wave form of the forward sweep (k_ric_fwd_w).  Every 16th instance against the
+    oracle: trajectories 1e-7 / 1e-6, identical step sizes, WeightedWbc on the published policy to 1e-5 N m."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B, N = 512, 100
+    nmax = N + 8
+    s = HunterSolver(params, batch=B, max_nodes=nmax)
+    try:
+        w = workload.device_trot_batch(s, params, n_intervals=N, cmd_vel_random=True)
+        refs = s.get_references()
+        s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+        s.step_resident()
+        x, u = s.get_solution()
+        sol, status = s.get_wbc_solution()
+        perf, mpc_status = s.get_performance(), s.mpc_status()
+    finally:
+        s.close()
+    assert mpc_status.max() == 0 and status.max() == 0 and np.isfinite(x).all() and np.isfinite(sol).all()
+    assert len(set(w["gaits"])) == 2, "the share holds trotting and standing instances"
+    sample = np.arange(0, B, 16)
+    sample[1] = int(np.flatnonzero(np.array(w["gaits"]) == "stance")[0])   # (a standing instance is in the sample for sure)
+    xo, uo, po = _oracle_sample_after_one_step(oracle, refs, w, sample, nmax)
+    nn = refs["n_nodes"][sample]
+    assert _ragged_max_err(x[sample], xo, nn, 1) < 1e-7 and _ragged_max_err(u[sample], uo, nn, 0) < 1e-6
+    assert np.array_equal(perf[sample, 3], po[:, 3])
+    _check_wbc_on_policy(oracle, refs, w, x[sample], u[sample], xo, uo, sol[sample], status[sample], sample, N)
+
+
+def test_configs4_share_1024_by_200_hierarchical_against_oracle(params, oracle):
+    """BASELINE.json configs[4] at ONE GPU's real share: 1024 DISTINCT instances x N = 200 (timeHorizon 3.0 s, swing constraints
+    active), HierarchicalWbc, every fourth robot standing and the others trotting; tables generated on the device, one resident step.
+    Sixteen instances (four of them standing) against the oracle: trajectories 1e-7 / 1e-6, identical step sizes, the three-level
+    cascade on the published policy 1e-6 relative / torques 1e-5 N m; size-independent properties on all 1024."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    B, N = 1024, 200
+    nmax = N + 8
+    s = HunterSolver(params, batch=B, max_nodes=nmax, wbc_type=1)
+    try:
+        w = workload.device_trot_batch(s, params, n_intervals=N, stand_every=4)
+        refs = s.get_references()
+        s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+        s.step_resident()
+        x, u = s.get_solution()
+        sol, status = s.get_wbc_solution()
+        perf, mpc_status = s.get_performance(), s.mpc_status()
+        for _ in range(4):
+            s.step_resident()
+        perf5 = s.get_performance()
+        sol5, status5 = s.get_wbc_solution()
+    finally:
+        s.close()
+    gaits = np.array(w["gaits"])
+    assert (gaits[3::4] == "stance").all() and (gaits[0::4] == "trot").all()
+    assert mpc_status.max() == 0 and status.max() == 0 and status5.max() == 0 and np.isfinite(x).all() and np.isfinite(sol5).all()
+    # dt-weighted SSE of the shooting defects / equality constraints over the 3 s horizon after five iterations, absolute and against the first
+    assert (perf[:, 3] > 0).all() and perf5[:, 1].max() < 1e-4 and perf5[:, 2].max() < 0.2, perf5[:, 1:3].max(axis=0)
+    assert perf5[:, 1].max() < 1e-2 * perf[:, 1].max() and perf5[:, 2].max() < 5e-2 * perf[:, 2].max(), (perf[:, 1:3].max(axis=0), perf5[:, 1:3].max(axis=0))
+    tl = np.tile(np.array(params["config"]["torque_limits"]), 2)
+    assert (np.abs(sol5[:, 28:]) <= tl + 1e-7).all()
+    assert len({x[i, 100].tobytes() for i in range(0, B, 16)}) == B // 16          # distinct instances
+    sample = np.arange(16) * 64 + np.arange(16)                                     # ids = 0 .. 3 mod 4: four standing robots
+    assert (gaits[sample] == "stance").sum() == 4
+    xo, uo, po = _oracle_sample_after_one_step(oracle, refs, w, sample, nmax)
+    nn = refs["n_nodes"][sample]
+    assert _ragged_max_err(x[sample], xo, nn, 1) < 1e-7 and _ragged_max_err(u[sample], uo, nn, 0) < 1e-6
+    assert np.array_equal(perf[sample, 3], po[:, 3])
+    # HierarchicalWbc on the published policy: the oracle's cascade fed the DEVICE's policy
+    tt = refs["t"]
+    xd, ud, md = np.zeros((16, 22)), np.zeros((16, 22)), np.zeros(16, dtype=np.int32)
+    for r, i in enumerate(sample):
+        k = int(np.searchsorted(tt[i, :int(refs["n_nodes"][i]) + 1], w["t_now"][i], side="right") - 1)
+        a = (w["t_now"][i] - tt[i, k]) / (tt[i, k + 1] - tt[i, k])
+        xd[r] = (1 - a) * x[i, k] + a * x[i, k + 1]
+        ud[r] = (1 - a) * u[i, k] + a * u[i, min(k + 1, int(refs["n_nodes"][i]) - 1)]
+        md[r] = refs["mode"][i, k]
+    so, sto = oracle.hwbc_update(xd, ud, w["rbd"][sample], md, threads=16)
+    assert np.array_equal(status[sample], sto) and sto.max() == 0
+    scale = np.maximum(1.0, np.abs(so[:, :28]).max(axis=1, keepdims=True))
+    assert (np.abs(sol[sample, :28] - so[:, :28]) / scale).max() < 1e-6
+    assert np.abs(sol[sample, 28:] - so[:, 28:]).max() < 1e-5
+
+
 def test_joint_command_law(params):
     """hb_joint_command vs the formulas of LeggedController.cpp:186-257 (restated here in numpy)."""
     from hunter_bipedal_control_amd import abi

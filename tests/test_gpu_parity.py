@@ -581,6 +581,31 @@ def _oracle_policy(refs, t_now, xo, uo):
     return xd, ud, md
 
 
+@pytest.mark.parametrize("reg", [0, 2])
+def test_wbc_regularisation_steps_other_than_the_rule_match_oracle(params, reg):
+    """hb_config.wbc_reg_steps = 0 (the plain Tikhonov point of rounds 1-4) and 2: the regularisation phases of k_wbc / k_hwbc are a
+    loop, not a special case of the rule's single step — both flavours against the oracle built with the same setting, on fast-moving
+    inputs (torque-limit / friction rows in the working sets, level-0 passes with violated rows)."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    from oracle.pyoracle import Oracle
+    B = 24
+    xd, ud, rbd, mode = _fast_moving_wbc_inputs(params, B, seed=5)
+    o = Oracle(params, wbc_reg_steps=reg)
+    for wbc_type in (0, 1):
+        s = HunterSolver(params, batch=B, max_nodes=4, wbc_type=wbc_type, wbc_reg_steps=reg)
+        try:
+            sol, status = s.wbc_update_direct(xd, ud, rbd, mode)
+        finally:
+            s.close()
+        if wbc_type == 0:
+            so, sto, _ = o.wbc_update(xd, ud, rbd, mode, stance_flag=np.zeros(B, dtype=np.int32), threads=4)
+        else:
+            so, sto = o.hwbc_update(xd, ud, rbd, mode, threads=4)
+        assert np.array_equal(status, sto) and status.max() == 0, (wbc_type, status, sto)
+        scale = np.maximum(1.0, np.abs(so).max(axis=1, keepdims=True))
+        assert (np.abs(sol - so) / scale).max() < 1e-6, wbc_type
+
+
 def test_config4_per_instance_commands_and_gaits(params, oracle):
     """SURVEY.md §8d config 4 (reduced batch): per-instance cmd_vel, stance/trot chosen by the walkGait thresholds —
     mixed mode sequences and projected-input widths inside one launch."""

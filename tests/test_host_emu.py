@@ -133,6 +133,38 @@ def test_device_hierarchical_wbc_violated_level0_rows(params, oracle, emu):
         assert np.abs(se - so[0]).max() < 1e-6 * max(1.0, np.abs(so[0]).max())
 
 
+def test_device_wbc_regularisation_phases_match_oracle(params, emu):
+    """hb_config.wbc_reg_steps = 0 / 1 / 2 (plain Tikhonov point / the reference's one regularisation step / two): the device code's
+    phases — the proximal step on the working set, the multiplier update, the dual loop going on from there; level 0 of the cascade
+    on its first-pass factor or over violated rows — against the oracle's, on fast-moving inputs whose working sets carry torque-limit
+    and friction rows (WeightedWbc on all 24 cases, the cascade on a sample incl. passes with violated level-0 rows)."""
+    from oracle.pyoracle import Oracle
+    from test_gpu_parity import _fast_moving_wbc_inputs
+    lib, mdl, _ = emu
+    xd, ud, rbd, mode = _fast_moving_wbc_inputs(params, 24, seed=5)
+    sols = {}
+    for reg in (0, 1, 2):
+        o = Oracle(params, wbc_reg_steps=reg)
+        cfg = abi.make_config(params, wbc_reg_steps=reg)
+        so, st, it = o.wbc_update(xd, ud, rbd, mode, stance_flag=np.zeros(24, dtype=np.int32), threads=4)
+        sols[reg] = so
+        for i in range(24):
+            se, ste, ite = np.zeros(38), C.c_int(), C.c_int()
+            lib.emu_wbc(C.byref(mdl), C.byref(cfg), _p(xd[i]), _p(ud[i]), _p(rbd[i]), C.c_int(int(mode[i])), C.c_int(0), _p(se), C.byref(ste), C.byref(ite))
+            assert ste.value == st[i] == 0, (reg, i)
+            assert np.abs(se - so[i]).max() < 1e-6 * max(1.0, np.abs(so[i]).max()), (reg, i)
+        sh, sth = o.hwbc_update(xd, ud, rbd, mode, threads=4)
+        for i in (0, 4, 6, 7, 8, 11, 17, 23):
+            se, ste = np.zeros(38), C.c_int()
+            lib.emu_hwbc(C.byref(mdl), C.byref(cfg), _p(xd[i]), _p(ud[i]), _p(rbd[i]), C.c_int(int(mode[i])), _p(se), C.byref(ste), C.c_int(3))
+            assert ste.value == sth[i] == 0, (reg, i)
+            assert np.abs(se - sh[i]).max() < 1e-6 * max(1.0, np.abs(sh[i]).max()), (reg, i)
+    # the step does something (first order in eps) and a second one much less (second order)
+    d01 = np.abs(sols[0] - sols[1])[:, 28:].max(axis=1)
+    d12 = np.abs(sols[1] - sols[2])[:, 28:].max(axis=1)
+    assert np.median(d01) > 1e-5 and np.median(d12) < 1e-2 * np.median(d01)
+
+
 def test_device_estimator_matches_oracle(params, oracle, emu):
     """hb_estimator.hpp (structured filter algebra, Cholesky instead of LU, forward momentum map) vs oracle/estimator.hpp."""
     from hunter_bipedal_control_amd import abi as _abi

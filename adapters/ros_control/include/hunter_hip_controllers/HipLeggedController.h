@@ -36,6 +36,8 @@ class HipLeggedController
   void starting(const ros::Time& time) override;
   void stopping(const ros::Time& /*time*/) override { mpcRunning_ = false; }
   int plannedMode() const { return plannedMode_; }   // mode of the policy at the last control tick (the reference publishes it on a topic)
+  // StateEstimateBase::getEstContactForce (StateEstimateBase.h:87-90): [wrench leg 0 (6) | wrench leg 1 (6) | |F0| |F1| | |W0| |W1|] of the last tick
+  const hunter_hip::vector_t& estContactForce() const { return stateEstimate_->getEstContactForce(); }
   // LeggedController::resetMPC (LeggedController.cpp:460-465): cold start of the solver from the current observation, taken up by the
   // next MPC pass.  The reference declares it and never calls it; nothing here calls it either — it is for an operator service or a
   // test.  A failed SQP call (non-finite value / Riccati pivot) stops the controller as in the reference (:413-418), it is NOT retried.

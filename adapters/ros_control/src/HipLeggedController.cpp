@@ -141,10 +141,11 @@ void HipLeggedController::starting(const ros::Time& time) {   // ≙ :112-135
 }
 
 void HipLeggedController::updateStateEstimation(const ros::Time& time, const ros::Duration& period) {   // ≙ :280-349
-  vector_t jointPos(10), jointVel(10), quat(4), angularVel(3), linearAccel(3);
+  vector_t jointPos(10), jointVel(10), jointTor(10), quat(4), angularVel(3), linearAccel(3);
   for (size_t i = 0; i < hybridJointHandles_.size(); ++i) {
     jointPos[i] = hybridJointHandles_[i].getPosition();
     jointVel[i] = hybridJointHandles_[i].getVelocity();
+    jointTor[i] = hybridJointHandles_[i].getEffort();
   }
   for (size_t i = 0; i < 4; ++i) quat[i] = imuSensorHandle_.getOrientation()[i];
   for (size_t i = 0; i < 3; ++i) {
@@ -158,6 +159,7 @@ void HipLeggedController::updateStateEstimation(const ros::Time& time, const ros
     contact = {L, R, L, R};
   }
   measuredRbdState_ = stateEstimate_->update(period.toSec(), quat, angularVel, linearAccel, jointPos, jointVel, contact);
+  stateEstimate_->estContactForce(period.toSec(), jointTor);   // setCmdTorque + estContactForce (:344-345): no reader in the reference either
   std::lock_guard<std::mutex> lk(cmdMutex_);
   currentObservation_.time = time.toSec();
   currentObservation_.state = stateEstimate_->observationState();   // incl. the yaw unwrapping of :331-334

@@ -136,7 +136,8 @@ def make_config(params: dict, **overrides) -> HbConfig:
 class HbEstimatorConfig(C.Structure):
     _fields_ = [(k, C.c_double) for k in (
         "foot_radius", "imu_process_noise_position", "imu_process_noise_velocity", "foot_process_noise_position",
-        "foot_sensor_noise_position", "foot_sensor_noise_velocity", "foot_height_sensor_noise")]
+        "foot_sensor_noise_position", "foot_sensor_noise_velocity", "foot_height_sensor_noise",
+        "contact_force_cutoff_frequency", "contact_threshold")]
 
 
 def make_estimator_config(params: dict, **overrides) -> HbEstimatorConfig:

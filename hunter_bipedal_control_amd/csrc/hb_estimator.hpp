@@ -324,4 +324,143 @@ HB_HD void estimator_update(const Ctx& cx, const DevModel& M, const hb_estimator
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// StateEstimateBase::estContactForce (legged_estimation/src/StateEstimateBase.cpp:130-206; every control tick at
+// legged_controllers/src/LeggedController.cpp:344-345 with the measured joint efforts): generalised-momentum observer + per-leg wrench.
+//     p = M v,   w = beta p + S' tau + C' v - g,   z <- (1 - gamma) w + gamma z,   tau_dist = beta p - z
+// pinocchio's crba / getCoriolisMatrix / computeGeneralizedGravity / getFrameJacobian are replaced by ONE inward pass over composite
+// MOMENTA (no matrix is formed): with P_i, K_i the linear momentum of the subtree behind coordinate i and its angular momentum about the
+// coordinate's origin o_i, a_i its axis, w_par the angular velocity of the body the joint hangs on and v_o the velocity of o_i,
+//     p_i       = a_i . K_i                                        (row i of M v)
+//     (C' v)_i  = d(1/2 v' M v)/dq_i = (w_par x a_i) . K_i + (v_o x a_i) . P_i     (Mdot = C + C', C v = nle - g  =>  C' v = dT/dq)
+//     g_i       = g (a_i x sum_b m_b (c_b - o_i))_z
+// (translations: p = total momentum, C'v = 0, g = m g e_z).  The oracle takes dT/dq with dual numbers over a sum-over-bodies model.
+struct CfLegWork {   // forward data of one leg the inward pass needs (the kernel keeps it in LDS: the joint loops index it dynamically)
+  Vec3<double> o[5], a[5], wp[5], vo[5], Pb[5], Hb[5], mcb[5];   // origin, axis, parent angular velocity, origin velocity, body momentum,
+  double mb[5];                                                  // body spin angular momentum + (c - o) x P, m_b (c_b - 0), m_b
+};
+// rbd[32], tau[10] (joint efforts), z[16] in/out (pSCgZinvlast_), dist[16] out (estDisturbancetorque_), cf[16] out (estContactforce_:
+// wrench of leg 0 (6), of leg 1 (6), |F0|, |F1|, |W0|, |W1|).  gamma = exp(-cutoff dt), beta = (1 - gamma) / (gamma dt) come from the host.
+HB_HD void contact_force_estimate(const DevModel& M, double gama, double beta, const double* rbd, const double* tau, double* z, double* dist,
+                                  double* cf, CfLegWork& W) {
+  double sz, cz, sy, cy, sx, cxr;
+  sincos_t(rbd[0], sz, cz);
+  sincos_t(rbd[1], sy, cy);
+  sincos_t(rbd[2], sx, cxr);
+  Mat3<double> R0;
+  R0.m[0] = cz * cy; R0.m[1] = cz * sy * sx - sz * cxr; R0.m[2] = cz * sy * cxr + sz * sx;
+  R0.m[3] = sz * cy; R0.m[4] = sz * sy * sx + cz * cxr; R0.m[5] = sz * sy * cxr - cz * sx;
+  R0.m[6] = -sy;     R0.m[7] = cy * sx;                 R0.m[8] = cy * cxr;
+  const Vec3<double> E[3] = {Vec3<double>(0.0, 0.0, 1.0), Vec3<double>(-sz, cz, 0.0), Vec3<double>(cz * cy, sz * cy, -sy)};
+  const Vec3<double> w0(rbd[HB_NV], rbd[HB_NV + 1], rbd[HB_NV + 2]), v0(rbd[HB_NV + 3], rbd[HB_NV + 4], rbd[HB_NV + 5]);
+  const Vec3<double> er = euler_rates_from_omega<double>(sz, cz, sy, cy, w0);   // v[3..5]
+  // base body
+  const Vec3<double> c0 = R0 * Vec3<double>(M.com[0][0], M.com[0][1], M.com[0][2]);
+  const Sym3<double> I0 = rotate_inertia<double>(R0, M.inertia[0]);
+  Vec3<double> Ptot = M.mass[0] * (v0 + cross(w0, c0));
+  Vec3<double> KO = I0 * w0 + cross(c0, Ptot);
+  Vec3<double> mctot = M.mass[0] * c0;
+  double p[HB_NV], ctv[HB_NV], g[HB_NV];
+  Vec3<double> wrench_rows_lin[2][5], wrench_rows_ang[2][5];
+  for (int leg = 0; leg < 2; ++leg) {
+    Mat3<double> R = R0;
+    Vec3<double> op, w = w0, vo = v0;
+#pragma unroll 1
+    for (int k = 0; k < 5; ++k) {
+      const int j = 5 * leg + k, b = j + 1;
+      const Vec3<double> r = R * Vec3<double>(M.origin[j][0], M.origin[j][1], M.origin[j][2]);
+      const Vec3<double> ok = op + r;
+      const Vec3<double> ak = R * Vec3<double>(M.axis[j][0], M.axis[j][1], M.axis[j][2]);
+      vo = vo + cross(w, r);
+      W.o[k] = ok; W.a[k] = ak; W.wp[k] = w; W.vo[k] = vo;
+      w = w + rbd[HB_NV + 6 + j] * ak;
+      R = R * axis_rot<double>(M.axis[j], rbd[6 + j]);
+      const Vec3<double> rc = R * Vec3<double>(M.com[b][0], M.com[b][1], M.com[b][2]);
+      const Vec3<double> Pb = M.mass[b] * (vo + cross(w, rc));
+      W.Pb[k] = Pb;
+      W.Hb[k] = rotate_inertia<double>(R, M.inertia[b]) * w + cross(rc, Pb);   // about o_k
+      W.mcb[k] = M.mass[b] * (ok + rc);
+      W.mb[k] = M.mass[b];
+      op = ok;
+    }
+    const Vec3<double> foot = op + R * Vec3<double>(M.contact_offset[leg][0], M.contact_offset[leg][1], M.contact_offset[leg][2]);   // contact frame `leg` (L_f1 / R_f1)
+    Vec3<double> Pc, Kc, mcc, onext;
+    double mc = 0.0;
+#pragma unroll 1
+    for (int k = 4; k >= 0; --k) {
+      const Vec3<double> ok = W.o[k], ak = W.a[k];
+      if (k < 4) Kc = Kc + cross(onext - ok, Pc);   // shift the outboard composite's reference point to o_k
+      Pc = Pc + W.Pb[k];
+      Kc = Kc + W.Hb[k];
+      mc += W.mb[k];
+      mcc = mcc + W.mcb[k];
+      const int i = 6 + 5 * leg + k;
+      p[i] = dot(ak, Kc);
+      ctv[i] = dot(cross(W.wp[k], ak), Kc) + dot(cross(W.vo[k], ak), Pc);
+      g[i] = M.gravity * cross(ak, mcc - mc * ok).z;
+      wrench_rows_lin[leg][k] = cross(ak, foot - ok);
+      wrench_rows_ang[leg][k] = ak;
+      onext = ok;
+    }
+    Ptot = Ptot + Pc;
+    KO = KO + Kc + cross(onext, Pc);
+    mctot = mctot + mcc;
+  }
+  p[0] = Ptot.x; p[1] = Ptot.y; p[2] = Ptot.z;
+  ctv[0] = ctv[1] = ctv[2] = 0.0;
+  g[0] = g[1] = 0.0; g[2] = M.total_mass * M.gravity;
+  {
+    Vec3<double> wpar;
+    for (int c = 0; c < 3; ++c) {
+      p[3 + c] = dot(E[c], KO);
+      ctv[3 + c] = dot(cross(wpar, E[c]), KO) + dot(cross(v0, E[c]), Ptot);
+      g[3 + c] = M.gravity * cross(E[c], mctot).z;
+      wpar = wpar + comp(er, c) * E[c];
+    }
+  }
+  for (int i = 0; i < HB_NV; ++i) {
+    const double wv = beta * p[i] + (i >= 6 ? tau[i - 6] : 0.0) + ctv[i] - g[i];
+    const double zi = (1.0 - gama) * wv + gama * z[i];
+    z[i] = zi;
+    dist[i] = beta * p[i] - zi;
+  }
+  // per leg: minimum-norm solution of  A wrench = tau_dist(leg rows),  A(k, :) = [a_k x (foot - o_k) | a_k]  (5 x 6):  A' (A A')^-1 b
+  for (int leg = 0; leg < 2; ++leg) {
+    double G[5][5], y[5];
+    for (int i = 0; i < 5; ++i) {
+      y[i] = dist[6 + 5 * leg + i];
+      for (int j2 = 0; j2 <= i; ++j2)
+        G[i][j2] = dot(wrench_rows_lin[leg][i], wrench_rows_lin[leg][j2]) + dot(wrench_rows_ang[leg][i], wrench_rows_ang[leg][j2]);
+    }
+    for (int j2 = 0; j2 < 5; ++j2) {   // Cholesky G = L L' in place (lower), then L y' = y, L' y'' = y'
+      double d = G[j2][j2];
+      for (int k = 0; k < j2; ++k) d -= G[j2][k] * G[j2][k];
+      const double l = sqrt(d), li = 1.0 / l;
+      G[j2][j2] = l;
+      for (int i = j2 + 1; i < 5; ++i) {
+        double sacc = G[i][j2];
+        for (int k = 0; k < j2; ++k) sacc -= G[i][k] * G[j2][k];
+        G[i][j2] = sacc * li;
+      }
+    }
+    for (int i = 0; i < 5; ++i) {
+      double sacc = y[i];
+      for (int k = 0; k < i; ++k) sacc -= G[i][k] * y[k];
+      y[i] = sacc / G[i][i];
+    }
+    for (int i = 4; i >= 0; --i) {
+      double sacc = y[i];
+      for (int k = i + 1; k < 5; ++k) sacc -= G[k][i] * y[k];
+      y[i] = sacc / G[i][i];
+    }
+    Vec3<double> F, T;
+    for (int k = 0; k < 5; ++k) { F = F + y[k] * wrench_rows_lin[leg][k]; T = T + y[k] * wrench_rows_ang[leg][k]; }
+    double* o6 = cf + 6 * leg;
+    o6[0] = F.x; o6[1] = F.y; o6[2] = F.z; o6[3] = T.x; o6[4] = T.y; o6[5] = T.z;
+    cf[12 + leg] = sqrt(dot(F, F));
+    cf[14 + leg] = sqrt(dot(F, F) + dot(T, T));
+  }
+}
+
 }  // namespace hb

@@ -1013,6 +1013,8 @@ struct EstBatch {
   const int* contact;                                 // [B][4]
   double *rbd, *x;                                    // outputs [B][32], [B][22]
   double *res_rbd, *res_x0;                           // resident inputs of hb_step_resident (or null)
+  // hb_estimator_contact_force: low-pass state pSCgZinvlast_ [B][16], joint efforts [B][10], outputs [B][16] each, a host-given rbd [B][32]
+  double *cf_z, *cf_tau, *cf_dist, *cf_out, *cf_rbd;
 };
 
 __global__ __launch_bounds__(64) void k_estimator(EstBatch e, const DevModel* __restrict__ M, hb_estimator_config K, double dt) {
@@ -1026,6 +1028,18 @@ __global__ __launch_bounds__(64) void k_estimator(EstBatch e, const DevModel* __
     for (int c = cx.lane; c < HB_NRBD; c += 64) e.res_rbd[HB_NRBD * i + c] = e.rbd[HB_NRBD * i + c];
     for (int c = cx.lane; c < HB_NX; c += 64) e.res_x0[HB_NX * i + c] = e.x[HB_NX * i + c];
   }
+}
+// StateEstimateBase::estContactForce for every instance, one thread each (hb_estimator.hpp contact_force_estimate); the per-leg forward
+// data sits in LDS (the joint loops index it dynamically).  Not on the timed path of the update: 4096 instances take ~ 0.1 ms.
+constexpr int kCfThreads = 32;
+__global__ __launch_bounds__(kCfThreads) void k_contact_force(int B, const DevModel* __restrict__ M, double gama, double beta, const double* rbd,
+                                                              const double* tau, double* z, double* dist, double* cf) {
+  static_assert(sizeof(CfLegWork) % 8 == 0, "CfLegWork is an array of doubles");
+  __shared__ double wk_raw[kCfThreads * (sizeof(CfLegWork) / 8)];   // (Vec3 has a constructor: raw storage, never read before it is written)
+  const int i = blockIdx.x * kCfThreads + threadIdx.x;
+  if (i >= B) return;
+  contact_force_estimate(*M, gama, beta, rbd + size_t(i) * HB_NRBD, tau + size_t(i) * HB_NJ, z + size_t(i) * HB_NV, dist + size_t(i) * HB_NV,
+                         cf + size_t(i) * 16, *reinterpret_cast<CfLegWork*>(wk_raw + threadIdx.x * (sizeof(CfLegWork) / 8)));
 }
 __global__ void k_estimator_reset(int B, double* xhat, double* P, double* yaw_last, const double* xhat0) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1635,6 +1649,11 @@ int32_t hb_estimator_reset(hb_ctx* ctx, const hb_estimator_config* cfg, const do
     HB_HIP(dalloc(ctx, &contact, B * 4));
     HB_HIP(dalloc(ctx, &e.rbd, B * HB_NRBD));
     HB_HIP(dalloc(ctx, &e.x, B * HB_NX));
+    HB_HIP(dalloc(ctx, &e.cf_z, B * HB_NV));
+    HB_HIP(dalloc(ctx, &e.cf_tau, B * HB_NJ));
+    HB_HIP(dalloc(ctx, &e.cf_dist, B * HB_NV));
+    HB_HIP(dalloc(ctx, &e.cf_out, B * 16));
+    HB_HIP(dalloc(ctx, &e.cf_rbd, B * HB_NRBD));
     e.quat = quat; e.w_local = wl; e.a_local = al; e.qj = qj; e.qdj = qdj; e.contact = contact;
     e.B = ctx->B;
   }
@@ -1644,11 +1663,41 @@ int32_t hb_estimator_reset(hb_ctx* ctx, const hb_estimator_config* cfg, const do
     x0_dev = e.x;
     HB_HIP(hipMemcpy(x0_dev, x_hat0, B * 18 * 8, hipMemcpyHostToDevice));
   }
+  HB_HIP(hipMemsetAsync(e.cf_z, 0, B * HB_NV * 8, ctx->s_wbc));   // pSCgZinvlast_ = 0 (StateEstimateBase.cpp:58-59)
   const int n = int(B) * 324;
   hipLaunchKernelGGL(k_estimator_reset, dim3((n + 255) / 256), dim3(256), 0, ctx->s_wbc, int(B), e.xhat, e.P, e.yaw_last, x0_dev);
   HB_HIP(hipGetLastError());
   HB_HIP(hipStreamSynchronize(ctx->s_wbc));
   ctx->est_ready = true;
+  return HB_OK;
+}
+
+int32_t hb_estimator_contact_force(hb_ctx* ctx, double dt, const double* rbd, const double* joint_torque, double* est_disturbance_torque,
+                                   double* est_contact_force) {
+  if (ctx) lazy_join(ctx);
+  if (!ctx || !joint_torque || !(dt > 0.0)) return HB_ERR_ARG;
+  if (!ctx->est_ready) {
+    ctx->err = "hb_estimator_contact_force: call hb_estimator_reset first (it carries the cut-off frequency and zeroes the observer state)";
+    return HB_ERR_STATE;
+  }
+  HB_HIP(hipSetDevice(ctx->device));
+  const size_t B = ctx->B;
+  EstBatch& e = ctx->est;
+  hipStream_t s = ctx->s_wbc;   // control-thread side, behind the estimator update it follows (LeggedController.cpp:327-345)
+  if (dt > 1.0) dt = 0.002;     // (StateEstimateBase.cpp:133-134)
+  const double gama = std::exp(-ctx->est_cfg.contact_force_cutoff_frequency * dt), beta = (1.0 - gama) / (gama * dt);
+  HB_HIP(hipMemcpyAsync(e.cf_tau, joint_torque, B * HB_NJ * 8, hipMemcpyHostToDevice, s));
+  const double* rbd_dev = e.rbd;   // NULL: the rbd state the last hb_estimator_update left on the device
+  if (rbd) {
+    HB_HIP(hipMemcpyAsync(e.cf_rbd, rbd, B * HB_NRBD * 8, hipMemcpyHostToDevice, s));
+    rbd_dev = e.cf_rbd;
+  }
+  hipLaunchKernelGGL(k_contact_force, dim3((ctx->B + kCfThreads - 1) / kCfThreads), dim3(kCfThreads), 0, s, ctx->B, ctx->dmodel, gama, beta, rbd_dev,
+                     e.cf_tau, e.cf_z, e.cf_dist, e.cf_out);
+  HB_HIP(hipGetLastError());
+  if (est_disturbance_torque) HB_HIP(hipMemcpyAsync(est_disturbance_torque, e.cf_dist, B * HB_NV * 8, hipMemcpyDeviceToHost, s));
+  if (est_contact_force) HB_HIP(hipMemcpyAsync(est_contact_force, e.cf_out, B * 16 * 8, hipMemcpyDeviceToHost, s));
+  HB_HIP(hipStreamSynchronize(s));   // (the joint efforts were read from the caller's array)
   return HB_OK;
 }
 

@@ -265,6 +265,9 @@ def read_config(task_file: str | Path, reference_file: str | Path, gait_file: st
             foot_sensor_noise_position=f("kalmanFilter.footSensorNoisePosition", 0.005),
             foot_sensor_noise_velocity=f("kalmanFilter.footSensorNoiseVelocity", 0.1),
             foot_height_sensor_noise=f("kalmanFilter.footHeightSensorNoise", 0.01),
+            # contactForceEsimation block (sic), StateEstimateBase::loadSettings (StateEstimateBase.cpp:365-377)
+            contact_force_cutoff_frequency=f("contactForceEsimation.cutoffFrequency", 250.0),
+            contact_threshold=f("contactForceEsimation.contactThreshold", 75.0),
         ),
         # reference.info
         com_height=float(info_get(ref, "comHeight")),

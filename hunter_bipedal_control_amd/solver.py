@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "hb_wbc_update", "hb_wbc_update_direct", "hb_set_resident_inputs", "hb_step_resident", "hb_set_resident_x0_sequence",
     "hb_get_wbc_solution", "hb_set_chunks",
     "hb_sync", "hb_get_stats", "hb_get_input_cost", "hb_version", "hb_eval_flow_map", "hb_eval_foot_kinematics",
-    "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter",
+    "hb_eval_rbd", "hb_riccati_solve", "hb_estimator_reset", "hb_estimator_update", "hb_estimator_get_filter", "hb_estimator_contact_force",
     "hb_refgen_reset", "hb_refgen_set_schedule", "hb_refgen_update", "hb_mpc_get_references", "hb_joint_command", "hb_centroidal_state_from_rbd", "hb_plant_reset", "hb_plant_step",
     "hb_plant_get_state", "hb_hoqp_solve", "hb_mpc_reset_masked", "hb_mpc_get_status", "hb_joint_set_flags",
     "hb_joint_get_emergency_stop", "hb_set_resident_time", "hb_get_wbc_iterations", "hb_ik_solve", "hb_debug_chunk_counters", "hb_debug_graph_state", "hb_refgen_get_status", "hb_tick_resident",
@@ -372,6 +372,14 @@ class HunterSolver:
         wire = np.zeros((self.B, 496), dtype=np.uint8)
         self._check(self.lib.hb_joint_command_lcm(self.ctx, C.byref(gains), C.c_double(dt), C.c_int64(timestamp_ns), _p(wire)), "hb_joint_command_lcm")
         return wire
+
+    def estimator_contact_force(self, dt, joint_torque, rbd=None):
+        """hb_estimator_contact_force (StateEstimateBase::estContactForce): -> estDisturbancetorque_ [B][16], estContactforce_ [B][16].
+        rbd = None: the state the last estimator_update left on the device."""
+        dist, cf = np.zeros((self.B, 16)), np.zeros((self.B, 16))
+        self._check(self.lib.hb_estimator_contact_force(self.ctx, C.c_double(dt), _p(None if rbd is None else _f64(rbd, (self.B, 32))),
+                                                        _p(_f64(joint_torque, (self.B, 10))), _p(dist), _p(cf)), "hb_estimator_contact_force")
+        return dist, cf
 
     def estimator_filter(self):
         xh, P = np.zeros((self.B, 18)), np.zeros((self.B, 18, 18))

@@ -297,6 +297,9 @@ typedef struct hb_estimator_config {  /* task.info kalmanFilter block (:336-345)
   double foot_radius;
   double imu_process_noise_position, imu_process_noise_velocity, foot_process_noise_position;
   double foot_sensor_noise_position, foot_sensor_noise_velocity, foot_height_sensor_noise;
+  /* task.info contactForceEsimation block (:347-351), StateEstimateBase::loadSettings (StateEstimateBase.cpp:365-377) */
+  double contact_force_cutoff_frequency;   /* lambda of the momentum observer's low pass (hb_estimator_contact_force) */
+  double contact_threshold;                /* normal force above which estContactState would call a leg "in contact" (:206-226) */
 } hb_estimator_config;
 /* (Re)initialise: xHat = x_hat0 (or zeros if NULL), P = 100 I, last yaw = 0 (LinearKalmanFilter.cpp:31-60). */
 int32_t hb_estimator_reset(hb_ctx* ctx, const hb_estimator_config* cfg, const double* x_hat0 /*[batch][18] or NULL*/);
@@ -310,6 +313,17 @@ int32_t hb_estimator_reset(hb_ctx* ctx, const hb_estimator_config* cfg, const do
 int32_t hb_estimator_update(hb_ctx* ctx, double dt, const double* quat, const double* ang_vel_local,
                             const double* lin_acc_local, const double* joint_pos, const double* joint_vel,
                             const int32_t* contact_flag, int32_t to_resident, double* rbd, double* x_state);
+/* StateEstimateBase::setCmdTorque + estContactForce (legged_estimation/src/StateEstimateBase.cpp:130-206), which
+ * LeggedController::updateStateEstimation runs every tick behind the filter update (LeggedController.cpp:344-345): a
+ * generalised-momentum observer for the disturbance torque (low pass exp(-cutoff dt) from hb_estimator_config, state per
+ * instance on the device, zeroed by hb_estimator_reset) and, per leg, the minimum-norm wrench at its first contact frame
+ * (L_f1 / R_f1).  rbd [batch][32] or NULL = the state the last hb_estimator_update left on the device;
+ * joint_torque [batch][10] = the measured joint efforts.  Out (either may be NULL): est_disturbance_torque [batch][16]
+ * (estDisturbancetorque_), est_contact_force [batch][16] = [wrench leg 0 (force 3, moment 3) | wrench leg 1 | |F0| |F1| |
+ * |W0| |W1|] (estContactforce_).  In the reference nothing reads these values (estContactState, their only reader, is
+ * never called); they are provided for the same diagnostics. */
+int32_t hb_estimator_contact_force(hb_ctx* ctx, double dt, const double* rbd, const double* joint_torque,
+                                   double* est_disturbance_torque, double* est_contact_force);
 /* Filter state to the host (either may be NULL): x_hat[batch][18], P[batch][18][18]. */
 int32_t hb_estimator_get_filter(hb_ctx* ctx, double* x_hat, double* P);
 

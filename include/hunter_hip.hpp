@@ -461,10 +461,22 @@ class KalmanFilterEstimate {
     return rbdState_;
   }
   const vector_t& observationState() const { return observationState_; }  // currentObservation_.state per instance
+  // StateEstimateBase::setCmdTorque + estContactForce (StateEstimateBase.cpp:130-206; LeggedController.cpp:344-345): the momentum
+  // observer on the rbd state the last update() left on the device.  cmdTorque [batch][10] = the measured joint efforts.
+  void estContactForce(scalar_t period, const vector_t& cmdTorque) {
+    const size_t B = size_t(ctx_.batch());
+    if (cmdTorque.size() != B * HB_NJ) throw std::invalid_argument("[hunter_hip] KalmanFilterEstimate::estContactForce: wrong vector size");
+    estDisturbanceTorque_.resize(B * HB_NV);
+    estContactForce_.resize(B * 16);
+    ctx_.check(hb_estimator_contact_force(ctx_.get(), period, nullptr, cmdTorque.data(), estDisturbanceTorque_.data(), estContactForce_.data()),
+               "hb_estimator_contact_force");
+  }
+  const vector_t& getEstContactForce() const { return estContactForce_; }            // StateEstimateBase.h:87-90
+  const vector_t& getEstDisturbanceTorque() const { return estDisturbanceTorque_; }  // StateEstimateBase.h:91-94
 
  private:
   Context ctx_;
-  vector_t rbdState_, observationState_;
+  vector_t rbdState_, observationState_, estContactForce_, estDisturbanceTorque_;
 };
 
 // ---- LCM bridge: legged::LeggedMujocoSim::read / write (legged_examples/legged_mujoco/src/LeggedMujocoSim.cpp:28-62) ----

@@ -281,6 +281,9 @@ inline void readConfig(const std::string& taskFile, const std::string& reference
   e.foot_sensor_noise_position = task.number("kalmanFilter.footSensorNoisePosition", 0.005);
   e.foot_sensor_noise_velocity = task.number("kalmanFilter.footSensorNoiseVelocity", 0.1);
   e.foot_height_sensor_noise = task.number("kalmanFilter.footHeightSensorNoise", 0.01);
+  // contactForceEsimation block (sic), StateEstimateBase::loadSettings (StateEstimateBase.cpp:365-377)
+  e.contact_force_cutoff_frequency = task.number("contactForceEsimation.cutoffFrequency", 250.0);
+  e.contact_threshold = task.number("contactForceEsimation.contactThreshold", 75.0);
   // reference generation (swing_trajectory_config; the loader key is next_position_z, SwingTrajectoryPlanner.cpp:560)
   hb_refgen_config& g = p.refgen;
   std::memset(&g, 0, sizeof(g));

@@ -13,6 +13,8 @@
 #include <cstring>
 #include <vector>
 
+#include "dual.hpp"
+#include "linalg.hpp"
 #include "model.hpp"
 
 namespace orc {
@@ -250,6 +252,124 @@ inline void kf_update(const hb_model& mdl, const hb_estimator_config& cfg, KfSta
   if (d > pi) d -= 2 * pi;
   x[9] = st.yaw_last + d;
   st.yaw_last = x[9];
+}
+
+
+// ---- StateEstimateBase::estContactForce (legged_estimation/src/StateEstimateBase.cpp:130-206; called every control tick at
+// legged_controllers/src/LeggedController.cpp:344-345 with the MEASURED joint efforts as "cmdTorque").  A generalised-momentum
+// observer (Bledt et al., "Contact model fusion for event-based locomotion in unstructured terrains"):
+//     p = M v,   w = beta p + S' tau + C' v - g,   z <- (1 - gamma) w + gamma z,   tau_dist = beta p - z
+// with gamma = exp(-lambda dt), beta = (1 - gamma) / (gamma dt), then per leg the wrench at its first contact frame from the leg's
+// five rows of tau_dist:  (S_l J_i')  wrench = S_l tau_dist  (5 x 6, minimum-norm solution: Eigen BDCSVD::solve).
+// pinocchio's pieces restated from first principles: M by sums over bodies; g = dU/dq; C' v — pinocchio's Coriolis matrix satisfies
+// Mdot = C + C' and C v = nle - g, hence C' v = Mdot v - C v = d(1/2 v' M(q) v)/dq, the gradient of the kinetic energy at fixed v —
+// taken here with dual numbers over q; the 6-D frame Jacobian (LOCAL_WORLD_ALIGNED) of contact frame i from the geometric Jacobian.
+struct ContactForceState {
+  double z[HB_NV] = {0};   // pSCgZinvlast_ (zero at construction, :58-59)
+};
+// q, v: pinocchio coordinates [pos, zyx, joints] and their rates.  Outputs of the rigid-body part, exposed for the reference stand-ins:
+// M (16 x 16), g (16), CTv = C' v (16), J6[2][6][16] (linear rows then angular rows of contact frames 0 and 1).
+inline void contact_force_rbd(const hb_model& mdl, const double q[HB_NV], const double v[HB_NV], double M[HB_NV][HB_NV], double g[HB_NV],
+                              double CTv[HB_NV], double J6[2][6][HB_NV]) {
+  Kin<double> k;
+  k.compute(mdl, q);
+  for (int i = 0; i < HB_NV; ++i) {
+    g[i] = 0.0;
+    for (int j = 0; j < HB_NV; ++j) M[i][j] = 0.0;
+  }
+  for (int b = 0; b < HB_NBODY; ++b) {
+    V3<double> jc[HB_NV], jw[HB_NV];
+    for (int j = 0; j < HB_NV; ++j) { jc[j] = k.lin_jac(b, k.c[b], j); jw[j] = k.ang_jac(b, j); }
+    for (int i = 0; i < HB_NV; ++i) {
+      g[i] += mdl.mass[b] * mdl.gravity * jc[i].z;   // dU/dq_i, U = sum m g z
+      const V3<double> Iwi = k.Iw[b] * jw[i];
+      for (int j = 0; j < HB_NV; ++j) M[i][j] += mdl.mass[b] * dot3(jc[i], jc[j]) + dot3(Iwi, jw[j]);
+    }
+  }
+  // kinetic energy with dual q (16 tangents), v fixed
+  using DQ = Dual<HB_NV>;
+  DQ qd[HB_NV];
+  for (int i = 0; i < HB_NV; ++i) qd[i] = DQ::seed(q[i], i);
+  Kin<DQ> kd;
+  kd.compute(mdl, qd);
+  DQ T(0.0);
+  for (int b = 0; b < HB_NBODY; ++b) {
+    V3<DQ> vc, w;
+    for (int j = 0; j < HB_NV; ++j) {
+      vc = vc + DQ(v[j]) * kd.lin_jac(b, kd.c[b], j);
+      w = w + DQ(v[j]) * kd.ang_jac(b, j);
+    }
+    T = T + DQ(0.5 * mdl.mass[b]) * dot3(vc, vc) + DQ(0.5) * dot3(w, kd.Iw[b] * w);
+  }
+  for (int i = 0; i < HB_NV; ++i) CTv[i] = T.d[i];
+  for (int f = 0; f < 2; ++f) {
+    const int b = mdl.contact_body[f];
+    const V3<double> p = k.contact_point(mdl, f);
+    for (int c = 0; c < HB_NV; ++c) {
+      const V3<double> l = k.lin_jac(b, p, c), a = k.ang_jac(b, c);
+      for (int r = 0; r < 3; ++r) { J6[f][r][c] = l[r]; J6[f][3 + r][c] = a[r]; }
+    }
+  }
+}
+// minimum-norm solution of the 5 x 6 system A w = b by the pseudo-inverse (eigen-decomposition of A A'; singular values below
+// epsilon * 6 * sigma_max are dropped, as Eigen's SVD solvers do by default)
+inline void min_norm_solve_5x6(const double A[5][6], const double b[5], double w[6]) {
+  Mat G(5, 5);
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 5; ++j) {
+      double s = 0;
+      for (int c = 0; c < 6; ++c) s += A[i][c] * A[j][c];
+      G(i, j) = s;
+    }
+  Vec ev;
+  Mat V;
+  sym_eig(G, ev, V);
+  const double smax = std::sqrt(std::max(ev.back(), 0.0)), thr = 2.220446049250313e-16 * 6.0 * smax;
+  double y[5] = {0, 0, 0, 0, 0};
+  for (int e = 0; e < 5; ++e) {
+    if (!(ev[size_t(e)] > 0.0) || std::sqrt(ev[size_t(e)]) <= thr) continue;
+    double vb = 0;
+    for (int i = 0; i < 5; ++i) vb += V(i, e) * b[i];
+    for (int i = 0; i < 5; ++i) y[i] += V(i, e) * vb / ev[size_t(e)];
+  }
+  for (int c = 0; c < 6; ++c) {
+    double s = 0;
+    for (int i = 0; i < 5; ++i) s += A[i][c] * y[i];
+    w[c] = s;
+  }
+}
+// One call of estContactForce.  rbd[32] as everywhere; tau[10] = the joint efforts handed to setCmdTorque.
+// dist[16] = estDisturbancetorque_, cf[16] = estContactforce_ = [wrench leg 0 (6) | wrench leg 1 (6) | |F0| |F1| | |W0| |W1|].
+inline void contact_force_estimate(const hb_model& mdl, double cutoff_frequency, ContactForceState& st, double dt, const double rbd[HB_NRBD],
+                                   const double tau[HB_NJ], double dist[HB_NV], double cf[16]) {
+  if (dt > 1) dt = 0.002;   // (:133-134)
+  const double gama = std::exp(-cutoff_frequency * dt), beta = (1 - gama) / (gama * dt);
+  double q[HB_NV], v[HB_NV], rates[3];
+  euler_rates_from_global_omega(rbd, rbd + HB_NV, rates);
+  for (int i = 0; i < 3; ++i) { q[i] = rbd[3 + i]; q[3 + i] = rbd[i]; v[i] = rbd[HB_NV + 3 + i]; v[3 + i] = rates[i]; }
+  for (int j = 0; j < HB_NJ; ++j) { q[6 + j] = rbd[6 + j]; v[6 + j] = rbd[6 + HB_NV + j]; }
+  double M[HB_NV][HB_NV], g[HB_NV], CTv[HB_NV], J6[2][6][HB_NV];
+  contact_force_rbd(mdl, q, v, M, g, CTv, J6);
+  for (int i = 0; i < HB_NV; ++i) {
+    double p = 0;
+    for (int j = 0; j < HB_NV; ++j) p += M[i][j] * v[j];
+    const double w = beta * p + (i >= 6 ? tau[i - 6] : 0.0) + CTv[i] - g[i];
+    st.z[i] = (1 - gama) * w + gama * st.z[i];
+    dist[i] = beta * p - st.z[i];
+  }
+  for (int leg = 0; leg < 2; ++leg) {
+    double A[5][6], b[5];
+    for (int kk = 0; kk < 5; ++kk) {
+      for (int c = 0; c < 6; ++c) A[kk][c] = J6[leg][c][6 + 5 * leg + kk];
+      b[kk] = dist[6 + 5 * leg + kk];
+    }
+    min_norm_solve_5x6(A, b, cf + 6 * leg);
+  }
+  for (int i = 0; i < 2; ++i) {
+    const double* w = cf + 6 * i;
+    cf[12 + i] = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    cf[14 + i] = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3] + w[4] * w[4] + w[5] * w[5]);
+  }
 }
 
 }  // namespace orc

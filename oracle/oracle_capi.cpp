@@ -436,6 +436,25 @@ void orc_kf_update(const hb_model* mdl, const hb_estimator_config* cfg, int n, d
   }
 }
 
+// StateEstimateBase::estContactForce, batched.  z[n][16] (pSCgZinvlast_) in/out; dist[n][16], cf[n][16] out.
+void orc_contact_force(const hb_model* mdl, double cutoff_frequency, int n, double dt, double* z, const double* rbd, const double* tau,
+                       double* dist, double* cf) {
+  for (int i = 0; i < n; ++i) {
+    ContactForceState st;
+    std::memcpy(st.z, z + size_t(i) * HB_NV, HB_NV * 8);
+    contact_force_estimate(*mdl, cutoff_frequency, st, dt, rbd + size_t(i) * HB_NRBD, tau + size_t(i) * HB_NJ, dist + size_t(i) * HB_NV,
+                           cf + size_t(i) * 16);
+    std::memcpy(z + size_t(i) * HB_NV, st.z, HB_NV * 8);
+  }
+}
+// its rigid-body part at pinocchio coordinates q, v: M (16 x 16), g (16), C'v (16), the 6-D Jacobians of contact frames 0 / 1 (2 x 6 x 16)
+void orc_contact_force_rbd(const hb_model* mdl, const double* q, const double* v, double* M, double* g, double* CTv, double* J6) {
+  double Mm[HB_NV][HB_NV], Jm[2][6][HB_NV];
+  contact_force_rbd(*mdl, q, v, Mm, g, CTv, Jm);
+  std::memcpy(M, Mm, sizeof Mm);
+  std::memcpy(J6, Jm, sizeof Jm);
+}
+
 void orc_centroidal_state_from_rbd(const hb_model* mdl, int n, const double* rbd, double* x) {
   for (int i = 0; i < n; ++i) centroidal_state_from_rbd(*mdl, rbd + size_t(i) * HB_NRBD, x + size_t(i) * HB_NX);
 }

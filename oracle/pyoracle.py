@@ -229,6 +229,24 @@ class Oracle:
                                C.byref(it))
         return x, st, it.value
 
+    # ---- contact-force estimate (StateEstimateBase::estContactForce) ------------------------------------
+    def contact_force(self, cutoff_frequency, dt, z, rbd, tau):
+        """z [n][16] is updated in place (pSCgZinvlast_); -> (estDisturbancetorque_ [n][16], estContactforce_ [n][16])."""
+        c = lambda a: np.ascontiguousarray(np.atleast_2d(a), dtype=np.float64)
+        rbd, tau = c(rbd), c(tau)
+        n = rbd.shape[0]
+        assert z.flags.c_contiguous and z.shape == (n, 16) and z.dtype == np.float64
+        dist, cf = np.zeros((n, 16)), np.zeros((n, 16))
+        self.lib.orc_contact_force(C.byref(self.model), C.c_double(cutoff_frequency), C.c_int(n), C.c_double(dt), _opt(z), _opt(rbd), _opt(tau),
+                                   _opt(dist), _opt(cf))
+        return dist, cf
+
+    def contact_force_rbd(self, q, v):
+        q, v = np.ascontiguousarray(q, dtype=np.float64), np.ascontiguousarray(v, dtype=np.float64)
+        o = dict(M=np.zeros((16, 16)), g=np.zeros(16), CTv=np.zeros(16), J6=np.zeros((2, 6, 16)))
+        self.lib.orc_contact_force_rbd(C.byref(self.model), _opt(q), _opt(v), _opt(o["M"]), _opt(o["g"]), _opt(o["CTv"]), _opt(o["J6"]))
+        return o
+
     # ---- hierarchical QP / HierarchicalWbc ------------------------------------------------------------
     def hoqp(self, tasks, eps=1e-8, max_iter=500, reg_steps=1):
         """tasks: list (highest priority first) of dicts with optional A,b (A x = b) and D,f (D x <= f)."""

@@ -88,6 +88,30 @@ void refkf_settings(void* hv, double* out7) {
   std::memcpy(out7, v, sizeof v);
 }
 
+// StateEstimateBase::loadSettings (StateEstimateBase.cpp:365-377): the contactForceEsimation block of task.info
+void refkf_load_contact_force_settings(void* hv, const char* task_file, double* out2) {
+  Handle& h = *static_cast<Handle*>(hv);
+  h.kf->StateEstimateBase::loadSettings(task_file, false);
+  out2[0] = h.kf->cutoffFrequency_;
+  out2[1] = h.kf->contactThreshold_;
+}
+// setCmdTorque + estContactForce (LeggedController.cpp:344-345; StateEstimateBase.cpp:130-206) on the rbd state the object holds (the one
+// the last refkf_update left).  The pinocchio results it reads are FED: M (16 x 16), g, C'v with its v, the angular rows of the 6-D
+// Jacobians of contact frames 0 / 1, the linear rows of the contact Jacobians (12 x 16) — all from the oracle's contact_force_rbd at the
+// q, v estContactForce builds.  Out: estDisturbancetorque_ (16), estContactforce_ (16), pSCgZinvlast_ (16).
+void refkf_contact_force(void* hv, double dt, const double* tau, const double* M, const double* g, const double* CTv, const double* v,
+                         const double* Jlin, const double* Jang, double* dist, double* cf, double* z) {
+  Handle& h = *static_cast<Handle*>(hv);
+  ref_feed::Rbd& f = ref_feed::feed().role[0];
+  f.M = M; f.g = g; f.CTv = CTv; f.v = v; f.J = Jlin; f.Jang = Jang;
+  vector_t t(10);
+  for (int i = 0; i < 10; ++i) t(i) = tau[i];
+  h.kf->setCmdTorque(t);
+  h.kf->estContactForce(ros::Duration(dt));
+  for (int i = 0; i < 16; ++i) { dist[i] = h.kf->estDisturbancetorque_(i); cf[i] = h.kf->estContactforce_(i); z[i] = h.kf->pSCgZinvlast_(i); }
+  f.g = nullptr; f.CTv = nullptr; f.v = nullptr; f.Jang = nullptr;
+}
+
 // quatToZyx of StateEstimateBase.h:153-166 (a template in the reference's header)
 void refkf_quat_to_zyx(const double* quat_wxyz, double* zyx) {
   const Eigen::Quaternion<scalar_t> q(quat_wxyz[0], quat_wxyz[1], quat_wxyz[2], quat_wxyz[3]);

@@ -70,7 +70,10 @@ template <class JAC> void frame_jac(const Model& m, const Data& d, int frame, JA
   } else {
     const double* src = variation ? f.dJ : f.J;
     for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < m.nv; ++c) jac(r, c) = src[(3 * frame + r) * m.nv + c];  // angular rows stay as the caller initialised them (zero)
+      for (int c = 0; c < m.nv; ++c) jac(r, c) = src[(3 * frame + r) * m.nv + c];  // angular rows stay as the caller initialised them (zero) ...
+    if (!variation && f.Jang && frame < 2)   // ... unless the 6-D Jacobian is fed (estContactForce: contact frames 0 and 1)
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < m.nv; ++c) jac(3 + r, c) = f.Jang[(3 * frame + r) * m.nv + c];
   }
 }
 template <class JAC> void getFrameJacobian(const Model& m, const Data& d, size_t frame, ReferenceFrame rf, JAC& jac) {
@@ -130,8 +133,23 @@ template <class M3> Eigen::Matrix<double, 3, 1> log3(const M3& R) {
   const double t = (theta > 1.220703125e-4 /* eps^(1/4) */ ? theta / std::sin(theta) : 1.0) / 2.0;
   return Eigen::Matrix<double, 3, 1>(t * (R(2, 1) - R(1, 2)), t * (R(0, 2) - R(2, 0)), t * (R(1, 0) - R(0, 1)));
 }
-// declared for legged_estimation/src/StateEstimateBase.cpp::estContactForce, which the golden vectors never run
-// (StateEstimateBase::estContactForce reads data.C and data.g; its result has no consumer in the reference: zeros of the right shape)
-inline void getCoriolisMatrix(const Model& m, Data& d) { d.C.setZero(m.nv, m.nv); }
-template <class Q> void computeGeneralizedGravity(const Model& m, Data& d, const Q&) { d.g.setZero(m.nv); }
+// legged_estimation/src/StateEstimateBase.cpp::estContactForce reads data.C only through data.C.transpose() * v, and data.g.
+// [pinocchio-knowledge] getCoriolisMatrix returns a C with Mdot = C + C' and C v = nle - g; any such C has C' v = d(1/2 v'M v)/dq.
+// The stand-in hands back the rank-one matrix v (C'v)' / (v'v), whose transpose times v is exactly the fed C'v (zero when v = 0).
+inline void getCoriolisMatrix(const Model& m, Data& d) {
+  d.C.setZero(m.nv, m.nv);
+  const ref_feed::Rbd& f = fed(d);
+  if (!f.CTv || !f.v) return;
+  double vv = 0.0;
+  for (int i = 0; i < m.nv; ++i) vv += f.v[i] * f.v[i];
+  if (vv == 0.0) return;
+  for (int i = 0; i < m.nv; ++i)
+    for (int j = 0; j < m.nv; ++j) d.C(i, j) = f.v[i] * f.CTv[j] / vv;
+}
+template <class Q> void computeGeneralizedGravity(const Model& m, Data& d, const Q&) {
+  d.g.setZero(m.nv);
+  const ref_feed::Rbd& f = fed(d);
+  if (f.g)
+    for (int i = 0; i < m.nv; ++i) d.g(i) = f.g[i];
+}
 }  // namespace pinocchio

@@ -14,6 +14,11 @@ struct Rbd {                 // one pinocchio::Data worth of results
   const double* dJb = nullptr;    // 6 x 16
   const double* ee_pos = nullptr; // 4 x 3 contact positions
   const double* ee_vel = nullptr; // 4 x 3 contact velocities
+  // StateEstimateBase::estContactForce (fed by the oracle's contact_force_rbd)
+  const double* g = nullptr;      // 16 generalised gravity
+  const double* CTv = nullptr;    // 16 C(q, v)' v
+  const double* v = nullptr;      // 16 the velocity C' v belongs to
+  const double* Jang = nullptr;   // 2 x 3 x 16 angular rows of the 6-D Jacobians of contact frames 0 and 1
 };
 struct Feed {
   Rbd role[2];                    // 0: the "measured" interface, 1: the "desired" interface (copy order in WbcBase's constructor)

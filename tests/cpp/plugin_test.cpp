@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
 
   const double dt = 0.002;
   const int ticks = int(seconds / dt + 0.5);
-  double t = 0.0, max_tau = 0.0, max_tilt = 0.0, min_h = 1e9, max_h = -1e9, x_at_walk = 0.0;
+  double t = 0.0, max_tau = 0.0, max_tilt = 0.0, min_h = 1e9, max_h = -1e9, x_at_walk = 0.0, cf_fz_sum = 0.0;
   bool finite = true, hooks_ok = true, gains_seen = false, gains_bad = false, obs_ok = true;
   int modes_seen = 0;
   const double walk_from = 1.0;
@@ -148,6 +148,11 @@ int main(int argc, char** argv) {
       tau[j] = c[4] + c[2] * (c[0] - q[6 + j]) + c[3] * (c[1] - v[6 + j]);
       finite = finite && std::isfinite(tau[j]);
       max_tau = std::fmax(max_tau, std::fabs(tau[j]));
+      hw.eff[j] = tau[j];   // the effort the next tick's estContactForce reads (LeggedController.cpp:288, :344)
+    }
+    if (k == 240) {   // standing for 0.48 s: the momentum observer (cut-off 250 / s) has settled — the two legs carry the weight
+      const auto& cfv = hip->estContactForce();
+      cf_fz_sum = cfv.size() == 16 ? cfv[2] + cfv[8] : -1.0;
     }
     const int pm = hip->plannedMode();
     modes_seen |= 1 << pm;
@@ -164,8 +169,8 @@ int main(int argc, char** argv) {
   }
   ctrl->stopRequest(ros::Time(t));
   std::printf("RESULT ok 1 ticks %d finite %d max_tau %.6g min_h %.6g max_h %.6g max_tilt %.6g dx_walk %.6g speed %.6g modes_seen %d final_mode %d "
-              "hooks_ok %d gains_seen %d gains_bad %d obs_ok %d obs_count %ld\n",
+              "hooks_ok %d gains_seen %d gains_bad %d obs_ok %d obs_count %ld cf_fz_sum %.6g\n",
               ticks, finite ? 1 : 0, max_tau, min_h, max_h, max_tilt, q[0] - x_at_walk, v[0], modes_seen, hip->plannedMode(), hooks_ok ? 1 : 0,
-              gains_seen ? 1 : 0, gains_bad ? 1 : 0, obs_ok ? 1 : 0, ros::mock::publishCount()["legged_robot_mpc_observation"]);
+              gains_seen ? 1 : 0, gains_bad ? 1 : 0, obs_ok ? 1 : 0, ros::mock::publishCount()["legged_robot_mpc_observation"], cf_fz_sum);
   return 0;
 }

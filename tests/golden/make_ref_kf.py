@@ -32,6 +32,8 @@ lib.refkf_set_sensors.argtypes = [C.c_void_p, DP, DP, DP, DP, DP, IP, DP]
 lib.refkf_update.argtypes = [C.c_void_p, C.c_double, DP, DP, DP, DP, DP]
 lib.refkf_settings.argtypes = [C.c_void_p, DP]
 lib.refkf_quat_to_zyx.argtypes = [DP, DP]
+lib.refkf_load_contact_force_settings.argtypes = [C.c_void_p, C.c_char_p, DP]
+lib.refkf_contact_force.argtypes = [C.c_void_p, C.c_double] + [DP] * 10
 
 
 def quat_xyzw_from_zyx(zyx):
@@ -72,8 +74,12 @@ def main():
             st = np.zeros(7)
             lib.refkf_settings(h, _d(st))
             out["settings"] = st
-        ins = {k: [] for k in ("quat", "w", "a", "qj", "qdj", "contact")}
-        outs = {k: [] for k in ("rbd", "xhat", "P", "zyx")}
+        cfs = np.zeros(2)
+        lib.refkf_load_contact_force_settings(h, TASK_INFO.encode(), _d(cfs))   # contactForceEsimation block: cutoffFrequency, contactThreshold
+        out["contact_force_settings"] = cfs
+        trng = np.random.default_rng(100 + seed)
+        ins = {k: [] for k in ("quat", "w", "a", "qj", "qdj", "contact", "tau")}
+        outs = {k: [] for k in ("rbd", "xhat", "P", "zyx", "dist", "cf", "z")}
         for m in stream(params, name, ticks, seed):
             q_wxyz = np.array([m["quat"][3], m["quat"][0], m["quat"][1], m["quat"][2]])
             contact = np.ascontiguousarray(m["contact"], dtype=np.int32)
@@ -91,6 +97,19 @@ def main():
             lib.refkf_update(h, dt, _d(kin["ee_pos"]), _d(kin["ee_vel"]), _d(rbd), _d(xhat), _d(P))
             zyx = np.zeros(3)
             lib.refkf_quat_to_zyx(_d(q_wxyz), _d(zyx))
+            # setCmdTorque + estContactForce (LeggedController.cpp:344-345) on the rbd state the update left: q, v of StateEstimateBase.cpp:140-149
+            m["tau"] = 8.0 * trng.standard_normal(10)
+            qc = np.concatenate([rbd[3:6], rbd[0:3], rbd[6:16]])
+            zc, yc, wgc = rbd[0], rbd[1], rbd[16:19]
+            dxc = (np.cos(zc) * wgc[0] + np.sin(zc) * wgc[1]) / np.cos(yc)
+            vc = np.concatenate([rbd[19:22], [wgc[2] + np.sin(yc) * dxc, np.cos(zc) * wgc[1] - np.sin(zc) * wgc[0], dxc], rbd[22:32]])
+            cr = o.contact_force_rbd(qc, vc)
+            Jlin = np.ascontiguousarray(o.rbd_full(qc, vc)["J"])
+            Jang = np.ascontiguousarray(cr["J6"][:, 3:, :])
+            dist, cf, zf = np.zeros(16), np.zeros(16), np.zeros(16)
+            lib.refkf_contact_force(h, dt, _d(np.ascontiguousarray(m["tau"])), _d(cr["M"]), _d(cr["g"]), _d(cr["CTv"]), _d(np.ascontiguousarray(vc)),
+                                    _d(Jlin), _d(Jang), _d(dist), _d(cf), _d(zf))
+            outs["dist"].append(dist); outs["cf"].append(cf); outs["z"].append(zf)
             for k in ins:
                 ins[k].append(np.array(m[k]))
             outs["rbd"].append(rbd); outs["xhat"].append(xhat); outs["P"].append(P); outs["zyx"].append(zyx)

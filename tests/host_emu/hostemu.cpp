@@ -188,6 +188,15 @@ void emu_kf_update(const hb_model* m, const hb_estimator_config* k, double dt, d
 }
 
 extern "C" {
+// StateEstimateBase::estContactForce of the device code (hb_estimator.hpp contact_force_estimate) for one instance
+void emu_contact_force(const hb_model* m, double gama, double beta, const double* rbd, const double* tau, double* z, double* dist, double* cf) {
+  DevModel d = make_dev_model(*m);
+  CfLegWork wk;
+  contact_force_estimate(d, gama, beta, rbd, tau, z, dist, cf, wk);
+}
+}
+
+extern "C" {
 // the device's logarithm scheme (hb_math.hpp log_fd), host build
 void emu_log_fd(const double* x, int n, double* y) {
   for (int i = 0; i < n; ++i) y[i] = log_fd(x[i]);

@@ -45,6 +45,29 @@ def test_oracle_filter_matches_reference_filter(gold, params, oracle):
             assert np.abs(st["P"][0] - Pr).max() < 1e-12 * max(1.0, np.abs(Pr).max()), (name, k)
 
 
+def test_oracle_contact_force_estimate_matches_reference_estContactForce(gold, params, oracle):
+    """StateEstimateBase::estContactForce (StateEstimateBase.cpp:130-206, called every tick at LeggedController.cpp:344-345) compiled
+    and run on the rbd state the filter update left, tick after tick on one object (the low-pass state pSCgZinvlast_ persists): the
+    momentum observer's disturbance torque (16), the two legs' wrenches and their norms (16), the filter state (16).  What is fed into
+    the reference are pinocchio's results (M, g, C'v, Jacobians: the oracle's); what is pinned is everything the reference does with
+    them — beta / gamma, the S' tau selection, the leg rows, the minimum-norm solve of the 5 x 6 system, the norms."""
+    cutoff = float(gold["contact_force_settings"][0])
+    assert cutoff == params["config"]["kalman"]["contact_force_cutoff_frequency"] == 250.0
+    assert float(gold["contact_force_settings"][1]) == params["config"]["kalman"]["contact_threshold"] == 75.0
+    dt = float(gold["dt"])
+    for name in gold["streams"]:
+        z = np.zeros((1, 16))
+        for k in range(len(gold[f"{name}_tau"])):
+            dist, cf = oracle.contact_force(cutoff, dt, z, gold[f"{name}_out_rbd"][k], gold[f"{name}_tau"][k])
+            scale = max(1.0, np.abs(gold[f"{name}_out_dist"][k]).max())
+            assert np.abs(dist[0] - gold[f"{name}_out_dist"][k]).max() < 1e-10 * scale, (name, k)
+            assert np.abs(z[0] - gold[f"{name}_out_z"][k]).max() < 1e-10 * scale, (name, k)
+            assert np.abs(cf[0] - gold[f"{name}_out_cf"][k]).max() < 1e-9 * max(1.0, np.abs(gold[f"{name}_out_cf"][k]).max()), (name, k)
+    # a robot at rest: the observer settles on the weight in the base-z row, the legs' wrenches carry it
+    m = sum(params["model"]["mass"])
+    assert abs(gold["standing_out_dist"][-1][2] - m * 9.81) < 1e-3 * m * 9.81
+
+
 @pytest.mark.gpu
 def test_device_filter_matches_reference_filter(gold, params):
     from hunter_bipedal_control_amd.solver import HunterSolver
@@ -66,3 +89,54 @@ def test_device_filter_matches_reference_filter(gold, params):
                 assert np.abs(P[i] - Pr).max() < 1e-9 * max(1.0, np.abs(Pr).max()), (n, k)
     finally:
         s.close()
+
+
+def test_device_contact_force_algorithm_on_the_host_emulator_matches_reference(gold, params):
+    """hb_estimator.hpp::contact_force_estimate — one inward pass over composite momenta instead of crba / getCoriolisMatrix /
+    computeGeneralizedGravity / getFrameJacobian — compiled for the host, against the reference's compiled estContactForce."""
+    import ctypes as C
+    import _hostemu
+    lib = C.CDLL(str(_hostemu.build()))
+    mdl = abi.make_model(params)
+    cutoff, dt = float(gold["contact_force_settings"][0]), float(gold["dt"])
+    gama = np.exp(-cutoff * dt)
+    beta = (1 - gama) / (gama * dt)
+    _p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for name in gold["streams"]:
+        z = np.zeros(16)
+        for k in range(len(gold[f"{name}_tau"])):
+            rbd, tau = np.ascontiguousarray(gold[f"{name}_out_rbd"][k]), np.ascontiguousarray(gold[f"{name}_tau"][k])
+            dist, cf = np.zeros(16), np.zeros(16)
+            lib.emu_contact_force(C.byref(mdl), C.c_double(gama), C.c_double(beta), _p(rbd), _p(tau), _p(z), _p(dist), _p(cf))
+            scale = max(1.0, np.abs(gold[f"{name}_out_dist"][k]).max())
+            assert np.abs(dist - gold[f"{name}_out_dist"][k]).max() < 1e-9 * scale, (name, k)
+            assert np.abs(z - gold[f"{name}_out_z"][k]).max() < 1e-9 * scale, (name, k)
+            assert np.abs(cf - gold[f"{name}_out_cf"][k]).max() < 1e-8 * max(1.0, np.abs(gold[f"{name}_out_cf"][k]).max()), (name, k)
+
+
+@pytest.mark.gpu
+def test_device_contact_force_matches_reference_estContactForce(gold, params):
+    """hb_estimator_contact_force through the C-ABI: the four sensor streams as a batch of four, tick after tick (observer state on the
+    device), once on the rbd state the device filter itself left behind (rbd = NULL) and once on the reference's rbd handed in."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    names = [str(n) for n in gold["streams"]]
+    ticks = min(len(gold[f"{n}_quat"]) for n in names)
+    B = len(names)
+    ecfg = abi.make_estimator_config(params)
+    for resident in (True, False):
+        s = HunterSolver(params, batch=B, max_nodes=4)
+        try:
+            s.estimator_reset(ecfg)
+            for k in range(ticks):
+                args = [np.stack([gold[f"{n}_{key}"][k] for n in names]) for key in KEYS]
+                s.estimator_update(float(gold["dt"]), *args)
+                tau = np.stack([gold[f"{n}_tau"][k] for n in names])
+                rbd = None if resident else np.stack([gold[f"{n}_out_rbd"][k] for n in names])
+                dist, cf = s.estimator_contact_force(float(gold["dt"]), tau, rbd)
+                for i, n in enumerate(names):
+                    scale = max(1.0, np.abs(gold[f"{n}_out_dist"][k]).max())
+                    tol = 1e-7 if resident else 1e-9      # (resident: the device filter's own rbd, 1e-10 from the reference's, times beta ~ 5e2)
+                    assert np.abs(dist[i] - gold[f"{n}_out_dist"][k]).max() < tol * scale, (resident, n, k)
+                    assert np.abs(cf[i] - gold[f"{n}_out_cf"][k]).max() < 10 * tol * max(1.0, np.abs(gold[f"{n}_out_cf"][k]).max()), (resident, n, k)
+        finally:
+            s.close()

@@ -82,3 +82,6 @@ def test_plugin_control_plane_hooks():
     assert res["hooks_ok"] == "1" and res["gains_seen"] == "1" and res["gains_bad"] == "0", res
     assert res["obs_ok"] == "1" and int(res["obs_count"]) >= 590, res
     assert 0.60 < float(res["min_h"]) and float(res["max_h"]) < 0.66 and float(res["max_tilt"]) < 0.08, res
+    # estContactForce behind every estimator update (LeggedController.cpp:344-345) on the measured joint efforts: standing, the
+    # momentum observer's two leg wrenches carry the robot's weight (12.587 kg)
+    assert abs(float(res["cf_fz_sum"]) - 12.586944 * 9.81) < 0.1 * 12.586944 * 9.81, res

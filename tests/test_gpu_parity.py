@@ -470,6 +470,8 @@ def test_error_conventions(params):
         s.set_references(refs)
         with pytest.raises(HunterHipError):
             s.wbc_update(t_now, rbd)                             # HB_ERR_STATE: nothing published
+        with pytest.raises(HunterHipError, match="hb_estimator_reset"):
+            s.estimator_contact_force(0.002, np.zeros((2, 10)), rbd)   # HB_ERR_STATE: the estimator carries its settings and state
     finally:
         s.close()
 

@@ -754,7 +754,8 @@ HB_HD void hwbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, cons
 #if defined(__HIP_DEVICE_COMPILE__)
   double rinv = 0.0;      // 1 / R_jj of that factor (lane j)
 #endif
-  for (int phase = 0; phase <= C.wbc_reg_steps && status == 0; ++phase) {
+  const int n_reg = C.wbc_reg_steps > 0 ? C.wbc_reg_steps : 0;   // (phase 0 — the solve with every constraint — runs whatever the field holds)
+  for (int phase = 0; phase <= n_reg && status == 0; ++phase) {
   if (phase > 0) {
     for (int i = cx.lane; i < NW; i += cx.nlanes) { np[i] = x[i] - xc[i]; xc[i] = x[i]; }   // x_k - x_{k-1}; the new centre
     cx.sync();

@@ -76,6 +76,7 @@ struct Batch {
   int* modep;       // [B][Nmax]
   int* np_nodes;    // [B]
   int* grid_dirty;  // [B] the node tables changed since the iterate was last brought onto them
+  double* lqpark;   // [B][Nmax + LqPark::trip_max][LqPark::size]: phase-1 images of the nodes, parked by the value phase of k_lq_trip
 };
 
 __global__ void k_set_x0(Batch b) {
@@ -243,6 +244,77 @@ __global__ __launch_bounds__(64, 3) void k_lq(Batch b, const DevModel* __restric
   }
   in.mode = __builtin_amdgcn_readfirstlane(mode_v);  // (uniform by construction; tells the compiler so: mode tests become scalar)
   lq_node(WaveCtx(), *M, *C, in, lds, b.recs + nd * REC_SIZE);
+}
+
+// The LQ approximation of a TRIP of up to 2^tshift consecutive nodes of an instance per wavefront (hb_lq.hpp lq_trip_values): the
+// lane-sparse value phases of all the trip's nodes at once, one (node, leg evaluation) pair per lane, their phase-1 images parked in
+// global memory; then node after node: image -> LDS, direction pass, tail.  The arithmetic of a node does not depend on the trip
+// length (a lane's work is the same whatever its neighbours do), so launches that cut the batch differently agree bit for bit.
+__global__ __launch_bounds__(64, 3) void k_lq_trip(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C, int tshift) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the value phase exists for the device only)
+  // Workgroups are handed out in the order of their index: every instance's FULL trips first, the short last trip of each horizon
+  // (N = 100, 16 nodes a trip: six full trips and one of four nodes) at the end of the grid, where it fills the gaps the full trips leave
+  // on the chip — 4096 x 6 full trips are exactly eight rounds of the 3072 wavefront slots.  (longest job first)
+  int trip, inst;
+  {
+    const int ntrip = (b.Nmax + (1 << tshift) - 1) >> tshift, g = blockIdx.x, nfull = (ntrip - 1) * b.B;
+    if (g < nfull) { inst = g / (ntrip - 1); trip = g - inst * (ntrip - 1); }
+    else { inst = g - nfull; trip = ntrip - 1; }
+    if (ntrip == 1) { inst = g; trip = 0; }
+  }
+  __shared__ double lds[LqLds::total + HB_LQ_LDS_PAD];
+  const int n_nodes = b.n_nodes[inst];
+  const int k0 = trip << tshift;
+  if (k0 >= n_nodes) return;
+  const int nt = min(1 << tshift, n_nodes - k0);
+  const double* tt = b.t + size_t(inst) * (b.Nmax + 1);
+  double* park = b.lqpark + (size_t(inst) * (b.Nmax + LqPark::trip_max) + k0) * LqPark::size;   // the trip's parked data (LqPark)
+  lq_trip_stage_constants(*M, lds, threadIdx.x);
+  WaveCtx().sync();
+  // (profiling build, 125: the value phase runs once per trip, later launches re-use what it parked — the dense part alone on valid data)
+  if (!(HB_ABLATE_ON && C->debug_stop == 125 && park[size_t(LqPark::n_feet / 4 << tshift) * 16] != 0.0)) {
+    // every lane runs the value phase (the staged stores are the whole wavefront's work)
+    lq_trip_values(LqTrip{lds, park, tshift, nt, int(threadIdx.x), HB_ABLATE_ON ? C->debug_stop : 0}, *M, *C, b.x + size_t(inst) * (b.Nmax + 1) * HB_NX, b.u + size_t(inst) * b.Nmax * HB_NU,
+                   b.swing + size_t(inst) * b.Nmax * 24, tt, b.mode + size_t(inst) * b.Nmax, k0);
+  }
+  // the images are read back by other lanes of this wavefront: stores complete before the first load is issued
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (HB_ABLATE_ON && C->debug_stop >= 126 && C->debug_stop <= 128) return;   // profiling build: the value phase alone (127 / 128: parts of it)
+  for (int t = 0; t < nt; ++t) {
+    // (the lane id is rebuilt from an opaque copy every node: as loop invariants the compiler hoists the per-lane offsets of the whole
+    // node out of the loop and spills them — as in k_ric_bwd)
+    int l = threadIdx.x;
+    asm volatile("" : "+v"(l));
+    l &= 63;   // (the range is what lets the compiler turn the lane-strided loops of the node into single passes)
+    const WaveCtx cx(l);
+    const int k = k0 + t;
+    const size_t nd = size_t(inst) * b.Nmax + k;
+    NodeIn in;
+    in.x = b.x + (size_t(inst) * (b.Nmax + 1) + k) * HB_NX;
+    in.xnext = in.x + HB_NX;
+    in.u = b.u + nd * HB_NU;
+    in.xref = b.xref + nd * HB_NX;
+    in.swing = b.swing + nd * 24;
+    double x_lane = 0.0, u_lane = 0.0;
+    if (l < HB_NX) { x_lane = in.x[l]; u_lane = in.u[l]; }
+    {
+      const double dtv = tt[k + 1] - tt[k];  // (uniform: kept in a scalar register pair for the whole node)
+      const long long bits = __builtin_bit_cast(long long, dtv);
+      const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(bits)), hi = __builtin_amdgcn_readfirstlane(unsigned(bits >> 32));
+      in.dt = __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+    }
+    in.mode = __builtin_amdgcn_readfirstlane(b.mode[nd]);
+    lq_image_to_lds(park, t, tshift, lds, l);
+    if (l < HB_NX) { lds[LqLds::xs + l] = x_lane; lds[LqLds::us + l] = u_lane; }
+    cx.sync();
+    const double* park_lds = lds + LqLds::park;
+    const double* xnext_lds = lds + LqLds::xnext_park;
+    lq_node_dense(cx, *M, *C, in, lds, b.recs + nd * REC_SIZE, [park_lds](int i) { return park_lds[i]; }, [xnext_lds](int i) { return xnext_lds[i]; });
+    cx.sync();
+  }
+#endif
 }
 
 constexpr int kRicBwd4MaxBatch = 512;    // instances per launch up to which the four-wavefront backward sweep is taken (measured)
@@ -1065,7 +1137,7 @@ struct ErrSlot {
 };
 
 struct hb_ctx {
-  int device = 0, B = 0, Nmax = 0;
+  int device = 0, B = 0, Nmax = 0, n_cu = 256;
   // Guards the host-side state both threads touch while ENQUEUEING work (policy hand-over flags, counters); never held across
   // a device synchronisation.
   std::mutex mtx;
@@ -1183,6 +1255,13 @@ int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch,
     g_create_error = "hb_create: model topology is not base + two 5-joint legs";
     return HB_ERR_ARG;
   }
+  // (the struct has grown over the rounds and carries no size field: a caller built against an older, smaller hb_config makes the library
+  // read past its end — fields that gate loops are therefore range-checked, and the tail word must be the documented 0)
+  if (config->wbc_reg_steps < 0 || config->wbc_reg_steps > HB_WBC_REG_STEPS_MAX || config->reserved2 != 0 || config->wbc_max_iter <= 0 ||
+      !(config->wbc_eps_reg > 0.0)) {
+    g_create_error = "hb_create: hb_config.wbc_reg_steps outside [0, 8], reserved2 != 0, wbc_max_iter <= 0 or wbc_eps_reg <= 0 (struct built against another header?)";
+    return HB_ERR_ARG;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) {
     g_create_error = "hb_create: no HIP device visible (the solver has no CPU fallback)";
@@ -1205,6 +1284,10 @@ int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch,
   };
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ctx->n_cu = ncu;
+  }
   if ((e = hipStreamCreateWithFlags(&ctx->s_mpc, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
   if ((e = hipStreamCreateWithFlags(&ctx->s_wbc, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
   for (auto& ev : ctx->ev)
@@ -1246,6 +1329,7 @@ int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch,
   A(b.modep, B * N);
   A(b.np_nodes, B);
   A(b.grid_dirty, B);
+  A(b.lqpark, B * (N + LqPark::trip_max) * LqPark::size);
   WbcBatch& w = ctx->w;
   w.B = batch;
   A(w.t_now, B);
@@ -2011,7 +2095,7 @@ static Batch batch_view(const Batch& b, int i0, int cnt) {
   v.x += o * (N + 1) * HB_NX; v.u += o * N * HB_NU; v.x0 += o * HB_NX; v.recs += o * N * REC_SIZE; v.gains += o * N * GAIN_SIZE;
   v.dx += o * (N + 1) * HB_NX; v.du += o * N * HB_NU; v.acc += o * 4; v.partial += o * N * 3; v.ls_tail += o * LS_TAIL_MAX * N * 3; v.ls_norm += o * 2; v.accepted += o; v.perf += o * 4;
   v.ric_fail += o; v.mpc_status += o; v.xp += o * (N + 1) * HB_NX; v.up += o * N * HB_NU; v.tp += o * (N + 1); v.modep += o * N;
-  v.np_nodes += o; v.grid_dirty += o;
+  v.np_nodes += o; v.grid_dirty += o; v.lqpark += o * (N + LqPark::trip_max) * LqPark::size;
   return v;
 }
 static WbcBatch wbc_view(const WbcBatch& w, int Nmax, int i0, int cnt) {
@@ -2050,6 +2134,27 @@ static void launch_ric_bwd(hb_ctx* ctx, const Batch& b, int B, int concurrent, h
   else hipLaunchKernelGGL(k_ric_bwd, dim3(B), dim3(64), 0, s, b, sel);
 }
 
+// LQ approximation: trips of 2^tshift nodes per wavefront (k_lq_trip).  Longer trips fill the lanes of the value phase better (16 nodes:
+// all 64) — measured best or equal at 512 .. 4096 instances —, shorter ones keep small batches spread over the chip: the longest trip
+// that still gives every wavefront slot of the chip (12 per CU) a trip of the CONCURRENT batch.  The result does not depend on the
+// choice.  hb_config.reserved = 120 + s forces 2^s; 129 the one-node-per-wavefront kernel of rounds 1-5 (k_lq: cooperative leg
+// pass; A / B only, differs from the trips by rounding).
+constexpr int kLqTripsPerSlot = 1;
+static int lq_trip_shift(const hb_ctx* ctx, int concurrent) {
+  const int sel = ctx->hconfig.debug_stop;
+  if (sel >= 120 && sel <= 124) return sel - 120;
+  const long slots = 12L * ctx->n_cu;
+  for (int sh = 4; sh > 0; --sh)
+    if (long(concurrent) * ((ctx->Nmax + (1 << sh) - 1) >> sh) >= kLqTripsPerSlot * slots) return sh;
+  return 0;
+}
+static void launch_lq(hb_ctx* ctx, const Batch& b, int B, int concurrent, hipStream_t s) {
+  if (ctx->hconfig.debug_stop == 129) { hipLaunchKernelGGL(k_lq, dim3(ctx->Nmax, B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig); return; }
+  const int sh = lq_trip_shift(ctx, concurrent);
+  const int ntrip = (ctx->Nmax + (1 << sh) - 1) >> sh;
+  hipLaunchKernelGGL(k_lq_trip, dim3(unsigned(ntrip) * B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, sh);
+}
+
 // Forward sweep: the wave form while the batch leaves a SIMD one wavefront (hb_config.reserved = 111 / 114 force the row / the wave form)
 static void launch_ric_fwd(hb_ctx* ctx, const Batch& b, int B, int concurrent, hipStream_t s) {
   const int sel = ctx->hconfig.debug_stop;
@@ -2070,7 +2175,7 @@ static int32_t mpc_iterations(hb_ctx* ctx, int i0 = 0, int cnt = -1, hipStream_t
     const bool timed = (it == 0) && whole;
     hipLaunchKernelGGL(k_set_x0, dim3((B * HB_NX + 255) / 256), dim3(256), 0, s, b);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[0], s));
-    hipLaunchKernelGGL(k_lq, dim3(N, B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig);
+    launch_lq(ctx, b, B, ctx->B, s);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[1], s));
     launch_ric_bwd(ctx, b, B, ctx->B, s);
     if (timed) HB_HIP(hipEventRecord(ctx->ev[2], s));

@@ -1144,6 +1144,392 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
 }
 
+// Everything behind the value passes of one node: direction pass, closed-form directions, then lq_tail.  Expects the phase-1 image of
+// the node in LDS (LqLds: x, u, leg blocks incl. the point's uniform values in their LEGJ_MS slots, leg values, sin / cos pairs,
+// f(x, u), f(x_e, u) in the x_e slot, constraint-row values, contact point - COM waiting in the CDt rows of the base-position directions) —
+// written by the value passes of lq_node or copied from the parked image the trip kernel's lane-dense value phase leaves (lq_trip_*).
+template <class Ctx, class XR, class XN>
+HB_HD void lq_node_dense(const Ctx& cx, const DevModel& M, const DevConfig& C, const NodeIn& in, double* lds, double* rec, XR xref_at, XN xnext_at) {
+  const LqP1 P1 = lq_p1(lds);
+  // ---- stage 2: tangents of the whole-body combine per (point, direction).  Only 29 of the 44 directions are nonlinear (momentum
+  // 0..5, zyx 9..11, joints 12..21, joint rates 34..43), so both RK2 points fit ONE pass of the wave: task = 29 pt + index.
+  for (int task = cx.lane; task < 58; task += cx.nlanes) lq_tangent_task(M, C, lds, in.mode, task >= 29 ? 1 : 0, task >= 29 ? task - 29 : task);
+  cx.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (contact point - COM) of both points for the contact-force directions of the compose: from their waiting place to the slot of the
+  // contact's velocity, which the pass has finished with
+  if (cx.lane < 24) {
+    const int pt = cx.lane / 12, e = cx.lane - 12 * pt;
+    lds[LqLds::fr_slot(pt, e / 3) + e % 3] = (P1.CDt + 6 * 12)[cx.lane];
+  }
+  cx.sync();
+#endif
+  HB_ABLATE_STOP(C.debug_stop == 9);
+  // constraint rows of the base-position directions (closed form)
+  for (int task = cx.lane; task < 3; task += cx.nlanes) lq_closed_task(C, lds, in.mode, task);
+  cx.sync();
+  lq_tail(cx, M, C, in, lds, rec, xref_at, xnext_at);
+}
+
+// ---- lane-dense value phase of a TRIP of nodes (k_lq, round 6) -------------------------------------------------------------------
+// The leg value passes (one task per (leg evaluation, joint): 20 lanes) and the whole-body value passes (4 lanes) of a node are the
+// lane-sparse part of the LQ approximation — 29 % of the kernel's wave-instructions at <= 31 % lane occupancy when every node runs them
+// on its own wavefront.  A wavefront now takes a trip of up to 16 consecutive nodes of an instance: it first runs those phases for ALL
+// nodes of the trip at once, one (node, leg evaluation) pair per lane — lane 4 t + e, e = 2 point + leg: a serial leg pass without
+// cross-lane scans (lq_trip_leg_pass) and, on the same four lanes, the value pass of contact point e; the two legs / two points of
+// a node meet through LDS and quad permutes —, leaves every node's phase-1 data in global memory, and then walks the nodes: parked
+// data -> the LDS image lq_node_dense expects, direction pass, tail.
+// Parked layout: every lane owns LqPark::per_lane doubles; entry n of lane (t, e) of a trip of T nodes lies at
+//   ((n >> 2) T + t) 16 + ((n & 3) >> 1) 8 + 2 e + (n & 1)        (doubles from the trip's base)
+// i.e. 128-byte lines that belong to ONE node (4 entries x 4 leg evaluations), the lines of the trip's nodes side by side, and inside
+// a line the entry PAIRS (n even, n + 1) of a leg evaluation together: a lane of the value phase stores two entries at once (16 bytes),
+// the four lanes of a node 64 contiguous bytes, and a node's data is read back as whole lines whose 16-byte pairs are two consecutive
+// LDS doubles.  (Stored one entry = 8 bytes a lane, a store instruction of the phase cost the memory pipeline ~76 cycles and the phase
+// was 1.1 ms of store issue; staged through an LDS tile into whole-line stores it was bound by the tile's round trips.)  Entries of a lane:
+//   0..199   the five joint blocks of its leg evaluation (LEGJ layout)     200..205 its two contact points
+//   206..211 the leg's joint-induced contact-point velocities              212..214 constraint-row values of contact point e
+//   then per RK2 point (215.. / 232..): contact point e - COM (3) | entries 9 e .. 9 e + 8 of the node's 36 values of the point:
+//   [sin / cos pairs (6) | flow map rows 0..11 | I_com^-1, w_b, l_j, P (15) | h_b (3)] | entries 5 leg .. 5 leg + 4 of [R (9) | 1 / cos(pitch)]
+//   (-> the LEGJ_MS slots, lq_ms_slot; taken from the evaluation's own point only)
+struct LqPark {
+  static constexpr int per_lane = 256, size = 4 * per_lane;   // doubles per node: 64 lines, 8 KiB
+  static constexpr int n_feet = LEGJ_FEET, n_vj = 206, n_row = 212, n_fr0 = 215, n_ns0 = 218, n_rm0 = 227, n_fr1 = 232, n_ns1 = 235, n_rm1 = 244, n_end = 249;
+  static constexpr int trip_max = 16;               // nodes of a trip: 64 lanes / 4
+  static constexpr int n_tab0 = 192;                // entries below it go straight to the leg blocks (the first six rounds of the read-back)
+  // LDS of the value phase (the node's own LDS, idle until the trip's first node is staged)
+  static constexpr int stash_pt = 39 * trip_max;    // per RK2 point and quad: [summed composites 15 | leg 0: contact points, velocities 12 | leg 1]
+  // during the leg pass: sin / cos of joints 1..4 (8 a lane) | the leg's two contact points (6 a lane) | joint constants (2 x 5 x 16)
+  static constexpr int sncs = 0, feet = 512, jc_tab = 896;
+  static constexpr int hand = 0;                    // afterwards: the hand-out of a point's 36 values (over the first point's stash, dead by then)
+  // LDS place (double index) of entry n of leg evaluation e; -1: nothing to place
+  static constexpr int ns_dest(int pt, int j) {
+    if (j < 6) return LqLds::fv + 12 + 6 * pt + j;                                   // sin / cos pairs (LqLds::SC)
+    if (j < 18) return (pt == 0 ? LqLds::fv : LqLds::xe) + (j - 6);                  // f(x, u) | f(x_e, u) in the x_e slot
+    if (j < 33) return LqLds::LV + pt * LqLds::LVP + (j - 18);                       // LQ_CV_IINV .. LQ_CV_P
+    return LqLds::xe + 12 + 3 * pt + (j - 33);                                       // h_b
+  }
+  static constexpr int dest(int n, int e) {
+    if (n < n_vj) return (n < n_feet && n % LEGJ_STRIDE == LEGJ_MS && n >= n_tab0) ? -1 : LqLds::LJ + e * LEGJ_SIZE + n;
+    if (n < n_row) return LqLds::LV + (e >> 1) * LqLds::LVP + 15 + 6 * (e & 1) + (n - n_vj);
+    if (n < n_fr0) return LqLds::rowval + 3 * e + (n - n_row);
+    if (n < n_ns0) return LqLds::CDt + 72 + 3 * e + (n - n_fr0);
+    if (n < n_rm0) return ns_dest(0, 9 * e + (n - n_ns0));
+    if (n < n_fr1) return (e >> 1) == 0 ? LqLds::LJ + e * LEGJ_SIZE + (n - n_rm0) * LEGJ_STRIDE + LEGJ_MS : -1;
+    if (n < n_ns1) return LqLds::CDt + 72 + 12 + 3 * e + (n - n_fr1);
+    if (n < n_rm1) return ns_dest(1, 9 * e + (n - n_ns1));
+    if (n < n_end) return (e >> 1) == 1 ? LqLds::LJ + e * LEGJ_SIZE + (n - n_rm1) * LEGJ_STRIDE + LEGJ_MS : -1;
+    return -1;
+  }
+};
+struct LqParkTab { int d[LqPark::per_lane - LqPark::n_tab0][4]; };
+constexpr LqParkTab lq_park_tab() {
+  LqParkTab t{};
+  for (int n = LqPark::n_tab0; n < LqPark::per_lane; ++n)
+    for (int e = 0; e < 4; ++e) t.d[n - LqPark::n_tab0][e] = LqPark::dest(n, e);
+  return t;
+}
+static_assert(LqPark::jc_tab + 160 <= LqLds::total && 2 * LqPark::stash_pt <= LqLds::total && LqPark::hand + 36 * LqPark::trip_max <= LqPark::stash_pt,
+              "the value phase's LDS lives in the node's");
+static_assert(LqPark::n_tab0 % 4 == 0 && LqPark::n_tab0 <= LqPark::n_feet && LqPark::n_tab0 / 4 * 8 % 64 == 0, "whole rounds of the read-back go to the leg blocks");
+static_assert(LqPark::per_lane % 8 == 0 && LEGJ_STRIDE % 8 == 0 && LEGJ_FEET % 8 == 0, "entries leave eight at a time");
+#if defined(__HIP_DEVICE_COMPILE__)
+static_assert(LqLds::SC == LqLds::fv + 12, "the sin / cos pairs sit in the second half of fv");
+__device__ const LqParkTab kLqParkTab = lq_park_tab();
+struct LqTrip {   // what the value phase's helpers share
+  double* lds;
+  double* park;   // the trip's parked data
+  int tshift, nt, lane;
+  int dbg;        // profiling build: 127 / 128 leave the value phase behind the forward sweep / the leg pass
+};
+__device__ __forceinline__ void lq_wave_order() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// Entries n0 .. n0 + 7 (n0 a multiple of 8) of the lane -> the parked data: four 16-byte stores
+__device__ __forceinline__ void lq_park_out(const LqTrip& tr, int n0, const double* v8) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  int lane = tr.lane;
+  asm volatile("" : "+v"(lane));   // (addresses rebuilt per call: kept across the calls of a whole phase they were spilled)
+  lane &= 63;
+  const int t = lane >> 2, e = lane & 3;
+  if (t < tr.nt) {
+    double* line = tr.park + ((size_t(n0 >> 2) << tr.tshift) + t) * 16 + 2 * e;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      d2 x;
+      x.x = v8[i]; x.y = v8[i + 1];
+      *reinterpret_cast<d2*>(line + ((size_t(i >> 2) << tr.tshift) * 16) + ((i & 3) >> 1) * 8) = x;
+    }
+  }
+}
+// joint constants of both legs -> LDS (LegJointConst order), once per trip
+__device__ __forceinline__ void lq_trip_stage_constants(const DevModel& M, double* lds, int lane) {
+  for (int i = lane; i < 160; i += 64) {
+    const int j = i >> 4, c = i & 15, b = j + 1;
+    lds[LqPark::jc_tab + i] = c < 3 ? M.axis[j][c] : (c < 6 ? M.origin[j][c - 3] : (c < 9 ? M.com[b][c - 6] : (c < 15 ? M.inertia[b][c - 9] : M.mass[b])));
+  }
+}
+// Serial leg pass of the lane's leg evaluation (same quantities as hb_model.hpp leg_value_pass), written for a block that is never
+// read back: the forward sweep keeps the sines / cosines of the joint angles (LDS), the frame behind the last joint, its origin and the
+// TOTALS of the joint-rate twist; the backward sweep peels the frames off again — R_k^- = P_k E_k', o_(k-1) = o_k - R_k^- origin_k —,
+// unwinds the twist sums, and forms axis, body terms, suffix sums and momenta of a joint from P_k alone: the 40 entries of a joint block
+// are complete when the joint is done and leave through lq_park_out.  Differs from the other forms of the pass by rounding only.
+__device__ __forceinline__ void lq_trip_leg_pass(const LqTrip& tr, const DevModel& M, int leg, double dts, const double* xk, const double* uk, double* val) {
+  const double* jct = tr.lds + LqPark::jc_tab + leg * 80;
+  double* sncs = tr.lds + LqPark::sncs + 8 * tr.lane - 2;   // (sin, cos) of joint k >= 1 at [2 k], [2 k + 1]: the first joint is never peeled off
+  double* pfl = tr.lds + LqPark::feet + 6 * tr.lane;         // the leg's two contact points: read where used, not carried through the backward sweep
+  const int j0 = 5 * leg;
+  // the leg's joint angles and rates, requested together up front and picked by the (uniform) joint index with selects: read where they
+  // are used, every joint of the sweeps waited for a global-memory round trip — behind the staged stores of the joint before it
+  double qa[5], qr[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { qr[k] = uk[12 + j0 + k]; qa[k] = xk[12 + j0 + k] + dts * qr[k]; }
+  auto pick = [](const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : (k == 3 ? v[3] : v[4]))); };
+  Mat3<double> R = Mat3<double>::identity();
+  Vec3<double> op, om, w;
+#pragma unroll 1
+  for (int k = 0; k < 5; ++k) {
+    const double* jc = jct + 16 * k;
+    const double ax[3] = {jc[0], jc[1], jc[2]};
+    const Vec3<double> o = op + R * Vec3<double>(jc[3], jc[4], jc[5]);
+    const Vec3<double> a = R * Vec3<double>(ax[0], ax[1], ax[2]);
+    const double qd = pick(qr, k);
+    om = om + qd * a;
+    w = w + qd * cross(a, o);
+    double sk, ck;
+    sincos_bounded(pick(qa, k), sk, ck);
+    if (k > 0) { sncs[2 * k] = sk; sncs[2 * k + 1] = ck; }
+    R = R * axis_rot_sc<double>(ax, sk, ck);
+    op = o;
+  }
+  if (HB_ABLATE_ON && tr.dbg == 127) return;
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int ci = leg + 2 * f;
+    st3(pfl + 3 * f, op + R * Vec3<double>(M.contact_offset[ci][0], M.contact_offset[ci][1], M.contact_offset[ci][2]));
+  }
+  double ms = 0.0;
+  Vec3<double> mc, lin, ang, vj[2];
+  Sym3<double> IO;
+#pragma unroll 1
+  for (int k = 4; k >= 0; --k) {
+    const double* jc = jct + 16 * k;
+    const double ax[3] = {jc[0], jc[1], jc[2]};
+    const Vec3<double> o = op;
+    const Vec3<double> a = R * Vec3<double>(ax[0], ax[1], ax[2]);   // (the joint's own rotation leaves its axis alone: P_k a = R_k^- a)
+    const double mb = jc[15];
+    const Vec3<double> c = o + R * Vec3<double>(jc[6], jc[7], jc[8]);
+    const double in[6] = {jc[9], jc[10], jc[11], jc[12], jc[13], jc[14]};
+    ms += mb;
+    mc = mc + mb * c;
+    IO = IO + (rotate_inertia<double>(R, in) + point_inertia<double>(mb, c));
+    const Vec3<double> l = cross(a, mc - ms * o);
+    const Vec3<double> L = IO * a - cross(mc, cross(a, o));
+    const double qd = pick(qr, k);
+    lin = lin + qd * l;
+    ang = ang + qd * L;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) vj[f] = vj[f] + qd * cross(a, ld3(pfl + 3 * f) - o);
+    om = om - qd * a;              // twist of the joints BEFORE k
+    w = w - qd * cross(a, o);
+    {
+      double v[LEGJ_STRIDE];
+      st3(v + LEGJ_A, a); st3(v + LEGJ_O, o); st3(v + LEGJ_l, l); st3(v + LEGJ_L, L); st3(v + LEGJ_MC, mc); st6(v + LEGJ_IO, IO);
+      st3(v + LEGJ_LIN, lin); st3(v + LEGJ_ANG, ang); st3(v + LEGJ_VJ, vj[0]); st3(v + LEGJ_VJ + 3, vj[1]); st3(v + LEGJ_OMP, om); st3(v + LEGJ_WP, w);
+      v[LEGJ_MS] = ms;
+#pragma unroll
+      for (int cch = 0; cch < LEGJ_STRIDE / 8; ++cch) lq_park_out(tr, k * LEGJ_STRIDE + 8 * cch, v + 8 * cch);
+    }
+    if (k > 0) {
+      // peel joint k off: R_k^- = P_k E_k' and the origin of the joint before
+      const Mat3<double> E = axis_rot_sc<double>(ax, sncs[2 * k], sncs[2 * k + 1]);
+      Mat3<double> Pm;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) Pm.m[3 * i + jj] = R.m[3 * i] * E.m[3 * jj] + R.m[3 * i + 1] * E.m[3 * jj + 1] + R.m[3 * i + 2] * E.m[3 * jj + 2];
+      op = o - Pm * Vec3<double>(jc[3], jc[4], jc[5]);
+      R = Pm;
+    }
+  }
+  st3(val + 0, mc); st6(val + 3, IO); st3(val + 9, lin); st3(val + 12, ang);
+  st3(val + 15, ld3(pfl)); st3(val + 18, ld3(pfl + 3)); st3(val + 21, vj[0]); st3(val + 24, vj[1]);
+}
+// value phase of the lane's (node, leg evaluation) pair (the four lanes of a quad share a node; lanes beyond the trip's last node repeat
+// it — every lane takes part in the staged stores — and nothing of theirs is parked)
+// Uniform arguments: the instance's state / input / swing-reference / node-time / mode arrays and the trip's first node; the lane's node
+// pointers are formed twice — for the leg pass and, from an opaque copy of the lane id, again behind it: carried across the leg pass
+// (the register peak of the phase) they were spilled.
+__device__ __forceinline__ void lq_trip_values(const LqTrip& tr, const DevModel& M, const DevConfig& C, const double* x_inst, const double* u_inst,
+                                               const double* sw_inst, const double* tt, const int* mode_inst, int k0) {
+  const int lane = tr.lane, e = lane & 3, leg = e & 1, quad = lane >> 2;
+  const bool pt_own = e >> 1;
+  double* lds = tr.lds;
+  const double *xk, *uk;
+  double dt;
+  {
+    const int k = k0 + min(lane >> 2, tr.nt - 1);
+    xk = x_inst + size_t(k) * HB_NX;
+    uk = u_inst + size_t(k) * HB_NU;
+    dt = tt[k + 1] - tt[k];
+  }
+  // entries 200 .. 255 of the lane (LqPark), staged eight at a time as they become known
+  double tail[8], vjr[4];
+  {
+    double val[27];
+    lq_trip_leg_pass(tr, M, leg, pt_own ? dt : 0.0, xk, uk, val);
+    if (HB_ABLATE_ON && (tr.dbg == 127 || tr.dbg == 128)) return;
+    // its contact points, and the head of their joint-induced velocities: entries 200..207
+#pragma unroll
+    for (int n = 0; n < 8; ++n) tail[n] = val[15 + n];
+    lq_park_out(tr, LqPark::n_feet, tail);
+    // What the value passes need of the leg pass goes through LDS, per RK2 point and quad: the summed composites of the point's two legs
+    // (the partner leg sits one lane away) and each leg's contact points and their joint-induced velocities.  Held in registers across
+    // both value passes they were spilled.
+    double* st = lds + (e >> 1) * LqPark::stash_pt + quad * 39;
+#pragma unroll
+    for (int n = 0; n < 15; ++n) {
+      const double sm = val[n] + dpp_full_f64<0xB1>(val[n]);   // quad_perm:[1,0,3,2]
+      if (leg == 0) st[n] = sm;
+    }
+#pragma unroll
+    for (int n = 0; n < 12; ++n) st[15 + 12 * leg + n] = val[15 + n];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) vjr[n] = val[23 + n];   // (entries 208..211 leave with the first point's)
+  }
+  const double* swk;
+  int mode;
+  {
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    const int k = k0 + min((lo & 63) >> 2, tr.nt - 1);
+    xk = x_inst + size_t(k) * HB_NX;
+    uk = u_inst + size_t(k) * HB_NU;
+    swk = sw_inst + size_t(k) * 24;
+    dt = tt[k + 1] - tt[k];
+    mode = mode_inst[k];
+  }
+  const bool cL = (mode == 2 || mode == 3), cR = (mode == 1 || mode == 3);
+  const bool contact = leg ? cR : cL;   // contact point e sits on leg e & 1
+  const int f = e >> 1;                 // ... and is its contact point f
+  lq_wave_order();   // (stash written; the leg pass's values end here)
+  const Vec3<double> F(uk[3 * e], uk[3 * e + 1], uk[3 * e + 2]);
+  const double inv_m = rcp_t(M.total_mass);
+  double sc[6], xe[6];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) sincos_bounded(xk[9 + a], sc[2 * a], sc[2 * a + 1]);
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const double* st = lds + pt * LqPark::stash_pt + quad * 39;
+    // contact point f of leg e & 1 at this point (position, joint-induced velocity; base frame)
+    const Vec3<double> fb = ld3(st + 15 + 12 * leg + 3 * f), vjf = ld3(st + 15 + 12 * leg + 6 + 3 * f);
+    LqPointValues pv;
+    lq_point_values(M, st, sc, pt == 0 ? xk : xe, pv);
+    const Vec3<double> fr = pv.R * fb;
+    const Vec3<double> fvel = pv.v_lin + cross(pv.omega, fr) + pv.R * vjf;
+    const Vec3<double> rr = fr - pv.com_rel;
+    const Vec3<double> mi = cross(rr, F);
+    const double msx = quad_sum_f64(mi.x), msy = quad_sum_f64(mi.y), msz = quad_sum_f64(mi.z);
+    const double fsx = quad_sum_f64(F.x), fsy = quad_sum_f64(F.y), fsz = quad_sum_f64(F.z);
+    // R (9) and 1 / cos(pitch): entries 5 leg .. 5 leg + 4 (lq_ms_slot; the read-back takes them from the evaluation's own point)
+    double rm[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) rm[j] = leg ? (j < 4 ? pv.R.m[5 + j] : pv.icy) : pv.R.m[j];
+    // The node's 36 values of this point — every lane of the quad holds all of them, lane e parks entries 9 e .. 9 e + 8: handed out
+    // through LDS (lane 0 of the quad writes, everyone picks its nine; selected in registers, the 36 were the phase's register peak).
+    // The place is the staging tile's (over the first point's stash), free once every lane has read this point's stash.
+    const double flin[3] = {inv_m * fsx, inv_m * fsy, inv_m * fsz - M.gravity};
+    const double fang[3] = {inv_m * msx, inv_m * msy, inv_m * msz};
+    double mine[9];
+    {
+      lq_wave_order();
+      double* nq = lds + LqPark::hand + quad * 36;
+      if (e == 0) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) nq[a] = sc[a];
+        nq[6] = flin[0]; nq[7] = flin[1]; nq[8] = flin[2];
+        nq[9] = fang[0]; nq[10] = fang[1]; nq[11] = fang[2];
+        st3(nq + 12, pv.v_lin);
+        st3(nq + 15, pv.euler_rate);
+        st6(nq + 18 + LQ_CV_IINV, pv.Iinv);
+        st3(nq + 18 + LQ_CV_WB, pv.wb);
+        st3(nq + 18 + LQ_CV_LJ, pv.lj);
+        st3(nq + 18 + LQ_CV_P, pv.P);
+        st3(nq + 33, pv.hb);
+      }
+      lq_wave_order();
+#pragma unroll
+      for (int j = 0; j < 9; ++j) mine[j] = nq[9 * e + j];
+      lq_wave_order();
+    }
+    if (pt == 0) {
+      double rv[3], sw[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) sw[a] = swk[6 * e + a];
+      lq_row_values(C, contact, xk[8] + fr.z, xk[6] + fr.x, xk[7] + fr.y, fvel, sw, rv);
+      // second evaluation point of Heun's method: x + dt f(x, u), same input
+      // (the value pass of the second point reads the momentum rows and, through their sines / cosines, the ZYX angles only)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { xe[a] = xk[a] + dt * flin[a]; xe[3 + a] = xk[3 + a] + dt * fang[a]; }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) sincos_bounded(xk[9 + a] + dt * comp(pv.euler_rate, a), sc[2 * a], sc[2 * a + 1]);
+      // entries 208..231: velocities (4) | row values (3) | contact point - COM (3) | values (9) | rotation entries (5)
+      tail[0] = vjr[0]; tail[1] = vjr[1]; tail[2] = vjr[2]; tail[3] = vjr[3]; tail[4] = rv[0]; tail[5] = rv[1]; tail[6] = rv[2]; tail[7] = rr.x;
+      lq_park_out(tr, 208, tail);
+      tail[0] = rr.y; tail[1] = rr.z;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) tail[2 + j] = mine[j];
+      lq_park_out(tr, 216, tail);
+      tail[0] = mine[6]; tail[1] = mine[7]; tail[2] = mine[8];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) tail[3 + j] = rm[j];
+      lq_park_out(tr, 224, tail);
+    } else {
+      // entries 232..255: contact point - COM (3) | values (9) | rotation entries (5) | padding
+      tail[0] = rr.x; tail[1] = rr.y; tail[2] = rr.z;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) tail[3 + j] = mine[j];
+      lq_park_out(tr, 232, tail);
+      tail[0] = mine[5]; tail[1] = mine[6]; tail[2] = mine[7]; tail[3] = mine[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tail[4 + j] = rm[j];
+      lq_park_out(tr, 240, tail);
+      tail[0] = rm[4];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) tail[j] = 0.0;
+      lq_park_out(tr, 248, tail);
+    }
+  }
+}
+static_assert(LqPark::n_vj == 206 && LqPark::n_row == 212 && LqPark::n_fr0 == 215 && LqPark::n_ns0 == 218 && LqPark::n_rm0 == 227 && LqPark::n_fr1 == 232 &&
+              LqPark::n_ns1 == 235 && LqPark::n_rm1 == 244 && LqPark::per_lane == 256, "lq_trip_values packs the entries behind the leg block by hand");
+// the parked data of node t of a trip of T = 2^tshift nodes -> its LDS places: 8 rounds of 64 sixteen-byte pairs (a pair = entries n, n + 1
+// of one leg evaluation: two consecutive LDS doubles wherever the entries go to the leg blocks)
+__device__ __forceinline__ void lq_image_to_lds(const double* trip_base, int t, int tshift, double* lds, int lane) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int NPAIR = LqPark::per_lane / 4 * 8, NR = NPAIR / 64, NR_BLK = LqPark::n_tab0 / 4 * 8 / 64;   // 8 rounds, the first 6 of them all leg block
+  static_assert(NPAIR % 64 == 0, "whole rounds");
+  const d2* src = reinterpret_cast<const d2*>(trip_base) + ((((lane >> 3) << tshift) + t) << 3) + (lane & 7);
+  const int rstride = 64 << tshift;   // pairs between the rounds (8 lines further)
+  d2 v[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) v[r] = src[r * rstride];
+  const int pp = lane & 7, e = pp & 3;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int n = ((lane >> 3) + 8 * r) * 4 + (pp >> 2) * 2;   // (even)
+    if (r < NR_BLK) {
+      *reinterpret_cast<d2*>(lds + LqLds::LJ + e * LEGJ_SIZE + n) = v[r];
+    } else {
+      const int d0 = kLqParkTab.d[n - LqPark::n_tab0][e], d1 = kLqParkTab.d[n + 1 - LqPark::n_tab0][e];
+      if (d0 >= 0) lds[d0] = v[r].x;
+      if (d1 >= 0) lds[d1] = v[r].y;
+    }
+  }
+}
+static_assert(LqLds::LJ % 2 == 0 && LEGJ_SIZE % 2 == 0, "the pairs of the leg blocks are 16-byte aligned in LDS");
+#endif
+
 // model constants of the (leg evaluation, joint) task lane `lane` has in k_lq's leg pass (leg_value_pass_coop: group lane >> 3, joint lane & 7)
 HB_HD void lq_leg_const_of_lane(const DevModel& M, int lane, LegJointConst& jc) {
   const int dg = lane >> 3, dk = lane & 7;
@@ -1293,24 +1679,7 @@ HB_HD void lq_node(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
 #endif
   HB_ABLATE_STOP(C.debug_stop == 7);
-  // ---- stage 2: tangents of the whole-body combine per (point, direction).  Only 29 of the 44 directions are nonlinear (momentum
-  // 0..5, zyx 9..11, joints 12..21, joint rates 34..43), so both RK2 points fit ONE pass of the wave: task = 29 pt + index.
-  for (int task = cx.lane; task < 58; task += cx.nlanes) lq_tangent_task(M, C, lds, in.mode, task >= 29 ? 1 : 0, task >= 29 ? task - 29 : task);
-  cx.sync();
-#if defined(__HIP_DEVICE_COMPILE__)
-  // (contact point - COM) of both points for the contact-force directions of the compose: from their waiting place to the slot of the
-  // contact's velocity, which the pass has finished with
-  if (cx.lane < 24) {
-    const int pt = cx.lane / 12, e = cx.lane - 12 * pt;
-    lds[LqLds::fr_slot(pt, e / 3) + e % 3] = (P1.CDt + 6 * 12)[cx.lane];
-  }
-  cx.sync();
-#endif
-  HB_ABLATE_STOP(C.debug_stop == 9);
-  // constraint rows of the base-position directions (closed form)
-  for (int task = cx.lane; task < 3; task += cx.nlanes) lq_closed_task(C, lds, in.mode, task);
-  cx.sync();
-  lq_tail(cx, M, C, in, lds, rec, xref_at, xnext_at);
+  lq_node_dense(cx, M, C, in, lds, rec, xref_at, xnext_at);
 }
 
 }  // namespace hb

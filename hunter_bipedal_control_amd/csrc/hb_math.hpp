@@ -78,8 +78,22 @@ HB_HD Dual1& operator-=(Dual1& a, Dual1 b) { a.v -= b.v; a.d -= b.d; return a; }
 // minimax kernels on [-pi/4, pi/4] (coefficients: the classic fdlibm __kernel_sin/__kernel_cos sets); absolute error
 // < 2e-16.  The generic library path — whose large-argument reduction made up a quarter of k_lq's instruction
 // stream — is only taken for |a| >= 1e5.
+HB_HD void sincos_reduced(double a, double& s, double& c);
 HB_HD void sincos_t(double a, double& s, double& c) {
   if (!(fabs(a) < 1.0e5)) { s = sin(a); c = cos(a); return; }
+  sincos_reduced(a, s, c);
+}
+// The same without the library path: NaN beyond |a| < 1e5 (and for NaN / inf, as the library gives).  For code whose register budget
+// cannot carry the library routine's large-argument reduction along (k_lq's value phase evaluates eleven angles per lane): a joint or
+// Euler angle of 1e5 rad is a diverged iterate, and the NaN marks the instance HB_INST_NAN like any other non-finite number.
+HB_HD void sincos_bounded(double a, double& s, double& c) {
+  double sv, cv;
+  sincos_reduced(fabs(a) < 1.0e5 ? a : 0.0, sv, cv);
+  const bool ok = fabs(a) < 1.0e5;
+  s = ok ? sv : NAN;
+  c = ok ? cv : NAN;
+}
+HB_HD void sincos_reduced(double a, double& s, double& c) {
   const double k = rint(a * 6.36619772367581382433e-01);
   double r = fma(-k, 1.57079632673412561417e+00, a);
   r = fma(-k, 6.07710050630396597660e-11, r);

@@ -845,7 +845,8 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   // eps -> 0 limit, the minimum-norm minimiser.
   for (int i = cx.lane; i < NW; i += cx.nlanes) xb[i] = 0.0;
   cx.sync();
-  for (int phase = 0; phase <= C.wbc_reg_steps && status == 0; ++phase) {
+  const int n_reg = C.wbc_reg_steps > 0 ? C.wbc_reg_steps : 0;   // (phase 0 — the solve with every constraint — runs whatever the field holds)
+  for (int phase = 0; phase <= n_reg && status == 0; ++phase) {
   if (phase > 0) {
     for (int i = cx.lane; i < NW; i += cx.nlanes) { np[i] = x[i] - xb[i]; xb[i] = x[i]; }
     cx.sync();

@@ -101,8 +101,8 @@ typedef struct hb_config {
   double wbc_eps_reg;              /* Tikhonov term of the regularised-minimiser rule */
   int32_t wbc_max_iter;            /* working-set-change limit; reference nWSR = 20 (WeightedWbc.cpp:50) */
   int32_t reserved;                /* 0.  Tests and tuning only: 101 / 104 force the one- / four-wavefront backward sweep, 111 / 114 the row /
-                                      wave form of the forward sweep (the library picks both by the number of instances in flight; the forms
-                                      are bit-identical); other values are phase-by-phase exits of the profiling build (-DHB_ABLATE) */
+                                      wave form of the forward sweep, 120 + s trips of 2^s nodes per wavefront in the LQ kernel (the library
+                                      picks all three by the number of instances in flight; the forms are bit-identical); other values are phase-by-phase exits of the profiling build (-DHB_ABLATE) */
   double default_joint_state[HB_NJ]; /* reference.info:7-19 */
   double delta_tol;                /* sqp.deltaTol, task.info:84: the line search gives up (no step, as at alpha_min) once
                                       alpha |dx| and alpha |du| — l2 norms over the whole trajectory — are both below it
@@ -111,8 +111,9 @@ typedef struct hb_config {
                                       numRegularisationSteps = 1 (WeightedWbc.cpp:47-48, HoQp.cpp:175-176 [qpOASES-knowledge]).  Each step is
                                       one proximal-point step x <- argmin f(x) + eps/2 |x - x_prev|^2 on the final working set; 1 removes
                                       the first-order-in-eps bias of the regularised minimiser.  0 = plain Tikhonov point */
-  int32_t reserved2;               /* 0 */
+  int32_t reserved2;               /* 0 (checked by hb_create) */
 } hb_config;
+#define HB_WBC_REG_STEPS_MAX 8     /* hb_create rejects wbc_reg_steps outside [0, HB_WBC_REG_STEPS_MAX] */
 
 typedef struct hb_ctx hb_ctx;
 

@@ -9,6 +9,10 @@ ORDER = [(10, "loads"), (6, "leg value pass"), (7, "value pre-pass"), (9, "direc
          (3, "solves"), (30, "defect, A~ B~ tiles"), (31, "B~ columns, b~"), (4, "cost"), (5, "soft rows, Pj, M"), (32, "Q~ q~"), (33, "P~ r~"),
          (34, "R~"), (0, "recovery data, end")]   # (code order: A~ / B~ / b~ are formed right behind the projection)
 root = Path(sys.argv[1])
+KERNEL, PER = "k_lq", 1.0
+if len(sys.argv) > 2 and sys.argv[2] == "--trip":   # k_lq_trip: a wavefront walks a trip of nodes; counters are shown per NODE (100 nodes = 7 trips of <= 16)
+    KERNEL, PER = "k_lq_trip", 100.0 / 7.0
+    ORDER = [(126, "value phase (trip)")] + [(sp, ("read-back + " if sp == 9 else "") + nm) for sp, nm in ORDER if sp not in (10, 6, 7)]
 prev = None
 print(f"{'phase':26s} {'us':>8s} {'VALU':>7s} {'SALU':>7s} {'LDS':>6s} {'kcyc/wave':>10s} {'stall%':>7s} {'wait%':>6s}   (increments; counters per wavefront)")
 for stop, name in ORDER:
@@ -16,11 +20,11 @@ for stop, name in ORDER:
     if not dbs:
         print(f"{name:26s} (no data)")
         continue
-    k = per_kernel(str(dbs[0])).get("k_lq")
+    k = per_kernel(str(dbs[0])).get(KERNEL)
     if not k:
-        print(f"{name:26s} (k_lq not found)")
+        print(f"{name:26s} ({KERNEL} not found)")
         continue
-    w = k["SQ_WAVES"]
+    w = k["SQ_WAVES"] * PER
     cur = dict(us=k["avg_us_under_profiling"], valu=k["SQ_INSTS_VALU"] / w, salu=k["SQ_INSTS_SALU"] / w, lds=k["SQ_INSTS_LDS"] / w,
                cyc=k["SQ_WAVE_CYCLES"] / w * 4 / 1e3, stall=k["SQ_WAIT_INST_ANY"] / w * 4 / 1e3, wait=k["SQ_WAIT_ANY"] / w * 4 / 1e3)
     d = {n: cur[n] - (prev[n] if prev else 0.0) for n in cur}

@@ -14,6 +14,7 @@ ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--chunks", type=int, default=1)
 ap.add_argument("--no-tail", action="store_true", help="A/B: alpha_decay = 0, i.e. no backtracking-tail launches")
 ap.add_argument("--standing", action="store_true", help="every instance stands (mode STANCE at every node: the 12-wide stages of the sweeps)")
+ap.add_argument("--reserved", type=int, default=0, help="hb_config.reserved of the timed run (e.g. 120 + s: LQ trips of 2^s nodes; 129: the one-node kernel)")
 ap.add_argument("--stop", type=int, default=None, help="run ONLY this ablation stop (HB_ABLATE build), few steps: for counter passes")
 args = ap.parse_args()
 from pathlib import Path
@@ -72,7 +73,7 @@ if args.stop is not None:
     sys.exit(0)
 if args.chunks > 1:
     run(steps=3)  # throwaway context: the first context of a process overlaps its chunk streams worse
-print(json.dumps(dict(lib=args.lib or "default", **run(steps=max(args.steps, 30 * 4096 // B)))))
+print(json.dumps(dict(lib=args.lib or "default", **run(args.reserved, steps=max(args.steps, 30 * 4096 // B)))))
 if args.ablate_lq:
     for stop in (10, 6, 7, 9, 1, 2, 3, 30, 31, 4, 5, 32, 33, 34):  # (code order)
         r = run(stop, steps=5)

@@ -94,6 +94,7 @@ class HipLeggedController
   double cmdVel_[4] = {0.0, 0.0, 0.0, 0.0};   // filtered command [vx vy vz yawRate]
   double timeHorizon_ = 0.8, mpcDesiredFrequency_ = 100.0;
   std::atomic_int plannedMode_{3};
+  bool estimateContactForce_ = false;   // /hunter_hip/estimate_contact_force: run StateEstimateBase::estContactForce every tick (diagnostics)
   int mpcEveryNTicks_ = 0;   // 0: own MPC thread at mpcDesiredFrequency; n > 0: lock-step, one MPC pass every n control ticks
   long tick_ = 0;
   bool coldStarted_ = false;

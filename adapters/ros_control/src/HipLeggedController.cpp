@@ -41,6 +41,9 @@ bool HipLeggedController::init(hardware_interface::RobotHW* robot_hw, ros::NodeH
     controller_nh.getParam("/hunter_hip/time_horizon", timeHorizon_);
     controller_nh.getParam("/hunter_hip/mpc_frequency", mpcDesiredFrequency_);
     controller_nh.getParam("/hunter_hip/mpc_every_n_ticks", mpcEveryNTicks_);   // > 0: lock-step MPC inside update() (simulation)
+    // the contact-force observer of StateEstimateBase (LeggedController.cpp:344-345) has no reader in the reference: off by default here —
+    // on, it adds an upload, a kernel, two downloads and a stream synchronisation to every 2 ms control tick
+    controller_nh.getParam("/hunter_hip/estimate_contact_force", estimateContactForce_);
     const int maxNodes = int(std::ceil(timeHorizon_ / config_.dt)) + 8;   // event-clipped grid: a few nodes more than T / dt
     ctx_.reset(new hunter_hip::Context(model_, config_, /*batch*/ 1, maxNodes, device));
     setupMpc();
@@ -159,7 +162,7 @@ void HipLeggedController::updateStateEstimation(const ros::Time& time, const ros
     contact = {L, R, L, R};
   }
   measuredRbdState_ = stateEstimate_->update(period.toSec(), quat, angularVel, linearAccel, jointPos, jointVel, contact);
-  stateEstimate_->estContactForce(period.toSec(), jointTor);   // setCmdTorque + estContactForce (:344-345): no reader in the reference either
+  if (estimateContactForce_) stateEstimate_->estContactForce(period.toSec(), jointTor);   // setCmdTorque + estContactForce (:344-345)
   std::lock_guard<std::mutex> lk(cmdMutex_);
   currentObservation_.time = time.toSec();
   currentObservation_.state = stateEstimate_->observationState();   // incl. the yaw unwrapping of :331-334

@@ -489,6 +489,8 @@ def main():
     elapsed = time.perf_counter() - t0
     chunk_counters = s.chunk_counters()
     elapsed = sharding.max_over_ranks(elapsed, dist, device="cuda")
+    # who took part: an RCCL SUM all-reduce of 1 and the gathered device identities (no derived figure: facts the launch can be checked against)
+    rccl_ranks, devices = sharding.participants(sharding.device_identity(local_rank), dist, device="cuda")
     ms_per_step = 1e3 * elapsed / args.steps
     value = total_instances * args.steps / elapsed
 
@@ -510,6 +512,20 @@ def main():
     sol, status = s.get_wbc_solution()
     mpc_status = s.mpc_status()
     n_nodes = s.get_references()["n_nodes"]
+    # Optimality of the WBC solutions of the last update, from the product's own rigid-body terms (hb_eval_rbd) — SURVEY.md 8d: the
+    # equation of motion M a + nle = S' tau + J' F is the equality block of the QP; torque limits and the friction pyramid its inequalities.
+    # (stationarity needs the multipliers, which stay on the device: that half of the KKT conditions is held by the oracle tests)
+    Mq, nle, Jc, _ = s.eval_rbd(w["rbd"])
+    acc, Fc, tau = sol[:, :16], sol[:, 16:28], sol[:, 28:38]
+    eom = np.einsum("bij,bj->bi", Mq, acc) + nle - np.einsum("bki,bk->bi", Jc, Fc)
+    eom[:, 6:] -= tau
+    wbc_eom_res = float(np.abs(eom).max())
+    tl = np.asarray(params["config"]["torque_limits"], dtype=float)
+    wbc_tau_viol = float(max(0.0, (np.abs(tau) - np.tile(tl, 2)[None, :]).max()))
+    mu = float(params["config"]["wbc_friction_mu"])
+    F3 = Fc.reshape(-1, 4, 3)
+    wbc_cone_viol = float(max(0.0, np.maximum.reduce([np.abs(F3[..., 0]) - mu * F3[..., 2], np.abs(F3[..., 1]) - mu * F3[..., 2], -F3[..., 2]]).max()))
+    wbc_eom_res, wbc_tau_viol, wbc_cone_viol = (float(v) for v in sharding.max_vector_over_ranks([wbc_eom_res, wbc_tau_viol, wbc_cone_viol], dist, device="cuda"))
     hist = sharding.sum_over_ranks([int((status == k).sum()) for k in range(4)], dist, device="cuda")
     mpc_hist = sharding.sum_over_ranks([int((mpc_status == k).sum()) for k in range(4)], dist, device="cuda")
     wbc_iters = s.get_wbc_iterations()            # active-set iterations of the last WBC solve (nWSR of the reference)
@@ -610,7 +626,8 @@ def main():
                     v["counter_over_algorithmic"] = cb / (BYTES_PER_NODE[k] * int(n_nodes.sum()))
         out = {
             "metric": metric_string(strong, total_instances, B, world, N),
-            "value": value, "value_per_gpu": value / world, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "value_per_gpu": value / world, "unit": "updates/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "devices": devices,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{total_instances} distinct hunter instances ({B}/GPU, state seed 1234 + id), "
@@ -622,7 +639,8 @@ def main():
                                      "x0 of every call perturbed by measurement noise (sigma 0.01) so that no call re-solves a converged problem: "
                                      "every line search accepts the full step, NO backtracking inside the timed region "
                                      "(the backtracking case is the separate figure with_backtracking_line_search), "
-                                     "inputs resident in HBM (BASELINE.json configs[" + ("4" if args.hierarchical else "3" if args.random_cmd or world > 1 else "2") + "])",
+                                     "inputs resident in HBM (BASELINE.json configs[" + ("4" if args.hierarchical else "3" if args.random_cmd else "2") + "]"
+                                     + (f" workload sharded over {world} GPUs" if world > 1 and not args.random_cmd and not args.hierarchical else "") + ")",
                        "batch_per_gpu": B, "total_instances": total_instances, "horizon_nodes": N, "setup_s": t_setup,
                        "parallelism": (f"strong scaling: {total_instances} instances split over {world} rank(s)" if strong else
                                        f"weak scaling: {B} instances per rank x {world}") +
@@ -639,6 +657,10 @@ def main():
             "halves": {"mpc_solves_per_s_per_gpu": B / (phases["mpc_total"] * 1e-3), "wbc_solves_per_s_per_gpu": B / (phases["k_wbc"] * 1e-3),
                        "note": "device time of each half alone (HIP events); the reference runs them 1:5 (100 Hz MPC, 500 Hz WBC)"},
             "solver_state": {"max_dyn_sse": float(perf[:, 1].max()), "max_eq_sse": float(perf[:, 2].max()),
+                             "wbc_eom_residual_max": wbc_eom_res, "wbc_torque_limit_violation_max": wbc_tau_viol,
+                             "wbc_friction_pyramid_violation_max": wbc_cone_viol,
+                             "wbc_optimality_note": "max over the batch of |M a + nle - S' tau - J' F| (N, N m), of |tau| - limit and of the friction-pyramid "
+                                                    "rows, from hb_eval_rbd on the rbd states of the last update; dual residuals: tests/test_oracle_qp.py",
                              "wbc_status_histogram_all_ranks": hist, "mpc_status_histogram_all_ranks": mpc_hist,
                              "wbc_active_set_iterations_histogram_all_ranks": {f"{lo}..{hi - 1}" if hi < (1 << 30) else f">={lo}": n
                                                                                for lo, hi, n in zip(it_edges, it_edges[1:], it_hist)},

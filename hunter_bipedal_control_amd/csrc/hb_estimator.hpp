@@ -433,10 +433,17 @@ HB_HD void contact_force_estimate(const DevModel& M, double gama, double beta, c
       for (int j2 = 0; j2 <= i; ++j2)
         G[i][j2] = dot(wrench_rows_lin[leg][i], wrench_rows_lin[leg][j2]) + dot(wrench_rows_ang[leg][i], wrench_rows_ang[leg][j2]);
     }
-    for (int j2 = 0; j2 < 5; ++j2) {   // Cholesky G = L L' in place (lower), then L y' = y, L' y'' = y'
+    // Cholesky G = L L' in place (lower), then L y' = y, L' y'' = y'.  At a straight-leg singularity (hip-pitch, knee and ankle axes
+    // parallel, their origins in line) A loses rank and a pivot falls to rounding level: that row is dropped (zero column, zero
+    // unknown) — a finite truncated solution like the reference's bdcSvd().solve (StateEstimateBase.cpp:196) and the oracle's
+    // thresholded pseudo-inverse give there, instead of the NaN of sqrt(d <= 0).
+    double trace = 0.0;
+    for (int i = 0; i < 5; ++i) trace += G[i][i];
+    for (int j2 = 0; j2 < 5; ++j2) {
       double d = G[j2][j2];
       for (int k = 0; k < j2; ++k) d -= G[j2][k] * G[j2][k];
-      const double l = sqrt(d), li = 1.0 / l;
+      const bool live = d > 1e-12 * trace;
+      const double l = live ? sqrt(d) : 0.0, li = live ? 1.0 / l : 0.0;
       G[j2][j2] = l;
       for (int i = j2 + 1; i < 5; ++i) {
         double sacc = G[i][j2];
@@ -447,12 +454,12 @@ HB_HD void contact_force_estimate(const DevModel& M, double gama, double beta, c
     for (int i = 0; i < 5; ++i) {
       double sacc = y[i];
       for (int k = 0; k < i; ++k) sacc -= G[i][k] * y[k];
-      y[i] = sacc / G[i][i];
+      y[i] = G[i][i] > 0.0 ? sacc / G[i][i] : 0.0;
     }
     for (int i = 4; i >= 0; --i) {
       double sacc = y[i];
       for (int k = i + 1; k < 5; ++k) sacc -= G[k][i] * y[k];
-      y[i] = sacc / G[i][i];
+      y[i] = G[i][i] > 0.0 ? sacc / G[i][i] : 0.0;
     }
     Vec3<double> F, T;
     for (int k = 0; k < 5; ++k) { F = F + y[k] * wrench_rows_lin[leg][k]; T = T + y[k] * wrench_rows_ang[leg][k]; }

@@ -2136,10 +2136,11 @@ static void launch_ric_bwd(hb_ctx* ctx, const Batch& b, int B, int concurrent, h
 
 // LQ approximation: trips of 2^tshift nodes per wavefront (k_lq_trip).  Longer trips fill the lanes of the value phase better (16 nodes:
 // all 64) — measured best or equal at 512 .. 4096 instances —, shorter ones keep small batches spread over the chip: the longest trip
-// that still gives every wavefront slot of the chip (12 per CU) a trip of the CONCURRENT batch.  The result does not depend on the
+// that still gives every wavefront slot of the chip (12 per CU) two trips of the CONCURRENT batch (512 x 108 on two ranges: 16 nodes a
+// trip left a slot ONE trip, 1.73 ms a step against 1.55).  The result does not depend on the
 // choice.  hb_config.reserved = 120 + s forces 2^s; 129 the one-node-per-wavefront kernel of rounds 1-5 (k_lq: cooperative leg
 // pass; A / B only, differs from the trips by rounding).
-constexpr int kLqTripsPerSlot = 1;
+constexpr int kLqTripsPerSlot = 2;
 static int lq_trip_shift(const hb_ctx* ctx, int concurrent) {
   const int sel = ctx->hconfig.debug_stop;
   if (sel >= 120 && sel <= 124) return sel - 120;

@@ -27,6 +27,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hunter_hip.h"
@@ -545,5 +546,144 @@ inline void controllerUpdate(MpcMrtInterface& mpcMrt, const vector_t& time, cons
                         out.optimizedState.data(), out.optimizedInput.data(), out.plannedMode.data(), out.status.data()),
           "hb_wbc_update");
 }
+
+// ---- one batch over several GPUs (BASELINE north_star: "independent robot instances shard across the 8 GPUs of one
+// node") -----------------------------------------------------------------------------------------------------------------------------
+// Instances are independent: device g owns the contiguous range shardRange(batch, G, g) — the split of the Python harness
+// (hunter_bipedal_control_amd/sharding.py) — with its own Context, and every call runs the shards side by side, one host thread per
+// device for the duration of the call (a context's MPC-side calls come from one thread at a time, as the ABI asks).  Nothing is exchanged
+// between devices; results are gathered into the caller's arrays in instance order, so a sharded run returns bit for bit what one
+// context of the whole batch returns (tests/cpp/sharded_test.cpp).  `devices` may name a device more than once (two shards on one GPU).
+class ShardedSolver {
+ public:
+  // rank r of `world` owns [begin, end): sizes differ by at most one, earlier ranks take the remainder
+  static std::pair<int, int> shardRange(int total, int world, int rank) {
+    const int base = total / world, rem = total % world;
+    const int begin = rank * base + std::min(rank, rem);
+    return {begin, begin + base + (rank < rem ? 1 : 0)};
+  }
+  ShardedSolver(const hb_model& model, const hb_config& config, int batch, int maxNodes, const std::vector<int>& devices)
+      : batch_(batch), maxNodes_(maxNodes) {
+    if (devices.empty() || batch < int(devices.size())) throw std::invalid_argument("[hunter_hip] ShardedSolver: at least one instance per device");
+    for (size_t g = 0; g < devices.size(); ++g) {
+      const std::pair<int, int> r = shardRange(batch, int(devices.size()), int(g));
+      begin_.push_back(r.first);
+      mpc_.emplace_back(Context(model, config, r.second - r.first, maxNodes, devices[g]));
+      wbc_.emplace_back(mpc_.back().context());
+    }
+    begin_.push_back(batch);
+  }
+  int shards() const { return int(mpc_.size()); }
+  int batch() const { return batch_; }
+  int shardBegin(int g) const { return begin_[size_t(g)]; }
+  MpcMrtInterface& shard(int g) { return mpc_[size_t(g)]; }
+
+  void setReferences(const ReferenceTables& r) {
+    const size_t N = size_t(maxNodes_);
+    if (r.nNodes.size() != size_t(batch_)) throw std::invalid_argument("[hunter_hip] ShardedSolver::setReferences: tables of the whole batch expected");
+    forEachShard([&](int g, size_t b, size_t n) {
+      ReferenceTables s;
+      s.nNodes.assign(r.nNodes.begin() + b, r.nNodes.begin() + b + n);
+      s.t.assign(r.t.begin() + b * (N + 1), r.t.begin() + (b + n) * (N + 1));
+      s.mode.assign(r.mode.begin() + b * N, r.mode.begin() + (b + n) * N);
+      s.xRef.assign(r.xRef.begin() + b * N * HB_NX, r.xRef.begin() + (b + n) * N * HB_NX);
+      s.swingRef.assign(r.swingRef.begin() + b * N * HB_NC * HB_SWING_REF, r.swingRef.begin() + (b + n) * N * HB_NC * HB_SWING_REF);
+      mpc_[size_t(g)].setReferences(s);
+    });
+  }
+  void resetMpcNode(const vector_t& initialStates) {
+    requireSize(initialStates, size_t(batch_) * HB_NX, "resetMpcNode");
+    forEachShard([&](int g, size_t b, size_t n) { mpc_[size_t(g)].resetMpcNode(slice(initialStates, b, n, HB_NX)); });
+  }
+  // states [batch][22]: the observation every shard's next advanceMpc starts from
+  void setCurrentObservation(const vector_t& states) {
+    requireSize(states, size_t(batch_) * HB_NX, "setCurrentObservation");
+    forEachShard([&](int g, size_t b, size_t n) {
+      std::vector<SystemObservation> obs(n);
+      for (size_t i = 0; i < n; ++i) obs[i].state.assign(states.begin() + (b + i) * HB_NX, states.begin() + (b + i + 1) * HB_NX);
+      mpc_[size_t(g)].setCurrentObservation(obs);
+    });
+  }
+  // MPC_MRT_Interface::advanceMpc on every device at once; returns the per-instance status words in instance order
+  const std::vector<int32_t>& advanceMpc() {
+    mpcStatus_.assign(size_t(batch_), 0);
+    forEachShard([&](int g, size_t b, size_t) {
+      mpc_[size_t(g)].advanceMpc();
+      const std::vector<int32_t>& st = mpc_[size_t(g)].mpcStatus();
+      std::copy(st.begin(), st.end(), mpcStatus_.begin() + b);
+    });
+    return mpcStatus_;
+  }
+  void getSolution(vector_t& stateTrajectory, vector_t& inputTrajectory) {
+    const size_t N = size_t(maxNodes_);
+    stateTrajectory.assign(size_t(batch_) * (N + 1) * HB_NX, 0.0);
+    inputTrajectory.assign(size_t(batch_) * N * HB_NU, 0.0);
+    forEachShard([&](int g, size_t b, size_t) {
+      vector_t xs, us;
+      mpc_[size_t(g)].getSolution(xs, us);
+      std::copy(xs.begin(), xs.end(), stateTrajectory.begin() + b * (N + 1) * HB_NX);
+      std::copy(us.begin(), us.end(), inputTrajectory.begin() + b * N * HB_NU);
+    });
+  }
+  vector_t getPerformanceIndices() {
+    vector_t perf(size_t(batch_) * 4, 0.0);
+    forEachShard([&](int g, size_t b, size_t) {
+      const vector_t p = mpc_[size_t(g)].getPerformanceIndices();
+      std::copy(p.begin(), p.end(), perf.begin() + b * 4);
+    });
+    return perf;
+  }
+  // the hot part of LeggedController::update for the whole batch (controllerUpdate per shard); outputs in instance order
+  void controllerUpdate(const vector_t& time, const vector_t& rbdStateMeasured, const std::vector<int32_t>* walkFlag, scalar_t period,
+                        ControlOutput& out) {
+    const size_t B = size_t(batch_);
+    if (time.size() != B || rbdStateMeasured.size() != B * HB_NRBD || (walkFlag && walkFlag->size() != B))
+      throw std::invalid_argument("[hunter_hip] ShardedSolver::controllerUpdate: wrong vector size");
+    out.x.assign(B * HB_NWBC, 0.0);
+    out.optimizedState.assign(B * HB_NX, 0.0);
+    out.optimizedInput.assign(B * HB_NU, 0.0);
+    out.plannedMode.assign(B, 0);
+    out.status.assign(B, 0);
+    forEachShard([&](int g, size_t b, size_t n) {
+      ControlOutput o;
+      std::vector<int32_t> wf;
+      if (walkFlag) wf.assign(walkFlag->begin() + b, walkFlag->begin() + b + n);
+      hunter_hip::controllerUpdate(mpc_[size_t(g)], slice(time, b, n, 1), slice(rbdStateMeasured, b, n, HB_NRBD), walkFlag ? &wf : nullptr, period, o);
+      std::copy(o.x.begin(), o.x.end(), out.x.begin() + b * HB_NWBC);
+      std::copy(o.optimizedState.begin(), o.optimizedState.end(), out.optimizedState.begin() + b * HB_NX);
+      std::copy(o.optimizedInput.begin(), o.optimizedInput.end(), out.optimizedInput.begin() + b * HB_NU);
+      std::copy(o.plannedMode.begin(), o.plannedMode.end(), out.plannedMode.begin() + b);
+      std::copy(o.status.begin(), o.status.end(), out.status.begin() + b);
+    });
+  }
+
+ private:
+  static vector_t slice(const vector_t& v, size_t b, size_t n, size_t w) { return vector_t(v.begin() + b * w, v.begin() + (b + n) * w); }
+  static void requireSize(const vector_t& v, size_t n, const char* who) {
+    if (v.size() != n) throw std::invalid_argument(std::string("[hunter_hip] ShardedSolver::") + who + ": wrong vector size");
+  }
+  // f(shard, first instance, instance count) on one host thread per shard; the first exception any of them threw is rethrown here
+  template <class F>
+  void forEachShard(F f) {
+    std::vector<std::exception_ptr> err(mpc_.size());
+    std::vector<std::thread> th;
+    for (size_t g = 0; g < mpc_.size(); ++g)
+      th.emplace_back([&, g] {
+        try {
+          f(int(g), size_t(begin_[g]), size_t(begin_[g + 1] - begin_[g]));
+        } catch (...) {
+          err[g] = std::current_exception();
+        }
+      });
+    for (std::thread& t : th) t.join();
+    for (const std::exception_ptr& e : err)
+      if (e) std::rethrow_exception(e);
+  }
+  int batch_, maxNodes_;
+  std::vector<int> begin_;
+  std::vector<MpcMrtInterface> mpc_;
+  std::vector<Wbc> wbc_;
+  std::vector<int32_t> mpcStatus_;
+};
 
 }  // namespace hunter_hip

@@ -59,6 +59,7 @@ int main(int argc, char** argv) {
   const std::string mode = argv[a];
   const double seconds = argc > a + 1 ? std::atof(argv[a + 1]) : 3.0;
   if (mode == "lockstep" || mode == "hooks") ros::mock::setParam("/hunter_hip/mpc_every_n_ticks", 8.0);
+  ros::mock::setParam("/hunter_hip/estimate_contact_force", 1.0);   // (off by default: the reference's observer has no reader)
   ros::mock::setParam("/hunter_hip/time_horizon", 1.5);   // the benchmark's horizon (N = 100); task.info ships 0.8
 
   // ---- controller_manager's part: instantiate the plugin by its registered name and initialise it

@@ -120,6 +120,8 @@ def test_bench_under_the_launcher_goes_through_rccl_even_with_one_rank():
     assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
     j = json.loads(lines[-1])
     assert j["n_gpus"] == 1 and j["scaling"] == "strong" and j["config"]["total_instances"] == 96 and j["config"]["batch_per_gpu"] == 96
+    # the line says who took part: one rank in the RCCL all-reduce, one distinct device (N of each on N GPUs — what a SCALE run is audited on)
+    assert j["rccl_ranks"] == 1 and isinstance(j["devices"], list) and len(j["devices"]) == 1 and j["devices"][0]
     assert j["metric"] == "MPC+WBC updates/sec (batch=96, N=24, 12-DoF)" and j["value_per_gpu"] == j["value"]
     assert j["gather"]["bytes_per_rank"] > 0 and j["gather"]["ms_per_step"] > 0
     assert j["roofline"]["frac"] > 0 and j["roofline"]["traffic"] is None   # (counter traffic belongs to the 4096 x 100 headline only)

@@ -178,3 +178,45 @@ def test_cpp_lcm_codec_matches_the_reference_bytes(tmp_path):
     r = subprocess.run([str(exe), str(PARAMS_BIN), "lcm", str(vec)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout + r.stderr)
     assert f"ok: {n} lcm messages" in r.stdout
+
+
+def _build_sharded():
+    lib = PKG / "libhunter_hip.so"
+    if not lib.exists():
+        pytest.skip("libhunter_hip.so not built (python __graft_entry__.py build)")
+    out = ROOT / "tests" / "cpp" / "_build"
+    out.mkdir(exist_ok=True)
+    exe = out / "sharded_test"
+    src = ROOT / "tests" / "cpp" / "sharded_test.cpp"
+    newest = max(src.stat().st_mtime, (ROOT / "include" / "hunter_hip.hpp").stat().st_mtime, lib.stat().st_mtime)
+    if not exe.exists() or exe.stat().st_mtime < newest:
+        subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-pthread", "-I", str(ROOT / "include"), str(src), "-L", str(PKG),
+                               "-lhunter_hip", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    return exe
+
+
+def test_cpp_sharded_solver_splits_like_the_python_harness():
+    """hunter_hip::ShardedSolver::shardRange == sharding.shard_range (SURVEY.md 8e: contiguous ranges, remainder to the first ranks)."""
+    from hunter_bipedal_control_amd import sharding
+    exe = _build_sharded()
+    for total, world in ((4096, 8), (4096, 1), (10, 3), (7, 7), (8193, 8)):
+        r = subprocess.run([str(exe), "-", "ranges", str(total), str(world)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got = [tuple(int(v) for v in line.split()) for line in r.stdout.strip().splitlines()]
+        assert got == [sharding.shard_range(total, world, k) for k in range(world)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [2, 3])
+def test_cpp_sharded_solver_equals_one_context_bit_for_bit(params, tmp_path, shards):
+    """One batch over G contexts (here all on device 0, one host thread each) returns exactly what one context of the whole batch
+    returns: trajectories, status words, performance indices, policy evaluation and WBC solutions (the multi-device entry below
+    Python that BASELINE's north_star asks of the C++ host side)."""
+    exe = _build_sharded()
+    B, N = 7, 40
+    refs, x0, rbd, t_now = workloads.trot_batch(params, B, n_intervals=N)
+    nmax = refs["mode"].shape[1]
+    prob = tmp_path / "problem.bin"
+    _write_problem(prob, refs, x0, rbd, t_now, nmax)
+    r = subprocess.run([str(exe), str(PARAMS_BIN), "run", str(prob), str(shards), "2"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("identical"), r.stdout + r.stderr

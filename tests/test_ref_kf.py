@@ -114,6 +114,48 @@ def test_device_contact_force_algorithm_on_the_host_emulator_matches_reference(g
             assert np.abs(cf - gold[f"{name}_out_cf"][k]).max() < 1e-8 * max(1.0, np.abs(gold[f"{name}_out_cf"][k]).max()), (name, k)
 
 
+def test_device_contact_force_algorithm_stays_finite_at_leg_singularities(params, oracle):
+    """the per-leg minimum-norm wrench solves a 5 x 5 system A A' that loses rank when a leg's pitch axes line up.  The device
+    algorithm (host emulator) must return finite numbers there — a truncated solution like the reference's bdcSvd().solve and the
+    oracle's thresholded pseudo-inverse — and agree with the oracle wherever A A' is well conditioned.  Sweep: joint configurations around
+    zero knee / ankle angles, the places where the hunter's hip-pitch, knee and ankle axes (all parallel) can come into line."""
+    import ctypes as C
+    import _hostemu
+    lib = C.CDLL(str(_hostemu.build()))
+    mdl = abi.make_model(params)
+    dt, cutoff = 0.002, 250.0
+    gama = np.exp(-cutoff * dt)
+    beta = (1 - gama) / (gama * dt)
+    _p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(7)
+    n_checked = 0
+    for trial in range(40):
+        rbd = np.zeros(32)
+        rbd[5] = 0.9
+        qj = 0.3 * rng.standard_normal(10)
+        if trial % 2 == 0:
+            qj[[3, 4, 8, 9]] = 0.0 if trial % 4 == 0 else 1e-9 * rng.standard_normal(4)   # straight knees and ankles
+        if trial % 8 == 0:
+            qj[[2, 7]] = 0.0
+        rbd[6:16] = qj
+        rbd[16:] = 0.2 * rng.standard_normal(16)
+        tau = 5.0 * rng.standard_normal(10)
+        z, dist, cf = np.zeros(16), np.zeros(16), np.zeros(16)
+        lib.emu_contact_force(C.byref(mdl), C.c_double(gama), C.c_double(beta), _p(rbd), _p(tau), _p(z), _p(dist), _p(cf))
+        assert np.isfinite(dist).all() and np.isfinite(cf).all() and np.isfinite(z).all(), (trial, cf)
+        # agreement with the oracle where the leg rows are well conditioned
+        J6 = oracle.contact_force_rbd(np.concatenate([rbd[3:6], rbd[0:3], rbd[6:16]]), np.zeros(16))["J6"]
+        conds = [np.linalg.cond(J6[leg][:, 6 + 5 * leg:11 + 5 * leg]) for leg in range(2)]
+        zo = np.zeros((1, 16))
+        do, co = oracle.contact_force(cutoff, dt, zo, rbd, tau)
+        assert np.abs(dist - do[0]).max() < 1e-8 * max(1.0, np.abs(do).max())
+        for leg in range(2):
+            if conds[leg] < 1e6:
+                assert np.abs(cf[6 * leg:6 * leg + 6] - co[0][6 * leg:6 * leg + 6]).max() < 1e-6 * max(1.0, np.abs(co).max()), (trial, leg, conds)
+                n_checked += 1
+    assert n_checked >= 20
+
+
 @pytest.mark.gpu
 def test_device_contact_force_matches_reference_estContactForce(gold, params):
     """hb_estimator_contact_force through the C-ABI: the four sensor streams as a batch of four, tick after tick (observer state on the

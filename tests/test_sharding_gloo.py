@@ -88,7 +88,8 @@ def _worker(rank, world, port, q):
         t = sharding.max_over_ranks(1.0 + rank, dist)                    # slowest rank defines the step time
         accepted = sum(1 for r in rows if r[2] > 0.0)
         hist = sharding.sum_over_ranks([accepted, len(rows) - accepted, 0, 0], dist)   # status histogram of the whole job
-        q.put((rank, rows, t, hist))
+        who = sharding.participants(f"dev{rank}", dist)                  # ranks in the all-reduce of 1 + every rank's device identity
+        q.put((rank, rows, t, hist, who))
     finally:
         dist.destroy_process_group()
 
@@ -110,7 +111,8 @@ def test_two_ranks_over_gloo_solve_disjoint_shards_equal_to_one_rank(params):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, rows0, t0, h0), (r1, rows1, t1, h1) = out
+    (r0, rows0, t0, h0, w0), (r1, rows1, t1, h1, w1) = out
+    assert w0 == w1 == (2, ["dev0", "dev1"])                             # what bench.py prints as rccl_ranks / devices
     assert [r[0] for r in rows0] == [0, 1, 2] and [r[0] for r in rows1] == [3, 4, 5]
     assert t0 == t1 == 2.0 and h0 == h1 and sum(h0) == TOTAL
     whole = _solve_shard(params, 0, TOTAL)

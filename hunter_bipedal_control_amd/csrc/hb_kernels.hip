@@ -214,6 +214,9 @@ __global__ void k_mpc_status(Batch b, int first_iteration) {
 #ifndef HB_LQ_LDS_PAD
 #define HB_LQ_LDS_PAD 0
 #endif
+#ifndef HB_LQ_S_PRIO
+#define HB_LQ_S_PRIO 0
+#endif
 __global__ __launch_bounds__(64, 3) void k_lq(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
   const int k = blockIdx.x, inst = blockIdx.y;
   __shared__ double lds[LqLds::total + HB_LQ_LDS_PAD];
@@ -273,9 +276,11 @@ __global__ __launch_bounds__(64, 3) void k_lq_trip(Batch b, const DevModel* __re
   WaveCtx().sync();
   // (profiling build, 125: the value phase runs once per trip, later launches re-use what it parked — the dense part alone on valid data)
   if (!(HB_ABLATE_ON && C->debug_stop == 125 && park[size_t(LqPark::n_feet / 4 << tshift) * 16] != 0.0)) {
-    // every lane runs the value phase (the staged stores are the whole wavefront's work)
+    // (the phase is one long dependent chain of a single wavefront: ask the arbiter to issue it ahead of the dense work it shares the SIMD with)
+    __builtin_amdgcn_s_setprio(HB_LQ_S_PRIO);
     lq_trip_values(LqTrip{lds, park, tshift, nt, int(threadIdx.x), HB_ABLATE_ON ? C->debug_stop : 0}, *M, *C, b.x + size_t(inst) * (b.Nmax + 1) * HB_NX, b.u + size_t(inst) * b.Nmax * HB_NU,
                    b.swing + size_t(inst) * b.Nmax * 24, tt, b.mode + size_t(inst) * b.Nmax, k0);
+    __builtin_amdgcn_s_setprio(0);
   }
   // the images are read back by other lanes of this wavefront: stores complete before the first load is issued
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2135,12 +2140,12 @@ static void launch_ric_bwd(hb_ctx* ctx, const Batch& b, int B, int concurrent, h
 }
 
 // LQ approximation: trips of 2^tshift nodes per wavefront (k_lq_trip).  Longer trips fill the lanes of the value phase better (16 nodes:
-// all 64) — measured best or equal at 512 .. 4096 instances —, shorter ones keep small batches spread over the chip: the longest trip
-// that still gives every wavefront slot of the chip (12 per CU) two trips of the CONCURRENT batch (512 x 108 on two ranges: 16 nodes a
-// trip left a slot ONE trip, 1.73 ms a step against 1.55).  The result does not depend on the
+// all 64), shorter ones keep small batches spread over the chip and balance them finer: the longest trip
+// that still gives every wavefront slot of the chip (12 per CU) four trips of the CONCURRENT batch — 16 nodes from 2048 instances up, 8 at
+// 1024, 4 at 512 (512 x 108 on two ranges, updates/s: one-node kernel 329.7 k, 4 nodes 325.0 k, 8: 316.9 k, 16: 305.2 k).  The result does not depend on the
 // choice.  hb_config.reserved = 120 + s forces 2^s; 129 the one-node-per-wavefront kernel of rounds 1-5 (k_lq: cooperative leg
 // pass; A / B only, differs from the trips by rounding).
-constexpr int kLqTripsPerSlot = 2;
+constexpr int kLqTripsPerSlot = 4;
 static int lq_trip_shift(const hb_ctx* ctx, int concurrent) {
   const int sel = ctx->hconfig.debug_stop;
   if (sel >= 120 && sel <= 124) return sel - 120;

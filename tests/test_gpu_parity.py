@@ -1047,3 +1047,52 @@ def test_sqp_step_identical_with_either_form_of_the_sweeps(params, gait):
         for k, (p, q) in enumerate(zip(res[101], res[variant])):
             assert np.array_equal(p, q), (gait, variant, k)
     assert res[101][7].max() == 0 and np.isfinite(res[101][0]).all()
+
+
+@pytest.mark.parametrize("gait", ["trot", "ragged"])
+def test_lq_trip_lengths_agree_bit_for_bit_and_with_the_one_node_kernel(params, gait):
+    """k_lq_trip: a wavefront takes a trip of 2^s consecutive nodes of an instance (hb_config.reserved = 120 + s; the product picks s by
+    the number of instances in flight).  A node's arithmetic does not depend on the trip length — every s gives the same bits, ragged
+    horizons and trips cut short by the horizon's end included —, and the one-node-per-wavefront kernel of rounds 1-5 (129: cooperative
+    leg pass with cross-lane scans) differs from the trips by rounding only (serial leg pass, peeled frames): 1e-9 relative on the
+    iterate after three SQP iterations, identical accepted step sizes and status words."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    if gait == "trot":
+        refs, x0, rbd, t_now = workloads.trot_batch(params, 12, n_intervals=37, max_nodes=44)
+    else:
+        specs = [("trot", 0.03, 0.6), ("standing_trot", 0.03, 0.6), ("flying_trot", 0.03, 0.6), ("trot", 0.1, 0.015),
+                 ("flying_trot", 0.26, 0.2), ("stance", 0.0, 0.3), ("trot", 0.37, 0.5), ("standing_trot", 0.2, 0.33)]
+        tabs, xs = [], []
+        for i, (g, t0, hor) in enumerate(specs):
+            xi = workload.perturbed_state(params, 100 + i)
+            tabs.append(refgen.make_trot_problem(params, t0, hor, xi, (0.25, 0.05, 0.0, 0.2), 44, gait=g))
+            xs.append(xi)
+        refs, x0 = refgen.stack_tables(tabs), np.stack(xs)
+        rbd = np.stack([workload.rbd_from_state(x0[i], i) for i in range(len(specs))])
+        t_now = refs["t"][:, 0] + 0.004
+    B = x0.shape[0]
+    res = {}
+    for variant in (120, 121, 122, 123, 124, 129):
+        s = HunterSolver(params, batch=B, max_nodes=44, reserved=variant)
+        try:
+            s.set_references(refs)
+            s.reset(x0)
+            s.set_resident_inputs(x0, t_now, rbd)
+            for _ in range(3):
+                s.step_resident()
+            xs_, us_ = s.get_solution()
+            dx_, du_ = s.get_step()
+            sol_, st_ = s.get_wbc_solution()
+            res[variant] = (xs_, us_, dx_, du_, s.get_performance(), sol_, st_, s.mpc_status())
+        finally:
+            s.close()
+    for variant in (121, 122, 123, 124):
+        for k, (p, q) in enumerate(zip(res[120], res[variant])):
+            assert np.array_equal(p, q), (gait, variant, k)
+    assert res[124][7].max() == 0 and np.isfinite(res[124][0]).all()
+    one = res[129]
+    assert np.array_equal(one[7], res[124][7]) and np.array_equal(one[6], res[124][6])
+    assert np.array_equal(one[4][:, 3], res[124][4][:, 3])                       # accepted step sizes
+    for k in (0, 1):
+        scale = max(1.0, np.abs(one[k]).max())
+        assert np.abs(one[k] - res[124][k]).max() < 1e-9 * scale, (gait, k, np.abs(one[k] - res[124][k]).max())

@@ -601,6 +601,9 @@ def main():
             try:
                 pj = json.loads(pmc.read_text())
                 stamp = f"tag {pj.get('tag')}, commit {pj.get('git_head')}, kernel sources sha256 {str(pj.get('source_sha256'))[:12]}"
+                # (the counter file names kernels as the profiler does: the LQ approximation runs as k_lq_trip since round 6)
+                if "k_lq_trip" in pj:
+                    pj["k_lq"] = pj["k_lq_trip"]
                 if pj.get("source_sha256") == source_fingerprint():
                     traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
                     traffic_source = (f"profiles/pmc_latest.json ({stamp} = the running tree's kernel sources): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "

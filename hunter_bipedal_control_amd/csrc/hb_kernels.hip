@@ -214,9 +214,6 @@ __global__ void k_mpc_status(Batch b, int first_iteration) {
 #ifndef HB_LQ_LDS_PAD
 #define HB_LQ_LDS_PAD 0
 #endif
-#ifndef HB_LQ_S_PRIO
-#define HB_LQ_S_PRIO 0
-#endif
 __global__ __launch_bounds__(64, 3) void k_lq(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C) {
   const int k = blockIdx.x, inst = blockIdx.y;
   __shared__ double lds[LqLds::total + HB_LQ_LDS_PAD];
@@ -276,11 +273,10 @@ __global__ __launch_bounds__(64, 3) void k_lq_trip(Batch b, const DevModel* __re
   WaveCtx().sync();
   // (profiling build, 125: the value phase runs once per trip, later launches re-use what it parked — the dense part alone on valid data)
   if (!(HB_ABLATE_ON && C->debug_stop == 125 && park[size_t(LqPark::n_feet / 4 << tshift) * 16] != 0.0)) {
-    // (the phase is one long dependent chain of a single wavefront: ask the arbiter to issue it ahead of the dense work it shares the SIMD with)
-    __builtin_amdgcn_s_setprio(HB_LQ_S_PRIO);
+    // (every lane runs the phase: lanes beyond the trip's last node repeat it and park nothing.  Raising the wavefront's priority for
+    // this one long dependent chain was tried — s_setprio 3: 515 k against 525 k updates/s — and dropped)
     lq_trip_values(LqTrip{lds, park, tshift, nt, int(threadIdx.x), HB_ABLATE_ON ? C->debug_stop : 0}, *M, *C, b.x + size_t(inst) * (b.Nmax + 1) * HB_NX, b.u + size_t(inst) * b.Nmax * HB_NU,
                    b.swing + size_t(inst) * b.Nmax * 24, tt, b.mode + size_t(inst) * b.Nmax, k0);
-    __builtin_amdgcn_s_setprio(0);
   }
   // the images are read back by other lanes of this wavefront: stores complete before the first load is issued
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -1252,7 +1252,7 @@ __device__ __forceinline__ void lq_park_out(const LqTrip& tr, int n0, const doub
   asm volatile("" : "+v"(lane));   // (addresses rebuilt per call: kept across the calls of a whole phase they were spilled)
   lane &= 63;
   const int t = lane >> 2, e = lane & 3;
-  if (t < tr.nt) {
+  if (t < tr.nt && !(HB_ABLATE_ON && tr.dbg == 119)) {   // (profiling build, 119: the value phase computes but parks nothing — stale data is read back)
     double* line = tr.park + ((size_t(n0 >> 2) << tr.tshift) + t) * 16 + 2 * e;
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
@@ -1280,7 +1280,7 @@ __device__ __forceinline__ void lq_trip_leg_pass(const LqTrip& tr, const DevMode
   double* pfl = tr.lds + LqPark::feet + 6 * tr.lane;         // the leg's two contact points: read where used, not carried through the backward sweep
   const int j0 = 5 * leg;
   // the leg's joint angles and rates, requested together up front and picked by the (uniform) joint index with selects: read where they
-  // are used, every joint of the sweeps waited for a global-memory round trip — behind the staged stores of the joint before it
+  // are used, every joint of the sweeps waited for a global-memory round trip — behind the stores of the joint before it
   double qa[5], qr[5];
 #pragma unroll
   for (int k = 0; k < 5; ++k) { qr[k] = uk[12 + j0 + k]; qa[k] = xk[12 + j0 + k] + dts * qr[k]; }
@@ -1356,7 +1356,7 @@ __device__ __forceinline__ void lq_trip_leg_pass(const LqTrip& tr, const DevMode
   st3(val + 15, ld3(pfl)); st3(val + 18, ld3(pfl + 3)); st3(val + 21, vj[0]); st3(val + 24, vj[1]);
 }
 // value phase of the lane's (node, leg evaluation) pair (the four lanes of a quad share a node; lanes beyond the trip's last node repeat
-// it — every lane takes part in the staged stores — and nothing of theirs is parked)
+// it and nothing of theirs is parked)
 // Uniform arguments: the instance's state / input / swing-reference / node-time / mode arrays and the trip's first node; the lane's node
 // pointers are formed twice — for the leg pass and, from an opaque copy of the lane id, again behind it: carried across the leg pass
 // (the register peak of the phase) they were spilled.
@@ -1437,7 +1437,7 @@ __device__ __forceinline__ void lq_trip_values(const LqTrip& tr, const DevModel&
     for (int j = 0; j < 5; ++j) rm[j] = leg ? (j < 4 ? pv.R.m[5 + j] : pv.icy) : pv.R.m[j];
     // The node's 36 values of this point — every lane of the quad holds all of them, lane e parks entries 9 e .. 9 e + 8: handed out
     // through LDS (lane 0 of the quad writes, everyone picks its nine; selected in registers, the 36 were the phase's register peak).
-    // The place is the staging tile's (over the first point's stash), free once every lane has read this point's stash.
+    // The place lies over the first point's stash, free once every lane has read this point's stash.
     const double flin[3] = {inv_m * fsx, inv_m * fsy, inv_m * fsz - M.gravity};
     const double fang[3] = {inv_m * msx, inv_m * msy, inv_m * msz};
     double mine[9];

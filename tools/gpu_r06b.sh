@@ -1,4 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
-python tools/share_ab.py --reserved 0 129 124 123 122 0 129
-python tools/share_ab.py --lib variants/lib_base.so --reserved 0 0
+python tools/perf_quick.py --lib variants/libhunter_hip_ablate.so --steps 20
+python tools/perf_quick.py --lib variants/libhunter_hip_ablate.so --steps 20 --reserved 119
+python tools/perf_quick.py --lib variants/libhunter_hip_ablate.so --steps 20 --reserved 125

@@ -283,6 +283,8 @@ __global__ __launch_bounds__(64, 3) void k_lq_trip(Batch b, const DevModel* __re
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   if (HB_ABLATE_ON && C->debug_stop >= 126 && C->debug_stop <= 128) return;   // profiling build: the value phase alone (127 / 128: parts of it)
+  // the lane's entry of the table the cost phase reads per lane, for all the trip's nodes (NodeIn::consts)
+  const double c_tab = lq_lane_constants(*M, *C, threadIdx.x);
   for (int t = 0; t < nt; ++t) {
     // (the lane id is rebuilt from an opaque copy every node: as loop invariants the compiler hoists the per-lane offsets of the whole
     // node out of the loop and spills them — as in k_ric_bwd)
@@ -307,12 +309,16 @@ __global__ __launch_bounds__(64, 3) void k_lq_trip(Batch b, const DevModel* __re
       in.dt = __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
     }
     in.mode = __builtin_amdgcn_readfirstlane(b.mode[nd]);
+    in.consts = true;
+    in.c_tab = c_tab;
     lq_image_to_lds(park, t, tshift, lds, l);
     if (l < HB_NX) { lds[LqLds::xs + l] = x_lane; lds[LqLds::us + l] = u_lane; }
     cx.sync();
     const double* park_lds = lds + LqLds::park;
     const double* xnext_lds = lds + LqLds::xnext_park;
-    lq_node_dense(cx, *M, *C, in, lds, b.recs + nd * REC_SIZE, [park_lds](int i) { return park_lds[i]; }, [xnext_lds](int i) { return xnext_lds[i]; });
+    // (profiling build, 117: every node of a workgroup writes ONE record slot — the stores are issued, their lines stay in the L2)
+    double* recp = b.recs + ((HB_ABLATE_ON && C->debug_stop == 117) ? size_t(blockIdx.x & 4095) : nd) * REC_SIZE;
+    lq_node_dense(cx, *M, *C, in, lds, recp, [park_lds](int i) { return park_lds[i]; }, [xnext_lds](int i) { return xnext_lds[i]; });
     cx.sync();
   }
 #endif

@@ -210,6 +210,12 @@ struct NodeIn {
   bool preloaded = false;
   double x_lane = 0.0, u_lane = 0.0;
   const LegJointConst* jc = nullptr;
+  // device kernel: the lane's entry of the node-INVARIANT table the cost phase reads per lane (lq_lane_constants) — entry `lane` of
+  // [Q_diag 22 | R_FF_diag 12 | q_lower 10 | q_upper 10 | qd_limit 10].  The trip kernel holds it in a register pair for all its nodes and
+  // lq_tail requests R_jj before the record's first store: read where they are used — behind those stores — every one of these loads
+  // waited for the stores before it to drain (loads and stores retire in order on one counter), five times per node.
+  bool consts = false;
+  double c_tab = 0.0;
 };
 
 // Pointers into the phase-1 view of one node's LDS region (LqLds).
@@ -758,11 +764,22 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
 
   HB_ABLATE_STOP(C.debug_stop == 3);
 #if defined(__HIP_DEVICE_COMPILE__)
-  // the per-role constants of the cost phase (lane = role): weight and the two limits of the role's relaxed barrier, requested HERE —
-  // behind the projection, whose factor has left the registers — so that their global-memory round trip runs under the record's dynamics
-  // part instead of in the middle of the cost phase
+  // the per-role constants of the cost phase (lane = role): weight and the two limits of the role's relaxed barrier.  With the lane's table
+  // entries in registers (NodeIn::consts) they are gathered from the other lanes in the cost phase itself; otherwise requested HERE — behind
+  // the projection, whose factor has left the registers
   double cw_reg = 0.0, clo_reg = 0.0, chi_reg = 0.0;
-  {
+  // R_jj (100 doubles: entries l and 64 + l of a lane) is requested HERE — before the record's first store — and dropped into the head of W
+  // (dead behind the solves; P_j is written there behind the soft-row product, whose accumulator start values are the last thing read from
+  // this copy) right before that store, with the A~ product between request and use.  Issued behind a store, a load waits for every store
+  // before it to drain (one in-order counter), and the compiler's count of the stores in between is the minimum over all paths around the
+  // lane-masked store blocks, i.e. nearly a full drain.
+  double rj0_reg = 0.0, rj1_reg = 0.0;
+  if (in.consts) {
+    rj0_reg = C.R_jj[cx.lane];
+    if (cx.lane < 36) rj1_reg = C.R_jj[64 + cx.lane];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!in.consts) {
     const int role = cx.lane;
     if (role < 22) {
       cw_reg = C.Q_diag[role];
@@ -795,6 +812,13 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     WaveTile<1, 2> ta;
     tile_init(cx, ta, 12, 22, [ABt](int row, int c) { return ABt[c * 12 + row]; });
     tile_mma<12, 12, true, LDK, false, 10>(cx, ta, ABt + 34 * 12, Kx, 12, LDK);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (in.consts) {
+      W[cx.lane] = rj0_reg;
+      if (cx.lane < 36) W[64 + cx.lane] = rj1_reg;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     tile_store_rm_cols<REC_LD>(cx, ta, 12, 0, 22, rec + rec_A(0, 0));
     tile_store_rm_cols<1>(cx, ta, 12, 22, 23, btmp - 22);
     tile_store_rm_cols<REC_LD>(cx, ta, 12, 23, 23 + nz, rec + rec_A(0, 0) + n_f);
@@ -873,6 +897,24 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
     double shift_sum = 0;
     for (int i = 0; i < HB_NC; ++i)
       if (cf[i]) shift_sum += -coneb[12 * i + 8] * C.friction_shift;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The lane-indexed constants of this phase out of the registers the kernel holds them in (NodeIn::consts; table order
+    // [Q_diag 22 | R_FF_diag 12 | q_lower 10 | q_upper 10 | qd_limit 10], entry l in lane l): role < 34 reads its own entry, the limits and
+    // the R_FF weights of the foot roles come from other lanes through the LDS crossbar; R_jj waits at the head of W (see behind the solves).
+    double rff_reg[3] = {0.0, 0.0, 0.0};
+    const double* Rc_lds = C.R_jj;
+    if (in.consts) {
+      const int l = cx.lane, foot = (l - 56) & 3;
+      const double g1 = wave_gather_f64(in.c_tab, l < 22 ? l + 22 : (l < 44 ? l + 20 : 22 + 3 * foot));
+      const double g2 = wave_gather_f64(in.c_tab, l < 22 ? l + 32 : 23 + 3 * foot);
+      const double g3 = wave_gather_f64(in.c_tab, 24 + 3 * foot);
+      cw_reg = in.c_tab;
+      clo_reg = g1;
+      chi_reg = g2;
+      rff_reg[0] = g1; rff_reg[1] = g2; rff_reg[2] = g3;
+      Rc_lds = W;
+    }
+#endif
     for (int role = cx.lane; role < 64; role += cx.nlanes) {
       double pc = 0, pd = 0, pe = 0;
       // two-sided relaxed barrier of this role, evaluated once on a common path (joint position limits, F_z limits,
@@ -954,7 +996,11 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
       } else if (role < 44) {
         const int k = role - 34;
         double sacc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int l = 0; l < HB_NJ; ++l) sacc += Rc_lds[k * 10 + l] * us[12 + l];
+#else
         for (int l = 0; l < HB_NJ; ++l) sacc += C.R_jj[k * 10 + l] * us[12 + l];
+#endif
         pc += 0.5 * us[12 + k] * sacc;
         pc += bval;
         ru[12 + k] = sacc + bd1;
@@ -969,7 +1015,11 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
         // R_FF block of this foot: diagonal weight + shift (+ F_z limit curvature) + friction-cone curvature
         double blk[9];
         for (int e = 0; e < 9; ++e) blk[e] = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int a = 0; a < 3; ++a) blk[4 * a] = (in.consts ? rff_reg[a] : C.R_FF_diag[3 * foot + a]) + shift_sum;
+#else
         for (int a = 0; a < 3; ++a) blk[4 * a] = C.R_FF_diag[3 * foot + a] + shift_sum;
+#endif
         {
           const double h = us[3 * foot + 2];
           blk[8] += bf.d2(h - C.force_lim[0]) + bf.d2(C.force_lim[1] - h);
@@ -1021,7 +1071,11 @@ HB_HD void lq_tail(const Ctx& cx, const DevModel& M, const DevConfig& C, const N
   }
   {
     const double sw = C.soft_w;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double* Rc = in.consts ? W : C.R_jj;   // (the copy behind the solves: P_j is written there by this product's store)
+#else
     const double* Rc = C.R_jj;
+#endif
     WaveTile<1, 2> tg;
     tile_init(cx, tg, 10, 32, [Rc, scal](int k, int r) {
       const int rr = (r >= 22 ? r : 22) - 22;
@@ -1530,6 +1584,10 @@ __device__ __forceinline__ void lq_image_to_lds(const double* trip_base, int t, 
 static_assert(LqLds::LJ % 2 == 0 && LEGJ_SIZE % 2 == 0, "the pairs of the leg blocks are 16-byte aligned in LDS");
 #endif
 
+// the lane's entry of the node-invariant table of the cost phase (NodeIn::consts)
+HB_HD double lq_lane_constants(const DevModel& M, const DevConfig& C, int l) {
+  return l < 22 ? C.Q_diag[l] : (l < 34 ? C.R_FF_diag[l - 22] : (l < 44 ? M.q_lower[l - 34] : (l < 54 ? M.q_upper[l - 44] : M.qd_limit[l - 54])));
+}
 // model constants of the (leg evaluation, joint) task lane `lane` has in k_lq's leg pass (leg_value_pass_coop: group lane >> 3, joint lane & 7)
 HB_HD void lq_leg_const_of_lane(const DevModel& M, int lane, LegJointConst& jc) {
   const int dg = lane >> 3, dk = lane & 7;

@@ -246,6 +246,12 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __device__ __forceinline__ double wave_bcast_f64(double v, int src) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
+// Value of lane `src` (per lane, 0..63) — through the LDS crossbar (ds_bpermute_b32 x 2): no memory is touched and nothing queues behind
+// the wavefront's global stores
+__device__ __forceinline__ double wave_gather_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
 // Scans over groups of eight lanes whose lanes 5..7 hold zeros (group = one leg evaluation, lane k < 5 = joint k).  Row shifts
 // stay inside a DPP row of 16 = two groups; the bank mask (banks = lanes 0-3, 4-7, 8-11, 12-15 of the row) keeps a shift from
 // writing lanes it must not: a suffix sum never needs to update lanes 4..7 of a group (lane 4 would only add the zeros above

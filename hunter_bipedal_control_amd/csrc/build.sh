@@ -7,11 +7,13 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=../libhunter_hip.so
 # --ablate: the profiling variant with the phase-by-phase exits compiled in (tools/perf_quick.py --lib variants/libhunter_hip_ablate.so --ablate-lq)
-if [ "$1" = "--ablate" ]; then shift; mkdir -p ../../variants; OUT=../../variants/libhunter_hip_ablate.so; set -- -DHB_ABLATE "$@"; fi
+# (the profiling variant may spill: its phase exits change the register allocation; scratch there is reported, not fatal)
+ABLATE=0
+if [ "$1" = "--ablate" ]; then shift; mkdir -p ../../variants; OUT=../../variants/libhunter_hip_ablate.so; ABLATE=1; set -- -DHB_ABLATE "$@"; fi
 LOG=$(mktemp)
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -mllvm -disable-machine-licm -fPIC -shared -Rpass-analysis=kernel-resource-usage -o $OUT hb_kernels.hip "$@" 2> "$LOG" || { cat "$LOG" >&2; rm -f "$LOG"; exit 1; }
 grep -E "error|warning:" "$LOG" | grep -v "Wcomment" >&2 || true
-python3 - "$LOG" <<'PY'
+python3 - "$LOG" "$ABLATE" <<'PY'
 import re, sys
 hot = ["k_lqE", "k_lq_tripE", "8k_refgenE", "k_refgen_ikE", "k_refgen_nodesE", "k_estimatorE", "k_warm_shiftE", "k_ric_bwdE", "k_ric_bwd4E", "k_ric_fwdE", "k_ric_fwd_wE", "5k_wbcE", "6k_hwbcE", "k_ls_evalE", "k_ls_tail_evalE", "k_ls_tail_decideE", "k_policy_evalE"]
 txt = open(sys.argv[1]).read()
@@ -24,7 +26,9 @@ for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?Scra
             bad.append(name)
 print("hot-kernel resources (gfx950):")
 print("\n".join(rows))
-if bad:
+if bad and sys.argv[2] == "1":
+    print("build.sh --ablate: scratch memory in " + ", ".join(bad) + " (profiling variant: tolerated)")
+elif bad:
     sys.exit("build.sh: scratch memory in hot kernel(s): " + ", ".join(bad))
 PY
 rm -f "$LOG"

@@ -282,6 +282,16 @@ __global__ __launch_bounds__(64, 3) void k_lq_trip(Batch b, const DevModel* __re
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#if defined(HB_ABLATE) && defined(HB_LQV_TRACE)
+  if (C->debug_stop == 118 && blockIdx.x == 1000 && threadIdx.x == 0) {
+    const long long* m = reinterpret_cast<const long long*>(lds + LqLds::total - 24);
+    const long long t12 = __builtin_readcyclecounter();
+    printf("lq value-phase trace (cycles): loads %lld | fwd sweep %lld | feet %lld | bwd joints %lld %lld %lld %lld %lld | stash %lld | wait %lld | value pass 0 %lld | 1 %lld | drain %lld\n",
+           m[1] - m[0], m[2] - m[1], 0LL, m[3] - m[2], m[4] - m[3], m[5] - m[4], m[6] - m[5], m[7] - m[6], m[8] - m[7], m[9] - m[8], m[10] - m[9], m[11] - m[10], t12 - m[11]);
+    printf("   value pass 1: stash reads %lld | point values %lld | contact point, sums %lld | hand-out %lld | park %lld\n", m[12] - m[10], m[13] - m[12], m[14] - m[13], m[15] - m[14], m[11] - m[15]);
+  }
+  if (C->debug_stop == 118) return;
+#endif
   if (HB_ABLATE_ON && C->debug_stop >= 126 && C->debug_stop <= 128) return;   // profiling build: the value phase alone (127 / 128: parts of it)
   // the lane's entry of the table the cost phase reads per lane, for all the trip's nodes (NodeIn::consts)
   const double c_tab = lq_lane_constants(*M, *C, threadIdx.x);

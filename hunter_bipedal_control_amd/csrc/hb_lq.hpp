@@ -1295,6 +1295,13 @@ struct LqTrip {   // what the value phase's helpers share
   int tshift, nt, lane;
   int dbg;        // profiling build: 127 / 128 leave the value phase behind the forward sweep / the leg pass
 };
+#if defined(HB_ABLATE) && defined(HB_LQV_TRACE)
+// cycle-counter trace of ONE wavefront's value phase (build.sh --ablate -DHB_LQV_TRACE, tools/perf_quick.py --stop 118): marks in the last
+// words of the node's LDS.  The compiler moves arithmetic across the marks: good for the sweeps and the waits, coarse inside the value passes.
+#define HB_LQV_MARK(tr, i) if ((tr).dbg == 118 && blockIdx.x == 1000 && (tr).lane == 0) reinterpret_cast<long long*>((tr).lds + LqLds::total - 24)[i] = __builtin_readcyclecounter();
+#else
+#define HB_LQV_MARK(tr, i)
+#endif
 __device__ __forceinline__ void lq_wave_order() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -1341,6 +1348,7 @@ __device__ __forceinline__ void lq_trip_leg_pass(const LqTrip& tr, const DevMode
   auto pick = [](const double* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : (k == 3 ? v[3] : v[4]))); };
   Mat3<double> R = Mat3<double>::identity();
   Vec3<double> op, om, w;
+  HB_LQV_MARK(tr, 1)
 #pragma unroll 1
   for (int k = 0; k < 5; ++k) {
     const double* jc = jct + 16 * k;
@@ -1357,6 +1365,7 @@ __device__ __forceinline__ void lq_trip_leg_pass(const LqTrip& tr, const DevMode
     op = o;
   }
   if (HB_ABLATE_ON && tr.dbg == 127) return;
+  HB_LQV_MARK(tr, 2)
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const int ci = leg + 2 * f;
@@ -1394,6 +1403,7 @@ __device__ __forceinline__ void lq_trip_leg_pass(const LqTrip& tr, const DevMode
 #pragma unroll
       for (int cch = 0; cch < LEGJ_STRIDE / 8; ++cch) lq_park_out(tr, k * LEGJ_STRIDE + 8 * cch, v + 8 * cch);
     }
+    HB_LQV_MARK(tr, 3 + (4 - k))
     if (k > 0) {
       // peel joint k off: R_k^- = P_k E_k' and the origin of the joint before
       const Mat3<double> E = axis_rot_sc<double>(ax, sncs[2 * k], sncs[2 * k + 1]);
@@ -1429,9 +1439,11 @@ __device__ __forceinline__ void lq_trip_values(const LqTrip& tr, const DevModel&
   }
   // entries 200 .. 255 of the lane (LqPark), staged eight at a time as they become known
   double tail[8], vjr[4];
+  HB_LQV_MARK(tr, 0)
   {
     double val[27];
     lq_trip_leg_pass(tr, M, leg, pt_own ? dt : 0.0, xk, uk, val);
+    HB_LQV_MARK(tr, 8)
     if (HB_ABLATE_ON && (tr.dbg == 127 || tr.dbg == 128)) return;
     // its contact points, and the head of their joint-induced velocities: entries 200..207
 #pragma unroll
@@ -1467,6 +1479,7 @@ __device__ __forceinline__ void lq_trip_values(const LqTrip& tr, const DevModel&
   const bool contact = leg ? cR : cL;   // contact point e sits on leg e & 1
   const int f = e >> 1;                 // ... and is its contact point f
   lq_wave_order();   // (stash written; the leg pass's values end here)
+  HB_LQV_MARK(tr, 9)
   const Vec3<double> F(uk[3 * e], uk[3 * e + 1], uk[3 * e + 2]);
   const double inv_m = rcp_t(M.total_mass);
   double sc[6], xe[6];
@@ -1478,7 +1491,9 @@ __device__ __forceinline__ void lq_trip_values(const LqTrip& tr, const DevModel&
     // contact point f of leg e & 1 at this point (position, joint-induced velocity; base frame)
     const Vec3<double> fb = ld3(st + 15 + 12 * leg + 3 * f), vjf = ld3(st + 15 + 12 * leg + 6 + 3 * f);
     LqPointValues pv;
+    if (pt == 1) { HB_LQV_MARK(tr, 12) }
     lq_point_values(M, st, sc, pt == 0 ? xk : xe, pv);
+    if (pt == 1) { HB_LQV_MARK(tr, 13) }
     const Vec3<double> fr = pv.R * fb;
     const Vec3<double> fvel = pv.v_lin + cross(pv.omega, fr) + pv.R * vjf;
     const Vec3<double> rr = fr - pv.com_rel;
@@ -1495,6 +1510,7 @@ __device__ __forceinline__ void lq_trip_values(const LqTrip& tr, const DevModel&
     const double flin[3] = {inv_m * fsx, inv_m * fsy, inv_m * fsz - M.gravity};
     const double fang[3] = {inv_m * msx, inv_m * msy, inv_m * msz};
     double mine[9];
+    if (pt == 1) { HB_LQV_MARK(tr, 14) }
     {
       lq_wave_order();
       double* nq = lds + LqPark::hand + quad * 36;
@@ -1516,6 +1532,7 @@ __device__ __forceinline__ void lq_trip_values(const LqTrip& tr, const DevModel&
       for (int j = 0; j < 9; ++j) mine[j] = nq[9 * e + j];
       lq_wave_order();
     }
+    if (pt == 1) { HB_LQV_MARK(tr, 15) }
     if (pt == 0) {
       double rv[3], sw[6];
 #pragma unroll
@@ -1538,6 +1555,7 @@ __device__ __forceinline__ void lq_trip_values(const LqTrip& tr, const DevModel&
 #pragma unroll
       for (int j = 0; j < 5; ++j) tail[3 + j] = rm[j];
       lq_park_out(tr, 224, tail);
+      HB_LQV_MARK(tr, 10)
     } else {
       // entries 232..255: contact point - COM (3) | values (9) | rotation entries (5) | padding
       tail[0] = rr.x; tail[1] = rr.y; tail[2] = rr.z;
@@ -1552,6 +1570,7 @@ __device__ __forceinline__ void lq_trip_values(const LqTrip& tr, const DevModel&
 #pragma unroll
       for (int j = 1; j < 8; ++j) tail[j] = 0.0;
       lq_park_out(tr, 248, tail);
+      HB_LQV_MARK(tr, 11)
     }
   }
 }

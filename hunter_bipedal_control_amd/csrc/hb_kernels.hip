@@ -246,36 +246,36 @@ __global__ __launch_bounds__(64, 3) void k_lq(Batch b, const DevModel* __restric
   lq_node(WaveCtx(), *M, *C, in, lds, b.recs + nd * REC_SIZE);
 }
 
-// The LQ approximation of a TRIP of up to 2^tshift consecutive nodes of an instance per wavefront (hb_lq.hpp lq_trip_values): the
+// The LQ approximation of a TRIP of up to tlen <= 16 consecutive nodes of an instance per wavefront (hb_lq.hpp lq_trip_values): the
 // lane-sparse value phases of all the trip's nodes at once, one (node, leg evaluation) pair per lane, their phase-1 images parked in
 // global memory; then node after node: image -> LDS, direction pass, tail.  The arithmetic of a node does not depend on the trip
 // length (a lane's work is the same whatever its neighbours do), so launches that cut the batch differently agree bit for bit.
-__global__ __launch_bounds__(64, 3) void k_lq_trip(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C, int tshift) {
+__global__ __launch_bounds__(64, 3) void k_lq_trip(Batch b, const DevModel* __restrict__ M, const DevConfig* __restrict__ C, int tlen) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (the value phase exists for the device only)
   // Workgroups are handed out in the order of their index: every instance's FULL trips first, the short last trip of each horizon
   // (N = 100, 16 nodes a trip: six full trips and one of four nodes) at the end of the grid, where it fills the gaps the full trips leave
   // on the chip — 4096 x 6 full trips are exactly eight rounds of the 3072 wavefront slots.  (longest job first)
   int trip, inst;
   {
-    const int ntrip = (b.Nmax + (1 << tshift) - 1) >> tshift, g = blockIdx.x, nfull = (ntrip - 1) * b.B;
+    const int ntrip = (b.Nmax + tlen - 1) / tlen, g = blockIdx.x, nfull = (ntrip - 1) * b.B;
     if (g < nfull) { inst = g / (ntrip - 1); trip = g - inst * (ntrip - 1); }
     else { inst = g - nfull; trip = ntrip - 1; }
     if (ntrip == 1) { inst = g; trip = 0; }
   }
   __shared__ double lds[LqLds::total + HB_LQ_LDS_PAD];
   const int n_nodes = b.n_nodes[inst];
-  const int k0 = trip << tshift;
+  const int k0 = trip * tlen;
   if (k0 >= n_nodes) return;
-  const int nt = min(1 << tshift, n_nodes - k0);
+  const int nt = min(tlen, n_nodes - k0);
   const double* tt = b.t + size_t(inst) * (b.Nmax + 1);
   double* park = b.lqpark + (size_t(inst) * (b.Nmax + LqPark::trip_max) + k0) * LqPark::size;   // the trip's parked data (LqPark)
   lq_trip_stage_constants(*M, lds, threadIdx.x);
   WaveCtx().sync();
   // (profiling build, 125: the value phase runs once per trip, later launches re-use what it parked — the dense part alone on valid data)
-  if (!(HB_ABLATE_ON && C->debug_stop == 125 && park[size_t(LqPark::n_feet / 4 << tshift) * 16] != 0.0)) {
+  if (!(HB_ABLATE_ON && C->debug_stop == 125 && park[size_t(LqPark::n_feet / 4 * tlen) * 16] != 0.0)) {
     // (every lane runs the phase: lanes beyond the trip's last node repeat it and park nothing.  Raising the wavefront's priority for
     // this one long dependent chain was tried — s_setprio 3: 515 k against 525 k updates/s — and dropped)
-    lq_trip_values(LqTrip{lds, park, tshift, nt, int(threadIdx.x), HB_ABLATE_ON ? C->debug_stop : 0}, *M, *C, b.x + size_t(inst) * (b.Nmax + 1) * HB_NX, b.u + size_t(inst) * b.Nmax * HB_NU,
+    lq_trip_values(LqTrip{lds, park, tlen, nt, int(threadIdx.x), HB_ABLATE_ON ? C->debug_stop : 0}, *M, *C, b.x + size_t(inst) * (b.Nmax + 1) * HB_NX, b.u + size_t(inst) * b.Nmax * HB_NU,
                    b.swing + size_t(inst) * b.Nmax * 24, tt, b.mode + size_t(inst) * b.Nmax, k0);
   }
   // the images are read back by other lanes of this wavefront: stores complete before the first load is issued
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64, 3) void k_lq_trip(Batch b, const DevModel* __re
     in.mode = __builtin_amdgcn_readfirstlane(b.mode[nd]);
     in.consts = true;
     in.c_tab = c_tab;
-    lq_image_to_lds(park, t, tshift, lds, l);
+    lq_image_to_lds(park, t, tlen, lds, l);
     if (l < HB_NX) { lds[LqLds::xs + l] = x_lane; lds[LqLds::us + l] = u_lane; }
     cx.sync();
     const double* park_lds = lds + LqLds::park;
@@ -2151,26 +2151,28 @@ static void launch_ric_bwd(hb_ctx* ctx, const Batch& b, int B, int concurrent, h
   else hipLaunchKernelGGL(k_ric_bwd, dim3(B), dim3(64), 0, s, b, sel);
 }
 
-// LQ approximation: trips of 2^tshift nodes per wavefront (k_lq_trip).  Longer trips fill the lanes of the value phase better (16 nodes:
+// LQ approximation: trips of tlen nodes per wavefront (k_lq_trip).  Longer trips fill the lanes of the value phase better (16 nodes:
 // all 64), shorter ones keep small batches spread over the chip and balance them finer: the longest trip
 // that still gives every wavefront slot of the chip (12 per CU) four trips of the CONCURRENT batch — 16 nodes from 2048 instances up, 8 at
 // 1024, 4 at 512 (512 x 108 on two ranges, updates/s: one-node kernel 329.7 k, 4 nodes 325.0 k, 8: 316.9 k, 16: 305.2 k).  The result does not depend on the
-// choice.  hb_config.reserved = 120 + s forces 2^s; 129 the one-node-per-wavefront kernel of rounds 1-5 (k_lq: cooperative leg
+// choice.  hb_config.reserved = 120 + s forces 2^s, 130 + L any length L <= 16 (lengths that are no power of two measured within the
+// noise of the powers of two at 512, 1024 and 4096 instances); 129 the one-node-per-wavefront kernel of rounds 1-5 (k_lq: cooperative leg
 // pass; A / B only, differs from the trips by rounding).
 constexpr int kLqTripsPerSlot = 4;
-static int lq_trip_shift(const hb_ctx* ctx, int concurrent) {
+static int lq_trip_len(const hb_ctx* ctx, int concurrent) {
   const int sel = ctx->hconfig.debug_stop;
-  if (sel >= 120 && sel <= 124) return sel - 120;
+  if (sel >= 120 && sel <= 124) return 1 << (sel - 120);
+  if (sel >= 131 && sel <= 146) return sel - 130;   // any trip length 1..16 (launch-geometry sweeps)
   const long slots = 12L * ctx->n_cu;
   for (int sh = 4; sh > 0; --sh)
-    if (long(concurrent) * ((ctx->Nmax + (1 << sh) - 1) >> sh) >= kLqTripsPerSlot * slots) return sh;
-  return 0;
+    if (long(concurrent) * ((ctx->Nmax + (1 << sh) - 1) >> sh) >= kLqTripsPerSlot * slots) return 1 << sh;
+  return 1;
 }
 static void launch_lq(hb_ctx* ctx, const Batch& b, int B, int concurrent, hipStream_t s) {
   if (ctx->hconfig.debug_stop == 129) { hipLaunchKernelGGL(k_lq, dim3(ctx->Nmax, B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig); return; }
-  const int sh = lq_trip_shift(ctx, concurrent);
-  const int ntrip = (ctx->Nmax + (1 << sh) - 1) >> sh;
-  hipLaunchKernelGGL(k_lq_trip, dim3(unsigned(ntrip) * B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, sh);
+  const int len = lq_trip_len(ctx, concurrent);
+  const int ntrip = (ctx->Nmax + len - 1) / len;
+  hipLaunchKernelGGL(k_lq_trip, dim3(unsigned(ntrip) * B), dim3(64), 0, s, b, ctx->dmodel, ctx->dconfig, len);
 }
 
 // Forward sweep: the wave form while the batch leaves a SIMD one wavefront (hb_config.reserved = 111 / 114 force the row / the wave form)

@@ -1292,7 +1292,7 @@ __device__ const LqParkTab kLqParkTab = lq_park_tab();
 struct LqTrip {   // what the value phase's helpers share
   double* lds;
   double* park;   // the trip's parked data
-  int tshift, nt, lane;
+  int tlen, nt, lane;   // lines of a node lie tlen lines apart (the trip's nominal length, 1..16), nt <= tlen nodes exist
   int dbg;        // profiling build: 127 / 128 leave the value phase behind the forward sweep / the leg pass
 };
 #if defined(HB_ABLATE) && defined(HB_LQV_TRACE)
@@ -1314,12 +1314,12 @@ __device__ __forceinline__ void lq_park_out(const LqTrip& tr, int n0, const doub
   lane &= 63;
   const int t = lane >> 2, e = lane & 3;
   if (t < tr.nt && !(HB_ABLATE_ON && tr.dbg == 119)) {   // (profiling build, 119: the value phase computes but parks nothing — stale data is read back)
-    double* line = tr.park + ((size_t(n0 >> 2) << tr.tshift) + t) * 16 + 2 * e;
+    double* line = tr.park + (size_t(n0 >> 2) * tr.tlen + t) * 16 + 2 * e;
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
       d2 x;
       x.x = v8[i]; x.y = v8[i + 1];
-      *reinterpret_cast<d2*>(line + ((size_t(i >> 2) << tr.tshift) * 16) + ((i & 3) >> 1) * 8) = x;
+      *reinterpret_cast<d2*>(line + (size_t(i >> 2) * tr.tlen * 16) + ((i & 3) >> 1) * 8) = x;
     }
   }
 }
@@ -1576,14 +1576,14 @@ __device__ __forceinline__ void lq_trip_values(const LqTrip& tr, const DevModel&
 }
 static_assert(LqPark::n_vj == 206 && LqPark::n_row == 212 && LqPark::n_fr0 == 215 && LqPark::n_ns0 == 218 && LqPark::n_rm0 == 227 && LqPark::n_fr1 == 232 &&
               LqPark::n_ns1 == 235 && LqPark::n_rm1 == 244 && LqPark::per_lane == 256, "lq_trip_values packs the entries behind the leg block by hand");
-// the parked data of node t of a trip of T = 2^tshift nodes -> its LDS places: 8 rounds of 64 sixteen-byte pairs (a pair = entries n, n + 1
+// the parked data of node t of a trip of nominal length T = tlen nodes -> its LDS places: 8 rounds of 64 sixteen-byte pairs (a pair = entries n, n + 1
 // of one leg evaluation: two consecutive LDS doubles wherever the entries go to the leg blocks)
-__device__ __forceinline__ void lq_image_to_lds(const double* trip_base, int t, int tshift, double* lds, int lane) {
+__device__ __forceinline__ void lq_image_to_lds(const double* trip_base, int t, int tlen, double* lds, int lane) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   constexpr int NPAIR = LqPark::per_lane / 4 * 8, NR = NPAIR / 64, NR_BLK = LqPark::n_tab0 / 4 * 8 / 64;   // 8 rounds, the first 6 of them all leg block
   static_assert(NPAIR % 64 == 0, "whole rounds");
-  const d2* src = reinterpret_cast<const d2*>(trip_base) + ((((lane >> 3) << tshift) + t) << 3) + (lane & 7);
-  const int rstride = 64 << tshift;   // pairs between the rounds (8 lines further)
+  const d2* src = reinterpret_cast<const d2*>(trip_base) + ((((lane >> 3) * tlen) + t) << 3) + (lane & 7);
+  const int rstride = 64 * tlen;   // pairs between the rounds (8 lines further)
   d2 v[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) v[r] = src[r * rstride];

@@ -101,7 +101,7 @@ typedef struct hb_config {
   double wbc_eps_reg;              /* Tikhonov term of the regularised-minimiser rule */
   int32_t wbc_max_iter;            /* working-set-change limit; reference nWSR = 20 (WeightedWbc.cpp:50) */
   int32_t reserved;                /* 0.  Tests and tuning only: 101 / 104 force the one- / four-wavefront backward sweep, 111 / 114 the row /
-                                      wave form of the forward sweep, 120 + s trips of 2^s nodes per wavefront in the LQ kernel (the library
+                                      wave form of the forward sweep, 120 + s trips of 2^s nodes per wavefront in the LQ kernel, 130 + L trips of L <= 16 nodes, 129 the one-node kernel (the library
                                       picks all three by the number of instances in flight; the forms are bit-identical); other values are phase-by-phase exits of the profiling build (-DHB_ABLATE) */
   double default_joint_state[HB_NJ]; /* reference.info:7-19 */
   double delta_tol;                /* sqp.deltaTol, task.info:84: the line search gives up (no step, as at alpha_min) once

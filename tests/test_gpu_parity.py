@@ -1051,8 +1051,9 @@ def test_sqp_step_identical_with_either_form_of_the_sweeps(params, gait):
 
 @pytest.mark.parametrize("gait", ["trot", "ragged"])
 def test_lq_trip_lengths_agree_bit_for_bit_and_with_the_one_node_kernel(params, gait):
-    """k_lq_trip: a wavefront takes a trip of 2^s consecutive nodes of an instance (hb_config.reserved = 120 + s; the product picks s by
-    the number of instances in flight).  A node's arithmetic does not depend on the trip length — every s gives the same bits, ragged
+    """k_lq_trip: a wavefront takes a trip of L <= 16 consecutive nodes of an instance (hb_config.reserved = 120 + s: L = 2^s, 130 + L:
+    any length; the product picks a power of two by the number of instances in flight).  A node's arithmetic does not depend on the trip
+    length — every L gives the same bits, ragged
     horizons and trips cut short by the horizon's end included —, and the one-node-per-wavefront kernel of rounds 1-5 (129: cooperative
     leg pass with cross-lane scans) differs from the trips by rounding only (serial leg pass, peeled frames): 1e-9 relative on the
     iterate after three SQP iterations, identical accepted step sizes and status words."""
@@ -1072,7 +1073,7 @@ def test_lq_trip_lengths_agree_bit_for_bit_and_with_the_one_node_kernel(params, 
         t_now = refs["t"][:, 0] + 0.004
     B = x0.shape[0]
     res = {}
-    for variant in (120, 121, 122, 123, 124, 129):
+    for variant in (120, 121, 122, 123, 124, 133, 137, 143, 129):
         s = HunterSolver(params, batch=B, max_nodes=44, reserved=variant)
         try:
             s.set_references(refs)
@@ -1086,7 +1087,7 @@ def test_lq_trip_lengths_agree_bit_for_bit_and_with_the_one_node_kernel(params, 
             res[variant] = (xs_, us_, dx_, du_, s.get_performance(), sol_, st_, s.mpc_status())
         finally:
             s.close()
-    for variant in (121, 122, 123, 124):
+    for variant in (121, 122, 123, 124, 133, 137, 143):
         for k, (p, q) in enumerate(zip(res[120], res[variant])):
             assert np.array_equal(p, q), (gait, variant, k)
     assert res[124][7].max() == 0 and np.isfinite(res[124][0]).all()

@@ -411,9 +411,14 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
     asm volatile("" : "+v"(l));
     cxk.lane = l;
     HB_RIC_FETCH_Q(k, l);
-    if (k > 0) {  // (requested a whole stage earlier — right after the staging stores, 254 VGPRs, no scratch — the sweep
-      HB_RIC_FETCH(k - 1, l);  //  takes the same 2.06 ms: it does not wait for HBM, it is bound by its own dependent work)
-      const double* meta = b.recs + (size_t(inst) * b.Nmax + k - 1) * REC_SIZE + REC_META;
+    {  // (requested a whole stage earlier — right after the staging stores, 254 VGPRs, no scratch — the sweep takes the same 2.06 ms:
+       //  it does not wait for HBM, it is bound by its own dependent work.)
+       // UNCONDITIONAL: the last stage requests its own record once more.  Under `if (k > 0)` the 40 prefetch registers were live
+       // through the whole stage for the compiler (the old values "survive" the iteration that does not refill them), right across
+       // the register-resident factorisation.
+      const int kn = k > 0 ? k - 1 : 0;
+      HB_RIC_FETCH(kn, l);
+      const double* meta = b.recs + (size_t(inst) * b.Nmax + kn) * REC_SIZE + REC_META;
       meta_nf = meta[0];
       meta_nz = meta[1];
     }
@@ -519,9 +524,10 @@ __global__ __launch_bounds__(256, 2) void k_ric_bwd4(Batch b, int dbg) {
     const int n_til = int(meta_nf) + int(meta_nz);
     // The next record is requested NOW — four 16-byte loads per thread, 8 registers: the whole stage covers their latency (the
     // one-wavefront form holds 14 loads per lane and can only afford them behind its register-resident factorisation)
-    if (k > 0) {
-      HB_RIC4_FETCH(k - 1, t);
-      const double* meta = b.recs + (size_t(inst) * b.Nmax + k - 1) * REC_SIZE + REC_META;
+    {  // (unconditional — the last stage requests its own record again: see k_ric_bwd)
+      const int kn = k > 0 ? k - 1 : 0;
+      HB_RIC4_FETCH(kn, t);
+      const double* meta = b.recs + (size_t(inst) * b.Nmax + kn) * REC_SIZE + REC_META;
       meta_nf = meta[0];
       meta_nz = meta[1];
     }

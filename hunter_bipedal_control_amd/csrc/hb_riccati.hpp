@@ -188,38 +188,34 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* Hu, double* Kk, double* flag,
   asm volatile("" ::: "memory");
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr bool reg_factor = NT <= 9;
+  constexpr bool reg_factor = true;   // (the factor never leaves the registers, either width)
 #else
   constexpr bool reg_factor = false;
 #endif
   constexpr int NB1 = NT <= 9 ? NT : 9;
   double Lr[NB1 * (NB1 + 1) / 2];
+#if defined(__HIP_DEVICE_COMPILE__)
+  double u21[3][9], S3[6];   // rows 9..11 of the 12 x 12 factor (NT == 12 only)
+#endif
   if constexpr (NT <= 9) {
     const bool bad = ric_chol_block<NT, reg_factor>(cx, Hu, Lr);
     if (bad && cx.lane == 0) *flag = 1.0;
   } else {
     // 12 projected inputs (double support: 12 contact forces): blocked — the 9 x 9 leading block in registers as above, then
-    // rows 9..11 against it and the 3 x 3 Schur complement (ric_factor_tail).  A 78-element register triangle (156 VGPRs) next to
-    // the record prefetch was what put 100 B/lane of this kernel into scratch memory.
+    // rows 9..11 against it and the 3 x 3 Schur complement (ric_factor_tail).
     static_assert(NT == 12, "blocked factorisation: 9 + 3");
 #if defined(__HIP_DEVICE_COMPILE__)
-    // Device: every lane continues redundantly in registers (the 9 x 9 block is still there) — no LDS round trip inside, one
-    // barrier at the end.  (ric_chol_block<9, KEEP> leaves Huu untouched: rows 9..11 are read from it.)
+    // Device: every lane continues redundantly in registers (the 9 x 9 block is still there).  (ric_chol_block<9, KEEP> leaves Huu
+    // untouched: rows 9..11 are read from it.)
     bool bad = ric_chol_block<9, true>(cx, Hu, Lr);
-    {
-      double t21[3][9], S[6];
-      bad = ric_factor_tail(Lr, [Hu](int r, int j) { return Hu[(9 + r) * RicLds::LDW + RicLds::CU + j]; }, t21, S) || bad;
-      cx.sync();   // every lane has read rows 9..11 of Huu before lane 0 overwrites them with the factor
-      if (cx.lane == 0) {
+    // rows 9..11 of the factor stay in registers as well (u = t r1 in place of t; 78 doubles with the leading block): the solves are
+    // pure FMA chains for every row, no LDS round trip of the factor, no barrier.  (Rounds 3-5 parked these rows in LDS: with the record
+    // prefetch held live across the stage by its `if (k > 0)` the register file had no room for them.)
+    bad = ric_factor_tail(Lr, [Hu](int r, int j) { return Hu[(9 + r) * RicLds::LDW + RicLds::CU + j]; }, u21, S3) || bad;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int j = 0; j < 9; ++j) Hu[(9 + r) * RicLds::LDW + RicLds::CU + j] = t21[r][j] * Lr[j * (j + 1) / 2 + j];
-#pragma unroll
-          for (int c = 0; c <= r; ++c) Hu[(9 + r) * RicLds::LDW + RicLds::CU + 9 + c] = S[r * (r + 1) / 2 + c];
-        }
-      }
-    }
+      for (int j = 0; j < 9; ++j) u21[r][j] *= Lr[j * (j + 1) / 2 + j];
 #else
     // Host emulator (the lanes run one after the other): the same arithmetic from copies of the rows, then the whole factor to LDS
     bool bad = ric_chol_block<9, true>(cx, Hu, Lr);
@@ -247,15 +243,23 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* Hu, double* Kk, double* flag,
     const double* Lm = Hu + RicLds::CU;  // U(i, j) = Lm[i * LDW + j], j < i; the diagonal holds the reciprocals r
 #if defined(__HIP_DEVICE_COMPILE__)
     // 12-wide (double support): the leading 9 x 9 block of the factor is still in this lane's registers (ric_chol_block left it
-    // there); only rows 9..11 come from LDS
+    // there), rows 9..11 in u21 / S3
     constexpr int NREG = NT <= 9 ? NT : 9;
 #else
     constexpr int NREG = 0;
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto Lf = [&Lr, Lm, &u21, &S3](int i, int j) {
+      if (i < NREG) return Lr[i * (i + 1) / 2 + j];
+      if constexpr (NT > 9) return j < 9 ? u21[i - 9][j] : S3[(i - 9) * (i - 8) / 2 + (j - 9)];
+      return Lm[i * RicLds::LDW + j];
+    };
+#else
     auto Lf = [&Lr, Lm](int i, int j) {
       if (i < NREG) return Lr[i * (i + 1) / 2 + j];
       return Lm[i * RicLds::LDW + j];
     };
+#endif
     for (int c = cx.lane; c < 23; c += cx.nlanes) {  // columns 0..21 = Hux, 22 = hu
       double y[NU_T];
 #pragma unroll
@@ -264,10 +268,6 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* Hu, double* Kk, double* flag,
 #pragma unroll
         for (int k = 0; k < a; ++k) sacc = fma(-Lf(a, k), y[k], sacc);
         y[a] = sacc;
-#if defined(__HIP_DEVICE_COMPILE__)
-        // 12-wide: keep the factor loads of rows 9..11 row by row — hoisted all at once they took the register file
-        if (NT > 9 && a >= 8) asm volatile("" ::: "memory");
-#endif
       }
 #pragma unroll
       for (int a = NT - 1; a >= 0; --a) {   // y = U'^-1 (r z)
@@ -275,10 +275,6 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* Hu, double* Kk, double* flag,
 #pragma unroll
         for (int k = a + 1; k < NT; ++k) sacc = fma(-Lf(k, a), y[k], sacc);
         y[a] = sacc;
-#if defined(__HIP_DEVICE_COMPILE__)
-        // (below row 9 only the three entries U(9..11, a) of every column come from LDS: their loads may run three columns ahead)
-        if (NT > 9 && (a >= 9 || a % 3 == 0)) asm volatile("" ::: "memory");
-#endif
       }
 #pragma unroll
       for (int a = NT; a < NU_T; ++a) y[a] = 0.0;

@@ -406,7 +406,8 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
     // n_til: number of projected inputs of this stage (uniform; requested one stage ahead with the prefetch)
     const int n_til = int(meta_nf) + int(meta_nz);
     HB_RIC1_MARK(1)
-    ric_phase12(cxk, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE, n_til, dbg);
+    WaveTile<2, 2> m1;   // M1 = S [A~ b~ B~] stays in the accumulators of GEMM 1 for GEMM 2 and GEMM 3 (hb_riccati.hpp ric_phase1)
+    ric_phase12(cxk, lds, b.gains + (size_t(inst) * b.Nmax + k) * GAIN_SIZE, n_til, m1, dbg);
     HB_RIC1_MARK(2)
     asm volatile("" : "+v"(l));
     cxk.lane = l;
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(64, 2) void k_ric_bwd(Batch b, int dbg) {
     if (HB_ABLATE_ON && (dbg == 21 || dbg == 22 || dbg == 23)) continue;
     RicT3 t;
     HB_RIC1_MARK(3)
-    ric_phase3_mma(cxk, lds, t);
+    ric_phase3_mma(cxk, lds, t, m1);
     HB_RIC1_MARK(4)
     {
       d2* Qs2 = reinterpret_cast<d2*>(lds + RicLds::Qs) + l;

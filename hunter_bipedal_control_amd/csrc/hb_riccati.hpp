@@ -24,7 +24,6 @@ struct RicLds {
   static constexpr int X = 0;                    // 24 x 36
   static constexpr int S = X;                    // 22 x 24
   static constexpr int s = S + 22 * LDN;         // 24
-  static constexpr int M1 = X;                   // 24 x 36 : S [A~ b~ B~ .] (+ s on the vector column); rows 22, 23 stay zero
   static constexpr int ABb = X + 24 * LDW;       // 24 x 36
   static constexpr int PRr = ABb + 24 * LDW;     // 12 x 36
   static constexpr int Hu = PRr;                 // 12 x 36 : [Hux | hu | . | Huu]
@@ -61,23 +60,22 @@ static_assert(Ric4Lds::total * 8 <= 40960, "k_ric_bwd4: four instances per CU");
 //   S <- sym(Q~ + A~' M1_A + Hux' K~),  s <- q~ + A~' M1_b + Hux' k~          
 // NTW = number of 16-column tiles of the wide operands that are formed: 3 in general, 2 when the stage has at most 9
 // projected inputs (columns 0..31 = x block, vector, inputs 0..8): GEMM 1 24 instead of 36 MFMAs, GEMM 2 12 instead of 18.
+// M1 STAYS IN THE ACCUMULATORS of GEMM 1 (round 6): the accumulator layout of a tile is the right-operand fragment layout of the products
+// that contract over its rows (hb_tile.hpp tile_mma_bacc), so GEMM 2 (B~' M1) and the A~' M1 part of GEMM 3 take M1 straight from the
+// registers — no store of M1 to LDS, no ordering point behind it, no operand loads of M1 (46 LDS instructions and two LDS round trips of a
+// stage), same terms in the same order.  S | s stay untouched until the new S is stored.
 template <int NTW, class Ctx>
-HB_HD void ric_phase1(const Ctx& cx, double* lds) {
+HB_HD void ric_phase1(const Ctx& cx, double* lds, WaveTile<2, NTW>& t) {
   const double* sv = lds + RicLds::s;
-  double* M1 = lds + RicLds::M1;
   constexpr int NC = NTW * 16 < RicLds::LDW ? NTW * 16 : RicLds::LDW;
-  WaveTile<2, NTW> t;
   // (start values and, in GEMM 2 / 3, all operands of a product requested together: since the build dropped machine LICM the sweep has
-  // the registers for it — 254 instead of 226, no scratch; 1.70 -> 1.66 ms per 4096 x 100, 2.57 -> 2.50 standing; bit-identical)
+  // the registers for it; 1.70 -> 1.66 ms per 4096 x 100, 2.57 -> 2.50 standing; bit-identical)
   tile_init_col(cx, t, 22, RicLds::CV, sv);
   // S is EXACTLY symmetric (the previous stage stored the upper triangle of T mirrored; S = 0 at the end of the horizon), so the left operand
   // is read transposed, S(i, k) as S(k, i): 16 lanes then read 16 consecutive doubles instead of 16 doubles 24 apart (a four-way
-  // bank conflict on every operand read).  The K-padding rows 22 / 23 of this view are s and stale finite words; the zero rows 22 / 23
-  // of [A~ b~ B~] cancel them.
+  // bank conflict on every operand read).  The K-padding rows 22 / 23 of this view are s and a zero row; the zero rows 22 / 23
+  // of [A~ b~ B~] cancel them.  Rows 22 / 23 of M1 itself come out exactly zero (columns 22 / 23 of S are the zero K-padding).
   tile_mma<24, RicLds::LDN, true, RicLds::LDW, false, 24, false>(cx, t, lds + RicLds::S, lds + RicLds::ABb, 22, NC);
-  // M1 overwrites S | s: every operand read above precedes these stores in the wave's program order
-  tile_store(cx, t, 22, NC, [M1](int i, int c, double v) { M1[i * RicLds::LDW + c] = v; });
-  cx.sync();
 }
 // Factorisation of the leading NT x NT block of Huu and the 23 solves.  Every lane factors the (uniform) block redundantly in
 // registers, lane c < 23 then solves its own right-hand side.  NT = 9 serves every stage with at most 9 projected inputs (single
@@ -291,31 +289,42 @@ HB_HD void ric_factor_solve(const Ctx& cx, double* Hu, double* Kk, double* flag,
 }
 // `n_til` = number of projected inputs of the stage (contact-force + kernel coordinates, REC_META)
 template <int NTW, class Ctx>
-HB_HD void ric_phase2_gemm(const Ctx& cx, double* lds) {
+HB_HD void ric_phase2_gemm(const Ctx& cx, double* lds, const WaveTile<2, NTW>& m1) {
   const double* PRr = lds + RicLds::PRr;
   double* Hu = lds + RicLds::Hu;
   constexpr int NC = NTW * 16 < RicLds::LDW ? NTW * 16 : RicLds::LDW;
   WaveTile<1, NTW> t;
   tile_init_rm<RicLds::LDW>(cx, t, NU_T, NC, PRr);
-  tile_mma<24, RicLds::LDW, true, RicLds::LDW, false, 24, true>(cx, t, lds + RicLds::ABb + RicLds::CU, lds + RicLds::M1, NU_T, NC);
+  tile_mma_bacc<24, RicLds::LDW, true>(cx, t, lds + RicLds::ABb + RicLds::CU, m1, 0, NU_T, NC);
   tile_store(cx, t, NU_T, NC, [Hu](int a, int c, double v) { Hu[a * RicLds::LDW + c] = v; });  // over [P~ r~ R~]
   cx.sync();
 }
 // GEMM 1, GEMM 2 and the factorisation / solves of one stage
+// `m1` receives the x block and the vector column of M1 (columns 0..31: what GEMM 3 contracts with)
 template <class Ctx>
-HB_HD void ric_phase12(const Ctx& cx, double* lds, double* gains, int n_til, int dbg = 0) {
+HB_HD void ric_phase12(const Ctx& cx, double* lds, double* gains, int n_til, WaveTile<2, 2>& m1, int dbg = 0) {
   static_assert(RicLds::CU + 9 <= 32, "x block, vector and 9 inputs must fit two tiles");
   if (n_til <= 9) {
-    ric_phase1<2>(cx, lds);
+    ric_phase1<2>(cx, lds, m1);
     HB_ABLATE_STOP(dbg == 21);
-    ric_phase2_gemm<2>(cx, lds);
+    ric_phase2_gemm<2>(cx, lds, m1);
     HB_ABLATE_STOP(dbg == 22);
     ric_factor_solve<9>(cx, lds + RicLds::Hu, lds + RicLds::Kk, lds + RicLds::flag, gains);
   } else {
-    ric_phase1<3>(cx, lds);
+    WaveTile<2, 3> m1w;
+    ric_phase1<3>(cx, lds, m1w);
     HB_ABLATE_STOP(dbg == 21);
-    ric_phase2_gemm<3>(cx, lds);
+    ric_phase2_gemm<3>(cx, lds, m1w);
     HB_ABLATE_STOP(dbg == 22);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) m1.acc[tm][tn] = m1w.acc[tm][tn];
+#else
+    for (int i = 0; i < 32; ++i)
+      for (int j = 0; j < 32; ++j) m1.c[i][j] = m1w.c[i][j];
+#endif
     ric_factor_solve<NU_T>(cx, lds + RicLds::Hu, lds + RicLds::Kk, lds + RicLds::flag, gains);
   }
 }
@@ -329,11 +338,11 @@ struct RicT3 {
   WaveTile<1, 1> t1;  // rows 16..31, columns 16..31
 };
 template <class Ctx>
-HB_HD void ric_phase3_mma(const Ctx& cx, double* lds, RicT3& t) {
+HB_HD void ric_phase3_mma(const Ctx& cx, double* lds, RicT3& t, const WaveTile<2, 2>& m1) {
   tile_init(cx, t.t0, 16, 23, [](int, int) { return 0.0; });
   tile_init(cx, t.t1, 6, 7, [](int, int) { return 0.0; });
-  tile_mma<24, RicLds::LDW, true, RicLds::LDW, false, 24, true>(cx, t.t0, lds + RicLds::ABb, lds + RicLds::M1, 16, 23);
-  tile_mma<24, RicLds::LDW, true, RicLds::LDW, false, 24, true>(cx, t.t1, lds + RicLds::ABb + 16, lds + RicLds::M1 + 16, 6, 7);
+  tile_mma_bacc<24, RicLds::LDW, true>(cx, t.t0, lds + RicLds::ABb, m1, 0, 16, 23);
+  tile_mma_bacc<24, RicLds::LDW, true>(cx, t.t1, lds + RicLds::ABb + 16, m1, 1, 6, 7);
   tile_mma<NU_T, RicLds::LDW, true, RicLds::LDN, false, NU_T, true>(cx, t.t0, lds + RicLds::Hu, lds + RicLds::Kk, 16, 23);
   tile_mma<NU_T, RicLds::LDW, true, RicLds::LDN, false, NU_T, true>(cx, t.t1, lds + RicLds::Hu + 16, lds + RicLds::Kk + 16, 6, 7);
   cx.sync();
@@ -397,12 +406,11 @@ HB_HD void ric_phase3_finish(const Ctx& cx, double* lds, const RicT3& t) {
   double* sv = lds + RicLds::s;
   const double* Qs = lds + RicLds::Qs;
   cx.sync();
-  // The new S | s overwrite M1 (narrow rows): every operand read of the GEMMs precedes these stores in the wave's program
+  // The new S | s overwrite the old ones: every operand read of the GEMMs precedes these stores in the wave's program
   // order.  Element (i, c), i <= c < 22, goes to S(i, c) and S(c, i); column 22 is the vector s.
   ric_store_T<RicLds::LDN>(cx, t.t0, 16, 23, 0, 0, S, sv, Qs, lds + RicLds::flag + 2);
   ric_store_T<RicLds::LDN>(cx, t.t1, 6, 7, 16, 16, S, sv, Qs, lds + RicLds::flag + 2);
-  // restore the zero K-padding of S (columns 22, 23 were covered by M1)
-  for (int idx = cx.lane; idx < 44; idx += cx.nlanes) S[(idx >> 1) * RicLds::LDN + RicLds::CV + (idx & 1)] = 0.0;
+  // (columns 22, 23 of S — the zero K-padding — are never written: M1 no longer lives in LDS)
   cx.sync();
 }
 // Reference staging of one record (host emulation; the kernel batches its global loads instead).
@@ -413,10 +421,11 @@ HB_HD void ric_stage(const Ctx& cx, double* lds, const double* rec) {
 }
 template <class Ctx>
 HB_HD void riccati_bwd_node(const Ctx& cx, double* lds, const double* rec, double* gains, int dbg = 0) {
-  ric_phase12(cx, lds, gains, int(rec[REC_META]) + int(rec[REC_META + 1]), dbg);
+  WaveTile<2, 2> m1;
+  ric_phase12(cx, lds, gains, int(rec[REC_META]) + int(rec[REC_META + 1]), m1, dbg);
   HB_ABLATE_STOP(dbg == 21 || dbg == 22 || dbg == 23);  // profiling ablation markers (hb_config.reserved)
   RicT3 t;
-  ric_phase3_mma(cx, lds, t);
+  ric_phase3_mma(cx, lds, t, m1);
   double* Qs = lds + RicLds::Qs;
   for (int e = cx.lane; e < REC_QT_PACKED + 22; e += cx.nlanes) Qs[e] = rec[REC_QT + e];
   ric_phase3_finish(cx, lds, t);

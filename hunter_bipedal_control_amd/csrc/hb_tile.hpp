@@ -173,6 +173,42 @@ HB_HD void tile_mma(const Ctx& cx, WaveTile<MT, NT>& t, const double* A, const d
     }
 #endif
 }
+// t += A Bt over K with the right operand taken from the ACCUMULATORS of an earlier product: B(k, j) = Bt(k, 16 tnb0 + j).  The accumulator
+// layout (rows lk + 4 r of a 16-row tile, column li) IS the B-fragment layout of K-step 4 tm + r (k = 4 s + lk), so the fragments are the
+// registers themselves: no LDS store of the earlier product, no operand loads, same terms in the same order as the product out of LDS
+// (bit-identical).  A as in tile_mma; K a multiple of 4 with zero K-padding on the A side (rows of Bt beyond the real depth only have to be
+// finite).  All A fragments are requested before the first matrix instruction.
+template <int K, int LDA, bool TA, int MT, int NT, int MTB, int NTB, class Ctx>
+HB_HD void tile_mma_bacc(const Ctx& cx, WaveTile<MT, NT>& t, const double* A, const WaveTile<MTB, NTB>& Bt, int tnb0, int Mr, int Nr) {
+  static_assert(K % 4 == 0 && K <= 16 * MTB, "the contraction runs over the rows of Bt");
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)Mr; (void)Nr;
+  const int li = cx.lane & 15, lk = cx.lane >> 4;
+  const double* ap = A + (TA ? lk * LDA + li : li * LDA + lk);
+  constexpr int KS = K / 4;
+  double av[KS][MT];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm) av[s][tm] = ap[TA ? 4 * s * LDA + 16 * tm : 16 * tm * LDA + 4 * s];
+  asm volatile("" ::: "memory");   // (the reads stay in front of the matrix instructions)
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+        t.acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s][tm], Bt.acc[s / 4][tnb0 + tn][s % 4], t.acc[tm][tn], 0, 0, 0);
+#else
+  (void)cx;
+  for (int i = 0; i < Mr; ++i)
+    for (int j = 0; j < Nr; ++j) {
+      double acc = t.c[i][j];
+      for (int k = 0; k < K; ++k) acc += (TA ? A[k * LDA + i] : A[i * LDA + k]) * Bt.c[k][16 * tnb0 + j];
+      t.c[i][j] = acc;
+    }
+#endif
+}
 // t += o, element by element
 template <int MT, int NT>
 HB_HD void tile_add(WaveTile<MT, NT>& t, const WaveTile<MT, NT>& o) {

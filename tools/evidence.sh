@@ -9,6 +9,7 @@
 #   <tag>_full_tick_breakdown.json, <tag>_occupancy_sweep.json, <tag>_wbc_eps_sensitivity.json
 #   <tag>_pmc.{txt,json} + pmc_latest.json  counter passes (separate runs, no trace domains next to --pmc)
 #   <tag>_lq_phase_pmc.txt                  k_lq phase by phase (ablation build)
+#   <tag>_timeline_b512.txt                 8 ms of the kernel trace of configs[3]'s share (512 instances, two ranges), per queue
 set +e
 tag=${1:-r04}
 R=$PWD; out=$R/gpurun_out/$tag/final; mkdir -p $out
@@ -26,6 +27,11 @@ prof main python $R/bench.py --steps 20 --warmup 3 --chunks 1 --no-extras --no-c
 prof chunked python $R/bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline
 prof b512 python $R/bench.py --batch 512 --steps 40 --warmup 3 --chunks 1 --no-extras --no-cpu-baseline
 prof full_tick python $R/tools/bench_tick.py --steps 10
+# timeline of configs[3]'s per-GPU share (512 instances, per-instance commands, two free-running ranges): which kernels are co-resident
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $out/prof_tl512 -o run -- python $R/bench.py --batch 512 --random-cmd --steps 60 --warmup 5 --no-extras --no-cpu-baseline > $out/prof_tl512.log 2>&1)
+db=$(find $out/prof_tl512 -name "*results.db" | head -1)
+[ -n "$db" ] && python tools/rocprof_timeline.py $db "" 8.0 > $out/${tag}_timeline_b512.txt 2>> $out/prof_tl512.log
+rm -rf $out/prof_tl512
 prof config4_share python $R/bench.py --hierarchical --batch 1024 --nodes 200 --steps 20 --warmup 3 --chunks 1 --no-extras --no-cpu-baseline
 prof rollout python $R/tools/bench_rollout.py
 (timeout 600 python tools/bench_tick.py > $out/${tag}_full_tick_breakdown.json) 2> $out/tick.err

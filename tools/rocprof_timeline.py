@@ -8,7 +8,7 @@ import sqlite3
 import sys
 
 db = sys.argv[1]
-t_first = float(sys.argv[2]) if len(sys.argv) > 2 else None
+t_first = float(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "" else None
 t_len = float(sys.argv[3]) if len(sys.argv) > 3 else 25.0
 c = sqlite3.connect(db)
 tables = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]

@@ -8,6 +8,14 @@ foot positions / velocities pinocchio would deliver for the q, v the filter buil
 are computed by the CPU oracle and fed in.  Stored: the sensor streams (inputs) and, under out_*, the reference's rbdState,
 xHat and P after every tick, for several independent streams incl. yaw crossing +pi, swing / stance mixes, and a long
 all-contact stream that triggers the covariance reset rule (LinearKalmanFilter.cpp:150-155).
+
+What the `estContactForce` part of the file pins and what it does NOT: the reference's own arithmetic in
+StateEstimateBase.cpp:130-206 — beta / gamma, the momentum recursion, the S' tau selection, the per-leg rows and `bdcSvd().solve` (a
+one-sided Jacobi SVD stand-in) — runs as compiled.  The pinocchio quantities it consumes (M, g, C'v, the 6-D frame Jacobians) are FED
+FROM THE ORACLE through the shim, so they are not reference-pinned by this file: M and nle rest on the CRBA / RNEA invariants of
+tests/test_oracle_*.py, dT/dq on the dual-number oracle against the device's composite-momentum pass (1e-9).  The reference calls
+getCoriolisMatrix without computeCoriolisMatrix / the RNEA derivatives, so its real data.C is not the quantity reproduced here either;
+C'v is taken as d(1/2 v'Mv)/dq, which every valid Coriolis factorisation gives.
 """
 import ctypes as C
 import sys

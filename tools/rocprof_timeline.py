@@ -20,8 +20,8 @@ names = {r[0]: r[1].replace("(anonymous namespace)::", "").split("(")[0] for r i
 rows = list(c.execute(f"select kernel_id, start, end, {qcol or '0'} from {kd} order by start"))
 t0 = rows[0][1]
 end_all = max(r[2] for r in rows)
-if t_first is None:
-    t_first = (end_all - t0) / 1e6 - t_len - 12.0   # the steady part just before the end of the run
+if t_first is None:   # the steady part: the window starts with the kernel at 60 % of the run's kernel count
+    t_first = (rows[int(0.6 * len(rows))][1] - t0) / 1e6
 lo, hi = t0 + t_first * 1e6, t0 + (t_first + t_len) * 1e6
 win = [r for r in rows if r[1] >= lo and r[1] < hi]
 print(f"# {db}: {len(rows)} kernels over {(end_all - t0) / 1e6:.1f} ms; window {t_first:.1f} .. {t_first + t_len:.1f} ms, {len(win)} kernels; queue column: {qcol}")

@@ -1,8 +1,8 @@
 #!/bin/bash
 export TMPDIR=/tmp
-f() { python -c "
-import sys,json
-for l in sys.stdin:
-    try: d=json.loads(l); print('$1', d['updates_per_s'], 'ms', d['ms_per_step'], d['sane'])
-    except Exception: print(l.strip()[:300])"; }
-for b in 512 1024; do for c in 1 2 3 4 6 8; do python tools/perf_quick.py --steps 60 --batch $b --chunks $c 2>&1 | tail -1 | f "B$b-chunks$c"; done; done
+R=$PWD; out=$R/gpurun_out/r06tl; mkdir -p $out
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $out/prof_tl -o run -- python $R/bench.py --steps 40 --warmup 5 --no-extras --no-cpu-baseline > $out/prof_tl.log 2>&1)
+db=$(find $out/prof_tl -name "*results.db" | head -1)
+python tools/rocprof_timeline.py $db "" 16.0 > $out/r06_timeline_headline.txt
+rm -rf $out/prof_tl
+grep -E "k_lq_trip|k_ric_bwd|k_ric_fwd|k_wbc|k_ls_eval" $out/r06_timeline_headline.txt | head -70

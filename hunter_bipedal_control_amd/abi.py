@@ -53,7 +53,7 @@ class HbConfig(C.Structure):
         ("wbc_max_iter", C.c_int32), ("reserved", C.c_int32),
         ("default_joint_state", C.c_double * NJ),
         ("delta_tol", C.c_double),
-        ("wbc_reg_steps", C.c_int32), ("reserved2", C.c_int32),
+        ("wbc_reg_steps", C.c_int32), ("wbc_eps_mode", C.c_int32),
     ]
 
 

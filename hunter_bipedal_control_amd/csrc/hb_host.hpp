@@ -89,6 +89,7 @@ inline DevConfig make_dev_config(const hb_config& c, const DevModel& M) {
   d.w_swing = c.weight_swing_leg; d.w_base = c.weight_base_accel; d.w_force = c.weight_contact_force;
   d.wbc_eps = c.wbc_eps_reg; d.wbc_max_iter = c.wbc_max_iter; d.wbc_type = c.wbc_type;
   d.wbc_reg_steps = c.wbc_reg_steps;
+  d.wbc_eps_mode = c.wbc_eps_mode;
   for (int i = 0; i < HB_NJ; ++i) d.default_joint_state[i] = c.default_joint_state[i];
   d.debug_stop = c.reserved;  // hb_config.reserved doubles as the profiling ablation switch
   return d;

@@ -1281,9 +1281,9 @@ int32_t hb_create(const hb_model* model, const hb_config* config, int32_t batch,
   }
   // (the struct has grown over the rounds and carries no size field: a caller built against an older, smaller hb_config makes the library
   // read past its end — fields that gate loops are therefore range-checked, and the tail word must be the documented 0)
-  if (config->wbc_reg_steps < 0 || config->wbc_reg_steps > HB_WBC_REG_STEPS_MAX || config->reserved2 != 0 || config->wbc_max_iter <= 0 ||
+  if (config->wbc_reg_steps < 0 || config->wbc_reg_steps > HB_WBC_REG_STEPS_MAX || config->wbc_eps_mode < 0 || config->wbc_eps_mode > 1 || (config->wbc_eps_mode == 1 && config->wbc_type != 0) || config->wbc_max_iter <= 0 ||
       !(config->wbc_eps_reg > 0.0)) {
-    g_create_error = "hb_create: hb_config.wbc_reg_steps outside [0, 8], reserved2 != 0, wbc_max_iter <= 0 or wbc_eps_reg <= 0 (struct built against another header?)";
+    g_create_error = "hb_create: hb_config.wbc_reg_steps outside [0, 8], wbc_eps_mode not 0 / 1 (1: WeightedWbc only), wbc_max_iter <= 0 or wbc_eps_reg <= 0 (struct built against another header?)";
     return HB_ERR_ARG;
   }
   int ndev = 0;

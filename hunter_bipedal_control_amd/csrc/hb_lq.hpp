@@ -36,6 +36,7 @@ struct DevConfig {
   double default_joint_state[HB_NJ];
   int debug_stop;  // >0: lq_node returns after that phase (profiling ablation only)
   int wbc_reg_steps;
+  int wbc_eps_mode;   // 0 fixed wbc_eps, 1 |H|_F * 1e3 EPS per problem (WeightedWbc)
 };
 
 // ---- node record layout in HBM (doubles) ------------------------------------------------------------

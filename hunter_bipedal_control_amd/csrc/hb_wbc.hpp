@@ -571,13 +571,33 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
   HB_WBC_MARK(1)
 
   HB_ABLATE_STOP(C.debug_stop == 11 || (C.debug_stop >= 13 && C.debug_stop <= 15));
+  // The Tikhonov term of this problem (hb_config.wbc_eps_mode): the configured constant, or what qpOASES 3.2's regulariseHessian adds to
+  // the diagonal, |H|_F * epsRegularisation with epsRegularisation = 1e3 * EPS (Options::setToMPC; WeightedWbc.cpp:44-55 passes
+  // H = A_w' A_w [qpOASES-knowledge]).  A_w = [Aw (n_aw x 16) | w_force I (12, walking) | 0], so |H|_F^2 = |Aw' Aw|_F^2 + 12 w_force^4.
+  double eps = C.wbc_eps;
+  if (C.wbc_eps_mode == 1) {
+    double part = 0.0;
+    for (int e = cx.lane; e < 256; e += cx.nlanes) {
+      const int i = e >> 4, j = e & 15;
+      double g = 0.0;
+      for (int rw = 0; rw < n_aw; ++rw) g += Aw[rw * 16 + i] * Aw[rw * 16 + j];
+      part += g * g;
+    }
+    red[cx.lane] = part;
+    cx.sync();
+    double h2 = stance_mode ? 0.0 : 12.0 * (C.w_force * C.w_force) * (C.w_force * C.w_force);
+    for (int l = 0; l < cx.nlanes; ++l) h2 += red[l];   // (every lane, same order: a uniform value)
+    cx.sync();
+    const double e1 = sqrt(h2) * (1.0e3 * 2.220446049250313e-16);
+    eps = e1 > 0.0 ? e1 : C.wbc_eps;
+  }
   // ------------------------------------------------------------------ phase B: R~ by Givens row insertion
-  const double se = sqrt(C.wbc_eps);
+  const double se = sqrt(eps);
   for (int idx = cx.lane; idx < NW * NW; idx += cx.nlanes) Rm[idx] = (idx / NW == idx % NW) ? se : 0.0;
   cx.sync();
   // contact-force cost rows (weight w_force, WbcBase.cpp:325-338) are diagonal: fold into the diagonal start
   if (!stance_mode && C.w_force != 0.0) {
-    for (int i = cx.lane; i < 12; i += cx.nlanes) Rm[(16 + i) * NW + 16 + i] = sqrt(C.wbc_eps + C.w_force * C.w_force);
+    for (int i = cx.lane; i < 12; i += cx.nlanes) Rm[(16 + i) * NW + 16 + i] = sqrt(eps + C.w_force * C.w_force);
     cx.sync();
   }
   // right-hand side g = A_w' b_w accumulates in d (dense over 38)
@@ -868,7 +888,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
 #endif
         sa[j & 3] += jij * (j >= q ? d[j] : 0.0);
       }
-      x[i] += C.wbc_eps * ((sa[0] + sa[1]) + (sa[2] + sa[3]));
+      x[i] += eps * ((sa[0] + sa[1]) + (sa[2] + sa[3]));
       if (i < q) r[i] = d[i];
     }
     cx.sync();
@@ -878,7 +898,7 @@ HB_HD void wbc_solve(const Ctx& cx, const DevModel& M, const DevConfig& C, const
       const double ri = r[i] / Rm[i * NW + i];
       cx.sync();
       for (int k = next_eq_active + cx.lane; k < i; k += cx.nlanes) r[k] -= Rm[k * NW + i] * ri;
-      if (cx.lane == 0) lam[i] = fmax(0.0, lam[i] + C.wbc_eps * ri);   // (a multiplier that sat at zero: the row stays, at multiplier zero)
+      if (cx.lane == 0) lam[i] = fmax(0.0, lam[i] + eps * ri);   // (a multiplier that sat at zero: the row stays, at multiplier zero)
       cx.sync();
     }
   }

@@ -111,7 +111,10 @@ typedef struct hb_config {
                                       numRegularisationSteps = 1 (WeightedWbc.cpp:47-48, HoQp.cpp:175-176 [qpOASES-knowledge]).  Each step is
                                       one proximal-point step x <- argmin f(x) + eps/2 |x - x_prev|^2 on the final working set; 1 removes
                                       the first-order-in-eps bias of the regularised minimiser.  0 = plain Tikhonov point */
-  int32_t reserved2;               /* 0 (checked by hb_create) */
+  int32_t wbc_eps_mode;            /* 0: the Tikhonov term is wbc_eps_reg for every problem (default).  1 (WeightedWbc only): per problem,
+                                      eps = |H|_F * 1e3 * DBL_EPSILON with H = A_w' A_w — what qpOASES 3.2's regulariseHessian adds to the
+                                      diagonal (epsRegularisation = 1e3 EPS, Options::setToMPC; [qpOASES-knowledge]); wbc_eps_reg
+                                      is then unused.  Other values and mode 1 with wbc_type = 1 are rejected by hb_create */
 } hb_config;
 #define HB_WBC_REG_STEPS_MAX 8     /* hb_create rejects wbc_reg_steps outside [0, HB_WBC_REG_STEPS_MAX] */
 

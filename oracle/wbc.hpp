@@ -367,7 +367,21 @@ inline QpResult weighted_wbc(const Problem& pb, const double* x_des, const doubl
                        ws.contact_force(u_des).scaled(pb.cfg.weight_contact_force));
   }
   if (ws_out) *ws_out = ws;
-  return solve_lsqp(cost.A, cost.b, pb.cfg.wbc_eps_reg, cons.A, cons.b, cons.D, cons.f, pb.cfg.wbc_max_iter, pb.cfg.wbc_reg_steps);
+  // hb_config.wbc_eps_mode = 1: qpOASES 3.2's regulariseHessian — regVal = |H|_F * epsRegularisation, epsRegularisation = 1e3 * EPS
+  // (Options::setToMPC), H = A' A as WeightedWbc.cpp:44-55 hands it over [qpOASES-knowledge]
+  double eps = pb.cfg.wbc_eps_reg;
+  if (pb.cfg.wbc_eps_mode == 1) {
+    double h2 = 0.0;
+    for (int i = 0; i < cost.A.c; ++i)
+      for (int j = 0; j < cost.A.c; ++j) {
+        double g = 0.0;
+        for (int r = 0; r < cost.A.r; ++r) g += cost.A(r, i) * cost.A(r, j);
+        h2 += g * g;
+      }
+    const double e1 = std::sqrt(h2) * (1.0e3 * 2.220446049250313e-16);
+    if (e1 > 0.0) eps = e1;
+  }
+  return solve_lsqp(cost.A, cost.b, eps, cons.A, cons.b, cons.D, cons.f, pb.cfg.wbc_max_iter, pb.cfg.wbc_reg_steps);
 }
 
 }  // namespace orc

@@ -608,6 +608,28 @@ def test_wbc_regularisation_steps_other_than_the_rule_match_oracle(params, reg):
         assert (np.abs(sol - so) / scale).max() < 1e-6, wbc_type
 
 
+def test_wbc_norm_scaled_regularisation_matches_oracle_and_is_weighted_wbc_only(params):
+    """hb_config.wbc_eps_mode = 1 (eps = |A_w' A_w|_F * 1e3 * EPS per problem, qpOASES 3.2 regulariseHessian under setToMPC): k_wbc against
+    the oracle built with the same setting; hb_create refuses the mode for the HierarchicalWbc flavour and any value other than 0 / 1."""
+    from hunter_bipedal_control_amd.solver import HunterSolver
+    from oracle.pyoracle import Oracle
+    B = 24
+    xd, ud, rbd, mode = _fast_moving_wbc_inputs(params, B, seed=5)
+    o = Oracle(params, wbc_eps_mode=1)
+    s = HunterSolver(params, batch=B, max_nodes=4, wbc_eps_mode=1)
+    try:
+        sol, status = s.wbc_update_direct(xd, ud, rbd, mode)
+    finally:
+        s.close()
+    so, sto, _ = o.wbc_update(xd, ud, rbd, mode, stance_flag=np.zeros(B, dtype=np.int32), threads=4)
+    assert np.array_equal(status, sto) and status.max() == 0
+    scale = np.maximum(1.0, np.abs(so).max(axis=1, keepdims=True))
+    assert (np.abs(sol - so) / scale).max() < 1e-6
+    for bad in (dict(wbc_eps_mode=1, wbc_type=1), dict(wbc_eps_mode=2)):
+        with pytest.raises(Exception):
+            HunterSolver(params, batch=2, max_nodes=4, **bad).close()
+
+
 def test_config4_per_instance_commands_and_gaits(params, oracle):
     """SURVEY.md §8d config 4 (reduced batch): per-instance cmd_vel, stance/trot chosen by the walkGait thresholds —
     mixed mode sequences and projected-input widths inside one launch."""

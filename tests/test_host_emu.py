@@ -165,6 +165,36 @@ def test_device_wbc_regularisation_phases_match_oracle(params, emu):
     assert np.median(d01) > 1e-5 and np.median(d12) < 1e-2 * np.median(d01)
 
 
+def test_device_wbc_norm_scaled_regularisation_matches_oracle(params, emu):
+    """hb_config.wbc_eps_mode = 1: the Tikhonov term of a WeightedWbc problem is |A_w' A_w|_F * 1e3 * EPS — what qpOASES 3.2 adds to the
+    diagonal under Options::setToMPC (WeightedWbc.cpp:44-55 hands it H = A' A) — instead of one constant for every problem.  The device code
+    (|Aw' Aw|_F from the 16 dense columns + the diagonal force block) against the oracle (Frobenius norm of the dense 38 x 38 product), on
+    fast-moving and on standing inputs; and the two rules give the same torques to second order in eps (regularisation step on)."""
+    from oracle.pyoracle import Oracle
+    from test_gpu_parity import _fast_moving_wbc_inputs
+    lib, mdl, _ = emu
+    xd, ud, rbd, mode = _fast_moving_wbc_inputs(params, 24, seed=5)
+    sols = {}
+    for em in (0, 1):
+        o = Oracle(params, wbc_eps_mode=em)
+        cfg = abi.make_config(params, wbc_eps_mode=em)
+        for stance in (0, 1):
+            flag = np.full(24, stance, dtype=np.int32)
+            so, st, it = o.wbc_update(xd, ud, rbd, mode if not stance else np.full(24, 3, dtype=mode.dtype), stance_flag=flag, threads=4)
+            sols[em, stance] = so
+            for i in range(24):
+                se, ste, ite = np.zeros(38), C.c_int(), C.c_int()
+                lib.emu_wbc(C.byref(mdl), C.byref(cfg), _p(xd[i]), _p(ud[i]), _p(rbd[i]), C.c_int(3 if stance else int(mode[i])), C.c_int(stance), _p(se),
+                            C.byref(ste), C.byref(ite))
+                assert ste.value == st[i] == 0, (em, stance, i)
+                assert np.abs(se - so[i]).max() < 1e-6 * max(1.0, np.abs(so[i]).max()), (em, stance, i)
+    # |H|_F ~ 7e3 for this robot's task weights: the scaled term is of the order of the constant 1e-8, and with the regularisation step the
+    # torques of the two rules agree far below the first-order bias of either
+    d = np.abs(sols[0, 0] - sols[1, 0])[:, 28:].max(axis=1)
+    assert np.median(d) < 1e-4 and d.max() < 5.0, (np.median(d), d.max())
+    assert np.median(d) > 0.0   # (the rules do differ)
+
+
 def test_device_estimator_matches_oracle(params, oracle, emu):
     """hb_estimator.hpp (structured filter algebra, Cholesky instead of LU, forward momentum map) vs oracle/estimator.hpp."""
     from hunter_bipedal_control_amd import abi as _abi

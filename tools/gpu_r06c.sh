@@ -1,8 +1,12 @@
 #!/bin/bash
 export TMPDIR=/tmp
-R=$PWD; out=$R/gpurun_out/r06tl; mkdir -p $out
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $out/prof_tl -o run -- python $R/bench.py --steps 40 --warmup 5 --no-extras --no-cpu-baseline > $out/prof_tl.log 2>&1)
-db=$(find $out/prof_tl -name "*results.db" | head -1)
-python tools/rocprof_timeline.py $db "" 16.0 > $out/r06_timeline_headline.txt
-rm -rf $out/prof_tl
-grep -E "k_lq_trip|k_ric_bwd|k_ric_fwd|k_wbc|k_ls_eval" $out/r06_timeline_headline.txt | head -70
+timeout 600 python -m pytest tests -m gpu -x -q -k "wbc" 2>&1 | tail -3
+timeout 600 python tools/wbc_eps_sensitivity.py > gpurun_out/r06_wbc_eps_sensitivity.json 2> gpurun_out/eps.err; tail -3 gpurun_out/eps.err
+python - <<'P'
+import json
+d=json.load(open('gpurun_out/r06_wbc_eps_sensitivity.json'))
+for k in d:
+    if 'norm' in k: print(k, d[k])
+print(d['torque_movement_between_eps']['reg_steps_1']['1e-08_vs_1e-10'])
+P
+python tools/perf_quick.py --steps 30 2>&1 | tail -1 | cut -c1-300

@@ -32,6 +32,18 @@ for eps in (1e-6, 1e-8, 1e-10, 1e-12):
             s.close()
 
 
+# the norm-scaled rule (hb_config.wbc_eps_mode = 1: eps = |A_w' A_w|_F * 1e3 * EPS per problem, qpOASES 3.2 regulariseHessian), with the step
+s = HunterSolver(P, batch=B, max_nodes=N, wbc_eps_mode=1, wbc_reg_steps=1)
+try:
+    w = workload.device_trot_batch(s, P, n_intervals=N)
+    s.set_resident_inputs(w["x0"], w["t_now"], w["rbd"])
+    s.step_resident()
+    sol, status = s.get_wbc_solution()
+    sols[("norm", 1)] = (sol, status, s.get_wbc_iterations())
+finally:
+    s.close()
+
+
 def cmp(a, b):
     (sa, sta, ita), (sb, stb, _) = sols[a], sols[b]
     ok = (sta == 0) & (stb == 0)
@@ -52,6 +64,8 @@ for reg in (0, 1):
         blk[f"{a:g}_vs_{b:g}"] = cmp((a, reg), (b, reg))
     out["torque_movement_between_eps"][f"reg_steps_{reg}"] = blk
 out["step_itself_at_1e-8 (reg 0 vs reg 1)"] = cmp((1e-8, 0), (1e-8, 1))
+out["fixed_1e-8_vs_norm_scaled (wbc_eps_mode 0 vs 1, both with the step)"] = cmp((1e-8, 1), ("norm", 1))
+out["fixed_1e-10_vs_norm_scaled"] = cmp((1e-10, 1), ("norm", 1))
 # the instances whose answer still moves by more than 1e-3 N m between eps = 1e-8 and 1e-10 WITH the step: their reduced Hessian has an
 # eigenvalue of the order of eps itself (tests/test_oracle_qp.py::test_regularisation_step_* shows it on the oracle), i.e. eps / lambda ~ 1
 ref = sols[(1e-8, 1)][0]
